@@ -1,0 +1,444 @@
+// project.hip -- stage 1 (projection + EWA + SH colour + tile count) and stage 5 (its backward).
+//
+// One thread per gaussian; 256-thread blocks (4 wave64).  The kernels are HBM-streaming: per gaussian
+// the forward reads 44 B of geometry + up to 192 B of SH coefficients and writes one 64-B splat
+// record + 16 B of integers.  The [N,16,3] SH rows (192-B stride) are staged through LDS by whole
+// waves so the HBM side sees contiguous 16-B-per-lane accesses in both directions
+// (a lane-per-row access pattern would touch 64 cache lines per instruction).
+//
+// Restates SURVEY.md Appendix A.2 / A.3 (forward) and A.7 (backward) -- the gsplat kernels behind
+// /root/reference/src/backends/gsplat_backend.py:168-182.
+
+#include "project_math.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kRowQ = 12;      // float4 per [16,3] SH row
+constexpr int kRowQPad = 13;   // padded LDS row (52 floats): conflict-free ds_read_b128 across lanes
+
+template <int DEG>
+__host__ __device__ constexpr int sh_needed_q() {  // float4 per row that hold the active coefficients
+    return DEG < 0 ? 0 : (3 * (DEG + 1) * (DEG + 1) + 3) / 4;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int DEG, bool STAGE>
+__global__ __launch_bounds__(kBlock) void project_fwd_kernel(
+    int n, const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
+    const float *__restrict__ opacities, const float *__restrict__ colors, int sh_coeffs,
+    const float *__restrict__ viewmat, const float *__restrict__ intrin, int width, int height, int tile_w,
+    int tile_h, int cull_mode, float *__restrict__ splat, int32_t *__restrict__ radii,
+    int32_t *__restrict__ tiles_touched, uint32_t *__restrict__ depth_keys) {
+    __shared__ float4 sh_lds[STAGE ? 4 * 64 * kRowQPad : 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+
+    if constexpr (STAGE && DEG >= 1) {
+        constexpr int NQ = sh_needed_q<DEG>();
+        const long wave_base = (long)blockIdx.x * kBlock + wave * 64;
+        const long rows = min((long)64, (long)n - wave_base);
+        const float4 *src = reinterpret_cast<const float4 *>(colors) + wave_base * kRowQ;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            int idx = k * 64 + lane;
+            int row = idx / NQ, col = idx - row * NQ;
+            if (row < rows) sh_lds[(wave * 64 + row) * kRowQPad + col] = src[row * kRowQ + col];
+        }
+        __syncthreads();
+    }
+    if (i >= n) return;
+
+    GsaCamera cam = gsa_load_camera(viewmat, intrin);
+    GsaProj p = gsa_project_one(cam, means + i * 3, quats + i * 4, scales + i * 3, width, height);
+    const float opac = opacities[i];
+
+    bool visible = p.ok && (opac >= GSA_ALPHA_THRESHOLD);
+    float sig_max = logf(fmaxf(opac, GSA_ALPHA_THRESHOLD) * 255.0f);  // alpha >= 1/255  <=>  sigma <= ln(255 o)
+    float ext = fminf(GSA_RADIUS_EXTEND, sqrtf(2.0f * sig_max));
+    float rxf = ceilf(ext * sqrtf(fmaxf(p.c00, 0.f)));
+    float ryf = ceilf(ext * sqrtf(fmaxf(p.c11, 0.f)));
+    visible = visible && !(rxf <= GSA_RADIUS_CLIP && ryf <= GSA_RADIUS_CLIP);
+    visible = visible && !(p.mx + rxf <= 0.f || p.mx - rxf >= (float)width || p.my + ryf <= 0.f ||
+                           p.my - ryf >= (float)height);
+
+    float4 *out = reinterpret_cast<float4 *>(splat + i * GSA_SPLAT_STRIDE);
+    if (!visible) {
+        float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        out[0] = z4; out[1] = z4; out[2] = z4; out[3] = z4;
+        radii[2 * i] = 0; radii[2 * i + 1] = 0;
+        tiles_touched[i] = 0;
+        depth_keys[i] = 0xFFFFFFFFu;
+        return;
+    }
+
+    // ---- colour (A.3)
+    float r, g, b;
+    if constexpr (DEG < 0) {
+        r = colors[i * 3]; g = colors[i * 3 + 1]; b = colors[i * 3 + 2];
+    } else {
+        constexpr int NB = (DEG + 1) * (DEG + 1);
+        float dx = means[i * 3] - cam.campos[0], dy = means[i * 3 + 1] - cam.campos[1],
+              dz = means[i * 3 + 2] - cam.campos[2];
+        float inv = rsqrtf(dx * dx + dy * dy + dz * dz);
+        float B[NB];
+        gsa_sh_basis<DEG>(dx * inv, dy * inv, dz * inv, B);
+        float c[NB * 3];
+        if constexpr (STAGE && DEG >= 1) {
+            constexpr int NQ = sh_needed_q<DEG>();
+            const float4 *row = &sh_lds[threadIdx.x * kRowQPad];
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                float4 v = row[k];
+                if (4 * k + 0 < NB * 3) c[4 * k + 0] = v.x;
+                if (4 * k + 1 < NB * 3) c[4 * k + 1] = v.y;
+                if (4 * k + 2 < NB * 3) c[4 * k + 2] = v.z;
+                if (4 * k + 3 < NB * 3) c[4 * k + 3] = v.w;
+            }
+        } else {
+            const float *row = colors + i * (long)sh_coeffs * 3;
+#pragma unroll
+            for (int k = 0; k < NB * 3; ++k) c[k] = row[k];
+        }
+        r = g = b = 0.f;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            r += B[j] * c[3 * j]; g += B[j] * c[3 * j + 1]; b += B[j] * c[3 * j + 2];
+        }
+        r = fmaxf(r + 0.5f, 0.f); g = fmaxf(g + 0.5f, 0.f); b = fmaxf(b + 0.5f, 0.f);
+    }
+
+    // ---- tile count (A.4)
+    int rx = (int)rxf, ry = (int)ryf;
+    GsaTileRect tr = gsa_tile_rect(p.mx, p.my, rx, ry, tile_w, tile_h);
+    int count;
+    if (cull_mode == 0) {
+        count = (tr.x1 - tr.x0) * (tr.y1 - tr.y0);
+    } else {
+        count = 0;
+        for (int ty = tr.y0; ty < tr.y1; ++ty)
+            for (int tx = tr.x0; tx < tr.x1; ++tx)
+                count += gsa_tile_hit(p.mx, p.my, p.qa, p.qb, p.qc, sig_max, tx, ty) ? 1 : 0;
+    }
+
+    out[0] = make_float4(p.mx, p.my, p.qa, p.qb);
+    out[1] = make_float4(p.qc, opac, r, g);
+    out[2] = make_float4(b, p.z, 0.f, 0.f);
+    out[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    radii[2 * i] = rx; radii[2 * i + 1] = ry;
+    tiles_touched[i] = count;
+    depth_keys[i] = __float_as_uint(p.z);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward (A.7)
+// ------------------------------------------------------------------------------------------------
+template <int DEG, bool STAGE>
+__global__ __launch_bounds__(kBlock) void project_bwd_kernel(
+    int n, const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
+    const float *__restrict__ colors, int sh_coeffs, const float *__restrict__ viewmat,
+    const float *__restrict__ intrin, int width, int height, const float *__restrict__ splat,
+    const int32_t *__restrict__ radii, const float *__restrict__ v_splat, float *__restrict__ v_means,
+    float *__restrict__ v_quats, float *__restrict__ v_scales, float *__restrict__ v_opacities,
+    float *__restrict__ v_colors) {
+    __shared__ float4 sh_lds[STAGE ? 4 * 64 * kRowQPad : 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    const long wave_base = (long)blockIdx.x * kBlock + wave * 64;
+    const long rows = min((long)64, (long)n - wave_base);
+    constexpr int NB = DEG < 0 ? 1 : (DEG + 1) * (DEG + 1);
+
+    if constexpr (STAGE && DEG >= 1) {
+        constexpr int NQ = sh_needed_q<DEG>();
+        const float4 *src = reinterpret_cast<const float4 *>(colors) + wave_base * kRowQ;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            int idx = k * 64 + lane;
+            int row = idx / NQ, col = idx - row * NQ;
+            if (row < rows) sh_lds[(wave * 64 + row) * kRowQPad + col] = src[row * kRowQ + col];
+        }
+        __syncthreads();
+    }
+
+    bool active = i < n;
+    bool visible = active && radii[2 * i] > 0 && radii[2 * i + 1] > 0;
+    float vm[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f}, vo = 0.f;
+    float vc[NB * 3];
+#pragma unroll
+    for (int k = 0; k < NB * 3; ++k) vc[k] = 0.f;
+
+    if (visible) {
+        GsaCamera cam = gsa_load_camera(viewmat, intrin);
+        GsaProj p = gsa_project_one(cam, means + i * 3, quats + i * 4, scales + i * 3, width, height);
+        const float4 *vrow = reinterpret_cast<const float4 *>(v_splat + i * GSA_SPLAT_STRIDE);
+        float4 v0 = vrow[0], v1 = vrow[1], v2 = vrow[2];
+        float v_mx = v0.x, v_my = v0.y, v_a = v0.z, v_b = v0.w, v_c = v1.x;
+        vo = v1.y;
+        float v_rgb[3] = {v1.z, v1.w, v2.x};
+        float v_depth = v2.y;
+
+        // ---- conic -> blurred cov2d:  G = -Q V Q,  V = [[v_a, v_b/2], [v_b/2, v_c]]
+        float a = p.qa, b = p.qb, c = p.qc, hb = 0.5f * v_b;
+        float q00 = a * v_a + b * hb, q01 = a * hb + b * v_c;
+        float q10 = b * v_a + c * hb, q11 = b * hb + c * v_c;
+        float G00 = -(q00 * a + q01 * b);
+        float G01 = -(q00 * b + q01 * c);
+        float G11 = -(q10 * b + q11 * c);
+
+        // ---- cov2d = J Sc J^T
+        float J00 = p.J00, J02 = p.J02, J11 = p.J11, J12 = p.J12;
+        float vS00 = J00 * J00 * G00;
+        float vS01 = J00 * J11 * G01;
+        float vS02 = J00 * (G00 * J02 + G01 * J12);
+        float vS11 = J11 * J11 * G11;
+        float vS12 = J11 * (G01 * J02 + G11 * J12);
+        float vS22 = J02 * J02 * G00 + 2.f * J02 * J12 * G01 + J12 * J12 * G11;
+        float T00 = J00 * p.S00 + J02 * p.S02, T01 = J00 * p.S01 + J02 * p.S12, T02 = J00 * p.S02 + J02 * p.S22;
+        float T10 = J11 * p.S01 + J12 * p.S02, T11 = J11 * p.S11 + J12 * p.S12, T12 = J11 * p.S12 + J12 * p.S22;
+        float vJ00 = 2.f * (G00 * T00 + G01 * T10);
+        float vJ02 = 2.f * (G00 * T02 + G01 * T12);
+        float vJ11 = 2.f * (G01 * T01 + G11 * T11);
+        float vJ12 = 2.f * (G01 * T02 + G11 * T12);
+
+        // ---- camera-space mean
+        float fx = cam.fx, fy = cam.fy, rz = p.rz, rz2 = p.rz2, rz3 = p.rz2 * p.rz;
+        float vx = fx * rz * v_mx;
+        float vy = fy * rz * v_my;
+        float vz = -(fx * p.x * v_mx + fy * p.y * v_my) * rz2 + v_depth;
+        if (p.x_in) vx += -fx * rz2 * vJ02; else vz += -fx * rz3 * vJ02 * p.tx;
+        if (p.y_in) vy += -fy * rz2 * vJ12; else vz += -fy * rz3 * vJ12 * p.ty;
+        vz += -fx * rz2 * vJ00 - fy * rz2 * vJ11 + 2.f * fx * p.tx * rz3 * vJ02 + 2.f * fy * p.ty * rz3 * vJ12;
+        const float *R = cam.R;
+        vm[0] = R[0] * vx + R[3] * vy + R[6] * vz;
+        vm[1] = R[1] * vx + R[4] * vy + R[7] * vz;
+        vm[2] = R[2] * vx + R[5] * vy + R[8] * vz;
+
+        // ---- Sigma_c = R Sigma R^T  ->  vSig = R^T vSc R
+        float U00 = vS00 * R[0] + vS01 * R[3] + vS02 * R[6], U01 = vS00 * R[1] + vS01 * R[4] + vS02 * R[7],
+              U02 = vS00 * R[2] + vS01 * R[5] + vS02 * R[8];
+        float U10 = vS01 * R[0] + vS11 * R[3] + vS12 * R[6], U11 = vS01 * R[1] + vS11 * R[4] + vS12 * R[7],
+              U12 = vS01 * R[2] + vS11 * R[5] + vS12 * R[8];
+        float U20 = vS02 * R[0] + vS12 * R[3] + vS22 * R[6], U21 = vS02 * R[1] + vS12 * R[4] + vS22 * R[7],
+              U22 = vS02 * R[2] + vS12 * R[5] + vS22 * R[8];
+        float W[9];
+        W[0] = R[0] * U00 + R[3] * U10 + R[6] * U20; W[1] = R[0] * U01 + R[3] * U11 + R[6] * U21;
+        W[2] = R[0] * U02 + R[3] * U12 + R[6] * U22;
+        W[3] = R[1] * U00 + R[4] * U10 + R[7] * U20; W[4] = R[1] * U01 + R[4] * U11 + R[7] * U21;
+        W[5] = R[1] * U02 + R[4] * U12 + R[7] * U22;
+        W[6] = R[2] * U00 + R[5] * U10 + R[8] * U20; W[7] = R[2] * U01 + R[5] * U11 + R[8] * U21;
+        W[8] = R[2] * U02 + R[5] * U12 + R[8] * U22;
+
+        // ---- Sigma = M M^T, M = Rq diag(s):  vM = 2 vSig M
+        const float *Rq = p.Rq;
+        float s[3] = {p.sx, p.sy, p.sz};
+        float vM[9];
+#pragma unroll
+        for (int r_ = 0; r_ < 3; ++r_)
+#pragma unroll
+            for (int c_ = 0; c_ < 3; ++c_)
+                vM[r_ * 3 + c_] = 2.f * (W[r_ * 3 + 0] * Rq[0 * 3 + c_] + W[r_ * 3 + 1] * Rq[1 * 3 + c_] +
+                                         W[r_ * 3 + 2] * Rq[2 * 3 + c_]) * s[c_];
+        float vR[9];
+#pragma unroll
+        for (int c_ = 0; c_ < 3; ++c_) {
+            vs[c_] = Rq[0 * 3 + c_] * vM[0 * 3 + c_] + Rq[1 * 3 + c_] * vM[1 * 3 + c_] + Rq[2 * 3 + c_] * vM[2 * 3 + c_];
+#pragma unroll
+            for (int r_ = 0; r_ < 3; ++r_) vR[r_ * 3 + c_] = vM[r_ * 3 + c_] * s[c_];
+        }
+        // ---- rotation matrix -> normalised quaternion -> raw quaternion
+        float w = p.qw, x = p.qx, y = p.qy, z = p.qz;
+        float gw = 2.f * (x * (vR[7] - vR[5]) + y * (vR[2] - vR[6]) + z * (vR[3] - vR[1]));
+        float gx = 2.f * (-2.f * x * (vR[4] + vR[8]) + y * (vR[1] + vR[3]) + z * (vR[2] + vR[6]) + w * (vR[7] - vR[5]));
+        float gy = 2.f * (-2.f * y * (vR[0] + vR[8]) + x * (vR[1] + vR[3]) + z * (vR[5] + vR[7]) + w * (vR[2] - vR[6]));
+        float gz = 2.f * (-2.f * z * (vR[0] + vR[4]) + x * (vR[2] + vR[6]) + y * (vR[5] + vR[7]) + w * (vR[3] - vR[1]));
+        float dotq = gw * w + gx * x + gy * y + gz * z;
+        vq[0] = (gw - dotq * w) * p.qinv; vq[1] = (gx - dotq * x) * p.qinv;
+        vq[2] = (gy - dotq * y) * p.qinv; vq[3] = (gz - dotq * z) * p.qinv;
+
+        // ---- colour
+        if constexpr (DEG < 0) {
+            vc[0] = v_rgb[0]; vc[1] = v_rgb[1]; vc[2] = v_rgb[2];
+        } else {
+            const float4 *srow = reinterpret_cast<const float4 *>(splat + i * GSA_SPLAT_STRIDE);
+            float4 s1 = srow[1], s2 = srow[2];
+            float vr[3] = {s1.z > 0.f ? v_rgb[0] : 0.f, s1.w > 0.f ? v_rgb[1] : 0.f, s2.x > 0.f ? v_rgb[2] : 0.f};
+            float dx = means[i * 3] - cam.campos[0], dy = means[i * 3 + 1] - cam.campos[1],
+                  dz = means[i * 3 + 2] - cam.campos[2];
+            float inv = rsqrtf(dx * dx + dy * dy + dz * dz);
+            float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+            float B[NB];
+            gsa_sh_basis<DEG>(ux, uy, uz, B);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                vc[3 * j] = B[j] * vr[0]; vc[3 * j + 1] = B[j] * vr[1]; vc[3 * j + 2] = B[j] * vr[2];
+            }
+            if constexpr (DEG >= 1) {
+                float cf[NB * 3];
+                if constexpr (STAGE) {
+                    constexpr int NQ = sh_needed_q<DEG>();
+                    const float4 *row = &sh_lds[threadIdx.x * kRowQPad];
+#pragma unroll
+                    for (int k = 0; k < NQ; ++k) {
+                        float4 v = row[k];
+                        if (4 * k + 0 < NB * 3) cf[4 * k + 0] = v.x;
+                        if (4 * k + 1 < NB * 3) cf[4 * k + 1] = v.y;
+                        if (4 * k + 2 < NB * 3) cf[4 * k + 2] = v.z;
+                        if (4 * k + 3 < NB * 3) cf[4 * k + 3] = v.w;
+                    }
+                } else {
+                    const float *row = colors + i * (long)sh_coeffs * 3;
+#pragma unroll
+                    for (int k = 0; k < NB * 3; ++k) cf[k] = row[k];
+                }
+                float vB[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    vB[j] = cf[3 * j] * vr[0] + cf[3 * j + 1] * vr[1] + cf[3 * j + 2] * vr[2];
+                float hx, hy, hz;
+                gsa_sh_basis_vjp<DEG>(ux, uy, uz, vB, hx, hy, hz);
+                float dd = hx * ux + hy * uy + hz * uz;
+                vm[0] += (hx - dd * ux) * inv; vm[1] += (hy - dd * uy) * inv; vm[2] += (hz - dd * uz) * inv;
+            }
+        }
+    }
+
+    if (active) {
+        v_means[i * 3] = vm[0]; v_means[i * 3 + 1] = vm[1]; v_means[i * 3 + 2] = vm[2];
+        v_quats[i * 4] = vq[0]; v_quats[i * 4 + 1] = vq[1]; v_quats[i * 4 + 2] = vq[2]; v_quats[i * 4 + 3] = vq[3];
+        v_scales[i * 3] = vs[0]; v_scales[i * 3 + 1] = vs[1]; v_scales[i * 3 + 2] = vs[2];
+        v_opacities[i] = vo;
+    }
+
+    // ---- colour gradient rows: every element written (zeros above the active degree / when culled)
+    if constexpr (DEG < 0) {
+        if (active) { v_colors[i * 3] = vc[0]; v_colors[i * 3 + 1] = vc[1]; v_colors[i * 3 + 2] = vc[2]; }
+    } else if (STAGE) {
+        __syncthreads();  // all lanes have consumed their coefficient rows
+        float4 *row = &sh_lds[threadIdx.x * kRowQPad];
+#pragma unroll
+        for (int k = 0; k < kRowQ; ++k) {
+            float4 v;
+            v.x = 4 * k + 0 < NB * 3 ? vc[(4 * k + 0) % (NB * 3)] : 0.f;
+            v.y = 4 * k + 1 < NB * 3 ? vc[(4 * k + 1) % (NB * 3)] : 0.f;
+            v.z = 4 * k + 2 < NB * 3 ? vc[(4 * k + 2) % (NB * 3)] : 0.f;
+            v.w = 4 * k + 3 < NB * 3 ? vc[(4 * k + 3) % (NB * 3)] : 0.f;
+            row[k] = v;
+        }
+        __syncthreads();
+        float4 *dst = reinterpret_cast<float4 *>(v_colors) + wave_base * kRowQ;
+#pragma unroll
+        for (int k = 0; k < kRowQ; ++k) {
+            int idx = k * 64 + lane;
+            int r_ = idx / kRowQ, c_ = idx - r_ * kRowQ;
+            if (r_ < rows) dst[idx] = sh_lds[(wave * 64 + r_) * kRowQPad + c_];
+        }
+    } else if (active) {
+        float *row = v_colors + i * (long)sh_coeffs * 3;
+        for (int k = 0; k < sh_coeffs * 3; ++k) row[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NB * 3; ++k) row[k] = vc[k];
+    }
+}
+
+template <int DEG>
+int launch_fwd(bool stage, int n, const float *means, const float *quats, const float *scales,
+               const float *opacities, const float *colors, int sh_coeffs, const float *viewmat,
+               const float *intrin, int width, int height, int cull_mode, float *splat, int32_t *radii,
+               int32_t *tiles_touched, uint32_t *depth_keys, hipStream_t s) {
+    int tile_w = gsa_div_up(width, GSA_TILE_SIZE), tile_h = gsa_div_up(height, GSA_TILE_SIZE);
+    dim3 grid(gsa_div_up(n, kBlock)), block(kBlock);
+    if (stage)
+        project_fwd_kernel<DEG, true><<<grid, block, 0, s>>>(n, means, quats, scales, opacities, colors, sh_coeffs,
+                                                             viewmat, intrin, width, height, tile_w, tile_h, cull_mode,
+                                                             splat, radii, tiles_touched, depth_keys);
+    else
+        project_fwd_kernel<DEG, false><<<grid, block, 0, s>>>(n, means, quats, scales, opacities, colors, sh_coeffs,
+                                                              viewmat, intrin, width, height, tile_w, tile_h,
+                                                              cull_mode, splat, radii, tiles_touched, depth_keys);
+    GSA_LAUNCH_CHECK();
+    return GSA_OK;
+}
+
+template <int DEG>
+int launch_bwd(bool stage, int n, const float *means, const float *quats, const float *scales,
+               const float *colors, int sh_coeffs, const float *viewmat, const float *intrin, int width,
+               int height, const float *splat, const int32_t *radii, const float *v_splat, float *v_means,
+               float *v_quats, float *v_scales, float *v_opacities, float *v_colors, hipStream_t s) {
+    dim3 grid(gsa_div_up(n, kBlock)), block(kBlock);
+    if (stage)
+        project_bwd_kernel<DEG, true><<<grid, block, 0, s>>>(n, means, quats, scales, colors, sh_coeffs, viewmat,
+                                                             intrin, width, height, splat, radii, v_splat, v_means,
+                                                             v_quats, v_scales, v_opacities, v_colors);
+    else
+        project_bwd_kernel<DEG, false><<<grid, block, 0, s>>>(n, means, quats, scales, colors, sh_coeffs, viewmat,
+                                                              intrin, width, height, splat, radii, v_splat, v_means,
+                                                              v_quats, v_scales, v_opacities, v_colors);
+    GSA_LAUNCH_CHECK();
+    return GSA_OK;
+}
+
+bool can_stage(const float *colors, int sh_degree, int sh_coeffs) {
+    return sh_degree >= 0 && sh_coeffs == 16 && (reinterpret_cast<uintptr_t>(colors) & 15) == 0;
+}
+
+}  // namespace
+
+extern "C" int gsa_project_fwd(int n, const float *means, const float *quats, const float *scales,
+                               const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
+                               const float *viewmat, const float *intrin, int width, int height, int cull_mode,
+                               float *splat, int32_t *radii, int32_t *tiles_touched, uint32_t *depth_keys,
+                               gsa_stream_t stream) {
+    GSA_RETURN_IF(n < 0 || width <= 0 || height <= 0, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(sh_degree < -1 || sh_degree > 3, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(sh_degree >= 0 && sh_coeffs < (sh_degree + 1) * (sh_degree + 1), GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(cull_mode != 0 && cull_mode != 1, GSA_ERR_INVALID_ARGUMENT);
+    if (n == 0) return GSA_OK;
+    GSA_RETURN_IF(!means || !quats || !scales || !opacities || !colors || !viewmat || !intrin || !splat || !radii ||
+                      !tiles_touched || !depth_keys,
+                  GSA_ERR_INVALID_ARGUMENT);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // degree 0 needs 12 B of each 192-B row: direct loads beat staging whole rows
+    bool stage = can_stage(colors, sh_degree, sh_coeffs) && sh_degree >= 1;
+#define GSA_FWD(D)                                                                                              \
+    return launch_fwd<D>(stage, n, means, quats, scales, opacities, colors, sh_coeffs, viewmat, intrin, width, \
+                         height, cull_mode, splat, radii, tiles_touched, depth_keys, s)
+    switch (sh_degree) {
+        case -1: GSA_FWD(-1);
+        case 0: GSA_FWD(0);
+        case 1: GSA_FWD(1);
+        case 2: GSA_FWD(2);
+        default: GSA_FWD(3);
+    }
+#undef GSA_FWD
+}
+
+extern "C" int gsa_project_bwd(int n, const float *means, const float *quats, const float *scales,
+                               const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
+                               const float *viewmat, const float *intrin, int width, int height,
+                               const float *splat, const int32_t *radii, const float *v_splat, float *v_means,
+                               float *v_quats, float *v_scales, float *v_opacities, float *v_colors,
+                               gsa_stream_t stream) {
+    (void)opacities;
+    GSA_RETURN_IF(n < 0 || width <= 0 || height <= 0, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(sh_degree < -1 || sh_degree > 3, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(sh_degree >= 0 && sh_coeffs < (sh_degree + 1) * (sh_degree + 1), GSA_ERR_INVALID_ARGUMENT);
+    if (n == 0) return GSA_OK;
+    GSA_RETURN_IF(!means || !quats || !scales || !colors || !viewmat || !intrin || !splat || !radii || !v_splat ||
+                      !v_means || !v_quats || !v_scales || !v_opacities || !v_colors,
+                  GSA_ERR_INVALID_ARGUMENT);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    bool stage = can_stage(colors, sh_degree, sh_coeffs) && (reinterpret_cast<uintptr_t>(v_colors) & 15) == 0;
+#define GSA_BWD(D)                                                                                                  \
+    return launch_bwd<D>(stage, n, means, quats, scales, colors, sh_coeffs, viewmat, intrin, width, height, splat, \
+                         radii, v_splat, v_means, v_quats, v_scales, v_opacities, v_colors, s)
+    switch (sh_degree) {
+        case -1: GSA_BWD(-1);
+        case 0: GSA_BWD(0);
+        case 1: GSA_BWD(1);
+        case 2: GSA_BWD(2);
+        default: GSA_BWD(3);
+    }
+#undef GSA_BWD
+}

@@ -1,0 +1,333 @@
+// sort.hip -- stage 2: tile binning (row a3.3 of the scope table).
+//
+// The published pipeline sorts M (tile<<32 | depth_bits, gaussian) records with a 64-bit-key radix
+// sort.  The required order is (tile, depth bits, gaussian index).  Here it is produced with far less
+// HBM traffic by splitting the key:
+//   1. stable LSD radix sort of the N gaussians by their 32 depth bits (values = gaussian index, so
+//      ties keep index order);
+//   2. records are EMITTED in that order (exclusive scan of tiles_touched in depth order);
+//   3. stable LSD radix sort of the M records by tile id only (<= 16 bits -> 2 passes instead of 6).
+// All kernels are bandwidth-bound integer work: coalesced 4-B-per-lane streams, LDS histograms,
+// wave64 ballot ranking.  No MFMA.
+//
+// Replaces gsplat's isect_tiles / radix sort / isect_offset_encode behind
+// /root/reference/src/backends/gsplat_backend.py:168-182.
+
+#include "project_math.h"
+
+namespace {
+
+constexpr int kSortThreads = 256;
+constexpr int kSortItems = 16;                          // keys per thread
+constexpr int kSortChunk = kSortThreads * kSortItems;   // keys per block
+constexpr int kRadix = 256;
+
+// ---- pass 1: per-block digit histogram, written digit-major: hist[d * nblocks + block] -------------
+__global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(int n, const uint32_t *__restrict__ keys,
+                                                                  int shift, int nblocks,
+                                                                  uint32_t *__restrict__ hist) {
+    __shared__ uint32_t h[kRadix];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    long base = (long)blockIdx.x * kSortChunk;
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        long i = base + r * kSortThreads + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & (kRadix - 1)], 1u);
+    }
+    __syncthreads();
+    hist[(long)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// ---- pass 2: one block per digit: exclusive scan of its row in place, row total out -----------------
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < GSA_WAVE; d <<= 1) {
+        uint32_t o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread across a 256-thread block; returns the exclusive prefix and
+// (through total) the block sum.  scratch: 4 words of LDS.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *scratch, uint32_t &total) {
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = wave_incl_scan(v, lane);
+    if (lane == 63) scratch[wave] = inc;
+    __syncthreads();
+    uint32_t s0 = scratch[0], s1 = scratch[1], s2 = scratch[2], s3 = scratch[3];
+    uint32_t wave_off = wave == 0 ? 0 : wave == 1 ? s0 : wave == 2 ? s0 + s1 : s0 + s1 + s2;
+    total = s0 + s1 + s2 + s3;
+    __syncthreads();
+    return wave_off + inc - v;
+}
+
+__global__ __launch_bounds__(kSortThreads) void radix_scan_rows_kernel(int nblocks, uint32_t *__restrict__ hist,
+                                                                       uint32_t *__restrict__ digit_total) {
+    __shared__ uint32_t scratch[4];
+    uint32_t *row = hist + (long)blockIdx.x * nblocks;
+    uint32_t carry = 0;
+    for (int base = 0; base < nblocks; base += kSortThreads) {
+        int i = base + threadIdx.x;
+        uint32_t v = i < nblocks ? row[i] : 0;
+        uint32_t total;
+        uint32_t ex = block_excl_scan(v, scratch, total);
+        if (i < nblocks) row[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) digit_total[blockIdx.x] = carry;
+}
+
+// ---- pass 3: stable scatter ---------------------------------------------------------------------
+__global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
+    int n, const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+    uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int shift, int nblocks,
+    const uint32_t *__restrict__ hist, const uint32_t *__restrict__ digit_total) {
+    __shared__ uint32_t scratch[4];
+    __shared__ uint32_t running[kRadix];      // next free output slot per digit for this block
+    __shared__ uint32_t wave_cnt[4][kRadix];  // per round: items of digit d in wave w
+    __shared__ uint32_t wave_off[4][kRadix];  // per round: first output slot for wave w, digit d
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+    // global base of digit d = exclusive scan of digit totals; + this block's offset inside the digit
+    uint32_t tot, dt = digit_total[t];
+    uint32_t dbase = block_excl_scan(dt, scratch, tot);
+    running[t] = dbase + hist[(long)t * nblocks + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) wave_cnt[w][t] = 0;
+
+    long base = (long)blockIdx.x * kSortChunk;
+    uint32_t k[kSortItems], v[kSortItems];
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        long i = base + r * kSortThreads + t;
+        k[r] = i < n ? keys_in[i] : 0xFFFFFFFFu;
+        v[r] = i < n ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        long i = base + r * kSortThreads + t;
+        bool valid = i < n;
+        uint32_t d = (k[r] >> shift) & (kRadix - 1);
+        // lanes of this wave holding the same digit
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            unsigned long long m = __ballot((d >> b) & 1);
+            peers &= ((d >> b) & 1) ? m : ~m;
+        }
+        uint32_t rank = __popcll(peers & ((1ull << lane) - 1ull));
+        if (valid && rank == 0) wave_cnt[wave][d] = __popcll(peers);
+        __syncthreads();
+        {
+            uint32_t c0 = wave_cnt[0][t], c1 = wave_cnt[1][t], c2 = wave_cnt[2][t], c3 = wave_cnt[3][t];
+            uint32_t o = running[t];
+            wave_off[0][t] = o; wave_off[1][t] = o + c0; wave_off[2][t] = o + c0 + c1; wave_off[3][t] = o + c0 + c1 + c2;
+            running[t] = o + c0 + c1 + c2 + c3;
+            wave_cnt[0][t] = 0; wave_cnt[1][t] = 0; wave_cnt[2][t] = 0; wave_cnt[3][t] = 0;
+        }
+        __syncthreads();
+        if (valid) {
+            uint32_t pos = wave_off[wave][d] + rank;
+            keys_out[pos] = k[r];
+            vals_out[pos] = v[r];
+        }
+    }
+}
+
+// ---- exclusive scan of tiles_touched in depth order ------------------------------------------------
+constexpr int kScanItems = 4;
+constexpr int kScanChunk = kSortThreads * kScanItems;
+
+__device__ __forceinline__ uint32_t scan_load(const int32_t *__restrict__ tiles_touched,
+                                              const uint32_t *__restrict__ order, long i, int n) {
+    return i < n ? (uint32_t)tiles_touched[order[i]] : 0u;
+}
+
+__global__ __launch_bounds__(kSortThreads) void scan_reduce_kernel(int n, const int32_t *__restrict__ tiles_touched,
+                                                                   const uint32_t *__restrict__ order,
+                                                                   uint32_t *__restrict__ block_sums) {
+    __shared__ uint32_t scratch[4];
+    long base = (long)blockIdx.x * kScanChunk + threadIdx.x * kScanItems;
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) s += scan_load(tiles_touched, order, base + j, n);
+    uint32_t total;
+    block_excl_scan(s, scratch, total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kSortThreads) void scan_blocks_kernel(int nblocks, uint32_t *__restrict__ block_sums,
+                                                                   uint32_t *__restrict__ total_out) {
+    __shared__ uint32_t scratch[4];
+    uint32_t carry = 0;
+    for (int base = 0; base < nblocks; base += kSortThreads) {
+        int i = base + threadIdx.x;
+        uint32_t v = i < nblocks ? block_sums[i] : 0;
+        uint32_t total;
+        uint32_t ex = block_excl_scan(v, scratch, total);
+        if (i < nblocks) block_sums[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ __launch_bounds__(kSortThreads) void scan_final_kernel(int n, const int32_t *__restrict__ tiles_touched,
+                                                                  const uint32_t *__restrict__ order,
+                                                                  const uint32_t *__restrict__ block_sums,
+                                                                  uint32_t *__restrict__ offsets) {
+    __shared__ uint32_t scratch[4];
+    long base = (long)blockIdx.x * kScanChunk + threadIdx.x * kScanItems;
+    uint32_t v[kScanItems], s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+        v[j] = scan_load(tiles_touched, order, base + j, n);
+        s += v[j];
+    }
+    uint32_t total;
+    uint32_t ex = block_excl_scan(s, scratch, total) + block_sums[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+        if (base + j < n) offsets[base + j] = ex;
+        ex += v[j];
+    }
+}
+
+// ---- record emission ------------------------------------------------------------------------------
+__global__ __launch_bounds__(kSortThreads) void tile_emit_kernel(
+    int n, const uint32_t *__restrict__ order, const uint32_t *__restrict__ offsets,
+    const float *__restrict__ splat, const int32_t *__restrict__ radii, int tile_w, int tile_h, int n_tiles,
+    int cull_mode, uint32_t m_capacity, uint32_t *__restrict__ isect_tile, uint32_t *__restrict__ isect_gid) {
+    long k = (long)blockIdx.x * kSortThreads + threadIdx.x;
+    if (k >= n) return;
+    uint32_t g = order[k];
+    int rx = radii[2 * (long)g], ry = radii[2 * (long)g + 1];
+    if (rx <= 0 || ry <= 0) return;
+    uint32_t begin = offsets[k];
+    uint32_t end = (k + 1 < n) ? offsets[k + 1] : m_capacity;  // == begin + tiles_touched[g]
+    end = min(end, m_capacity);
+    const float4 *row = reinterpret_cast<const float4 *>(splat + (long)g * GSA_SPLAT_STRIDE);
+    float4 q0 = row[0], q1 = row[1];
+    float mx = q0.x, my = q0.y, a = q0.z, b = q0.w, c = q1.x, opac = q1.y;
+    float sig_max = logf(fmaxf(opac, GSA_ALPHA_THRESHOLD) * 255.0f);
+    GsaTileRect tr = gsa_tile_rect(mx, my, rx, ry, tile_w, tile_h);
+    uint32_t pos = begin;
+    for (int ty = tr.y0; ty < tr.y1; ++ty)
+        for (int tx = tr.x0; tx < tr.x1; ++tx) {
+            bool hit = cull_mode == 0 || gsa_tile_hit(mx, my, a, b, c, sig_max, tx, ty);
+            if (hit && pos < end) {
+                isect_tile[pos] = (uint32_t)(ty * tile_w + tx);
+                isect_gid[pos] = g;
+                ++pos;
+            }
+        }
+    // count and emit run the same arithmetic on the same stored floats; should they ever disagree the
+    // unused slots become sentinel records that sort behind every real tile and are never composited
+    for (; pos < end; ++pos) {
+        isect_tile[pos] = (uint32_t)n_tiles;
+        isect_gid[pos] = g;
+    }
+}
+
+// tile_offsets[t] = first index i with sorted_tile[i] >= t,  t in [0, n_tiles]
+__global__ __launch_bounds__(kSortThreads) void tile_offsets_kernel(uint32_t m, const uint32_t *__restrict__ sorted_tile,
+                                                                    int n_tiles, int32_t *__restrict__ tile_offsets) {
+    long i = (long)blockIdx.x * kSortThreads + threadIdx.x;
+    if (i > m) return;
+    long lo = (i == 0) ? 0 : (long)sorted_tile[i - 1] + 1;
+    long hi = (i == m) ? n_tiles : min((long)sorted_tile[i], (long)n_tiles);
+    for (long t = lo; t <= hi; ++t) tile_offsets[t] = (int32_t)i;
+}
+
+int sort_blocks(int n) { return gsa_div_up(n, kSortChunk); }
+
+}  // namespace
+
+extern "C" size_t gsa_sort_workspace_bytes(int n) {
+    if (n < 0) n = 0;
+    size_t nb_sort = (size_t)sort_blocks(n) + 1;
+    size_t nb_scan = (size_t)gsa_div_up(n, kScanChunk) + 1;
+    size_t words = kRadix * nb_sort + kRadix + nb_scan + 64;
+    return words * sizeof(uint32_t);
+}
+
+extern "C" int gsa_sort_pairs_u32(int n, const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out,
+                                  uint32_t *vals_out, uint32_t *keys_tmp, uint32_t *vals_tmp, int begin_bit,
+                                  int end_bit, void *workspace, size_t workspace_bytes, gsa_stream_t stream) {
+    GSA_RETURN_IF(n < 0 || begin_bit < 0 || end_bit > 32 || end_bit <= begin_bit, GSA_ERR_INVALID_ARGUMENT);
+    if (n == 0) return GSA_OK;
+    GSA_RETURN_IF(!keys_in || !keys_out || !vals_out || !keys_tmp || !vals_tmp || !workspace, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(workspace_bytes < gsa_sort_workspace_bytes(n), GSA_ERR_WORKSPACE_TOO_SMALL);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nblocks = sort_blocks(n);
+    uint32_t *hist = static_cast<uint32_t *>(workspace);
+    uint32_t *digit_total = hist + (size_t)kRadix * nblocks;
+    const int passes = (end_bit - begin_bit + 7) / 8;
+    // ping-pong so that the last pass lands in *_out
+    const uint32_t *kin = keys_in, *vin = vals_in;
+    for (int p = 0; p < passes; ++p) {
+        bool to_out = ((passes - 1 - p) % 2) == 0;
+        uint32_t *kout = to_out ? keys_out : keys_tmp;
+        uint32_t *vout = to_out ? vals_out : vals_tmp;
+        int shift = begin_bit + 8 * p;
+        radix_hist_kernel<<<nblocks, kSortThreads, 0, s>>>(n, kin, shift, nblocks, hist);
+        GSA_LAUNCH_CHECK();
+        radix_scan_rows_kernel<<<kRadix, kSortThreads, 0, s>>>(nblocks, hist, digit_total);
+        GSA_LAUNCH_CHECK();
+        radix_scatter_kernel<<<nblocks, kSortThreads, 0, s>>>(n, kin, vin, kout, vout, shift, nblocks, hist, digit_total);
+        GSA_LAUNCH_CHECK();
+        kin = kout;
+        vin = vout;
+    }
+    return GSA_OK;
+}
+
+extern "C" int gsa_scan_tiles(int n, const int32_t *tiles_touched, const uint32_t *order, uint32_t *offsets,
+                              uint32_t *total, void *workspace, size_t workspace_bytes, gsa_stream_t stream) {
+    GSA_RETURN_IF(n < 0, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(!total, GSA_ERR_INVALID_ARGUMENT);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n == 0) {
+        hipError_t e = hipMemsetAsync(total, 0, sizeof(uint32_t), s);
+        return (int)e;
+    }
+    GSA_RETURN_IF(!tiles_touched || !order || !offsets || !workspace, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(workspace_bytes < gsa_sort_workspace_bytes(n), GSA_ERR_WORKSPACE_TOO_SMALL);
+    uint32_t *block_sums = static_cast<uint32_t *>(workspace);
+    int nblocks = gsa_div_up(n, kScanChunk);
+    scan_reduce_kernel<<<nblocks, kSortThreads, 0, s>>>(n, tiles_touched, order, block_sums);
+    GSA_LAUNCH_CHECK();
+    scan_blocks_kernel<<<1, kSortThreads, 0, s>>>(nblocks, block_sums, total);
+    GSA_LAUNCH_CHECK();
+    scan_final_kernel<<<nblocks, kSortThreads, 0, s>>>(n, tiles_touched, order, block_sums, offsets);
+    GSA_LAUNCH_CHECK();
+    return GSA_OK;
+}
+
+extern "C" int gsa_tile_emit(int n, const uint32_t *order, const uint32_t *offsets, const float *splat,
+                             const int32_t *radii, int width, int height, int cull_mode, uint32_t m_capacity,
+                             uint32_t *isect_tile, uint32_t *isect_gid, gsa_stream_t stream) {
+    GSA_RETURN_IF(n < 0 || width <= 0 || height <= 0, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(cull_mode != 0 && cull_mode != 1, GSA_ERR_INVALID_ARGUMENT);
+    if (n == 0 || m_capacity == 0) return GSA_OK;
+    GSA_RETURN_IF(!order || !offsets || !splat || !radii || !isect_tile || !isect_gid, GSA_ERR_INVALID_ARGUMENT);
+    int tile_w = gsa_div_up(width, GSA_TILE_SIZE), tile_h = gsa_div_up(height, GSA_TILE_SIZE);
+    tile_emit_kernel<<<gsa_div_up(n, kSortThreads), kSortThreads, 0, static_cast<hipStream_t>(stream)>>>(
+        n, order, offsets, splat, radii, tile_w, tile_h, tile_w * tile_h, cull_mode, m_capacity, isect_tile, isect_gid);
+    GSA_LAUNCH_CHECK();
+    return GSA_OK;
+}
+
+extern "C" int gsa_tile_offsets(uint32_t m, const uint32_t *sorted_tile, int n_tiles, int32_t *tile_offsets,
+                                gsa_stream_t stream) {
+    GSA_RETURN_IF(n_tiles <= 0 || !tile_offsets, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(m > 0 && !sorted_tile, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(m >= 0x7FFFFFFFu, GSA_ERR_UNSUPPORTED);
+    tile_offsets_kernel<<<gsa_div_up((long long)m + 1, kSortThreads), kSortThreads, 0,
+                          static_cast<hipStream_t>(stream)>>>(m, sorted_tile, n_tiles, tile_offsets);
+    GSA_LAUNCH_CHECK();
+    return GSA_OK;
+}

@@ -1,0 +1,63 @@
+"""ctypes binding of ``lib/libgsplat_amd.so`` -- the C ABI declared in ``include/gsplat_amd.h``.
+
+Loading fails loudly (ImportError) when the library has not been built: there is no CPU or
+PyTorch fallback on the product path.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_int, c_size_t, c_uint32, c_void_p
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libgsplat_amd.so")
+ABI_VERSION = 1
+SPLAT_STRIDE = 16
+
+P = c_void_p  # every device pointer and the stream cross the boundary as void*
+
+# name -> (restype, argtypes); mirrors include/gsplat_amd.h one to one
+SIGNATURES = {
+    "gsa_abi_version": (c_int, []),
+    "gsa_error_string": (c_char_p, [c_int]),
+    "gsa_project_fwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, c_int, P, P, P, P, P]),
+    "gsa_sort_workspace_bytes": (c_size_t, [c_int]),
+    "gsa_sort_pairs_u32": (c_int, [c_int, P, P, P, P, P, P, c_int, c_int, P, c_size_t, P]),
+    "gsa_scan_tiles": (c_int, [c_int, P, P, P, P, P, c_size_t, P]),
+    "gsa_tile_emit": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_uint32, P, P, P]),
+    "gsa_tile_offsets": (c_int, [c_uint32, P, c_int, P, P]),
+    "gsa_composite_fwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P]),
+    "gsa_composite_bwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P]),
+    "gsa_project_bwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, P, P, P, P, P, P, P, P, P]),
+}
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"gsplat_amd: HIP library not built ({LIB_PATH} missing). Run `python __graft_entry__.py` or "
+            "`python 3d-gaussian-splatting_amd/gsplat_amd/build.py` (needs hipcc, gfx950). There is no fallback path."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.gsa_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"gsplat_amd: library ABI {got} != binding ABI {ABI_VERSION}; rebuild the library")
+    return lib
+
+
+lib = _load()
+
+
+class GsaError(RuntimeError):
+    pass
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = lib.gsa_error_string(code)
+        raise GsaError(f"{what} failed with code {code}: {msg.decode() if msg else '?'}")

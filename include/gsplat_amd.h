@@ -1,0 +1,141 @@
+/*
+ * gsplat_amd.h -- C ABI of the MI355X-native (gfx950) differentiable 3D-Gaussian rasterizer.
+ *
+ * Drop-in boundary
+ * ----------------
+ * The reference has no FFI of its own on this path: its whole hot path is one Python call,
+ *     gsplat.rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, height,
+ *                          packed=False, render_mode=..., sh_degree=..., backgrounds=...)
+ * made at /root/reference/src/backends/gsplat_backend.py:168-182 (live) and :83-97 (dead),
+ * behind the plugin method GSplatBackend.render_with_depth (gsplat_backend.py:129-210).
+ * The entry points below are the stages of that one call;
+ * the Python host side (3d-gaussian-splatting_amd/gsplat_amd/) binds them with ctypes and
+ * re-assembles the reference's operator and plugin surface on top.
+ *
+ * Conventions
+ * -----------
+ *  - extern "C", plain C types only; no torch / C++ types cross this boundary.
+ *  - Every pointer is a DEVICE pointer unless its comment says "host".
+ *  - Every function takes the hipStream_t to launch on (as void*; pass
+ *    torch.cuda.current_stream().cuda_stream) and is asynchronous with respect to the host.
+ *  - Every function returns int: 0 = success, > 0 = a hipError_t, < 0 = a GSA_ERR_* code.
+ *    Nothing throws, nothing calls exit(), nothing allocates: all scratch is caller-provided
+ *    (sizes from the *_workspace_bytes queries) so the caller's caching allocator owns it.
+ *  - Re-entrant and thread-compatible: no mutable globals.
+ *  - All floating tensors are float32 and contiguous; indices are int32/uint32.
+ *
+ * Per-gaussian "splat record" (GSA_SPLAT_STRIDE floats = 64 B, one cache-line-sized row per gaussian;
+ * written by gsa_project_fwd, gathered by the compositor; the gradient record has the same layout):
+ *    [0] mean2d.x  [1] mean2d.y  [2] conic a  [3] conic b  [4] conic c  [5] opacity
+ *    [6] r  [7] g  [8] b  [9] depth (camera z)  [10..15] unused (zero)
+ */
+#ifndef GSPLAT_AMD_H
+#define GSPLAT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "gsplat_amd_constants.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSA_ABI_VERSION 1
+#define GSA_SPLAT_STRIDE 16
+
+#define GSA_OK 0
+#define GSA_ERR_INVALID_ARGUMENT (-1) /* null pointer, negative extent, unsupported SH degree ...   */
+#define GSA_ERR_WORKSPACE_TOO_SMALL (-2)
+#define GSA_ERR_UNSUPPORTED (-3)      /* e.g. more tiles than the sort key holds                    */
+
+typedef void *gsa_stream_t; /* hipStream_t */
+
+/* ABI version of the loaded library (== GSA_ABI_VERSION of the header it was built from). */
+int gsa_abi_version(void);
+
+/* Static, human-readable text for a return code of this library (host pointer, never freed). */
+const char *gsa_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stage 1 (SURVEY 8a rows a3.1 + a3.2): projection + EWA covariance + SH colour + tile count.
+ * Replaces gsplat's projection and spherical-harmonics kernels behind gsplat_backend.py:168-182.
+ *
+ *  means[N,3] quats[N,4](w first) scales[N,3] opacities[N]
+ *  colors: sh_degree >= 0 -> SH coefficients [N, sh_coeffs, 3] (first (sh_degree+1)^2 used);
+ *          sh_degree == -1 -> post-activation colours [N,3] used as they are.
+ *  viewmat[16] row-major world->camera, intrin[9] row-major K (both on the device).
+ *  cull_mode: 0 = tile rectangle of (mean2d +- radius), exactly the published rule;
+ *             1 = additionally drop tiles the alpha >= 1/255 ellipse cannot reach (same image).
+ * Outputs: splat[N,16] (record above; zero rows for culled gaussians), radii[N,2] int32 (0 = culled),
+ *          tiles_touched[N] int32, depth_keys[N] uint32 (float bits of depth; 0xFFFFFFFF if culled).
+ */
+int gsa_project_fwd(int n, const float *means, const float *quats, const float *scales,
+                    const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
+                    const float *viewmat, const float *intrin, int width, int height, int cull_mode,
+                    float *splat, int32_t *radii, int32_t *tiles_touched, uint32_t *depth_keys,
+                    gsa_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stage 2 (row a3.3): tile binning.  Replaces gsplat's isect_tiles + 64-bit radix sort +
+ * isect_offset_encode.  Same resulting order (tile, then depth bits, then gaussian index), built
+ * as: stable sort of the N gaussians by depth bits; emit records in that order; stable sort of the
+ * M records by tile id only.
+ */
+size_t gsa_sort_workspace_bytes(int n);
+
+/* Stable LSD radix sort of n (key,value) uint32 pairs on bits [begin_bit, end_bit) of the key.
+ * vals_in == NULL means value i = i.  keys_tmp/vals_tmp: n elements each.  in/out/tmp must not alias. */
+int gsa_sort_pairs_u32(int n, const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out,
+                       uint32_t *vals_out, uint32_t *keys_tmp, uint32_t *vals_tmp, int begin_bit,
+                       int end_bit, void *workspace, size_t workspace_bytes, gsa_stream_t stream);
+
+/* offsets[k] = sum_{j<k} tiles_touched[order[j]] (exclusive, in depth order); *total = M.
+ * workspace: gsa_sort_workspace_bytes(n). */
+int gsa_scan_tiles(int n, const int32_t *tiles_touched, const uint32_t *order, uint32_t *offsets,
+                   uint32_t *total, void *workspace, size_t workspace_bytes, gsa_stream_t stream);
+
+/* For k in depth order, g = order[k]: write that gaussian's tile ids and its index g at
+ * [offsets[k], offsets[k] + tiles_touched[g]).  Must use the cull_mode of gsa_project_fwd. */
+int gsa_tile_emit(int n, const uint32_t *order, const uint32_t *offsets, const float *splat,
+                  const int32_t *radii, int width, int height, int cull_mode, uint32_t m_capacity,
+                  uint32_t *isect_tile, uint32_t *isect_gid, gsa_stream_t stream);
+
+/* tile_offsets[t] = first record of tile t in the tile-sorted list, t in [0, n_tiles]; [n_tiles] = m. */
+int gsa_tile_offsets(uint32_t m, const uint32_t *sorted_tile, int n_tiles, int32_t *tile_offsets,
+                     gsa_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stage 3 (row a3.4): front-to-back alpha compositing of RGB (channels == 3) or RGB+depth
+ * (channels == 4) per 16x16 tile.  background: [channels] or NULL (= zeros).
+ * Outputs: render[H,W,channels], alpha[H,W], last_id[H,W] int32 (index into the sorted list of the
+ * last splat blended, -1 if none).
+ */
+int gsa_composite_fwd(int width, int height, int channels, const float *splat,
+                      const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
+                      float *render, float *alpha, int32_t *last_id, gsa_stream_t stream);
+
+/* Stage 4 (row a3.5): reverse-order gradient sweep.  v_splat[N,16] must be zero on entry and
+ * receives d loss / d (mean2d, conic, opacity, rgb, depth) in the record layout. */
+int gsa_composite_bwd(int width, int height, int channels, const float *splat,
+                      const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
+                      const float *alpha, const int32_t *last_id, const float *v_render,
+                      const float *v_alpha, float *v_splat, gsa_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stage 5 (row a3.6): projection + SH backward.  Reads the record gradients and the saved
+ * forward record / radii; writes EVERY element of v_means[N,3], v_quats[N,4], v_scales[N,3],
+ * v_opacities[N] and v_colors (same shape as colors; zeros above the active degree and for
+ * culled gaussians).
+ */
+int gsa_project_bwd(int n, const float *means, const float *quats, const float *scales,
+                    const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
+                    const float *viewmat, const float *intrin, int width, int height,
+                    const float *splat, const int32_t *radii, const float *v_splat, float *v_means,
+                    float *v_quats, float *v_scales, float *v_opacities, float *v_colors,
+                    gsa_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSPLAT_AMD_H */

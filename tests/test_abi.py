@@ -1,0 +1,61 @@
+"""No-GPU checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/gsplat_amd.h declares, the ctypes binding covers exactly those, and the argument checks
+answer with error codes (no compute call is made without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "gsplat_amd.h")
+
+
+def _declared():
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(gsa_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import gsplat_amd
+    from gsplat_amd import _lib
+
+    names = _declared()
+    assert len(names) >= 11
+    raw = ctypes.CDLL(gsplat_amd.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in gsplat_amd.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes binding and header disagree"
+    assert gsplat_amd.lib.gsa_abi_version() == 1
+
+
+def test_header_cites_reference_boundary():
+    text = open(HEADER).read()
+    assert "src/backends/gsplat_backend.py:168-182" in text
+
+
+def test_error_codes_and_strings():
+    from gsplat_amd._lib import GsaError, check, lib
+
+    assert lib.gsa_error_string(0) == b"ok"
+    assert b"invalid" in lib.gsa_error_string(-1)
+    assert b"workspace" in lib.gsa_error_string(-2)
+    # argument validation happens on the host before any launch
+    assert lib.gsa_project_fwd(-1, None, None, None, None, None, 3, 16, None, None, 64, 64, 0, None, None, None, None, None) == -1
+    assert lib.gsa_project_fwd(10, None, None, None, None, None, 3, 16, None, None, 64, 64, 0, None, None, None, None, None) == -1
+    assert lib.gsa_project_fwd(10, None, None, None, None, None, 7, 16, None, None, 64, 64, 0, None, None, None, None, None) == -1
+    assert lib.gsa_composite_fwd(64, 64, 5, None, None, None, None, None, None, None, None) == -1
+    assert lib.gsa_sort_pairs_u32(16, None, None, None, None, None, None, 0, 40, None, 0, None) == -1
+    assert lib.gsa_sort_workspace_bytes(1_000_000) > 0
+    with pytest.raises(GsaError):
+        check(-1, "x")
+
+
+def test_product_does_not_import_oracle():
+    """The product path must not route through the oracle (or any CPU fallback)."""
+    pkg = os.path.join(ROOT, "3d-gaussian-splatting_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(d, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
