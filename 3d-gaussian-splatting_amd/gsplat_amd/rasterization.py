@@ -2,7 +2,7 @@
 the reference makes at /root/reference/src/backends/gsplat_backend.py:168-182
 (``gsplat.rasterization``), executed by the HIP library through its C ABI.
 
-One ``torch.autograd.Function`` per camera wraps the five C-ABI stages; torch only owns memory
+One ``torch.autograd.Function`` per camera chains the C-ABI stages (``stages.py``); torch only owns memory
 (caching allocator), the stream and autograd bookkeeping.
 """
 
@@ -13,40 +13,11 @@ from typing import Dict, Optional, Tuple
 
 import torch
 
-from ._lib import SPLAT_STRIDE, check, lib
+from . import stages as S
+from .stages import TILE_SIZE
 
-TILE_SIZE = 16
 _RENDER_MODES = ("RGB", "D", "ED", "RGB+D", "RGB+ED")
 _DEFAULT_CULL_MODE = 0
-
-
-def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
-    return None if t is None else t.data_ptr()
-
-
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
-
-
-def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
-    if not t.is_cuda:
-        raise RuntimeError(f"gsplat_amd.rasterization: `{name}` must live on a HIP device (got {t.device}); "
-                           "there is no CPU path in the product")
-    return t.detach().to(torch.float32).contiguous()
-
-
-def _sort_pairs(n: int, keys: torch.Tensor, vals: Optional[torch.Tensor], begin_bit: int, end_bit: int):
-    """Stable radix sort of int32-typed storage holding uint32 keys; returns (sorted_keys, sorted_vals)."""
-    dev = keys.device
-    k_out = torch.empty(n, dtype=torch.int32, device=dev)
-    v_out = torch.empty(n, dtype=torch.int32, device=dev)
-    k_tmp = torch.empty(n, dtype=torch.int32, device=dev)
-    v_tmp = torch.empty(n, dtype=torch.int32, device=dev)
-    ws_bytes = lib.gsa_sort_workspace_bytes(n)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    check(lib.gsa_sort_pairs_u32(n, _ptr(keys), _ptr(vals), _ptr(k_out), _ptr(v_out), _ptr(k_tmp), _ptr(v_tmp),
-                                 begin_bit, end_bit, _ptr(ws), ws_bytes, _stream()), "gsa_sort_pairs_u32")
-    return k_out, v_out
 
 
 class _RasterizeOneCamera(torch.autograd.Function):
@@ -57,58 +28,20 @@ class _RasterizeOneCamera(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, colors, viewmat, Kmat, background,
                 width: int, height: int, sh_degree: int, channels: int, cull_mode: int):
-        dev = means.device
-        N = means.shape[0]
-        means_c, quats_c, scales_c = _f32c(means, "means"), _f32c(quats, "quats"), _f32c(scales, "scales")
-        opac_c, colors_c = _f32c(opacities, "opacities"), _f32c(colors, "colors")
-        view_c, K_c = _f32c(viewmat, "viewmats"), _f32c(Kmat, "Ks")
-        bg_c = None if background is None else _f32c(background, "backgrounds")
-        sh_coeffs = colors_c.shape[1] if sh_degree >= 0 else 0
-        tile_w = (width + TILE_SIZE - 1) // TILE_SIZE
-        tile_h = (height + TILE_SIZE - 1) // TILE_SIZE
-        n_tiles = tile_w * tile_h
-        st = _stream()
+        means_c, quats_c, scales_c = S.f32c(means, "means"), S.f32c(quats, "quats"), S.f32c(scales, "scales")
+        opac_c, colors_c = S.f32c(opacities, "opacities"), S.f32c(colors, "colors")
+        view_c, K_c = S.f32c(viewmat, "viewmats"), S.f32c(Kmat, "Ks")
+        bg_c = None if background is None else S.f32c(background, "backgrounds")
 
-        splat = torch.empty(N, SPLAT_STRIDE, dtype=torch.float32, device=dev)
-        radii = torch.empty(N, 2, dtype=torch.int32, device=dev)
-        tiles_touched = torch.empty(N, dtype=torch.int32, device=dev)
-        depth_keys = torch.empty(N, dtype=torch.int32, device=dev)
-        check(lib.gsa_project_fwd(N, _ptr(means_c), _ptr(quats_c), _ptr(scales_c), _ptr(opac_c), _ptr(colors_c),
-                                  sh_degree, sh_coeffs, _ptr(view_c), _ptr(K_c), width, height, cull_mode,
-                                  _ptr(splat), _ptr(radii), _ptr(tiles_touched), _ptr(depth_keys), st),
-              "gsa_project_fwd")
-
-        # depth order of the gaussians (ties keep index order; culled ones sort last)
-        _, order = _sort_pairs(N, depth_keys, None, 0, 32)
-        offsets = torch.empty(N, dtype=torch.int32, device=dev)
-        total = torch.empty(1, dtype=torch.int32, device=dev)
-        ws_bytes = lib.gsa_sort_workspace_bytes(N)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        check(lib.gsa_scan_tiles(N, _ptr(tiles_touched), _ptr(order), _ptr(offsets), _ptr(total), _ptr(ws),
-                                 ws_bytes, st), "gsa_scan_tiles")
-        M = int(total.item())  # the one host read-back of the path: sizes the record buffers
-
-        isect_tile = torch.empty(M, dtype=torch.int32, device=dev)
-        isect_gid = torch.empty(M, dtype=torch.int32, device=dev)
-        check(lib.gsa_tile_emit(N, _ptr(order), _ptr(offsets), _ptr(splat), _ptr(radii), width, height, cull_mode,
-                                M, _ptr(isect_tile), _ptr(isect_gid), st), "gsa_tile_emit")
-        tile_bits = max(1, math.ceil(math.log2(n_tiles + 1)))
-        if M > 0:
-            sorted_tile, sorted_gid = _sort_pairs(M, isect_tile, isect_gid, 0, tile_bits)
-        else:
-            sorted_tile, sorted_gid = isect_tile, isect_gid
-        tile_offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
-        check(lib.gsa_tile_offsets(M, _ptr(sorted_tile), n_tiles, _ptr(tile_offsets), st), "gsa_tile_offsets")
-
-        render = torch.empty(height, width, channels, dtype=torch.float32, device=dev)
-        alpha = torch.empty(height, width, 1, dtype=torch.float32, device=dev)
-        last_id = torch.empty(height, width, dtype=torch.int32, device=dev)
-        check(lib.gsa_composite_fwd(width, height, channels, _ptr(splat), _ptr(sorted_gid), _ptr(tile_offsets),
-                                    _ptr(bg_c), _ptr(render), _ptr(alpha), _ptr(last_id), st), "gsa_composite_fwd")
+        splat, radii, tiles_touched, depth_keys = S.project_fwd(means_c, quats_c, scales_c, opac_c, colors_c,
+                                                                sh_degree, view_c, K_c, width, height, cull_mode)
+        sorted_tile, sorted_gid, tile_offsets = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height,
+                                                            cull_mode)
+        render, alpha, last_id = S.composite_fwd(splat, sorted_gid, tile_offsets, bg_c, width, height, channels)
 
         ctx.save_for_backward(means_c, quats_c, scales_c, opac_c, colors_c, view_c, K_c, bg_c, splat, radii,
                               sorted_gid, tile_offsets, alpha, last_id)
-        ctx.dims = (N, width, height, sh_degree, sh_coeffs, channels)
+        ctx.dims = (width, height, sh_degree, channels)
         ctx.in_shapes = (means.shape, quats.shape, scales.shape, opacities.shape, colors.shape)
         extras = (splat, radii, tiles_touched, sorted_tile, sorted_gid, tile_offsets, last_id)
         ctx.mark_non_differentiable(*extras)
@@ -118,32 +51,17 @@ class _RasterizeOneCamera(torch.autograd.Function):
     def backward(ctx, v_render, v_alpha, *unused):
         (means_c, quats_c, scales_c, opac_c, colors_c, view_c, K_c, bg_c, splat, radii, sorted_gid, tile_offsets,
          alpha, last_id) = ctx.saved_tensors
-        N, width, height, sh_degree, sh_coeffs, channels = ctx.dims
-        dev = means_c.device
-        st = _stream()
+        width, height, sh_degree, channels = ctx.dims
         if v_render is None:
-            v_render = torch.zeros(height, width, channels, dtype=torch.float32, device=dev)
+            v_render = torch.zeros(height, width, channels, dtype=torch.float32, device=means_c.device)
         v_render = v_render.to(torch.float32).contiguous()
         v_alpha_c = None if v_alpha is None else v_alpha.to(torch.float32).contiguous()
-
-        v_splat = torch.zeros(N, SPLAT_STRIDE, dtype=torch.float32, device=dev)
-        check(lib.gsa_composite_bwd(width, height, channels, _ptr(splat), _ptr(sorted_gid), _ptr(tile_offsets),
-                                    _ptr(bg_c), _ptr(alpha), _ptr(last_id), _ptr(v_render), _ptr(v_alpha_c),
-                                    _ptr(v_splat), st), "gsa_composite_bwd")
-        v_means = torch.empty_like(means_c)
-        v_quats = torch.empty_like(quats_c)
-        v_scales = torch.empty_like(scales_c)
-        v_opac = torch.empty_like(opac_c)
-        v_colors = torch.empty_like(colors_c)
-        check(lib.gsa_project_bwd(N, _ptr(means_c), _ptr(quats_c), _ptr(scales_c), _ptr(opac_c), _ptr(colors_c),
-                                  sh_degree, sh_coeffs, _ptr(view_c), _ptr(K_c), width, height, _ptr(splat),
-                                  _ptr(radii), _ptr(v_splat), _ptr(v_means), _ptr(v_quats), _ptr(v_scales),
-                                  _ptr(v_opac), _ptr(v_colors), st), "gsa_project_bwd")
-        shp = ctx.in_shapes
+        v_splat = S.composite_bwd(splat, sorted_gid, tile_offsets, bg_c, alpha, last_id, v_render, v_alpha_c,
+                                  width, height, channels)
+        grads = S.project_bwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
+                              splat, radii, v_splat)
         need = ctx.needs_input_grad
-        grads = (v_means.view(shp[0]) if need[0] else None, v_quats.view(shp[1]) if need[1] else None,
-                 v_scales.view(shp[2]) if need[2] else None, v_opac.view(shp[3]) if need[3] else None,
-                 v_colors.view(shp[4]) if need[4] else None)
+        grads = tuple(g.view(shp) if nd else None for g, shp, nd in zip(grads, ctx.in_shapes, need[:5]))
         return grads + (None,) * 8
 
 

@@ -1,0 +1,128 @@
+"""Thin Python wrappers over the C-ABI stages (``include/gsplat_amd.h``): one function per entry point
+family, tensors in / tensors out, memory from torch's caching allocator, launches on torch's current
+stream.  ``rasterization.py`` chains them inside one autograd Function; the parity tests also call them
+one at a time."""
+
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import SPLAT_STRIDE, check, lib
+
+TILE_SIZE = 16
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"gsplat_amd: `{name}` must live on a HIP device (got {t.device}); "
+                           "there is no CPU path in the product")
+    return t.detach().to(torch.float32).contiguous()
+
+
+def tile_grid(width: int, height: int) -> Tuple[int, int]:
+    return (width + TILE_SIZE - 1) // TILE_SIZE, (height + TILE_SIZE - 1) // TILE_SIZE
+
+
+def project_fwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat, Kmat, width: int, height: int,
+                cull_mode: int = 0):
+    """-> splat [N,16], radii [N,2] i32, tiles_touched [N] i32, depth_keys [N] (uint32 bits in int32 storage)."""
+    dev, N = means.device, means.shape[0]
+    sh_coeffs = colors.shape[1] if sh_degree >= 0 else 0
+    splat = torch.empty(N, SPLAT_STRIDE, dtype=torch.float32, device=dev)
+    radii = torch.empty(N, 2, dtype=torch.int32, device=dev)
+    tiles_touched = torch.empty(N, dtype=torch.int32, device=dev)
+    depth_keys = torch.empty(N, dtype=torch.int32, device=dev)
+    check(lib.gsa_project_fwd(N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), _ptr(colors), sh_degree,
+                              sh_coeffs, _ptr(viewmat), _ptr(Kmat), width, height, cull_mode, _ptr(splat),
+                              _ptr(radii), _ptr(tiles_touched), _ptr(depth_keys), _stream()), "gsa_project_fwd")
+    return splat, radii, tiles_touched, depth_keys
+
+
+def sort_pairs(n: int, keys: torch.Tensor, vals: Optional[torch.Tensor], begin_bit: int, end_bit: int):
+    """Stable radix sort of int32-typed storage holding uint32 keys; returns (sorted_keys, sorted_vals)."""
+    dev = keys.device
+    k_out = torch.empty(n, dtype=torch.int32, device=dev)
+    v_out = torch.empty(n, dtype=torch.int32, device=dev)
+    k_tmp = torch.empty(n, dtype=torch.int32, device=dev)
+    v_tmp = torch.empty(n, dtype=torch.int32, device=dev)
+    ws_bytes = lib.gsa_sort_workspace_bytes(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    check(lib.gsa_sort_pairs_u32(n, _ptr(keys), _ptr(vals), _ptr(k_out), _ptr(v_out), _ptr(k_tmp), _ptr(v_tmp),
+                                 begin_bit, end_bit, _ptr(ws), ws_bytes, _stream()), "gsa_sort_pairs_u32")
+    return k_out, v_out
+
+
+def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, cull_mode: int = 0):
+    """Depth-order the gaussians, emit their tile records in that order, stable-sort the records by tile.
+    -> sorted_tile [M] i32, sorted_gid [M] i32, tile_offsets [n_tiles+1] i32.  One host read-back (M)."""
+    dev, N = splat.device, splat.shape[0]
+    tile_w, tile_h = tile_grid(width, height)
+    n_tiles = tile_w * tile_h
+    st = _stream()
+    _, order = sort_pairs(N, depth_keys, None, 0, 32)  # ties keep index order; culled gaussians sort last
+    offsets = torch.empty(N, dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)
+    ws_bytes = lib.gsa_sort_workspace_bytes(N)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    check(lib.gsa_scan_tiles(N, _ptr(tiles_touched), _ptr(order), _ptr(offsets), _ptr(total), _ptr(ws), ws_bytes,
+                             st), "gsa_scan_tiles")
+    M = int(total.item())  # the one host read-back of the path: sizes the record buffers
+    isect_tile = torch.empty(M, dtype=torch.int32, device=dev)
+    isect_gid = torch.empty(M, dtype=torch.int32, device=dev)
+    check(lib.gsa_tile_emit(N, _ptr(order), _ptr(offsets), _ptr(splat), _ptr(radii), width, height, cull_mode, M,
+                            _ptr(isect_tile), _ptr(isect_gid), st), "gsa_tile_emit")
+    tile_bits = max(1, math.ceil(math.log2(n_tiles + 1)))
+    if M > 0:
+        sorted_tile, sorted_gid = sort_pairs(M, isect_tile, isect_gid, 0, tile_bits)
+    else:
+        sorted_tile, sorted_gid = isect_tile, isect_gid
+    tile_offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+    check(lib.gsa_tile_offsets(M, _ptr(sorted_tile), n_tiles, _ptr(tile_offsets), st), "gsa_tile_offsets")
+    return sorted_tile, sorted_gid, tile_offsets
+
+
+def composite_fwd(splat, sorted_gid, tile_offsets, background, width: int, height: int, channels: int):
+    """-> render [H,W,channels], alpha [H,W,1], last_id [H,W] i32."""
+    dev = splat.device
+    render = torch.empty(height, width, channels, dtype=torch.float32, device=dev)
+    alpha = torch.empty(height, width, 1, dtype=torch.float32, device=dev)
+    last_id = torch.empty(height, width, dtype=torch.int32, device=dev)
+    check(lib.gsa_composite_fwd(width, height, channels, _ptr(splat), _ptr(sorted_gid), _ptr(tile_offsets),
+                                _ptr(background), _ptr(render), _ptr(alpha), _ptr(last_id), _stream()),
+          "gsa_composite_fwd")
+    return render, alpha, last_id
+
+
+def composite_bwd(splat, sorted_gid, tile_offsets, background, alpha, last_id, v_render, v_alpha, width: int,
+                  height: int, channels: int):
+    """-> v_splat [N,16]: d loss / d (mean2d, conic, opacity, rgb, depth) in the splat-record layout."""
+    v_splat = torch.zeros_like(splat)
+    check(lib.gsa_composite_bwd(width, height, channels, _ptr(splat), _ptr(sorted_gid), _ptr(tile_offsets),
+                                _ptr(background), _ptr(alpha), _ptr(last_id), _ptr(v_render), _ptr(v_alpha),
+                                _ptr(v_splat), _stream()), "gsa_composite_bwd")
+    return v_splat
+
+
+def project_bwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat, Kmat, width: int, height: int,
+                splat, radii, v_splat):
+    """-> v_means, v_quats, v_scales, v_opacities, v_colors (every element written)."""
+    N = means.shape[0]
+    sh_coeffs = colors.shape[1] if sh_degree >= 0 else 0
+    v_means, v_quats, v_scales = torch.empty_like(means), torch.empty_like(quats), torch.empty_like(scales)
+    v_opac, v_colors = torch.empty_like(opacities), torch.empty_like(colors)
+    check(lib.gsa_project_bwd(N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), _ptr(colors), sh_degree,
+                              sh_coeffs, _ptr(viewmat), _ptr(Kmat), width, height, _ptr(splat), _ptr(radii),
+                              _ptr(v_splat), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac),
+                              _ptr(v_colors), _stream()), "gsa_project_bwd")
+    return v_means, v_quats, v_scales, v_opac, v_colors

@@ -25,6 +25,7 @@ import math
 from typing import Dict, Optional, Tuple
 
 import torch
+import torch.utils.checkpoint
 
 from . import constants as K_
 
@@ -231,11 +232,18 @@ def composite(
     sorted_gids: torch.Tensor,   # [M] gaussian index per sorted record (this camera)
     tile_offsets: torch.Tensor,  # [T+1] start of each tile's slice (last = M)
     budget: int = 6_000_000,
-) -> Tuple[torch.Tensor, torch.Tensor]:
+    ambiguity_tol: Optional[float] = None,
+    checkpoint: bool = False,
+):
     """Per pixel, front to back over its tile's sorted list (Appendix A.5):
     sigma = 1/2 (a dx^2 + c dy^2) + b dx dy;  alpha = min(0.999, o exp(-sigma));
     skip if sigma < 0 or alpha < 1/255;  stop (splat not added) when T (1 - alpha) <= 1e-4.
-    Returns render [H,W,D] (incl. T*background) and alpha [H,W,1] = 1 - T."""
+    Returns render [H,W,D] (incl. T*background) and alpha [H,W,1] = 1 - T.
+
+    The function is discontinuous at its three thresholds (alpha = 1/255, T(1-alpha) = 1e-4, and for the
+    gradient o*exp(-sigma) = 0.999).  With ``ambiguity_tol`` a third value is returned: a bool [H,W] mask of
+    the pixels where some comparison the pixel actually reaches sits within that RELATIVE distance of its
+    threshold -- there two correct fp32 implementations may legitimately decide differently."""
     dt = means2d.dtype
     N, D = feats.shape
     tw = (width + tile_size - 1) // tile_size
@@ -254,30 +262,12 @@ def composite(
     px_in = (lin % tile_size).to(dt) + 0.5
     py_in = (lin // tile_size).to(dt) + 0.5
 
-    order = torch.argsort(counts, stable=True)
-    order = order[counts[order] > 0]
-    tile_idx_out, color_out, trans_out = [], [], []
-    i = 0
-    while i < order.numel():
-        # grow a batch of tiles of similar list length under the element budget
-        j = i + 1
-        while j < order.numel() and (j + 1 - i) * npx * int(counts[order[j]]) <= budget:
-            j += 1
-        tiles = order[i:j]
-        i = j
-        L = int(counts[tiles].max())
-        pos = tile_offsets[tiles].long()[:, None] + torch.arange(L)[None, :]
-        ok = torch.arange(L)[None, :] < counts[tiles][:, None]
-        ids = torch.where(ok, sorted_gids.long()[pos.clamp(max=max(sorted_gids.numel() - 1, 0))],
-                          torch.full_like(pos, N))                      # [nb, L]
-        ox = ((tiles % tw) * tile_size).to(dt)
-        oy = ((tiles // tw) * tile_size).to(dt)
-        px = ox[:, None] + px_in[None, :]                               # [nb, npx]
-        py = oy[:, None] + py_in[None, :]
-        g_m = m2[ids]                                                   # [nb, L, 2]
-        g_c = cn[ids]
-        g_o = op[ids]
-        g_f = ft[ids]                                                   # [nb, L, D]
+    def blend(ids, px, py, m2_, cn_, op_, ft_):
+        """One batch of tiles: ids [nb,L] (padded with N), pixel centres [nb,npx]."""
+        g_m = m2_[ids]                                                  # [nb, L, 2]
+        g_c = cn_[ids]
+        g_o = op_[ids]
+        g_f = ft_[ids]                                                  # [nb, L, D]
         dx = g_m[:, None, :, 0] - px[:, :, None]                        # [nb, npx, L]
         dy = g_m[:, None, :, 1] - py[:, :, None]
         sigma = 0.5 * (g_c[:, None, :, 0] * dx * dx + g_c[:, None, :, 2] * dy * dy) \
@@ -288,21 +278,60 @@ def composite(
             a_v = torch.where(valid, alpha, torch.zeros_like(alpha))
             next_T = torch.cumprod(1.0 - a_v, dim=-1)
             contrib = valid & (next_T > K_.TRANSMITTANCE_EPS)
+            amb = torch.zeros(ids.shape[0], px.shape[1], dtype=torch.bool)
+            if ambiguity_tol is not None:
+                tol = ambiguity_tol
+                raw = g_o[:, None, :] * torch.exp(-sigma)
+                live = torch.cat([torch.ones_like(contrib[..., :1]), next_T[..., :-1] > K_.TRANSMITTANCE_EPS], -1)
+                near_a = (alpha * 255.0 - 1.0).abs() < tol
+                near_t = valid & ((next_T / K_.TRANSMITTANCE_EPS - 1.0).abs() < tol)
+                near_c = valid & ((raw / K_.MAX_ALPHA - 1.0).abs() < tol)
+                amb = ((near_a | near_t | near_c) & live & (sigma >= 0)).any(dim=-1)
         a_eff = torch.where(contrib, alpha, torch.zeros_like(alpha))
         T_incl = torch.cumprod(1.0 - a_eff, dim=-1)
         T_excl = torch.cat([torch.ones_like(T_incl[..., :1]), T_incl[..., :-1]], dim=-1)
         w = a_eff * T_excl
-        color = torch.einsum("tpl,tld->tpd", w, g_f)
+        return torch.einsum("tpl,tld->tpd", w, g_f), T_incl[..., -1], amb
+
+    order = torch.argsort(counts, stable=True)
+    order = order[counts[order] > 0]
+    lens = counts[order].tolist()
+    ar_max = torch.arange(max(lens) if lens else 0)
+    tile_idx_out, color_out, trans_out, amb_out = [], [], [], []
+    i, n_t = 0, len(lens)
+    while i < n_t:
+        # grow a batch of tiles of similar list length (ascending) under the element budget
+        j = i + 1
+        while j < n_t and (j + 1 - i) * npx * lens[j] <= budget:
+            j += 1
+        tiles = order[i:j]
+        L = lens[j - 1]
+        i = j
+        pos = tile_offsets[tiles].long()[:, None] + ar_max[None, :L]
+        ok = ar_max[None, :L] < counts[tiles][:, None]
+        ids = torch.where(ok, sorted_gids.long()[pos.clamp(max=max(sorted_gids.numel() - 1, 0))],
+                          torch.full_like(pos, N))                      # [nb, L]
+        px = ((tiles % tw) * tile_size).to(dt)[:, None] + px_in[None, :]   # [nb, npx]
+        py = ((tiles // tw) * tile_size).to(dt)[:, None] + py_in[None, :]
+        if checkpoint and torch.is_grad_enabled():
+            color, t_fin, amb = torch.utils.checkpoint.checkpoint(blend, ids, px, py, m2, cn, op, ft,
+                                                                  use_reentrant=False)
+        else:
+            color, t_fin, amb = blend(ids, px, py, m2, cn, op, ft)
         tile_idx_out.append(tiles)
         color_out.append(color)
-        trans_out.append(T_incl[..., -1])
+        trans_out.append(t_fin)
+        amb_out.append(amb)
 
     canvas_c = means2d.new_zeros(T_, npx, D)
     canvas_t = means2d.new_ones(T_, npx)
+    canvas_a = torch.zeros(T_, npx, dtype=torch.bool)
     if tile_idx_out:
         tiles_all = torch.cat(tile_idx_out)
         canvas_c = canvas_c.index_copy(0, tiles_all, torch.cat(color_out))
         canvas_t = canvas_t.index_copy(0, tiles_all, torch.cat(trans_out))
+        if ambiguity_tol is not None:
+            canvas_a = canvas_a.index_copy(0, tiles_all, torch.cat(amb_out))
     if background is not None:
         canvas_c = canvas_c + canvas_t[..., None] * background.to(dt)
 
@@ -311,6 +340,8 @@ def composite(
         v = v.reshape(th, tw, tile_size, tile_size, k).permute(0, 2, 1, 3, 4)
         return v.reshape(th * tile_size, tw * tile_size, k)[:height, :width]
 
+    if ambiguity_tol is not None:
+        return untile(canvas_c), untile((1.0 - canvas_t)[..., None]), untile(canvas_a[..., None])[..., 0]
     return untile(canvas_c), untile((1.0 - canvas_t)[..., None])
 
 
@@ -336,9 +367,13 @@ def rasterization(
     tile_size: int = K_.TILE_SIZE,
     backgrounds: Optional[torch.Tensor] = None,
     render_mode: str = "RGB",
+    ambiguity_tol: Optional[float] = None,
+    checkpoint: bool = False,
     **unsupported,
 ) -> Tuple[torch.Tensor, torch.Tensor, Dict]:
-    """Same keyword surface and return contract as the call at
+    """``ambiguity_tol`` (oracle-only extension): adds ``meta['ambiguous']`` [C,H,W] bool, see ``composite``.
+
+    Same keyword surface and return contract as the call at
     /root/reference/src/backends/gsplat_backend.py:168-182:
     ``(renders [C,H,W,D], alphas [C,H,W,1], meta)`` with ``meta['means2d']`` [C,N,2] and
     ``meta['radii']`` [C,N,2] int32 (read at gsplat_backend.py:204-208)."""
@@ -364,7 +399,7 @@ def rasterization(
 
     out_r, out_a = [], []
     m_means2d, m_radii, m_depths, m_conics, m_tiles = [], [], [], [], []
-    keys_all, flat_all = [], []
+    keys_all, flat_all, m_amb = [], [], []
     for c in range(C):
         pr = project(means, quats, scales, opacities, viewmats[c], Ks[c], width, height,
                      near_plane, far_plane, radius_clip, eps2d)
@@ -398,8 +433,12 @@ def rasterization(
         tile_bits = max(1, math.ceil(math.log2(max(tw * th, 2))))
         tile_of = (keys >> 32) & ((1 << tile_bits) - 1)
         offs = torch.searchsorted(tile_of, torch.arange(tw * th + 1))
-        img, alpha = composite(pr["means2d"], pr["conics"], opacities, feats, bg,
-                               width, height, tile_size, flat.long() - c * N, offs)
+        comp = composite(pr["means2d"], pr["conics"], opacities, feats, bg,
+                         width, height, tile_size, flat.long() - c * N, offs, ambiguity_tol=ambiguity_tol,
+                         checkpoint=checkpoint)
+        img, alpha = comp[0], comp[1]
+        if ambiguity_tol is not None:
+            m_amb.append(comp[2])
         if render_mode in ("ED", "RGB+ED"):
             img = torch.cat([img[..., :-1], img[..., -1:] / alpha.clamp(min=K_.DEPTH_ALPHA_EPS)], dim=-1)
         out_r.append(img)
@@ -426,6 +465,8 @@ def rasterization(
         "tile_width": tw, "tile_height": th, "tile_size": tile_size,
         "width": width, "height": height, "n_cameras": C,
     }
+    if ambiguity_tol is not None:
+        meta["ambiguous"] = torch.stack(m_amb)
     return torch.stack(out_r), torch.stack(out_a), meta
 
 
