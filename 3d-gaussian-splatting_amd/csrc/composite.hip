@@ -35,7 +35,7 @@ template <int CH>
 __global__ __launch_bounds__(kBlock) void composite_fwd_kernel(
     int width, int height, int tile_w, const float *__restrict__ splat, const uint32_t *__restrict__ sorted_gid,
     const int32_t *__restrict__ tile_offsets, const float *__restrict__ background, float *__restrict__ render,
-    float *__restrict__ alpha_out, int32_t *__restrict__ last_id) {
+    float *__restrict__ alpha_out, float *__restrict__ final_T, int32_t *__restrict__ last_id) {
     __shared__ float4 s_q0[kBlock];  // mean.x mean.y conic.a conic.b
     __shared__ float4 s_q1[kBlock];  // conic.c opacity r g
     __shared__ float2 s_q2[kBlock];  // b depth
@@ -88,6 +88,7 @@ __global__ __launch_bounds__(kBlock) void composite_fwd_kernel(
 #pragma unroll
         for (int k = 0; k < CH; ++k) render[pix * CH + k] = acc[k] + (background ? T * background[k] : 0.f);
         alpha_out[pix] = 1.f - T;
+        final_T[pix] = T;  // kept beside alpha: 1 - (1 - T) loses the low bits of a small T
         last_id[pix] = last;
     }
 }
@@ -116,7 +117,7 @@ template <int CH>
 __global__ __launch_bounds__(kBlock) void composite_bwd_kernel(
     int width, int height, int tile_w, const float *__restrict__ splat, const uint32_t *__restrict__ sorted_gid,
     const int32_t *__restrict__ tile_offsets, const float *__restrict__ background,
-    const float *__restrict__ alpha_img, const int32_t *__restrict__ last_id, const float *__restrict__ v_render,
+    const float *__restrict__ final_T, const int32_t *__restrict__ last_id, const float *__restrict__ v_render,
     const float *__restrict__ v_alpha, float *__restrict__ v_splat) {
     __shared__ float4 s_q0[kBlock];
     __shared__ float4 s_q1[kBlock];
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void composite_bwd_kernel(
 
     const size_t pix = inside ? (size_t)py * width + px : 0;
     const int bin_final = inside ? last_id[pix] : -1;
-    const float T_final = inside ? 1.f - alpha_img[pix] : 1.f;
+    const float T_final = inside ? final_T[pix] : 1.f;
     float T = T_final;
     float vout[CH], buf[CH];
     float bgdot = 0.f;
@@ -224,36 +225,37 @@ __global__ __launch_bounds__(kBlock) void composite_bwd_kernel(
 
 extern "C" int gsa_composite_fwd(int width, int height, int channels, const float *splat,
                                  const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
-                                 float *render, float *alpha, int32_t *last_id, gsa_stream_t stream) {
+                                 float *render, float *alpha, float *final_T, int32_t *last_id,
+                                 gsa_stream_t stream) {
     GSA_RETURN_IF(width <= 0 || height <= 0 || (channels != 3 && channels != 4), GSA_ERR_INVALID_ARGUMENT);
-    GSA_RETURN_IF(!tile_offsets || !render || !alpha || !last_id, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(!tile_offsets || !render || !alpha || !final_T || !last_id, GSA_ERR_INVALID_ARGUMENT);
     int tile_w = gsa_div_up(width, kTile), tile_h = gsa_div_up(height, kTile);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (channels == 3)
         composite_fwd_kernel<3><<<tile_w * tile_h, kBlock, 0, s>>>(width, height, tile_w, splat, sorted_gid,
-                                                                  tile_offsets, background, render, alpha, last_id);
+                                                                  tile_offsets, background, render, alpha, final_T, last_id);
     else
         composite_fwd_kernel<4><<<tile_w * tile_h, kBlock, 0, s>>>(width, height, tile_w, splat, sorted_gid,
-                                                                  tile_offsets, background, render, alpha, last_id);
+                                                                  tile_offsets, background, render, alpha, final_T, last_id);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }
 
 extern "C" int gsa_composite_bwd(int width, int height, int channels, const float *splat,
                                  const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
-                                 const float *alpha, const int32_t *last_id, const float *v_render,
+                                 const float *final_T, const int32_t *last_id, const float *v_render,
                                  const float *v_alpha, float *v_splat, gsa_stream_t stream) {
     GSA_RETURN_IF(width <= 0 || height <= 0 || (channels != 3 && channels != 4), GSA_ERR_INVALID_ARGUMENT);
-    GSA_RETURN_IF(!tile_offsets || !alpha || !last_id || !v_render || !v_splat, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(!tile_offsets || !final_T || !last_id || !v_render || !v_splat, GSA_ERR_INVALID_ARGUMENT);
     int tile_w = gsa_div_up(width, kTile), tile_h = gsa_div_up(height, kTile);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (channels == 3)
         composite_bwd_kernel<3><<<tile_w * tile_h, kBlock, 0, s>>>(width, height, tile_w, splat, sorted_gid,
-                                                                  tile_offsets, background, alpha, last_id, v_render,
+                                                                  tile_offsets, background, final_T, last_id, v_render,
                                                                   v_alpha, v_splat);
     else
         composite_bwd_kernel<4><<<tile_w * tile_h, kBlock, 0, s>>>(width, height, tile_w, splat, sorted_gid,
-                                                                  tile_offsets, background, alpha, last_id, v_render,
+                                                                  tile_offsets, background, final_T, last_id, v_render,
                                                                   v_alpha, v_splat);
     GSA_LAUNCH_CHECK();
     return GSA_OK;

@@ -37,10 +37,10 @@ class _RasterizeOneCamera(torch.autograd.Function):
                                                                 sh_degree, view_c, K_c, width, height, cull_mode)
         sorted_tile, sorted_gid, tile_offsets = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height,
                                                             cull_mode)
-        render, alpha, last_id = S.composite_fwd(splat, sorted_gid, tile_offsets, bg_c, width, height, channels)
+        render, alpha, final_T, last_id = S.composite_fwd(splat, sorted_gid, tile_offsets, bg_c, width, height, channels)
 
         ctx.save_for_backward(means_c, quats_c, scales_c, opac_c, colors_c, view_c, K_c, bg_c, splat, radii,
-                              sorted_gid, tile_offsets, alpha, last_id)
+                              sorted_gid, tile_offsets, final_T, last_id)
         ctx.dims = (width, height, sh_degree, channels)
         ctx.in_shapes = (means.shape, quats.shape, scales.shape, opacities.shape, colors.shape)
         extras = (splat, radii, tiles_touched, sorted_tile, sorted_gid, tile_offsets, last_id)
@@ -50,13 +50,13 @@ class _RasterizeOneCamera(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_render, v_alpha, *unused):
         (means_c, quats_c, scales_c, opac_c, colors_c, view_c, K_c, bg_c, splat, radii, sorted_gid, tile_offsets,
-         alpha, last_id) = ctx.saved_tensors
+         final_T, last_id) = ctx.saved_tensors
         width, height, sh_degree, channels = ctx.dims
         if v_render is None:
             v_render = torch.zeros(height, width, channels, dtype=torch.float32, device=means_c.device)
         v_render = v_render.to(torch.float32).contiguous()
         v_alpha_c = None if v_alpha is None else v_alpha.to(torch.float32).contiguous()
-        v_splat = S.composite_bwd(splat, sorted_gid, tile_offsets, bg_c, alpha, last_id, v_render, v_alpha_c,
+        v_splat = S.composite_bwd(splat, sorted_gid, tile_offsets, bg_c, final_T, last_id, v_render, v_alpha_c,
                                   width, height, channels)
         grads = S.project_bwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
                               splat, radii, v_splat)

@@ -93,23 +93,24 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
 
 
 def composite_fwd(splat, sorted_gid, tile_offsets, background, width: int, height: int, channels: int):
-    """-> render [H,W,channels], alpha [H,W,1], last_id [H,W] i32."""
+    """-> render [H,W,channels], alpha [H,W,1], final_T [H,W], last_id [H,W] i32."""
     dev = splat.device
     render = torch.empty(height, width, channels, dtype=torch.float32, device=dev)
     alpha = torch.empty(height, width, 1, dtype=torch.float32, device=dev)
+    final_T = torch.empty(height, width, dtype=torch.float32, device=dev)
     last_id = torch.empty(height, width, dtype=torch.int32, device=dev)
     check(lib.gsa_composite_fwd(width, height, channels, _ptr(splat), _ptr(sorted_gid), _ptr(tile_offsets),
-                                _ptr(background), _ptr(render), _ptr(alpha), _ptr(last_id), _stream()),
-          "gsa_composite_fwd")
-    return render, alpha, last_id
+                                _ptr(background), _ptr(render), _ptr(alpha), _ptr(final_T), _ptr(last_id),
+                                _stream()), "gsa_composite_fwd")
+    return render, alpha, final_T, last_id
 
 
-def composite_bwd(splat, sorted_gid, tile_offsets, background, alpha, last_id, v_render, v_alpha, width: int,
+def composite_bwd(splat, sorted_gid, tile_offsets, background, final_T, last_id, v_render, v_alpha, width: int,
                   height: int, channels: int):
     """-> v_splat [N,16]: d loss / d (mean2d, conic, opacity, rgb, depth) in the splat-record layout."""
     v_splat = torch.zeros_like(splat)
     check(lib.gsa_composite_bwd(width, height, channels, _ptr(splat), _ptr(sorted_gid), _ptr(tile_offsets),
-                                _ptr(background), _ptr(alpha), _ptr(last_id), _ptr(v_render), _ptr(v_alpha),
+                                _ptr(background), _ptr(final_T), _ptr(last_id), _ptr(v_render), _ptr(v_alpha),
                                 _ptr(v_splat), _stream()), "gsa_composite_bwd")
     return v_splat
 

@@ -108,18 +108,19 @@ int gsa_tile_offsets(uint32_t m, const uint32_t *sorted_tile, int n_tiles, int32
 /* ---------------------------------------------------------------------------------------------
  * Stage 3 (row a3.4): front-to-back alpha compositing of RGB (channels == 3) or RGB+depth
  * (channels == 4) per 16x16 tile.  background: [channels] or NULL (= zeros).
- * Outputs: render[H,W,channels], alpha[H,W], last_id[H,W] int32 (index into the sorted list of the
- * last splat blended, -1 if none).
+ * Outputs: render[H,W,channels], alpha[H,W] = 1 - T, final_T[H,W] = T (saved for the backward: recomputing
+ * 1 - alpha would lose the low bits of a small T), last_id[H,W] int32 (index into the sorted list of
+ * the last splat blended, -1 if none).
  */
 int gsa_composite_fwd(int width, int height, int channels, const float *splat,
                       const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
-                      float *render, float *alpha, int32_t *last_id, gsa_stream_t stream);
+                      float *render, float *alpha, float *final_T, int32_t *last_id, gsa_stream_t stream);
 
 /* Stage 4 (row a3.5): reverse-order gradient sweep.  v_splat[N,16] must be zero on entry and
  * receives d loss / d (mean2d, conic, opacity, rgb, depth) in the record layout. */
 int gsa_composite_bwd(int width, int height, int channels, const float *splat,
                       const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
-                      const float *alpha, const int32_t *last_id, const float *v_render,
+                      const float *final_T, const int32_t *last_id, const float *v_render,
                       const float *v_alpha, float *v_splat, gsa_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
