@@ -17,7 +17,6 @@ from . import stages as S
 from .stages import TILE_SIZE
 
 _RENDER_MODES = ("RGB", "D", "ED", "RGB+D", "RGB+ED")
-_DEFAULT_CULL_MODE = 0
 
 
 class _RasterizeOneCamera(torch.autograd.Function):
@@ -126,7 +125,7 @@ def rasterization(
     if backgrounds is not None and backgrounds.shape != (C, 3):
         raise ValueError("backgrounds must be [C,3]")
     width, height = int(width), int(height)
-    cull = _DEFAULT_CULL_MODE if cull_mode is None else int(cull_mode)
+    cull = S.DEFAULT_CULL_MODE if cull_mode is None else int(cull_mode)
     want_depth = render_mode != "RGB"
     channels = 4 if want_depth else 3
 

@@ -13,6 +13,43 @@ import torch
 from ._lib import SPLAT_STRIDE, check, lib
 
 TILE_SIZE = 16
+DEFAULT_CULL_MODE = 0  # 0: published tile rectangle; 1: + exact ellipse-vs-tile test (rasterization docstring)
+
+
+class StageTimer:
+    """Optional per-stage device timing with events on the launch stream (bench.py's roofline leg).
+    Disabled by default: the hot path then records nothing."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []  # (stage name, start event, end event)
+
+    def reset(self, enabled: bool) -> None:
+        self.enabled = enabled
+        self.records = []
+
+    def summary(self):
+        """{stage: (calls, total ms)} -- call after a device synchronize."""
+        out = {}
+        for name, a, b in self.records:
+            c, t = out.get(name, (0, 0.0))
+            out[name] = (c + 1, t + a.elapsed_time(b))
+        return out
+
+
+TIMER = StageTimer()
+
+
+def _call(name: str, fn, *args) -> None:
+    """Launch one C-ABI stage on the current stream; raise on a non-zero return code."""
+    if TIMER.enabled:
+        start = torch.cuda.Event(enable_timing=True)
+        start.record()
+    check(fn(*args), name)
+    if TIMER.enabled:
+        end = torch.cuda.Event(enable_timing=True)
+        end.record()
+        TIMER.records.append((name, start, end))
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -43,9 +80,9 @@ def project_fwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat
     radii = torch.empty(N, 2, dtype=torch.int32, device=dev)
     tiles_touched = torch.empty(N, dtype=torch.int32, device=dev)
     depth_keys = torch.empty(N, dtype=torch.int32, device=dev)
-    check(lib.gsa_project_fwd(N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), _ptr(colors), sh_degree,
+    _call("gsa_project_fwd", lib.gsa_project_fwd, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), _ptr(colors), sh_degree,
                               sh_coeffs, _ptr(viewmat), _ptr(Kmat), width, height, cull_mode, _ptr(splat),
-                              _ptr(radii), _ptr(tiles_touched), _ptr(depth_keys), _stream()), "gsa_project_fwd")
+                              _ptr(radii), _ptr(tiles_touched), _ptr(depth_keys), _stream())
     return splat, radii, tiles_touched, depth_keys
 
 
@@ -58,8 +95,8 @@ def sort_pairs(n: int, keys: torch.Tensor, vals: Optional[torch.Tensor], begin_b
     v_tmp = torch.empty(n, dtype=torch.int32, device=dev)
     ws_bytes = lib.gsa_sort_workspace_bytes(n)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    check(lib.gsa_sort_pairs_u32(n, _ptr(keys), _ptr(vals), _ptr(k_out), _ptr(v_out), _ptr(k_tmp), _ptr(v_tmp),
-                                 begin_bit, end_bit, _ptr(ws), ws_bytes, _stream()), "gsa_sort_pairs_u32")
+    _call("gsa_sort_pairs_u32", lib.gsa_sort_pairs_u32, n, _ptr(keys), _ptr(vals), _ptr(k_out), _ptr(v_out), _ptr(k_tmp), _ptr(v_tmp),
+                                 begin_bit, end_bit, _ptr(ws), ws_bytes, _stream())
     return k_out, v_out
 
 
@@ -75,20 +112,20 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
     total = torch.empty(1, dtype=torch.int32, device=dev)
     ws_bytes = lib.gsa_sort_workspace_bytes(N)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    check(lib.gsa_scan_tiles(N, _ptr(tiles_touched), _ptr(order), _ptr(offsets), _ptr(total), _ptr(ws), ws_bytes,
-                             st), "gsa_scan_tiles")
+    _call("gsa_scan_tiles", lib.gsa_scan_tiles, N, _ptr(tiles_touched), _ptr(order), _ptr(offsets), _ptr(total), _ptr(ws), ws_bytes,
+                             st)
     M = int(total.item())  # the one host read-back of the path: sizes the record buffers
     isect_tile = torch.empty(M, dtype=torch.int32, device=dev)
     isect_gid = torch.empty(M, dtype=torch.int32, device=dev)
-    check(lib.gsa_tile_emit(N, _ptr(order), _ptr(offsets), _ptr(splat), _ptr(radii), width, height, cull_mode, M,
-                            _ptr(isect_tile), _ptr(isect_gid), st), "gsa_tile_emit")
+    _call("gsa_tile_emit", lib.gsa_tile_emit, N, _ptr(order), _ptr(offsets), _ptr(splat), _ptr(radii), width, height, cull_mode, M,
+                            _ptr(isect_tile), _ptr(isect_gid), st)
     tile_bits = max(1, math.ceil(math.log2(n_tiles + 1)))
     if M > 0:
         sorted_tile, sorted_gid = sort_pairs(M, isect_tile, isect_gid, 0, tile_bits)
     else:
         sorted_tile, sorted_gid = isect_tile, isect_gid
     tile_offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
-    check(lib.gsa_tile_offsets(M, _ptr(sorted_tile), n_tiles, _ptr(tile_offsets), st), "gsa_tile_offsets")
+    _call("gsa_tile_offsets", lib.gsa_tile_offsets, M, _ptr(sorted_tile), n_tiles, _ptr(tile_offsets), st)
     return sorted_tile, sorted_gid, tile_offsets
 
 
@@ -99,9 +136,9 @@ def composite_fwd(splat, sorted_gid, tile_offsets, background, width: int, heigh
     alpha = torch.empty(height, width, 1, dtype=torch.float32, device=dev)
     final_T = torch.empty(height, width, dtype=torch.float32, device=dev)
     last_id = torch.empty(height, width, dtype=torch.int32, device=dev)
-    check(lib.gsa_composite_fwd(width, height, channels, _ptr(splat), _ptr(sorted_gid), _ptr(tile_offsets),
+    _call("gsa_composite_fwd", lib.gsa_composite_fwd, width, height, channels, _ptr(splat), _ptr(sorted_gid), _ptr(tile_offsets),
                                 _ptr(background), _ptr(render), _ptr(alpha), _ptr(final_T), _ptr(last_id),
-                                _stream()), "gsa_composite_fwd")
+                                _stream())
     return render, alpha, final_T, last_id
 
 
@@ -109,9 +146,9 @@ def composite_bwd(splat, sorted_gid, tile_offsets, background, final_T, last_id,
                   height: int, channels: int):
     """-> v_splat [N,16]: d loss / d (mean2d, conic, opacity, rgb, depth) in the splat-record layout."""
     v_splat = torch.zeros_like(splat)
-    check(lib.gsa_composite_bwd(width, height, channels, _ptr(splat), _ptr(sorted_gid), _ptr(tile_offsets),
+    _call("gsa_composite_bwd", lib.gsa_composite_bwd, width, height, channels, _ptr(splat), _ptr(sorted_gid), _ptr(tile_offsets),
                                 _ptr(background), _ptr(final_T), _ptr(last_id), _ptr(v_render), _ptr(v_alpha),
-                                _ptr(v_splat), _stream()), "gsa_composite_bwd")
+                                _ptr(v_splat), _stream())
     return v_splat
 
 
@@ -122,8 +159,8 @@ def project_bwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat
     sh_coeffs = colors.shape[1] if sh_degree >= 0 else 0
     v_means, v_quats, v_scales = torch.empty_like(means), torch.empty_like(quats), torch.empty_like(scales)
     v_opac, v_colors = torch.empty_like(opacities), torch.empty_like(colors)
-    check(lib.gsa_project_bwd(N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), _ptr(colors), sh_degree,
+    _call("gsa_project_bwd", lib.gsa_project_bwd, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), _ptr(colors), sh_degree,
                               sh_coeffs, _ptr(viewmat), _ptr(Kmat), width, height, _ptr(splat), _ptr(radii),
                               _ptr(v_splat), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac),
-                              _ptr(v_colors), _stream()), "gsa_project_bwd")
+                              _ptr(v_colors), _stream())
     return v_means, v_quats, v_scales, v_opac, v_colors

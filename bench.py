@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpix/s of rasterizer forward+backward on the synthetic 1M-gaussian / 1080p scene
+(BASELINE.json metric; SURVEY.md section 8d workload "C3"), 1..8 MI355X, one process per GPU.
+
+A step = one pass of the hot path over one view per rank: rasterization forward (project, bin, composite)
++ the synthetic upstream gradient v_render + full backward to the five input gradients; with N > 1 ranks the
+view-parallel exchange (RCCL all-reduce of the 59*N-float gaussian gradients) is inside the step.
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "3d-gaussian-splatting_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+WORKLOADS = {
+    # name: (gaussians, width, height, sh_degree)
+    "C3": (1_000_000, 1920, 1080, 3),
+    "C2": (100_000, 1920, 1080, 3),
+    "C5": (5_000_000, 3840, 2160, 3),
+}
+
+
+def algorithmic_bytes(n: int, m: int, p: int, sh_degree: int):
+    """compulsory traffic per stage for one fwd+bwd view (bytes)."""
+    ka = (sh_degree + 1) ** 2
+    return {
+        "gsa_project_fwd": n * (44 + 12 * ka + 48),
+        "binning": m * (12 + 24),
+        "gsa_composite_fwd": m * (4 + 36) + p * 20,
+        "gsa_composite_bwd": m * (4 + 36 + 36) + p * 24,
+        "gsa_project_bwd": n * (44 + 20 + 36 + 44 + 12 * ka + 192),
+    }
+
+
+def cpu_baseline(n: int, width: int, height: int, sh_degree: int, crop=(480, 270)):
+    """The CPU oracle ("port": the restatement of the gsplat contract the reference lacks) timed on this box's
+    host cores, forward+backward, on a bounded sample of the same workload: the central crop of the same
+    1M-gaussian 1080p view (all N gaussians are projected; 1/16 of the pixels are composited)."""
+    from gsplat_amd import scene
+    from oracle import rasterization as oracle_rasterization
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cw, ch = crop
+    sc = scene.make_scene(n, seed=0, sh_degree=sh_degree)
+    K = scene.make_intrinsics(width, height).clone()
+    K[0, 2] -= (width - cw) / 2.0
+    K[1, 2] -= (height - ch) / 2.0
+    vm = scene.make_camera(0, 1)
+    v = scene.make_v_render(cw, ch)
+    leaves = [sc[k].clone().requires_grad_(True) for k in ("means3D", "rotations", "scales", "opacities", "shs")]
+    t0 = time.perf_counter()
+    r, _, meta = oracle_rasterization(leaves[0], leaves[1], leaves[2], leaves[3][:, 0], leaves[4], vm[None], K[None],
+                                      cw, ch, sh_degree=sh_degree, backgrounds=torch.zeros(1, 3))
+    (r[0] * v).sum().backward()
+    dt = time.perf_counter() - t0
+    return {"value": round(cw * ch / dt / 1e6, 5), "unit": "Mpix/s", "cores": cores, "kind": "port",
+            "sample": f"central {cw}x{ch} crop of the {n}-gaussian {width}x{height} view 0, fwd+bwd, torch fp32 "
+                      f"oracle, 1 run of {dt:.1f} s, M={meta['flatten_ids'].numel()}"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--cull-mode", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import gsplat_amd
+    from gsplat_amd import scene, stages
+
+    n, width, height, deg = WORKLOADS[args.workload]
+    sc = scene.make_scene(n, seed=0, sh_degree=deg, device="cpu")
+    names = ("means3D", "rotations", "scales", "opacities", "shs")
+    leaves = [sc[k].to(dev).requires_grad_(True) for k in names]
+    opac = leaves[3]
+    K = scene.make_intrinsics(width, height).to(dev)[None]
+    # weak scaling: rank r renders view r of a ring of `world` cameras (view 0 = the single-GPU view)
+    vm = scene.make_camera(rank, world).to(dev)[None]
+    v_render = scene.make_v_render(width, height, seed=2).to(dev)[None]
+    bg = torch.zeros(1, 3, device=dev)
+    info = {}
+
+    def step():
+        for t in leaves:
+            t.grad = None
+        r, a, meta = gsplat_amd.rasterization(leaves[0], leaves[1], leaves[2], opac[:, 0], leaves[4], vm, K, width,
+                                              height, sh_degree=deg, backgrounds=bg, cull_mode=args.cull_mode)
+        r.backward(v_render)
+        if dist is not None:  # view-parallel exchange: sum the gaussian gradients over ranks (RCCL over xGMI)
+            works = [dist.all_reduce(t.grad, async_op=True) for t in leaves]
+            for w in works:
+                w.wait()
+        info["M"] = meta["flatten_ids"].numel()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    stages.TIMER.reset(enabled=True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    stage_ms = {k: (c, t) for k, (c, t) in stages.TIMER.summary().items()}
+    stages.TIMER.reset(enabled=False)
+
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        m, p = info["M"], width * height
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * p * args.steps / elapsed / 1e6
+        alg = algorithmic_bytes(n, m, p, deg)
+        # per C-ABI stage: average device time per step (binning = sorts + scan + emit + offsets)
+        per = {}
+        for name, (calls, total) in stage_ms.items():
+            key = name if name in alg else "binning"
+            per[key] = per.get(key, 0.0) + total / args.steps
+        dominant = max((k for k in per if k in alg), key=lambda k: per[k])
+        ach = alg[dominant] / (per[dominant] * 1e-3) / 1e9
+        total_bytes = sum(alg.values())
+        line = {
+            "metric": "Mpix/s fwd+bwd @1M gaussians/1080p", "value": round(value, 3), "unit": "Mpix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {n} gaussians, {width}x{height}, SH degree {deg}, "
+                                   f"1 view per GPU per step, forward+backward"
+                                   + (", RCCL all-reduce of 59N-float grads" if world > 1 else ""),
+                       "intersections_M": m, "cull_mode": stages.DEFAULT_CULL_MODE if args.cull_mode is None else args.cull_mode},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg[dominant], "avg_launch_ms": round(per[dominant], 4)},
+            "roofline_whole_step": {"algorithmic_bytes": total_bytes,
+                                    "achieved_GBs": round(total_bytes / (ms_per_step * 1e-3) / 1e9, 2),
+                                    "frac": round(total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "stage_ms": {k: round(v, 4) for k, v in sorted(per.items())},
+        }
+        if world == 1 and not args.no_cpu_baseline and args.workload == "C3":
+            line["cpu_baseline"] = cpu_baseline(n, width, height, deg)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
