@@ -120,12 +120,12 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(
         count = 0;
         for (int ty = tr.y0; ty < tr.y1; ++ty)
             for (int tx = tr.x0; tx < tr.x1; ++tx)
-                count += gsa_tile_hit(p.mx, p.my, p.qa, p.qb, p.qc, sig_max, tx, ty) ? 1 : 0;
+                count += gsa_quadrant_mask(p.mx, p.my, p.qa, p.qb, p.qc, sig_max, tx, ty) != 0u ? 1 : 0;
     }
 
     out[0] = make_float4(p.mx, p.my, p.qa, p.qb);
     out[1] = make_float4(p.qc, opac, r, g);
-    out[2] = make_float4(b, p.z, 0.f, 0.f);
+    out[2] = make_float4(b, p.z, sig_max, 0.f);
     out[3] = make_float4(0.f, 0.f, 0.f, 0.f);
     radii[2 * i] = rx; radii[2 * i + 1] = ry;
     tiles_touched[i] = count;

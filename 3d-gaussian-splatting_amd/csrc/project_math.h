@@ -209,11 +209,18 @@ __device__ __forceinline__ float gsa_min_sigma_rect(float mx, float my, float a,
     return best;
 }
 
-// Can the alpha >= 1/255 region of this splat reach any pixel centre of tile (tx, ty)?  Conservative:
-// a small margin on the threshold keeps every pixel the per-pixel test would accept.
-__device__ __forceinline__ bool gsa_tile_hit(float mx, float my, float a, float b, float c, float sig_max,
-                                             int tx, int ty) {
-    float x0 = tx * GSA_TILE_SIZE + 0.5f, y0 = ty * GSA_TILE_SIZE + 0.5f;
-    float s = gsa_min_sigma_rect(mx, my, a, b, c, x0, y0, x0 + (GSA_TILE_SIZE - 1), y0 + (GSA_TILE_SIZE - 1));
-    return s <= sig_max * 1.0001f + 1e-4f;
+// Which 8x8 quadrants of tile (tx, ty) can the alpha >= 1/255 region of this splat reach?  Bit g (gx = g & 1,
+// gy = g >> 1) is set if some pixel CENTRE of the quadrant may pass the per-pixel alpha test.  Conservative:
+// a small margin on the threshold keeps every pixel the per-pixel test would accept.  sig_max = ln(255 o).
+__device__ __forceinline__ uint32_t gsa_quadrant_mask(float mx, float my, float a, float b, float c, float sig_max,
+                                                      int tx, int ty) {
+    const float thr = sig_max * 1.0001f + 1e-4f;
+    uint32_t m = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float x0 = tx * GSA_TILE_SIZE + (g & 1) * 8 + 0.5f, y0 = ty * GSA_TILE_SIZE + (g >> 1) * 8 + 0.5f;
+        float s = gsa_min_sigma_rect(mx, my, a, b, c, x0, y0, x0 + 7.f, y0 + 7.f);
+        m |= (s <= thr) ? (1u << g) : 0u;
+    }
+    return m;
 }

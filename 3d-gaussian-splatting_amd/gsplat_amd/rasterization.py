@@ -89,7 +89,7 @@ def rasterization(
     """Returns ``(renders [C,H,W,D], alphas [C,H,W,1], meta)``; ``meta['means2d']`` [C,N,2] and
     ``meta['radii']`` [C,N,2] int32 are what the reference reads (gsplat_backend.py:204-208).
 
-    ``cull_mode`` (extension, default 0): 0 = tile rectangle of mean2d +- radius (the published rule);
+    ``cull_mode`` (extension, default ``stages.DEFAULT_CULL_MODE`` = 1): 0 = tile rectangle of mean2d +- radius (the published rule);
     1 = also skip tiles the alpha >= 1/255 ellipse cannot reach (same image and gradients, fewer records).
     """
     for k, v in unsupported.items():
@@ -129,9 +129,7 @@ def rasterization(
     want_depth = render_mode != "RGB"
     channels = 4 if want_depth else 3
 
-    renders, alphas = [], []
-    m_splat, m_radii, m_tiles, m_keys_tile, m_flat, m_offs = [], [], [], [], [], []
-    base = 0
+    renders, alphas, per_cam = [], [], []
     for c in range(C):
         bg = None
         if backgrounds is not None:
@@ -140,56 +138,78 @@ def rasterization(
                 bg = torch.cat([bg, bg.new_zeros(1)])
         out = _RasterizeOneCamera.apply(means, quats, scales, opacities, colors, viewmats[c], Ks[c], bg,
                                         width, height, deg, channels, cull)
-        render, alpha, splat, radii, tiles_touched, sorted_tile, sorted_gid, tile_offsets, _last = out
+        render, alpha = out[0], out[1]
         if render_mode in ("ED", "RGB+ED"):
             render = torch.cat([render[..., :3], render[..., 3:] / alpha.clamp(min=1e-10)], dim=-1)
         if render_mode in ("D", "ED"):
             render = render[..., 3:]
         renders.append(render)
         alphas.append(alpha)
-        m_splat.append(splat); m_radii.append(radii); m_tiles.append(tiles_touched)
-        m_keys_tile.append(sorted_tile); m_flat.append(sorted_gid + c * N)
-        m_offs.append(tile_offsets[:-1] + base)
-        base += sorted_gid.numel()
+        per_cam.append(out[2:])  # splat, radii, tiles_touched, sorted_tile, sorted_val, tile_offsets, last_id
 
-    splat_all = torch.stack(m_splat)  # [C,N,16]
-    tile_w = (width + TILE_SIZE - 1) // TILE_SIZE
-    tile_h = (height + TILE_SIZE - 1) // TILE_SIZE
+    def gather(i):  # [C, ...] without a copy for the single-camera call the reference makes
+        return per_cam[0][i][None] if C == 1 else torch.stack([pc[i] for pc in per_cam])
+
+    tile_w, tile_h = S.tile_grid(width, height)
+    gid_mask = (1 << S.GID_BITS) - 1
     meta = _Meta({
-        "camera_ids": None, "gaussian_ids": None,
-        "means2d": splat_all[..., 0:2], "conics": splat_all[..., 2:5], "depths": splat_all[..., 9],
-        "radii": torch.stack(m_radii), "opacities": opacities[None].expand(C, N),
-        "tiles_per_gauss": torch.stack(m_tiles), "flatten_ids": torch.cat(m_flat),
-        "isect_offsets": torch.stack(m_offs).reshape(C, tile_h, tile_w),
+        "camera_ids": None, "gaussian_ids": None, "opacities": opacities[None].expand(C, N),
         "tile_width": tile_w, "tile_height": tile_h, "tile_size": TILE_SIZE,
         "width": width, "height": height, "n_cameras": C, "cull_mode": cull,
+        "n_isects": sum(int(pc[4].numel()) for pc in per_cam),
     })
-    meta._lazy_isect = (m_keys_tile, m_flat, splat_all, N, n_tiles_bits(tile_w * tile_h))
+    # everything below is a view or is built on first access: the hot path pays for none of it
+    meta._lazy = {
+        "means2d": lambda: gather(0)[..., 0:2], "conics": lambda: gather(0)[..., 2:5],
+        "depths": lambda: gather(0)[..., 9], "radii": lambda: gather(1), "tiles_per_gauss": lambda: gather(2),
+        "flatten_ids": lambda: torch.cat([(pc[4] & gid_mask) + c * N for c, pc in enumerate(per_cam)]),
+        "isect_offsets": lambda: _isect_offsets(per_cam, tile_h, tile_w),
+        "isect_ids": lambda: _isect_ids(per_cam, N, gid_mask, tile_w * tile_h),
+    }
+    if C == 1:
+        return renders[0][None], alphas[0][None], meta
     return torch.stack(renders), torch.stack(alphas), meta
 
 
-def n_tiles_bits(n_tiles: int) -> int:
-    return max(1, math.ceil(math.log2(max(n_tiles, 2))))
+def _isect_offsets(per_cam, tile_h: int, tile_w: int) -> torch.Tensor:
+    offs, base = [], 0
+    for pc in per_cam:
+        offs.append(pc[5][:-1] + base)
+        base += pc[4].numel()
+    return torch.stack(offs).reshape(len(per_cam), tile_h, tile_w)
+
+
+def _isect_ids(per_cam, n: int, gid_mask: int, n_tiles: int) -> torch.Tensor:
+    """The 64-bit keys of the published layout (camera | tile | depth bits).  The kernels never need them
+    (the sort works on split keys); they are materialised only when asked for."""
+    tile_bits = max(1, math.ceil(math.log2(max(n_tiles, 2))))
+    parts = []
+    for c, pc in enumerate(per_cam):
+        depth_bits = pc[0][:, 9].contiguous().view(torch.int32).long() & 0xFFFFFFFF
+        gid = pc[4].long() & gid_mask
+        parts.append((c << (32 + tile_bits)) | (pc[3].long() << 32) | depth_bits[gid])
+    return torch.cat(parts)
 
 
 class _Meta(dict):
-    """``meta`` dict; the 64-bit ``isect_ids`` of the published layout (camera | tile | depth bits) are
-    not needed by the kernels (the sort works on split keys) and are only materialised when asked for."""
+    """``meta`` dict whose tensor entries are produced on first access (views of the saved buffers, or small
+    derived tensors), so that a caller who reads only ``means2d`` / ``radii`` -- like the reference
+    (gsplat_backend.py:204-208) -- costs the hot path nothing."""
 
-    _lazy_isect = None
+    _lazy = {}
 
     def __missing__(self, key):
-        if key == "isect_ids" and self._lazy_isect is not None:
-            tiles, flats, splat_all, N, tile_bits = self._lazy_isect
-            parts = []
-            for c, (tl, fl) in enumerate(zip(tiles, flats)):
-                depth_bits = splat_all[c, :, 9].contiguous().view(torch.int32).long() & 0xFFFFFFFF
-                gid = fl.long() - c * N
-                parts.append((c << (32 + tile_bits)) | (tl.long() << 32) | depth_bits[gid])
-            val = torch.cat(parts) if parts else torch.empty(0, dtype=torch.int64)
+        if key in self._lazy:
+            val = self._lazy[key]()
             self[key] = val
             return val
         raise KeyError(key)
 
     def __contains__(self, key):
-        return dict.__contains__(self, key) or (key == "isect_ids" and self._lazy_isect is not None)
+        return dict.__contains__(self, key) or key in self._lazy
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def keys(self):
+        return list(dict.keys(self)) + [k for k in self._lazy if not dict.__contains__(self, k)]

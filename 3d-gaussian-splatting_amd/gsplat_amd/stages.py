@@ -13,7 +13,8 @@ import torch
 from ._lib import SPLAT_STRIDE, check, lib
 
 TILE_SIZE = 16
-DEFAULT_CULL_MODE = 0  # 0: published tile rectangle; 1: + exact ellipse-vs-tile test (rasterization docstring)
+GID_BITS = 28          # record value = gaussian index | quadrant mask << 28 (include/gsplat_amd.h)
+DEFAULT_CULL_MODE = 1  # 0: published tile rectangle; 1: + exact ellipse-vs-tile test (rasterization docstring)
 
 
 class StageTimer:
@@ -102,7 +103,8 @@ def sort_pairs(n: int, keys: torch.Tensor, vals: Optional[torch.Tensor], begin_b
 
 def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, cull_mode: int = 0):
     """Depth-order the gaussians, emit their tile records in that order, stable-sort the records by tile.
-    -> sorted_tile [M] i32, sorted_gid [M] i32, tile_offsets [n_tiles+1] i32.  One host read-back (M)."""
+    -> sorted_tile [M] i32, sorted_val [M] i32 (gaussian index | quadrant mask << GID_BITS),
+    tile_offsets [n_tiles+1] i32.  One host read-back (M)."""
     dev, N = splat.device, splat.shape[0]
     tile_w, tile_h = tile_grid(width, height)
     n_tiles = tile_w * tile_h

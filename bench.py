@@ -122,7 +122,7 @@ def main() -> None:
             works = [dist.all_reduce(t.grad, async_op=True) for t in leaves]
             for w in works:
                 w.wait()
-        info["M"] = meta["flatten_ids"].numel()
+        info["M"] = meta["n_isects"]
 
     def fence():
         torch.cuda.synchronize()

@@ -27,7 +27,8 @@
  * Per-gaussian "splat record" (GSA_SPLAT_STRIDE floats = 64 B, one cache-line-sized row per gaussian;
  * written by gsa_project_fwd, gathered by the compositor; the gradient record has the same layout):
  *    [0] mean2d.x  [1] mean2d.y  [2] conic a  [3] conic b  [4] conic c  [5] opacity
- *    [6] r  [7] g  [8] b  [9] depth (camera z)  [10..15] unused (zero)
+ *    [6] r  [7] g  [8] b  [9] depth (camera z)  [10] ln(255 * opacity) (the largest sigma with alpha >= 1/255;
+ *    zero in the gradient record)  [11..15] unused (zero)
  */
 #ifndef GSPLAT_AMD_H
 #define GSPLAT_AMD_H
@@ -43,6 +44,7 @@ extern "C" {
 
 #define GSA_ABI_VERSION 1
 #define GSA_SPLAT_STRIDE 16
+#define GSA_GID_BITS 28 /* a record value = gaussian index | (quadrant mask << 28); n <= 2^28 */
 
 #define GSA_OK 0
 #define GSA_ERR_INVALID_ARGUMENT (-1) /* null pointer, negative extent, unsupported SH degree ...   */
@@ -66,7 +68,8 @@ const char *gsa_error_string(int code);
  *          sh_degree == -1 -> post-activation colours [N,3] used as they are.
  *  viewmat[16] row-major world->camera, intrin[9] row-major K (both on the device).
  *  cull_mode: 0 = tile rectangle of (mean2d +- radius), exactly the published rule;
- *             1 = additionally drop tiles the alpha >= 1/255 ellipse cannot reach (same image).
+ *             1 = additionally drop tiles whose pixel centres the alpha >= 1/255 ellipse cannot reach
+ *                 (same image and gradients, fewer records).
  * Outputs: splat[N,16] (record above; zero rows for culled gaussians), radii[N,2] int32 (0 = culled),
  *          tiles_touched[N] int32, depth_keys[N] uint32 (float bits of depth; 0xFFFFFFFF if culled).
  */
@@ -95,8 +98,11 @@ int gsa_sort_pairs_u32(int n, const uint32_t *keys_in, const uint32_t *vals_in, 
 int gsa_scan_tiles(int n, const int32_t *tiles_touched, const uint32_t *order, uint32_t *offsets,
                    uint32_t *total, void *workspace, size_t workspace_bytes, gsa_stream_t stream);
 
-/* For k in depth order, g = order[k]: write that gaussian's tile ids and its index g at
- * [offsets[k], offsets[k] + tiles_touched[g]).  Must use the cull_mode of gsa_project_fwd. */
+/* For k in depth order, g = order[k]: write that gaussian's tile ids and record values at
+ * [offsets[k], offsets[k] + tiles_touched[g]).  Must use the cull_mode of gsa_project_fwd.
+ * A record value is g | (mask << GSA_GID_BITS): mask bit q is set if the splat's alpha >= 1/255 region can
+ * reach a pixel centre of 8x8 quadrant q (qx = q & 1, qy = q >> 1) of the tile; the compositor skips the
+ * other quadrants (every pixel there fails the per-pixel alpha test anyway). */
 int gsa_tile_emit(int n, const uint32_t *order, const uint32_t *offsets, const float *splat,
                   const int32_t *radii, int width, int height, int cull_mode, uint32_t m_capacity,
                   uint32_t *isect_tile, uint32_t *isect_gid, gsa_stream_t stream);
@@ -107,7 +113,8 @@ int gsa_tile_offsets(uint32_t m, const uint32_t *sorted_tile, int n_tiles, int32
 
 /* ---------------------------------------------------------------------------------------------
  * Stage 3 (row a3.4): front-to-back alpha compositing of RGB (channels == 3) or RGB+depth
- * (channels == 4) per 16x16 tile.  background: [channels] or NULL (= zeros).
+ * (channels == 4) per 16x16 tile.  background: [channels] or NULL (= zeros).  sorted_gid holds the
+ * tile-sorted record values of gsa_tile_emit (index | quadrant mask << GSA_GID_BITS).
  * Outputs: render[H,W,channels], alpha[H,W] = 1 - T, final_T[H,W] = T (saved for the backward: recomputing
  * 1 - alpha would lose the low bits of a small T), last_id[H,W] int32 (index into the sorted list of
  * the last splat blended, -1 if none).

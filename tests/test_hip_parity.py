@@ -161,7 +161,8 @@ def test_projection_and_binning_match_oracle(gsa, deg):
     colors = sc["shs"] if deg is not None else sc["shs"][:, 0, :] * 0.28 + 0.5
     args = (sc["means3D"], sc["rotations"], sc["scales"], sc["opacities"][:, 0], colors)
     with torch.no_grad():
-        r1, a1, m1 = gsa.rasterization(*[t.cuda() for t in args], vm[None].cuda(), K[None].cuda(), W, H, sh_degree=deg)
+        r1, a1, m1 = gsa.rasterization(*[t.cuda() for t in args], vm[None].cuda(), K[None].cuda(), W, H, sh_degree=deg,
+                                       cull_mode=0)  # the published tile rectangle: binning comparable 1:1
         r0, a0, m0 = oracle_rasterization(*args, vm[None], K[None], W, H, sh_degree=deg,
                                           ambiguity_tol=_amb_tol_e2e(W, H))
     rad1, rad0 = m1["radii"].cpu(), m0["radii"]
@@ -212,7 +213,7 @@ def test_stage_composite_fwd_bwd(gsa, W, H, N, cull_mode, with_bg):
         leaves = [sp[:, 0:2].to(dtype).requires_grad_(True), sp[:, 2:5].to(dtype).requires_grad_(True),
                   sp[:, 5].to(dtype).requires_grad_(True), sp[:, 6:9].to(dtype).requires_grad_(True)]
         img, al, amb = orc.composite(*leaves, None if bg is None else bg.to(dtype), W, H, 16,
-                                     sorted_gid.cpu().long(), tile_offsets.cpu().long(),
+                                     sorted_gid.cpu().long() & ((1 << S.GID_BITS) - 1), tile_offsets.cpu().long(),
                                      ambiguity_tol=AMB_TOL_STAGE)
         if keep is None:
             keep = (~amb).float()
@@ -422,4 +423,4 @@ def test_config_c2_100k_1080p_deg3(gsa):
     m1, m0, errs = _compare(sc, scene.make_camera(0, 1), scene.make_intrinsics(W, H), W, H, 3,
                             bg=torch.zeros(3), use_v_alpha=False, checkpoint=True)
     print("C2 (err HIP vs fp64, err fp32-oracle vs fp64):", errs, "M =", m1["flatten_ids"].numel())
-    assert abs(m1["flatten_ids"].numel() - m0["flatten_ids"].numel()) <= 64
+    assert 0 < m1["flatten_ids"].numel() <= m0["flatten_ids"].numel() + 64  # default cull_mode drops unreachable tiles
