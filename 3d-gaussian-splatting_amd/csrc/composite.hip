@@ -12,7 +12,9 @@
 //  * Staging: the wave gathers 64 sorted splat records at a time (one 64-B record per lane, one cache line,
 //    served from L2 / Infinity Cache) into its private LDS slice.  Each sorted record value carries, above
 //    the gaussian index, the 4-bit mask of the quadrants whose pixel centres the alpha >= 1/255 ellipse can
-//    reach (computed once by gsa_tile_emit: exact ellipse-vs-rectangle test, conservative margin).
+//    reach (exact ellipse-vs-rectangle test, conservative margin).  The forward pass computes it while
+//    staging -- only ~20 % of the binned records are ever visited -- and writes it back into the record
+//    value, where the backward pass finds it.
 //  * Blend loop: every lane reads the same record (LDS broadcast, 3 reads per record for 256 pixels, issued
 //    one record ahead), the mask is moved to an SGPR and the four quadrants are evaluated under scalar
 //    branches -- a quadrant the splat cannot touch, or whose 64 pixels are all finished, costs nothing.
@@ -29,9 +31,16 @@
 // Restates SURVEY.md Appendix A.5 (forward) and A.6 (backward) -- gsplat's rasterize_to_pixels behind
 // /root/reference/src/backends/gsplat_backend.py:168-182.
 
-#include "gsa_common.h"
+#include "project_math.h"
 
 namespace {
+
+#ifndef GSA_FWD_WAVES_PER_SIMD
+#define GSA_FWD_WAVES_PER_SIMD 6  // register budget of the forward compositor (512 / waves VGPRs per lane)
+#endif
+#ifndef GSA_BWD_WAVES_PER_SIMD
+#define GSA_BWD_WAVES_PER_SIMD 5
+#endif
 
 constexpr int kTile = GSA_TILE_SIZE;
 constexpr int kWavesPerBlock = 4;
@@ -61,9 +70,9 @@ __device__ __forceinline__ int wave_tile(int wave, int n_tiles) {
 // forward
 // ------------------------------------------------------------------------------------------------
 template <int CH>
-__global__ __launch_bounds__(kBlock) void composite_fwd_kernel(
-    int width, int height, int tile_w, int n_tiles,
-    const float *__restrict__ splat, const uint32_t *__restrict__ sorted_gid,
+__global__ __launch_bounds__(kBlock, GSA_FWD_WAVES_PER_SIMD) void composite_fwd_kernel(
+    int width, int height, int tile_w, int n_tiles, int fill_masks,
+    const float *__restrict__ splat, uint32_t *__restrict__ sorted_gid,
     const int32_t *__restrict__ tile_offsets, const float *__restrict__ background, float *__restrict__ render,
     float *__restrict__ alpha_out, float *__restrict__ final_T, int32_t *__restrict__ last_id) {
     // conic pre-scaled for exp2:  s = log2(e) * sigma = dx (ha dx + hb dy) + hc dy^2
@@ -102,9 +111,13 @@ __global__ __launch_bounds__(kBlock) void composite_fwd_kernel(
         for (int base = start; base < end && alive != 0; base += kBatch) {
             const int idx = base + lane;
             if (idx < end) {
-                const uint32_t val = sorted_gid[idx];
+                uint32_t val = sorted_gid[idx];
                 const float4 *row = reinterpret_cast<const float4 *>(splat + (size_t)(val & kGidMask) * GSA_SPLAT_STRIDE);
                 float4 r0 = row[0], r1 = row[1], r2 = row[2];
+                if (fill_masks) {  // quadrant mask of this record, kept in the record value for the backward pass
+                    val |= gsa_quadrant_mask(r0.x, r0.y, r0.z, r0.w, r1.x, r2.z, tx, ty) << GSA_GID_BITS;
+                    sorted_gid[idx] = val;
+                }
                 s_q0[w][lane] = make_float4(r0.x, r0.y, 0.5f * kLog2e * r0.z, kLog2e * r0.w);
                 s_q1[w][lane] = make_float4(0.5f * kLog2e * r1.x, r1.y, r1.z, r1.w);
                 s_q2[w][lane] = make_float4(r2.x, r2.y, __uint_as_float(val >> GSA_GID_BITS), 0.f);
@@ -218,7 +231,7 @@ __device__ __forceinline__ float reduce8(const float *f, int lane) {
 }
 
 template <int CH>
-__global__ __launch_bounds__(kBlock) void composite_bwd_kernel(
+__global__ __launch_bounds__(kBlock, GSA_BWD_WAVES_PER_SIMD) void composite_bwd_kernel(
     int width, int height, int tile_w, int n_tiles,
     const float *__restrict__ splat, const uint32_t *__restrict__ sorted_gid,
     const int32_t *__restrict__ tile_offsets, const float *__restrict__ background,
@@ -351,8 +364,8 @@ int tile_grid_blocks(int n_tiles) { return 8 * gsa_div_up(gsa_div_up(n_tiles, kW
 
 }  // namespace
 
-extern "C" int gsa_composite_fwd(int width, int height, int channels, const float *splat,
-                                 const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
+extern "C" int gsa_composite_fwd(int width, int height, int channels, int fill_masks, const float *splat,
+                                 uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
                                  float *render, float *alpha, float *final_T, int32_t *last_id,
                                  gsa_stream_t stream) {
     GSA_RETURN_IF(width <= 0 || height <= 0 || (channels != 3 && channels != 4), GSA_ERR_INVALID_ARGUMENT);
@@ -362,10 +375,10 @@ extern "C" int gsa_composite_fwd(int width, int height, int channels, const floa
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int grid = tile_grid_blocks(n_tiles);
     if (channels == 3)
-        composite_fwd_kernel<3><<<grid, kBlock, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid,
+        composite_fwd_kernel<3><<<grid, kBlock, 0, s>>>(width, height, tile_w, n_tiles, fill_masks, splat, sorted_gid,
                                                        tile_offsets, background, render, alpha, final_T, last_id);
     else
-        composite_fwd_kernel<4><<<grid, kBlock, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid,
+        composite_fwd_kernel<4><<<grid, kBlock, 0, s>>>(width, height, tile_w, n_tiles, fill_masks, splat, sorted_gid,
                                                        tile_offsets, background, render, alpha, final_T, last_id);
     GSA_LAUNCH_CHECK();
     return GSA_OK;

@@ -217,7 +217,9 @@ __global__ __launch_bounds__(kSortThreads) void tile_emit_kernel(
     uint32_t pos = begin;
     for (int ty = tr.y0; ty < tr.y1; ++ty)
         for (int tx = tr.x0; tx < tr.x1; ++tx) {
-            const uint32_t qm = gsa_quadrant_mask(mx, my, a, b, c, sig_max, tx, ty);
+            // cull_mode 1 also decides here which quadrants the splat can reach; cull_mode 0 leaves the
+            // mask bits clear and the forward compositor fills them in for the records it actually visits
+            const uint32_t qm = cull_mode == 0 ? 0u : gsa_quadrant_mask(mx, my, a, b, c, sig_max, tx, ty);
             if ((cull_mode == 0 || qm != 0u) && pos < end) {
                 isect_tile[pos] = (uint32_t)(ty * tile_w + tx);
                 isect_gid[pos] = g | (qm << GSA_GID_BITS);

@@ -26,6 +26,7 @@ def _newer(a: str, b: str) -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     """Compile every HIP source to an object and link ``lib/libgsplat_amd.so``; returns its path."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra = os.environ.get("GSA_EXTRA_HIPCC_FLAGS", "").split()  # developer tuning, e.g. -DGSA_FWD_WAVES_PER_SIMD=6
     os.makedirs(LIB_DIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers += [os.path.join(REPO_ROOT, "include", f) for f in os.listdir(os.path.join(REPO_ROOT, "include"))]
@@ -34,7 +35,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
         if force or _newer(s, o) or any(_newer(h, o) for h in headers):
-            cmd = [hipcc, *FLAGS, "-c", s, "-o", o]
+            cmd = [hipcc, *FLAGS, *extra, "-c", s, "-o", o]
             if verbose:
                 print("[gsplat_amd.build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -36,7 +36,8 @@ class _RasterizeOneCamera(torch.autograd.Function):
                                                                 sh_degree, view_c, K_c, width, height, cull_mode)
         sorted_tile, sorted_gid, tile_offsets = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height,
                                                             cull_mode)
-        render, alpha, final_T, last_id = S.composite_fwd(splat, sorted_gid, tile_offsets, bg_c, width, height, channels)
+        render, alpha, final_T, last_id = S.composite_fwd(splat, sorted_gid, tile_offsets, bg_c, width, height, channels,
+                                                          fill_masks=(cull_mode == 0))
 
         ctx.save_for_backward(means_c, quats_c, scales_c, opac_c, colors_c, view_c, K_c, bg_c, splat, radii,
                               sorted_gid, tile_offsets, final_T, last_id)
@@ -89,7 +90,7 @@ def rasterization(
     """Returns ``(renders [C,H,W,D], alphas [C,H,W,1], meta)``; ``meta['means2d']`` [C,N,2] and
     ``meta['radii']`` [C,N,2] int32 are what the reference reads (gsplat_backend.py:204-208).
 
-    ``cull_mode`` (extension, default ``stages.DEFAULT_CULL_MODE`` = 1): 0 = tile rectangle of mean2d +- radius (the published rule);
+    ``cull_mode`` (extension, default ``stages.DEFAULT_CULL_MODE`` = 0): 0 = tile rectangle of mean2d +- radius (the published rule);
     1 = also skip tiles the alpha >= 1/255 ellipse cannot reach (same image and gradients, fewer records).
     """
     for k, v in unsupported.items():

@@ -226,7 +226,8 @@ def test_stage_composite_fwd_bwd(gsa, W, H, N, cull_mode, with_bg):
     img32, al32, g32, _ = oracle(torch.float32, keep)
 
     bg_d = None if bg is None else bg.cuda()
-    img1, al1, fin_T, last = S.composite_fwd(splat, sorted_gid, tile_offsets, bg_d, W, H, 3)
+    img1, al1, fin_T, last = S.composite_fwd(splat, sorted_gid, tile_offsets, bg_d, W, H, 3,
+                                             fill_masks=(cull_mode == 0))
     v_splat = S.composite_bwd(splat, sorted_gid, tile_offsets, bg_d, fin_T, last, (v_r * keep[..., None]).cuda(),
                               (v_a * keep).cuda().contiguous(), W, H, 3).cpu()
     k3 = keep[..., None]
