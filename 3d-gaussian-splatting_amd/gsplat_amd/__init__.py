@@ -13,12 +13,12 @@ Importing this package loads the HIP library and raises ImportError if it is not
 
 import sys as _sys
 
-from . import scene  # noqa: F401
+from . import harness, scene, stages  # noqa: F401
 from ._lib import ABI_VERSION, LIB_PATH, GsaError, lib  # noqa: F401
 from .backend import HipBackend  # noqa: F401
 from .rasterization import rasterization  # noqa: F401
 
-__all__ = ["rasterization", "HipBackend", "install_as_gsplat", "scene", "lib", "LIB_PATH", "ABI_VERSION"]
+__all__ = ["rasterization", "HipBackend", "install_as_gsplat", "scene", "stages", "harness", "lib", "LIB_PATH", "ABI_VERSION"]
 
 
 def install_as_gsplat() -> None:

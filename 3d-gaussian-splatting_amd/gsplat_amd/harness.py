@@ -1,0 +1,200 @@
+"""Training-step harness around the hot path, single-GPU and view-parallel (SURVEY.md section 8 rows a4 and e).
+
+Counterpart of the reference's per-step logic -- ``GaussianTrainer._training_step``
+(/root/reference/src/training/trainer.py:447-519) with its helpers ``_gaussian_params`` (:399-406),
+``_stclamp`` (:102-107), ``_compute_ssim`` (:354-371), ``_psnr`` (:70-75), ``_scale_ratio_reg`` (:434-445),
+``_setup_optimizer`` (:331-340), ``_update_learning_rate`` (:373-382), ``_active_sh_degree`` (:77-87) -- written
+for one-process-per-GPU execution:
+
+* the six parameter tensors of the scene model (/root/reference/src/gaussians/gaussian_model.py:59-88) are views
+  into ONE flat fp32 buffer of 59*N floats, and their ``.grad`` tensors are views into one flat gradient bucket;
+* with ``world_size`` > 1 the B views of a batch are dealt round-robin to the ranks, every rank renders its own
+  views with the HIP rasterizer, and the gradient bucket is summed with ONE all-reduce (RCCL over xGMI) before
+  an identical Adam step on every rank.  The reference has no multi-GPU code; the contract here
+  is "N-rank result == 1-rank result on the same batch".
+
+The rendering backend is injected (anything with ``render_with_depth``): ``HipBackend`` in production.
+Nothing here imports the CPU oracle.
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+# (name, per-gaussian shape) in the order of the reference's optimizer groups (trainer.py:331-340)
+FIELDS = (("xyz", (3,)), ("features_dc", (1, 3)), ("features_rest", (15, 3)), ("opacity", (1,)),
+          ("scaling", (3,)), ("rotation", (4,)))
+FLOATS_PER_GAUSSIAN = sum(math.prod(s) for _, s in FIELDS)  # 59
+
+
+@dataclass
+class StepConfig:
+    """The subset of the reference's ``TrainingConfig`` that shapes a step
+    (/root/reference/src/gaussians/training_config.py:43-73); same defaults."""
+    lambda_dssim: float = 0.2
+    scale_reg_max_ratio: float = 10.0
+    scale_reg_weight: float = 0.1
+    sh_degree_max: int = 3
+    sh_increment_interval: int = 1000
+    position_lr_init: float = 1.6e-4
+    position_lr_final: float = 1.6e-7
+    position_lr_max_steps: float = 3e5
+
+
+class SplatModel:
+    """Scene parameters with the reference model's names, shapes and activations
+    (gaussian_model.py:59-108), stored as views of one flat buffer (+ one flat gradient bucket)."""
+
+    def __init__(self, n: int, device="cuda"):
+        self.n = int(n)
+        self.flat = torch.zeros(FLOATS_PER_GAUSSIAN * self.n, dtype=torch.float32, device=device)
+        self.flat_grad = torch.zeros_like(self.flat)
+        off = 0
+        for name, shape in FIELDS:
+            cnt = self.n * math.prod(shape)
+            p = self.flat[off:off + cnt].view(self.n, *shape)
+            p.requires_grad_(True)
+            p.grad = self.flat_grad[off:off + cnt].view(self.n, *shape)
+            setattr(self, name, p)
+            off += cnt
+        with torch.no_grad():  # the reference's initial values (gaussian_model.py:66-84)
+            self.scaling.fill_(-3.0)
+            self.rotation[:, 0] = 1.0
+
+    def parameters(self) -> List[torch.Tensor]:
+        return [getattr(self, name) for name, _ in FIELDS]
+
+    @torch.no_grad()
+    def load(self, **tensors: torch.Tensor) -> "SplatModel":
+        for name, value in tensors.items():
+            getattr(self, name).copy_(value.reshape(getattr(self, name).shape))
+        return self
+
+    def activated(self) -> Dict[str, torch.Tensor]:
+        """What the reference hands to the backend (trainer.py:399-406)."""
+        return {
+            "means3D": self.xyz,
+            "scales": torch.exp(self.scaling),
+            "rotations": F.normalize(self.rotation, dim=-1),
+            "opacities": torch.sigmoid(self.opacity),
+            "shs": torch.cat([self.features_dc, self.features_rest], dim=1),
+        }
+
+    def zero_grad(self) -> None:
+        self.flat_grad.zero_()
+
+
+# ---- the reference's per-view loss pieces ------------------------------------------------------------------
+def straight_through_clamp(x: torch.Tensor) -> torch.Tensor:
+    """Forward clamp to [0,1], identity backward (trainer.py:102-107)."""
+    return x + (x.clamp(0.0, 1.0) - x).detach()
+
+
+def ssim_3x3(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """Mean SSIM with a 3x3 box window, zero padding counted in the mean (trainer.py:354-371). [1,3,H,W]."""
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    box = lambda t: F.avg_pool2d(t, 3, 1, padding=1)  # noqa: E731
+    mu_a, mu_b = box(a), box(b)
+    var_a = box(a * a) - mu_a * mu_a
+    var_b = box(b * b) - mu_b * mu_b
+    cov = box(a * b) - mu_a * mu_b
+    num = (2 * mu_a * mu_b + c1) * (2 * cov + c2)
+    den = (mu_a * mu_a + mu_b * mu_b + c1) * (var_a + var_b + c2)
+    return (num / den).mean()
+
+
+def psnr(pred: torch.Tensor, target: torch.Tensor) -> float:
+    """-10 log10(mse); 100 below 1e-10 (trainer.py:70-75)."""
+    mse = float(F.mse_loss(pred, target))
+    return 100.0 if mse < 1e-10 else -10.0 * math.log10(mse)
+
+
+def scale_ratio_reg(scales: torch.Tensor, max_ratio: float, weight: float) -> torch.Tensor:
+    """Hinge on max/min activated scale per gaussian (trainer.py:434-445)."""
+    ratio = scales.amax(dim=-1) / scales.amin(dim=-1).clamp(min=1e-8)
+    return weight * (ratio.clamp(min=max_ratio) - max_ratio).mean()
+
+
+def view_loss(rendered: torch.Tensor, target: torch.Tensor, lambda_dssim: float):
+    """(1 - lambda) L1 + lambda (1 - SSIM) on the straight-through-clamped render (trainer.py:485-492)."""
+    img = straight_through_clamp(rendered)
+    l1 = F.l1_loss(img, target)
+    ssim = ssim_3x3(img.permute(2, 0, 1)[None], target.permute(2, 0, 1)[None])
+    return (1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - ssim), l1, ssim
+
+
+class ViewParallelTrainer:
+    """One optimisation step over a batch of views, sharded by view across ``world_size`` ranks."""
+
+    def __init__(self, model: SplatModel, backend, config: Optional[StepConfig] = None,
+                 process_group=None, rank: int = 0, world_size: int = 1):
+        self.model, self.backend = model, backend
+        self.cfg = config or StepConfig()
+        self.group, self.rank, self.world = process_group, rank, world_size
+        self.iteration = 0
+        c = self.cfg
+        self.optimizer = torch.optim.Adam([  # trainer.py:331-340
+            {"params": [model.xyz], "lr": c.position_lr_init, "name": "xyz"},
+            {"params": [model.features_dc], "lr": 0.0025, "name": "f_dc"},
+            {"params": [model.features_rest], "lr": 0.0025 / 20.0, "name": "f_rest"},
+            {"params": [model.opacity], "lr": 0.05, "name": "opacity"},
+            {"params": [model.scaling], "lr": 0.005, "name": "scaling"},
+            {"params": [model.rotation], "lr": 0.001, "name": "rotation"},
+        ], lr=0.0, eps=1e-15)
+
+    def active_sh_degree(self) -> int:
+        return min(int(self.iteration // self.cfg.sh_increment_interval), int(self.cfg.sh_degree_max))
+
+    def update_learning_rate(self) -> float:
+        c = self.cfg
+        progress = min(self.iteration / c.position_lr_max_steps, 1.0)
+        lr = c.position_lr_init * (c.position_lr_final / c.position_lr_init) ** progress
+        for group in self.optimizer.param_groups:
+            if group.get("name") == "xyz":
+                group["lr"] = lr
+        return lr
+
+    def _all_reduce(self, t: torch.Tensor) -> None:
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def training_step(self, batch: Sequence[Dict]) -> Dict[str, float]:
+        """``batch``: B dicts {image [H,W,3], pose [4,4] world->camera, width, height} -- the SAME list on every
+        rank (trainer.py:270-281).  Rank r renders views r, r + world, ...; the summed gradient equals the
+        single-process one: each view's loss is divided by B, the scale regulariser is added on rank 0 only."""
+        m, c = self.model, self.cfg
+        m.zero_grad()
+        params = m.activated()
+        degree = self.active_sh_degree()
+        dev = m.flat.device
+        n_views = len(batch)
+        total = torch.zeros((), device=dev)
+        stats = torch.zeros(3, device=dev, dtype=torch.float64)  # l1, ssim, psnr sums over the local views
+        for view in batch[self.rank::self.world]:
+            viewpoint = {"world_view_transform": view["pose"], "image_width": view["width"],
+                         "image_height": view["height"]}
+            out = self.backend.render_with_depth(params, viewpoint, bg_color=torch.zeros(3, device=dev),
+                                                 render_mode="RGB", device=str(dev), sh_degree=degree)
+            rendered, target = out["render"], view["image"]
+            loss, l1, ssim = view_loss(rendered, target, c.lambda_dssim)
+            total = total + loss
+            stats += torch.tensor([float(l1.detach()), float(ssim.detach()), psnr(rendered.detach().clamp(0, 1), target)],
+                                  dtype=torch.float64, device=dev)
+        total = total / n_views
+        reg = scale_ratio_reg(params["scales"], c.scale_reg_max_ratio, c.scale_reg_weight)
+        if self.rank == 0:
+            total = total + reg
+        total.backward()
+        self._all_reduce(m.flat_grad)  # the one exchange step: 59*N floats, SUM
+        self.optimizer.step()
+
+        report = torch.cat([stats, total.detach().double()[None]])
+        self._all_reduce(report)
+        return {"loss": float(report[3]), "l1": float(report[0]) / n_views, "ssim": float(report[1]) / n_views,
+                "psnr": float(report[2]) / n_views, "scale_reg": float(reg.detach())}
