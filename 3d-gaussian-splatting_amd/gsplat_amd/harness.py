@@ -124,7 +124,10 @@ def view_loss(rendered: torch.Tensor, target: torch.Tensor, lambda_dssim: float)
     """(1 - lambda) L1 + lambda (1 - SSIM) on the straight-through-clamped render (trainer.py:485-492)."""
     img = straight_through_clamp(rendered)
     l1 = F.l1_loss(img, target)
-    ssim = ssim_3x3(img.permute(2, 0, 1)[None], target.permute(2, 0, 1)[None])
+    # .contiguous(): PyTorch 2.10+rocm7.0 returns a WRONG avg_pool2d gradient on the GPU for the permuted
+    # (channels-last-strided) [1,3,H,W] view that trainer.py:487-490 builds (measured on MI355X: SSIM gradient
+    # off by more than its own magnitude; exact once the view is made contiguous).  Same values either way.
+    ssim = ssim_3x3(img.permute(2, 0, 1)[None].contiguous(), target.permute(2, 0, 1)[None].contiguous())
     return (1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - ssim), l1, ssim
 
 

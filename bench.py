@@ -102,8 +102,23 @@ def main() -> None:
 
     n, width, height, deg = WORKLOADS[args.workload]
     sc = scene.make_scene(n, seed=0, sh_degree=deg, device="cpu")
-    names = ("means3D", "rotations", "scales", "opacities", "shs")
-    leaves = [sc[k].to(dev).requires_grad_(True) for k in names]
+    # the five rasterizer inputs (59 floats per gaussian) are views of one flat buffer and their gradients are
+    # views of one flat bucket, so the view-parallel exchange is ONE all-reduce of 59*N floats (harness.SplatModel
+    # lays the six raw parameter tensors out the same way)
+    shapes = (("means3D", (n, 3)), ("rotations", (n, 4)), ("scales", (n, 3)), ("opacities", (n, 1)), ("shs", (n, 16, 3)))
+    flat = torch.empty(59 * n, dtype=torch.float32, device=dev)
+    flat_grad = torch.zeros_like(flat)
+    leaves, off = [], 0
+    for name, shape in shapes:
+        cnt = 1
+        for d in shape:
+            cnt *= d
+        leaf = flat[off:off + cnt].view(shape)
+        leaf.copy_(sc[name].to(dev))
+        leaf.requires_grad_(True)
+        leaf.grad = flat_grad[off:off + cnt].view(shape)
+        leaves.append(leaf)
+        off += cnt
     opac = leaves[3]
     K = scene.make_intrinsics(width, height).to(dev)[None]
     # weak scaling: rank r renders view r of a ring of `world` cameras (view 0 = the single-GPU view)
@@ -113,15 +128,12 @@ def main() -> None:
     info = {}
 
     def step():
-        for t in leaves:
-            t.grad = None
+        flat_grad.zero_()
         r, a, meta = gsplat_amd.rasterization(leaves[0], leaves[1], leaves[2], opac[:, 0], leaves[4], vm, K, width,
                                               height, sh_degree=deg, backgrounds=bg, cull_mode=args.cull_mode)
         r.backward(v_render)
         if dist is not None:  # view-parallel exchange: sum the gaussian gradients over ranks (RCCL over xGMI)
-            works = [dist.all_reduce(t.grad, async_op=True) for t in leaves]
-            for w in works:
-                w.wait()
+            dist.all_reduce(flat_grad)
         info["M"] = meta["n_isects"]
 
     def fence():
