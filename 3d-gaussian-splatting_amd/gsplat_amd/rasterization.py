@@ -26,7 +26,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, colors, viewmat, Kmat, background,
-                width: int, height: int, sh_degree: int, channels: int, cull_mode: int):
+                width: int, height: int, sh_degree: int, channels: int, cull_mode: int, grad_out):
         means_c, quats_c, scales_c = S.f32c(means, "means"), S.f32c(quats, "quats"), S.f32c(scales, "scales")
         opac_c, colors_c = S.f32c(opacities, "opacities"), S.f32c(colors, "colors")
         view_c, K_c = S.f32c(viewmat, "viewmats"), S.f32c(Kmat, "Ks")
@@ -42,6 +42,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
         ctx.save_for_backward(means_c, quats_c, scales_c, opac_c, colors_c, view_c, K_c, bg_c, splat, radii,
                               sorted_gid, tile_offsets, final_T, last_id)
         ctx.dims = (width, height, sh_degree, channels)
+        ctx.grad_out = grad_out
         ctx.in_shapes = (means.shape, quats.shape, scales.shape, opacities.shape, colors.shape)
         extras = (splat, radii, tiles_touched, sorted_tile, sorted_gid, tile_offsets, last_id)
         ctx.mark_non_differentiable(*extras)
@@ -59,10 +60,10 @@ class _RasterizeOneCamera(torch.autograd.Function):
         v_splat = S.composite_bwd(splat, sorted_gid, tile_offsets, bg_c, final_T, last_id, v_render, v_alpha_c,
                                   width, height, channels)
         grads = S.project_bwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
-                              splat, radii, v_splat)
+                              splat, radii, v_splat, out=ctx.grad_out)
         need = ctx.needs_input_grad
         grads = tuple(g.view(shp) if nd else None for g, shp, nd in zip(grads, ctx.in_shapes, need[:5]))
-        return grads + (None,) * 8
+        return grads + (None,) * 9
 
 
 def rasterization(
@@ -85,6 +86,7 @@ def rasterization(
     backgrounds: Optional[torch.Tensor] = None,
     render_mode: str = "RGB",
     cull_mode: Optional[int] = None,
+    grad_out=None,
     **unsupported,
 ) -> Tuple[torch.Tensor, torch.Tensor, Dict]:
     """Returns ``(renders [C,H,W,D], alphas [C,H,W,1], meta)``; ``meta['means2d']`` [C,N,2] and
@@ -92,6 +94,9 @@ def rasterization(
 
     ``cull_mode`` (extension, default ``stages.DEFAULT_CULL_MODE`` = 0): 0 = tile rectangle of mean2d +- radius (the published rule);
     1 = also skip tiles the alpha >= 1/255 ellipse cannot reach (same image and gradients, fewer records).
+    ``grad_out`` (extension, single camera): five preallocated tensors (means, quats, scales, opacities, colors
+    order) the backward pass writes its gradients into and hands to autograd -- e.g. views of one flat bucket
+    that is then all-reduced in one call.
     """
     for k, v in unsupported.items():
         ok = (k in ("sparse_grad", "absgrad", "distributed") and not v) or \
@@ -125,6 +130,8 @@ def rasterization(
             raise ValueError("colors must be [N,K,3] with K >= (sh_degree+1)^2")
     if backgrounds is not None and backgrounds.shape != (C, 3):
         raise ValueError("backgrounds must be [C,3]")
+    if grad_out is not None and C != 1:
+        raise ValueError("grad_out needs a single camera (each camera's backward would overwrite it)")
     width, height = int(width), int(height)
     cull = S.DEFAULT_CULL_MODE if cull_mode is None else int(cull_mode)
     want_depth = render_mode != "RGB"
@@ -138,7 +145,7 @@ def rasterization(
             if want_depth:
                 bg = torch.cat([bg, bg.new_zeros(1)])
         out = _RasterizeOneCamera.apply(means, quats, scales, opacities, colors, viewmats[c], Ks[c], bg,
-                                        width, height, deg, channels, cull)
+                                        width, height, deg, channels, cull, grad_out)
         render, alpha = out[0], out[1]
         if render_mode in ("ED", "RGB+ED"):
             render = torch.cat([render[..., :3], render[..., 3:] / alpha.clamp(min=1e-10)], dim=-1)

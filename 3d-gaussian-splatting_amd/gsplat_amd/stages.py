@@ -158,12 +158,20 @@ def composite_bwd(splat, sorted_gid, tile_offsets, background, final_T, last_id,
 
 
 def project_bwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat, Kmat, width: int, height: int,
-                splat, radii, v_splat):
-    """-> v_means, v_quats, v_scales, v_opacities, v_colors (every element written)."""
+                splat, radii, v_splat, out=None):
+    """-> v_means, v_quats, v_scales, v_opacities, v_colors (every element written).  ``out``: five preallocated
+    contiguous fp32 tensors to write into instead (e.g. views of one flat all-reduce bucket)."""
     N = means.shape[0]
     sh_coeffs = colors.shape[1] if sh_degree >= 0 else 0
-    v_means, v_quats, v_scales = torch.empty_like(means), torch.empty_like(quats), torch.empty_like(scales)
-    v_opac, v_colors = torch.empty_like(opacities), torch.empty_like(colors)
+    if out is None:
+        v_means, v_quats, v_scales = torch.empty_like(means), torch.empty_like(quats), torch.empty_like(scales)
+        v_opac, v_colors = torch.empty_like(opacities), torch.empty_like(colors)
+    else:
+        v_means, v_quats, v_scales, v_opac, v_colors = out
+        for got, like in zip(out, (means, quats, scales, opacities, colors)):
+            if got.numel() != like.numel() or got.dtype != torch.float32 or not got.is_contiguous() \
+                    or got.device != like.device:
+                raise ValueError("grad_out tensors must be contiguous fp32, sized like the inputs, on their device")
     _call("gsa_project_bwd", lib.gsa_project_bwd, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), _ptr(colors), sh_degree,
                               sh_coeffs, _ptr(viewmat), _ptr(Kmat), width, height, _ptr(splat), _ptr(radii),
                               _ptr(v_splat), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac),

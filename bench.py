@@ -108,7 +108,7 @@ def main() -> None:
     shapes = (("means3D", (n, 3)), ("rotations", (n, 4)), ("scales", (n, 3)), ("opacities", (n, 1)), ("shs", (n, 16, 3)))
     flat = torch.empty(59 * n, dtype=torch.float32, device=dev)
     flat_grad = torch.zeros_like(flat)
-    leaves, off = [], 0
+    leaves, grad_views, off = [], [], 0
     for name, shape in shapes:
         cnt = 1
         for d in shape:
@@ -116,8 +116,8 @@ def main() -> None:
         leaf = flat[off:off + cnt].view(shape)
         leaf.copy_(sc[name].to(dev))
         leaf.requires_grad_(True)
-        leaf.grad = flat_grad[off:off + cnt].view(shape)
         leaves.append(leaf)
+        grad_views.append(flat_grad[off:off + cnt].view(shape if name != "opacities" else (n,)))
         off += cnt
     opac = leaves[3]
     K = scene.make_intrinsics(width, height).to(dev)[None]
@@ -128,9 +128,12 @@ def main() -> None:
     info = {}
 
     def step():
-        flat_grad.zero_()
+        for t in leaves:
+            t.grad = None
+        # the backward pass writes every gradient element straight into the bucket (no zero-fill, no copy)
         r, a, meta = gsplat_amd.rasterization(leaves[0], leaves[1], leaves[2], opac[:, 0], leaves[4], vm, K, width,
-                                              height, sh_degree=deg, backgrounds=bg, cull_mode=args.cull_mode)
+                                              height, sh_degree=deg, backgrounds=bg, cull_mode=args.cull_mode,
+                                              grad_out=grad_views)
         r.backward(v_render)
         if dist is not None:  # view-parallel exchange: sum the gaussian gradients over ranks (RCCL over xGMI)
             dist.all_reduce(flat_grad)

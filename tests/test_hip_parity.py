@@ -425,3 +425,35 @@ def test_config_c2_100k_1080p_deg3(gsa):
                             bg=torch.zeros(3), use_v_alpha=False, checkpoint=True)
     print("C2 (err HIP vs fp64, err fp32-oracle vs fp64):", errs, "M =", m1["flatten_ids"].numel())
     assert 0 < m1["flatten_ids"].numel() <= m0["flatten_ids"].numel() + 64  # default cull_mode drops unreachable tiles
+
+
+def test_grad_out_writes_into_caller_bucket(gsa):
+    """``grad_out``: the backward pass writes straight into caller-provided buffers (one flat all-reduce bucket)
+    and autograd hands out those very tensors; values equal the default path up to float-atomic ordering."""
+    from gsplat_amd import scene
+    W, H, n = 160, 96, 3000
+    sc = {k: v.cuda() for k, v in _scene(n, seed=0).items()}
+    K, vm = scene.make_intrinsics(W, H).cuda()[None], scene.make_camera(1, 8).cuda()[None]
+
+    def run(bucket):
+        leaves = [sc[k].clone().requires_grad_(True) for k in NAMES]
+        outs = None
+        if bucket is not None:
+            outs, off = [], 0
+            for t in leaves:
+                shape = t.shape if t.shape != (n, 1) else (n,)
+                outs.append(bucket[off:off + t.numel()].view(shape))
+                off += t.numel()
+        r, a, _ = gsa.rasterization(leaves[0], leaves[1], leaves[2], leaves[3][:, 0], leaves[4], vm, K, W, H,
+                                    sh_degree=3, grad_out=outs)
+        (r * torch.linspace(0.5, 1.5, 3, device="cuda")).sum().backward()
+        return [t.grad for t in leaves]
+
+    bucket = torch.full((59 * n,), float("nan"), device="cuda")
+    g0, g1 = run(None), run(bucket)
+    assert g1[0].data_ptr() == bucket.data_ptr() and not torch.isnan(bucket).any()  # every element written
+    for a, b in zip(g0, g1):
+        assert _rel(b.reshape(-1), a.reshape(-1)) < 1e-5
+    with pytest.raises(ValueError):
+        gsa.rasterization(*[sc[k] if k != "opacities" else sc[k][:, 0] for k in NAMES], vm.repeat(2, 1, 1),
+                          K.repeat(2, 1, 1), W, H, sh_degree=3, grad_out=[bucket] * 5)
