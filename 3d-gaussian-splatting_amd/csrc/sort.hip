@@ -217,12 +217,10 @@ __global__ __launch_bounds__(kSortThreads) void tile_emit_kernel(
     uint32_t pos = begin;
     for (int ty = tr.y0; ty < tr.y1; ++ty)
         for (int tx = tr.x0; tx < tr.x1; ++tx) {
-            // cull_mode 1 also decides here which quadrants the splat can reach; cull_mode 0 leaves the
-            // mask bits clear and the forward compositor fills them in for the records it actually visits
-            const uint32_t qm = cull_mode == 0 ? 0u : gsa_quadrant_mask(mx, my, a, b, c, sig_max, tx, ty);
-            if ((cull_mode == 0 || qm != 0u) && pos < end) {
+            const bool hit = cull_mode == 0 || gsa_quadrant_mask(mx, my, a, b, c, sig_max, tx, ty) != 0u;
+            if (hit && pos < end) {
                 isect_tile[pos] = (uint32_t)(ty * tile_w + tx);
-                isect_gid[pos] = g | (qm << GSA_GID_BITS);
+                isect_gid[pos] = g;
                 ++pos;
             }
         }
@@ -316,7 +314,6 @@ extern "C" int gsa_tile_emit(int n, const uint32_t *order, const uint32_t *offse
     GSA_RETURN_IF(cull_mode != 0 && cull_mode != 1, GSA_ERR_INVALID_ARGUMENT);
     if (n == 0 || m_capacity == 0) return GSA_OK;
     GSA_RETURN_IF(!order || !offsets || !splat || !radii || !isect_tile || !isect_gid, GSA_ERR_INVALID_ARGUMENT);
-    GSA_RETURN_IF(n > (1 << GSA_GID_BITS), GSA_ERR_UNSUPPORTED);
     int tile_w = gsa_div_up(width, GSA_TILE_SIZE), tile_h = gsa_div_up(height, GSA_TILE_SIZE);
     tile_emit_kernel<<<gsa_div_up(n, kSortThreads), kSortThreads, 0, static_cast<hipStream_t>(stream)>>>(
         n, order, offsets, splat, radii, tile_w, tile_h, tile_w * tile_h, cull_mode, m_capacity, isect_tile, isect_gid);

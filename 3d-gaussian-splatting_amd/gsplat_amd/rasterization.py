@@ -36,8 +36,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
                                                                 sh_degree, view_c, K_c, width, height, cull_mode)
         sorted_tile, sorted_gid, tile_offsets = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height,
                                                             cull_mode)
-        render, alpha, final_T, last_id = S.composite_fwd(splat, sorted_gid, tile_offsets, bg_c, width, height, channels,
-                                                          fill_masks=(cull_mode == 0))
+        render, alpha, final_T, last_id = S.composite_fwd(splat, sorted_gid, tile_offsets, bg_c, width, height, channels)
 
         ctx.save_for_backward(means_c, quats_c, scales_c, opac_c, colors_c, view_c, K_c, bg_c, splat, radii,
                               sorted_gid, tile_offsets, final_T, last_id)
@@ -153,13 +152,12 @@ def rasterization(
             render = render[..., 3:]
         renders.append(render)
         alphas.append(alpha)
-        per_cam.append(out[2:])  # splat, radii, tiles_touched, sorted_tile, sorted_val, tile_offsets, last_id
+        per_cam.append(out[2:])  # splat, radii, tiles_touched, sorted_tile, sorted_gid, tile_offsets, last_id
 
     def gather(i):  # [C, ...] without a copy for the single-camera call the reference makes
         return per_cam[0][i][None] if C == 1 else torch.stack([pc[i] for pc in per_cam])
 
     tile_w, tile_h = S.tile_grid(width, height)
-    gid_mask = (1 << S.GID_BITS) - 1
     meta = _Meta({
         "camera_ids": None, "gaussian_ids": None, "opacities": opacities[None].expand(C, N),
         "tile_width": tile_w, "tile_height": tile_h, "tile_size": TILE_SIZE,
@@ -170,9 +168,9 @@ def rasterization(
     meta._lazy = {
         "means2d": lambda: gather(0)[..., 0:2], "conics": lambda: gather(0)[..., 2:5],
         "depths": lambda: gather(0)[..., 9], "radii": lambda: gather(1), "tiles_per_gauss": lambda: gather(2),
-        "flatten_ids": lambda: torch.cat([(pc[4] & gid_mask) + c * N for c, pc in enumerate(per_cam)]),
+        "flatten_ids": lambda: torch.cat([pc[4] + c * N for c, pc in enumerate(per_cam)]),
         "isect_offsets": lambda: _isect_offsets(per_cam, tile_h, tile_w),
-        "isect_ids": lambda: _isect_ids(per_cam, N, gid_mask, tile_w * tile_h),
+        "isect_ids": lambda: _isect_ids(per_cam, tile_w * tile_h),
     }
     if C == 1:
         return renders[0][None], alphas[0][None], meta
@@ -187,14 +185,14 @@ def _isect_offsets(per_cam, tile_h: int, tile_w: int) -> torch.Tensor:
     return torch.stack(offs).reshape(len(per_cam), tile_h, tile_w)
 
 
-def _isect_ids(per_cam, n: int, gid_mask: int, n_tiles: int) -> torch.Tensor:
+def _isect_ids(per_cam, n_tiles: int) -> torch.Tensor:
     """The 64-bit keys of the published layout (camera | tile | depth bits).  The kernels never need them
     (the sort works on split keys); they are materialised only when asked for."""
     tile_bits = max(1, math.ceil(math.log2(max(n_tiles, 2))))
     parts = []
     for c, pc in enumerate(per_cam):
         depth_bits = pc[0][:, 9].contiguous().view(torch.int32).long() & 0xFFFFFFFF
-        gid = pc[4].long() & gid_mask
+        gid = pc[4].long()
         parts.append((c << (32 + tile_bits)) | (pc[3].long() << 32) | depth_bits[gid])
     return torch.cat(parts)
 

@@ -13,7 +13,6 @@ import torch
 from ._lib import SPLAT_STRIDE, check, lib
 
 TILE_SIZE = 16
-GID_BITS = 28          # record value = gaussian index | quadrant mask << 28 (include/gsplat_amd.h)
 DEFAULT_CULL_MODE = 0  # 0: published tile rectangle; 1: + exact ellipse-vs-tile test (rasterization docstring)
 
 
@@ -103,8 +102,7 @@ def sort_pairs(n: int, keys: torch.Tensor, vals: Optional[torch.Tensor], begin_b
 
 def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, cull_mode: int = 0):
     """Depth-order the gaussians, emit their tile records in that order, stable-sort the records by tile.
-    -> sorted_tile [M] i32, sorted_val [M] i32 (gaussian index | quadrant mask << GID_BITS),
-    tile_offsets [n_tiles+1] i32.  One host read-back (M)."""
+    -> sorted_tile [M] i32, sorted_gid [M] i32, tile_offsets [n_tiles+1] i32.  One host read-back (M)."""
     dev, N = splat.device, splat.shape[0]
     tile_w, tile_h = tile_grid(width, height)
     n_tiles = tile_w * tile_h
@@ -131,17 +129,14 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
     return sorted_tile, sorted_gid, tile_offsets
 
 
-def composite_fwd(splat, sorted_gid, tile_offsets, background, width: int, height: int, channels: int,
-                  fill_masks: bool = True):
-    """``fill_masks``: the records come from ``bin_tiles(cull_mode=0)`` and still lack their quadrant masks; the
-    pass computes them for the records it visits and ORs them into ``sorted_gid`` IN PLACE.
-    -> render [H,W,channels], alpha [H,W,1], final_T [H,W], last_id [H,W] i32."""
+def composite_fwd(splat, sorted_gid, tile_offsets, background, width: int, height: int, channels: int):
+    """-> render [H,W,channels], alpha [H,W,1], final_T [H,W], last_id [H,W] i32."""
     dev = splat.device
     render = torch.empty(height, width, channels, dtype=torch.float32, device=dev)
     alpha = torch.empty(height, width, 1, dtype=torch.float32, device=dev)
     final_T = torch.empty(height, width, dtype=torch.float32, device=dev)
     last_id = torch.empty(height, width, dtype=torch.int32, device=dev)
-    _call("gsa_composite_fwd", lib.gsa_composite_fwd, width, height, channels, int(fill_masks), _ptr(splat), _ptr(sorted_gid), _ptr(tile_offsets),
+    _call("gsa_composite_fwd", lib.gsa_composite_fwd, width, height, channels, _ptr(splat), _ptr(sorted_gid), _ptr(tile_offsets),
                                 _ptr(background), _ptr(render), _ptr(alpha), _ptr(final_T), _ptr(last_id),
                                 _stream())
     return render, alpha, final_T, last_id

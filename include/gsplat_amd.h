@@ -44,7 +44,6 @@ extern "C" {
 
 #define GSA_ABI_VERSION 1
 #define GSA_SPLAT_STRIDE 16
-#define GSA_GID_BITS 28 /* a record value = gaussian index | (quadrant mask << 28); n <= 2^28 */
 
 #define GSA_OK 0
 #define GSA_ERR_INVALID_ARGUMENT (-1) /* null pointer, negative extent, unsupported SH degree ...   */
@@ -98,12 +97,8 @@ int gsa_sort_pairs_u32(int n, const uint32_t *keys_in, const uint32_t *vals_in, 
 int gsa_scan_tiles(int n, const int32_t *tiles_touched, const uint32_t *order, uint32_t *offsets,
                    uint32_t *total, void *workspace, size_t workspace_bytes, gsa_stream_t stream);
 
-/* For k in depth order, g = order[k]: write that gaussian's tile ids and record values at
- * [offsets[k], offsets[k] + tiles_touched[g]).  Must use the cull_mode of gsa_project_fwd.
- * A record value is g | (mask << GSA_GID_BITS): mask bit q is set if the splat's alpha >= 1/255 region can
- * reach a pixel centre of 8x8 quadrant q (qx = q & 1, qy = q >> 1) of the tile; the compositor skips the
- * other quadrants (every pixel there fails the per-pixel alpha test anyway).  cull_mode 1 fills the mask
- * here (it needs it to drop unreachable tiles); cull_mode 0 leaves it clear for gsa_composite_fwd. */
+/* For k in depth order, g = order[k]: write that gaussian's tile ids and its index g at
+ * [offsets[k], offsets[k] + tiles_touched[g]).  Must use the cull_mode of gsa_project_fwd. */
 int gsa_tile_emit(int n, const uint32_t *order, const uint32_t *offsets, const float *splat,
                   const int32_t *radii, int width, int height, int cull_mode, uint32_t m_capacity,
                   uint32_t *isect_tile, uint32_t *isect_gid, gsa_stream_t stream);
@@ -114,16 +109,13 @@ int gsa_tile_offsets(uint32_t m, const uint32_t *sorted_tile, int n_tiles, int32
 
 /* ---------------------------------------------------------------------------------------------
  * Stage 3 (row a3.4): front-to-back alpha compositing of RGB (channels == 3) or RGB+depth
- * (channels == 4) per 16x16 tile.  background: [channels] or NULL (= zeros).  sorted_gid holds the
- * tile-sorted record values of gsa_tile_emit (index | quadrant mask << GSA_GID_BITS).  fill_masks != 0
- * (records emitted with cull_mode 0, mask bits clear): the quadrant mask of every record the pass visits
- * is computed here and OR-ed into sorted_gid in place, for gsa_composite_bwd to use.
+ * (channels == 4) per 16x16 tile.  background: [channels] or NULL (= zeros).
  * Outputs: render[H,W,channels], alpha[H,W] = 1 - T, final_T[H,W] = T (saved for the backward: recomputing
  * 1 - alpha would lose the low bits of a small T), last_id[H,W] int32 (index into the sorted list of
  * the last splat blended, -1 if none).
  */
-int gsa_composite_fwd(int width, int height, int channels, int fill_masks, const float *splat,
-                      uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
+int gsa_composite_fwd(int width, int height, int channels, const float *splat,
+                      const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
                       float *render, float *alpha, float *final_T, int32_t *last_id, gsa_stream_t stream);
 
 /* Stage 4 (row a3.5): reverse-order gradient sweep.  v_splat[N,16] must be zero on entry and

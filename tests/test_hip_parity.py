@@ -213,7 +213,7 @@ def test_stage_composite_fwd_bwd(gsa, W, H, N, cull_mode, with_bg):
         leaves = [sp[:, 0:2].to(dtype).requires_grad_(True), sp[:, 2:5].to(dtype).requires_grad_(True),
                   sp[:, 5].to(dtype).requires_grad_(True), sp[:, 6:9].to(dtype).requires_grad_(True)]
         img, al, amb = orc.composite(*leaves, None if bg is None else bg.to(dtype), W, H, 16,
-                                     sorted_gid.cpu().long() & ((1 << S.GID_BITS) - 1), tile_offsets.cpu().long(),
+                                     sorted_gid.cpu().long(), tile_offsets.cpu().long(),
                                      ambiguity_tol=AMB_TOL_STAGE)
         if keep is None:
             keep = (~amb).float()
@@ -226,8 +226,7 @@ def test_stage_composite_fwd_bwd(gsa, W, H, N, cull_mode, with_bg):
     img32, al32, g32, _ = oracle(torch.float32, keep)
 
     bg_d = None if bg is None else bg.cuda()
-    img1, al1, fin_T, last = S.composite_fwd(splat, sorted_gid, tile_offsets, bg_d, W, H, 3,
-                                             fill_masks=(cull_mode == 0))
+    img1, al1, fin_T, last = S.composite_fwd(splat, sorted_gid, tile_offsets, bg_d, W, H, 3)
     v_splat = S.composite_bwd(splat, sorted_gid, tile_offsets, bg_d, fin_T, last, (v_r * keep[..., None]).cuda(),
                               (v_a * keep).cuda().contiguous(), W, H, 3).cpu()
     k3 = keep[..., None]
