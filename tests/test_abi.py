@@ -59,3 +59,38 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(d, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="reference tree only exists in the authoring container")
+def test_reference_backend_binds_to_this_package_by_module_name():
+    """INTEGRATION.md level 1: with ``install_as_gsplat()`` the reference's own ``GSplatBackend``
+    (src/backends/gsplat_backend.py:4,9) picks up this package's ``rasterization`` -- and a CPU call fails loudly
+    instead of falling back."""
+    import sys
+
+    import torch
+
+    import gsplat_amd
+
+    saved = {k: sys.modules.get(k) for k in ("gsplat", "src", "src.backends", "src.backends.gsplat_backend")}
+    sys.path.insert(0, "/root/reference")
+    try:
+        gsplat_amd.install_as_gsplat()
+        for k in ("src", "src.backends", "src.backends.gsplat_backend"):
+            sys.modules.pop(k, None)
+        from src.backends.gsplat_backend import GSplatBackend
+
+        be = GSplatBackend(torch.eye(3))
+        assert be.rasterization is gsplat_amd.rasterization
+        params = {"means3D": torch.zeros(4, 3), "scales": torch.ones(4, 3), "rotations": torch.ones(4, 4),
+                  "opacities": torch.ones(4, 1), "shs": torch.zeros(4, 16, 3)}
+        vp = {"world_view_transform": torch.eye(4), "image_width": 32, "image_height": 32}
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            be.render_with_depth(params, vp, bg_color=torch.zeros(3), render_mode="RGB", device="cpu", sh_degree=0)
+    finally:
+        sys.path.remove("/root/reference")
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
