@@ -45,6 +45,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
         ctx.in_shapes = (means.shape, quats.shape, scales.shape, opacities.shape, colors.shape)
         extras = (splat, radii, tiles_touched, sorted_tile, sorted_gid, tile_offsets, last_id)
         ctx.mark_non_differentiable(*extras)
+        ctx.set_materialize_grads(False)  # no zero tensors for the seven outputs nobody differentiates
         return (render, alpha) + extras
 
     @staticmethod

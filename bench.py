@@ -185,6 +185,13 @@ def main() -> None:
         dominant = max((k for k in per if k in alg), key=lambda k: per[k])
         ach = alg[dominant] / (per[dominant] * 1e-3) / 1e9
         total_bytes = sum(alg.values())
+        traffic = None  # measured HBM bytes per launch of the dominant kernel (separate rocprofv3 --pmc passes)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+                if args.workload == "C3":
+                    traffic = json.load(fh)["kernels"][dominant]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
         line = {
             "metric": "Mpix/s fwd+bwd @1M gaussians/1080p", "value": round(value, 3), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -194,7 +201,7 @@ def main() -> None:
                                    + (", RCCL all-reduce of 59N-float grads" if world > 1 else ""),
                        "intersections_M": m, "cull_mode": stages.DEFAULT_CULL_MODE if args.cull_mode is None else args.cull_mode},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg[dominant], "avg_launch_ms": round(per[dominant], 4)},
             "roofline_whole_step": {"algorithmic_bytes": total_bytes,
                                     "achieved_GBs": round(total_bytes / (ms_per_step * 1e-3) / 1e9, 2),
