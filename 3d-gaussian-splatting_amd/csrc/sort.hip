@@ -80,24 +80,38 @@ __global__ __launch_bounds__(kSortThreads) void radix_scan_rows_kernel(int nbloc
 }
 
 // ---- pass 3: stable scatter ---------------------------------------------------------------------
+// Items are first placed in LDS in block-sorted order (stable ballot ranking, 256 items per round), then written
+// out: consecutive threads then write consecutive addresses inside each digit's run, so HBM sees 64-B+ runs
+// instead of one 4-B store per 64-B line (the low-digit pass of a tile sort scatters neighbouring records to
+// 256 different buckets).
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     int n, const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int shift, int nblocks,
     const uint32_t *__restrict__ hist, const uint32_t *__restrict__ digit_total) {
     __shared__ uint32_t scratch[4];
-    __shared__ uint32_t running[kRadix];      // next free output slot per digit for this block
+    __shared__ uint32_t gbase[kRadix];        // global slot of this block's first item of digit d
+    __shared__ uint32_t lexcl[kRadix];        // slot of that item in the block-sorted order
+    __shared__ uint32_t running[kRadix];      // next free block-local slot per digit
     __shared__ uint32_t wave_cnt[4][kRadix];  // per round: items of digit d in wave w
-    __shared__ uint32_t wave_off[4][kRadix];  // per round: first output slot for wave w, digit d
+    __shared__ uint32_t wave_off[4][kRadix];  // per round: first block-local slot for wave w, digit d
+    __shared__ uint32_t s_key[kSortChunk], s_val[kSortChunk];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
-    // global base of digit d = exclusive scan of digit totals; + this block's offset inside the digit
-    uint32_t tot, dt = digit_total[t];
-    uint32_t dbase = block_excl_scan(dt, scratch, tot);
-    running[t] = dbase + hist[(long)t * nblocks + blockIdx.x];
+    {   // digit t: global base (exclusive scan of digit totals + offset of this block inside the digit) and
+        // block-local base (exclusive scan of this block's own digit counts, recovered from the scanned rows)
+        uint32_t tot, dt = digit_total[t];
+        const uint32_t mine = hist[(long)t * nblocks + blockIdx.x];
+        const uint32_t next = (int)blockIdx.x + 1 < nblocks ? hist[(long)t * nblocks + blockIdx.x + 1] : dt;
+        const uint32_t dbase = block_excl_scan(dt, scratch, tot);
+        const uint32_t lbase = block_excl_scan(next - mine, scratch, tot);
+        gbase[t] = dbase + mine;
+        lexcl[t] = lbase;
+        running[t] = lbase;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) wave_cnt[w][t] = 0;
+        for (int w = 0; w < 4; ++w) wave_cnt[w][t] = 0;
+    }
 
-    long base = (long)blockIdx.x * kSortChunk;
+    const long base = (long)blockIdx.x * kSortChunk;
     uint32_t k[kSortItems], v[kSortItems];
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
@@ -131,9 +145,22 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
         }
         __syncthreads();
         if (valid) {
-            uint32_t pos = wave_off[wave][d] + rank;
-            keys_out[pos] = k[r];
-            vals_out[pos] = v[r];
+            uint32_t lp = wave_off[wave][d] + rank;
+            s_key[lp] = k[r];
+            s_val[lp] = v[r];
+        }
+    }
+    __syncthreads();
+    const int m = (int)min((long)kSortChunk, (long)n - base);
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        int lp = r * kSortThreads + t;
+        if (lp < m) {
+            uint32_t key = s_key[lp];
+            uint32_t d = (key >> shift) & (kRadix - 1);
+            uint32_t pos = gbase[d] + ((uint32_t)lp - lexcl[d]);
+            keys_out[pos] = key;
+            vals_out[pos] = s_val[lp];
         }
     }
 }
