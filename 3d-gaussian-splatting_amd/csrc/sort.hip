@@ -259,6 +259,58 @@ __global__ __launch_bounds__(kSortThreads) void tile_emit_kernel(
     }
 }
 
+// Wave-cooperative emission for cull_mode 0 (every tile of the rectangle is a record): a wave owns 64
+// depth-consecutive gaussians, whose records are one contiguous output range; its lanes walk that range 64
+// slots at a time -- slot -> gaussian by a 6-step binary search over the 64 start offsets kept in LDS, slot ->
+// tile by the rectangle arithmetic -- so every store instruction writes 256 contiguous bytes.
+__global__ __launch_bounds__(kSortThreads) void tile_emit_coop_kernel(
+    int n, const uint32_t *__restrict__ order, const uint32_t *__restrict__ offsets,
+    const float *__restrict__ splat, const int32_t *__restrict__ radii, int tile_w, int tile_h,
+    uint32_t m_total, uint32_t *__restrict__ isect_tile, uint32_t *__restrict__ isect_gid) {
+    __shared__ uint32_t s_start[4][64 + 1];
+    __shared__ uint32_t s_gid[4][64];
+    __shared__ int s_x0[4][64], s_y0[4][64], s_w[4][64];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long k0 = (long)blockIdx.x * kSortThreads + w * 64;
+    if (k0 >= n) return;
+    const long k = k0 + lane;
+    uint32_t g = 0, begin = m_total;
+    int x0 = 0, y0 = 0, wd = 1;
+    if (k < n) {
+        g = order[k];
+        begin = offsets[k];
+        const int rx = radii[2 * (long)g], ry = radii[2 * (long)g + 1];
+        if (rx > 0 && ry > 0) {
+            const float2 m2 = *reinterpret_cast<const float2 *>(splat + (long)g * GSA_SPLAT_STRIDE);
+            GsaTileRect tr = gsa_tile_rect(m2.x, m2.y, rx, ry, tile_w, tile_h);
+            x0 = tr.x0; y0 = tr.y0; wd = max(tr.x1 - tr.x0, 1);
+        }
+    }
+    const uint32_t wave_base = __builtin_amdgcn_readfirstlane(begin);
+    const long k_end = min((long)n, k0 + 64);
+    const uint32_t wave_end = k_end < n ? offsets[k_end] : m_total;   // uniform address
+    s_start[w][lane] = begin - wave_base;
+    if (lane == 0) s_start[w][64] = 0xFFFFFFFFu;
+    s_gid[w][lane] = g; s_x0[w][lane] = x0; s_y0[w][lane] = y0; s_w[w][lane] = wd;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t total = __builtin_amdgcn_readfirstlane(wave_end) - wave_base;
+    for (uint32_t s = lane; s < total; s += 64) {
+        int l = 0;  // largest l with start[l] <= s (starts are non-decreasing; empty gaussians share a start)
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1)
+            if (s_start[w][l + step] <= s) l += step;
+        const uint32_t j = s - s_start[w][l];
+        const int wl = s_w[w][l];
+        const int row = (int)(((float)j + 0.5f) / (float)wl);  // exact: j, wl < 2^15
+        const int col = (int)j - row * wl;
+        isect_tile[wave_base + s] = (uint32_t)((s_y0[w][l] + row) * tile_w + s_x0[w][l] + col);
+        isect_gid[wave_base + s] = s_gid[w][l];
+    }
+}
+
+// tile_offsets[t] = first index i with sorted_tile[i] >= t,  t in [0, n_tiles]
 // tile_offsets[t] = first index i with sorted_tile[i] >= t,  t in [0, n_tiles]
 __global__ __launch_bounds__(kSortThreads) void tile_offsets_kernel(uint32_t m, const uint32_t *__restrict__ sorted_tile,
                                                                     int n_tiles, int32_t *__restrict__ tile_offsets) {
@@ -267,6 +319,20 @@ __global__ __launch_bounds__(kSortThreads) void tile_offsets_kernel(uint32_t m, 
     long lo = (i == 0) ? 0 : (long)sorted_tile[i - 1] + 1;
     long hi = (i == m) ? n_tiles : min((long)sorted_tile[i], (long)n_tiles);
     for (long t = lo; t <= hi; ++t) tile_offsets[t] = (int32_t)i;
+}
+
+// the same by binary search, one thread per tile: for long lists (M >> n_tiles) 27 dependent loads per tile beat
+// streaming all M keys
+__global__ __launch_bounds__(kSortThreads) void tile_offsets_bsearch_kernel(uint32_t m, const uint32_t *__restrict__ sorted_tile,
+                                                                            int n_tiles, int32_t *__restrict__ tile_offsets) {
+    int t = blockIdx.x * kSortThreads + threadIdx.x;
+    if (t > n_tiles) return;
+    uint32_t lo = 0, hi = m;  // first index with key >= t
+    while (lo < hi) {
+        uint32_t mid = lo + ((hi - lo) >> 1);
+        if (sorted_tile[mid] < (uint32_t)t) lo = mid + 1; else hi = mid;
+    }
+    tile_offsets[t] = (int32_t)lo;
 }
 
 int sort_blocks(int n) { return gsa_div_up(n, kSortChunk); }
@@ -342,8 +408,13 @@ extern "C" int gsa_tile_emit(int n, const uint32_t *order, const uint32_t *offse
     if (n == 0 || m_capacity == 0) return GSA_OK;
     GSA_RETURN_IF(!order || !offsets || !splat || !radii || !isect_tile || !isect_gid, GSA_ERR_INVALID_ARGUMENT);
     int tile_w = gsa_div_up(width, GSA_TILE_SIZE), tile_h = gsa_div_up(height, GSA_TILE_SIZE);
-    tile_emit_kernel<<<gsa_div_up(n, kSortThreads), kSortThreads, 0, static_cast<hipStream_t>(stream)>>>(
-        n, order, offsets, splat, radii, tile_w, tile_h, tile_w * tile_h, cull_mode, m_capacity, isect_tile, isect_gid);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (cull_mode == 0 && tile_w < (1 << 15) && tile_h < (1 << 15))
+        tile_emit_coop_kernel<<<gsa_div_up(n, kSortThreads), kSortThreads, 0, s>>>(n, order, offsets, splat, radii, tile_w,
+                                                                                  tile_h, m_capacity, isect_tile, isect_gid);
+    else
+        tile_emit_kernel<<<gsa_div_up(n, kSortThreads), kSortThreads, 0, s>>>(
+            n, order, offsets, splat, radii, tile_w, tile_h, tile_w * tile_h, cull_mode, m_capacity, isect_tile, isect_gid);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }
@@ -353,8 +424,13 @@ extern "C" int gsa_tile_offsets(uint32_t m, const uint32_t *sorted_tile, int n_t
     GSA_RETURN_IF(n_tiles <= 0 || !tile_offsets, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(m > 0 && !sorted_tile, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(m >= 0x7FFFFFFFu, GSA_ERR_UNSUPPORTED);
-    tile_offsets_kernel<<<gsa_div_up((long long)m + 1, kSortThreads), kSortThreads, 0,
-                          static_cast<hipStream_t>(stream)>>>(m, sorted_tile, n_tiles, tile_offsets);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((long long)m > 1024LL * n_tiles)
+        tile_offsets_bsearch_kernel<<<gsa_div_up(n_tiles + 1, kSortThreads), kSortThreads, 0, s>>>(m, sorted_tile, n_tiles,
+                                                                                                tile_offsets);
+    else
+        tile_offsets_kernel<<<gsa_div_up((long long)m + 1, kSortThreads), kSortThreads, 0, s>>>(m, sorted_tile, n_tiles,
+                                                                                               tile_offsets);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }
