@@ -71,6 +71,17 @@ def tile_grid(width: int, height: int) -> Tuple[int, int]:
     return (width + TILE_SIZE - 1) // TILE_SIZE, (height + TILE_SIZE - 1) // TILE_SIZE
 
 
+_PINNED = {}
+
+
+def _pinned_scalar(dev):
+    """One pinned int64 + event per device for the record-count read-back (allocated once)."""
+    key = (dev.type, dev.index)
+    if key not in _PINNED:
+        _PINNED[key] = (torch.empty(1, dtype=torch.int64, pin_memory=True), torch.cuda.Event())
+    return _PINNED[key]
+
+
 def project_fwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat, Kmat, width: int, height: int,
                 cull_mode: int = 0):
     """-> splat [N,16], radii [N,2] i32, tiles_touched [N] i32, depth_keys [N] (uint32 bits in int32 storage)."""
@@ -80,9 +91,9 @@ def project_fwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat
     radii = torch.empty(N, 2, dtype=torch.int32, device=dev)
     tiles_touched = torch.empty(N, dtype=torch.int32, device=dev)
     depth_keys = torch.empty(N, dtype=torch.int32, device=dev)
-    _call("gsa_project_fwd", lib.gsa_project_fwd, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), _ptr(colors), sh_degree,
-                              sh_coeffs, _ptr(viewmat), _ptr(Kmat), width, height, cull_mode, _ptr(splat),
-                              _ptr(radii), _ptr(tiles_touched), _ptr(depth_keys), _stream())
+    _call("gsa_project_fwd", lib.gsa_project_fwd, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
+          _ptr(colors), sh_degree, sh_coeffs, _ptr(viewmat), _ptr(Kmat), width, height, cull_mode, _ptr(splat),
+          _ptr(radii), _ptr(tiles_touched), _ptr(depth_keys), _stream())
     return splat, radii, tiles_touched, depth_keys
 
 
@@ -95,8 +106,8 @@ def sort_pairs(n: int, keys: torch.Tensor, vals: Optional[torch.Tensor], begin_b
     v_tmp = torch.empty(n, dtype=torch.int32, device=dev)
     ws_bytes = lib.gsa_sort_workspace_bytes(n)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    _call("gsa_sort_pairs_u32", lib.gsa_sort_pairs_u32, n, _ptr(keys), _ptr(vals), _ptr(k_out), _ptr(v_out), _ptr(k_tmp), _ptr(v_tmp),
-                                 begin_bit, end_bit, _ptr(ws), ws_bytes, _stream())
+    _call("gsa_sort_pairs_u32", lib.gsa_sort_pairs_u32, n, _ptr(keys), _ptr(vals), _ptr(k_out), _ptr(v_out),
+          _ptr(k_tmp), _ptr(v_tmp), begin_bit, end_bit, _ptr(ws), ws_bytes, _stream())
     return k_out, v_out
 
 
@@ -107,18 +118,25 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
     tile_w, tile_h = tile_grid(width, height)
     n_tiles = tile_w * tile_h
     st = _stream()
+    # The record count M sizes the buffers below, so the host must read it back.  It does not depend on the
+    # depth order: reduce it right after projection, start an asynchronous copy to pinned memory, and only wait
+    # for it after the depth sort and the scan have been queued -- the GPU never idles on the read-back.
+    m_host, m_event = _pinned_scalar(dev)
+    m_host.copy_(tiles_touched.sum(dtype=torch.int64).reshape(1), non_blocking=True)
+    m_event.record()
     _, order = sort_pairs(N, depth_keys, None, 0, 32)  # ties keep index order; culled gaussians sort last
     offsets = torch.empty(N, dtype=torch.int32, device=dev)
     total = torch.empty(1, dtype=torch.int32, device=dev)
     ws_bytes = lib.gsa_sort_workspace_bytes(N)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    _call("gsa_scan_tiles", lib.gsa_scan_tiles, N, _ptr(tiles_touched), _ptr(order), _ptr(offsets), _ptr(total), _ptr(ws), ws_bytes,
-                             st)
-    M = int(total.item())  # the one host read-back of the path: sizes the record buffers
+    _call("gsa_scan_tiles", lib.gsa_scan_tiles, N, _ptr(tiles_touched), _ptr(order), _ptr(offsets), _ptr(total),
+          _ptr(ws), ws_bytes, st)
+    m_event.synchronize()
+    M = int(m_host[0])
     isect_tile = torch.empty(M, dtype=torch.int32, device=dev)
     isect_gid = torch.empty(M, dtype=torch.int32, device=dev)
-    _call("gsa_tile_emit", lib.gsa_tile_emit, N, _ptr(order), _ptr(offsets), _ptr(splat), _ptr(radii), width, height, cull_mode, M,
-                            _ptr(isect_tile), _ptr(isect_gid), st)
+    _call("gsa_tile_emit", lib.gsa_tile_emit, N, _ptr(order), _ptr(offsets), _ptr(splat), _ptr(radii), width,
+          height, cull_mode, M, _ptr(isect_tile), _ptr(isect_gid), st)
     tile_bits = max(1, math.ceil(math.log2(n_tiles + 1)))
     if M > 0:
         sorted_tile, sorted_gid = sort_pairs(M, isect_tile, isect_gid, 0, tile_bits)
@@ -136,9 +154,8 @@ def composite_fwd(splat, sorted_gid, tile_offsets, background, width: int, heigh
     alpha = torch.empty(height, width, 1, dtype=torch.float32, device=dev)
     final_T = torch.empty(height, width, dtype=torch.float32, device=dev)
     last_id = torch.empty(height, width, dtype=torch.int32, device=dev)
-    _call("gsa_composite_fwd", lib.gsa_composite_fwd, width, height, channels, _ptr(splat), _ptr(sorted_gid), _ptr(tile_offsets),
-                                _ptr(background), _ptr(render), _ptr(alpha), _ptr(final_T), _ptr(last_id),
-                                _stream())
+    _call("gsa_composite_fwd", lib.gsa_composite_fwd, width, height, channels, _ptr(splat), _ptr(sorted_gid),
+          _ptr(tile_offsets), _ptr(background), _ptr(render), _ptr(alpha), _ptr(final_T), _ptr(last_id), _stream())
     return render, alpha, final_T, last_id
 
 
@@ -146,9 +163,9 @@ def composite_bwd(splat, sorted_gid, tile_offsets, background, final_T, last_id,
                   height: int, channels: int):
     """-> v_splat [N,16]: d loss / d (mean2d, conic, opacity, rgb, depth) in the splat-record layout."""
     v_splat = torch.zeros_like(splat)
-    _call("gsa_composite_bwd", lib.gsa_composite_bwd, width, height, channels, _ptr(splat), _ptr(sorted_gid), _ptr(tile_offsets),
-                                _ptr(background), _ptr(final_T), _ptr(last_id), _ptr(v_render), _ptr(v_alpha),
-                                _ptr(v_splat), _stream())
+    _call("gsa_composite_bwd", lib.gsa_composite_bwd, width, height, channels, _ptr(splat), _ptr(sorted_gid),
+          _ptr(tile_offsets), _ptr(background), _ptr(final_T), _ptr(last_id), _ptr(v_render), _ptr(v_alpha),
+          _ptr(v_splat), _stream())
     return v_splat
 
 
@@ -167,8 +184,7 @@ def project_bwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat
             if got.numel() != like.numel() or got.dtype != torch.float32 or not got.is_contiguous() \
                     or got.device != like.device:
                 raise ValueError("grad_out tensors must be contiguous fp32, sized like the inputs, on their device")
-    _call("gsa_project_bwd", lib.gsa_project_bwd, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), _ptr(colors), sh_degree,
-                              sh_coeffs, _ptr(viewmat), _ptr(Kmat), width, height, _ptr(splat), _ptr(radii),
-                              _ptr(v_splat), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac),
-                              _ptr(v_colors), _stream())
+    _call("gsa_project_bwd", lib.gsa_project_bwd, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
+          _ptr(colors), sh_degree, sh_coeffs, _ptr(viewmat), _ptr(Kmat), width, height, _ptr(splat), _ptr(radii),
+          _ptr(v_splat), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac), _ptr(v_colors), _stream())
     return v_means, v_quats, v_scales, v_opac, v_colors
