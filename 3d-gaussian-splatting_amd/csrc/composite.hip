@@ -4,26 +4,28 @@
 // pixel (lane l -> (x = l & 7, y = l >> 3) inside the quadrant).
 //
 //  * Staging: the workgroup gathers 256 sorted splat records at a time (one 64-B record per thread, one cache
-//    line, served from L2 / Infinity Cache) into LDS.  The staging thread also computes for ITS record the
-//    4-bit mask of the quadrants whose pixel centres the alpha >= 1/255 ellipse can reach (exact
+//    line, served from L2 / Infinity Cache) into a 48-B LDS image.  The staging thread also computes for ITS
+//    record the 4-bit mask of the quadrants whose pixel centres the alpha >= 1/255 ellipse can reach (exact
 //    ellipse-vs-rectangle test, conservative margin).
-//  * Ballot compaction: each wave turns the mask bits of its own quadrant into a 64-bit SGPR mask per 64
-//    staged records (__ballot) and walks only the set bits (s_ff1) -- a record that cannot touch the quadrant
-//    costs the wave nothing, and there is no per-record test at all.  About 45 % of (quadrant, record)
-//    pairs survive.  Results are identical to the plain per-pixel loop: a skipped pair fails the alpha test
-//    at every pixel of the quadrant anyway.
-//  * Blend: the surviving record is read as an LDS broadcast; per-pixel termination is carried in the sign
-//    of T (negative = finished), so the body is branch-free.  A wave leaves the loop when its 64 pixels are
-//    done (ballot), the workgroup stops staging when all 256 are (__syncthreads_count).
-//  * Backward: per (quadrant, record) the 64 per-pixel contributions are reduced across the wave -- the eight
-//    leading fields by a transpose-reduce built on the gfx950 v_permlane32_swap / v_permlane16_swap
-//    instructions (24 VALU ops instead of 54) -- and added with one atomic instruction whose active lanes
-//    cover one 64-B gradient record (a single memory-side request).
+//  * Compaction: each wave turns the mask bits of its own quadrant into a compacted LIST of LDS record offsets
+//    (ballot + mbcnt, 16-bit entries).  A record that cannot touch the quadrant costs the wave nothing; about
+//    45 % of (quadrant, record) pairs survive.  Results are identical to the plain per-pixel loop: a skipped
+//    pair fails the alpha test at every pixel of the quadrant anyway.
+//  * Walk: one 8-B LDS broadcast yields four list entries; each record is three ds_read_b128 broadcasts.  The
+//    blend body has NO scalar mask logic (the CU's single scalar unit was the forward's bottleneck when the
+//    walk was an s_ff1 bit scan with s_and-combined predicates): a rejected record is blended with alpha = 0,
+//    per-pixel termination lives in the sign of T (negative = finished).  A wave leaves the loop when its 64
+//    pixels are done (one ballot per four records), the workgroup stops staging when all 256 are.
+//  * Backward: records are taken in PAIRS; the 2 x 9 (10) per-pixel moment contributions are summed over the
+//    wave by one transpose-reduce (v_permlane32_swap / v_permlane16_swap / select + DPP: ~22 VALU per record
+//    instead of ~55 for per-value butterflies) and added with ONE atomic instruction whose active lanes cover
+//    the two 64-B gradient records.  The sweep accumulates raw moments of u = dL/dsigma; project_bwd turns
+//    them into mean / conic / opacity gradients once per gaussian.
 //
 // Why one wave per quadrant and not per tile: a lone wave issues a dependent instruction stream at a small
 // fraction of the SIMD rate, so the longest tile bounds the kernel.  A wave-per-tile version (4 pixels per
-// lane, same masks) had a 2.6x longer critical path and ran 0.25 / 0.49 ms where this runs faster; a
-// persistent-wave variant pulling tiles from per-XCD atomic queues was slower still.
+// lane, same masks) had a 2.6x longer critical path; a persistent-wave variant pulling tiles from per-XCD
+// atomic queues was slower still.
 //
 // Restates SURVEY.md Appendix A.5 (forward) and A.6 (backward) -- gsplat's rasterize_to_pixels behind
 // /root/reference/src/backends/gsplat_backend.py:168-182.
@@ -35,6 +37,8 @@ namespace {
 constexpr int kTile = GSA_TILE_SIZE;
 constexpr int kBlock = 256;   // 4 waves = 4 quadrants
 constexpr int kBatch = 256;   // records staged per workgroup and step
+constexpr int kRecBytes = 48; // LDS image of one staged record: 3 x float4
+constexpr int kNull = kBatch * kRecBytes;  // byte offset of the null record (opacity 0: blends nothing)
 constexpr float kLog2e = 1.4426950408889634f;
 
 // Workgroup -> tile.  Workgroups are dealt round-robin over the 8 XCDs (speed only, never correctness):
@@ -45,11 +49,66 @@ __device__ __forceinline__ int xcd_band_tile(int b, int n_tiles) {
     return (b & 7) * chunk + (b >> 3);
 }
 
-// 64-bit mask of the staged records [c*64, c*64+64) that can touch quadrant q (wave-uniform result)
-__device__ __forceinline__ unsigned long long relevant_records(const uint32_t *s_mask, int c, int q, int lane, int cnt) {
-    const int j = c * 64 + lane;
-    const bool hit = j < cnt && ((s_mask[j] >> q) & 1u);
-    return __ballot(hit);
+// LDS image of the staged batch.  rec[3*j .. 3*j+2] = record j:
+//   [0] mean.x  mean.y  log2e*a/2  log2e*b        (conic pre-scaled for exp2: s = log2e * sigma)
+//   [1] log2e*c/2  opacity  r  g
+//   [2] b  depth  (int) position in the sorted list  (uint) gaussian id
+// list[q] = byte offsets (j * 48) of the records that can touch quadrant q, in walk order, padded with
+// kNull up to a multiple of 4.  Each wave builds and reads only its own list[q].
+struct Staged {
+    float4 rec[(kBatch + 1) * 3];
+    uint32_t mask[kBatch];
+    uint16_t list[4][kBatch + 8];
+};
+
+__device__ __forceinline__ void stage_null_record(Staged &st, int t) {
+    if (t < 3) st.rec[kBatch * 3 + t] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// Thread t stages sorted record `idx` (position in the sorted list) into slot t and computes its quadrant mask.
+__device__ __forceinline__ void stage_record(Staged &st, int t, int idx, const float *__restrict__ splat,
+                                             const uint32_t *__restrict__ sorted_gid, int tx, int ty) {
+    const uint32_t gi = sorted_gid[idx];
+    const float4 *row = reinterpret_cast<const float4 *>(splat + (size_t)gi * GSA_SPLAT_STRIDE);
+    const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+    st.rec[3 * t + 0] = make_float4(r0.x, r0.y, 0.5f * kLog2e * r0.z, kLog2e * r0.w);
+    st.rec[3 * t + 1] = make_float4(0.5f * kLog2e * r1.x, r1.y, r1.z, r1.w);
+    st.rec[3 * t + 2] = make_float4(r2.x, r2.y, __int_as_float(idx), __uint_as_float(gi));
+    st.mask[t] = gsa_quadrant_mask(r0.x, r0.y, r0.z, r0.w, r1.x, r2.z, tx, ty);
+}
+
+// Wave q compacts the slots [from, cnt) whose mask has bit q into list[q] (ballot + mbcnt); returns the
+// count (wave-uniform).  The list is padded with three null entries so the walk can run in groups of 4.
+__device__ __forceinline__ int build_list(Staged &st, int q, int lane, int from, int cnt) {
+    int n = 0;
+    for (int c = from >> 6; c * 64 < cnt; ++c) {
+        const int j = c * 64 + lane;
+        const bool hit = j >= from && j < cnt && ((st.mask[j] >> q) & 1u);
+        const unsigned long long b = __ballot(hit);
+        const int pos = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
+        if (hit) st.list[q][pos] = (uint16_t)(j * kRecBytes);
+        n += __builtin_popcountll(b);
+    }
+#ifdef GSA_EXP_NOWALK   // experiment: measure everything but the walk
+    n = 0;
+#endif
+    if (lane < 3) st.list[q][n + lane] = (uint16_t)kNull;
+    // LDS operations of one wave complete in order; this only stops the compiler from moving the reads up
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return __builtin_amdgcn_readfirstlane(n);
+}
+
+// log2(e) * sigma at one pixel.  ONE expression with explicit fused steps for both kernels: the backward sweep
+// must reproduce the forward's alpha bit for bit, or a pixel's threshold decisions could differ between them.
+__device__ __forceinline__ float scaled_sigma(const float4 &q0, const float4 &q1, float dx, float dy) {
+#pragma clang fp contract(off)
+    return __builtin_fmaf(dx, __builtin_fmaf(q0.z, dx, q0.w * dy), (q1.x * dy) * dy);
+}
+
+__device__ __forceinline__ const float4 *rec_at(const Staged &st, uint32_t byte_off) {
+    return reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(st.rec) + byte_off);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -61,11 +120,7 @@ __global__ __launch_bounds__(kBlock) void composite_fwd_kernel(
     const uint32_t *__restrict__ sorted_gid, const int32_t *__restrict__ tile_offsets,
     const float *__restrict__ background, float *__restrict__ render, float *__restrict__ alpha_out,
     float *__restrict__ final_T, int32_t *__restrict__ last_id) {
-    // conic pre-scaled for exp2:  s = log2(e) * sigma = dx (ha dx + hb dy) + hc dy^2
-    __shared__ float4 s_q0[kBatch];    // mean.x mean.y ha hb
-    __shared__ float4 s_q1[kBatch];    // hc opacity r g
-    __shared__ float2 s_q2[kBatch];    // b depth
-    __shared__ uint32_t s_mask[kBatch];
+    __shared__ Staged st;
 
     const int tile = xcd_band_tile(blockIdx.x, n_tiles);
     if (tile >= n_tiles) return;
@@ -85,45 +140,43 @@ __global__ __launch_bounds__(kBlock) void composite_fwd_kernel(
     for (int k = 0; k < CH; ++k) acc[k] = 0.f;
     int last = -1;
     bool wave_live = __ballot(T > 0.f) != 0ull;
+    stage_null_record(st, t);
 
     for (int base = start; base < end; base += kBatch) {
         // also orders the previous batch's LDS reads before this batch's LDS writes
         if (__syncthreads_count(T > 0.f) == 0) break;
-        const int idx = base + t;
-        if (idx < end) {
-            const float4 *row = reinterpret_cast<const float4 *>(splat + (size_t)sorted_gid[idx] * GSA_SPLAT_STRIDE);
-            const float4 r0 = row[0], r1 = row[1], r2 = row[2];
-            s_q0[t] = make_float4(r0.x, r0.y, 0.5f * kLog2e * r0.z, kLog2e * r0.w);
-            s_q1[t] = make_float4(0.5f * kLog2e * r1.x, r1.y, r1.z, r1.w);
-            s_q2[t] = make_float2(r2.x, r2.y);
-            s_mask[t] = gsa_quadrant_mask(r0.x, r0.y, r0.z, r0.w, r1.x, r2.z, tx, ty);
-        }
+        if (base + t < end) stage_record(st, t, base + t, splat, sorted_gid, tx, ty);
         __syncthreads();
-        const int cnt = min(kBatch, end - base);
-        for (int c = 0; c * 64 < cnt && wave_live; ++c) {
-            unsigned long long bits = relevant_records(s_mask, c, q, lane, cnt);
-            int seen = 0;
-            while (bits) {
-                const int j = c * 64 + __builtin_ctzll(bits);
-                bits &= bits - 1;
-                const float4 q0 = s_q0[j], q1 = s_q1[j];
-                const float2 q2 = s_q2[j];
+        if (!wave_live) continue;
+        const int n = build_list(st, q, lane, 0, min(kBatch, end - base));
+        // Walk the compacted list four records at a time (one 8-B LDS broadcast gives the four offsets).
+        // The body is branch-free and needs no scalar mask logic: a record the alpha test rejects is blended
+        // with alpha = 0, a finished pixel (T < 0) turns every candidate T' negative.
+        for (int i = 0; i < n; i += 4) {
+            const uint2 o4 = *reinterpret_cast<const uint2 *>(&st.list[q][i]);
+            const uint32_t off[4] = {o4.x & 0xFFFFu, o4.x >> 16, o4.y & 0xFFFFu, o4.y >> 16};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float4 *p = rec_at(st, off[e]);
+                const float4 q0 = p[0], q1 = p[1], q2 = p[2];
                 const float dx = q0.x - pxf, dy = q0.y - pyf;
-                const float s = dx * (q0.z * dx + q0.w * dy) + (q1.x * dy) * dy;
-                const float a = fminf(GSA_MAX_ALPHA, q1.y * __builtin_amdgcn_exp2f(-s));
-                const bool valid = (s >= 0.f) && (a >= GSA_ALPHA_THRESHOLD);
+                const float s = scaled_sigma(q0, q1, dx, dy);
+                float a = fminf(GSA_MAX_ALPHA, q1.y * __builtin_amdgcn_exp2f(-s));
+                a = (s >= 0.f) ? a : 0.f;
+                a = (a >= GSA_ALPHA_THRESHOLD) ? a : 0.f;     // rejected: alpha 0 leaves T and acc as they are
                 const float nT = T * (1.f - a);
-                const bool contrib = valid && (nT > GSA_TRANSMITTANCE_EPS);  // false once T < 0
-                const float wgt = contrib ? a * T : 0.f;
-                acc[0] += q1.z * wgt; acc[1] += q1.w * wgt; acc[2] += q2.x * wgt;
-                if (CH == 4) acc[CH - 1] += q2.y * wgt;
-                last = contrib ? base + j : last;
-                // valid but not blended: the stop rule fired (or the pixel was finished already)
-                T = contrib ? nT : (valid ? -fabsf(T) : T);
-                if ((++seen & 7) == 0 && __ballot(T > 0.f) == 0ull) {  // all 64 pixels finished
-                    wave_live = false;
-                    break;
-                }
+                const bool ok = nT > GSA_TRANSMITTANCE_EPS;   // false once T < 0, and when the stop rule fires
+                const float wgt = ok ? a * T : 0.f;
+                // explicit fused steps: the rounding must not depend on a record's position in its group of four
+                acc[0] = __builtin_fmaf(q1.z, wgt, acc[0]); acc[1] = __builtin_fmaf(q1.w, wgt, acc[1]);
+                acc[2] = __builtin_fmaf(q2.x, wgt, acc[2]);
+                if (CH == 4) acc[CH - 1] = __builtin_fmaf(q2.y, wgt, acc[CH - 1]);
+                last = (wgt > 0.f) ? __float_as_int(q2.z) : last;
+                T = ok ? nT : -fabsf(T);
+            }
+            if (__ballot(T > 0.f) == 0ull) {  // all 64 pixels finished
+                wave_live = false;
+                break;
             }
         }
     }
@@ -144,65 +197,68 @@ __global__ __launch_bounds__(kBlock) void composite_fwd_kernel(
 // ------------------------------------------------------------------------------------------------
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-    int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
-    return v + __int_as_float(r);
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
 }
 
-// sum over the 64 lanes of a wave; result is wave-uniform
-__device__ __forceinline__ float wave_sum(float v) {
-    v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
-    v = dpp_add<0x141, 0xF>(v);  // row_half_mirror
-    v = dpp_add<0x140, 0xF>(v);  // row_mirror        -> every lane holds its row-of-16 sum
-    v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
-    v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-
-// lanes [0,32): sum over both halves of x;  lanes [32,64): the same for y   (v_permlane32_swap)
+// Transpose-reduce steps.  fold32(x, y): lanes [0,32) get x summed over both wave halves, lanes [32,64) the
+// same for y (v_permlane32_swap).  fold16: rows 0 and 2 get x summed over their row pair, rows 1 and 3 the same
+// for y (v_permlane16_swap).  fold8 / fold4 / fold2: the lanes whose bit 3 / 2 / 1 is clear get x summed with
+// the partner lane, the others y (select + one DPP add).  After the five levels every lane pair holds the
+// wave-wide sum of ONE of the inputs -- one instruction per input at the top, instead of six per input for
+// plain butterflies.
 __device__ __forceinline__ float fold32(float x, float y) {
     u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
     return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
-// even rows: x summed over its row pair; odd rows: the same for y   (v_permlane16_swap)
 __device__ __forceinline__ float fold16(float x, float y) {
     u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
     return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
+template <int CTRL>
+__device__ __forceinline__ float fold_sel(float x, float y, bool hi) {
+    const float keep = hi ? y : x, send = hi ? x : y;
+    return keep + dpp_mov<CTRL>(send);
+}
+constexpr int kRor8 = 0x128, kHalfMirror = 0x141, kQuadXor2 = 0x4E, kQuadXor1 = 0xB1;
 
-// Transpose-reduce of eight per-lane values: on return lane 8k (and its 7 neighbours) holds the wave-wide
-// sum of f[k].  24 VALU ops; the plain butterfly needs 6 per value.
-__device__ __forceinline__ float reduce8(const float *f, int lane) {
-    // level 32: (f0,f4) (f2,f6) (f1,f5) (f3,f7)
-    float X = fold32(f[0], f[4]), Y = fold32(f[2], f[6]), Z = fold32(f[1], f[5]), W = fold32(f[3], f[7]);
-    // level 16: rows become [f0, f2, f4, f6] and [f1, f3, f5, f7]
-    float P = fold16(X, Y), Q = fold16(Z, W);
-    // level 8: low half-row keeps P, high half-row keeps Q; partner is 8 lanes away in the same row
-    const bool hi = (lane & 8) != 0;
-    float keep = hi ? Q : P, send = hi ? P : Q;
-    int r = __builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x128 /* row_ror:8 */, 0xF, 0xF, false);
-    float v = keep + __int_as_float(r);
-    // levels 4, 2, 1 inside each group of 8 lanes
-    v = dpp_add<0xB1, 0xF>(v);
-    v = dpp_add<0x4E, 0xF>(v);
-    v = dpp_add<0x141, 0xF>(v);
-    return v;
+// Sums 2 * NF per-lane values (NF fields of two records, v[2 * f + e]) over the wave.  On return the lane with
+//   field = 8 b1 + 4 b2 + 2 b3 + b4 (b1 = 0)  or  8 + b4 (b1 = 1, b2 = b3 = 0),   record e = b5
+// (b_k = bit k of the lane id) holds the total of v[2 * field + e]; lanes 2k and 2k+1 hold the same value.
+template <int NF>
+__device__ __forceinline__ float reduce_pair(const float *v, int lane) {
+    static_assert(NF == 9 || NF == 10, "field count");
+    float w[10];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) w[f] = fold32(v[2 * f], v[2 * f + 1]);
+    if (NF == 9) w[9] = w[8];
+    float z[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) z[k] = fold16(w[2 * k], w[2 * k + 1]);
+    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0;
+    const float y0 = fold_sel<kRor8>(z[0], z[1], b3), y1 = fold_sel<kRor8>(z[2], z[3], b3);
+    const float y2 = z[4] + dpp_mov<kRor8>(z[4]);
+    const float x0 = fold_sel<kHalfMirror>(y0, y1, b2);
+    const float x1 = y2 + dpp_mov<kHalfMirror>(y2);
+    const float r = fold_sel<kQuadXor2>(x0, x1, b1);
+    return r + dpp_mov<kQuadXor1>(r);
 }
 
+// Gradient record written by the backward sweep (v_splat[N,16], consumed by project_bwd):
+//   [0] sum u dx   [1] sum u dy   [2] sum u dx^2   [3] sum u dx dy   [4] sum u dy^2   [5] sum u
+//   [6..8] sum fac * v_out(rgb)   [9] sum fac * v_out(depth)
+// with u = d loss / d sigma at one pixel and d = mean2d - pixel: the raw moments of u.  Mean, conic and
+// opacity gradients are linear in them (project_bwd finishes that per gaussian, once, instead of per pixel).
 template <int CH>
 __global__ __launch_bounds__(kBlock) void composite_bwd_kernel(
     int width, int height, int tile_w, int n_tiles, const float *__restrict__ splat,
     const uint32_t *__restrict__ sorted_gid, const int32_t *__restrict__ tile_offsets,
     const float *__restrict__ background, const float *__restrict__ final_T, const int32_t *__restrict__ last_id,
     const float *__restrict__ v_render, const float *__restrict__ v_alpha, float *__restrict__ v_splat) {
-    __shared__ float4 s_q0[kBatch];    // mean.x mean.y a/2 b
-    __shared__ float4 s_q1[kBatch];    // c/2 opacity r g
-    __shared__ float2 s_q2[kBatch];    // b depth
-    __shared__ uint32_t s_mask[kBatch];
-    __shared__ uint32_t s_gid[kBatch];
+    __shared__ Staged st;
     __shared__ int s_max_last;
+    constexpr int NF = 6 + CH;
 
     const int tile = xcd_band_tile(blockIdx.x, n_tiles);
     if (tile >= n_tiles) return;
@@ -230,11 +286,18 @@ __global__ __launch_bounds__(kBlock) void composite_bwd_kernel(
     }
     float Wd = Tf * (((inside && v_alpha) ? v_alpha[pix] : 0.f) - bgdot);
 
+    // which (field, record) total this lane holds after reduce_pair, and whether it is the lane that adds it
+    const int my_field = (lane & 2) ? 8 + ((lane >> 4) & 1)
+                                    : ((lane >> 2) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 4) & 1);
+    const bool my_add = !(lane & 1) && my_field < NF && (!(lane & 2) || !(lane & 12));
+    const bool my_rec1 = (lane & 32) != 0;
+
     int mx = binf;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
     const int qmax = __builtin_amdgcn_readfirstlane(mx);  // last record any pixel of this quadrant blended
     if (t == 0) s_max_last = -1;
+    stage_null_record(st, t);
     __syncthreads();
     if (lane == 0 && qmax >= 0) atomicMax(&s_max_last, qmax);
     __syncthreads();
@@ -243,67 +306,49 @@ __global__ __launch_bounds__(kBlock) void composite_bwd_kernel(
     for (int top = top0; top > start; top -= kBatch) {
         const int cnt = min(kBatch, top - start);
         __syncthreads();
-        if (t < cnt) {  // slot t holds record top-1-t: the loop below walks slots upwards = records backwards
-            const uint32_t gi = sorted_gid[top - 1 - t];
-            const float4 *row = reinterpret_cast<const float4 *>(splat + (size_t)gi * GSA_SPLAT_STRIDE);
-            const float4 r0 = row[0], r1 = row[1], r2 = row[2];
-            s_q0[t] = make_float4(r0.x, r0.y, 0.5f * r0.z, r0.w);
-            s_q1[t] = make_float4(0.5f * r1.x, r1.y, r1.z, r1.w);
-            s_q2[t] = make_float2(r2.x, r2.y);
-            s_mask[t] = gsa_quadrant_mask(r0.x, r0.y, r0.z, r0.w, r1.x, r2.z, tx, ty);
-            s_gid[t] = gi;
-        }
+        // slot t holds record top-1-t: the list walks slots upwards = records backwards
+        if (t < cnt) stage_record(st, t, top - 1 - t, splat, sorted_gid, tx, ty);
         __syncthreads();
-        const int first = max(0, top - 1 - qmax);  // slots below `first` hold records behind this quadrant's last one
-        for (int c = first >> 6; c * 64 < cnt; ++c) {
-            unsigned long long bits = relevant_records(s_mask, c, q, lane, cnt);
-            if (c == (first >> 6)) bits &= ~0ull << (first & 63);
-            while (bits) {
-                const int j = c * 64 + __builtin_ctzll(bits);
-                bits &= bits - 1;
-                const int rec = top - 1 - j;
-                const float4 q0 = s_q0[j], q1 = s_q1[j];
-                const float2 q2 = s_q2[j];
-                const float ha = q0.z, cb = q0.w, hc = q1.x, op = q1.y;
+        // slots below `first` hold records behind this quadrant's last one
+        const int n = build_list(st, q, lane, max(0, top - 1 - qmax), cnt);
+        for (int i = 0; i < n; i += 2) {
+            const uint32_t o2 = *reinterpret_cast<const uint32_t *>(&st.list[q][i]);
+            const uint32_t off[2] = {o2 & 0xFFFFu, o2 >> 16};
+            float v[2 * NF];
+            uint32_t gid[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float4 *p = rec_at(st, off[e]);
+                const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+                gid[e] = __float_as_uint(q2.w);
                 const float dx = q0.x - pxf, dy = q0.y - pyf;
-                const float hadx = ha * dx, hcdy = hc * dy;
-                const float sx = hadx + cb * dy;              // a/2 dx + b dy
-                const float sigma = dx * sx + hcdy * dy;
-                const float vis = __builtin_amdgcn_exp2f(-kLog2e * sigma);
-                const float raw = op * vis;
-                const float a = fminf(GSA_MAX_ALPHA, raw);
-                const bool valid = (rec <= binf) && (sigma >= 0.f) && (a >= GSA_ALPHA_THRESHOLD);
-                if (__ballot(valid) == 0ull) continue;
+                const float s = scaled_sigma(q0, q1, dx, dy);
+                const float raw = q1.y * __builtin_amdgcn_exp2f(-s);
+                float a = fminf(GSA_MAX_ALPHA, raw);
+                a = (s >= 0.f && __float_as_int(q2.z) <= binf) ? a : 0.f;   // the pixel stopped in front of it
+                a = (a >= GSA_ALPHA_THRESHOLD) ? a : 0.f;
+                // a == 0: ra = 1, fac = 0 -- T, Wd and the sums pass through unchanged, no selects needed
                 const float ra = __builtin_amdgcn_rcpf(1.f - a);
                 const float Tn = T * ra;             // transmittance in front of this splat
-                const float fac = valid ? a * Tn : 0.f;
+                const float fac = a * Tn;
                 float cv = q1.z * vout[0] + q1.w * vout[1] + q2.x * vout[2];
                 if (CH == 4) cv += q2.y * vout[CH - 1];
                 const float v_a = Tn * cv + ra * Wd;
                 Wd -= fac * cv;
-                const bool gate = valid && (raw <= GSA_MAX_ALPHA);
-                const float u = gate ? -raw * v_a : 0.f;    // d loss / d sigma
-                const float hu = 0.5f * u;
-                float f[8];                                  // v_mx v_my v_a v_b v_c v_o v_r v_g
-                f[0] = u * (sx + hadx);                      // a dx + b dy
-                f[1] = u * (cb * dx + 2.f * hcdy);           // b dx + c dy
-                f[2] = (hu * dx) * dx;
-                f[3] = (u * dx) * dy;
-                f[4] = (hu * dy) * dy;
-                f[5] = gate ? vis * v_a : 0.f;
-                f[6] = fac * vout[0];
-                f[7] = fac * vout[1];
-                T = valid ? Tn : T;
-                // one reduction and one atomic instruction (one 64-B request) per (quadrant, splat)
-                const float r8 = reduce8(f, lane);
-                const float t8 = wave_sum(fac * vout[2]);
-                const float t9 = (CH == 4) ? wave_sum(fac * vout[CH - 1]) : 0.f;
-                float *dst = v_splat + (size_t)s_gid[j] * GSA_SPLAT_STRIDE;
-                const bool lead = (lane & 7) == 0;
-                const int off = lead ? (lane >> 3) : (lane == 1 ? 8 : 9);
-                const float val = lead ? r8 : (lane == 1 ? t8 : t9);
-                if (lead || lane == 1 || (CH == 4 && lane == 2)) atomicAdd(dst + off, val);
+                T = Tn;
+                // blended and not capped at 0.999  <=>  a == raw
+                const float u = (a == raw) ? -raw * v_a : 0.f;    // d loss / d sigma
+                const float udx = u * dx, udy = u * dy;
+                v[0 + e] = udx; v[2 + e] = udy; v[4 + e] = udx * dx; v[6 + e] = udx * dy; v[8 + e] = udy * dy;
+                v[10 + e] = u;
+                v[12 + e] = fac * vout[0]; v[14 + e] = fac * vout[1]; v[16 + e] = fac * vout[2];
+                if (CH == 4) v[18 + e] = fac * vout[CH - 1];
             }
+            // one transpose-reduce and one atomic instruction (two 64-B requests) per PAIR of records
+            const float total = reduce_pair<NF>(v, lane);
+            const uint32_t g = my_rec1 ? gid[1] : gid[0];
+            if (my_add && (!my_rec1 || off[1] != (uint32_t)kNull))
+                atomicAdd(v_splat + (size_t)g * GSA_SPLAT_STRIDE + my_field, total);
         }
     }
 }

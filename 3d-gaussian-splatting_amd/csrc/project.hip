@@ -174,8 +174,13 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
         GsaProj p = gsa_project_one(cam, means + i * 3, quats + i * 4, scales + i * 3, width, height);
         const float4 *vrow = reinterpret_cast<const float4 *>(v_splat + i * GSA_SPLAT_STRIDE);
         float4 v0 = vrow[0], v1 = vrow[1], v2 = vrow[2];
-        float v_mx = v0.x, v_my = v0.y, v_a = v0.z, v_b = v0.w, v_c = v1.x;
-        vo = v1.y;
+        // The sweep leaves the raw moments of u = d loss / d sigma over d = mean2d - pixel (composite.hip):
+        // sigma = (a dx^2 + c dy^2) / 2 + b dx dy and alpha = o * exp(-sigma) make every gradient linear in them.
+        const float m_dx = v0.x, m_dy = v0.y, m_dxdx = v0.z, m_dxdy = v0.w, m_dydy = v1.x, m_u = v1.y;
+        const float s_opac = splat[i * GSA_SPLAT_STRIDE + 5];
+        float v_mx = p.qa * m_dx + p.qb * m_dy, v_my = p.qb * m_dx + p.qc * m_dy;
+        float v_a = 0.5f * m_dxdx, v_b = m_dxdy, v_c = 0.5f * m_dydy;
+        vo = -m_u / s_opac;   // d alpha / d o = alpha / o  and  u = -alpha * v_alpha
         float v_rgb[3] = {v1.z, v1.w, v2.x};
         float v_depth = v2.y;
 

@@ -11,7 +11,8 @@ import os
 from ctypes import c_char_p, c_int, c_size_t, c_uint32, c_void_p
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libgsplat_amd.so")
+# GSPLAT_AMD_LIB: developer override to A/B another build of the SAME C ABI (still a HIP library; no fallback)
+LIB_PATH = os.environ.get("GSPLAT_AMD_LIB") or os.path.join(_PKG_ROOT, "lib", "libgsplat_amd.so")
 ABI_VERSION = 1
 SPLAT_STRIDE = 16
 

@@ -159,9 +159,40 @@ def composite_fwd(splat, sorted_gid, tile_offsets, background, width: int, heigh
     return render, alpha, final_T, last_id
 
 
+def moments_to_record_grads(splat: torch.Tensor, v_splat: torch.Tensor) -> torch.Tensor:
+    """Diagnostic / test helper: the sweep's raw moments (``composite_bwd``'s output, see composite.hip) ->
+    d loss / d (mean2d.xy, conic abc, opacity, rgb, depth) in the splat-record layout.  ``project_bwd`` does this
+    conversion itself on the device; this is the same linear map in torch."""
+    a, b, c, o = splat[:, 2], splat[:, 3], splat[:, 4], splat[:, 5]
+    m = v_splat
+    g = v_splat.clone()
+    g[:, 0] = a * m[:, 0] + b * m[:, 1]
+    g[:, 1] = b * m[:, 0] + c * m[:, 1]
+    g[:, 2] = 0.5 * m[:, 2]
+    g[:, 4] = 0.5 * m[:, 4]
+    g[:, 5] = torch.where(o > 0, -m[:, 5] / o.clamp_min(1e-30), torch.zeros_like(o))  # culled: o = 0
+    return g
+
+
+def record_grads_to_moments(splat: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    """Inverse of ``moments_to_record_grads`` (the conic is positive definite): lets a test drive ``project_bwd``
+    with a chosen record gradient."""
+    a, b, c, o = splat[:, 2], splat[:, 3], splat[:, 4], splat[:, 5]
+    det = a * c - b * b
+    m = g.clone()
+    m[:, 0] = (c * g[:, 0] - b * g[:, 1]) / det
+    m[:, 1] = (a * g[:, 1] - b * g[:, 0]) / det
+    m[:, 2] = 2.0 * g[:, 2]
+    m[:, 4] = 2.0 * g[:, 4]
+    m[:, 5] = -g[:, 5] * o
+    return m
+
+
 def composite_bwd(splat, sorted_gid, tile_offsets, background, final_T, last_id, v_render, v_alpha, width: int,
                   height: int, channels: int):
-    """-> v_splat [N,16]: d loss / d (mean2d, conic, opacity, rgb, depth) in the splat-record layout."""
+    """-> v_splat [N,16]: per gaussian the raw moments of u = d loss / d sigma over d = mean2d - pixel
+    (sum u dx, u dy, u dx^2, u dx dy, u dy^2, u) and sum fac * v_out per channel -- the gradient record
+    ``project_bwd`` consumes (``moments_to_record_grads`` gives the mean / conic / opacity gradients)."""
     v_splat = torch.zeros_like(splat)
     _call("gsa_composite_bwd", lib.gsa_composite_bwd, width, height, channels, _ptr(splat), _ptr(sorted_gid),
           _ptr(tile_offsets), _ptr(background), _ptr(final_T), _ptr(last_id), _ptr(v_render), _ptr(v_alpha),

@@ -118,15 +118,18 @@ int gsa_composite_fwd(int width, int height, int channels, const float *splat,
                       const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
                       float *render, float *alpha, float *final_T, int32_t *last_id, gsa_stream_t stream);
 
-/* Stage 4 (row a3.5): reverse-order gradient sweep.  v_splat[N,16] must be zero on entry and
- * receives d loss / d (mean2d, conic, opacity, rgb, depth) in the record layout. */
+/* Stage 4 (row a3.5): reverse-order gradient sweep.  v_splat[N,16] must be zero on entry and receives, per
+ * gaussian, the raw moments of u = d loss / d sigma over d = mean2d - pixel:
+ *   [0] sum u dx  [1] sum u dy  [2] sum u dx^2  [3] sum u dx dy  [4] sum u dy^2  [5] sum u
+ *   [6..8] sum fac * v_render(rgb)  [9] sum fac * v_render(depth)   (fac = alpha * T in front)
+ * d loss / d (mean2d, conic, opacity) are linear in them; gsa_project_bwd finishes that per gaussian. */
 int gsa_composite_bwd(int width, int height, int channels, const float *splat,
                       const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
                       const float *final_T, const int32_t *last_id, const float *v_render,
                       const float *v_alpha, float *v_splat, gsa_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Stage 5 (row a3.6): projection + SH backward.  Reads the record gradients and the saved
+ * Stage 5 (row a3.6): projection + SH backward.  Reads the sweep's moment records (stage 4) and the saved
  * forward record / radii; writes EVERY element of v_means[N,3], v_quats[N,4], v_scales[N,3],
  * v_opacities[N] and v_colors (same shape as colors; zeros above the active degree and for
  * culled gaussians).

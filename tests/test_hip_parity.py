@@ -228,7 +228,8 @@ def test_stage_composite_fwd_bwd(gsa, W, H, N, cull_mode, with_bg):
     bg_d = None if bg is None else bg.cuda()
     img1, al1, fin_T, last = S.composite_fwd(splat, sorted_gid, tile_offsets, bg_d, W, H, 3)
     v_splat = S.composite_bwd(splat, sorted_gid, tile_offsets, bg_d, fin_T, last, (v_r * keep[..., None]).cuda(),
-                              (v_a * keep).cuda().contiguous(), W, H, 3).cpu()
+                              (v_a * keep).cuda().contiguous(), W, H, 3)
+    v_splat = S.moments_to_record_grads(splat.double(), v_splat.double()).float().cpu()  # raw moments -> gradients
     k3 = keep[..., None]
     checks = [("render", img1.cpu() * k3, img32 * k3, img0 * k3), ("alpha", al1.cpu() * k3, al32 * k3, al0 * k3),
               ("v_means2d", v_splat[:, 0:2], g32[0], g0[0]), ("v_conics", v_splat[:, 2:5], g32[1], g0[1]),
@@ -260,7 +261,10 @@ def test_stage_project_bwd(gsa, deg):
     v = torch.randn(N, 16, generator=g)
     v[:, 10:] = 0
     v[~vis] = 0
-    got = S.project_bwd(*args, hdeg, vm.cuda(), K.cuda(), W, H, splat, radii, v.cuda())
+    # project_bwd consumes the sweep's raw moments: hand it the moments whose implied record gradient is v
+    mom = S.record_grads_to_moments(splat.double().cpu(), v.double()).float()
+    mom[~vis] = 0
+    got = S.project_bwd(*args, hdeg, vm.cuda(), K.cuda(), W, H, splat, radii, mom.cuda())
 
     def oracle(dtype):
         leaves = [sc[k].to(dtype).clone().requires_grad_(True) for k in NAMES]
