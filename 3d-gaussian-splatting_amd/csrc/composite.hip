@@ -37,9 +37,47 @@ namespace {
 constexpr int kTile = GSA_TILE_SIZE;
 constexpr int kBlock = 256;   // 4 waves = 4 quadrants
 constexpr int kBatch = 256;   // records staged per workgroup and step
-constexpr int kRecBytes = 48; // LDS image of one staged record: 3 x float4
-constexpr int kNull = kBatch * kRecBytes;  // byte offset of the null record (opacity 0: blends nothing)
 constexpr float kLog2e = 1.4426950408889634f;
+constexpr uint32_t kSign = 0x80000000u;
+
+#ifdef GSA_TRACE   // developer build: per-workgroup timeline and phase times of wave 0 (tools/trace_tiles.py)
+__device__ unsigned long long *g_trace = nullptr;
+struct TraceState {
+    unsigned long long t0, mark, acc[8];
+    int batches, visits;
+};
+__device__ __forceinline__ void trace_begin(TraceState &ts) {
+    ts.t0 = ts.mark = __builtin_amdgcn_s_memrealtime();
+    for (int k = 0; k < 8; ++k) ts.acc[k] = 0;
+    ts.batches = ts.visits = 0;
+}
+__device__ __forceinline__ void trace_mark(TraceState &ts, int k) {
+    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+    ts.acc[k] += now - ts.mark;
+    ts.mark = now;
+}
+__device__ __forceinline__ void trace_end(const TraceState &ts, int kernel, int tile, int work) {
+    if (g_trace && threadIdx.x == 0) {
+        unsigned long long *r = g_trace + ((size_t)kernel * 65536 + tile) * 16;
+        r[0] = ts.t0;
+        r[1] = __builtin_amdgcn_s_memrealtime();
+        r[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32) |
+               __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // XCC_ID[3:0], HW_ID[31:0]
+        r[3] = work;
+        for (int k = 0; k < 8; ++k) r[4 + k] = ts.acc[k];
+        r[12] = ts.batches; r[13] = ts.visits;
+    }
+}
+#define GSA_TRACE_BEGIN() TraceState trace_ts; trace_begin(trace_ts)
+#define GSA_TRACE_MARK(k) trace_mark(trace_ts, k)
+#define GSA_TRACE_COUNT(n) do { ++trace_ts.batches; trace_ts.visits += (n); } while (0)
+#define GSA_TRACE_END(kernel, tile, work) do { __syncthreads(); trace_end(trace_ts, kernel, tile, work); } while (0)
+#else
+#define GSA_TRACE_BEGIN()
+#define GSA_TRACE_MARK(k)
+#define GSA_TRACE_COUNT(n)
+#define GSA_TRACE_END(kernel, tile, work)
+#endif
 
 // Workgroup -> tile.  Workgroups are dealt round-robin over the 8 XCDs (speed only, never correctness):
 // give every XCD one contiguous band of tile rows so neighbouring tiles (which share splats) share an L2.
@@ -49,50 +87,68 @@ __device__ __forceinline__ int xcd_band_tile(int b, int n_tiles) {
     return (b & 7) * chunk + (b >> 3);
 }
 
-// LDS image of the staged batch.  rec[3*j .. 3*j+2] = record j:
+// LDS image of the staged batch, F4 float4 per record (3 for RGB, 4 with the depth channel):
 //   [0] mean.x  mean.y  log2e*a/2  log2e*b        (conic pre-scaled for exp2: s = log2e * sigma)
 //   [1] log2e*c/2  opacity  r  g
-//   [2] b  depth  (int) position in the sorted list  (uint) gaussian id
-// list[q] = byte offsets (j * 48) of the records that can touch quadrant q, in walk order, padded with
-// kNull up to a multiple of 4.  Each wave builds and reads only its own list[q].
+//   [2] b  smax = log2e*ln(255 o)  (int) position in the sorted list  (uint) gaussian id
+//   [3] depth  -  -  -
+// Slots kBatch + q are per-wave NULL records (opacity 0: blend nothing) that pad wave q's list to a multiple of
+// four; their list position is set to that of the wave's last real entry.
+// list[q] = byte offsets of the records that can touch quadrant q, in walk order.  Each wave builds and reads
+// only its own list[q].
+template <int F4>
 struct Staged {
-    float4 rec[(kBatch + 1) * 3];
+    static constexpr int kRecBytes = 16 * F4;
+    float4 rec[(kBatch + 4) * F4];
     uint32_t mask[kBatch];
     uint16_t list[4][kBatch + 8];
 };
 
-__device__ __forceinline__ void stage_null_record(Staged &st, int t) {
-    if (t < 3) st.rec[kBatch * 3 + t] = make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
 // Thread t stages sorted record `idx` (position in the sorted list) into slot t and computes its quadrant mask.
-__device__ __forceinline__ void stage_record(Staged &st, int t, int idx, const float *__restrict__ splat,
+// Returns true if the record's opacity exceeds the 0.999 alpha cap (then the walk must apply the cap).
+template <int F4>
+__device__ __forceinline__ bool stage_record(Staged<F4> &st, int t, int idx, const float *__restrict__ splat,
                                              const uint32_t *__restrict__ sorted_gid, int tx, int ty) {
     const uint32_t gi = sorted_gid[idx];
     const float4 *row = reinterpret_cast<const float4 *>(splat + (size_t)gi * GSA_SPLAT_STRIDE);
     const float4 r0 = row[0], r1 = row[1], r2 = row[2];
-    st.rec[3 * t + 0] = make_float4(r0.x, r0.y, 0.5f * kLog2e * r0.z, kLog2e * r0.w);
-    st.rec[3 * t + 1] = make_float4(0.5f * kLog2e * r1.x, r1.y, r1.z, r1.w);
-    st.rec[3 * t + 2] = make_float4(r2.x, r2.y, __int_as_float(idx), __uint_as_float(gi));
+    st.rec[F4 * t + 0] = make_float4(r0.x, r0.y, 0.5f * kLog2e * r0.z, kLog2e * r0.w);
+    st.rec[F4 * t + 1] = make_float4(0.5f * kLog2e * r1.x, r1.y, r1.z, r1.w);
+    st.rec[F4 * t + 2] = make_float4(r2.x, fmaxf(0.f, kLog2e * r2.z), __int_as_float(idx), __uint_as_float(gi));
+    if (F4 == 4) st.rec[F4 * t + 3] = make_float4(r2.y, 0.f, 0.f, 0.f);
+#ifdef GSA_EXP_MORE_MASK   // experiment: the mask computation twice
+    st.mask[t] = gsa_quadrant_mask(r0.x, r0.y, r0.z, r0.w, r1.x, r2.z, tx, ty) |
+                 (gsa_quadrant_mask(r0.x + 1e-3f, r0.y, r0.z, r0.w, r1.x, r2.z, tx, ty) & (uint32_t)(idx == -7));
+#else
     st.mask[t] = gsa_quadrant_mask(r0.x, r0.y, r0.z, r0.w, r1.x, r2.z, tx, ty);
+#endif
+    return r1.y > GSA_MAX_ALPHA;
 }
 
-// Wave q compacts the slots [from, cnt) whose mask has bit q into list[q] (ballot + mbcnt); returns the
-// count (wave-uniform).  The list is padded with three null entries so the walk can run in groups of 4.
-__device__ __forceinline__ int build_list(Staged &st, int q, int lane, int from, int cnt) {
-    int n = 0;
+// Wave q compacts the slots [from, cnt) whose mask has bit q into list[q] (ballot + mbcnt) and pads it with
+// three null entries so the walk can run in groups of 4; returns the count (wave-uniform).  idx_of(slot) gives
+// the list position of a slot's record; the wave's null record inherits that of the last listed slot.
+template <int F4, typename IdxOf>
+__device__ __forceinline__ int build_list(Staged<F4> &st, int q, int lane, int from, int cnt, IdxOf idx_of) {
+    int n = 0, last_slot = 0;
     for (int c = from >> 6; c * 64 < cnt; ++c) {
         const int j = c * 64 + lane;
         const bool hit = j >= from && j < cnt && ((st.mask[j] >> q) & 1u);
         const unsigned long long b = __ballot(hit);
         const int pos = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
-        if (hit) st.list[q][pos] = (uint16_t)(j * kRecBytes);
+        if (hit) st.list[q][pos] = (uint16_t)(j * Staged<F4>::kRecBytes);
         n += __builtin_popcountll(b);
+        if (b) last_slot = c * 64 + 63 - __builtin_clzll(b);
     }
 #ifdef GSA_EXP_NOWALK   // experiment: measure everything but the walk
     n = 0;
 #endif
-    if (lane < 3) st.list[q][n + lane] = (uint16_t)kNull;
+    if (lane < 3) st.list[q][n + lane] = (uint16_t)((kBatch + q) * Staged<F4>::kRecBytes);
+    if (lane < F4) {
+        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane == 2) z.z = __int_as_float(idx_of(last_slot));
+        st.rec[(kBatch + q) * F4 + lane] = z;
+    }
     // LDS operations of one wave complete in order; this only stops the compiler from moving the reads up
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -107,89 +163,186 @@ __device__ __forceinline__ float scaled_sigma(const float4 &q0, const float4 &q1
     return __builtin_fmaf(dx, __builtin_fmaf(q0.z, dx, q0.w * dy), (q1.x * dy) * dy);
 }
 
-__device__ __forceinline__ const float4 *rec_at(const Staged &st, uint32_t byte_off) {
+// alpha of one record at one pixel, 0 if the record is skipped there.  The skip rule "sigma < 0 or
+// o exp(-sigma) < 1/255" is evaluated as ONE unsigned compare of the float bits, 0 <= s <= smax (a negative or
+// NaN s has a larger bit pattern than any smax >= 0); `off_bit` (0 or the sign bit) switches a lane off.
+// The 0.999 cap is only compiled in for batches that hold an opacity above it (exp2(-s) <= 1 otherwise keeps
+// alpha <= o).  Instruction costs that shaped this (tools/inst_microbench.hip): v_cmp / v_min / SGPR-operand
+// forms issue at half the rate of v_fma / v_mul / v_and.
+template <bool CLAMP>
+__device__ __forceinline__ float record_alpha(float s, float smax, float opacity, uint32_t off_bit, float &raw) {
+    raw = opacity * __builtin_amdgcn_exp2f(-s);
+    const float al = CLAMP ? fminf(GSA_MAX_ALPHA, raw) : raw;
+    return ((__float_as_uint(s) | off_bit) <= __float_as_uint(smax)) ? al : 0.f;
+}
+
+template <int F4>
+__device__ __forceinline__ const float4 *rec_at(const Staged<F4> &st, uint32_t byte_off) {
     return reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(st.rec) + byte_off);
 }
 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+// Per-pixel state of the forward walk.  A pixel is LIVE until the stop rule fires (T (1 - alpha) <= 1e-4 at a
+// record that passes the alpha test); then `dead` holds the sign bit (which switches the lane off inside
+// record_alpha), Tend its final transmittance, and T is parked at 1 so the optimistic group test below passes.
 template <int CH>
-__global__ __launch_bounds__(kBlock) void composite_fwd_kernel(
+struct FwdPixel {
+    float T, Tend, acc[CH];
+    uint32_t dead;
+    int last;
+};
+
+#ifndef GSA_FWD_GROUP
+#define GSA_FWD_GROUP 4      // records per trip of the forward walk (2 or 4)
+#endif
+#ifndef GSA_FWD_WAVES
+#define GSA_FWD_WAVES 1      // minimum waves per SIMD the forward kernel is compiled for (register budget)
+#endif
+
+// One group of G list entries starting at entry i: per-record alpha (0 where skipped / pixel finished), colours,
+// list positions.
+template <int CH, int F4, bool CLAMP, int G>
+__device__ __forceinline__ void eval_group(const Staged<F4> &st, int q, int i, float pxf, float pyf, uint32_t dead,
+                                           float (&a)[G], float (&col)[G][CH], int (&idx)[G]) {
+    // one LDS broadcast gives G list entries
+    uint32_t off[G];
+    if (G == 4) {
+        const uint2 o4 = *reinterpret_cast<const uint2 *>(&st.list[q][i]);
+        off[0] = o4.x & 0xFFFFu; off[1] = o4.x >> 16; off[G - 2] = o4.y & 0xFFFFu; off[G - 1] = o4.y >> 16;
+    } else {
+        const uint32_t o2 = *reinterpret_cast<const uint32_t *>(&st.list[q][i]);
+        off[0] = o2 & 0xFFFFu; off[1] = o2 >> 16;
+    }
+#pragma unroll
+    for (int e = 0; e < G; ++e) {
+        const float4 *p = rec_at(st, off[e]);
+        const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+        const float dx = q0.x - pxf, dy = q0.y - pyf;
+        float raw;
+        a[e] = record_alpha<CLAMP>(scaled_sigma(q0, q1, dx, dy), q2.y, q1.y, dead, raw);
+#ifdef GSA_EXP_MORE_VALU  // experiment: the alpha evaluation twice (wrong results)
+        {
+            float raw2;
+            a[e] += 1e-9f * record_alpha<CLAMP>(scaled_sigma(q0, q1, dy, dx), q2.y, q1.y, dead, raw2);
+        }
+#endif
+        col[e][0] = q1.z; col[e][1] = q1.w; col[e][2] = q2.x;
+        if (CH == 4) col[e][CH - 1] = p[F4 - 1].x;
+        idx[e] = __float_as_int(q2.z);
+    }
+}
+
+// Walks n list entries of quadrant q.  Returns false when all 64 pixels of the wave are finished.
+template <int CH, int F4, bool CLAMP>
+__device__ __forceinline__ bool walk_fwd(const Staged<F4> &st, int q, int n, float pxf, float pyf, FwdPixel<CH> &px) {
+    constexpr int G = GSA_FWD_GROUP;
+    int i = 0;
+    while (i < n) {
+        // Optimistic loop: as long as no pixel stops inside a group (T only shrinks, so testing the group's last
+        // value is enough; finished pixels have alpha 0 and T parked at 1) no per-record select is needed at all.
+        for (; i < n; i += G) {
+            float a[G], col[G][CH], t[G + 1];
+            int idx[G];
+            eval_group<CH, F4, CLAMP, G>(st, q, i, pxf, pyf, px.dead, a, col, idx);
+            t[0] = px.T;
+#pragma unroll
+            for (int e = 0; e < G; ++e) t[e + 1] = t[e] * (1.f - a[e]);
+            if (__ballot(t[G] > GSA_TRANSMITTANCE_EPS) != ~0ull) break;
+#pragma unroll
+            for (int e = 0; e < G; ++e) {
+                const float wgt = a[e] * t[e];
+                // explicit fused steps: the rounding must not depend on the path or the position in the group
+#pragma unroll
+                for (int k = 0; k < CH; ++k) px.acc[k] = __builtin_fmaf(col[e][k], wgt, px.acc[k]);
+            }
+            px.T = t[G];
+            px.last = px.dead ? px.last : idx[G - 1];   // last record seen while live (the backward starts there)
+        }
+        if (i >= n) break;
+        // some pixel stops in the group at i: the careful path, record by record
+        {
+            float a[G], col[G][CH];
+            int idx[G];
+            eval_group<CH, F4, CLAMP, G>(st, q, i, pxf, pyf, px.dead, a, col, idx);
+#pragma unroll
+            for (int e = 0; e < G; ++e) {
+                const float ae = px.dead ? 0.f : a[e];      // a pixel that stopped earlier in this group
+                const float nT = px.T * (1.f - ae);
+                const bool ok = nT > GSA_TRANSMITTANCE_EPS; // finished pixels: alpha 0, T = 1 -> true, no effect
+                const float wgt = ok ? ae * px.T : 0.f;
+#pragma unroll
+                for (int k = 0; k < CH; ++k) px.acc[k] = __builtin_fmaf(col[e][k], wgt, px.acc[k]);
+                px.last = (ok && !px.dead) ? idx[e] : px.last;
+                px.Tend = ok ? px.Tend : px.T;              // the stop rule fired: this record is not blended
+                px.dead = ok ? px.dead : kSign;
+                px.T = ok ? nT : 1.f;
+            }
+            i += G;
+            if (__ballot(px.dead == 0u) == 0ull) return false;   // all 64 pixels finished
+        }
+    }
+    return true;
+}
+
+template <int CH>
+__global__ __launch_bounds__(kBlock, GSA_FWD_WAVES) void composite_fwd_kernel(
     int width, int height, int tile_w, int n_tiles, const float *__restrict__ splat,
     const uint32_t *__restrict__ sorted_gid, const int32_t *__restrict__ tile_offsets,
     const float *__restrict__ background, float *__restrict__ render, float *__restrict__ alpha_out,
     float *__restrict__ final_T, int32_t *__restrict__ last_id) {
-    __shared__ Staged st;
+    constexpr int F4 = CH == 4 ? 4 : 3;
+    __shared__ Staged<F4> st;
 
     const int tile = xcd_band_tile(blockIdx.x, n_tiles);
     if (tile >= n_tiles) return;
+    GSA_TRACE_BEGIN();
     const int t = threadIdx.x, lane = t & 63;
     const int q = __builtin_amdgcn_readfirstlane(t >> 6);  // this wave's quadrant (wave-uniform -> scalar control flow)
     const int tx = tile % tile_w, ty = tile / tile_w;
-    const int px = tx * kTile + (q & 1) * 8 + (lane & 7), py = ty * kTile + (q >> 1) * 8 + (lane >> 3);
-    const bool inside = px < width && py < height;
-    const float pxf = px + 0.5f, pyf = py + 0.5f;
+    const int px_ = tx * kTile + (q & 1) * 8 + (lane & 7), py_ = ty * kTile + (q >> 1) * 8 + (lane >> 3);
+    const bool inside = px_ < width && py_ < height;
+    const float pxf = px_ + 0.5f, pyf = py_ + 0.5f;
     const int start = __builtin_amdgcn_readfirstlane(tile_offsets[tile]);
     const int end = __builtin_amdgcn_readfirstlane(tile_offsets[tile + 1]);
 
-    // T > 0: running transmittance; T < 0: pixel finished, |T| is its final transmittance
-    float T = inside ? 1.f : -1.f;
-    float acc[CH];
+    FwdPixel<CH> px;
+    px.T = 1.f; px.Tend = 1.f; px.dead = inside ? 0u : kSign; px.last = -1;
 #pragma unroll
-    for (int k = 0; k < CH; ++k) acc[k] = 0.f;
-    int last = -1;
-    bool wave_live = __ballot(T > 0.f) != 0ull;
-    stage_null_record(st, t);
+    for (int k = 0; k < CH; ++k) px.acc[k] = 0.f;
+    bool wave_live = __ballot(inside) != 0ull;
 
+    GSA_TRACE_MARK(0);
     for (int base = start; base < end; base += kBatch) {
         // also orders the previous batch's LDS reads before this batch's LDS writes
-        if (__syncthreads_count(T > 0.f) == 0) break;
-        if (base + t < end) stage_record(st, t, base + t, splat, sorted_gid, tx, ty);
-        __syncthreads();
+        if (__syncthreads_count(px.dead == 0u) == 0) break;
+        GSA_TRACE_MARK(5);
+        bool cap = false;
+        if (base + t < end) cap = stage_record(st, t, base + t, splat, sorted_gid, tx, ty);
+        GSA_TRACE_MARK(1);
+        const bool any_cap = __syncthreads_or(cap);
+        GSA_TRACE_MARK(2);
         if (!wave_live) continue;
-        const int n = build_list(st, q, lane, 0, min(kBatch, end - base));
-        // Walk the compacted list four records at a time (one 8-B LDS broadcast gives the four offsets).
-        // The body is branch-free and needs no scalar mask logic: a record the alpha test rejects is blended
-        // with alpha = 0, a finished pixel (T < 0) turns every candidate T' negative.
-        for (int i = 0; i < n; i += 4) {
-            const uint2 o4 = *reinterpret_cast<const uint2 *>(&st.list[q][i]);
-            const uint32_t off[4] = {o4.x & 0xFFFFu, o4.x >> 16, o4.y & 0xFFFFu, o4.y >> 16};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float4 *p = rec_at(st, off[e]);
-                const float4 q0 = p[0], q1 = p[1], q2 = p[2];
-                const float dx = q0.x - pxf, dy = q0.y - pyf;
-                const float s = scaled_sigma(q0, q1, dx, dy);
-                float a = fminf(GSA_MAX_ALPHA, q1.y * __builtin_amdgcn_exp2f(-s));
-                a = (s >= 0.f) ? a : 0.f;
-                a = (a >= GSA_ALPHA_THRESHOLD) ? a : 0.f;     // rejected: alpha 0 leaves T and acc as they are
-                const float nT = T * (1.f - a);
-                const bool ok = nT > GSA_TRANSMITTANCE_EPS;   // false once T < 0, and when the stop rule fires
-                const float wgt = ok ? a * T : 0.f;
-                // explicit fused steps: the rounding must not depend on a record's position in its group of four
-                acc[0] = __builtin_fmaf(q1.z, wgt, acc[0]); acc[1] = __builtin_fmaf(q1.w, wgt, acc[1]);
-                acc[2] = __builtin_fmaf(q2.x, wgt, acc[2]);
-                if (CH == 4) acc[CH - 1] = __builtin_fmaf(q2.y, wgt, acc[CH - 1]);
-                last = (wgt > 0.f) ? __float_as_int(q2.z) : last;
-                T = ok ? nT : -fabsf(T);
-            }
-            if (__ballot(T > 0.f) == 0ull) {  // all 64 pixels finished
-                wave_live = false;
-                break;
-            }
-        }
+        const int n = build_list(st, q, lane, 0, min(kBatch, end - base), [&](int slot) { return base + slot; });
+        GSA_TRACE_MARK(3);
+        GSA_TRACE_COUNT(n);
+        wave_live = any_cap ? walk_fwd<CH, F4, true>(st, q, n, pxf, pyf, px)
+                            : walk_fwd<CH, F4, false>(st, q, n, pxf, pyf, px);
+        GSA_TRACE_MARK(4);
     }
 
     if (inside) {
-        const size_t pix = (size_t)py * width + px;
-        const float Tf = fabsf(T);
+        const size_t pix = (size_t)py_ * width + px_;
+        const float Tf = px.dead ? px.Tend : px.T;
 #pragma unroll
-        for (int k = 0; k < CH; ++k) render[pix * CH + k] = acc[k] + (background ? Tf * background[k] : 0.f);
+        for (int k = 0; k < CH; ++k) render[pix * CH + k] = px.acc[k] + (background ? Tf * background[k] : 0.f);
         alpha_out[pix] = 1.f - Tf;
         final_T[pix] = Tf;  // kept beside alpha: 1 - (1 - T) loses the low bits of a small T
-        last_id[pix] = last;
+        last_id[pix] = px.last;
     }
+    GSA_TRACE_MARK(6);
+    GSA_TRACE_END(0, tile, end - start);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -205,9 +358,8 @@ __device__ __forceinline__ float dpp_mov(float v) {
 // Transpose-reduce steps.  fold32(x, y): lanes [0,32) get x summed over both wave halves, lanes [32,64) the
 // same for y (v_permlane32_swap).  fold16: rows 0 and 2 get x summed over their row pair, rows 1 and 3 the same
 // for y (v_permlane16_swap).  fold8 / fold4 / fold2: the lanes whose bit 3 / 2 / 1 is clear get x summed with
-// the partner lane, the others y (select + one DPP add).  After the five levels every lane pair holds the
-// wave-wide sum of ONE of the inputs -- one instruction per input at the top, instead of six per input for
-// plain butterflies.
+// the partner lane, the others y.  After the five levels every lane pair holds the wave-wide sum of ONE of the
+// inputs -- about one instruction per input at the top, instead of six per input for plain butterflies.
 __device__ __forceinline__ float fold32(float x, float y) {
     u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
     return __uint_as_float(r.x) + __uint_as_float(r.y);
@@ -215,6 +367,22 @@ __device__ __forceinline__ float fold32(float x, float y) {
 __device__ __forceinline__ float fold16(float x, float y) {
     u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
     return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+// fold8 / fold4 as two DPP adds with complementary bank masks (a bank = 4 lanes of a row): the first writes
+// x + partner(x) into the lanes that keep x, the second y + partner(y) into the others -- no selects.
+// s_nop 1: a DPP read of a VGPR the previous VALU instruction wrote needs two wait states, and the compiler's
+// hazard pass cannot see into inline assembly.
+__device__ __forceinline__ float fold8(float x, float y) {
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc"
+                 : "+v"(x) : "v"(y));
+    return x;
+}
+__device__ __forceinline__ float fold4(float x, float y) {
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa"
+                 : "+v"(x) : "v"(y));
+    return x;
 }
 template <int CTRL>
 __device__ __forceinline__ float fold_sel(float x, float y, bool hi) {
@@ -236,13 +404,59 @@ __device__ __forceinline__ float reduce_pair(const float *v, int lane) {
     float z[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) z[k] = fold16(w[2 * k], w[2 * k + 1]);
-    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0;
-    const float y0 = fold_sel<kRor8>(z[0], z[1], b3), y1 = fold_sel<kRor8>(z[2], z[3], b3);
+    const float y0 = fold8(z[0], z[1]), y1 = fold8(z[2], z[3]);
     const float y2 = z[4] + dpp_mov<kRor8>(z[4]);
-    const float x0 = fold_sel<kHalfMirror>(y0, y1, b2);
+    const float x0 = fold4(y0, y1);
     const float x1 = y2 + dpp_mov<kHalfMirror>(y2);
-    const float r = fold_sel<kQuadXor2>(x0, x1, b1);
+    const float r = fold_sel<kQuadXor2>(x0, x1, (lane & 2) != 0);
     return r + dpp_mov<kQuadXor1>(r);
+}
+
+// Walks n list entries (records in REVERSE list order) of quadrant q, two per trip.
+template <int CH, int F4, bool CLAMP>
+__device__ __forceinline__ void walk_bwd(const Staged<F4> &st, int q, int n, int lane, float pxf, float pyf, int binf,
+                                         const float (&vout)[CH], float &T, float &Wd, int my_field, bool my_add,
+                                         bool my_rec1, float *__restrict__ v_splat) {
+    constexpr int NF = 6 + CH;
+    for (int i = 0; i < n; i += 2) {
+        const uint32_t o2 = *reinterpret_cast<const uint32_t *>(&st.list[q][i]);
+        const uint32_t off[2] = {o2 & 0xFFFFu, o2 >> 16};
+        float v[2 * NF];
+        uint32_t gid[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float4 *p = rec_at(st, off[e]);
+            const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+            gid[e] = __float_as_uint(q2.w);
+            const float dx = q0.x - pxf, dy = q0.y - pyf;
+            // the pixel stopped in front of this record (its list position is beyond the pixel's last one):
+            // binf - position is negative, its sign bit switches the lane off
+            const uint32_t off_bit = (uint32_t)(binf - __float_as_int(q2.z)) & kSign;
+            float raw;
+            const float a = record_alpha<CLAMP>(scaled_sigma(q0, q1, dx, dy), q2.y, q1.y, off_bit, raw);
+            // a == 0: ra = 1, fac = 0 -- T, Wd and the sums pass through unchanged, no selects needed
+            const float ra = __builtin_amdgcn_rcpf(1.f - a);
+            const float Tn = T * ra;             // transmittance in front of this splat
+            const float fac = a * Tn;
+            float cv = q1.z * vout[0] + q1.w * vout[1] + q2.x * vout[2];
+            if (CH == 4) cv += p[F4 - 1].x * vout[CH - 1];
+            const float v_a = Tn * cv + ra * Wd;
+            Wd -= fac * cv;
+            T = Tn;
+            // d loss / d sigma = -alpha v_a where the record is blended and (CLAMP) not capped at 0.999 (a == raw)
+            const float u = CLAMP ? ((a == raw) ? -raw * v_a : 0.f) : -a * v_a;
+            const float udx = u * dx, udy = u * dy;
+            v[0 + e] = udx; v[2 + e] = udy; v[4 + e] = udx * dx; v[6 + e] = udx * dy; v[8 + e] = udy * dy;
+            v[10 + e] = u;
+            v[12 + e] = fac * vout[0]; v[14 + e] = fac * vout[1]; v[16 + e] = fac * vout[2];
+            if (CH == 4) v[18 + e] = fac * vout[CH - 1];
+        }
+        // one transpose-reduce and one atomic instruction (two 64-B requests) per PAIR of records
+        const float total = reduce_pair<NF>(v, lane);
+        const uint32_t g = my_rec1 ? gid[1] : gid[0];
+        if (my_add && (!my_rec1 || i + 1 < n))
+            atomicAdd(v_splat + (size_t)g * GSA_SPLAT_STRIDE + my_field, total);
+    }
 }
 
 // Gradient record written by the backward sweep (v_splat[N,16], consumed by project_bwd):
@@ -250,15 +464,19 @@ __device__ __forceinline__ float reduce_pair(const float *v, int lane) {
 //   [6..8] sum fac * v_out(rgb)   [9] sum fac * v_out(depth)
 // with u = d loss / d sigma at one pixel and d = mean2d - pixel: the raw moments of u.  Mean, conic and
 // opacity gradients are linear in them (project_bwd finishes that per gaussian, once, instead of per pixel).
+#ifndef GSA_BWD_WAVES
+#define GSA_BWD_WAVES 1      // minimum waves per SIMD the backward kernel is compiled for (register budget)
+#endif
 template <int CH>
-__global__ __launch_bounds__(kBlock) void composite_bwd_kernel(
+__global__ __launch_bounds__(kBlock, GSA_BWD_WAVES) void composite_bwd_kernel(
     int width, int height, int tile_w, int n_tiles, const float *__restrict__ splat,
     const uint32_t *__restrict__ sorted_gid, const int32_t *__restrict__ tile_offsets,
     const float *__restrict__ background, const float *__restrict__ final_T, const int32_t *__restrict__ last_id,
     const float *__restrict__ v_render, const float *__restrict__ v_alpha, float *__restrict__ v_splat) {
-    __shared__ Staged st;
-    __shared__ int s_max_last;
+    constexpr int F4 = CH == 4 ? 4 : 3;
     constexpr int NF = 6 + CH;
+    __shared__ Staged<F4> st;
+    __shared__ int s_max_last;
 
     const int tile = xcd_band_tile(blockIdx.x, n_tiles);
     if (tile >= n_tiles) return;
@@ -267,6 +485,7 @@ __global__ __launch_bounds__(kBlock) void composite_bwd_kernel(
     const int start = __builtin_amdgcn_readfirstlane(tile_offsets[tile]);
     const int end = __builtin_amdgcn_readfirstlane(tile_offsets[tile + 1]);
     if (end <= start) return;
+    GSA_TRACE_BEGIN();
     const int tx = tile % tile_w, ty = tile / tile_w;
     const int px = tx * kTile + (q & 1) * 8 + (lane & 7), py = ty * kTile + (q >> 1) * 8 + (lane >> 3);
     const bool inside = px < width && py < height;
@@ -275,7 +494,7 @@ __global__ __launch_bounds__(kBlock) void composite_bwd_kernel(
     // per pixel: T = transmittance behind the current record; Wd = T_final (v_alpha - bg.v_out) - sum of
     // (colour . v_out) * weight over the splats behind -- what d(out)/d(alpha_i) multiplies by 1/(1-alpha_i)
     const size_t pix = inside ? (size_t)py * width + px : 0;
-    const int binf = inside ? last_id[pix] : -1;
+    const int binf = inside ? last_id[pix] : -1;   // last list position the pixel saw while live
     const float Tf = inside ? final_T[pix] : 1.f;
     float T = Tf;
     float vout[CH], bgdot = 0.f;
@@ -295,65 +514,44 @@ __global__ __launch_bounds__(kBlock) void composite_bwd_kernel(
     int mx = binf;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
-    const int qmax = __builtin_amdgcn_readfirstlane(mx);  // last record any pixel of this quadrant blended
+    const int qmax = __builtin_amdgcn_readfirstlane(mx);  // last position any pixel of this quadrant saw
     if (t == 0) s_max_last = -1;
-    stage_null_record(st, t);
     __syncthreads();
     if (lane == 0 && qmax >= 0) atomicMax(&s_max_last, qmax);
     __syncthreads();
     const int top0 = s_max_last + 1;  // records at or beyond top0 touched no pixel of this tile
 
+    GSA_TRACE_MARK(0);
     for (int top = top0; top > start; top -= kBatch) {
         const int cnt = min(kBatch, top - start);
         __syncthreads();
+        GSA_TRACE_MARK(5);
         // slot t holds record top-1-t: the list walks slots upwards = records backwards
-        if (t < cnt) stage_record(st, t, top - 1 - t, splat, sorted_gid, tx, ty);
-        __syncthreads();
+        bool cap = false;
+        if (t < cnt) cap = stage_record(st, t, top - 1 - t, splat, sorted_gid, tx, ty);
+        GSA_TRACE_MARK(1);
+        const bool any_cap = __syncthreads_or(cap);
+        GSA_TRACE_MARK(2);
         // slots below `first` hold records behind this quadrant's last one
-        const int n = build_list(st, q, lane, max(0, top - 1 - qmax), cnt);
-        for (int i = 0; i < n; i += 2) {
-            const uint32_t o2 = *reinterpret_cast<const uint32_t *>(&st.list[q][i]);
-            const uint32_t off[2] = {o2 & 0xFFFFu, o2 >> 16};
-            float v[2 * NF];
-            uint32_t gid[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const float4 *p = rec_at(st, off[e]);
-                const float4 q0 = p[0], q1 = p[1], q2 = p[2];
-                gid[e] = __float_as_uint(q2.w);
-                const float dx = q0.x - pxf, dy = q0.y - pyf;
-                const float s = scaled_sigma(q0, q1, dx, dy);
-                const float raw = q1.y * __builtin_amdgcn_exp2f(-s);
-                float a = fminf(GSA_MAX_ALPHA, raw);
-                a = (s >= 0.f && __float_as_int(q2.z) <= binf) ? a : 0.f;   // the pixel stopped in front of it
-                a = (a >= GSA_ALPHA_THRESHOLD) ? a : 0.f;
-                // a == 0: ra = 1, fac = 0 -- T, Wd and the sums pass through unchanged, no selects needed
-                const float ra = __builtin_amdgcn_rcpf(1.f - a);
-                const float Tn = T * ra;             // transmittance in front of this splat
-                const float fac = a * Tn;
-                float cv = q1.z * vout[0] + q1.w * vout[1] + q2.x * vout[2];
-                if (CH == 4) cv += q2.y * vout[CH - 1];
-                const float v_a = Tn * cv + ra * Wd;
-                Wd -= fac * cv;
-                T = Tn;
-                // blended and not capped at 0.999  <=>  a == raw
-                const float u = (a == raw) ? -raw * v_a : 0.f;    // d loss / d sigma
-                const float udx = u * dx, udy = u * dy;
-                v[0 + e] = udx; v[2 + e] = udy; v[4 + e] = udx * dx; v[6 + e] = udx * dy; v[8 + e] = udy * dy;
-                v[10 + e] = u;
-                v[12 + e] = fac * vout[0]; v[14 + e] = fac * vout[1]; v[16 + e] = fac * vout[2];
-                if (CH == 4) v[18 + e] = fac * vout[CH - 1];
-            }
-            // one transpose-reduce and one atomic instruction (two 64-B requests) per PAIR of records
-            const float total = reduce_pair<NF>(v, lane);
-            const uint32_t g = my_rec1 ? gid[1] : gid[0];
-            if (my_add && (!my_rec1 || off[1] != (uint32_t)kNull))
-                atomicAdd(v_splat + (size_t)g * GSA_SPLAT_STRIDE + my_field, total);
-        }
+        const int n = build_list(st, q, lane, max(0, top - 1 - qmax), cnt, [&](int slot) { return top - 1 - slot; });
+        GSA_TRACE_MARK(3);
+        GSA_TRACE_COUNT(n);
+        if (any_cap)
+            walk_bwd<CH, F4, true>(st, q, n, lane, pxf, pyf, binf, vout, T, Wd, my_field, my_add, my_rec1, v_splat);
+        else
+            walk_bwd<CH, F4, false>(st, q, n, lane, pxf, pyf, binf, vout, T, Wd, my_field, my_add, my_rec1, v_splat);
+        GSA_TRACE_MARK(4);
     }
+    GSA_TRACE_END(1, tile, top0 - start);
 }
 
 }  // namespace
+
+#ifdef GSA_TRACE
+extern "C" int gsa_debug_set_trace(unsigned long long *buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &buf, sizeof(buf));
+}
+#endif
 
 extern "C" int gsa_composite_fwd(int width, int height, int channels, const float *splat,
                                  const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,

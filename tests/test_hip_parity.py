@@ -176,7 +176,13 @@ def test_projection_and_binning_match_oracle(gsa, deg):
         assert torch.equal(m1["tiles_per_gauss"].cpu(), m0["tiles_per_gauss"])
         assert torch.equal(m1["flatten_ids"].cpu(), m0["flatten_ids"])
         assert torch.equal(m1["isect_offsets"].cpu(), m0["isect_offsets"])
-        assert torch.equal(m1["isect_ids"].cpu(), m0["isect_ids"])
+        # 64-bit keys: the tile half must agree exactly; the depth half holds fp32 bits of camera-space z, whose last
+        # bits depend on how t + R.m is fused (cancellation when the camera sits inside the cloud) -- compare as floats
+        ids1, ids0 = m1["isect_ids"].cpu(), m0["isect_ids"]
+        assert torch.equal(ids1 >> 32, ids0 >> 32)
+        z1 = (ids1 & 0xFFFFFFFF).to(torch.int32).view(torch.float32)
+        z0 = (ids0 & 0xFFFFFFFF).to(torch.int32).view(torch.float32)
+        assert float((z1 - z0).abs().max()) <= 5e-5 * float(z0.abs().max())
     k3 = (~m0["ambiguous"]).float()[..., None]
     assert float(1 - k3.mean()) <= MAX_AMB_FRACTION
     assert _rel(r1.cpu() * k3, r0 * k3) < REL_TOL and _rel(a1.cpu() * k3, a0 * k3) < REL_TOL

@@ -5,7 +5,7 @@ name=$1; shift
 R=$(cd $(dirname $0)/.. && pwd); C=$R/3d-gaussian-splatting_amd/csrc; L=$R/3d-gaussian-splatting_amd/lib; T=/tmp/gsa_var_$name
 mkdir -p $T
 for f in abi project sort composite; do
-  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -munsafe-fp-atomics -I$R/include -I$C "$@" -c $C/$f.hip -o $T/$f.o &
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -munsafe-fp-atomics -fno-slp-vectorize -I$R/include -I$C "$@" -c $C/$f.hip -o $T/$f.o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $T/*.o -o $L/ab_$name.so
