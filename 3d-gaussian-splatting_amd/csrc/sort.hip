@@ -22,11 +22,19 @@ constexpr int kSortItems = 16;                          // keys per thread
 constexpr int kSortChunk = kSortThreads * kSortItems;   // keys per block
 constexpr int kRadix = 256;
 
+// Item counts may live on the device (the record count M is produced by the scan and the host does not wait for
+// it): kernels are launched for a CAPACITY and clamp to *n_dev when it is given.  Uniform address -> scalar load.
+__device__ __forceinline__ int resolve_count(int n_cap, const uint32_t *__restrict__ n_dev) {
+    return n_dev ? (int)min((uint32_t)n_cap, *n_dev) : n_cap;
+}
+
 // ---- pass 1: per-block digit histogram, written digit-major: hist[d * nblocks + block] -------------
-__global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(int n, const uint32_t *__restrict__ keys,
+__global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(int n_cap, const uint32_t *__restrict__ n_dev,
+                                                                  const uint32_t *__restrict__ keys,
                                                                   int shift, int nblocks,
                                                                   uint32_t *__restrict__ hist) {
     __shared__ uint32_t h[kRadix];
+    const int n = resolve_count(n_cap, n_dev);
     h[threadIdx.x] = 0;
     __syncthreads();
     long base = (long)blockIdx.x * kSortChunk;
@@ -85,7 +93,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scan_rows_kernel(int nbloc
 // instead of one 4-B store per 64-B line (the low-digit pass of a tile sort scatters neighbouring records to
 // 256 different buckets).
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
-    int n, const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+    int n_cap, const uint32_t *__restrict__ n_dev, const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int shift, int nblocks,
     const uint32_t *__restrict__ hist, const uint32_t *__restrict__ digit_total) {
     __shared__ uint32_t scratch[4];
@@ -96,6 +104,8 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     __shared__ uint32_t wave_off[4][kRadix];  // per round: first block-local slot for wave w, digit d
     __shared__ uint32_t s_key[kSortChunk], s_val[kSortChunk];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = resolve_count(n_cap, n_dev);
+    if ((long)blockIdx.x * kSortChunk >= n) return;   // whole block beyond the live items (capacity launch)
 
     {   // digit t: global base (exclusive scan of digit totals + offset of this block inside the digit) and
         // block-local base (exclusive scan of this block's own digit counts, recovered from the scanned rows)
@@ -227,9 +237,11 @@ __global__ __launch_bounds__(kSortThreads) void scan_final_kernel(int n, const i
 __global__ __launch_bounds__(kSortThreads) void tile_emit_kernel(
     int n, const uint32_t *__restrict__ order, const uint32_t *__restrict__ offsets,
     const float *__restrict__ splat, const int32_t *__restrict__ radii, int tile_w, int tile_h, int n_tiles,
-    int cull_mode, uint32_t m_capacity, uint32_t *__restrict__ isect_tile, uint32_t *__restrict__ isect_gid) {
+    int cull_mode, uint32_t m_cap, const uint32_t *__restrict__ m_dev, uint32_t *__restrict__ isect_tile,
+    uint32_t *__restrict__ isect_gid) {
     long k = (long)blockIdx.x * kSortThreads + threadIdx.x;
     if (k >= n) return;
+    const uint32_t m_capacity = m_dev ? min(m_cap, *m_dev) : m_cap;
     uint32_t g = order[k];
     int rx = radii[2 * (long)g], ry = radii[2 * (long)g + 1];
     if (rx <= 0 || ry <= 0) return;
@@ -266,8 +278,10 @@ __global__ __launch_bounds__(kSortThreads) void tile_emit_kernel(
 __global__ __launch_bounds__(kSortThreads) void tile_emit_coop_kernel(
     int n, const uint32_t *__restrict__ order, const uint32_t *__restrict__ offsets,
     const float *__restrict__ splat, const int32_t *__restrict__ radii, int tile_w, int tile_h,
-    uint32_t m_total, uint32_t *__restrict__ isect_tile, uint32_t *__restrict__ isect_gid) {
+    uint32_t m_cap, const uint32_t *__restrict__ m_dev, uint32_t *__restrict__ isect_tile,
+    uint32_t *__restrict__ isect_gid) {
     __shared__ uint32_t s_start[4][64 + 1];
+    const uint32_t m_total = m_dev ? min(m_cap, *m_dev) : m_cap;
     __shared__ uint32_t s_gid[4][64];
     __shared__ int s_x0[4][64], s_y0[4][64], s_w[4][64];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -278,7 +292,7 @@ __global__ __launch_bounds__(kSortThreads) void tile_emit_coop_kernel(
     int x0 = 0, y0 = 0, wd = 1;
     if (k < n) {
         g = order[k];
-        begin = offsets[k];
+        begin = min(offsets[k], m_total);   // clamp: with a device-side count the buffers may be too small (caller re-runs)
         const int rx = radii[2 * (long)g], ry = radii[2 * (long)g + 1];
         if (rx > 0 && ry > 0) {
             const float2 m2 = *reinterpret_cast<const float2 *>(splat + (long)g * GSA_SPLAT_STRIDE);
@@ -288,7 +302,7 @@ __global__ __launch_bounds__(kSortThreads) void tile_emit_coop_kernel(
     }
     const uint32_t wave_base = __builtin_amdgcn_readfirstlane(begin);
     const long k_end = min((long)n, k0 + 64);
-    const uint32_t wave_end = k_end < n ? offsets[k_end] : m_total;   // uniform address
+    const uint32_t wave_end = k_end < n ? min(offsets[k_end], m_total) : m_total;   // uniform address
     s_start[w][lane] = begin - wave_base;
     if (lane == 0) s_start[w][64] = 0xFFFFFFFFu;
     s_gid[w][lane] = g; s_x0[w][lane] = x0; s_y0[w][lane] = y0; s_w[w][lane] = wd;
@@ -312,8 +326,10 @@ __global__ __launch_bounds__(kSortThreads) void tile_emit_coop_kernel(
 
 // tile_offsets[t] = first index i with sorted_tile[i] >= t,  t in [0, n_tiles]
 // tile_offsets[t] = first index i with sorted_tile[i] >= t,  t in [0, n_tiles]
-__global__ __launch_bounds__(kSortThreads) void tile_offsets_kernel(uint32_t m, const uint32_t *__restrict__ sorted_tile,
+__global__ __launch_bounds__(kSortThreads) void tile_offsets_kernel(uint32_t m_cap, const uint32_t *__restrict__ m_dev,
+                                                                    const uint32_t *__restrict__ sorted_tile,
                                                                     int n_tiles, int32_t *__restrict__ tile_offsets) {
+    const uint32_t m = m_dev ? min(m_cap, *m_dev) : m_cap;
     long i = (long)blockIdx.x * kSortThreads + threadIdx.x;
     if (i > m) return;
     long lo = (i == 0) ? 0 : (long)sorted_tile[i - 1] + 1;
@@ -323,8 +339,10 @@ __global__ __launch_bounds__(kSortThreads) void tile_offsets_kernel(uint32_t m, 
 
 // the same by binary search, one thread per tile: for long lists (M >> n_tiles) 27 dependent loads per tile beat
 // streaming all M keys
-__global__ __launch_bounds__(kSortThreads) void tile_offsets_bsearch_kernel(uint32_t m, const uint32_t *__restrict__ sorted_tile,
+__global__ __launch_bounds__(kSortThreads) void tile_offsets_bsearch_kernel(uint32_t m_cap, const uint32_t *__restrict__ m_dev,
+                                                                            const uint32_t *__restrict__ sorted_tile,
                                                                             int n_tiles, int32_t *__restrict__ tile_offsets) {
+    const uint32_t m = m_dev ? min(m_cap, *m_dev) : m_cap;
     int t = blockIdx.x * kSortThreads + threadIdx.x;
     if (t > n_tiles) return;
     uint32_t lo = 0, hi = m;  // first index with key >= t
@@ -347,9 +365,9 @@ extern "C" size_t gsa_sort_workspace_bytes(int n) {
     return words * sizeof(uint32_t);
 }
 
-extern "C" int gsa_sort_pairs_u32(int n, const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out,
-                                  uint32_t *vals_out, uint32_t *keys_tmp, uint32_t *vals_tmp, int begin_bit,
-                                  int end_bit, void *workspace, size_t workspace_bytes, gsa_stream_t stream) {
+static int sort_pairs_impl(int n, const uint32_t *n_dev, const uint32_t *keys_in, const uint32_t *vals_in,
+                           uint32_t *keys_out, uint32_t *vals_out, uint32_t *keys_tmp, uint32_t *vals_tmp, int begin_bit,
+                           int end_bit, void *workspace, size_t workspace_bytes, gsa_stream_t stream) {
     GSA_RETURN_IF(n < 0 || begin_bit < 0 || end_bit > 32 || end_bit <= begin_bit, GSA_ERR_INVALID_ARGUMENT);
     if (n == 0) return GSA_OK;
     GSA_RETURN_IF(!keys_in || !keys_out || !vals_out || !keys_tmp || !vals_tmp || !workspace, GSA_ERR_INVALID_ARGUMENT);
@@ -366,16 +384,32 @@ extern "C" int gsa_sort_pairs_u32(int n, const uint32_t *keys_in, const uint32_t
         uint32_t *kout = to_out ? keys_out : keys_tmp;
         uint32_t *vout = to_out ? vals_out : vals_tmp;
         int shift = begin_bit + 8 * p;
-        radix_hist_kernel<<<nblocks, kSortThreads, 0, s>>>(n, kin, shift, nblocks, hist);
+        radix_hist_kernel<<<nblocks, kSortThreads, 0, s>>>(n, n_dev, kin, shift, nblocks, hist);
         GSA_LAUNCH_CHECK();
         radix_scan_rows_kernel<<<kRadix, kSortThreads, 0, s>>>(nblocks, hist, digit_total);
         GSA_LAUNCH_CHECK();
-        radix_scatter_kernel<<<nblocks, kSortThreads, 0, s>>>(n, kin, vin, kout, vout, shift, nblocks, hist, digit_total);
+        radix_scatter_kernel<<<nblocks, kSortThreads, 0, s>>>(n, n_dev, kin, vin, kout, vout, shift, nblocks, hist, digit_total);
         GSA_LAUNCH_CHECK();
         kin = kout;
         vin = vout;
     }
     return GSA_OK;
+}
+
+extern "C" int gsa_sort_pairs_u32(int n, const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out,
+                                  uint32_t *vals_out, uint32_t *keys_tmp, uint32_t *vals_tmp, int begin_bit,
+                                  int end_bit, void *workspace, size_t workspace_bytes, gsa_stream_t stream) {
+    return sort_pairs_impl(n, nullptr, keys_in, vals_in, keys_out, vals_out, keys_tmp, vals_tmp, begin_bit, end_bit,
+                           workspace, workspace_bytes, stream);
+}
+
+extern "C" int gsa_sort_pairs_u32_dev(int capacity, const uint32_t *n_dev, const uint32_t *keys_in,
+                                      const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out,
+                                      uint32_t *keys_tmp, uint32_t *vals_tmp, int begin_bit, int end_bit,
+                                      void *workspace, size_t workspace_bytes, gsa_stream_t stream) {
+    GSA_RETURN_IF(!n_dev, GSA_ERR_INVALID_ARGUMENT);
+    return sort_pairs_impl(capacity, n_dev, keys_in, vals_in, keys_out, vals_out, keys_tmp, vals_tmp, begin_bit,
+                           end_bit, workspace, workspace_bytes, stream);
 }
 
 extern "C" int gsa_scan_tiles(int n, const int32_t *tiles_touched, const uint32_t *order, uint32_t *offsets,
@@ -400,9 +434,9 @@ extern "C" int gsa_scan_tiles(int n, const int32_t *tiles_touched, const uint32_
     return GSA_OK;
 }
 
-extern "C" int gsa_tile_emit(int n, const uint32_t *order, const uint32_t *offsets, const float *splat,
-                             const int32_t *radii, int width, int height, int cull_mode, uint32_t m_capacity,
-                             uint32_t *isect_tile, uint32_t *isect_gid, gsa_stream_t stream) {
+static int tile_emit_impl(int n, const uint32_t *order, const uint32_t *offsets, const float *splat,
+                          const int32_t *radii, int width, int height, int cull_mode, uint32_t m_capacity,
+                          const uint32_t *m_dev, uint32_t *isect_tile, uint32_t *isect_gid, gsa_stream_t stream) {
     GSA_RETURN_IF(n < 0 || width <= 0 || height <= 0, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(cull_mode != 0 && cull_mode != 1, GSA_ERR_INVALID_ARGUMENT);
     if (n == 0 || m_capacity == 0) return GSA_OK;
@@ -410,27 +444,55 @@ extern "C" int gsa_tile_emit(int n, const uint32_t *order, const uint32_t *offse
     int tile_w = gsa_div_up(width, GSA_TILE_SIZE), tile_h = gsa_div_up(height, GSA_TILE_SIZE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (cull_mode == 0 && tile_w < (1 << 15) && tile_h < (1 << 15))
-        tile_emit_coop_kernel<<<gsa_div_up(n, kSortThreads), kSortThreads, 0, s>>>(n, order, offsets, splat, radii, tile_w,
-                                                                                  tile_h, m_capacity, isect_tile, isect_gid);
+        tile_emit_coop_kernel<<<gsa_div_up(n, kSortThreads), kSortThreads, 0, s>>>(
+            n, order, offsets, splat, radii, tile_w, tile_h, m_capacity, m_dev, isect_tile, isect_gid);
     else
         tile_emit_kernel<<<gsa_div_up(n, kSortThreads), kSortThreads, 0, s>>>(
-            n, order, offsets, splat, radii, tile_w, tile_h, tile_w * tile_h, cull_mode, m_capacity, isect_tile, isect_gid);
+            n, order, offsets, splat, radii, tile_w, tile_h, tile_w * tile_h, cull_mode, m_capacity, m_dev, isect_tile,
+            isect_gid);
+    GSA_LAUNCH_CHECK();
+    return GSA_OK;
+}
+
+extern "C" int gsa_tile_emit(int n, const uint32_t *order, const uint32_t *offsets, const float *splat,
+                             const int32_t *radii, int width, int height, int cull_mode, uint32_t m_capacity,
+                             uint32_t *isect_tile, uint32_t *isect_gid, gsa_stream_t stream) {
+    return tile_emit_impl(n, order, offsets, splat, radii, width, height, cull_mode, m_capacity, nullptr, isect_tile,
+                          isect_gid, stream);
+}
+
+extern "C" int gsa_tile_emit_dev(int n, const uint32_t *order, const uint32_t *offsets, const float *splat,
+                                 const int32_t *radii, int width, int height, int cull_mode, uint32_t m_capacity,
+                                 const uint32_t *m_dev, uint32_t *isect_tile, uint32_t *isect_gid,
+                                 gsa_stream_t stream) {
+    GSA_RETURN_IF(!m_dev, GSA_ERR_INVALID_ARGUMENT);
+    return tile_emit_impl(n, order, offsets, splat, radii, width, height, cull_mode, m_capacity, m_dev, isect_tile,
+                          isect_gid, stream);
+}
+
+static int tile_offsets_impl(uint32_t m, const uint32_t *m_dev, const uint32_t *sorted_tile, int n_tiles,
+                             int32_t *tile_offsets, gsa_stream_t stream) {
+    GSA_RETURN_IF(n_tiles <= 0 || !tile_offsets, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(m > 0 && !sorted_tile, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(m >= 0x7FFFFFFFu, GSA_ERR_UNSUPPORTED);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((long long)m > 1024LL * n_tiles)
+        tile_offsets_bsearch_kernel<<<gsa_div_up(n_tiles + 1, kSortThreads), kSortThreads, 0, s>>>(
+            m, m_dev, sorted_tile, n_tiles, tile_offsets);
+    else
+        tile_offsets_kernel<<<gsa_div_up((long long)m + 1, kSortThreads), kSortThreads, 0, s>>>(
+            m, m_dev, sorted_tile, n_tiles, tile_offsets);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }
 
 extern "C" int gsa_tile_offsets(uint32_t m, const uint32_t *sorted_tile, int n_tiles, int32_t *tile_offsets,
                                 gsa_stream_t stream) {
-    GSA_RETURN_IF(n_tiles <= 0 || !tile_offsets, GSA_ERR_INVALID_ARGUMENT);
-    GSA_RETURN_IF(m > 0 && !sorted_tile, GSA_ERR_INVALID_ARGUMENT);
-    GSA_RETURN_IF(m >= 0x7FFFFFFFu, GSA_ERR_UNSUPPORTED);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if ((long long)m > 1024LL * n_tiles)
-        tile_offsets_bsearch_kernel<<<gsa_div_up(n_tiles + 1, kSortThreads), kSortThreads, 0, s>>>(m, sorted_tile, n_tiles,
-                                                                                                tile_offsets);
-    else
-        tile_offsets_kernel<<<gsa_div_up((long long)m + 1, kSortThreads), kSortThreads, 0, s>>>(m, sorted_tile, n_tiles,
-                                                                                               tile_offsets);
-    GSA_LAUNCH_CHECK();
-    return GSA_OK;
+    return tile_offsets_impl(m, nullptr, sorted_tile, n_tiles, tile_offsets, stream);
+}
+
+extern "C" int gsa_tile_offsets_dev(uint32_t m_capacity, const uint32_t *m_dev, const uint32_t *sorted_tile,
+                                    int n_tiles, int32_t *tile_offsets, gsa_stream_t stream) {
+    GSA_RETURN_IF(!m_dev, GSA_ERR_INVALID_ARGUMENT);
+    return tile_offsets_impl(m_capacity, m_dev, sorted_tile, n_tiles, tile_offsets, stream);
 }

@@ -28,6 +28,9 @@ SIGNATURES = {
     "gsa_scan_tiles": (c_int, [c_int, P, P, P, P, P, c_size_t, P]),
     "gsa_tile_emit": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_uint32, P, P, P]),
     "gsa_tile_offsets": (c_int, [c_uint32, P, c_int, P, P]),
+    "gsa_sort_pairs_u32_dev": (c_int, [c_int, P, P, P, P, P, P, P, c_int, c_int, P, c_size_t, P]),
+    "gsa_tile_emit_dev": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_uint32, P, P, P, P]),
+    "gsa_tile_offsets_dev": (c_int, [c_uint32, P, P, c_int, P, P]),
     "gsa_composite_fwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P]),
     "gsa_composite_bwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P]),
     "gsa_project_bwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, P, P, P, P, P, P, P, P, P]),

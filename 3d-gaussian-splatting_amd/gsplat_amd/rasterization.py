@@ -34,9 +34,16 @@ class _RasterizeOneCamera(torch.autograd.Function):
 
         splat, radii, tiles_touched, depth_keys = S.project_fwd(means_c, quats_c, scales_c, opac_c, colors_c,
                                                                 sh_degree, view_c, K_c, width, height, cull_mode)
-        sorted_tile, sorted_gid, tile_offsets = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height,
-                                                            cull_mode)
-        render, alpha, final_T, last_id = S.composite_fwd(splat, sorted_gid, tile_offsets, bg_c, width, height, channels)
+        # the host does not wait for the record count: bins are sized for a remembered capacity, the compositor is
+        # queued, and only then is the count (long since copied back) checked -- a miss repeats with exact sizes
+        bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode)
+        render, alpha, final_T, last_id = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg_c, width,
+                                                          height, channels)
+        if not bins.finalize()[1]:
+            bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, exact=True)
+            render, alpha, final_T, last_id = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg_c,
+                                                              width, height, channels)
+        sorted_tile, sorted_gid, tile_offsets = bins.sorted_tile, bins.sorted_gid, bins.tile_offsets
 
         ctx.save_for_backward(means_c, quats_c, scales_c, opac_c, colors_c, view_c, K_c, bg_c, splat, radii,
                               sorted_gid, tile_offsets, final_T, last_id)

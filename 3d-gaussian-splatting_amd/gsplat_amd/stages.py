@@ -75,10 +75,10 @@ _PINNED = {}
 
 
 def _pinned_scalar(dev):
-    """One pinned int64 + event per device for the record-count read-back (allocated once)."""
+    """One pinned int32 + event per device for the record-count read-back (allocated once)."""
     key = (dev.type, dev.index)
     if key not in _PINNED:
-        _PINNED[key] = (torch.empty(1, dtype=torch.int64, pin_memory=True), torch.cuda.Event())
+        _PINNED[key] = (torch.empty(1, dtype=torch.int32, pin_memory=True), torch.cuda.Event())
     return _PINNED[key]
 
 
@@ -111,19 +111,63 @@ def sort_pairs(n: int, keys: torch.Tensor, vals: Optional[torch.Tensor], begin_b
     return k_out, v_out
 
 
-def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, cull_mode: int = 0):
+class TileBins:
+    """Result of ``bin_tiles``: record buffers sized for a CAPACITY, the live record count on the device, and
+    ``finalize()`` which the caller runs after it has queued the work that consumes the bins."""
+
+    def __init__(self, sorted_tile, sorted_gid, tile_offsets, capacity, m_known, key):
+        self._tile, self._gid, self.tile_offsets = sorted_tile, sorted_gid, tile_offsets
+        self.capacity, self._m, self._key = capacity, m_known, key
+
+    @property
+    def sorted_gid_buffer(self):   # what the compositor kernels read (they only follow tile_offsets)
+        return self._gid
+
+    def finalize(self):
+        """-> (M, ok).  Waits for the record count (copied to pinned memory right after the scan, long finished by
+        the time the compositor has been queued) and checks it against the capacity the kernels ran with."""
+        if self._m is None:
+            m_host, m_event = _pinned_scalar(self._gid.device)
+            m_event.synchronize()
+            self._m = int(m_host[0])
+            _note_count(self._key, self._m)
+        return self._m, self._m <= self.capacity
+
+    def __iter__(self):   # sorted_tile, sorted_gid, tile_offsets = bin_tiles(...)
+        return iter((self.sorted_tile, self.sorted_gid, self.tile_offsets))
+
+    @property
+    def sorted_tile(self):
+        return self._tile[:self.finalize()[0]]
+
+    @property
+    def sorted_gid(self):
+        return self._gid[:self.finalize()[0]]
+
+
+_CAPACITY = {}   # (device, N, W, H, cull_mode) -> record capacity the next call allocates (tracks the scene)
+
+
+def _note_count(key, m: int) -> None:
+    cap = _CAPACITY.get(key, 0)
+    if m > 0.9 * cap or m < 0.4 * cap:   # keep ~25 % head-room; shrink when the scene got much smaller
+        _CAPACITY[key] = max(4096, int(m * 1.25) + 1024)
+
+
+def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, cull_mode: int = 0,
+              exact: bool = False) -> TileBins:
     """Depth-order the gaussians, emit their tile records in that order, stable-sort the records by tile.
-    -> sorted_tile [M] i32, sorted_gid [M] i32, tile_offsets [n_tiles+1] i32.  One host read-back (M)."""
+    -> TileBins(sorted_tile, sorted_gid, tile_offsets [n_tiles+1] i32).
+
+    The record count M is only known on the device.  Steady state (a capacity is remembered per scene shape): all
+    kernels are queued for that capacity and read the live count from device memory, the host never waits; the
+    caller runs ``finalize()`` afterwards and repeats with ``exact=True`` if the capacity was too small.
+    First call / ``exact``: one host read-back of M sizes the buffers exactly."""
     dev, N = splat.device, splat.shape[0]
     tile_w, tile_h = tile_grid(width, height)
     n_tiles = tile_w * tile_h
     st = _stream()
-    # The record count M sizes the buffers below, so the host must read it back.  It does not depend on the
-    # depth order: reduce it right after projection, start an asynchronous copy to pinned memory, and only wait
-    # for it after the depth sort and the scan have been queued -- the GPU never idles on the read-back.
-    m_host, m_event = _pinned_scalar(dev)
-    m_host.copy_(tiles_touched.sum(dtype=torch.int64).reshape(1), non_blocking=True)
-    m_event.record()
+    key = (dev.type, dev.index, N, width, height, cull_mode)
     _, order = sort_pairs(N, depth_keys, None, 0, 32)  # ties keep index order; culled gaussians sort last
     offsets = torch.empty(N, dtype=torch.int32, device=dev)
     total = torch.empty(1, dtype=torch.int32, device=dev)
@@ -131,20 +175,35 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     _call("gsa_scan_tiles", lib.gsa_scan_tiles, N, _ptr(tiles_touched), _ptr(order), _ptr(offsets), _ptr(total),
           _ptr(ws), ws_bytes, st)
-    m_event.synchronize()
-    M = int(m_host[0])
-    isect_tile = torch.empty(M, dtype=torch.int32, device=dev)
-    isect_gid = torch.empty(M, dtype=torch.int32, device=dev)
-    _call("gsa_tile_emit", lib.gsa_tile_emit, N, _ptr(order), _ptr(offsets), _ptr(splat), _ptr(radii), width,
-          height, cull_mode, M, _ptr(isect_tile), _ptr(isect_gid), st)
+    m_host, m_event = _pinned_scalar(dev)
+    m_host.copy_(total, non_blocking=True)
+    m_event.record()
+    m_known = None
+    cap = None if exact else _CAPACITY.get(key)
+    if cap is None:
+        m_event.synchronize()
+        m_known = int(m_host[0]) & 0xFFFFFFFF
+        _note_count(key, m_known)
+        cap = m_known
+    isect_tile = torch.empty(cap, dtype=torch.int32, device=dev)
+    isect_gid = torch.empty(cap, dtype=torch.int32, device=dev)
+    _call("gsa_tile_emit", lib.gsa_tile_emit_dev, N, _ptr(order), _ptr(offsets), _ptr(splat), _ptr(radii), width,
+          height, cull_mode, cap, _ptr(total), _ptr(isect_tile), _ptr(isect_gid), st)
     tile_bits = max(1, math.ceil(math.log2(n_tiles + 1)))
-    if M > 0:
-        sorted_tile, sorted_gid = sort_pairs(M, isect_tile, isect_gid, 0, tile_bits)
+    if cap > 0:
+        sorted_tile = torch.empty(cap, dtype=torch.int32, device=dev)
+        sorted_gid = torch.empty(cap, dtype=torch.int32, device=dev)
+        k_tmp, v_tmp = torch.empty_like(sorted_tile), torch.empty_like(sorted_gid)
+        ws2_bytes = lib.gsa_sort_workspace_bytes(cap)
+        ws2 = torch.empty(ws2_bytes, dtype=torch.uint8, device=dev)
+        _call("gsa_sort_pairs_u32", lib.gsa_sort_pairs_u32_dev, cap, _ptr(total), _ptr(isect_tile), _ptr(isect_gid),
+              _ptr(sorted_tile), _ptr(sorted_gid), _ptr(k_tmp), _ptr(v_tmp), 0, tile_bits, _ptr(ws2), ws2_bytes, st)
     else:
         sorted_tile, sorted_gid = isect_tile, isect_gid
     tile_offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
-    _call("gsa_tile_offsets", lib.gsa_tile_offsets, M, _ptr(sorted_tile), n_tiles, _ptr(tile_offsets), st)
-    return sorted_tile, sorted_gid, tile_offsets
+    _call("gsa_tile_offsets", lib.gsa_tile_offsets_dev, cap, _ptr(total), _ptr(sorted_tile), n_tiles,
+          _ptr(tile_offsets), st)
+    return TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key)
 
 
 def composite_fwd(splat, sorted_gid, tile_offsets, background, width: int, height: int, channels: int):

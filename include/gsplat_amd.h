@@ -103,6 +103,21 @@ int gsa_tile_emit(int n, const uint32_t *order, const uint32_t *offsets, const f
                   const int32_t *radii, int width, int height, int cull_mode, uint32_t m_capacity,
                   uint32_t *isect_tile, uint32_t *isect_gid, gsa_stream_t stream);
 
+/* Device-side record count.  The record count M is produced on the device (gsa_scan_tiles' `total`).  These
+ * variants take a CAPACITY the buffers were sized for plus a pointer to the live count, so that the host can
+ * queue the whole forward pass without waiting for M; every kernel clamps to min(capacity, *count).  If the
+ * count turns out to exceed the capacity the results are truncated -- the caller checks (asynchronously) and
+ * re-runs with larger buffers. */
+int gsa_sort_pairs_u32_dev(int capacity, const uint32_t *n_dev, const uint32_t *keys_in,
+                           const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out,
+                           uint32_t *keys_tmp, uint32_t *vals_tmp, int begin_bit, int end_bit,
+                           void *workspace, size_t workspace_bytes, gsa_stream_t stream);
+int gsa_tile_emit_dev(int n, const uint32_t *order, const uint32_t *offsets, const float *splat,
+                      const int32_t *radii, int width, int height, int cull_mode, uint32_t m_capacity,
+                      const uint32_t *m_dev, uint32_t *isect_tile, uint32_t *isect_gid, gsa_stream_t stream);
+int gsa_tile_offsets_dev(uint32_t m_capacity, const uint32_t *m_dev, const uint32_t *sorted_tile,
+                         int n_tiles, int32_t *tile_offsets, gsa_stream_t stream);
+
 /* tile_offsets[t] = first record of tile t in the tile-sorted list, t in [0, n_tiles]; [n_tiles] = m. */
 int gsa_tile_offsets(uint32_t m, const uint32_t *sorted_tile, int n_tiles, int32_t *tile_offsets,
                      gsa_stream_t stream);

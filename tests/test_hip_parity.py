@@ -342,6 +342,28 @@ def test_cull_modes_give_identical_images(gsa):
     assert m1["flatten_ids"].numel() < m0["flatten_ids"].numel()
 
 
+def test_record_capacity_miss_is_repaired(gsa):
+    """The forward pass is queued for a remembered record capacity without waiting for the live count; when the
+    scene outgrows it the pass must notice and repeat with exact sizes -- same image, same record list."""
+    from gsplat_amd import scene, stages as S
+    W, H, N = 320, 200, 20_000
+    sc = _scene(N, seed=3, s_min=0.005, s_max=0.08)
+    args = [sc["means3D"], sc["rotations"], sc["scales"], sc["opacities"][:, 0], sc["shs"]]
+    args = [t.cuda() for t in args] + [scene.make_camera(1, 5)[None].cuda(), scene.make_intrinsics(W, H)[None].cuda()]
+    with torch.no_grad():
+        r0, a0, m0 = gsa.rasterization(*args, W, H, sh_degree=3)          # first call: exact sizes
+        ids0 = m0["flatten_ids"].clone()
+        r1, a1, m1 = gsa.rasterization(*args, W, H, sh_degree=3)          # steady state: capacity + device count
+        key = ("cuda", torch.cuda.current_device(), N, W, H, S.DEFAULT_CULL_MODE)
+        assert S._CAPACITY[key] >= m0["n_isects"]
+        S._CAPACITY[key] = m0["n_isects"] // 3                             # pretend the scene grew threefold
+        r2, a2, m2 = gsa.rasterization(*args, W, H, sh_degree=3)
+    for r, a, m in ((r1, a1, m1), (r2, a2, m2)):
+        assert torch.equal(r, r0) and torch.equal(a, a0)
+        assert m["n_isects"] == m0["n_isects"] and torch.equal(m["flatten_ids"], ids0)
+    assert S._CAPACITY[key] >= m0["n_isects"]                              # the miss re-learned the capacity
+
+
 @pytest.mark.parametrize("mode", ["D", "ED", "RGB+D", "RGB+ED"])
 def test_depth_render_modes(gsa, mode):
     from gsplat_amd import scene
