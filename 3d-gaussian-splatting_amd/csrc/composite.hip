@@ -1,31 +1,32 @@
 // composite.hip -- stage 3 (front-to-back alpha compositing) and stage 4 (reverse gradient sweep).
 //
-// Mapping (gfx950, wave64): one 256-thread workgroup per 16x16 tile, ONE WAVE PER 8x8 QUADRANT, one lane per
-// pixel (lane l -> (x = l & 7, y = l >> 3) inside the quadrant).
+// Mapping (gfx950, wave64): ONE INDEPENDENT WAVE PER 8x8 QUADRANT of a 16x16 tile, one lane per pixel
+// (lane l -> (x = l & 7, y = l >> 3) inside the quadrant), launched as one-wave workgroups: no workgroup
+// barrier anywhere, so while one wave waits for its gathers the others on the SIMD blend (a tile-wide
+// workgroup with barriers spent half its residency staging or waiting for its slowest quadrant:
+// tools/trace_tiles.py).  The four quadrants of a tile are dealt to the same XCD (they gather the same records).
 //
-//  * Staging: the workgroup gathers 256 sorted splat records at a time (one 64-B record per thread, one cache
-//    line, served from L2 / Infinity Cache) into a 48-B LDS image.  The staging thread also computes for ITS
-//    record the 4-bit mask of the quadrants whose pixel centres the alpha >= 1/255 ellipse can reach (exact
-//    ellipse-vs-rectangle test, conservative margin).
-//  * Compaction: each wave turns the mask bits of its own quadrant into a compacted LIST of LDS record offsets
-//    (ballot + mbcnt, 16-bit entries).  A record that cannot touch the quadrant costs the wave nothing; about
-//    45 % of (quadrant, record) pairs survive.  Results are identical to the plain per-pixel loop: a skipped
-//    pair fails the alpha test at every pixel of the quadrant anyway.
-//  * Walk: one 8-B LDS broadcast yields four list entries; each record is three ds_read_b128 broadcasts.  The
-//    blend body has NO scalar mask logic (the CU's single scalar unit was the forward's bottleneck when the
-//    walk was an s_ff1 bit scan with s_and-combined predicates): a rejected record is blended with alpha = 0,
-//    per-pixel termination lives in the sign of T (negative = finished).  A wave leaves the loop when its 64
-//    pixels are done (one ballot per four records), the workgroup stops staging when all 256 are.
+//  * Staging: the wave gathers 64 sorted splat records at a time (one 64-B record per lane, one cache line,
+//    served from L2 / Infinity Cache) into its own 48-B-per-record LDS image, and each lane tests whether the
+//    alpha >= 1/255 ellipse of ITS record can reach a pixel centre of the quadrant (ellipse-vs-rectangle,
+//    conservative margin).  The gathers are software-pipelined two batches deep in registers (gaussian ids of
+//    batch j+2 and records of batch j+1 are in flight while batch j is blended).
+//  * Compaction: ballot + mbcnt turn the 64 test bits into a compacted LIST of LDS record offsets.  A record
+//    that cannot touch the quadrant costs the wave nothing; about 45 % of (quadrant, record) pairs survive.
+//    Results are identical to the plain per-pixel loop: a skipped pair fails the alpha test at every pixel
+//    of the quadrant anyway.
+//  * Walk: one 8-B LDS broadcast yields four list entries; each record is three LDS broadcasts.  The blend body
+//    has no scalar mask logic and, in the common case, no per-record select at all (optimistic group of four;
+//    see walk_fwd).  A wave stops as soon as its 64 pixels are finished.
 //  * Backward: records are taken in PAIRS; the 2 x 9 (10) per-pixel moment contributions are summed over the
-//    wave by one transpose-reduce (v_permlane32_swap / v_permlane16_swap / select + DPP: ~22 VALU per record
-//    instead of ~55 for per-value butterflies) and added with ONE atomic instruction whose active lanes cover
-//    the two 64-B gradient records.  The sweep accumulates raw moments of u = dL/dsigma; project_bwd turns
-//    them into mean / conic / opacity gradients once per gaussian.
+//    wave by one transpose-reduce (v_permlane32_swap / v_permlane16_swap / DPP adds with bank masks: ~22 VALU
+//    per record instead of ~55 for per-value butterflies) and added with ONE atomic instruction whose active
+//    lanes cover the two 64-B gradient records.  The sweep accumulates raw moments of u = dL/dsigma;
+//    project_bwd turns them into mean / conic / opacity gradients once per gaussian.
 //
-// Why one wave per quadrant and not per tile: a lone wave issues a dependent instruction stream at a small
-// fraction of the SIMD rate, so the longest tile bounds the kernel.  A wave-per-tile version (4 pixels per
-// lane, same masks) had a 2.6x longer critical path; a persistent-wave variant pulling tiles from per-XCD
-// atomic queues was slower still.
+// Instruction costs that shaped the bodies (tools/inst_microbench.hip, cycles per wave64 instruction per SIMD):
+// v_fma/v_mul/v_add/v_and ~2.5, v_cmp/v_min/v_cndmask(sgpr)/DPP/SGPR-operand forms ~4.3, v_exp/v_rcp ~8,
+// v_permlane*_swap ~8.8, packed v_pk_* ~4.9 (no gain over two scalar ops; the library is built without SLP).
 //
 // Restates SURVEY.md Appendix A.5 (forward) and A.6 (backward) -- gsplat's rasterize_to_pixels behind
 // /root/reference/src/backends/gsplat_backend.py:168-182.
@@ -35,12 +36,12 @@
 namespace {
 
 constexpr int kTile = GSA_TILE_SIZE;
-constexpr int kBlock = 256;   // 4 waves = 4 quadrants
-constexpr int kBatch = 256;   // records staged per workgroup and step
+constexpr int kWave = 64;     // threads per workgroup = one wave = one quadrant
+constexpr int kBatch = 64;    // records staged per wave and step (one per lane)
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr uint32_t kSign = 0x80000000u;
 
-#ifdef GSA_TRACE   // developer build: per-workgroup timeline and phase times of wave 0 (tools/trace_tiles.py)
+#ifdef GSA_TRACE   // developer build: per-wave timeline and phase times (tools/trace_tiles.py)
 __device__ unsigned long long *g_trace = nullptr;
 struct TraceState {
     unsigned long long t0, mark, acc[8];
@@ -56,9 +57,9 @@ __device__ __forceinline__ void trace_mark(TraceState &ts, int k) {
     ts.acc[k] += now - ts.mark;
     ts.mark = now;
 }
-__device__ __forceinline__ void trace_end(const TraceState &ts, int kernel, int tile, int work) {
+__device__ __forceinline__ void trace_end(const TraceState &ts, int kernel, int unit, int work) {
     if (g_trace && threadIdx.x == 0) {
-        unsigned long long *r = g_trace + ((size_t)kernel * 65536 + tile) * 16;
+        unsigned long long *r = g_trace + ((size_t)kernel * 262144 + unit) * 16;
         r[0] = ts.t0;
         r[1] = __builtin_amdgcn_s_memrealtime();
         r[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32) |
@@ -71,89 +72,117 @@ __device__ __forceinline__ void trace_end(const TraceState &ts, int kernel, int 
 #define GSA_TRACE_BEGIN() TraceState trace_ts; trace_begin(trace_ts)
 #define GSA_TRACE_MARK(k) trace_mark(trace_ts, k)
 #define GSA_TRACE_COUNT(n) do { ++trace_ts.batches; trace_ts.visits += (n); } while (0)
-#define GSA_TRACE_END(kernel, tile, work) do { __syncthreads(); trace_end(trace_ts, kernel, tile, work); } while (0)
+#define GSA_TRACE_END(kernel, unit, work) trace_end(trace_ts, kernel, unit, work)
 #else
 #define GSA_TRACE_BEGIN()
 #define GSA_TRACE_MARK(k)
 #define GSA_TRACE_COUNT(n)
-#define GSA_TRACE_END(kernel, tile, work)
+#define GSA_TRACE_END(kernel, unit, work)
 #endif
 
-// Workgroup -> tile.  Workgroups are dealt round-robin over the 8 XCDs (speed only, never correctness):
-// give every XCD one contiguous band of tile rows so neighbouring tiles (which share splats) share an L2.
-// Injective from [0, 8 * chunk) onto itself; callers drop ids >= n_tiles.
-__device__ __forceinline__ int xcd_band_tile(int b, int n_tiles) {
+// Workgroup (= wave) -> (tile, quadrant).  Workgroups are dealt round-robin over the 8 XCDs (speed only, never
+// correctness): every XCD gets one contiguous band of tiles, and the four quadrants of a tile follow each other
+// on the same XCD so that their gathers of the same records meet in one L2.
+// Injective from [0, 32 * chunk) onto (tile, quadrant) pairs; callers drop tiles >= n_tiles.
+__device__ __forceinline__ void wave_unit(int b, int n_tiles, int &tile, int &q) {
     const int chunk = (n_tiles + 7) >> 3;
-    return (b & 7) * chunk + (b >> 3);
+    const int within = b >> 3;
+    q = within & 3;
+    tile = (b & 7) * chunk + (within >> 2);
 }
 
-// LDS image of the staged batch, F4 float4 per record (3 for RGB, 4 with the depth channel):
+// LDS image of the wave's staged batch, F4 float4 per record (3 for RGB, 4 with the depth channel):
 //   [0] mean.x  mean.y  log2e*a/2  log2e*b        (conic pre-scaled for exp2: s = log2e * sigma)
 //   [1] log2e*c/2  opacity  r  g
 //   [2] b  smax = log2e*ln(255 o)  (int) position in the sorted list  (uint) gaussian id
 //   [3] depth  -  -  -
-// Slots kBatch + q are per-wave NULL records (opacity 0: blend nothing) that pad wave q's list to a multiple of
-// four; their list position is set to that of the wave's last real entry.
-// list[q] = byte offsets of the records that can touch quadrant q, in walk order.  Each wave builds and reads
-// only its own list[q].
+// Slot kBatch is a NULL record (opacity 0: blends nothing) that pads the list to a multiple of four; its list
+// position is set to that of the last real entry.  list = byte offsets of the records that can touch the
+// quadrant, in walk order.
 template <int F4>
 struct Staged {
     static constexpr int kRecBytes = 16 * F4;
-    float4 rec[(kBatch + 4) * F4];
-    uint32_t mask[kBatch];
-    uint16_t list[4][kBatch + 8];
+    float4 rec[(kBatch + 1) * F4];
+    uint16_t list[kBatch + 8];
 };
 
-// Thread t stages sorted record `idx` (position in the sorted list) into slot t and computes its quadrant mask.
-// Returns true if the record's opacity exceeds the 0.999 alpha cap (then the walk must apply the cap).
-template <int F4>
-__device__ __forceinline__ bool stage_record(Staged<F4> &st, int t, int idx, const float *__restrict__ splat,
-                                             const uint32_t *__restrict__ sorted_gid, int tx, int ty) {
-    const uint32_t gi = sorted_gid[idx];
-    const float4 *row = reinterpret_cast<const float4 *>(splat + (size_t)gi * GSA_SPLAT_STRIDE);
-    const float4 r0 = row[0], r1 = row[1], r2 = row[2];
-    st.rec[F4 * t + 0] = make_float4(r0.x, r0.y, 0.5f * kLog2e * r0.z, kLog2e * r0.w);
-    st.rec[F4 * t + 1] = make_float4(0.5f * kLog2e * r1.x, r1.y, r1.z, r1.w);
-    st.rec[F4 * t + 2] = make_float4(r2.x, fmaxf(0.f, kLog2e * r2.z), __int_as_float(idx), __uint_as_float(gi));
-    if (F4 == 4) st.rec[F4 * t + 3] = make_float4(r2.y, 0.f, 0.f, 0.f);
-#ifdef GSA_EXP_MORE_MASK   // experiment: the mask computation twice
-    st.mask[t] = gsa_quadrant_mask(r0.x, r0.y, r0.z, r0.w, r1.x, r2.z, tx, ty) |
-                 (gsa_quadrant_mask(r0.x + 1e-3f, r0.y, r0.z, r0.w, r1.x, r2.z, tx, ty) & (uint32_t)(idx == -7));
-#else
-    st.mask[t] = gsa_quadrant_mask(r0.x, r0.y, r0.z, r0.w, r1.x, r2.z, tx, ty);
-#endif
-    return r1.y > GSA_MAX_ALPHA;
+// One lane's share of a batch in flight: the 64-B splat record of one sorted list entry.
+struct Row {
+    float4 r0, r1, r2;
+    uint32_t gid;
+};
+
+__device__ __forceinline__ Row load_row(const float *__restrict__ splat, uint32_t gid, bool valid) {
+    Row r;
+    r.gid = gid;
+    if (valid) {
+        const float4 *row = reinterpret_cast<const float4 *>(splat + (size_t)gid * GSA_SPLAT_STRIDE);
+        r.r0 = row[0]; r.r1 = row[1]; r.r2 = row[2];
+    } else {
+        r.r0 = r.r1 = r.r2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return r;
 }
 
-// Wave q compacts the slots [from, cnt) whose mask has bit q into list[q] (ballot + mbcnt) and pads it with
-// three null entries so the walk can run in groups of 4; returns the count (wave-uniform).  idx_of(slot) gives
-// the list position of a slot's record; the wave's null record inherits that of the last listed slot.
-template <int F4, typename IdxOf>
-__device__ __forceinline__ int build_list(Staged<F4> &st, int q, int lane, int from, int cnt, IdxOf idx_of) {
-    int n = 0, last_slot = 0;
-    for (int c = from >> 6; c * 64 < cnt; ++c) {
-        const int j = c * 64 + lane;
-        const bool hit = j >= from && j < cnt && ((st.mask[j] >> q) & 1u);
-        const unsigned long long b = __ballot(hit);
-        const int pos = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
-        if (hit) st.list[q][pos] = (uint16_t)(j * Staged<F4>::kRecBytes);
-        n += __builtin_popcountll(b);
-        if (b) last_slot = c * 64 + 63 - __builtin_clzll(b);
+// Can the alpha >= 1/255 region of a splat reach a pixel CENTRE of the 8x8 quadrant whose first centre is
+// (x0, y0)?  Smallest sigma over the rectangle of centres (convex quadratic: inside -> 0, else the best point of
+// the four edges) against ln(255 o) with a conservative margin.  The edge minimiser uses v_rcp: an error there
+// only moves the evaluated point ALONG the edge, which raises the value by a second-order amount the margin
+// covers.  Both kernels call this one function, so they always build the same lists.
+__device__ __forceinline__ bool quadrant_reach(float mx, float my, float a, float b, float c, float sig_max,
+                                               float x0, float y0) {
+    const float thr = sig_max * 1.0001f + 1e-4f;
+    const float x1 = x0 + 7.f, y1 = y0 + 7.f;
+    if (mx >= x0 && mx <= x1 && my >= y0 && my <= y1) return true;
+    const float nb_c = -b * __builtin_amdgcn_rcpf(c), nb_a = -b * __builtin_amdgcn_rcpf(a);
+    const float dlo = my - y1, dhi = my - y0, elo = mx - x1, ehi = mx - x0;
+    float best = 3.0e38f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float dx = e == 0 ? ehi : elo;                       // vertical edge x = x0 / x1
+        const float dy = fminf(dhi, fmaxf(dlo, nb_c * dx));
+        best = fminf(best, 0.5f * (a * dx * dx + c * dy * dy) + b * dx * dy);
+        const float ey = e == 0 ? dhi : dlo;                       // horizontal edge y = y0 / y1
+        const float ex = fminf(ehi, fmaxf(elo, nb_a * ey));
+        best = fminf(best, 0.5f * (a * ex * ex + c * ey * ey) + b * ex * ey);
     }
+    return best <= thr;
+}
+
+// Lane `lane` writes its record (list position idx) into slot `lane` of the wave's LDS image and tests it against
+// the quadrant; the wave compacts the hits into st.list.  Returns the number of listed records (wave-uniform);
+// `any_cap` tells whether a listed record's opacity exceeds the 0.999 alpha cap.
+template <int F4>
+__device__ __forceinline__ int stage_batch(Staged<F4> &st, int lane, const Row &row, bool valid, int idx, float qx0,
+                                           float qy0, bool &any_cap) {
+    const float4 r0 = row.r0, r1 = row.r1, r2 = row.r2;
+    st.rec[F4 * lane + 0] = make_float4(r0.x, r0.y, 0.5f * kLog2e * r0.z, kLog2e * r0.w);
+    st.rec[F4 * lane + 1] = make_float4(0.5f * kLog2e * r1.x, r1.y, r1.z, r1.w);
+    st.rec[F4 * lane + 2] = make_float4(r2.x, fmaxf(0.f, kLog2e * r2.z), __int_as_float(idx), __uint_as_float(row.gid));
+    if (F4 == 4) st.rec[F4 * lane + 3] = make_float4(r2.y, 0.f, 0.f, 0.f);
+    const bool hit = valid && quadrant_reach(r0.x, r0.y, r0.z, r0.w, r1.x, r2.z, qx0, qy0);
+    const unsigned long long b = __ballot(hit);
+    any_cap = __ballot(hit && r1.y > GSA_MAX_ALPHA) != 0ull;
+    int n = __builtin_popcountll(b);
 #ifdef GSA_EXP_NOWALK   // experiment: measure everything but the walk
     n = 0;
 #endif
-    if (lane < 3) st.list[q][n + lane] = (uint16_t)((kBatch + q) * Staged<F4>::kRecBytes);
+    const int pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
+    if (hit) st.list[pos] = (uint16_t)(lane * Staged<F4>::kRecBytes);
+    if (lane < 3) st.list[n + lane] = (uint16_t)(kBatch * Staged<F4>::kRecBytes);
+    // the null record: blends nothing, carries the list position of the last listed record
+    const int last_lane = b ? 63 - __builtin_clzll(b) : 0;
+    const int last_idx = __builtin_amdgcn_readlane(idx, last_lane);
     if (lane < F4) {
         float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lane == 2) z.z = __int_as_float(idx_of(last_slot));
-        st.rec[(kBatch + q) * F4 + lane] = z;
+        if (lane == 2) z.z = __int_as_float(last_idx);
+        st.rec[kBatch * F4 + lane] = z;
     }
     // LDS operations of one wave complete in order; this only stops the compiler from moving the reads up
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    return __builtin_amdgcn_readfirstlane(n);
+    return n;
 }
 
 // log2(e) * sigma at one pixel.  ONE expression with explicit fused steps for both kernels: the backward sweep
@@ -167,8 +196,7 @@ __device__ __forceinline__ float scaled_sigma(const float4 &q0, const float4 &q1
 // o exp(-sigma) < 1/255" is evaluated as ONE unsigned compare of the float bits, 0 <= s <= smax (a negative or
 // NaN s has a larger bit pattern than any smax >= 0); `off_bit` (0 or the sign bit) switches a lane off.
 // The 0.999 cap is only compiled in for batches that hold an opacity above it (exp2(-s) <= 1 otherwise keeps
-// alpha <= o).  Instruction costs that shaped this (tools/inst_microbench.hip): v_cmp / v_min / SGPR-operand
-// forms issue at half the rate of v_fma / v_mul / v_and.
+// alpha <= o).
 template <bool CLAMP>
 __device__ __forceinline__ float record_alpha(float s, float smax, float opacity, uint32_t off_bit, float &raw) {
     raw = opacity * __builtin_amdgcn_exp2f(-s);
@@ -200,19 +228,22 @@ struct FwdPixel {
 #ifndef GSA_FWD_WAVES
 #define GSA_FWD_WAVES 1      // minimum waves per SIMD the forward kernel is compiled for (register budget)
 #endif
+#ifndef GSA_BWD_WAVES
+#define GSA_BWD_WAVES 1      // the same for the backward kernel
+#endif
 
 // One group of G list entries starting at entry i: per-record alpha (0 where skipped / pixel finished), colours,
 // list positions.
 template <int CH, int F4, bool CLAMP, int G>
-__device__ __forceinline__ void eval_group(const Staged<F4> &st, int q, int i, float pxf, float pyf, uint32_t dead,
+__device__ __forceinline__ void eval_group(const Staged<F4> &st, int i, float pxf, float pyf, uint32_t dead,
                                            float (&a)[G], float (&col)[G][CH], int (&idx)[G]) {
     // one LDS broadcast gives G list entries
     uint32_t off[G];
     if (G == 4) {
-        const uint2 o4 = *reinterpret_cast<const uint2 *>(&st.list[q][i]);
+        const uint2 o4 = *reinterpret_cast<const uint2 *>(&st.list[i]);
         off[0] = o4.x & 0xFFFFu; off[1] = o4.x >> 16; off[G - 2] = o4.y & 0xFFFFu; off[G - 1] = o4.y >> 16;
     } else {
-        const uint32_t o2 = *reinterpret_cast<const uint32_t *>(&st.list[q][i]);
+        const uint32_t o2 = *reinterpret_cast<const uint32_t *>(&st.list[i]);
         off[0] = o2 & 0xFFFFu; off[1] = o2 >> 16;
     }
 #pragma unroll
@@ -222,21 +253,15 @@ __device__ __forceinline__ void eval_group(const Staged<F4> &st, int q, int i, f
         const float dx = q0.x - pxf, dy = q0.y - pyf;
         float raw;
         a[e] = record_alpha<CLAMP>(scaled_sigma(q0, q1, dx, dy), q2.y, q1.y, dead, raw);
-#ifdef GSA_EXP_MORE_VALU  // experiment: the alpha evaluation twice (wrong results)
-        {
-            float raw2;
-            a[e] += 1e-9f * record_alpha<CLAMP>(scaled_sigma(q0, q1, dy, dx), q2.y, q1.y, dead, raw2);
-        }
-#endif
         col[e][0] = q1.z; col[e][1] = q1.w; col[e][2] = q2.x;
         if (CH == 4) col[e][CH - 1] = p[F4 - 1].x;
         idx[e] = __float_as_int(q2.z);
     }
 }
 
-// Walks n list entries of quadrant q.  Returns false when all 64 pixels of the wave are finished.
+// Walks n list entries.  Returns false when all 64 pixels of the wave are finished.
 template <int CH, int F4, bool CLAMP>
-__device__ __forceinline__ bool walk_fwd(const Staged<F4> &st, int q, int n, float pxf, float pyf, FwdPixel<CH> &px) {
+__device__ __forceinline__ bool walk_fwd(const Staged<F4> &st, int n, float pxf, float pyf, FwdPixel<CH> &px) {
     constexpr int G = GSA_FWD_GROUP;
     int i = 0;
     while (i < n) {
@@ -245,7 +270,7 @@ __device__ __forceinline__ bool walk_fwd(const Staged<F4> &st, int q, int n, flo
         for (; i < n; i += G) {
             float a[G], col[G][CH], t[G + 1];
             int idx[G];
-            eval_group<CH, F4, CLAMP, G>(st, q, i, pxf, pyf, px.dead, a, col, idx);
+            eval_group<CH, F4, CLAMP, G>(st, i, pxf, pyf, px.dead, a, col, idx);
             t[0] = px.T;
 #pragma unroll
             for (int e = 0; e < G; ++e) t[e + 1] = t[e] * (1.f - a[e]);
@@ -265,7 +290,7 @@ __device__ __forceinline__ bool walk_fwd(const Staged<F4> &st, int q, int n, flo
         {
             float a[G], col[G][CH];
             int idx[G];
-            eval_group<CH, F4, CLAMP, G>(st, q, i, pxf, pyf, px.dead, a, col, idx);
+            eval_group<CH, F4, CLAMP, G>(st, i, pxf, pyf, px.dead, a, col, idx);
 #pragma unroll
             for (int e = 0; e < G; ++e) {
                 const float ae = px.dead ? 0.f : a[e];      // a pixel that stopped earlier in this group
@@ -287,7 +312,7 @@ __device__ __forceinline__ bool walk_fwd(const Staged<F4> &st, int q, int n, flo
 }
 
 template <int CH>
-__global__ __launch_bounds__(kBlock, GSA_FWD_WAVES) void composite_fwd_kernel(
+__global__ __launch_bounds__(kWave, GSA_FWD_WAVES) void composite_fwd_kernel(
     int width, int height, int tile_w, int n_tiles, const float *__restrict__ splat,
     const uint32_t *__restrict__ sorted_gid, const int32_t *__restrict__ tile_offsets,
     const float *__restrict__ background, float *__restrict__ render, float *__restrict__ alpha_out,
@@ -295,15 +320,16 @@ __global__ __launch_bounds__(kBlock, GSA_FWD_WAVES) void composite_fwd_kernel(
     constexpr int F4 = CH == 4 ? 4 : 3;
     __shared__ Staged<F4> st;
 
-    const int tile = xcd_band_tile(blockIdx.x, n_tiles);
+    int tile, q;
+    wave_unit(blockIdx.x, n_tiles, tile, q);
     if (tile >= n_tiles) return;
     GSA_TRACE_BEGIN();
-    const int t = threadIdx.x, lane = t & 63;
-    const int q = __builtin_amdgcn_readfirstlane(t >> 6);  // this wave's quadrant (wave-uniform -> scalar control flow)
+    const int lane = threadIdx.x;
     const int tx = tile % tile_w, ty = tile / tile_w;
-    const int px_ = tx * kTile + (q & 1) * 8 + (lane & 7), py_ = ty * kTile + (q >> 1) * 8 + (lane >> 3);
+    const int qx = tx * kTile + (q & 1) * 8, qy = ty * kTile + (q >> 1) * 8;
+    const int px_ = qx + (lane & 7), py_ = qy + (lane >> 3);
     const bool inside = px_ < width && py_ < height;
-    const float pxf = px_ + 0.5f, pyf = py_ + 0.5f;
+    const float pxf = px_ + 0.5f, pyf = py_ + 0.5f, qx0 = qx + 0.5f, qy0 = qy + 0.5f;
     const int start = __builtin_amdgcn_readfirstlane(tile_offsets[tile]);
     const int end = __builtin_amdgcn_readfirstlane(tile_offsets[tile + 1]);
 
@@ -311,25 +337,32 @@ __global__ __launch_bounds__(kBlock, GSA_FWD_WAVES) void composite_fwd_kernel(
     px.T = 1.f; px.Tend = 1.f; px.dead = inside ? 0u : kSign; px.last = -1;
 #pragma unroll
     for (int k = 0; k < CH; ++k) px.acc[k] = 0.f;
-    bool wave_live = __ballot(inside) != 0ull;
 
-    GSA_TRACE_MARK(0);
-    for (int base = start; base < end; base += kBatch) {
-        // also orders the previous batch's LDS reads before this batch's LDS writes
-        if (__syncthreads_count(px.dead == 0u) == 0) break;
-        GSA_TRACE_MARK(5);
-        bool cap = false;
-        if (base + t < end) cap = stage_record(st, t, base + t, splat, sorted_gid, tx, ty);
-        GSA_TRACE_MARK(1);
-        const bool any_cap = __syncthreads_or(cap);
-        GSA_TRACE_MARK(2);
-        if (!wave_live) continue;
-        const int n = build_list(st, q, lane, 0, min(kBatch, end - base), [&](int slot) { return base + slot; });
-        GSA_TRACE_MARK(3);
-        GSA_TRACE_COUNT(n);
-        wave_live = any_cap ? walk_fwd<CH, F4, true>(st, q, n, pxf, pyf, px)
-                            : walk_fwd<CH, F4, false>(st, q, n, pxf, pyf, px);
-        GSA_TRACE_MARK(4);
+    if (__ballot(inside) != 0ull && start < end) {
+        // software pipeline, two batches deep: ids of batch j+2 and records of batch j+1 are in flight while
+        // batch j is staged and blended (lane l of batch j holds list position start + 64 j + l)
+        auto load_gid = [&](int j) -> uint32_t {
+            const int p = start + j * kBatch + lane;
+            return p < end ? sorted_gid[p] : 0u;
+        };
+        uint32_t gid_next = load_gid(0);
+        Row row = load_row(splat, gid_next, start + lane < end);
+        gid_next = load_gid(1);
+        GSA_TRACE_MARK(0);
+        for (int base = start, j = 0; base < end; base += kBatch, ++j) {
+            const int idx = base + lane;
+            bool any_cap;
+            const int n = stage_batch(st, lane, row, idx < end, idx, qx0, qy0, any_cap);
+            GSA_TRACE_MARK(1);
+            // prefetch: the records of the next batch (their ids arrived during the previous walk), the ids after
+            row = load_row(splat, gid_next, idx + kBatch < end);
+            gid_next = load_gid(j + 2);
+            GSA_TRACE_COUNT(n);
+            const bool live = any_cap ? walk_fwd<CH, F4, true>(st, n, pxf, pyf, px)
+                                      : walk_fwd<CH, F4, false>(st, n, pxf, pyf, px);
+            GSA_TRACE_MARK(4);
+            if (!live) break;
+        }
     }
 
     if (inside) {
@@ -342,7 +375,7 @@ __global__ __launch_bounds__(kBlock, GSA_FWD_WAVES) void composite_fwd_kernel(
         last_id[pix] = px.last;
     }
     GSA_TRACE_MARK(6);
-    GSA_TRACE_END(0, tile, end - start);
+    GSA_TRACE_END(0, tile * 4 + q, end - start);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -412,14 +445,14 @@ __device__ __forceinline__ float reduce_pair(const float *v, int lane) {
     return r + dpp_mov<kQuadXor1>(r);
 }
 
-// Walks n list entries (records in REVERSE list order) of quadrant q, two per trip.
+// Walks n list entries (records in REVERSE list order), two per trip.
 template <int CH, int F4, bool CLAMP>
-__device__ __forceinline__ void walk_bwd(const Staged<F4> &st, int q, int n, int lane, float pxf, float pyf, int binf,
+__device__ __forceinline__ void walk_bwd(const Staged<F4> &st, int n, int lane, float pxf, float pyf, int binf,
                                          const float (&vout)[CH], float &T, float &Wd, int my_field, bool my_add,
                                          bool my_rec1, float *__restrict__ v_splat) {
     constexpr int NF = 6 + CH;
     for (int i = 0; i < n; i += 2) {
-        const uint32_t o2 = *reinterpret_cast<const uint32_t *>(&st.list[q][i]);
+        const uint32_t o2 = *reinterpret_cast<const uint32_t *>(&st.list[i]);
         const uint32_t off[2] = {o2 & 0xFFFFu, o2 >> 16};
         float v[2 * NF];
         uint32_t gid[2];
@@ -464,11 +497,8 @@ __device__ __forceinline__ void walk_bwd(const Staged<F4> &st, int q, int n, int
 //   [6..8] sum fac * v_out(rgb)   [9] sum fac * v_out(depth)
 // with u = d loss / d sigma at one pixel and d = mean2d - pixel: the raw moments of u.  Mean, conic and
 // opacity gradients are linear in them (project_bwd finishes that per gaussian, once, instead of per pixel).
-#ifndef GSA_BWD_WAVES
-#define GSA_BWD_WAVES 1      // minimum waves per SIMD the backward kernel is compiled for (register budget)
-#endif
 template <int CH>
-__global__ __launch_bounds__(kBlock, GSA_BWD_WAVES) void composite_bwd_kernel(
+__global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_kernel(
     int width, int height, int tile_w, int n_tiles, const float *__restrict__ splat,
     const uint32_t *__restrict__ sorted_gid, const int32_t *__restrict__ tile_offsets,
     const float *__restrict__ background, const float *__restrict__ final_T, const int32_t *__restrict__ last_id,
@@ -476,25 +506,37 @@ __global__ __launch_bounds__(kBlock, GSA_BWD_WAVES) void composite_bwd_kernel(
     constexpr int F4 = CH == 4 ? 4 : 3;
     constexpr int NF = 6 + CH;
     __shared__ Staged<F4> st;
-    __shared__ int s_max_last;
 
-    const int tile = xcd_band_tile(blockIdx.x, n_tiles);
+    int tile, q;
+    wave_unit(blockIdx.x, n_tiles, tile, q);
     if (tile >= n_tiles) return;
-    const int t = threadIdx.x, lane = t & 63;
-    const int q = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lane = threadIdx.x;
     const int start = __builtin_amdgcn_readfirstlane(tile_offsets[tile]);
     const int end = __builtin_amdgcn_readfirstlane(tile_offsets[tile + 1]);
     if (end <= start) return;
     GSA_TRACE_BEGIN();
     const int tx = tile % tile_w, ty = tile / tile_w;
-    const int px = tx * kTile + (q & 1) * 8 + (lane & 7), py = ty * kTile + (q >> 1) * 8 + (lane >> 3);
+    const int qx = tx * kTile + (q & 1) * 8, qy = ty * kTile + (q >> 1) * 8;
+    const int px = qx + (lane & 7), py = qy + (lane >> 3);
     const bool inside = px < width && py < height;
-    const float pxf = px + 0.5f, pyf = py + 0.5f;
+    const float pxf = px + 0.5f, pyf = py + 0.5f, qx0 = qx + 0.5f, qy0 = qy + 0.5f;
 
     // per pixel: T = transmittance behind the current record; Wd = T_final (v_alpha - bg.v_out) - sum of
     // (colour . v_out) * weight over the splats behind -- what d(out)/d(alpha_i) multiplies by 1/(1-alpha_i)
     const size_t pix = inside ? (size_t)py * width + px : 0;
     const int binf = inside ? last_id[pix] : -1;   // last list position the pixel saw while live
+    int mx = binf;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
+    const int qmax = __builtin_amdgcn_readfirstlane(mx);  // last position any pixel of this quadrant saw
+    if (qmax < start) return;                              // nothing was blended here (also covers qmax == -1)
+
+    // software pipeline as in the forward; lane l of batch j holds list position qmax - 64 j - l (walk order)
+    auto load_gid = [&](int j) -> uint32_t {
+        const int p = qmax - j * kBatch - lane;
+        return p >= start ? sorted_gid[p] : 0u;
+    };
+    uint32_t gid_next = load_gid(0);
     const float Tf = inside ? final_T[pix] : 1.f;
     float T = Tf;
     float vout[CH], bgdot = 0.f;
@@ -504,6 +546,8 @@ __global__ __launch_bounds__(kBlock, GSA_BWD_WAVES) void composite_bwd_kernel(
         if (background) bgdot += background[k] * vout[k];
     }
     float Wd = Tf * (((inside && v_alpha) ? v_alpha[pix] : 0.f) - bgdot);
+    Row row = load_row(splat, gid_next, qmax - lane >= start);
+    gid_next = load_gid(1);
 
     // which (field, record) total this lane holds after reduce_pair, and whether it is the lane that adds it
     const int my_field = (lane & 2) ? 8 + ((lane >> 4) & 1)
@@ -511,38 +555,22 @@ __global__ __launch_bounds__(kBlock, GSA_BWD_WAVES) void composite_bwd_kernel(
     const bool my_add = !(lane & 1) && my_field < NF && (!(lane & 2) || !(lane & 12));
     const bool my_rec1 = (lane & 32) != 0;
 
-    int mx = binf;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
-    const int qmax = __builtin_amdgcn_readfirstlane(mx);  // last position any pixel of this quadrant saw
-    if (t == 0) s_max_last = -1;
-    __syncthreads();
-    if (lane == 0 && qmax >= 0) atomicMax(&s_max_last, qmax);
-    __syncthreads();
-    const int top0 = s_max_last + 1;  // records at or beyond top0 touched no pixel of this tile
-
     GSA_TRACE_MARK(0);
-    for (int top = top0; top > start; top -= kBatch) {
-        const int cnt = min(kBatch, top - start);
-        __syncthreads();
-        GSA_TRACE_MARK(5);
-        // slot t holds record top-1-t: the list walks slots upwards = records backwards
-        bool cap = false;
-        if (t < cnt) cap = stage_record(st, t, top - 1 - t, splat, sorted_gid, tx, ty);
+    for (int top = qmax, j = 0; top >= start; top -= kBatch, ++j) {
+        const int idx = top - lane;
+        bool any_cap;
+        const int n = stage_batch(st, lane, row, idx >= start, idx, qx0, qy0, any_cap);
         GSA_TRACE_MARK(1);
-        const bool any_cap = __syncthreads_or(cap);
-        GSA_TRACE_MARK(2);
-        // slots below `first` hold records behind this quadrant's last one
-        const int n = build_list(st, q, lane, max(0, top - 1 - qmax), cnt, [&](int slot) { return top - 1 - slot; });
-        GSA_TRACE_MARK(3);
+        row = load_row(splat, gid_next, idx - kBatch >= start);
+        gid_next = load_gid(j + 2);
         GSA_TRACE_COUNT(n);
         if (any_cap)
-            walk_bwd<CH, F4, true>(st, q, n, lane, pxf, pyf, binf, vout, T, Wd, my_field, my_add, my_rec1, v_splat);
+            walk_bwd<CH, F4, true>(st, n, lane, pxf, pyf, binf, vout, T, Wd, my_field, my_add, my_rec1, v_splat);
         else
-            walk_bwd<CH, F4, false>(st, q, n, lane, pxf, pyf, binf, vout, T, Wd, my_field, my_add, my_rec1, v_splat);
+            walk_bwd<CH, F4, false>(st, n, lane, pxf, pyf, binf, vout, T, Wd, my_field, my_add, my_rec1, v_splat);
         GSA_TRACE_MARK(4);
     }
-    GSA_TRACE_END(1, tile, top0 - start);
+    GSA_TRACE_END(1, tile * 4 + q, qmax + 1 - start);
 }
 
 }  // namespace
@@ -561,14 +589,14 @@ extern "C" int gsa_composite_fwd(int width, int height, int channels, const floa
     GSA_RETURN_IF(!tile_offsets || !render || !alpha || !final_T || !last_id, GSA_ERR_INVALID_ARGUMENT);
     const int tile_w = gsa_div_up(width, kTile), tile_h = gsa_div_up(height, kTile);
     const int n_tiles = tile_w * tile_h;
-    const int grid = 8 * gsa_div_up(n_tiles, 8);
+    const int grid = 32 * gsa_div_up(n_tiles, 8);   // one wave per (tile, quadrant)
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (channels == 3)
-        composite_fwd_kernel<3><<<grid, kBlock, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid, tile_offsets,
-                                                       background, render, alpha, final_T, last_id);
+        composite_fwd_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid, tile_offsets,
+                                                      background, render, alpha, final_T, last_id);
     else
-        composite_fwd_kernel<4><<<grid, kBlock, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid, tile_offsets,
-                                                       background, render, alpha, final_T, last_id);
+        composite_fwd_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid, tile_offsets,
+                                                      background, render, alpha, final_T, last_id);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }
@@ -581,14 +609,14 @@ extern "C" int gsa_composite_bwd(int width, int height, int channels, const floa
     GSA_RETURN_IF(!tile_offsets || !final_T || !last_id || !v_render || !v_splat, GSA_ERR_INVALID_ARGUMENT);
     const int tile_w = gsa_div_up(width, kTile), tile_h = gsa_div_up(height, kTile);
     const int n_tiles = tile_w * tile_h;
-    const int grid = 8 * gsa_div_up(n_tiles, 8);
+    const int grid = 32 * gsa_div_up(n_tiles, 8);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (channels == 3)
-        composite_bwd_kernel<3><<<grid, kBlock, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid, tile_offsets,
-                                                       background, final_T, last_id, v_render, v_alpha, v_splat);
+        composite_bwd_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid, tile_offsets,
+                                                      background, final_T, last_id, v_render, v_alpha, v_splat);
     else
-        composite_bwd_kernel<4><<<grid, kBlock, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid, tile_offsets,
-                                                       background, final_T, last_id, v_render, v_alpha, v_splat);
+        composite_bwd_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid, tile_offsets,
+                                                      background, final_T, last_id, v_render, v_alpha, v_splat);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }

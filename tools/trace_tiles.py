@@ -1,4 +1,4 @@
-"""Developer aid: per-workgroup timeline of the two compositor kernels (needs a library built with -DGSA_TRACE:
+"""Developer aid: per-wave timeline of the two compositor kernels (needs a library built with -DGSA_TRACE:
 tools/build_variant.sh trace -DGSA_TRACE; GSPLAT_AMD_LIB=.../ab_trace.so python tools/trace_tiles.py)."""
 import ctypes, os, sys
 import numpy as np
@@ -14,7 +14,7 @@ sc = scene.make_scene(n, seed=0, sh_degree=deg)
 leaves = [sc[k].to(dev).requires_grad_(True) for k in ("means3D", "rotations", "scales", "opacities", "shs")]
 K = scene.make_intrinsics(W, H).to(dev)[None]; vm = scene.make_camera(0, 1).to(dev)[None]
 v = scene.make_v_render(W, H, seed=2).to(dev)[None]; bg = torch.zeros(1, 3, device=dev)
-buf = torch.zeros(2 * 65536 * 16, dtype=torch.int64, device=dev)
+buf = torch.zeros(2 * 262144 * 16, dtype=torch.int64, device=dev)
 def step():
     for t in leaves: t.grad = None
     r, a, meta = gsplat_amd.rasterization(leaves[0], leaves[1], leaves[2], leaves[3][:, 0], leaves[4], vm, K, W, H,
@@ -24,7 +24,7 @@ for _ in range(3): step()
 fn = _lib.lib.gsa_debug_set_trace; fn.argtypes = [ctypes.c_void_p]; fn.restype = ctypes.c_int
 assert fn(buf.data_ptr()) == 0
 torch.cuda.synchronize(); step(); torch.cuda.synchronize()
-tr = buf.cpu().numpy().reshape(2, 65536, 16)
+tr = buf.cpu().numpy().reshape(2, 262144, 16)
 for k, name in enumerate(("fwd", "bwd")):
     d = tr[k]; d = d[d[:, 1] > 0]
     t0, t1, hw, work = d[:, 0].astype(np.float64), d[:, 1].astype(np.float64), d[:, 2], d[:, 3]
@@ -33,7 +33,7 @@ for k, name in enumerate(("fwd", "bwd")):
     xcc = (hw >> 32) & 0xF; hwid = hw & 0xFFFFFFFF
     cu = (hwid >> 8) & 0xF; sh = (hwid >> 12) & 1; se = (hwid >> 13) & 0x7
     cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
-    print(f"== {name}: {len(d)} workgroups, span {t1.max():.1f} us, sum of WG time {dur.sum():.0f} us, "
+    print(f"== {name}: {len(d)} waves, span {t1.max():.1f} us, sum of WG time {dur.sum():.0f} us, "
           f"mean {dur.mean():.2f} us, p50 {np.percentile(dur,50):.2f}, p90 {np.percentile(dur,90):.2f}, "
           f"p99 {np.percentile(dur,99):.2f}, max {dur.max():.2f}")
     print(f"   distinct CUs seen {len(np.unique(cuid))}, avg concurrent WGs {dur.sum()/t1.max():.1f} "
@@ -50,7 +50,7 @@ for k, name in enumerate(("fwd", "bwd")):
         sel = order[int(lo * len(d)):int(hi * len(d))]
         print(f"   work quantile {lo:.2f}-{hi:.2f}: list len {work[sel].mean():.0f}, WG time {dur[sel].mean():.2f} us")
     acc = d[:, 4:12] / 100.0; nb, nv = d[:, 12], d[:, 13]
-    names = ["prologue", "loads+mask+LDS", "barrier(staged)", "build_list", "walk", "barrier(loop top)", "epilogue", "-"]
+    names = ["prologue", "stage (wait rows, LDS, test, list)", "-", "-", "walk", "-", "epilogue", "-"]
     print("   wave 0 phases, us per WG: " + ", ".join(f"{n} {acc[:, k].mean():.2f}" for k, n in enumerate(names[:7]))
           + f", unaccounted {(dur - acc.sum(1)).mean():.2f}")
     print(f"   batches/WG {nb.mean():.2f}, visits/WG (wave 0) {nv.mean():.1f}, walk per visit {1e3*acc[:,4].sum()/max(1,nv.sum()):.0f} ns")
