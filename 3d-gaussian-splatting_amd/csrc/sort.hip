@@ -29,15 +29,21 @@ __device__ __forceinline__ int resolve_count(int n_cap, const uint32_t *__restri
 }
 
 // ---- pass 1: per-block digit histogram, written digit-major: hist[d * nblocks + block] -------------
+// Plain per-lane LDS atomics: measured faster than aggregating same-digit lanes with ballots first (the LDS
+// resolves same-address adds of one instruction cheaply; the 8 ballots per key cost more than they save).
 __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(int n_cap, const uint32_t *__restrict__ n_dev,
                                                                   const uint32_t *__restrict__ keys,
                                                                   int shift, int nblocks,
                                                                   uint32_t *__restrict__ hist) {
     __shared__ uint32_t h[kRadix];
     const int n = resolve_count(n_cap, n_dev);
+    const long base = (long)blockIdx.x * kSortChunk;
+    if (base >= n) {   // capacity launch: nothing live in this block
+        hist[(long)threadIdx.x * nblocks + blockIdx.x] = 0;
+        return;
+    }
     h[threadIdx.x] = 0;
     __syncthreads();
-    long base = (long)blockIdx.x * kSortChunk;
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         long i = base + r * kSortThreads + threadIdx.x;
@@ -88,10 +94,15 @@ __global__ __launch_bounds__(kSortThreads) void radix_scan_rows_kernel(int nbloc
 }
 
 // ---- pass 3: stable scatter ---------------------------------------------------------------------
-// Items are first placed in LDS in block-sorted order (stable ballot ranking, 256 items per round), then written
-// out: consecutive threads then write consecutive addresses inside each digit's run, so HBM sees 64-B+ runs
-// instead of one 4-B store per 64-B line (the low-digit pass of a tile sort scatters neighbouring records to
-// 256 different buckets).
+// A block owns kSortChunk consecutive items, wave w the w-th quarter of them (16 rounds of 64 consecutive items).
+//   1. Each wave ranks its own items against WAVE-PRIVATE digit counters in LDS: per round 8 ballots give the
+//      lanes holding the same digit (rank inside the round), the counter gives the items of that digit the wave saw
+//      in earlier rounds.  No workgroup barrier inside the 16 rounds (the previous version synchronised the four
+//      waves twice per round: 32 barriers per block).
+//   2. One pass over the 256 digits turns the four waves' counters into block-sorted offsets.
+//   3. Items are placed in LDS in block-sorted order, then written out: consecutive threads write consecutive
+//      addresses inside each digit's run, so HBM sees 64-B+ runs instead of one 4-B store per 64-B line (the
+//      low-digit pass of a tile sort scatters neighbouring records to 256 different buckets).
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     int n_cap, const uint32_t *__restrict__ n_dev, const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int shift, int nblocks,
@@ -99,9 +110,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     __shared__ uint32_t scratch[4];
     __shared__ uint32_t gbase[kRadix];        // global slot of this block's first item of digit d
     __shared__ uint32_t lexcl[kRadix];        // slot of that item in the block-sorted order
-    __shared__ uint32_t running[kRadix];      // next free block-local slot per digit
-    __shared__ uint32_t wave_cnt[4][kRadix];  // per round: items of digit d in wave w
-    __shared__ uint32_t wave_off[4][kRadix];  // per round: first block-local slot for wave w, digit d
+    __shared__ uint32_t wave_cnt[4][kRadix];  // items of digit d wave w has ranked so far; then: its first block-sorted slot
     __shared__ uint32_t s_key[kSortChunk], s_val[kSortChunk];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n = resolve_count(n_cap, n_dev);
@@ -116,26 +125,25 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
         const uint32_t lbase = block_excl_scan(next - mine, scratch, tot);
         gbase[t] = dbase + mine;
         lexcl[t] = lbase;
-        running[t] = lbase;
 #pragma unroll
         for (int w = 0; w < 4; ++w) wave_cnt[w][t] = 0;
     }
 
-    const long base = (long)blockIdx.x * kSortChunk;
-    uint32_t k[kSortItems], v[kSortItems];
+    const long base = (long)blockIdx.x * kSortChunk + wave * (kSortChunk / 4);
+    uint32_t k[kSortItems], v[kSortItems], rk[kSortItems];
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
-        long i = base + r * kSortThreads + t;
+        long i = base + r * 64 + lane;
         k[r] = i < n ? keys_in[i] : 0xFFFFFFFFu;
         v[r] = i < n ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
     }
     __syncthreads();
 
+    uint32_t *cnt = wave_cnt[wave];
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
-        long i = base + r * kSortThreads + t;
-        bool valid = i < n;
-        uint32_t d = (k[r] >> shift) & (kRadix - 1);
+        const bool valid = base + r * 64 + lane < n;
+        const uint32_t d = (k[r] >> shift) & (kRadix - 1);
         // lanes of this wave holding the same digit
         unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -143,25 +151,33 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
             unsigned long long m = __ballot((d >> b) & 1);
             peers &= ((d >> b) & 1) ? m : ~m;
         }
-        uint32_t rank = __popcll(peers & ((1ull << lane) - 1ull));
-        if (valid && rank == 0) wave_cnt[wave][d] = __popcll(peers);
-        __syncthreads();
-        {
-            uint32_t c0 = wave_cnt[0][t], c1 = wave_cnt[1][t], c2 = wave_cnt[2][t], c3 = wave_cnt[3][t];
-            uint32_t o = running[t];
-            wave_off[0][t] = o; wave_off[1][t] = o + c0; wave_off[2][t] = o + c0 + c1; wave_off[3][t] = o + c0 + c1 + c2;
-            running[t] = o + c0 + c1 + c2 + c3;
-            wave_cnt[0][t] = 0; wave_cnt[1][t] = 0; wave_cnt[2][t] = 0; wave_cnt[3][t] = 0;
-        }
-        __syncthreads();
-        if (valid) {
-            uint32_t lp = wave_off[wave][d] + rank;
+        const uint32_t below = __popcll(peers & ((1ull << lane) - 1ull));
+        const uint32_t seen = cnt[d];                       // same value for all peers (read before the update)
+        rk[r] = seen + below;
+        // LDS operations of one wave complete in order: the read above precedes this write, the next round's read
+        // follows it; the fence only keeps the compiler from reordering them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (valid && below == 0) cnt[d] = seen + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __syncthreads();
+    {   // digit t: first block-sorted slot of each wave's items = lexcl + counts of the waves before it
+        uint32_t c0 = wave_cnt[0][t], c1 = wave_cnt[1][t], c2 = wave_cnt[2][t];
+        const uint32_t o = lexcl[t];
+        wave_cnt[0][t] = o; wave_cnt[1][t] = o + c0; wave_cnt[2][t] = o + c0 + c1; wave_cnt[3][t] = o + c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        if (base + r * 64 + lane < n) {
+            const uint32_t d = (k[r] >> shift) & (kRadix - 1);
+            const uint32_t lp = cnt[d] + rk[r];
             s_key[lp] = k[r];
             s_val[lp] = v[r];
         }
     }
     __syncthreads();
-    const int m = (int)min((long)kSortChunk, (long)n - base);
+    const int m = (int)min((long)kSortChunk, (long)n - (long)blockIdx.x * kSortChunk);
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         int lp = r * kSortThreads + t;
@@ -184,14 +200,21 @@ __device__ __forceinline__ uint32_t scan_load(const int32_t *__restrict__ tiles_
     return i < n ? (uint32_t)tiles_touched[order[i]] : 0u;
 }
 
+// `gathered` (the offsets buffer itself): the counts in depth order, so that the final pass streams them instead of
+// repeating the random gather through `order`
 __global__ __launch_bounds__(kSortThreads) void scan_reduce_kernel(int n, const int32_t *__restrict__ tiles_touched,
                                                                    const uint32_t *__restrict__ order,
-                                                                   uint32_t *__restrict__ block_sums) {
+                                                                   uint32_t *__restrict__ block_sums,
+                                                                   uint32_t *__restrict__ gathered) {
     __shared__ uint32_t scratch[4];
     long base = (long)blockIdx.x * kScanChunk + threadIdx.x * kScanItems;
     uint32_t s = 0;
 #pragma unroll
-    for (int j = 0; j < kScanItems; ++j) s += scan_load(tiles_touched, order, base + j, n);
+    for (int j = 0; j < kScanItems; ++j) {
+        const uint32_t c = scan_load(tiles_touched, order, base + j, n);
+        if (base + j < n) gathered[base + j] = c;
+        s += c;
+    }
     uint32_t total;
     block_excl_scan(s, scratch, total);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
@@ -212,16 +235,15 @@ __global__ __launch_bounds__(kSortThreads) void scan_blocks_kernel(int nblocks, 
     if (threadIdx.x == 0) *total_out = carry;
 }
 
-__global__ __launch_bounds__(kSortThreads) void scan_final_kernel(int n, const int32_t *__restrict__ tiles_touched,
-                                                                  const uint32_t *__restrict__ order,
-                                                                  const uint32_t *__restrict__ block_sums,
+// in place: offsets[] holds the depth-ordered counts on entry (scan_reduce_kernel), their exclusive prefix on exit
+__global__ __launch_bounds__(kSortThreads) void scan_final_kernel(int n, const uint32_t *__restrict__ block_sums,
                                                                   uint32_t *__restrict__ offsets) {
     __shared__ uint32_t scratch[4];
     long base = (long)blockIdx.x * kScanChunk + threadIdx.x * kScanItems;
     uint32_t v[kScanItems], s = 0;
 #pragma unroll
     for (int j = 0; j < kScanItems; ++j) {
-        v[j] = scan_load(tiles_touched, order, base + j, n);
+        v[j] = base + j < n ? offsets[base + j] : 0u;
         s += v[j];
     }
     uint32_t total;
@@ -425,11 +447,11 @@ extern "C" int gsa_scan_tiles(int n, const int32_t *tiles_touched, const uint32_
     GSA_RETURN_IF(workspace_bytes < gsa_sort_workspace_bytes(n), GSA_ERR_WORKSPACE_TOO_SMALL);
     uint32_t *block_sums = static_cast<uint32_t *>(workspace);
     int nblocks = gsa_div_up(n, kScanChunk);
-    scan_reduce_kernel<<<nblocks, kSortThreads, 0, s>>>(n, tiles_touched, order, block_sums);
+    scan_reduce_kernel<<<nblocks, kSortThreads, 0, s>>>(n, tiles_touched, order, block_sums, offsets);
     GSA_LAUNCH_CHECK();
     scan_blocks_kernel<<<1, kSortThreads, 0, s>>>(nblocks, block_sums, total);
     GSA_LAUNCH_CHECK();
-    scan_final_kernel<<<nblocks, kSortThreads, 0, s>>>(n, tiles_touched, order, block_sums, offsets);
+    scan_final_kernel<<<nblocks, kSortThreads, 0, s>>>(n, block_sums, offsets);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }
