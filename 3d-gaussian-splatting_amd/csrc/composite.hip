@@ -84,11 +84,16 @@ __device__ __forceinline__ void trace_end(const TraceState &ts, int kernel, int 
 // correctness): every XCD gets one contiguous band of tiles, and the four quadrants of a tile follow each other
 // on the same XCD so that their gathers of the same records meet in one L2.
 // Injective from [0, 32 * chunk) onto (tile, quadrant) pairs; callers drop tiles >= n_tiles.
-__device__ __forceinline__ void wave_unit(int b, int n_tiles, int &tile, int &q) {
+// `tile_order` (optional, gsa_tile_schedule): a permutation of each band that puts the tiles with long record
+// lists first, so that the launch ends on its short jobs (a wave runs for ~1/5 of the whole kernel on a full tile;
+// in index order the last round of waves left the chip a fifth empty).  Entries of -1 pad the last band.
+__device__ __forceinline__ void wave_unit(int b, int n_tiles, const int32_t *__restrict__ tile_order, int &tile, int &q) {
     const int chunk = (n_tiles + 7) >> 3;
     const int within = b >> 3;
     q = within & 3;
-    tile = (b & 7) * chunk + (within >> 2);
+    const int slot = (b & 7) * chunk + (within >> 2);
+    tile = tile_order ? tile_order[slot] : slot;
+    if (tile < 0) tile = n_tiles;
 }
 
 // LDS image of the wave's staged batch, F4 float4 per record (3 for RGB, 4 with the depth channel):
@@ -315,13 +320,13 @@ template <int CH>
 __global__ __launch_bounds__(kWave, GSA_FWD_WAVES) void composite_fwd_kernel(
     int width, int height, int tile_w, int n_tiles, const float *__restrict__ splat,
     const uint32_t *__restrict__ sorted_gid, const int32_t *__restrict__ tile_offsets,
-    const float *__restrict__ background, float *__restrict__ render, float *__restrict__ alpha_out,
-    float *__restrict__ final_T, int32_t *__restrict__ last_id) {
+    const float *__restrict__ background, const int32_t *__restrict__ tile_order, float *__restrict__ render,
+    float *__restrict__ alpha_out, float *__restrict__ final_T, int32_t *__restrict__ last_id) {
     constexpr int F4 = CH == 4 ? 4 : 3;
     __shared__ Staged<F4> st;
 
     int tile, q;
-    wave_unit(blockIdx.x, n_tiles, tile, q);
+    wave_unit(blockIdx.x, n_tiles, tile_order, tile, q);
     if (tile >= n_tiles) return;
     GSA_TRACE_BEGIN();
     const int lane = threadIdx.x;
@@ -501,14 +506,15 @@ template <int CH>
 __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_kernel(
     int width, int height, int tile_w, int n_tiles, const float *__restrict__ splat,
     const uint32_t *__restrict__ sorted_gid, const int32_t *__restrict__ tile_offsets,
-    const float *__restrict__ background, const float *__restrict__ final_T, const int32_t *__restrict__ last_id,
-    const float *__restrict__ v_render, const float *__restrict__ v_alpha, float *__restrict__ v_splat) {
+    const float *__restrict__ background, const int32_t *__restrict__ tile_order, const float *__restrict__ final_T,
+    const int32_t *__restrict__ last_id, const float *__restrict__ v_render, const float *__restrict__ v_alpha,
+    float *__restrict__ v_splat) {
     constexpr int F4 = CH == 4 ? 4 : 3;
     constexpr int NF = 6 + CH;
     __shared__ Staged<F4> st;
 
     int tile, q;
-    wave_unit(blockIdx.x, n_tiles, tile, q);
+    wave_unit(blockIdx.x, n_tiles, tile_order, tile, q);
     if (tile >= n_tiles) return;
     const int lane = threadIdx.x;
     const int start = __builtin_amdgcn_readfirstlane(tile_offsets[tile]);
@@ -573,7 +579,43 @@ __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_kernel(
     GSA_TRACE_END(1, tile * 4 + q, qmax + 1 - start);
 }
 
+// ------------------------------------------------------------------------------------------------
+// launch order: longest record lists first, inside each XCD band
+// ------------------------------------------------------------------------------------------------
+// One workgroup per band: counting sort of the band's tiles by list length (64 buckets of 64 records, longest
+// first).  The order inside a bucket comes from LDS atomics and may differ between launches -- it only moves
+// work in time, never changes a result.
+constexpr int kSchedThreads = 1024, kSchedBuckets = 64;
+__global__ __launch_bounds__(kSchedThreads) void tile_schedule_kernel(int n_tiles, const int32_t *__restrict__ tile_offsets,
+                                                                      int32_t *__restrict__ tile_order) {
+    __shared__ int cnt[kSchedBuckets], first[kSchedBuckets];
+    const int chunk = (n_tiles + 7) >> 3;
+    const int lo = blockIdx.x * chunk, hi = min(n_tiles, lo + chunk);
+    if (threadIdx.x < kSchedBuckets) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    auto bucket = [&](int t) {
+        const int len = tile_offsets[t + 1] - tile_offsets[t];
+        return kSchedBuckets - 1 - min(kSchedBuckets - 1, len >> 6);   // bucket 0 = longest lists
+    };
+    for (int t = lo + threadIdx.x; t < hi; t += kSchedThreads) atomicAdd(&cnt[bucket(t)], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int k = 0; k < kSchedBuckets; ++k) { first[k] = run; run += cnt[k]; }
+    }
+    __syncthreads();
+    for (int t = lo + threadIdx.x; t < hi; t += kSchedThreads) tile_order[lo + atomicAdd(&first[bucket(t)], 1)] = t;
+    for (int t = max(hi, lo) + threadIdx.x; t < lo + chunk; t += kSchedThreads) tile_order[t] = -1;   // padding
+}
+
 }  // namespace
+
+extern "C" int gsa_tile_schedule(int n_tiles, const int32_t *tile_offsets, int32_t *tile_order, gsa_stream_t stream) {
+    GSA_RETURN_IF(n_tiles <= 0 || !tile_offsets || !tile_order, GSA_ERR_INVALID_ARGUMENT);
+    tile_schedule_kernel<<<8, kSchedThreads, 0, static_cast<hipStream_t>(stream)>>>(n_tiles, tile_offsets, tile_order);
+    GSA_LAUNCH_CHECK();
+    return GSA_OK;
+}
 
 #ifdef GSA_TRACE
 extern "C" int gsa_debug_set_trace(unsigned long long *buf) {
@@ -583,8 +625,8 @@ extern "C" int gsa_debug_set_trace(unsigned long long *buf) {
 
 extern "C" int gsa_composite_fwd(int width, int height, int channels, const float *splat,
                                  const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
-                                 float *render, float *alpha, float *final_T, int32_t *last_id,
-                                 gsa_stream_t stream) {
+                                 const int32_t *tile_order, float *render, float *alpha, float *final_T,
+                                 int32_t *last_id, gsa_stream_t stream) {
     GSA_RETURN_IF(width <= 0 || height <= 0 || (channels != 3 && channels != 4), GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(!tile_offsets || !render || !alpha || !final_T || !last_id, GSA_ERR_INVALID_ARGUMENT);
     const int tile_w = gsa_div_up(width, kTile), tile_h = gsa_div_up(height, kTile);
@@ -593,18 +635,18 @@ extern "C" int gsa_composite_fwd(int width, int height, int channels, const floa
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (channels == 3)
         composite_fwd_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid, tile_offsets,
-                                                      background, render, alpha, final_T, last_id);
+                                                      background, tile_order, render, alpha, final_T, last_id);
     else
         composite_fwd_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid, tile_offsets,
-                                                      background, render, alpha, final_T, last_id);
+                                                      background, tile_order, render, alpha, final_T, last_id);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }
 
 extern "C" int gsa_composite_bwd(int width, int height, int channels, const float *splat,
                                  const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
-                                 const float *final_T, const int32_t *last_id, const float *v_render,
-                                 const float *v_alpha, float *v_splat, gsa_stream_t stream) {
+                                 const int32_t *tile_order, const float *final_T, const int32_t *last_id,
+                                 const float *v_render, const float *v_alpha, float *v_splat, gsa_stream_t stream) {
     GSA_RETURN_IF(width <= 0 || height <= 0 || (channels != 3 && channels != 4), GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(!tile_offsets || !final_T || !last_id || !v_render || !v_splat, GSA_ERR_INVALID_ARGUMENT);
     const int tile_w = gsa_div_up(width, kTile), tile_h = gsa_div_up(height, kTile);
@@ -613,10 +655,10 @@ extern "C" int gsa_composite_bwd(int width, int height, int channels, const floa
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (channels == 3)
         composite_bwd_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid, tile_offsets,
-                                                      background, final_T, last_id, v_render, v_alpha, v_splat);
+                                                      background, tile_order, final_T, last_id, v_render, v_alpha, v_splat);
     else
         composite_bwd_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid, tile_offsets,
-                                                      background, final_T, last_id, v_render, v_alpha, v_splat);
+                                                      background, tile_order, final_T, last_id, v_render, v_alpha, v_splat);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }

@@ -206,7 +206,18 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
     return TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key)
 
 
-def composite_fwd(splat, sorted_gid, tile_offsets, background, width: int, height: int, channels: int):
+def tile_schedule(tile_offsets: torch.Tensor, width: int, height: int) -> torch.Tensor:
+    """-> tile_order [8 * ceil(n_tiles / 8)] i32: per tile band, the tiles with the longest record lists first (launch
+    order of the compositor kernels; speed only)."""
+    tile_w, tile_h = tile_grid(width, height)
+    n_tiles = tile_w * tile_h
+    order = torch.empty(8 * ((n_tiles + 7) // 8), dtype=torch.int32, device=tile_offsets.device)
+    _call("gsa_tile_schedule", lib.gsa_tile_schedule, n_tiles, _ptr(tile_offsets), _ptr(order), _stream())
+    return order
+
+
+def composite_fwd(splat, sorted_gid, tile_offsets, background, width: int, height: int, channels: int,
+                  tile_order=None):
     """-> render [H,W,channels], alpha [H,W,1], final_T [H,W], last_id [H,W] i32."""
     dev = splat.device
     render = torch.empty(height, width, channels, dtype=torch.float32, device=dev)
@@ -214,7 +225,8 @@ def composite_fwd(splat, sorted_gid, tile_offsets, background, width: int, heigh
     final_T = torch.empty(height, width, dtype=torch.float32, device=dev)
     last_id = torch.empty(height, width, dtype=torch.int32, device=dev)
     _call("gsa_composite_fwd", lib.gsa_composite_fwd, width, height, channels, _ptr(splat), _ptr(sorted_gid),
-          _ptr(tile_offsets), _ptr(background), _ptr(render), _ptr(alpha), _ptr(final_T), _ptr(last_id), _stream())
+          _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(render), _ptr(alpha), _ptr(final_T),
+          _ptr(last_id), _stream())
     return render, alpha, final_T, last_id
 
 
@@ -248,14 +260,14 @@ def record_grads_to_moments(splat: torch.Tensor, g: torch.Tensor) -> torch.Tenso
 
 
 def composite_bwd(splat, sorted_gid, tile_offsets, background, final_T, last_id, v_render, v_alpha, width: int,
-                  height: int, channels: int):
+                  height: int, channels: int, tile_order=None):
     """-> v_splat [N,16]: per gaussian the raw moments of u = d loss / d sigma over d = mean2d - pixel
     (sum u dx, u dy, u dx^2, u dx dy, u dy^2, u) and sum fac * v_out per channel -- the gradient record
     ``project_bwd`` consumes (``moments_to_record_grads`` gives the mean / conic / opacity gradients)."""
     v_splat = torch.zeros_like(splat)
     _call("gsa_composite_bwd", lib.gsa_composite_bwd, width, height, channels, _ptr(splat), _ptr(sorted_gid),
-          _ptr(tile_offsets), _ptr(background), _ptr(final_T), _ptr(last_id), _ptr(v_render), _ptr(v_alpha),
-          _ptr(v_splat), _stream())
+          _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(final_T), _ptr(last_id), _ptr(v_render),
+          _ptr(v_alpha), _ptr(v_splat), _stream())
     return v_splat
 
 

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSA_ABI_VERSION 1
+#define GSA_ABI_VERSION 2
 #define GSA_SPLAT_STRIDE 16
 
 #define GSA_OK 0
@@ -131,7 +131,13 @@ int gsa_tile_offsets(uint32_t m, const uint32_t *sorted_tile, int n_tiles, int32
  */
 int gsa_composite_fwd(int width, int height, int channels, const float *splat,
                       const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
-                      float *render, float *alpha, float *final_T, int32_t *last_id, gsa_stream_t stream);
+                      const int32_t *tile_order, float *render, float *alpha, float *final_T, int32_t *last_id,
+                      gsa_stream_t stream);
+
+/* Launch order for stages 3 and 4 (optional; speed only, never results): tile_order[8 * ceil(n_tiles / 8)] receives,
+ * for each of the 8 tile bands, the band's tiles with the longest record lists first (-1 pads the last band). Pass it
+ * as `tile_order` to gsa_composite_fwd / gsa_composite_bwd, or pass NULL there for index order. */
+int gsa_tile_schedule(int n_tiles, const int32_t *tile_offsets, int32_t *tile_order, gsa_stream_t stream);
 
 /* Stage 4 (row a3.5): reverse-order gradient sweep.  v_splat[N,16] must be zero on entry and receives, per
  * gaussian, the raw moments of u = d loss / d sigma over d = mean2d - pixel:
@@ -140,8 +146,8 @@ int gsa_composite_fwd(int width, int height, int channels, const float *splat,
  * d loss / d (mean2d, conic, opacity) are linear in them; gsa_project_bwd finishes that per gaussian. */
 int gsa_composite_bwd(int width, int height, int channels, const float *splat,
                       const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
-                      const float *final_T, const int32_t *last_id, const float *v_render,
-                      const float *v_alpha, float *v_splat, gsa_stream_t stream);
+                      const int32_t *tile_order, const float *final_T, const int32_t *last_id,
+                      const float *v_render, const float *v_alpha, float *v_splat, gsa_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stage 5 (row a3.6): projection + SH backward.  Reads the sweep's moment records (stage 4) and the saved
