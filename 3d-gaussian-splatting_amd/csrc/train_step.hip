@@ -1,0 +1,226 @@
+// train_step.hip -- the two stages that follow the rasterizer in a training step:
+//
+//   gsa_view_loss   the reference's per-view photometric loss AND its gradient with respect to the render, in two
+//                   streaming passes:  loss = (1 - lambda) L1 + lambda (1 - SSIM_3x3)  on the straight-through-clamped
+//                   render (/root/reference/src/training/trainer.py:485-492 with _stclamp :102-107 and _compute_ssim
+//                   :354-371; PSNR's mse :70-75 comes out of the same pass).  The torch formulation makes ~10
+//                   full-image passes forward and as many backward; here the image is read once per pass.
+//   gsa_adam_step   one fused Adam update over the flat 59 N parameter bucket with per-segment learning rates
+//                   (torch.optim.Adam as configured at trainer.py:331-340: betas 0.9 / 0.999, eps 1e-15, no weight
+//                   decay, no amsgrad): 4 arrays read, 3 written, once.
+//
+// Both are HBM-streaming kernels (fp32, no MFMA).
+
+#include "gsa_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
+
+__device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
+
+// block sum of three doubles -> one atomicAdd each (sums[0..2])
+__device__ __forceinline__ void block_add3(double a, double b, double c, double *__restrict__ sums) {
+    __shared__ double red[3][kThreads / GSA_WAVE];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        a += __shfl_xor(a, d); b += __shfl_xor(b, d); c += __shfl_xor(c, d);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = a; red[1][wave] = b; red[2][wave] = c; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double s = 0;
+        for (int w = 0; w < kThreads / GSA_WAVE; ++w) s += red[threadIdx.x][w];
+        atomicAdd(&sums[threadIdx.x], s);
+    }
+}
+
+// Pass 1, one thread per pixel: 3x3 box statistics (zero padding, divisor 9 -- avg_pool2d(3, 1, padding=1) with
+// count_include_pad) of a = clamp(render) and b = target per channel; the SSIM value and its partial derivatives
+// with respect to the three a-dependent statistics mu_a, E[a^2], E[ab] go to `partials` [H,W,3,3].
+__global__ __launch_bounds__(kThreads) void loss_stats_kernel(int width, int height, const float *__restrict__ render,
+                                                              const float *__restrict__ target,
+                                                              float *__restrict__ partials, double *__restrict__ sums) {
+    const long p = (long)blockIdx.x * kThreads + threadIdx.x;
+    const long n_pix = (long)width * height;
+    double l1 = 0, ssim = 0, mse = 0;
+    if (p < n_pix) {
+        const int x = (int)(p % width), y = (int)(p / width);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float sa = 0.f, sb = 0.f, saa = 0.f, sbb = 0.f, sab = 0.f;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int xx = x + dx, yy = y + dy;
+                    if (xx >= 0 && xx < width && yy >= 0 && yy < height) {
+                        const long q = ((long)yy * width + xx) * 3 + c;
+                        const float a = clamp01(render[q]), b = target[q];
+                        sa += a; sb += b; saa += a * a; sbb += b * b; sab += a * b;
+                    }
+                }
+            const float inv9 = 1.f / 9.f;
+            const float mu_a = sa * inv9, mu_b = sb * inv9;
+            const float var_a = saa * inv9 - mu_a * mu_a, var_b = sbb * inv9 - mu_b * mu_b;
+            const float cov = sab * inv9 - mu_a * mu_b;
+            const float A1 = 2.f * mu_a * mu_b + kC1, A2 = 2.f * cov + kC2;
+            const float B1 = mu_a * mu_a + mu_b * mu_b + kC1, B2 = var_a + var_b + kC2;
+            const float inv = 1.f / (B1 * B2);
+            const float S = A1 * A2 * inv;
+            // d S / d mu_a with E[a^2], E[ab] held fixed: var_a and cov depend on mu_a too
+            const float dA1 = 2.f * mu_b, dA2 = -2.f * mu_b, dB1 = 2.f * mu_a, dB2 = -2.f * mu_a;
+            const float dmu = ((dA1 * A2 + A1 * dA2) - S * (dB1 * B2 + B1 * dB2)) * inv;
+            const float dEaa = -S / B2;          // B2 contains + E[a^2]
+            const float dEab = 2.f * A1 * inv;   // A2 contains + 2 E[ab]
+            float *out = partials + (p * 3 + c) * 3;
+            out[0] = dmu; out[1] = dEaa; out[2] = dEab;
+            const long q0 = p * 3 + c;
+            const float a0 = clamp01(render[q0]), d0 = a0 - target[q0];
+            l1 += fabsf(d0); mse += (double)d0 * d0; ssim += S;
+        }
+    }
+    block_add3(l1, ssim, mse, sums);
+}
+
+// Pass 2, one thread per pixel: v_render = grad_scale * [ (1 - lambda) sign(a - b) - lambda * adjoint of the box
+// filter applied to the partials ] / (3 H W); the clamp is straight-through (identity gradient).
+__global__ __launch_bounds__(kThreads) void loss_grad_kernel(int width, int height, const float *__restrict__ render,
+                                                             const float *__restrict__ target,
+                                                             const float *__restrict__ partials, float lambda_dssim,
+                                                             float grad_scale, float *__restrict__ v_render) {
+    const long p = (long)blockIdx.x * kThreads + threadIdx.x;
+    const long n_pix = (long)width * height;
+    if (p >= n_pix) return;
+    const int x = (int)(p % width), y = (int)(p / width);
+    const float inv_count = grad_scale / (3.f * (float)n_pix);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float s_mu = 0.f, s_aa = 0.f, s_ab = 0.f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = x + dx, yy = y + dy;
+                if (xx >= 0 && xx < width && yy >= 0 && yy < height) {
+                    const float *in = partials + (((long)yy * width + xx) * 3 + c) * 3;
+                    s_mu += in[0]; s_aa += in[1]; s_ab += in[2];
+                }
+            }
+        const long q = p * 3 + c;
+        const float a = clamp01(render[q]), b = target[q];
+        const float d_ssim = (s_mu + 2.f * a * s_aa + b * s_ab) * (1.f / 9.f);
+        const float d = a - b;
+        const float sign = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        v_render[q] = inv_count * ((1.f - lambda_dssim) * sign - lambda_dssim * d_ssim);
+    }
+}
+
+// One Adam step over a flat bucket.  seg_end[k] = one past the last element of segment k (ascending), lr[k] its
+// learning rate.  Mirrors torch.optim.Adam's single-tensor arithmetic:
+//   m += (g - m)(1 - b1);  v = b2 v + (1 - b2) g g;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+struct AdamSegments {
+    long end[8];
+    float lr[8];
+    int count;
+};
+
+__global__ __launch_bounds__(kThreads) void adam_kernel(long n, float *__restrict__ param, const float *__restrict__ grad,
+                                                        float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq,
+                                                        AdamSegments seg, float w1, float beta2, float w2, float eps,
+                                                        float inv_bc1, float inv_sqrt_bc2) {   // w = 1 - beta
+    const long i0 = ((long)blockIdx.x * kThreads + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    if (i0 + 4 <= n) {
+        const float4 g4 = *reinterpret_cast<const float4 *>(grad + i0);
+        float4 p4 = *reinterpret_cast<float4 *>(param + i0);
+        float4 m4 = *reinterpret_cast<float4 *>(exp_avg + i0);
+        float4 v4 = *reinterpret_cast<float4 *>(exp_avg_sq + i0);
+        float *pp = &p4.x, *mm = &m4.x, *vv = &v4.x;
+        const float *gg = &g4.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float lr = 0.f;
+#pragma unroll
+            for (int k = 7; k >= 0; --k)
+                if (k < seg.count && i0 + j < seg.end[k]) lr = seg.lr[k];
+            const float g = gg[j];
+            const float m = mm[j] + (g - mm[j]) * w1;
+            const float v = vv[j] * beta2 + w2 * g * g;
+            const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
+            pp[j] = pp[j] - (lr * inv_bc1) * (m / denom);
+            mm[j] = m; vv[j] = v;
+        }
+        *reinterpret_cast<float4 *>(param + i0) = p4;
+        *reinterpret_cast<float4 *>(exp_avg + i0) = m4;
+        *reinterpret_cast<float4 *>(exp_avg_sq + i0) = v4;
+    } else {
+        for (long i = i0; i < n; ++i) {
+            float lr = 0.f;
+            for (int k = seg.count - 1; k >= 0; --k)
+                if (i < seg.end[k]) lr = seg.lr[k];
+            const float g = grad[i];
+            const float m = exp_avg[i] + (g - exp_avg[i]) * w1;
+            const float v = exp_avg_sq[i] * beta2 + w2 * g * g;
+            const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
+            param[i] = param[i] - (lr * inv_bc1) * (m / denom);
+            exp_avg[i] = m; exp_avg_sq[i] = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t gsa_view_loss_workspace_bytes(int width, int height) {
+    if (width <= 0 || height <= 0) return 0;
+    return (size_t)width * height * 9 * sizeof(float);
+}
+
+extern "C" int gsa_view_loss(int width, int height, const float *render, const float *target, float lambda_dssim,
+                             float grad_scale, void *workspace, size_t workspace_bytes, float *v_render, double *sums,
+                             gsa_stream_t stream) {
+    GSA_RETURN_IF(width <= 0 || height <= 0 || !render || !target || !workspace || !sums, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(workspace_bytes < gsa_view_loss_workspace_bytes(width, height), GSA_ERR_WORKSPACE_TOO_SMALL);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = gsa_div_up((long long)width * height, kThreads);
+    float *partials = static_cast<float *>(workspace);
+    loss_stats_kernel<<<grid, kThreads, 0, s>>>(width, height, render, target, partials, sums);
+    GSA_LAUNCH_CHECK();
+    if (v_render) {
+        loss_grad_kernel<<<grid, kThreads, 0, s>>>(width, height, render, target, partials, lambda_dssim, grad_scale,
+                                                  v_render);
+        GSA_LAUNCH_CHECK();
+    }
+    return GSA_OK;
+}
+
+extern "C" int gsa_adam_step(long long n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                             int n_segments, const long long *segment_end, const float *segment_lr, double beta1,
+                             double beta2, double eps, int step, gsa_stream_t stream) {
+    GSA_RETURN_IF(n < 0 || n_segments < 1 || n_segments > 8 || step < 1, GSA_ERR_INVALID_ARGUMENT);
+    if (n == 0) return GSA_OK;
+    GSA_RETURN_IF(!param || !grad || !exp_avg || !exp_avg_sq || !segment_end || !segment_lr, GSA_ERR_INVALID_ARGUMENT);
+    AdamSegments seg;
+    seg.count = n_segments;
+    long long prev = 0;
+    for (int k = 0; k < 8; ++k) {
+        seg.end[k] = k < n_segments ? (long)segment_end[k] : (long)n;
+        seg.lr[k] = k < n_segments ? segment_lr[k] : 0.f;
+        if (k < n_segments) {
+            GSA_RETURN_IF(segment_end[k] < prev, GSA_ERR_INVALID_ARGUMENT);
+            prev = segment_end[k];
+        }
+    }
+    GSA_RETURN_IF(prev != n, GSA_ERR_INVALID_ARGUMENT);
+    // 1 - beta and the bias corrections in double on the host, as torch computes them in Python floats
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    const int grid = gsa_div_up((n + 3) / 4, kThreads);
+    adam_kernel<<<grid, kThreads, 0, static_cast<hipStream_t>(stream)>>>((long)n, param, grad, exp_avg, exp_avg_sq, seg,
+                                                                        (float)(1.0 - beta1), (float)beta2,
+                                                                        (float)(1.0 - beta2), (float)eps,
+                                                                        (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+    GSA_LAUNCH_CHECK();
+    return GSA_OK;
+}

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_int, c_size_t, c_uint32, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_uint32, c_void_p
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # GSPLAT_AMD_LIB: developer override to A/B another build of the SAME C ABI (still a HIP library; no fallback)
@@ -34,6 +34,9 @@ SIGNATURES = {
     "gsa_composite_fwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P]),
     "gsa_tile_schedule": (c_int, [c_int, P, P, P]),
     "gsa_composite_bwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P]),
+    "gsa_view_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "gsa_view_loss": (c_int, [c_int, c_int, P, P, c_float, c_float, P, c_size_t, P, P, P]),
+    "gsa_adam_step": (c_int, [c_longlong, P, P, P, P, c_int, P, P, c_double, c_double, c_double, c_int, P]),
     "gsa_project_bwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, P, P, P, P, P, P, P, P, P]),
 }
 

@@ -131,24 +131,68 @@ def view_loss(rendered: torch.Tensor, target: torch.Tensor, lambda_dssim: float)
     return (1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - ssim), l1, ssim
 
 
+def _adam_groups(model: SplatModel, c: StepConfig):
+    """The reference's six optimizer groups (trainer.py:331-340)."""
+    return [
+        {"params": [model.xyz], "lr": c.position_lr_init, "name": "xyz"},
+        {"params": [model.features_dc], "lr": 0.0025, "name": "f_dc"},
+        {"params": [model.features_rest], "lr": 0.0025 / 20.0, "name": "f_rest"},
+        {"params": [model.opacity], "lr": 0.05, "name": "opacity"},
+        {"params": [model.scaling], "lr": 0.005, "name": "scaling"},
+        {"params": [model.rotation], "lr": 0.001, "name": "rotation"},
+    ]
+
+
+class FusedBucketAdam:
+    """torch.optim.Adam (betas 0.9 / 0.999, eps 1e-15, no weight decay) over the model's ONE flat 59 N bucket as a
+    single HIP kernel (``gsa_adam_step``: 4 arrays read, 3 written, once) instead of torch's multi-pass foreach
+    update.  Exposes ``param_groups`` (name, lr) and ``state[param]`` (views of the flat moments) like the torch
+    optimizer it replaces, so schedules and checkpoints keep working."""
+
+    def __init__(self, model: SplatModel, groups, betas=(0.9, 0.999), eps: float = 1e-15):
+        self.model, self.betas, self.eps = model, betas, eps
+        self.param_groups = groups
+        self.exp_avg = torch.zeros_like(model.flat)
+        self.exp_avg_sq = torch.zeros_like(model.flat)
+        self.step_count = 0
+        self.segment_end, self.state, off = [], {}, 0
+        for g in groups:  # groups are in the order of FIELDS == the order of the flat layout
+            p = g["params"][0]
+            cnt = p.numel()
+            self.state[p] = {"exp_avg": self.exp_avg[off:off + cnt].view(p.shape),
+                             "exp_avg_sq": self.exp_avg_sq[off:off + cnt].view(p.shape)}
+            off += cnt
+            self.segment_end.append(off)
+        assert off == model.flat.numel()
+
+    def step(self) -> None:
+        from . import stages as S
+        self.step_count += 1
+        with torch.no_grad():
+            S.adam_step(self.model.flat, self.model.flat_grad, self.exp_avg, self.exp_avg_sq, self.segment_end,
+                        [g["lr"] for g in self.param_groups], self.step_count, self.betas[0], self.betas[1], self.eps)
+
+
 class ViewParallelTrainer:
-    """One optimisation step over a batch of views, sharded by view across ``world_size`` ranks."""
+    """One optimisation step over a batch of views, sharded by view across ``world_size`` ranks.
+
+    ``fused=True`` (HIP device only): the per-view loss and its gradient come from ``gsa_view_loss`` (two streaming
+    passes instead of ~20 torch passes per view) and Adam is one ``gsa_adam_step`` over the flat bucket."""
 
     def __init__(self, model: SplatModel, backend, config: Optional[StepConfig] = None,
-                 process_group=None, rank: int = 0, world_size: int = 1):
+                 process_group=None, rank: int = 0, world_size: int = 1, fused: bool = False):
         self.model, self.backend = model, backend
         self.cfg = config or StepConfig()
         self.group, self.rank, self.world = process_group, rank, world_size
         self.iteration = 0
-        c = self.cfg
-        self.optimizer = torch.optim.Adam([  # trainer.py:331-340
-            {"params": [model.xyz], "lr": c.position_lr_init, "name": "xyz"},
-            {"params": [model.features_dc], "lr": 0.0025, "name": "f_dc"},
-            {"params": [model.features_rest], "lr": 0.0025 / 20.0, "name": "f_rest"},
-            {"params": [model.opacity], "lr": 0.05, "name": "opacity"},
-            {"params": [model.scaling], "lr": 0.005, "name": "scaling"},
-            {"params": [model.rotation], "lr": 0.001, "name": "rotation"},
-        ], lr=0.0, eps=1e-15)
+        self.fused = bool(fused)
+        if self.fused and not model.flat.is_cuda:
+            raise RuntimeError("ViewParallelTrainer(fused=True) needs the model on a HIP device (no CPU path)")
+        groups = _adam_groups(model, self.cfg)
+        if self.fused:
+            self.optimizer = FusedBucketAdam(model, groups)
+        else:
+            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)  # trainer.py:331-340
 
     def active_sh_degree(self) -> int:
         return min(int(self.iteration // self.cfg.sh_increment_interval), int(self.cfg.sh_degree_max))
@@ -171,6 +215,8 @@ class ViewParallelTrainer:
         """``batch``: B dicts {image [H,W,3], pose [4,4] world->camera, width, height} -- the SAME list on every
         rank (trainer.py:270-281).  Rank r renders views r, r + world, ...; the summed gradient equals the
         single-process one: each view's loss is divided by B, the scale regulariser is added on rank 0 only."""
+        if self.fused:
+            return self._training_step_fused(batch)
         m, c = self.model, self.cfg
         m.zero_grad()
         params = m.activated()
@@ -201,3 +247,48 @@ class ViewParallelTrainer:
         self._all_reduce(report)
         return {"loss": float(report[3]), "l1": float(report[0]) / n_views, "ssim": float(report[1]) / n_views,
                 "psnr": float(report[2]) / n_views, "scale_reg": float(reg.detach())}
+
+    def _training_step_fused(self, batch: Sequence[Dict]) -> Dict[str, float]:
+        """Same step with the HIP loss and Adam kernels.  One host read-back, at the end (the metrics)."""
+        from . import stages as S
+        m, c = self.model, self.cfg
+        m.zero_grad()
+        params = m.activated()
+        degree = self.active_sh_degree()
+        dev = m.flat.device
+        n_views = len(batch)
+        renders, v_renders, sums = [], [], []
+        for view in batch[self.rank::self.world]:
+            viewpoint = {"world_view_transform": view["pose"], "image_width": view["width"],
+                         "image_height": view["height"]}
+            out = self.backend.render_with_depth(params, viewpoint, bg_color=torch.zeros(3, device=dev),
+                                                 render_mode="RGB", device=str(dev), sh_degree=degree)
+            rendered = out["render"]
+            s3, v = S.view_loss(rendered.detach(), view["image"], c.lambda_dssim, grad_scale=1.0 / n_views)
+            renders.append(rendered)
+            v_renders.append(v)
+            sums.append(s3 / float(rendered.numel()))     # -> l1, ssim, mse of this view
+        reg = scale_ratio_reg(params["scales"], c.scale_reg_max_ratio, c.scale_reg_weight)
+        roots, seeds = list(renders), list(v_renders)
+        if self.rank == 0:
+            roots.append(reg)
+            seeds.append(torch.ones_like(reg))
+        if roots:
+            torch.autograd.backward(roots, seeds)
+        self._all_reduce(m.flat_grad)  # the one exchange step: 59*N floats, SUM
+        self.optimizer.step()
+
+        report = torch.zeros(4, dtype=torch.float64, device=dev)  # l1, ssim, psnr sums over local views; loss share
+        if sums:
+            per_view = torch.stack(sums)                           # [B_local, 3]
+            mse = per_view[:, 2]
+            psnr_v = torch.where(mse < 1e-10, torch.full_like(mse, 100.0), -10.0 * torch.log10(mse.clamp_min(1e-300)))
+            loss_v = (1.0 - c.lambda_dssim) * per_view[:, 0] + c.lambda_dssim * (1.0 - per_view[:, 1])
+            report[0], report[1], report[2] = per_view[:, 0].sum(), per_view[:, 1].sum(), psnr_v.sum()
+            report[3] = loss_v.sum() / n_views
+        if self.rank == 0:
+            report[3] += reg.detach().double()
+        self._all_reduce(report)
+        r = report.tolist()
+        return {"loss": r[3], "l1": r[0] / n_views, "ssim": r[1] / n_views, "psnr": r[2] / n_views,
+                "scale_reg": float(reg.detach())}

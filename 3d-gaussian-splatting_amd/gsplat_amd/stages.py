@@ -290,3 +290,37 @@ def project_bwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat
           _ptr(colors), sh_degree, sh_coeffs, _ptr(viewmat), _ptr(Kmat), width, height, _ptr(splat), _ptr(radii),
           _ptr(v_splat), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac), _ptr(v_colors), _stream())
     return v_means, v_quats, v_scales, v_opac, v_colors
+
+
+# ---- training-step stages around the rasterizer ------------------------------------
+def view_loss(render: torch.Tensor, target: torch.Tensor, lambda_dssim: float, grad_scale: float = 1.0,
+              want_grad: bool = True):
+    """The reference's per-view loss (trainer.py:485-492) and its gradient in two streaming passes.
+    render / target: [H,W,3] fp32 on the device.  -> (sums [3] float64 on the device: sum |d|, sum SSIM map,
+    sum d^2 over the 3HW elements; v_render [H,W,3] = grad_scale * d loss / d render, or None)."""
+    if render.shape != target.shape or render.dim() != 3 or render.shape[2] != 3:
+        raise ValueError("render and target must both be [H,W,3]")
+    h, w = int(render.shape[0]), int(render.shape[1])
+    r, t = f32c(render, "render"), f32c(target, "target")
+    ws_bytes = lib.gsa_view_loss_workspace_bytes(w, h)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=r.device)
+    sums = torch.zeros(3, dtype=torch.float64, device=r.device)
+    v = torch.empty_like(r) if want_grad else None
+    _call("gsa_view_loss", lib.gsa_view_loss, w, h, _ptr(r), _ptr(t), float(lambda_dssim), float(grad_scale), _ptr(ws),
+          ws_bytes, _ptr(v), _ptr(sums), _stream())
+    return sums, v
+
+
+def adam_step(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
+              segment_end, segment_lr, step: int, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-15) -> None:
+    """One fused Adam update of a flat fp32 bucket in place (torch.optim.Adam arithmetic, per-segment lr)."""
+    import ctypes
+    n = param.numel()
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
+            raise ValueError("adam_step needs four contiguous fp32 device tensors of equal size")
+    k = len(segment_end)
+    ends = (ctypes.c_longlong * k)(*[int(e) for e in segment_end])
+    lrs = (ctypes.c_float * k)(*[float(x) for x in segment_lr])
+    _call("gsa_adam_step", lib.gsa_adam_step, n, _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), k,
+          ctypes.cast(ends, ctypes.c_void_p), ctypes.cast(lrs, ctypes.c_void_p), beta1, beta2, eps, int(step), _stream())

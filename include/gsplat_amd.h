@@ -162,6 +162,29 @@ int gsa_project_bwd(int n, const float *means, const float *quats, const float *
                     float *v_quats, float *v_scales, float *v_opacities, float *v_colors,
                     gsa_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training-step stages around the rasterizer.
+ *
+ * gsa_view_loss: the reference's per-view loss, src/training/trainer.py:485-492 --
+ *   loss = (1 - lambda) * L1(img, target) + lambda * (1 - SSIM_3x3(img, target)),  img = clamp(render, 0, 1) with a
+ *   straight-through gradient (:102-107), SSIM with a 3x3 zero-padded box window (:354-371) -- and its gradient with
+ *   respect to the render.  render/target: [H,W,3] fp32.  sums[3] (double, ACCUMULATED: zero them first) receive
+ *   sum |img - target|, sum SSIM map, sum (img - target)^2 over the 3 H W elements (L1 = sums[0] / 3HW, SSIM =
+ *   sums[1] / 3HW, PSNR's mse = sums[2] / 3HW, :70-75).  v_render (may be NULL) = grad_scale * d loss / d render.
+ *   workspace: gsa_view_loss_workspace_bytes(width, height).
+ *
+ * gsa_adam_step: one torch.optim.Adam step (no weight decay, no amsgrad) over a flat bucket of n floats split into
+ *   n_segments (<= 8) consecutive segments, segment k = [segment_end[k-1], segment_end[k]) with learning rate
+ *   segment_lr[k] (host arrays; segment_end[n_segments-1] == n) -- the six parameter groups of
+ *   trainer.py:331-340 laid out in one 59 N buffer.  step = 1 for the first update. */
+size_t gsa_view_loss_workspace_bytes(int width, int height);
+int gsa_view_loss(int width, int height, const float *render, const float *target, float lambda_dssim,
+                  float grad_scale, void *workspace, size_t workspace_bytes, float *v_render, double *sums,
+                  gsa_stream_t stream);
+int gsa_adam_step(long long n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                  int n_segments, const long long *segment_end, const float *segment_lr, double beta1,
+                  double beta2, double eps, int step, gsa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

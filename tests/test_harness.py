@@ -161,3 +161,68 @@ def test_training_step_on_hip_backend_matches_reference_trainer(gold):
     trainer = ViewParallelTrainer(model, gsplat_amd.HipBackend(_t(gold["K"], "cuda")))
     trainer.iteration = int(gold["step_iteration"])
     _check_against_golden(gold, model, trainer, batch, tol_metric=2e-5, tol_grad=2e-3, tol_param=2e-4)
+
+
+@pytest.mark.gpu
+def test_fused_training_step_matches_reference_trainer(gold):
+    """The same two steps with the HIP rasterizer AND the fused HIP loss (gsa_view_loss) and Adam (gsa_adam_step)
+    kernels: still the reference trainer's metrics, gradients, parameters and Adam moments."""
+    import gsplat_amd
+    from gsplat_amd.harness import ViewParallelTrainer
+    model, batch = _model_and_batch(gold, "cuda")
+    trainer = ViewParallelTrainer(model, gsplat_amd.HipBackend(_t(gold["K"], "cuda")), fused=True)
+    trainer.iteration = int(gold["step_iteration"])
+    _check_against_golden(gold, model, trainer, batch, tol_metric=2e-5, tol_grad=2e-3, tol_param=2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(32, 48), (67, 130), (1, 5)])
+def test_view_loss_kernel_matches_torch_formulation(gold, shape):
+    """gsa_view_loss vs autograd through the harness's torch formulation of the reference's loss (trainer.py:485-492):
+    L1, SSIM, mse and d loss / d render; values outside [0, 1] exercise the straight-through clamp."""
+    from gsplat_amd import stages as S
+    from gsplat_amd.harness import view_loss
+    h, w = shape
+    g = torch.Generator().manual_seed(h * 1000 + w)
+    render = (torch.rand(h, w, 3, generator=g) * 1.4 - 0.2).cuda()
+    target = torch.rand(h, w, 3, generator=g).cuda()
+    lam, scale = 0.2, 0.25
+    sums, v = S.view_loss(render, target, lam, grad_scale=scale)
+    r64 = render.double().requires_grad_(True)
+    loss, l1, ssim = view_loss(r64, target.double(), lam)
+    (loss * scale).backward()
+    n = render.numel()
+    assert abs(float(sums[0]) / n - float(l1.detach())) < 1e-6 and abs(float(sums[1]) / n - float(ssim.detach())) < 1e-5
+    mse = float(((render.clamp(0, 1) - target) ** 2).double().mean())
+    assert abs(float(sums[2]) / n - mse) < 1e-7
+    assert _rel(v.cpu().numpy(), r64.grad.float().cpu().numpy()) < 2e-4
+    # pinned transitively on the reference: view_loss / ssim_3x3 reproduce the reference's own SSIM, PSNR and
+    # straight-through-clamp goldens in test_helper_functions_match_reference
+
+
+@pytest.mark.gpu
+def test_fused_adam_matches_torch_adam():
+    """gsa_adam_step over a flat bucket with per-segment learning rates == torch.optim.Adam with the same groups,
+    five steps, including a ragged tail (length not a multiple of 4) and zero gradients."""
+    from gsplat_amd import stages as S
+    torch.manual_seed(0)
+    sizes, lrs = [37, 128, 1003, 2], [1.6e-4, 2.5e-3, 0.05, 1e-3]
+    n = sum(sizes)
+    flat = torch.randn(n, device="cuda")
+    ref_params = [p.clone().requires_grad_(True) for p in flat.split(sizes)]
+    opt = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(ref_params, lrs)], lr=0.0, eps=1e-15)
+    m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+    ends = list(np.cumsum(sizes))
+    for step in range(1, 6):
+        g = torch.randn(n, device="cuda") * (10.0 ** torch.randint(-6, 2, (n,), device="cuda").float())
+        g[::7] = 0.0
+        for p, gp in zip(ref_params, g.split(sizes)):
+            p.grad = gp.clone()
+        opt.step()
+        S.adam_step(flat, g, m, v, ends, lrs, step)
+        ref = torch.cat([p.detach() for p in ref_params])
+        assert float((flat - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    st = opt.state[ref_params[2]]
+    # moments: same update up to how (g - m) * 0.1 is fused; an element's error is bounded relative to the tensor
+    assert _rel(m.split(sizes)[2].cpu().numpy(), st["exp_avg"].cpu().numpy()) < 1e-6
+    assert _rel(v.split(sizes)[2].cpu().numpy(), st["exp_avg_sq"].cpu().numpy()) < 1e-6

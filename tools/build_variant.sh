@@ -4,7 +4,7 @@ set -e
 name=$1; shift
 R=$(cd $(dirname $0)/.. && pwd); C=$R/3d-gaussian-splatting_amd/csrc; L=$R/3d-gaussian-splatting_amd/lib; T=/tmp/gsa_var_$name
 mkdir -p $T
-for f in abi project sort composite; do
+for f in abi project sort composite train_step; do
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -munsafe-fp-atomics -fno-slp-vectorize -I$R/include -I$C "$@" -c $C/$f.hip -o $T/$f.o &
 done
 wait
