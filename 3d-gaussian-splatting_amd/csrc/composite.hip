@@ -18,10 +18,11 @@
 //  * Walk: one 8-B LDS broadcast yields four list entries; each record is three LDS broadcasts.  The blend body
 //    has no scalar mask logic and, in the common case, no per-record select at all (optimistic group of four;
 //    see walk_fwd).  A wave stops as soon as its 64 pixels are finished.
-//  * Backward: records are taken in PAIRS; the 2 x 9 (10) per-pixel moment contributions are summed over the
-//    wave by one transpose-reduce (v_permlane32_swap / v_permlane16_swap / DPP adds with bank masks: ~22 VALU
-//    per record instead of ~55 for per-value butterflies) and added with ONE atomic instruction whose active
-//    lanes cover the two 64-B gradient records.  The sweep accumulates raw moments of u = dL/dsigma;
+//  * Backward: records are taken FOUR at a time; the 4 x 9 (10) per-pixel moment contributions are summed over
+//    the wave by one transpose-reduce (DPP adds with bank masks for the two widest levels, then
+//    v_permlane32_swap / v_permlane16_swap, then two select folds: ~18 VALU per record instead of ~55 for
+//    per-value butterflies) and added with ONE atomic instruction whose active lanes cover the four 64-B
+//    gradient records.  The sweep accumulates raw moments of u = dL/dsigma;
 //    project_bwd turns them into mean / conic / opacity gradients once per gaussian.
 //
 // Instruction costs that shaped the bodies (tools/inst_microbench.hip, cycles per wave64 instruction per SIMD):
@@ -427,45 +428,46 @@ __device__ __forceinline__ float fold_sel(float x, float y, bool hi) {
     const float keep = hi ? y : x, send = hi ? x : y;
     return keep + dpp_mov<CTRL>(send);
 }
-constexpr int kRor8 = 0x128, kHalfMirror = 0x141, kQuadXor2 = 0x4E, kQuadXor1 = 0xB1;
+constexpr int kQuadXor2 = 0x4E, kQuadXor1 = 0xB1;
 
-// Sums 2 * NF per-lane values (NF fields of two records, v[2 * f + e]) over the wave.  On return the lane with
-//   field = 8 b1 + 4 b2 + 2 b3 + b4 (b1 = 0)  or  8 + b4 (b1 = 1, b2 = b3 = 0),   record e = b5
-// (b_k = bit k of the lane id) holds the total of v[2 * field + e]; lanes 2k and 2k+1 hold the same value.
+// Sums 4 * NF per-lane values (NF fields of FOUR records, v[4 * f + e]) over the wave.  The levels are ordered by
+// cost: the two bank-masked DPP levels (lane bits 3, 2) take the 36 (40) -> 9 (10) halvings, the permlane swaps
+// (bits 5, 4) the next two, the select folds (bits 1, 0) the last two values.  On return the lane with
+//   record e = 2 b2 + b3,   field f = 2 (2 r + b4) + b5  with r = b1 (b0 = 0)  or  r = 2, b1 = b4 = 0 (b0 = 1)
+// (b_k = bit k of the lane id) holds the wave-wide total of v[4 * f + e]; the other lanes hold duplicates.
 template <int NF>
-__device__ __forceinline__ float reduce_pair(const float *v, int lane) {
+__device__ __forceinline__ float reduce_quad(const float *v, int lane) {
     static_assert(NF == 9 || NF == 10, "field count");
-    float w[10];
+    float k2[2 * NF];   // after bit 3: index = 2 f + (e >> 1), lanes with b3 hold the odd record of the pair
 #pragma unroll
-    for (int f = 0; f < NF; ++f) w[f] = fold32(v[2 * f], v[2 * f + 1]);
-    if (NF == 9) w[9] = w[8];
-    float z[5];
+    for (int i = 0; i < 2 * NF; ++i) k2[i] = fold8(v[2 * i], v[2 * i + 1]);
+    float m[10];        // after bit 2: index = f
 #pragma unroll
-    for (int k = 0; k < 5; ++k) z[k] = fold16(w[2 * k], w[2 * k + 1]);
-    const float y0 = fold8(z[0], z[1]), y1 = fold8(z[2], z[3]);
-    const float y2 = z[4] + dpp_mov<kRor8>(z[4]);
-    const float x0 = fold4(y0, y1);
-    const float x1 = y2 + dpp_mov<kHalfMirror>(y2);
-    const float r = fold_sel<kQuadXor2>(x0, x1, (lane & 2) != 0);
-    return r + dpp_mov<kQuadXor1>(r);
+    for (int f = 0; f < NF; ++f) m[f] = fold4(k2[2 * f], k2[2 * f + 1]);
+    if (NF == 9) m[9] = m[8];
+    float n[5];         // after bit 5: index = f >> 1
+#pragma unroll
+    for (int i = 0; i < 5; ++i) n[i] = fold32(m[2 * i], m[2 * i + 1]);
+    const float r0 = fold16(n[0], n[1]), r1 = fold16(n[2], n[3]), r2 = fold16(n[4], n[4]);   // after bit 4
+    const float s0 = fold_sel<kQuadXor2>(r0, r1, (lane & 2) != 0);                            // after bit 1
+    const float s1 = r2 + dpp_mov<kQuadXor2>(r2);
+    return fold_sel<kQuadXor1>(s0, s1, (lane & 1) != 0);                                      // after bit 0
 }
 
-// Walks n list entries (records in REVERSE list order), two per trip.
+// Walks n list entries (records in REVERSE list order), four per trip.
 template <int CH, int F4, bool CLAMP>
 __device__ __forceinline__ void walk_bwd(const Staged<F4> &st, int n, int lane, float pxf, float pyf, int binf,
                                          const float (&vout)[CH], float &T, float &Wd, int my_field, bool my_add,
-                                         bool my_rec1, float *__restrict__ v_splat) {
+                                         float *__restrict__ v_splat) {
     constexpr int NF = 6 + CH;
-    for (int i = 0; i < n; i += 2) {
-        const uint32_t o2 = *reinterpret_cast<const uint32_t *>(&st.list[i]);
-        const uint32_t off[2] = {o2 & 0xFFFFu, o2 >> 16};
-        float v[2 * NF];
-        uint32_t gid[2];
+    for (int i = 0; i < n; i += 4) {
+        const uint2 o4 = *reinterpret_cast<const uint2 *>(&st.list[i]);
+        const uint32_t off[4] = {o4.x & 0xFFFFu, o4.x >> 16, o4.y & 0xFFFFu, o4.y >> 16};
+        float v[4 * NF];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < 4; ++e) {
             const float4 *p = rec_at(st, off[e]);
             const float4 q0 = p[0], q1 = p[1], q2 = p[2];
-            gid[e] = __float_as_uint(q2.w);
             const float dx = q0.x - pxf, dy = q0.y - pyf;
             // the pixel stopped in front of this record (its list position is beyond the pixel's last one):
             // binf - position is negative, its sign bit switches the lane off
@@ -484,16 +486,21 @@ __device__ __forceinline__ void walk_bwd(const Staged<F4> &st, int n, int lane, 
             // d loss / d sigma = -alpha v_a where the record is blended and (CLAMP) not capped at 0.999 (a == raw)
             const float u = CLAMP ? ((a == raw) ? -raw * v_a : 0.f) : -a * v_a;
             const float udx = u * dx, udy = u * dy;
-            v[0 + e] = udx; v[2 + e] = udy; v[4 + e] = udx * dx; v[6 + e] = udx * dy; v[8 + e] = udy * dy;
-            v[10 + e] = u;
-            v[12 + e] = fac * vout[0]; v[14 + e] = fac * vout[1]; v[16 + e] = fac * vout[2];
-            if (CH == 4) v[18 + e] = fac * vout[CH - 1];
+            v[0 + e] = udx; v[4 + e] = udy; v[8 + e] = udx * dx; v[12 + e] = udx * dy; v[16 + e] = udy * dy;
+            v[20 + e] = u;
+            v[24 + e] = fac * vout[0]; v[28 + e] = fac * vout[1]; v[32 + e] = fac * vout[2];
+            if (CH == 4) v[36 + e] = fac * vout[CH - 1];
         }
-        // one transpose-reduce and one atomic instruction (two 64-B requests) per PAIR of records
-        const float total = reduce_pair<NF>(v, lane);
-        const uint32_t g = my_rec1 ? gid[1] : gid[0];
-        if (my_add && (!my_rec1 || i + 1 < n))
+        // one transpose-reduce and one atomic instruction (four 64-B requests) per FOUR records
+        const float total = reduce_quad<NF>(v, lane);
+        // this lane's record: e = 2 b2 + b3 -> its list entry -> the gaussian id stored with the staged record
+        const uint32_t word = (lane & 4) ? o4.y : o4.x;
+        const uint32_t my_off = (lane & 8) ? word >> 16 : word & 0xFFFFu;
+        const int e = ((lane >> 2) & 1) * 2 + ((lane >> 3) & 1);
+        if (my_add && i + e < n) {
+            const uint32_t g = __float_as_uint(rec_at(st, my_off)[2].w);
             atomicAdd(v_splat + (size_t)g * GSA_SPLAT_STRIDE + my_field, total);
+        }
     }
 }
 
@@ -555,11 +562,10 @@ __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_kernel(
     Row row = load_row(splat, gid_next, qmax - lane >= start);
     gid_next = load_gid(1);
 
-    // which (field, record) total this lane holds after reduce_pair, and whether it is the lane that adds it
-    const int my_field = (lane & 2) ? 8 + ((lane >> 4) & 1)
-                                    : ((lane >> 2) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 4) & 1);
-    const bool my_add = !(lane & 1) && my_field < NF && (!(lane & 2) || !(lane & 12));
-    const bool my_rec1 = (lane & 32) != 0;
+    // which field's total this lane holds after reduce_quad (see there), and whether it is the lane that adds it
+    const int my_r = (lane & 1) ? 2 : ((lane >> 1) & 1);
+    const int my_field = 2 * (2 * my_r + ((lane >> 4) & 1)) + ((lane >> 5) & 1);
+    const bool my_add = my_field < NF && (!(lane & 1) || !(lane & (2 | 16)));   // b0 = 1: fields 8, 9 live at b1 = b4 = 0
 
     GSA_TRACE_MARK(0);
     for (int top = qmax, j = 0; top >= start; top -= kBatch, ++j) {
@@ -571,9 +577,9 @@ __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_kernel(
         gid_next = load_gid(j + 2);
         GSA_TRACE_COUNT(n);
         if (any_cap)
-            walk_bwd<CH, F4, true>(st, n, lane, pxf, pyf, binf, vout, T, Wd, my_field, my_add, my_rec1, v_splat);
+            walk_bwd<CH, F4, true>(st, n, lane, pxf, pyf, binf, vout, T, Wd, my_field, my_add, v_splat);
         else
-            walk_bwd<CH, F4, false>(st, n, lane, pxf, pyf, binf, vout, T, Wd, my_field, my_add, my_rec1, v_splat);
+            walk_bwd<CH, F4, false>(st, n, lane, pxf, pyf, binf, vout, T, Wd, my_field, my_add, v_splat);
         GSA_TRACE_MARK(4);
     }
     GSA_TRACE_END(1, tile * 4 + q, qmax + 1 - start);
