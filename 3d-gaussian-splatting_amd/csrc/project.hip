@@ -13,9 +13,20 @@
 
 namespace {
 
-constexpr int kBlock = 256;
+#ifndef GSA_PROJ_BLOCK
+#define GSA_PROJ_BLOCK 256
+#endif
+constexpr int kBlock = GSA_PROJ_BLOCK;
 constexpr int kRowQ = 12;      // float4 per [16,3] SH row
 constexpr int kRowQPad = 13;   // padded LDS row (52 floats): conflict-free ds_read_b128 across lanes
+
+// Every wave stages and reads back ONLY its own 64 rows of the LDS image, so no workgroup barrier is needed: LDS
+// operations of one wave complete in order; the fences keep the compiler from reordering across the hand-over.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 template <int DEG>
 __host__ __device__ constexpr int sh_needed_q() {  // float4 per row that hold the active coefficients
@@ -32,7 +43,7 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(
     const float *__restrict__ viewmat, const float *__restrict__ intrin, int width, int height, int tile_w,
     int tile_h, int cull_mode, float *__restrict__ splat, int32_t *__restrict__ radii,
     int32_t *__restrict__ tiles_touched, uint32_t *__restrict__ depth_keys) {
-    __shared__ float4 sh_lds[STAGE ? 4 * 64 * kRowQPad : 1];
+    __shared__ float4 sh_lds[STAGE ? kBlock * kRowQPad : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long i = (long)blockIdx.x * kBlock + threadIdx.x;
 
@@ -47,7 +58,7 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(
             int row = idx / NQ, col = idx - row * NQ;
             if (row < rows) sh_lds[(wave * 64 + row) * kRowQPad + col] = src[row * kRowQ + col];
         }
-        __syncthreads();
+        wave_lds_sync();
     }
     if (i >= n) return;
 
@@ -143,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
     const int32_t *__restrict__ radii, const float *__restrict__ v_splat, float *__restrict__ v_means,
     float *__restrict__ v_quats, float *__restrict__ v_scales, float *__restrict__ v_opacities,
     float *__restrict__ v_colors) {
-    __shared__ float4 sh_lds[STAGE ? 4 * 64 * kRowQPad : 1];
+    __shared__ float4 sh_lds[STAGE ? kBlock * kRowQPad : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long i = (long)blockIdx.x * kBlock + threadIdx.x;
     const long wave_base = (long)blockIdx.x * kBlock + wave * 64;
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
             int row = idx / NQ, col = idx - row * NQ;
             if (row < rows) sh_lds[(wave * 64 + row) * kRowQPad + col] = src[row * kRowQ + col];
         }
-        __syncthreads();
+        wave_lds_sync();
     }
 
     bool active = i < n;
@@ -320,7 +331,7 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
     if constexpr (DEG < 0) {
         if (active) { v_colors[i * 3] = vc[0]; v_colors[i * 3 + 1] = vc[1]; v_colors[i * 3 + 2] = vc[2]; }
     } else if (STAGE) {
-        __syncthreads();  // all lanes have consumed their coefficient rows
+        wave_lds_sync();  // all lanes have consumed their coefficient rows
         float4 *row = &sh_lds[threadIdx.x * kRowQPad];
 #pragma unroll
         for (int k = 0; k < kRowQ; ++k) {
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
             v.w = 4 * k + 3 < NB * 3 ? vc[(4 * k + 3) % (NB * 3)] : 0.f;
             row[k] = v;
         }
-        __syncthreads();
+        wave_lds_sync();
         float4 *dst = reinterpret_cast<float4 *>(v_colors) + wave_base * kRowQ;
 #pragma unroll
         for (int k = 0; k < kRowQ; ++k) {
