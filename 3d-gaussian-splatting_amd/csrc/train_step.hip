@@ -9,7 +9,9 @@
 //                   (torch.optim.Adam as configured at trainer.py:331-340: betas 0.9 / 0.999, eps 1e-15, no weight
 //                   decay, no amsgrad): 4 arrays read, 3 written, once.
 //
-// Both are HBM-streaming kernels (fp32, no MFMA).
+//   gsa_densify_gather   rank 2: clone / split / prune of the parameter bucket AND its Adam moments as one gather pass.
+//
+// All are HBM-streaming kernels (fp32, no MFMA).
 
 #include "gsa_common.h"
 
@@ -171,7 +173,84 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(long n, float *__restric
     }
 }
 
+// Densify / prune as ONE gather pass (gaussian_model.py:110-366 does it as ~20 index / cat operations per
+// event): output row j of every field copies row src_row[j] of the old bucket.  kind[j]: 0 = survivor (Adam
+// moments travel with it), 1 = clone (moments zero), 2 = split child (moments zero, log-scale lowered by
+// log(1.6), position moved by noise * new scale -- gaussian_model.py:296-303).  Buckets are field-major:
+// field f occupies [off_f * n, (off_f + w_f) * n) with off_f = sum of the widths before it.
+struct FieldLayout {
+    int width[8], offset[8];   // floats per gaussian of field f; sum of the widths before it
+    int count, total, xyz, scaling;
+};
+
+__global__ __launch_bounds__(kThreads) void densify_gather_kernel(
+    long n_old, long n_new, FieldLayout lay, float log_split, const int32_t *__restrict__ src_row,
+    const uint8_t *__restrict__ kind, const float *__restrict__ noise, const float *__restrict__ old_p,
+    const float *__restrict__ old_m, const float *__restrict__ old_v, float *__restrict__ new_p,
+    float *__restrict__ new_m, float *__restrict__ new_v) {
+    const long e = (long)blockIdx.x * kThreads + threadIdx.x;
+    if (e >= n_new * lay.total) return;
+    // e enumerates the NEW bucket in memory order: field-major, then row, then component
+    int f = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+        if (k < lay.count && e >= (long)lay.offset[k] * n_new) f = k;
+    const long within = e - (long)lay.offset[f] * n_new;
+    const int w = lay.width[f];
+    const long j = within / w;
+    const int c = (int)(within - j * w);
+    const long src = src_row[j];
+    const int kd = kind[j];
+    const long so = (long)lay.offset[f] * n_old + src * w + c;
+    float val = old_p[so];
+    if (kd == 2) {
+        if (f == lay.scaling) val -= log_split;
+        if (f == lay.xyz) {
+            const float sc = old_p[(long)lay.offset[lay.scaling] * n_old + src * lay.width[lay.scaling] + c] - log_split;
+            val += noise[j * 3 + c] * expf(sc);
+        }
+    }
+    new_p[e] = val;
+    if (new_m) {
+        new_m[e] = kd == 0 ? old_m[so] : 0.f;
+        new_v[e] = kd == 0 ? old_v[so] : 0.f;
+    }
+}
+
 }  // namespace
+
+extern "C" int gsa_densify_gather(long long n_old, long long n_new, int n_fields, const int *field_width, int xyz_field,
+                                  int scaling_field, float log_split, const int32_t *src_row, const uint8_t *kind,
+                                  const float *noise, const float *old_param, const float *old_exp_avg,
+                                  const float *old_exp_avg_sq, float *new_param, float *new_exp_avg,
+                                  float *new_exp_avg_sq, gsa_stream_t stream) {
+    GSA_RETURN_IF(n_old < 0 || n_new < 0 || n_fields < 1 || n_fields > 8 || !field_width, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(xyz_field < 0 || xyz_field >= n_fields || scaling_field < 0 || scaling_field >= n_fields,
+                  GSA_ERR_INVALID_ARGUMENT);
+    if (n_new == 0) return GSA_OK;
+    GSA_RETURN_IF(!src_row || !kind || !noise || !old_param || !new_param, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF((old_exp_avg == nullptr) != (new_exp_avg == nullptr) || (old_exp_avg == nullptr) != (old_exp_avg_sq == nullptr) ||
+                      (new_exp_avg == nullptr) != (new_exp_avg_sq == nullptr), GSA_ERR_INVALID_ARGUMENT);
+    FieldLayout lay;
+    lay.count = n_fields; lay.xyz = xyz_field; lay.scaling = scaling_field;
+    int run = 0;
+    for (int k = 0; k < 8; ++k) {
+        lay.width[k] = k < n_fields ? field_width[k] : 1;
+        lay.offset[k] = run;
+        if (k < n_fields) {
+            GSA_RETURN_IF(field_width[k] <= 0, GSA_ERR_INVALID_ARGUMENT);
+            run += field_width[k];
+        }
+    }
+    lay.total = run;
+    GSA_RETURN_IF(field_width[xyz_field] != 3 || field_width[scaling_field] != 3, GSA_ERR_INVALID_ARGUMENT);
+    const int grid = gsa_div_up(n_new * run, kThreads);
+    densify_gather_kernel<<<grid, kThreads, 0, static_cast<hipStream_t>(stream)>>>(
+        (long)n_old, (long)n_new, lay, log_split, src_row, kind, noise, old_param, old_exp_avg, old_exp_avg_sq, new_param,
+        new_exp_avg, new_exp_avg_sq);
+    GSA_LAUNCH_CHECK();
+    return GSA_OK;
+}
 
 extern "C" size_t gsa_view_loss_workspace_bytes(int width, int height) {
     if (width <= 0 || height <= 0) return 0;

@@ -51,20 +51,124 @@ class SplatModel:
     (gaussian_model.py:59-108), stored as views of one flat buffer (+ one flat gradient bucket)."""
 
     def __init__(self, n: int, device="cuda"):
-        self.n = int(n)
-        self.flat = torch.zeros(FLOATS_PER_GAUSSIAN * self.n, dtype=torch.float32, device=device)
-        self.flat_grad = torch.zeros_like(self.flat)
-        off = 0
-        for name, shape in FIELDS:
-            cnt = self.n * math.prod(shape)
-            p = self.flat[off:off + cnt].view(self.n, *shape)
-            p.requires_grad_(True)
-            p.grad = self.flat_grad[off:off + cnt].view(self.n, *shape)
-            setattr(self, name, p)
-            off += cnt
+        self._bind(int(n), torch.zeros(FLOATS_PER_GAUSSIAN * int(n), dtype=torch.float32, device=device))
         with torch.no_grad():  # the reference's initial values (gaussian_model.py:66-84)
             self.scaling.fill_(-3.0)
             self.rotation[:, 0] = 1.0
+
+    def _bind(self, n: int, flat: torch.Tensor) -> None:
+        """(Re)create the six parameter views, their gradient views and the densification buffers over a flat
+        bucket of 59 * n floats (gaussian_model.py:66-80)."""
+        self.n = n
+        self.flat = flat
+        self.flat_grad = torch.zeros_like(flat)
+        off = 0
+        for name, shape in FIELDS:
+            cnt = n * math.prod(shape)
+            p = self.flat[off:off + cnt].view(n, *shape)
+            p.requires_grad_(True)
+            p.grad = self.flat_grad[off:off + cnt].view(n, *shape)
+            setattr(self, name, p)
+            off += cnt
+        dev = flat.device
+        self.xyz_gradient_accum = torch.zeros(n, 3, device=dev)
+        self.xyz_gradient_count = torch.zeros(n, 1, device=dev)
+        self.max_radii_2D = torch.zeros(n, device=dev)
+
+    @torch.no_grad()
+    def accumulate_xyz_grad(self) -> None:
+        """What the reference's loop does after every step (trainer.py:786-791)."""
+        self.xyz_gradient_accum += torch.norm(self.xyz.grad, dim=-1, keepdim=True)
+        self.xyz_gradient_count += 1
+
+    @torch.no_grad()
+    def densify_and_prune(self, grads_threshold: float, min_opacity: float, extent: float, optimizer=None,
+                          clone_extent_ratio: float = 0.1, prune_extent_ratio: float = 2.0,
+                          max_gaussians: Optional[int] = None, noise: Optional[torch.Tensor] = None) -> Dict:
+        """Counterpart of ``GaussianModel.densify_and_prune`` (gaussian_model.py:110-231) with the same selection
+        rules, row order and Adam-state splicing, but ONE data pass: the masks give a source-row map for the final
+        population ([survivors] + [clones] + [first children] + [second children], minus the pruned rows), and
+        ``gsa_densify_gather`` builds the new 59 N' bucket and both Adam moment buckets from it.
+        ``noise``: [2 * n_split, 3] standard-normal draws for the split offsets (gaussian_model.py:302; default:
+        drawn on the device).  ``optimizer``: ``FusedBucketAdam`` or ``torch.optim.Adam`` over this model, or None."""
+        from . import stages as S
+        if not self.flat.is_cuda:
+            raise RuntimeError("SplatModel.densify_and_prune runs on the HIP device only (no CPU path)")
+        n, dev = self.n, self.flat.device
+        stats = {"cloned": 0, "split": 0, "pruned": 0, "n_before": n, "capped": False}
+        grads_norm = torch.norm(self.xyz_gradient_accum / (self.xyz_gradient_count + 1e-8), dim=-1)
+        max_scale = torch.exp(self.scaling).amax(dim=-1)
+        opacity = torch.sigmoid(self.opacity).squeeze(-1)
+        hot = (grads_norm >= grads_threshold) & (opacity > min_opacity)
+        clone_mask = hot & (max_scale <= extent * clone_extent_ratio)
+        split_mask = hot & (max_scale > extent * clone_extent_ratio)
+        if max_gaussians is not None and n >= int(max_gaussians):       # population cap (:167-180)
+            clone_mask, split_mask = torch.zeros_like(clone_mask), torch.zeros_like(split_mask)
+            stats["capped"] = True
+        elif max_gaussians is not None:
+            allowed = int(max_gaussians) - n
+            if int(clone_mask.sum()) + int(split_mask.sum()) > allowed:
+                stats["capped"] = True
+                combined = clone_mask | split_mask
+                keep = torch.zeros_like(combined)
+                if allowed > 0:
+                    idx = combined.nonzero().view(-1)
+                    keep[idx[torch.topk(grads_norm[idx], k=allowed).indices]] = True
+                clone_mask, split_mask = clone_mask & keep, split_mask & keep
+        idx_keep = (~split_mask).nonzero().view(-1)
+        idx_clone = clone_mask.nonzero().view(-1)
+        idx_split = split_mask.nonzero().view(-1)
+        n_clone, n_split = int(idx_clone.numel()), int(idx_split.numel())
+        stats["cloned"], stats["split"] = n_clone, n_split
+        src = torch.cat([idx_keep, idx_clone, idx_split, idx_split])
+        kind = torch.cat([torch.zeros_like(idx_keep), torch.ones_like(idx_clone),
+                          torch.full((2 * n_split,), 2, dtype=idx_split.dtype, device=dev)])
+        if noise is None:
+            noise = torch.randn(2 * n_split, 3, device=dev)
+        noise = noise.to(dev, torch.float32).reshape(2 * n_split, 3)
+        log_split = torch.log(torch.tensor(1.6))                         # fp32, as the reference computes it (:298)
+        # prune rule on the population after clone + split (:213-215): low opacity OR too large
+        scale_s = self.scaling[src] - (kind == 2).float()[:, None] * log_split.to(dev)
+        low_op = opacity[src] < min_opacity
+        too_big = torch.exp(scale_s).amax(dim=-1) > extent * prune_extent_ratio
+        prune = low_op | too_big
+        stats["pruned"], stats["pruned_low_op"], stats["pruned_too_big"] = int(prune.sum()), int(low_op.sum()), int(too_big.sum())
+        final = ~prune
+        noise_full = torch.zeros(src.numel(), 3, device=dev)
+        noise_full[src.numel() - 2 * n_split:] = noise
+        src_f, kind_f, noise_f = src[final], kind[final], noise_full[final]
+        old_m = old_v = None
+        if isinstance(optimizer, FusedBucketAdam):
+            old_m, old_v = optimizer.exp_avg, optimizer.exp_avg_sq
+        elif optimizer is not None:                                      # torch.optim.Adam: gather its per-parameter state
+            old_m = torch.cat([optimizer.state[p]["exp_avg"].reshape(-1) if p in optimizer.state else
+                               torch.zeros_like(p).reshape(-1) for p in self.parameters()])
+            old_v = torch.cat([optimizer.state[p]["exp_avg_sq"].reshape(-1) if p in optimizer.state else
+                               torch.zeros_like(p).reshape(-1) for p in self.parameters()])
+        widths = [math.prod(shape) for _, shape in FIELDS]
+        names = [name for name, _ in FIELDS]
+        new_p, new_m, new_v = S.densify_gather(n, widths, names.index("xyz"), names.index("scaling"), float(log_split),
+                                               src_f, kind_f, noise_f, self.flat.detach(), old_m, old_v)
+        old_params = self.parameters()
+        radii = torch.where(kind_f == 0, self.max_radii_2D[src_f], torch.zeros((), device=dev))
+        self._bind(int(src_f.numel()), new_p)            # also resets the gradient accumulators (:227-228)
+        self.max_radii_2D = radii
+        if isinstance(optimizer, FusedBucketAdam):
+            optimizer.rebind(self, new_m, new_v)
+        elif optimizer is not None:
+            off = 0
+            for group, old, new in zip(optimizer.param_groups, old_params, self.parameters()):
+                state = optimizer.state.pop(old, None)
+                group["params"] = [new]
+                if state is not None:
+                    cnt = new.numel()
+                    state = dict(state)
+                    state["exp_avg"] = new_m[off:off + cnt].view(new.shape)
+                    state["exp_avg_sq"] = new_v[off:off + cnt].view(new.shape)
+                    optimizer.state[new] = state
+                off += new.numel()
+        stats["n_after"] = self.n
+        return stats
 
     def parameters(self) -> List[torch.Tensor]:
         return [getattr(self, name) for name, _ in FIELDS]
@@ -161,6 +265,19 @@ class FusedBucketAdam:
             cnt = p.numel()
             self.state[p] = {"exp_avg": self.exp_avg[off:off + cnt].view(p.shape),
                              "exp_avg_sq": self.exp_avg_sq[off:off + cnt].view(p.shape)}
+            off += cnt
+            self.segment_end.append(off)
+        assert off == model.flat.numel()
+
+    def rebind(self, model: SplatModel, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor) -> None:
+        """After the model changed size (densify / prune): adopt the spliced moment buckets and the new parameters."""
+        self.model, self.exp_avg, self.exp_avg_sq = model, exp_avg, exp_avg_sq
+        self.segment_end, self.state, off = [], {}, 0
+        for g, p in zip(self.param_groups, model.parameters()):
+            g["params"] = [p]
+            cnt = p.numel()
+            self.state[p] = {"exp_avg": exp_avg[off:off + cnt].view(p.shape),
+                             "exp_avg_sq": exp_avg_sq[off:off + cnt].view(p.shape)}
             off += cnt
             self.segment_end.append(off)
         assert off == model.flat.numel()

@@ -324,3 +324,28 @@ def adam_step(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, ex
     lrs = (ctypes.c_float * k)(*[float(x) for x in segment_lr])
     _call("gsa_adam_step", lib.gsa_adam_step, n, _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), k,
           ctypes.cast(ends, ctypes.c_void_p), ctypes.cast(lrs, ctypes.c_void_p), beta1, beta2, eps, int(step), _stream())
+
+
+def densify_gather(n_old: int, field_width, xyz_field: int, scaling_field: int, log_split: float, src_row: torch.Tensor,
+                   kind: torch.Tensor, noise: torch.Tensor, old_param: torch.Tensor, old_m=None, old_v=None):
+    """One gather pass over a field-major bucket (and optionally its Adam moments): see ``gsa_densify_gather``.
+    -> (new_param, new_m, new_v) flat fp32 tensors for n_new = len(src_row) rows."""
+    import ctypes
+    n_new = int(src_row.numel())
+    total = int(sum(field_width))
+    dev = old_param.device
+    if old_param.numel() != total * n_old or (old_m is None) != (old_v is None):
+        raise ValueError("densify_gather: bucket size / moment arguments inconsistent")
+    src = src_row.to(torch.int32).contiguous()
+    kd = kind.to(torch.uint8).contiguous()
+    nz = f32c(noise, "noise")
+    if nz.shape != (n_new, 3):
+        raise ValueError("noise must be [n_new, 3]")
+    new_p = torch.empty(total * n_new, dtype=torch.float32, device=dev)
+    new_m = torch.empty_like(new_p) if old_m is not None else None
+    new_v = torch.empty_like(new_p) if old_v is not None else None
+    widths = (ctypes.c_int * len(field_width))(*[int(w) for w in field_width])
+    _call("gsa_densify_gather", lib.gsa_densify_gather, n_old, n_new, len(field_width), ctypes.cast(widths, ctypes.c_void_p),
+          xyz_field, scaling_field, float(log_split), _ptr(src), _ptr(kd), _ptr(nz), _ptr(old_param), _ptr(old_m),
+          _ptr(old_v), _ptr(new_p), _ptr(new_m), _ptr(new_v), _stream())
+    return new_p, new_m, new_v

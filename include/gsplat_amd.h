@@ -177,6 +177,18 @@ int gsa_project_bwd(int n, const float *means, const float *quats, const float *
  *   n_segments (<= 8) consecutive segments, segment k = [segment_end[k-1], segment_end[k]) with learning rate
  *   segment_lr[k] (host arrays; segment_end[n_segments-1] == n) -- the six parameter groups of
  *   trainer.py:331-340 laid out in one 59 N buffer.  step = 1 for the first update. */
+/* gsa_densify_gather: the data movement of GaussianModel.densify_and_prune
+ * (src/gaussians/gaussian_model.py:110-366: clone, split into two, prune, with the Adam moments spliced through,
+ * :9-50) as ONE pass.  Buckets are field-major (field f of width field_width[f] occupies a contiguous block of
+ * width * n floats, fields in order).  Output row j copies old row src_row[j]; kind[j] = 0 survivor (moments kept),
+ * 1 clone (moments zero), 2 split child (moments zero; log-scale field lowered by log_split = log 1.6, xyz moved by
+ * noise[j] * exp(new log-scale), :296-303).  noise: [n_new,3].  The three moment pointers may all be NULL. */
+int gsa_densify_gather(long long n_old, long long n_new, int n_fields, const int *field_width, int xyz_field,
+                       int scaling_field, float log_split, const int32_t *src_row, const uint8_t *kind,
+                       const float *noise, const float *old_param, const float *old_exp_avg,
+                       const float *old_exp_avg_sq, float *new_param, float *new_exp_avg, float *new_exp_avg_sq,
+                       gsa_stream_t stream);
+
 size_t gsa_view_loss_workspace_bytes(int width, int height);
 int gsa_view_loss(int width, int height, const float *render, const float *target, float lambda_dssim,
                   float grad_scale, void *workspace, size_t workspace_bytes, float *v_render, double *sums,

@@ -226,3 +226,50 @@ def test_fused_adam_matches_torch_adam():
     # moments: same update up to how (g - m) * 0.1 is fused; an element's error is bounded relative to the tensor
     assert _rel(m.split(sizes)[2].cpu().numpy(), st["exp_avg"].cpu().numpy()) < 1e-6
     assert _rel(v.split(sizes)[2].cpu().numpy(), st["exp_avg_sq"].cpu().numpy()) < 1e-6
+
+
+DENSIFY_GOLDEN = os.path.join(HERE, "golden", "densify_golden.npz")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["free", "capped"])
+@pytest.mark.parametrize("opt_kind", ["fused", "torch"])
+def test_densify_and_prune_matches_reference_model(case, opt_kind):
+    """SplatModel.densify_and_prune (one HIP gather pass over the 59 N bucket and both Adam moment buckets) ==
+    the reference's GaussianModel.densify_and_prune with its optimizer-state splicing (gaussian_model.py:9-50,110-366)
+    on the same inputs and the same split noise: statistics, all six parameter tensors, all twelve Adam moments.
+    'capped' exercises the max_gaussians top-k path."""
+    from gsplat_amd.harness import FIELDS, FusedBucketAdam, SplatModel, _adam_groups, StepConfig
+    g = {k: v for k, v in np.load(DENSIFY_GOLDEN).items()}
+    names = [n for n, _ in FIELDS]
+    n = g[f"{case}_in_xyz"].shape[0]
+    model = SplatModel(n, "cuda").load(**{k: _t(g[f"{case}_in_{k}"], "cuda") for k in names})
+    model.xyz_gradient_accum = _t(g[f"{case}_in_accum"], "cuda")
+    model.xyz_gradient_count = _t(g[f"{case}_in_count"], "cuda")
+    groups = _adam_groups(model, StepConfig())
+    if opt_kind == "fused":
+        opt = FusedBucketAdam(model, groups)
+        opt.exp_avg.copy_(torch.cat([_t(g[f"{case}_in_m_{k}"], "cuda").reshape(-1) for k in names]))
+        opt.exp_avg_sq.copy_(torch.cat([_t(g[f"{case}_in_v_{k}"], "cuda").reshape(-1) for k in names]))
+    else:
+        opt = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        for k in names:
+            opt.state[getattr(model, k)] = {"step": torch.tensor(2.0), "exp_avg": _t(g[f"{case}_in_m_{k}"], "cuda").clone(),
+                                            "exp_avg_sq": _t(g[f"{case}_in_v_{k}"], "cuda").clone()}
+    thr, min_op, extent, clone_r, prune_r, cap = g[f"{case}_args"]
+    stats = model.densify_and_prune(float(thr), float(min_op), float(extent), optimizer=opt,
+                                    clone_extent_ratio=float(clone_r), prune_extent_ratio=float(prune_r),
+                                    max_gaussians=None if cap < 0 else int(cap), noise=_t(g[f"{case}_noise"], "cuda"))
+    got = [stats[k] for k in ("cloned", "split", "pruned", "pruned_low_op", "pruned_too_big", "n_before", "n_after")]
+    assert got + [int(stats["capped"])] == g[f"{case}_stats"].tolist()
+    assert model.n == stats["n_after"] and float(model.xyz_gradient_accum.abs().max()) == 0
+    for k in names:
+        p = getattr(model, k)
+        assert p.requires_grad and p.grad is not None and p.grad.shape == p.shape
+        assert tuple(p.shape) == g[f"{case}_out_{k}"].shape, k
+        assert _rel(p.detach().cpu().numpy(), g[f"{case}_out_{k}"]) < 1e-6, k
+        st = opt.state[p]
+        assert np.array_equal(st["exp_avg"].cpu().numpy(), g[f"{case}_out_m_{k}"]), k
+        assert np.array_equal(st["exp_avg_sq"].cpu().numpy(), g[f"{case}_out_v_{k}"]), k
+    assert [grp["params"][0] is getattr(model, k) for grp, k in zip(opt.param_groups, names)] == [True] * 6
+    opt.step() if opt_kind == "torch" else opt.step()   # the spliced optimizer still steps
