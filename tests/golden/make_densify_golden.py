@@ -83,6 +83,19 @@ def main():
             out[f"{name}_out_v_{f}"] = opt.state[p]["exp_avg_sq"].numpy().copy()
         assert float(model.xyz_gradient_accum.abs().max()) == 0 and model.xyz_gradient_accum.shape[0] == stats["n_after"]
         print(name, stats)
+    # ---- checkpoint files as the reference writes them (trainer.py:384-395,993): bare state_dict and wrapped
+    model, opt = build(seed=33)
+    small = GaussianModel(6, "cpu")
+    with torch.no_grad():
+        for f in FIELDS:
+            getattr(small, f).copy_(getattr(model, f)[:6])
+    opt_small = torch.optim.Adam([{"params": [getattr(small, f)], "lr": 1e-3, "name": f} for f in FIELDS], lr=0.0, eps=1e-15)
+    for f in FIELDS:
+        getattr(small, f).grad = torch.ones_like(getattr(small, f)) * 1e-3
+    opt_small.step()
+    torch.save(small.state_dict(), os.path.join(HERE, "reference_final_model.pth"))
+    torch.save({"iteration": 10000, "model_state": small.state_dict(), "optimizer_state": opt_small.state_dict(),
+                "n_gaussians": 6}, os.path.join(HERE, "reference_checkpoint_10000.pth"))
     path = os.path.join(HERE, "densify_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, f"{os.path.getsize(path) / 1024:.0f} KiB")
