@@ -488,3 +488,57 @@ def test_grad_out_writes_into_caller_bucket(gsa):
     with pytest.raises(ValueError):
         gsa.rasterization(*[sc[k] if k != "opacities" else sc[k][:, 0] for k in NAMES], vm.repeat(2, 1, 1),
                           K.repeat(2, 1, 1), W, H, sh_degree=3, grad_out=[bucket] * 5)
+
+
+def test_full_size_properties_c3_1m_1080p(gsa):
+    """BASELINE config C3 size (1M gaussians, 1920x1080, degree 3), where the CPU oracle is out of reach: properties
+    that hold at any size.  (a) the forward image is bit-reproducible; (b) the backward pass is linear in the
+    upstream gradient; (c) gaussians the contract culls (opacity below 1/255, behind the camera) change nothing,
+    wherever they sit in the arrays; (d) alpha = 1 - T stays in [0, 1] and every gradient is finite; (e) the record
+    list is sorted by (tile, depth) and every tile's slice matches its offsets."""
+    from gsplat_amd import scene
+    N, W, H = 1_000_000, 1920, 1080
+    sc = scene.make_scene(N, seed=0, sh_degree=3)      # the bench scene (SURVEY 8d), view 0
+    vm, K = scene.make_camera(0, 1)[None].cuda(), scene.make_intrinsics(W, H)[None].cuda()
+    v = scene.make_v_render(W, H, seed=2).cuda()[None]
+
+    def run(leaves_in, upstream=None):
+        leaves = [t.clone().requires_grad_(upstream is not None) for t in leaves_in]
+        r, a, meta = gsa.rasterization(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], vm, K, W, H, sh_degree=3,
+                                       backgrounds=torch.zeros(1, 3, device="cuda"))
+        if upstream is not None:
+            r.backward(upstream)
+        return r.detach(), a.detach(), meta, [t.grad for t in leaves]
+
+    base = [sc["means3D"].cuda(), sc["rotations"].cuda(), sc["scales"].cuda(), sc["opacities"][:, 0].cuda(), sc["shs"].cuda()]
+    r0, a0, m0, g1 = run(base, v)
+    r1, a1, _, g2 = run(base, 2.0 * v)
+    assert torch.equal(r0, r1) and torch.equal(a0, a1)                                   # (a)
+    for name, x, y in zip(NAMES, g1, g2):                                                # (b) atomics reorder sums
+        assert torch.isfinite(x).all() and torch.isfinite(y).all(), name                 # (d)
+        assert _rel(2.0 * x.cpu(), y.cpu()) < 1e-4, name
+    assert float(a0.min()) >= 0.0 and float(a0.max()) <= 1.0                             # (d)
+    # (c) 1000 culled gaussians spliced in at random positions (half invisible by opacity, half behind the camera)
+    g = torch.Generator().manual_seed(9)
+    extra = 1000
+    pos = torch.randperm(N + extra, generator=g)[:extra].sort().values
+    keep = torch.ones(N + extra, dtype=torch.bool)
+    keep[pos] = False
+    spliced = []
+    for t in base:
+        big = torch.empty(N + extra, *t.shape[1:], device="cuda")
+        big[keep.cuda()] = t
+        big[pos.cuda()] = t[:extra]
+        spliced.append(big)
+    spliced[3][pos[:extra // 2].cuda()] = 1.0 / 512.0                                    # alpha can never reach 1/255
+    spliced[0][pos[extra // 2:].cuda(), 2] = -10.0                                       # camera-space z = -6: behind it
+    r2, a2, m2, _ = run(spliced)
+    assert torch.equal(r2, r0) and torch.equal(a2, a0)
+    assert m2["n_isects"] == m0["n_isects"]
+    # (e) sortedness of the binned records
+    ids = m0["isect_ids"]
+    assert bool((ids[1:] >= ids[:-1]).all())
+    offs = m0["isect_offsets"].reshape(-1).long()
+    tiles = (ids >> 32)
+    first = torch.searchsorted(tiles, torch.arange(offs.numel(), device=tiles.device))
+    assert torch.equal(first, offs)
