@@ -39,33 +39,58 @@ __device__ __forceinline__ void block_add3(double a, double b, double c, double 
     }
 }
 
-// Pass 1, one thread per pixel: 3x3 box statistics (zero padding, divisor 9 -- avg_pool2d(3, 1, padding=1) with
-// count_include_pad) of a = clamp(render) and b = target per channel; the SSIM value and its partial derivatives
-// with respect to the three a-dependent statistics mu_a, E[a^2], E[ab] go to `partials` [H,W,3,3].
+// Both passes work on 32x8-pixel tiles: the tile plus its one-pixel halo is staged through LDS with coalesced
+// row reads (each input element is read from HBM/L2 about 1.4 times instead of 9), the 3x3 window then reads LDS.
+constexpr int kTileW = 32, kTileH = 8, kHaloW = kTileW + 2, kHaloH = kTileH + 2;
+
+// Stage `nch` floats per pixel of the tile at (x0, y0) with its halo into lds[(yy * kHaloW + xx) * nch + c];
+// outside the image: zeros (the zero padding of avg_pool2d).  CLAMP applies clamp(., 0, 1) on the way in.
+template <bool CLAMP>
+__device__ __forceinline__ void stage_tile(float *__restrict__ lds, const float *__restrict__ src, int nch, int x0, int y0,
+                                           int width, int height) {
+    const int row_floats = kHaloW * nch;
+    for (int i = threadIdx.x; i < kHaloH * row_floats; i += kThreads) {
+        const int yy = i / row_floats, rest = i - yy * row_floats;
+        const int y = y0 - 1 + yy, xf = (x0 - 1) * nch + rest;       // float offset inside image row y
+        float v = 0.f;
+        if (y >= 0 && y < height && xf >= 0 && xf < width * nch) {
+            v = src[(long)y * width * nch + xf];
+            if (CLAMP) v = clamp01(v);
+        }
+        lds[i] = v;
+    }
+}
+
+// Pass 1: 3x3 box statistics (zero padding, divisor 9 -- avg_pool2d(3, 1, padding=1) with count_include_pad) of
+// a = clamp(render) and b = target per channel; the SSIM value and its partial derivatives with respect to the
+// three a-dependent statistics mu_a, E[a^2], E[ab] go to `partials` [H,W,3,3].
 __global__ __launch_bounds__(kThreads) void loss_stats_kernel(int width, int height, const float *__restrict__ render,
                                                               const float *__restrict__ target,
                                                               float *__restrict__ partials, double *__restrict__ sums) {
-    const long p = (long)blockIdx.x * kThreads + threadIdx.x;
-    const long n_pix = (long)width * height;
+    __shared__ float sa[kHaloH * kHaloW * 3], sb[kHaloH * kHaloW * 3];
+    const int tiles_x = (width + kTileW - 1) / kTileW;
+    const int x0 = (blockIdx.x % tiles_x) * kTileW, y0 = (blockIdx.x / tiles_x) * kTileH;
+    stage_tile<true>(sa, render, 3, x0, y0, width, height);
+    stage_tile<false>(sb, target, 3, x0, y0, width, height);
+    __syncthreads();
+    const int lx = threadIdx.x % kTileW, ly = threadIdx.x / kTileW;
+    const int x = x0 + lx, y = y0 + ly;
     double l1 = 0, ssim = 0, mse = 0;
-    if (p < n_pix) {
-        const int x = (int)(p % width), y = (int)(p / width);
+    if (x < width && y < height) {
+        const long p = (long)y * width + x;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float sa = 0.f, sb = 0.f, saa = 0.f, sbb = 0.f, sab = 0.f;
+            float s_a = 0.f, s_b = 0.f, saa = 0.f, sbb = 0.f, sab = 0.f;
 #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
+            for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int xx = x + dx, yy = y + dy;
-                    if (xx >= 0 && xx < width && yy >= 0 && yy < height) {
-                        const long q = ((long)yy * width + xx) * 3 + c;
-                        const float a = clamp01(render[q]), b = target[q];
-                        sa += a; sb += b; saa += a * a; sbb += b * b; sab += a * b;
-                    }
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int q = ((ly + dy) * kHaloW + lx + dx) * 3 + c;
+                    const float a = sa[q], b = sb[q];
+                    s_a += a; s_b += b; saa += a * a; sbb += b * b; sab += a * b;
                 }
             const float inv9 = 1.f / 9.f;
-            const float mu_a = sa * inv9, mu_b = sb * inv9;
+            const float mu_a = s_a * inv9, mu_b = s_b * inv9;
             const float var_a = saa * inv9 - mu_a * mu_a, var_b = sbb * inv9 - mu_b * mu_b;
             const float cov = sab * inv9 - mu_a * mu_b;
             const float A1 = 2.f * mu_a * mu_b + kC1, A2 = 2.f * cov + kC2;
@@ -79,37 +104,39 @@ __global__ __launch_bounds__(kThreads) void loss_stats_kernel(int width, int hei
             const float dEab = 2.f * A1 * inv;   // A2 contains + 2 E[ab]
             float *out = partials + (p * 3 + c) * 3;
             out[0] = dmu; out[1] = dEaa; out[2] = dEab;
-            const long q0 = p * 3 + c;
-            const float a0 = clamp01(render[q0]), d0 = a0 - target[q0];
+            const int q0 = ((ly + 1) * kHaloW + lx + 1) * 3 + c;
+            const float d0 = sa[q0] - sb[q0];
             l1 += fabsf(d0); mse += (double)d0 * d0; ssim += S;
         }
     }
     block_add3(l1, ssim, mse, sums);
 }
 
-// Pass 2, one thread per pixel: v_render = grad_scale * [ (1 - lambda) sign(a - b) - lambda * adjoint of the box
-// filter applied to the partials ] / (3 H W); the clamp is straight-through (identity gradient).
+// Pass 2: v_render = grad_scale * [ (1 - lambda) sign(a - b) - lambda * adjoint of the box filter applied to the
+// partials ] / (3 H W); the clamp is straight-through (identity gradient).
 __global__ __launch_bounds__(kThreads) void loss_grad_kernel(int width, int height, const float *__restrict__ render,
                                                              const float *__restrict__ target,
                                                              const float *__restrict__ partials, float lambda_dssim,
                                                              float grad_scale, float *__restrict__ v_render) {
-    const long p = (long)blockIdx.x * kThreads + threadIdx.x;
-    const long n_pix = (long)width * height;
-    if (p >= n_pix) return;
-    const int x = (int)(p % width), y = (int)(p / width);
-    const float inv_count = grad_scale / (3.f * (float)n_pix);
+    __shared__ float sp[kHaloH * kHaloW * 9];
+    const int tiles_x = (width + kTileW - 1) / kTileW;
+    const int x0 = (blockIdx.x % tiles_x) * kTileW, y0 = (blockIdx.x / tiles_x) * kTileH;
+    stage_tile<false>(sp, partials, 9, x0, y0, width, height);   // outside the image: no window there, zeros
+    __syncthreads();
+    const int lx = threadIdx.x % kTileW, ly = threadIdx.x / kTileW;
+    const int x = x0 + lx, y = y0 + ly;
+    if (x >= width || y >= height) return;
+    const long p = (long)y * width + x;
+    const float inv_count = grad_scale / (3.f * (float)width * (float)height);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float s_mu = 0.f, s_aa = 0.f, s_ab = 0.f;
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
+        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int xx = x + dx, yy = y + dy;
-                if (xx >= 0 && xx < width && yy >= 0 && yy < height) {
-                    const float *in = partials + (((long)yy * width + xx) * 3 + c) * 3;
-                    s_mu += in[0]; s_aa += in[1]; s_ab += in[2];
-                }
+            for (int dx = 0; dx < 3; ++dx) {
+                const float *in = sp + (((ly + dy) * kHaloW + lx + dx) * 3 + c) * 3;
+                s_mu += in[0]; s_aa += in[1]; s_ab += in[2];
             }
         const long q = p * 3 + c;
         const float a = clamp01(render[q]), b = target[q];
@@ -263,7 +290,7 @@ extern "C" int gsa_view_loss(int width, int height, const float *render, const f
     GSA_RETURN_IF(width <= 0 || height <= 0 || !render || !target || !workspace || !sums, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(workspace_bytes < gsa_view_loss_workspace_bytes(width, height), GSA_ERR_WORKSPACE_TOO_SMALL);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int grid = gsa_div_up((long long)width * height, kThreads);
+    const int grid = gsa_div_up(width, kTileW) * gsa_div_up(height, kTileH);
     float *partials = static_cast<float *>(workspace);
     loss_stats_kernel<<<grid, kThreads, 0, s>>>(width, height, render, target, partials, sums);
     GSA_LAUNCH_CHECK();
