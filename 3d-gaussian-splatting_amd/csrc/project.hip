@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
     const float *__restrict__ intrin, int width, int height, const float *__restrict__ splat,
     const int32_t *__restrict__ radii, const float *__restrict__ v_splat, float *__restrict__ v_means,
     float *__restrict__ v_quats, float *__restrict__ v_scales, float *__restrict__ v_opacities,
-    float *__restrict__ v_colors) {
+    float *__restrict__ v_colors, int accumulate) {
     __shared__ float4 sh_lds[STAGE ? kBlock * kRowQPad : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long i = (long)blockIdx.x * kBlock + threadIdx.x;
@@ -320,7 +320,16 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
         }
     }
 
+    // accumulate (wave-uniform): add to what the output buffers hold instead of overwriting them -- the views of a
+    // batch then sum into ONE gradient bucket with no separate accumulation pass
     if (active) {
+        if (accumulate) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { vm[k] += v_means[i * 3 + k]; vs[k] += v_scales[i * 3 + k]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) vq[k] += v_quats[i * 4 + k];
+            vo += v_opacities[i];
+        }
         v_means[i * 3] = vm[0]; v_means[i * 3 + 1] = vm[1]; v_means[i * 3 + 2] = vm[2];
         v_quats[i * 4] = vq[0]; v_quats[i * 4 + 1] = vq[1]; v_quats[i * 4 + 2] = vq[2]; v_quats[i * 4 + 3] = vq[3];
         v_scales[i * 3] = vs[0]; v_scales[i * 3 + 1] = vs[1]; v_scales[i * 3 + 2] = vs[2];
@@ -329,7 +338,10 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
 
     // ---- colour gradient rows: every element written (zeros above the active degree / when culled)
     if constexpr (DEG < 0) {
-        if (active) { v_colors[i * 3] = vc[0]; v_colors[i * 3 + 1] = vc[1]; v_colors[i * 3 + 2] = vc[2]; }
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v_colors[i * 3 + k] = vc[k] + (accumulate ? v_colors[i * 3 + k] : 0.f);
+        }
     } else if (STAGE) {
         wave_lds_sync();  // all lanes have consumed their coefficient rows
         float4 *row = &sh_lds[threadIdx.x * kRowQPad];
@@ -348,13 +360,21 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
         for (int k = 0; k < kRowQ; ++k) {
             int idx = k * 64 + lane;
             int r_ = idx / kRowQ, c_ = idx - r_ * kRowQ;
-            if (r_ < rows) dst[idx] = sh_lds[(wave * 64 + r_) * kRowQPad + c_];
+            if (r_ < rows) {
+                float4 v = sh_lds[(wave * 64 + r_) * kRowQPad + c_];
+                if (accumulate) {
+                    const float4 o = dst[idx];
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                dst[idx] = v;
+            }
         }
     } else if (active) {
         float *row = v_colors + i * (long)sh_coeffs * 3;
-        for (int k = 0; k < sh_coeffs * 3; ++k) row[k] = 0.f;
+        if (!accumulate)
+            for (int k = 0; k < sh_coeffs * 3; ++k) row[k] = 0.f;
 #pragma unroll
-        for (int k = 0; k < NB * 3; ++k) row[k] = vc[k];
+        for (int k = 0; k < NB * 3; ++k) row[k] = vc[k] + (accumulate ? row[k] : 0.f);
     }
 }
 
@@ -381,16 +401,16 @@ template <int DEG>
 int launch_bwd(bool stage, int n, const float *means, const float *quats, const float *scales,
                const float *colors, int sh_coeffs, const float *viewmat, const float *intrin, int width,
                int height, const float *splat, const int32_t *radii, const float *v_splat, float *v_means,
-               float *v_quats, float *v_scales, float *v_opacities, float *v_colors, hipStream_t s) {
+               float *v_quats, float *v_scales, float *v_opacities, float *v_colors, int accumulate, hipStream_t s) {
     dim3 grid(gsa_div_up(n, kBlock)), block(kBlock);
     if (stage)
         project_bwd_kernel<DEG, true><<<grid, block, 0, s>>>(n, means, quats, scales, colors, sh_coeffs, viewmat,
                                                              intrin, width, height, splat, radii, v_splat, v_means,
-                                                             v_quats, v_scales, v_opacities, v_colors);
+                                                             v_quats, v_scales, v_opacities, v_colors, accumulate);
     else
         project_bwd_kernel<DEG, false><<<grid, block, 0, s>>>(n, means, quats, scales, colors, sh_coeffs, viewmat,
                                                               intrin, width, height, splat, radii, v_splat, v_means,
-                                                              v_quats, v_scales, v_opacities, v_colors);
+                                                              v_quats, v_scales, v_opacities, v_colors, accumulate);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }
@@ -430,13 +450,11 @@ extern "C" int gsa_project_fwd(int n, const float *means, const float *quats, co
 #undef GSA_FWD
 }
 
-extern "C" int gsa_project_bwd(int n, const float *means, const float *quats, const float *scales,
-                               const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
-                               const float *viewmat, const float *intrin, int width, int height,
-                               const float *splat, const int32_t *radii, const float *v_splat, float *v_means,
-                               float *v_quats, float *v_scales, float *v_opacities, float *v_colors,
-                               gsa_stream_t stream) {
-    (void)opacities;
+static int project_bwd_impl(int n, const float *means, const float *quats, const float *scales, const float *colors,
+                            int sh_degree, int sh_coeffs, const float *viewmat, const float *intrin, int width, int height,
+                            const float *splat, const int32_t *radii, const float *v_splat, float *v_means,
+                            float *v_quats, float *v_scales, float *v_opacities, float *v_colors, int accumulate,
+                            gsa_stream_t stream) {
     GSA_RETURN_IF(n < 0 || width <= 0 || height <= 0, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_degree < -1 || sh_degree > 3, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_degree >= 0 && sh_coeffs < (sh_degree + 1) * (sh_degree + 1), GSA_ERR_INVALID_ARGUMENT);
@@ -448,7 +466,7 @@ extern "C" int gsa_project_bwd(int n, const float *means, const float *quats, co
     bool stage = can_stage(colors, sh_degree, sh_coeffs) && (reinterpret_cast<uintptr_t>(v_colors) & 15) == 0;
 #define GSA_BWD(D)                                                                                                  \
     return launch_bwd<D>(stage, n, means, quats, scales, colors, sh_coeffs, viewmat, intrin, width, height, splat, \
-                         radii, v_splat, v_means, v_quats, v_scales, v_opacities, v_colors, s)
+                         radii, v_splat, v_means, v_quats, v_scales, v_opacities, v_colors, accumulate ? 1 : 0, s)
     switch (sh_degree) {
         case -1: GSA_BWD(-1);
         case 0: GSA_BWD(0);
@@ -457,4 +475,26 @@ extern "C" int gsa_project_bwd(int n, const float *means, const float *quats, co
         default: GSA_BWD(3);
     }
 #undef GSA_BWD
+}
+
+extern "C" int gsa_project_bwd(int n, const float *means, const float *quats, const float *scales,
+                               const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
+                               const float *viewmat, const float *intrin, int width, int height,
+                               const float *splat, const int32_t *radii, const float *v_splat, float *v_means,
+                               float *v_quats, float *v_scales, float *v_opacities, float *v_colors,
+                               gsa_stream_t stream) {
+    (void)opacities;
+    return project_bwd_impl(n, means, quats, scales, colors, sh_degree, sh_coeffs, viewmat, intrin, width, height, splat,
+                            radii, v_splat, v_means, v_quats, v_scales, v_opacities, v_colors, 0, stream);
+}
+
+extern "C" int gsa_project_bwd_acc(int n, const float *means, const float *quats, const float *scales,
+                                   const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
+                                   const float *viewmat, const float *intrin, int width, int height,
+                                   const float *splat, const int32_t *radii, const float *v_splat, float *v_means,
+                                   float *v_quats, float *v_scales, float *v_opacities, float *v_colors,
+                                   int accumulate, gsa_stream_t stream) {
+    (void)opacities;
+    return project_bwd_impl(n, means, quats, scales, colors, sh_degree, sh_coeffs, viewmat, intrin, width, height, splat,
+                            radii, v_splat, v_means, v_quats, v_scales, v_opacities, v_colors, accumulate, stream);
 }

@@ -22,8 +22,9 @@ constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 
 __device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
 
-// block sum of three doubles -> one atomicAdd each (sums[0..2])
-__device__ __forceinline__ void block_add3(double a, double b, double c, double *__restrict__ sums) {
+// block sum of three doubles -> block_sums[3 * blockIdx.x ..].  (One atomicAdd per block on the three result words was
+// the whole cost of the kernel: 8100 blocks hammering three addresses serialise at the memory side at ~90 adds/us.)
+__device__ __forceinline__ void block_add3(double a, double b, double c, double *__restrict__ block_sums) {
     __shared__ double red[3][kThreads / GSA_WAVE];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -35,7 +36,28 @@ __device__ __forceinline__ void block_add3(double a, double b, double c, double 
     if (threadIdx.x < 3) {
         double s = 0;
         for (int w = 0; w < kThreads / GSA_WAVE; ++w) s += red[threadIdx.x][w];
-        atomicAdd(&sums[threadIdx.x], s);
+        block_sums[3 * (long)blockIdx.x + threadIdx.x] = s;
+    }
+}
+
+// sums[k] += sum over blocks of block_sums[3 * b + k]   (one workgroup)
+__global__ __launch_bounds__(kThreads) void loss_finalize_kernel(int n_blocks, const double *__restrict__ block_sums,
+                                                                 double *__restrict__ sums) {
+    __shared__ double red[3][kThreads / GSA_WAVE];
+    double acc[3] = {0, 0, 0};
+    for (int b = threadIdx.x; b < n_blocks; b += kThreads)
+        for (int k = 0; k < 3; ++k) acc[k] += block_sums[3 * (long)b + k];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        for (int k = 0; k < 3; ++k) acc[k] += __shfl_xor(acc[k], d);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+        for (int k = 0; k < 3; ++k) red[k][wave] = acc[k];
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double s = 0;
+        for (int w = 0; w < kThreads / GSA_WAVE; ++w) s += red[threadIdx.x][w];
+        sums[threadIdx.x] += s;
     }
 }
 
@@ -66,7 +88,7 @@ __device__ __forceinline__ void stage_tile(float *__restrict__ lds, const float 
 // three a-dependent statistics mu_a, E[a^2], E[ab] go to `partials` [H,W,3,3].
 __global__ __launch_bounds__(kThreads) void loss_stats_kernel(int width, int height, const float *__restrict__ render,
                                                               const float *__restrict__ target,
-                                                              float *__restrict__ partials, double *__restrict__ sums) {
+                                                              float *__restrict__ partials, double *__restrict__ block_sums) {
     __shared__ float sa[kHaloH * kHaloW * 3], sb[kHaloH * kHaloW * 3];
     const int tiles_x = (width + kTileW - 1) / kTileW;
     const int x0 = (blockIdx.x % tiles_x) * kTileW, y0 = (blockIdx.x / tiles_x) * kTileH;
@@ -109,7 +131,7 @@ __global__ __launch_bounds__(kThreads) void loss_stats_kernel(int width, int hei
             l1 += fabsf(d0); mse += (double)d0 * d0; ssim += S;
         }
     }
-    block_add3(l1, ssim, mse, sums);
+    block_add3(l1, ssim, mse, block_sums);
 }
 
 // Pass 2: v_render = grad_scale * [ (1 - lambda) sign(a - b) - lambda * adjoint of the box filter applied to the
@@ -279,9 +301,14 @@ extern "C" int gsa_densify_gather(long long n_old, long long n_new, int n_fields
     return GSA_OK;
 }
 
+static size_t loss_partials_bytes(int width, int height) {   // [H,W,3,3] floats, rounded up to 8 B for the doubles behind
+    return (((size_t)width * height * 9 * sizeof(float)) + 7) & ~(size_t)7;
+}
+
 extern "C" size_t gsa_view_loss_workspace_bytes(int width, int height) {
     if (width <= 0 || height <= 0) return 0;
-    return (size_t)width * height * 9 * sizeof(float);
+    const size_t blocks = (size_t)gsa_div_up(width, kTileW) * gsa_div_up(height, kTileH);
+    return loss_partials_bytes(width, height) + blocks * 3 * sizeof(double);
 }
 
 extern "C" int gsa_view_loss(int width, int height, const float *render, const float *target, float lambda_dssim,
@@ -292,7 +319,10 @@ extern "C" int gsa_view_loss(int width, int height, const float *render, const f
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int grid = gsa_div_up(width, kTileW) * gsa_div_up(height, kTileH);
     float *partials = static_cast<float *>(workspace);
-    loss_stats_kernel<<<grid, kThreads, 0, s>>>(width, height, render, target, partials, sums);
+    double *block_sums = reinterpret_cast<double *>(static_cast<char *>(workspace) + loss_partials_bytes(width, height));
+    loss_stats_kernel<<<grid, kThreads, 0, s>>>(width, height, render, target, partials, block_sums);
+    GSA_LAUNCH_CHECK();
+    loss_finalize_kernel<<<1, kThreads, 0, s>>>(grid, block_sums, sums);
     GSA_LAUNCH_CHECK();
     if (v_render) {
         loss_grad_kernel<<<grid, kThreads, 0, s>>>(width, height, render, target, partials, lambda_dssim, grad_scale,

@@ -366,32 +366,55 @@ class ViewParallelTrainer:
                 "psnr": float(report[2]) / n_views, "scale_reg": float(reg.detach())}
 
     def _training_step_fused(self, batch: Sequence[Dict]) -> Dict[str, float]:
-        """Same step with the HIP loss and Adam kernels.  One host read-back, at the end (the metrics)."""
+        """Same step on the HIP kernels end to end.  Besides the loss and Adam kernels, the gradients never pass
+        through autograd's accumulation: the activations (trainer.py:399-406) are evaluated once without a graph,
+        every view's backward ADDS its activated-parameter gradients into one bucket (``grad_accumulate``), and the
+        activation derivatives are applied once, writing the raw-parameter gradients into ``flat_grad``.
+        One host read-back, at the end (the metrics)."""
         from . import stages as S
+        from .rasterization import rasterization
         m, c = self.model, self.cfg
-        m.zero_grad()
-        params = m.activated()
         degree = self.active_sh_degree()
         dev = m.flat.device
-        n_views = len(batch)
-        renders, v_renders, sums = [], [], []
+        n, n_views = m.n, len(batch)
+        K = self.backend.K.to(dev)[None]
+        bg = torch.zeros(1, 3, device=dev)
+        with torch.no_grad():
+            scales = torch.exp(m.scaling)
+            rot_norm = m.rotation.norm(dim=-1, keepdim=True).clamp_min(1e-12)     # F.normalize's eps
+            quats = m.rotation / rot_norm
+            opac = torch.sigmoid(m.opacity)
+            shs = torch.cat([m.features_dc, m.features_rest], dim=1)
+        # gradient bucket of the ACTIVATED parameters; the xyz part IS the raw xyz gradient (identity activation)
+        if getattr(self, "_act_grad", None) is None or self._act_grad[1].shape[0] != n:
+            self._act_grad = (None, torch.empty(n, 4, device=dev), torch.empty(n, 3, device=dev),
+                              torch.empty(n, device=dev), torch.empty(n, 16, 3, device=dev))
+        g_means = m.xyz.grad
+        _, g_quats, g_scales, g_opac, g_shs = self._act_grad
+        grad_out = [g_means, g_quats, g_scales, g_opac, g_shs]
+        leaves = [t.detach().requires_grad_(True) for t in (m.xyz, quats, scales, opac[:, 0], shs)]
+        sums, first = [], True
         for view in batch[self.rank::self.world]:
-            viewpoint = {"world_view_transform": view["pose"], "image_width": view["width"],
-                         "image_height": view["height"]}
-            out = self.backend.render_with_depth(params, viewpoint, bg_color=torch.zeros(3, device=dev),
-                                                 render_mode="RGB", device=str(dev), sh_degree=degree)
-            rendered = out["render"]
-            s3, v = S.view_loss(rendered.detach(), view["image"], c.lambda_dssim, grad_scale=1.0 / n_views)
-            renders.append(rendered)
-            v_renders.append(v)
-            sums.append(s3 / float(rendered.numel()))     # -> l1, ssim, mse of this view
-        reg = scale_ratio_reg(params["scales"], c.scale_reg_max_ratio, c.scale_reg_weight)
-        roots, seeds = list(renders), list(v_renders)
+            r, _, _ = rasterization(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], view["pose"][None], K,
+                                    view["width"], view["height"], sh_degree=degree, backgrounds=bg,
+                                    grad_out=grad_out, grad_accumulate=not first)
+            s3, v = S.view_loss(r[0].detach(), view["image"], c.lambda_dssim, grad_scale=1.0 / n_views)
+            r.backward(v[None])
+            sums.append(s3 / float(v.numel()))            # -> l1, ssim, mse of this view
+            first = False
+        with torch.no_grad():
+            if first:                                      # this rank rendered nothing
+                m.flat_grad.zero_()
+            else:                                          # chain rule of the activations, once (trainer.py:399-406)
+                m.scaling.grad.copy_(g_scales * scales)
+                dot = (g_quats * quats).sum(dim=-1, keepdim=True)
+                m.rotation.grad.copy_((g_quats - dot * quats) / rot_norm)
+                m.opacity.grad.copy_((g_opac * (opac[:, 0] * (1.0 - opac[:, 0])))[:, None])
+                m.features_dc.grad.copy_(g_shs[:, :1])
+                m.features_rest.grad.copy_(g_shs[:, 1:])
+        reg = scale_ratio_reg(torch.exp(m.scaling), c.scale_reg_max_ratio, c.scale_reg_weight)
         if self.rank == 0:
-            roots.append(reg)
-            seeds.append(torch.ones_like(reg))
-        if roots:
-            torch.autograd.backward(roots, seeds)
+            reg.backward()                                 # adds into scaling.grad (a view of flat_grad)
         self._all_reduce(m.flat_grad)  # the one exchange step: 59*N floats, SUM
         self.optimizer.step()
 

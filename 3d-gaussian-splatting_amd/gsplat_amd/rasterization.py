@@ -26,7 +26,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, colors, viewmat, Kmat, background,
-                width: int, height: int, sh_degree: int, channels: int, cull_mode: int, grad_out):
+                width: int, height: int, sh_degree: int, channels: int, cull_mode: int, grad_out, grad_accumulate):
         means_c, quats_c, scales_c = S.f32c(means, "means"), S.f32c(quats, "quats"), S.f32c(scales, "scales")
         opac_c, colors_c = S.f32c(opacities, "opacities"), S.f32c(colors, "colors")
         view_c, K_c = S.f32c(viewmat, "viewmats"), S.f32c(Kmat, "Ks")
@@ -51,6 +51,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
                               sorted_gid, tile_offsets, final_T, last_id, tile_order)
         ctx.dims = (width, height, sh_degree, channels)
         ctx.grad_out = grad_out
+        ctx.grad_accumulate = bool(grad_accumulate)
         ctx.in_shapes = (means.shape, quats.shape, scales.shape, opacities.shape, colors.shape)
         extras = (splat, radii, tiles_touched, sorted_tile, sorted_gid, tile_offsets, last_id)
         ctx.mark_non_differentiable(*extras)
@@ -69,10 +70,12 @@ class _RasterizeOneCamera(torch.autograd.Function):
         v_splat = S.composite_bwd(splat, sorted_gid, tile_offsets, bg_c, final_T, last_id, v_render, v_alpha_c,
                                   width, height, channels, tile_order)
         grads = S.project_bwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
-                              splat, radii, v_splat, out=ctx.grad_out)
+                              splat, radii, v_splat, out=ctx.grad_out, accumulate=ctx.grad_accumulate)
+        if ctx.grad_accumulate:   # the sums live in the caller's buffers; autograd gets nothing to accumulate
+            return (None,) * 15
         need = ctx.needs_input_grad
         grads = tuple(g.view(shp) if nd else None for g, shp, nd in zip(grads, ctx.in_shapes, need[:5]))
-        return grads + (None,) * 9
+        return grads + (None,) * 10
 
 
 def rasterization(
@@ -96,6 +99,7 @@ def rasterization(
     render_mode: str = "RGB",
     cull_mode: Optional[int] = None,
     grad_out=None,
+    grad_accumulate: bool = False,
     **unsupported,
 ) -> Tuple[torch.Tensor, torch.Tensor, Dict]:
     """Returns ``(renders [C,H,W,D], alphas [C,H,W,1], meta)``; ``meta['means2d']`` [C,N,2] and
@@ -105,7 +109,9 @@ def rasterization(
     1 = also skip tiles the alpha >= 1/255 ellipse cannot reach (same image and gradients, fewer records).
     ``grad_out`` (extension, single camera): five preallocated tensors (means, quats, scales, opacities, colors
     order) the backward pass writes its gradients into and hands to autograd -- e.g. views of one flat bucket
-    that is then all-reduced in one call.
+    that is then all-reduced in one call.  With ``grad_accumulate=True`` the backward pass ADDS into ``grad_out``
+    (which the caller has initialised) and hands autograd nothing: several views sum into one bucket with no
+    accumulation pass (``harness.ViewParallelTrainer(fused=True)``).
     """
     for k, v in unsupported.items():
         ok = (k in ("sparse_grad", "absgrad", "distributed") and not v) or \
@@ -141,6 +147,8 @@ def rasterization(
         raise ValueError("backgrounds must be [C,3]")
     if grad_out is not None and C != 1:
         raise ValueError("grad_out needs a single camera (each camera's backward would overwrite it)")
+    if grad_accumulate and grad_out is None:
+        raise ValueError("grad_accumulate needs grad_out")
     width, height = int(width), int(height)
     cull = S.DEFAULT_CULL_MODE if cull_mode is None else int(cull_mode)
     want_depth = render_mode != "RGB"
@@ -154,7 +162,7 @@ def rasterization(
             if want_depth:
                 bg = torch.cat([bg, bg.new_zeros(1)])
         out = _RasterizeOneCamera.apply(means, quats, scales, opacities, colors, viewmats[c], Ks[c], bg,
-                                        width, height, deg, channels, cull, grad_out)
+                                        width, height, deg, channels, cull, grad_out, grad_accumulate)
         render, alpha = out[0], out[1]
         if render_mode in ("ED", "RGB+ED"):
             render = torch.cat([render[..., :3], render[..., 3:] / alpha.clamp(min=1e-10)], dim=-1)

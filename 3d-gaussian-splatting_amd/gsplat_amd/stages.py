@@ -272,7 +272,7 @@ def composite_bwd(splat, sorted_gid, tile_offsets, background, final_T, last_id,
 
 
 def project_bwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat, Kmat, width: int, height: int,
-                splat, radii, v_splat, out=None):
+                splat, radii, v_splat, out=None, accumulate: bool = False):
     """-> v_means, v_quats, v_scales, v_opacities, v_colors (every element written).  ``out``: five preallocated
     contiguous fp32 tensors to write into instead (e.g. views of one flat all-reduce bucket)."""
     N = means.shape[0]
@@ -286,9 +286,12 @@ def project_bwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat
             if got.numel() != like.numel() or got.dtype != torch.float32 or not got.is_contiguous() \
                     or got.device != like.device:
                 raise ValueError("grad_out tensors must be contiguous fp32, sized like the inputs, on their device")
-    _call("gsa_project_bwd", lib.gsa_project_bwd, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
+    if accumulate and out is None:
+        raise ValueError("project_bwd(accumulate=True) needs the `out` buffers it adds to")
+    _call("gsa_project_bwd", lib.gsa_project_bwd_acc, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
           _ptr(colors), sh_degree, sh_coeffs, _ptr(viewmat), _ptr(Kmat), width, height, _ptr(splat), _ptr(radii),
-          _ptr(v_splat), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac), _ptr(v_colors), _stream())
+          _ptr(v_splat), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac), _ptr(v_colors),
+          1 if accumulate else 0, _stream())
     return v_means, v_quats, v_scales, v_opac, v_colors
 
 

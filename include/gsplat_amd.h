@@ -162,6 +162,15 @@ int gsa_project_bwd(int n, const float *means, const float *quats, const float *
                     float *v_quats, float *v_scales, float *v_opacities, float *v_colors,
                     gsa_stream_t stream);
 
+/* The same with `accumulate` != 0: ADD to what the five output buffers hold (which must then be fully initialised)
+ * instead of overwriting them -- the views of a batch sum into one gradient bucket without a separate pass. */
+int gsa_project_bwd_acc(int n, const float *means, const float *quats, const float *scales,
+                        const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
+                        const float *viewmat, const float *intrin, int width, int height,
+                        const float *splat, const int32_t *radii, const float *v_splat, float *v_means,
+                        float *v_quats, float *v_scales, float *v_opacities, float *v_colors,
+                        int accumulate, gsa_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Training-step stages around the rasterizer.
  *

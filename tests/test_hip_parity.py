@@ -490,6 +490,39 @@ def test_grad_out_writes_into_caller_bucket(gsa):
                           K.repeat(2, 1, 1), W, H, sh_degree=3, grad_out=[bucket] * 5)
 
 
+@pytest.mark.parametrize("deg", [None, 1, 3])
+def test_grad_accumulate_sums_views_into_one_bucket(gsa, deg):
+    """``grad_accumulate``: the backward passes of several views ADD into the caller's buffers (first view overwrites)
+    and autograd receives nothing; the bucket equals the sum of the per-view gradients of the default path."""
+    from gsplat_amd import scene
+    W, H, n = 160, 96, 3000
+    sc = {k: v.cuda() for k, v in _scene(n, seed=2).items()}
+    colors = sc["shs"] if deg is not None else (sc["shs"][:, 0, :] * 0.28 + 0.5).contiguous()
+    K = scene.make_intrinsics(W, H).cuda()[None]
+    views = [scene.make_camera(v, 7).cuda()[None] for v in (1, 3, 4)]
+    w = torch.linspace(0.5, 1.5, 3, device="cuda")
+    base = [sc["means3D"], sc["rotations"], sc["scales"], sc["opacities"][:, 0].contiguous(), colors]
+    ref = [torch.zeros_like(t) for t in base]
+    for vm in views:
+        leaves = [t.clone().requires_grad_(True) for t in base]
+        r, _, _ = gsa.rasterization(*leaves, vm, K, W, H, sh_degree=deg)
+        (r * w).sum().backward()
+        for acc, t in zip(ref, leaves):
+            acc += t.grad
+    bucket = [torch.full_like(t, float("nan")) for t in base]
+    leaves = [t.clone().requires_grad_(True) for t in base]
+    for i, vm in enumerate(views):
+        r, _, _ = gsa.rasterization(*leaves, vm, K, W, H, sh_degree=deg, grad_out=bucket, grad_accumulate=i > 0)
+        (r * w).sum().backward()
+    # the overwriting first view hands autograd the bucket tensors themselves; the accumulating ones hand it nothing
+    assert all(t.grad is None or t.grad.data_ptr() == b.data_ptr() for t, b in zip(leaves, bucket))
+    for name, a, b in zip(NAMES, bucket, ref):
+        assert not torch.isnan(a).any(), name
+        assert _rel(a.reshape(-1).cpu(), b.reshape(-1).cpu()) < 1e-5, name
+    with pytest.raises(ValueError):
+        gsa.rasterization(*base, views[0], K, W, H, sh_degree=deg, grad_accumulate=True)
+
+
 def test_full_size_properties_c3_1m_1080p(gsa):
     """BASELINE config C3 size (1M gaussians, 1920x1080, degree 3), where the CPU oracle is out of reach: properties
     that hold at any size.  (a) the forward image is bit-reproducible; (b) the backward pass is linear in the

@@ -16,7 +16,7 @@ sc = scene.make_scene(n, seed=0, sh_degree=3)
 K = scene.make_intrinsics(W, H).to(dev)
 batch = [{"image": torch.rand(H, W, 3, device=dev), "pose": scene.make_camera(v, B).to(dev), "width": W, "height": H}
          for v in range(B)]
-for fused in (False, True):
+for fused in ((True,) if os.environ.get("FUSED_ONLY") else (False, True)):
     model = SplatModel(n, dev).load(xyz=sc["means3D"].to(dev), features_dc=sc["shs"][:, :1].to(dev),
                                     features_rest=sc["shs"][:, 1:].to(dev),
                                     opacity=torch.logit(sc["opacities"].clamp(1e-4, 1 - 1e-4)).to(dev),
