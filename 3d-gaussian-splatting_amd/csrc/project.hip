@@ -47,6 +47,17 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long i = (long)blockIdx.x * kBlock + threadIdx.x;
 
+    // geometry first: these loads are in flight while the SH rows are staged (one memory round trip per wave less;
+    // the kernel is latency-bound: ~80 % of its wave-cycles are waits on memory)
+    float g_mean[3] = {0.f, 0.f, 0.f}, g_quat[4] = {1.f, 0.f, 0.f, 0.f}, g_scale[3] = {1.f, 1.f, 1.f}, g_opac = 0.f;
+    if (i < n) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { g_mean[k] = means[i * 3 + k]; g_scale[k] = scales[i * 3 + k]; }
+        const float4 q4 = *reinterpret_cast<const float4 *>(quats + i * 4);
+        g_quat[0] = q4.x; g_quat[1] = q4.y; g_quat[2] = q4.z; g_quat[3] = q4.w;
+        g_opac = opacities[i];
+    }
+
     if constexpr (STAGE && DEG >= 1) {
         constexpr int NQ = sh_needed_q<DEG>();
         const long wave_base = (long)blockIdx.x * kBlock + wave * 64;
@@ -63,8 +74,8 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(
     if (i >= n) return;
 
     GsaCamera cam = gsa_load_camera(viewmat, intrin);
-    GsaProj p = gsa_project_one(cam, means + i * 3, quats + i * 4, scales + i * 3, width, height);
-    const float opac = opacities[i];
+    GsaProj p = gsa_project_one(cam, g_mean, g_quat, g_scale, width, height);
+    const float opac = g_opac;
 
     bool visible = p.ok && (opac >= GSA_ALPHA_THRESHOLD);
     float sig_max = logf(fmaxf(opac, GSA_ALPHA_THRESHOLD) * 255.0f);  // alpha >= 1/255  <=>  sigma <= ln(255 o)
@@ -91,8 +102,7 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(
         r = colors[i * 3]; g = colors[i * 3 + 1]; b = colors[i * 3 + 2];
     } else {
         constexpr int NB = (DEG + 1) * (DEG + 1);
-        float dx = means[i * 3] - cam.campos[0], dy = means[i * 3 + 1] - cam.campos[1],
-              dz = means[i * 3 + 2] - cam.campos[2];
+        float dx = g_mean[0] - cam.campos[0], dy = g_mean[1] - cam.campos[1], dz = g_mean[2] - cam.campos[2];
         float inv = rsqrtf(dx * dx + dy * dy + dz * dz);
         float B[NB];
         gsa_sh_basis<DEG>(dx * inv, dy * inv, dz * inv, B);
@@ -161,6 +171,23 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
     const long rows = min((long)64, (long)n - wave_base);
     constexpr int NB = DEG < 0 ? 1 : (DEG + 1) * (DEG + 1);
 
+    // per-gaussian inputs first: in flight while the SH rows are staged (see the forward kernel)
+    const bool active = i < n;
+    float g_mean[3] = {0.f, 0.f, 0.f}, g_quat[4] = {1.f, 0.f, 0.f, 0.f}, g_scale[3] = {1.f, 1.f, 1.f};
+    int g_rx = 0, g_ry = 0;
+    float4 g_v0 = make_float4(0.f, 0.f, 0.f, 0.f), g_v1 = g_v0, g_v2 = g_v0, g_s1 = g_v0, g_s2 = g_v0;
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { g_mean[k] = means[i * 3 + k]; g_scale[k] = scales[i * 3 + k]; }
+        const float4 q4 = *reinterpret_cast<const float4 *>(quats + i * 4);
+        g_quat[0] = q4.x; g_quat[1] = q4.y; g_quat[2] = q4.z; g_quat[3] = q4.w;
+        g_rx = radii[2 * i]; g_ry = radii[2 * i + 1];
+        const float4 *vrow = reinterpret_cast<const float4 *>(v_splat + i * GSA_SPLAT_STRIDE);
+        g_v0 = vrow[0]; g_v1 = vrow[1]; g_v2 = vrow[2];
+        const float4 *srow = reinterpret_cast<const float4 *>(splat + i * GSA_SPLAT_STRIDE);
+        g_s1 = srow[1]; g_s2 = srow[2];
+    }
+
     if constexpr (STAGE && DEG >= 1) {
         constexpr int NQ = sh_needed_q<DEG>();
         const float4 *src = reinterpret_cast<const float4 *>(colors) + wave_base * kRowQ;
@@ -173,8 +200,7 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
         wave_lds_sync();
     }
 
-    bool active = i < n;
-    bool visible = active && radii[2 * i] > 0 && radii[2 * i + 1] > 0;
+    bool visible = active && g_rx > 0 && g_ry > 0;
     float vm[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f}, vo = 0.f;
     float vc[NB * 3];
 #pragma unroll
@@ -182,13 +208,12 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
 
     if (visible) {
         GsaCamera cam = gsa_load_camera(viewmat, intrin);
-        GsaProj p = gsa_project_one(cam, means + i * 3, quats + i * 4, scales + i * 3, width, height);
-        const float4 *vrow = reinterpret_cast<const float4 *>(v_splat + i * GSA_SPLAT_STRIDE);
-        float4 v0 = vrow[0], v1 = vrow[1], v2 = vrow[2];
+        GsaProj p = gsa_project_one(cam, g_mean, g_quat, g_scale, width, height);
+        const float4 v0 = g_v0, v1 = g_v1, v2 = g_v2;
         // The sweep leaves the raw moments of u = d loss / d sigma over d = mean2d - pixel (composite.hip):
         // sigma = (a dx^2 + c dy^2) / 2 + b dx dy and alpha = o * exp(-sigma) make every gradient linear in them.
         const float m_dx = v0.x, m_dy = v0.y, m_dxdx = v0.z, m_dxdy = v0.w, m_dydy = v1.x, m_u = v1.y;
-        const float s_opac = splat[i * GSA_SPLAT_STRIDE + 5];
+        const float s_opac = g_s1.y;
         float v_mx = p.qa * m_dx + p.qb * m_dy, v_my = p.qb * m_dx + p.qc * m_dy;
         float v_a = 0.5f * m_dxdx, v_b = m_dxdy, v_c = 0.5f * m_dydy;
         vo = -m_u / s_opac;   // d alpha / d o = alpha / o  and  u = -alpha * v_alpha
@@ -277,11 +302,9 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
         if constexpr (DEG < 0) {
             vc[0] = v_rgb[0]; vc[1] = v_rgb[1]; vc[2] = v_rgb[2];
         } else {
-            const float4 *srow = reinterpret_cast<const float4 *>(splat + i * GSA_SPLAT_STRIDE);
-            float4 s1 = srow[1], s2 = srow[2];
+            const float4 s1 = g_s1, s2 = g_s2;
             float vr[3] = {s1.z > 0.f ? v_rgb[0] : 0.f, s1.w > 0.f ? v_rgb[1] : 0.f, s2.x > 0.f ? v_rgb[2] : 0.f};
-            float dx = means[i * 3] - cam.campos[0], dy = means[i * 3 + 1] - cam.campos[1],
-                  dz = means[i * 3 + 2] - cam.campos[2];
+            float dx = g_mean[0] - cam.campos[0], dy = g_mean[1] - cam.campos[1], dz = g_mean[2] - cam.campos[2];
             float inv = rsqrtf(dx * dx + dy * dy + dz * dz);
             float ux = dx * inv, uy = dy * inv, uz = dz * inv;
             float B[NB];
