@@ -18,7 +18,10 @@
 namespace {
 
 constexpr int kSortThreads = 256;
-constexpr int kSortItems = 16;                          // keys per thread
+#ifndef GSA_SORT_ITEMS
+#define GSA_SORT_ITEMS 16
+#endif
+constexpr int kSortItems = GSA_SORT_ITEMS;               // keys per thread
 constexpr int kSortChunk = kSortThreads * kSortItems;   // keys per block
 constexpr int kRadix = 256;
 
