@@ -146,7 +146,11 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(
 
     out[0] = make_float4(p.mx, p.my, p.qa, p.qb);
     out[1] = make_float4(p.qc, opac, r, g);
-    out[2] = make_float4(b, p.z, sig_max, 0.f);
+    // record word 11: the tile rectangle, packed (x0 | y0 << 10 | width << 20; 0 when a coordinate needs more than
+    // 10 bits) -- tile_emit then needs this one line per gaussian instead of the mean AND the radii
+    const bool packable = tile_w < 1024 && tile_h < 1024;
+    const uint32_t rect = packable ? ((uint32_t)tr.x0 | ((uint32_t)tr.y0 << 10) | ((uint32_t)(tr.x1 - tr.x0) << 20)) : 0u;
+    out[2] = make_float4(b, p.z, sig_max, __uint_as_float(rect));
     out[3] = make_float4(0.f, 0.f, 0.f, 0.f);
     radii[2 * i] = rx; radii[2 * i + 1] = ry;
     tiles_touched[i] = count;

@@ -318,11 +318,18 @@ __global__ __launch_bounds__(kSortThreads) void tile_emit_coop_kernel(
     if (k < n) {
         g = order[k];
         begin = min(offsets[k], m_total);   // clamp: with a device-side count the buffers may be too small (caller re-runs)
-        const int rx = radii[2 * (long)g], ry = radii[2 * (long)g + 1];
-        if (rx > 0 && ry > 0) {
-            const float2 m2 = *reinterpret_cast<const float2 *>(splat + (long)g * GSA_SPLAT_STRIDE);
-            GsaTileRect tr = gsa_tile_rect(m2.x, m2.y, rx, ry, tile_w, tile_h);
-            x0 = tr.x0; y0 = tr.y0; wd = max(tr.x1 - tr.x0, 1);
+        // the projection packed the tile rectangle into word 11 of the record (one gathered line per gaussian);
+        // 0 = culled (zero record) or not packable -> recompute from the mean and the radii
+        const uint32_t rect = __float_as_uint(splat[(long)g * GSA_SPLAT_STRIDE + 11]);
+        if (rect != 0u) {
+            x0 = (int)(rect & 1023u); y0 = (int)((rect >> 10) & 1023u); wd = max((int)(rect >> 20), 1);
+        } else {
+            const int rx = radii[2 * (long)g], ry = radii[2 * (long)g + 1];
+            if (rx > 0 && ry > 0) {
+                const float2 m2 = *reinterpret_cast<const float2 *>(splat + (long)g * GSA_SPLAT_STRIDE);
+                GsaTileRect tr = gsa_tile_rect(m2.x, m2.y, rx, ry, tile_w, tile_h);
+                x0 = tr.x0; y0 = tr.y0; wd = max(tr.x1 - tr.x0, 1);
+            }
         }
     }
     const uint32_t wave_base = __builtin_amdgcn_readfirstlane(begin);
