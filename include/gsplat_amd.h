@@ -126,8 +126,9 @@ int gsa_tile_offsets(uint32_t m, const uint32_t *sorted_tile, int n_tiles, int32
  * Stage 3 (row a3.4): front-to-back alpha compositing of RGB (channels == 3) or RGB+depth
  * (channels == 4) per 16x16 tile.  background: [channels] or NULL (= zeros).
  * Outputs: render[H,W,channels], alpha[H,W] = 1 - T, final_T[H,W] = T (saved for the backward: recomputing
- * 1 - alpha would lose the low bits of a small T), last_id[H,W] int32 (index into the sorted list of
- * the last splat blended, -1 if none).
+ * 1 - alpha would lose the low bits of a small T), last_id[H,W] int32: position in the sorted list of the last
+ * record the pixel's 8x8 quadrant walked while the pixel was still accumulating (it may itself have failed the
+ * alpha test there), -1 if none -- where stage 4 starts its reverse sweep for that pixel.
  */
 int gsa_composite_fwd(int width, int height, int channels, const float *splat,
                       const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
