@@ -160,14 +160,17 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(
 // ------------------------------------------------------------------------------------------------
 // backward (A.7)
 // ------------------------------------------------------------------------------------------------
-template <int DEG, bool STAGE>
+template <int DEG, bool STAGE, bool FACTORED>
 __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
     int n, const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
     const float *__restrict__ colors, int sh_coeffs, const float *__restrict__ viewmat,
     const float *__restrict__ intrin, int width, int height, const float *__restrict__ splat,
     const int32_t *__restrict__ radii, const float *__restrict__ v_splat, float *__restrict__ v_means,
     float *__restrict__ v_quats, float *__restrict__ v_scales, float *__restrict__ v_opacities,
-    float *__restrict__ v_colors, int accumulate) {
+    float *__restrict__ v_colors, int accumulate, float *__restrict__ v_rgb_out) {
+    // v_rgb_out (optional, [N,3]): FACTORED colour gradient -- instead of the [N,K,3] SH-coefficient gradient
+    // (v_colors, then unused) write only d loss / d rgb after the clamp mask.  The SH gradient is the outer product of
+    // the view's SH basis with it (gsa_sh_grad_expand), so 3 floats per gaussian carry what 48 would.
     __shared__ float4 sh_lds[STAGE ? kBlock * kRowQPad : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long i = (long)blockIdx.x * kBlock + threadIdx.x;
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
 
     bool visible = active && g_rx > 0 && g_ry > 0;
     float vm[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f}, vo = 0.f;
-    float vc[NB * 3];
+    float vc[NB * 3], vr_keep[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < NB * 3; ++k) vc[k] = 0.f;
 
@@ -308,14 +311,17 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
         } else {
             const float4 s1 = g_s1, s2 = g_s2;
             float vr[3] = {s1.z > 0.f ? v_rgb[0] : 0.f, s1.w > 0.f ? v_rgb[1] : 0.f, s2.x > 0.f ? v_rgb[2] : 0.f};
+            vr_keep[0] = vr[0]; vr_keep[1] = vr[1]; vr_keep[2] = vr[2];
             float dx = g_mean[0] - cam.campos[0], dy = g_mean[1] - cam.campos[1], dz = g_mean[2] - cam.campos[2];
             float inv = rsqrtf(dx * dx + dy * dy + dz * dz);
             float ux = dx * inv, uy = dy * inv, uz = dz * inv;
-            float B[NB];
-            gsa_sh_basis<DEG>(ux, uy, uz, B);
+            if constexpr (!FACTORED) {
+                float B[NB];
+                gsa_sh_basis<DEG>(ux, uy, uz, B);
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                vc[3 * j] = B[j] * vr[0]; vc[3 * j + 1] = B[j] * vr[1]; vc[3 * j + 2] = B[j] * vr[2];
+                for (int j = 0; j < NB; ++j) {
+                    vc[3 * j] = B[j] * vr[0]; vc[3 * j + 1] = B[j] * vr[1]; vc[3 * j + 2] = B[j] * vr[2];
+                }
             }
             if constexpr (DEG >= 1) {
                 float cf[NB * 3];
@@ -364,7 +370,9 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
     }
 
     // ---- colour gradient rows: every element written (zeros above the active degree / when culled)
-    if constexpr (DEG < 0) {
+    if constexpr (FACTORED) {
+        if (active) { v_rgb_out[i * 3] = vr_keep[0]; v_rgb_out[i * 3 + 1] = vr_keep[1]; v_rgb_out[i * 3 + 2] = vr_keep[2]; }
+    } else if constexpr (DEG < 0) {
         if (active) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) v_colors[i * 3 + k] = vc[k] + (accumulate ? v_colors[i * 3 + k] : 0.f);
@@ -428,16 +436,22 @@ template <int DEG>
 int launch_bwd(bool stage, int n, const float *means, const float *quats, const float *scales,
                const float *colors, int sh_coeffs, const float *viewmat, const float *intrin, int width,
                int height, const float *splat, const int32_t *radii, const float *v_splat, float *v_means,
-               float *v_quats, float *v_scales, float *v_opacities, float *v_colors, int accumulate, hipStream_t s) {
+               float *v_quats, float *v_scales, float *v_opacities, float *v_colors, int accumulate, float *v_rgb_out,
+               hipStream_t s) {
     dim3 grid(gsa_div_up(n, kBlock)), block(kBlock);
-    if (stage)
-        project_bwd_kernel<DEG, true><<<grid, block, 0, s>>>(n, means, quats, scales, colors, sh_coeffs, viewmat,
-                                                             intrin, width, height, splat, radii, v_splat, v_means,
-                                                             v_quats, v_scales, v_opacities, v_colors, accumulate);
-    else
-        project_bwd_kernel<DEG, false><<<grid, block, 0, s>>>(n, means, quats, scales, colors, sh_coeffs, viewmat,
-                                                              intrin, width, height, splat, radii, v_splat, v_means,
-                                                              v_quats, v_scales, v_opacities, v_colors, accumulate);
+#define GSA_BWD_LAUNCH(ST, FA)                                                                                        \
+    project_bwd_kernel<DEG, ST, FA><<<grid, block, 0, s>>>(n, means, quats, scales, colors, sh_coeffs, viewmat, intrin,  \
+                                                           width, height, splat, radii, v_splat, v_means, v_quats,      \
+                                                           v_scales, v_opacities, v_colors, accumulate, v_rgb_out)
+    if constexpr (DEG >= 0) {
+        if (v_rgb_out) {
+            if (stage) GSA_BWD_LAUNCH(true, true); else GSA_BWD_LAUNCH(false, true);
+            GSA_LAUNCH_CHECK();
+            return GSA_OK;
+        }
+    }
+    if (stage) GSA_BWD_LAUNCH(true, false); else GSA_BWD_LAUNCH(false, false);
+#undef GSA_BWD_LAUNCH
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }
@@ -481,19 +495,21 @@ static int project_bwd_impl(int n, const float *means, const float *quats, const
                             int sh_degree, int sh_coeffs, const float *viewmat, const float *intrin, int width, int height,
                             const float *splat, const int32_t *radii, const float *v_splat, float *v_means,
                             float *v_quats, float *v_scales, float *v_opacities, float *v_colors, int accumulate,
-                            gsa_stream_t stream) {
+                            float *v_rgb_out, gsa_stream_t stream) {
     GSA_RETURN_IF(n < 0 || width <= 0 || height <= 0, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_degree < -1 || sh_degree > 3, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_degree >= 0 && sh_coeffs < (sh_degree + 1) * (sh_degree + 1), GSA_ERR_INVALID_ARGUMENT);
     if (n == 0) return GSA_OK;
     GSA_RETURN_IF(!means || !quats || !scales || !colors || !viewmat || !intrin || !splat || !radii || !v_splat ||
-                      !v_means || !v_quats || !v_scales || !v_opacities || !v_colors,
+                      !v_means || !v_quats || !v_scales || !v_opacities || (!v_colors && !v_rgb_out),
                   GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(v_rgb_out && sh_degree < 0, GSA_ERR_INVALID_ARGUMENT);   // factored form: SH colours only
     hipStream_t s = static_cast<hipStream_t>(stream);
-    bool stage = can_stage(colors, sh_degree, sh_coeffs) && (reinterpret_cast<uintptr_t>(v_colors) & 15) == 0;
+    bool stage = can_stage(colors, sh_degree, sh_coeffs) &&
+                 (v_rgb_out || (reinterpret_cast<uintptr_t>(v_colors) & 15) == 0);
 #define GSA_BWD(D)                                                                                                  \
     return launch_bwd<D>(stage, n, means, quats, scales, colors, sh_coeffs, viewmat, intrin, width, height, splat, \
-                         radii, v_splat, v_means, v_quats, v_scales, v_opacities, v_colors, accumulate ? 1 : 0, s)
+                         radii, v_splat, v_means, v_quats, v_scales, v_opacities, v_colors, accumulate ? 1 : 0, v_rgb_out, s)
     switch (sh_degree) {
         case -1: GSA_BWD(-1);
         case 0: GSA_BWD(0);
@@ -512,7 +528,7 @@ extern "C" int gsa_project_bwd(int n, const float *means, const float *quats, co
                                gsa_stream_t stream) {
     (void)opacities;
     return project_bwd_impl(n, means, quats, scales, colors, sh_degree, sh_coeffs, viewmat, intrin, width, height, splat,
-                            radii, v_splat, v_means, v_quats, v_scales, v_opacities, v_colors, 0, stream);
+                            radii, v_splat, v_means, v_quats, v_scales, v_opacities, v_colors, 0, nullptr, stream);
 }
 
 extern "C" int gsa_project_bwd_acc(int n, const float *means, const float *quats, const float *scales,
@@ -523,5 +539,86 @@ extern "C" int gsa_project_bwd_acc(int n, const float *means, const float *quats
                                    int accumulate, gsa_stream_t stream) {
     (void)opacities;
     return project_bwd_impl(n, means, quats, scales, colors, sh_degree, sh_coeffs, viewmat, intrin, width, height, splat,
-                            radii, v_splat, v_means, v_quats, v_scales, v_opacities, v_colors, accumulate, stream);
+                            radii, v_splat, v_means, v_quats, v_scales, v_opacities, v_colors, accumulate, nullptr, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// factored SH gradient: project_bwd writes d loss / d rgb [N,3]; the [N,K,3] coefficient gradient is rebuilt from it
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+// v_colors[g][k][c] (+)= sum over views v of  basis_k(normalise(mean_g - campos_v)) * v_rgb[v][g][c]
+// One thread per gaussian; rows above the active degree are written as zeros (or left alone when accumulating).
+template <int DEG>
+__global__ __launch_bounds__(256) void sh_grad_expand_kernel(int n, const float *__restrict__ means, int sh_coeffs,
+                                                             int n_views, const float *__restrict__ viewmats,
+                                                             const float *__restrict__ intrin,
+                                                             const float *__restrict__ v_rgb, float *__restrict__ v_colors,
+                                                             int accumulate) {
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float mx = means[i * 3], my = means[i * 3 + 1], mz = means[i * 3 + 2];
+    float acc[NB * 3];
+#pragma unroll
+    for (int k = 0; k < NB * 3; ++k) acc[k] = 0.f;
+    for (int v = 0; v < n_views; ++v) {
+        const float *vr = v_rgb + ((long)v * n + i) * 3;
+        const float r = vr[0], g = vr[1], b = vr[2];
+        if (r == 0.f && g == 0.f && b == 0.f) continue;          // culled in that view (or clamped away)
+        const GsaCamera cam = gsa_load_camera(viewmats + 16 * v, intrin);
+        const float dx = mx - cam.campos[0], dy = my - cam.campos[1], dz = mz - cam.campos[2];
+        const float inv = rsqrtf(dx * dx + dy * dy + dz * dz);
+        float B[NB];
+        gsa_sh_basis<DEG>(dx * inv, dy * inv, dz * inv, B);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { acc[3 * k] += B[k] * r; acc[3 * k + 1] += B[k] * g; acc[3 * k + 2] += B[k] * b; }
+    }
+    float *row = v_colors + i * (long)sh_coeffs * 3;
+    if (accumulate) {
+#pragma unroll
+        for (int k = 0; k < NB * 3; ++k) row[k] += acc[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < NB * 3; ++k) row[k] = acc[k];
+        for (int k = NB * 3; k < sh_coeffs * 3; ++k) row[k] = 0.f;
+    }
+}
+
+}  // namespace
+
+extern "C" int gsa_project_bwd_factored(int n, const float *means, const float *quats, const float *scales,
+                                        const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
+                                        const float *viewmat, const float *intrin, int width, int height,
+                                        const float *splat, const int32_t *radii, const float *v_splat, float *v_means,
+                                        float *v_quats, float *v_scales, float *v_opacities, float *v_rgb,
+                                        int accumulate, gsa_stream_t stream) {
+    (void)opacities;
+    GSA_RETURN_IF(!v_rgb, GSA_ERR_INVALID_ARGUMENT);
+    return project_bwd_impl(n, means, quats, scales, colors, sh_degree, sh_coeffs, viewmat, intrin, width, height, splat,
+                            radii, v_splat, v_means, v_quats, v_scales, v_opacities, nullptr, accumulate, v_rgb, stream);
+}
+
+extern "C" int gsa_sh_grad_expand(int n, const float *means, int sh_degree, int sh_coeffs, int n_views,
+                                  const float *viewmats, const float *intrin, const float *v_rgb, float *v_colors,
+                                  int accumulate, gsa_stream_t stream) {
+    GSA_RETURN_IF(n < 0 || n_views < 1 || sh_degree < 0 || sh_degree > 3, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(sh_coeffs < (sh_degree + 1) * (sh_degree + 1), GSA_ERR_INVALID_ARGUMENT);
+    if (n == 0) return GSA_OK;
+    GSA_RETURN_IF(!means || !viewmats || !intrin || !v_rgb || !v_colors, GSA_ERR_INVALID_ARGUMENT);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = gsa_div_up(n, 256);
+#define GSA_EXP(D)                                                                                                \
+    sh_grad_expand_kernel<D><<<grid, 256, 0, s>>>(n, means, sh_coeffs, n_views, viewmats, intrin, v_rgb, v_colors, \
+                                                  accumulate ? 1 : 0);                                            \
+    break
+    switch (sh_degree) {
+        case 0: GSA_EXP(0);
+        case 1: GSA_EXP(1);
+        case 2: GSA_EXP(2);
+        default: GSA_EXP(3);
+    }
+#undef GSA_EXP
+    GSA_LAUNCH_CHECK();
+    return GSA_OK;
 }

@@ -39,6 +39,8 @@ SIGNATURES = {
     "gsa_view_loss": (c_int, [c_int, c_int, P, P, c_float, c_float, P, c_size_t, P, P, P]),
     "gsa_adam_step": (c_int, [c_longlong, P, P, P, P, c_int, P, P, c_double, c_double, c_double, c_int, P]),
     "gsa_project_bwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, P, P, P, P, P, P, P, P, P]),
+    "gsa_project_bwd_factored": (c_int, [c_int, P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, P, P, P, P, P, P, P, P, c_int, P]),
+    "gsa_sh_grad_expand": (c_int, [c_int, P, c_int, c_int, c_int, P, P, P, P, c_int, P]),
     "gsa_project_bwd_acc": (c_int, [c_int, P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, P, P, P, P, P, P, P, P, c_int, P]),
 }
 

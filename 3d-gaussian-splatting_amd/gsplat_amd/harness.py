@@ -297,7 +297,8 @@ class ViewParallelTrainer:
     passes instead of ~20 torch passes per view) and Adam is one ``gsa_adam_step`` over the flat bucket."""
 
     def __init__(self, model: SplatModel, backend, config: Optional[StepConfig] = None,
-                 process_group=None, rank: int = 0, world_size: int = 1, fused: bool = False):
+                 process_group=None, rank: int = 0, world_size: int = 1, fused: bool = False,
+                 factored_exchange: Optional[bool] = None):
         self.model, self.backend = model, backend
         self.cfg = config or StepConfig()
         self.group, self.rank, self.world = process_group, rank, world_size
@@ -305,6 +306,10 @@ class ViewParallelTrainer:
         self.fused = bool(fused)
         if self.fused and not model.flat.is_cuda:
             raise RuntimeError("ViewParallelTrainer(fused=True) needs the model on a HIP device (no CPU path)")
+        # fused, world > 1: exchange the SH-coefficient gradient in factored form (see _training_step_fused)
+        self.factored = (self.fused and world_size > 1) if factored_exchange is None else bool(factored_exchange)
+        if self.factored and not self.fused:
+            raise ValueError("factored_exchange needs fused=True (it is a property of the HIP backward pass)")
         groups = _adam_groups(model, self.cfg)
         if self.fused:
             self.optimizer = FusedBucketAdam(model, groups)
@@ -327,6 +332,14 @@ class ViewParallelTrainer:
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _all_gather_slabs(self, slabs: torch.Tensor) -> None:
+        """In-place all-gather: rank r owns ``slabs[r]``; afterwards every rank holds every slab."""
+        import torch.distributed as dist
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(slabs, slabs[self.rank], group=self.group)
+        else:
+            dist.all_gather(list(slabs.unbind(0)), slabs[self.rank].clone(), group=self.group)
 
     def training_step(self, batch: Sequence[Dict]) -> Dict[str, float]:
         """``batch``: B dicts {image [H,W,3], pose [4,4] world->camera, width, height} -- the SAME list on every
@@ -370,7 +383,13 @@ class ViewParallelTrainer:
         through autograd's accumulation: the activations (trainer.py:399-406) are evaluated once without a graph,
         every view's backward ADDS its activated-parameter gradients into one bucket (``grad_accumulate``), and the
         activation derivatives are applied once, writing the raw-parameter gradients into ``flat_grad``.
-        One host read-back, at the end (the metrics)."""
+        One host read-back, at the end (the metrics).
+
+        world > 1 (``factored``): 48 of the 59 gradient floats per gaussian are the SH-coefficient gradient, and per
+        view that is the outer product SH-basis(view direction) x d loss / d rgb.  Every rank holds the whole batch's
+        poses, so the ranks all-gather 3 N floats per view, all-reduce only the 11 N geometry floats, and each
+        rebuilds the coefficient gradient of the whole batch itself (``gsa_sh_grad_expand``; summed in batch order, so
+        bit-identical on every rank) -- instead of all-reducing 59 N floats."""
         from . import stages as S
         from .rasterization import rasterization
         m, c = self.model, self.cfg
@@ -393,11 +412,20 @@ class ViewParallelTrainer:
         _, g_quats, g_scales, g_opac, g_shs = self._act_grad
         grad_out = [g_means, g_quats, g_scales, g_opac, g_shs]
         leaves = [t.detach().requires_grad_(True) for t in (m.xyz, quats, scales, opac[:, 0], shs)]
+        factored = self.factored and self.world > 1
+        if factored:  # slot (r, j) = the j-th view of rank r; ranks with fewer views leave zeros (skipped by the expand)
+            slots = -(-n_views // self.world)
+            vr_all = torch.zeros(self.world, slots, n, 3, device=dev)
+            poses_all = torch.eye(4, device=dev).repeat(self.world, slots, 1, 1)
+            for r_ in range(self.world):
+                for j, view in enumerate(batch[r_::self.world]):
+                    poses_all[r_, j] = view["pose"]
         sums, first = [], True
-        for view in batch[self.rank::self.world]:
+        for j, view in enumerate(batch[self.rank::self.world]):
             r, _, _ = rasterization(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], view["pose"][None], K,
                                     view["width"], view["height"], sh_degree=degree, backgrounds=bg,
-                                    grad_out=grad_out, grad_accumulate=not first)
+                                    grad_out=grad_out, grad_accumulate=not first,
+                                    sh_grad_factored=vr_all[self.rank, j] if factored else None)
             s3, v = S.view_loss(r[0].detach(), view["image"], c.lambda_dssim, grad_scale=1.0 / n_views)
             r.backward(v[None])
             sums.append(s3 / float(v.numel()))            # -> l1, ssim, mse of this view
@@ -410,12 +438,24 @@ class ViewParallelTrainer:
                 dot = (g_quats * quats).sum(dim=-1, keepdim=True)
                 m.rotation.grad.copy_((g_quats - dot * quats) / rot_norm)
                 m.opacity.grad.copy_((g_opac * (opac[:, 0] * (1.0 - opac[:, 0])))[:, None])
-                m.features_dc.grad.copy_(g_shs[:, :1])
-                m.features_rest.grad.copy_(g_shs[:, 1:])
+                if not factored:
+                    m.features_dc.grad.copy_(g_shs[:, :1])
+                    m.features_rest.grad.copy_(g_shs[:, 1:])
         reg = scale_ratio_reg(torch.exp(m.scaling), c.scale_reg_max_ratio, c.scale_reg_weight)
         if self.rank == 0:
             reg.backward()                                 # adds into scaling.grad (a view of flat_grad)
-        self._all_reduce(m.flat_grad)  # the one exchange step: 59*N floats, SUM
+        if factored:
+            # the exchange: 3 N floats per view gathered, 11 N floats summed (xyz | opacity, scaling, rotation are the
+            # two ends of the bucket), the SH-coefficient gradient of the whole batch rebuilt locally
+            self._all_gather_slabs(vr_all)
+            self._all_reduce(m.flat_grad[:3 * n])
+            self._all_reduce(m.flat_grad[51 * n:])
+            S.sh_grad_expand(leaves[0].detach(), degree, poses_all.view(-1, 4, 4), K, vr_all.view(-1, n, 3), g_shs)
+            with torch.no_grad():
+                m.features_dc.grad.copy_(g_shs[:, :1])
+                m.features_rest.grad.copy_(g_shs[:, 1:])
+        else:
+            self._all_reduce(m.flat_grad)  # the one exchange step: 59*N floats, SUM
         self.optimizer.step()
 
         report = torch.zeros(4, dtype=torch.float64, device=dev)  # l1, ssim, psnr sums over local views; loss share

@@ -26,7 +26,8 @@ class _RasterizeOneCamera(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, colors, viewmat, Kmat, background,
-                width: int, height: int, sh_degree: int, channels: int, cull_mode: int, grad_out, grad_accumulate):
+                width: int, height: int, sh_degree: int, channels: int, cull_mode: int, grad_out, grad_accumulate,
+                sh_grad_factored):
         means_c, quats_c, scales_c = S.f32c(means, "means"), S.f32c(quats, "quats"), S.f32c(scales, "scales")
         opac_c, colors_c = S.f32c(opacities, "opacities"), S.f32c(colors, "colors")
         view_c, K_c = S.f32c(viewmat, "viewmats"), S.f32c(Kmat, "Ks")
@@ -52,6 +53,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
         ctx.dims = (width, height, sh_degree, channels)
         ctx.grad_out = grad_out
         ctx.grad_accumulate = bool(grad_accumulate)
+        ctx.sh_grad_factored = sh_grad_factored
         ctx.in_shapes = (means.shape, quats.shape, scales.shape, opacities.shape, colors.shape)
         extras = (splat, radii, tiles_touched, sorted_tile, sorted_gid, tile_offsets, last_id)
         ctx.mark_non_differentiable(*extras)
@@ -70,12 +72,13 @@ class _RasterizeOneCamera(torch.autograd.Function):
         v_splat = S.composite_bwd(splat, sorted_gid, tile_offsets, bg_c, final_T, last_id, v_render, v_alpha_c,
                                   width, height, channels, tile_order)
         grads = S.project_bwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
-                              splat, radii, v_splat, out=ctx.grad_out, accumulate=ctx.grad_accumulate)
+                              splat, radii, v_splat, out=ctx.grad_out, accumulate=ctx.grad_accumulate,
+                              v_rgb_out=ctx.sh_grad_factored)
         if ctx.grad_accumulate:   # the sums live in the caller's buffers; autograd gets nothing to accumulate
-            return (None,) * 15
+            return (None,) * 16
         need = ctx.needs_input_grad
-        grads = tuple(g.view(shp) if nd else None for g, shp, nd in zip(grads, ctx.in_shapes, need[:5]))
-        return grads + (None,) * 10
+        grads = tuple(g.view(shp) if (nd and g is not None) else None for g, shp, nd in zip(grads, ctx.in_shapes, need[:5]))
+        return grads + (None,) * 11
 
 
 def rasterization(
@@ -100,6 +103,7 @@ def rasterization(
     cull_mode: Optional[int] = None,
     grad_out=None,
     grad_accumulate: bool = False,
+    sh_grad_factored: Optional[torch.Tensor] = None,
     **unsupported,
 ) -> Tuple[torch.Tensor, torch.Tensor, Dict]:
     """Returns ``(renders [C,H,W,D], alphas [C,H,W,1], meta)``; ``meta['means2d']`` [C,N,2] and
@@ -112,6 +116,10 @@ def rasterization(
     that is then all-reduced in one call.  With ``grad_accumulate=True`` the backward pass ADDS into ``grad_out``
     (which the caller has initialised) and hands autograd nothing: several views sum into one bucket with no
     accumulation pass (``harness.ViewParallelTrainer(fused=True)``).
+    ``sh_grad_factored`` (extension, single camera, SH colours): a [N,3] fp32 tensor that receives d loss / d rgb per
+    gaussian instead of the [N,K,3] SH-coefficient gradient (``colors`` then gets no gradient; ``grad_out[4]`` is not
+    written).  The coefficient gradient is the outer product of the view's SH basis with it
+    (``stages.sh_grad_expand``): the form in which view-parallel ranks exchange it -- 3 floats instead of 48.
     """
     for k, v in unsupported.items():
         ok = (k in ("sparse_grad", "absgrad", "distributed") and not v) or \
@@ -149,6 +157,8 @@ def rasterization(
         raise ValueError("grad_out needs a single camera (each camera's backward would overwrite it)")
     if grad_accumulate and grad_out is None:
         raise ValueError("grad_accumulate needs grad_out")
+    if sh_grad_factored is not None and (grad_out is None or sh_degree is None):
+        raise ValueError("sh_grad_factored needs grad_out and SH colours (sh_degree given)")
     width, height = int(width), int(height)
     cull = S.DEFAULT_CULL_MODE if cull_mode is None else int(cull_mode)
     want_depth = render_mode != "RGB"
@@ -162,7 +172,7 @@ def rasterization(
             if want_depth:
                 bg = torch.cat([bg, bg.new_zeros(1)])
         out = _RasterizeOneCamera.apply(means, quats, scales, opacities, colors, viewmats[c], Ks[c], bg,
-                                        width, height, deg, channels, cull, grad_out, grad_accumulate)
+                                        width, height, deg, channels, cull, grad_out, grad_accumulate, sh_grad_factored)
         render, alpha = out[0], out[1]
         if render_mode in ("ED", "RGB+ED"):
             render = torch.cat([render[..., :3], render[..., 3:] / alpha.clamp(min=1e-10)], dim=-1)

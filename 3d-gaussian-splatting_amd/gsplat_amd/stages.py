@@ -272,7 +272,7 @@ def composite_bwd(splat, sorted_gid, tile_offsets, background, final_T, last_id,
 
 
 def project_bwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat, Kmat, width: int, height: int,
-                splat, radii, v_splat, out=None, accumulate: bool = False):
+                splat, radii, v_splat, out=None, accumulate: bool = False, v_rgb_out=None):
     """-> v_means, v_quats, v_scales, v_opacities, v_colors (every element written).  ``out``: five preallocated
     contiguous fp32 tensors to write into instead (e.g. views of one flat all-reduce bucket)."""
     N = means.shape[0]
@@ -288,6 +288,15 @@ def project_bwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat
                 raise ValueError("grad_out tensors must be contiguous fp32, sized like the inputs, on their device")
     if accumulate and out is None:
         raise ValueError("project_bwd(accumulate=True) needs the `out` buffers it adds to")
+    if v_rgb_out is not None:
+        # factored form: d loss / d rgb [N,3] instead of the [N,K,3] coefficient gradient (v_colors is not written)
+        if v_rgb_out.shape != (N, 3) or v_rgb_out.dtype != torch.float32 or not v_rgb_out.is_contiguous():
+            raise ValueError("v_rgb_out must be a contiguous fp32 [N,3] tensor")
+        _call("gsa_project_bwd", lib.gsa_project_bwd_factored, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
+              _ptr(colors), sh_degree, sh_coeffs, _ptr(viewmat), _ptr(Kmat), width, height, _ptr(splat), _ptr(radii),
+              _ptr(v_splat), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac), _ptr(v_rgb_out),
+              1 if accumulate else 0, _stream())
+        return v_means, v_quats, v_scales, v_opac, None
     _call("gsa_project_bwd", lib.gsa_project_bwd_acc, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
           _ptr(colors), sh_degree, sh_coeffs, _ptr(viewmat), _ptr(Kmat), width, height, _ptr(splat), _ptr(radii),
           _ptr(v_splat), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac), _ptr(v_colors),
@@ -352,3 +361,15 @@ def densify_gather(n_old: int, field_width, xyz_field: int, scaling_field: int, 
           xyz_field, scaling_field, float(log_split), _ptr(src), _ptr(kd), _ptr(nz), _ptr(old_param), _ptr(old_m),
           _ptr(old_v), _ptr(new_p), _ptr(new_m), _ptr(new_v), _stream())
     return new_p, new_m, new_v
+
+
+def sh_grad_expand(means, sh_degree: int, viewmats, Kmat, v_rgb_all, v_colors, accumulate: bool = False) -> None:
+    """v_colors [N,K,3] (+)= sum over views of SH-basis(view) (x) v_rgb_all[view]  (v_rgb_all: [V,N,3]; viewmats [V,4,4]).
+    Rebuilds the SH-coefficient gradient from the factored form ``project_bwd(v_rgb_out=...)`` leaves."""
+    N = means.shape[0]
+    V = viewmats.shape[0]
+    if v_rgb_all.shape != (V, N, 3) or not v_rgb_all.is_contiguous() or not v_colors.is_contiguous():
+        raise ValueError("sh_grad_expand: v_rgb_all must be contiguous [V,N,3], v_colors contiguous [N,K,3]")
+    _call("gsa_sh_grad_expand", lib.gsa_sh_grad_expand, N, _ptr(f32c(means, "means")), sh_degree, v_colors.shape[1], V,
+          _ptr(f32c(viewmats, "viewmats")), _ptr(f32c(Kmat, "Ks")), _ptr(v_rgb_all), _ptr(v_colors),
+          1 if accumulate else 0, _stream())

@@ -92,6 +92,8 @@ def main() -> None:
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--cull-mode", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", default="factored", choices=("factored", "allreduce"),
+                    help="N > 1: how ranks sum the gaussian gradients (see DESIGN.md section 6)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,13 +101,18 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+    # "nccl" is RCCL; GSPLAT_AMD_BENCH_BACKEND=gloo only exists to rehearse the N > 1 code path on a one-GPU box
+    # (the ranks then share the card)
+    backend = os.environ.get("GSPLAT_AMD_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     import gsplat_amd
     from gsplat_amd import scene, stages
@@ -136,6 +143,15 @@ def main() -> None:
     v_render = scene.make_v_render(width, height, seed=2).to(dev)[None]
     bg = torch.zeros(1, 3, device=dev)
     info = {}
+    # N > 1, factored exchange: 48 of the 59 gradient floats per gaussian are the SH-coefficient gradient, which is
+    # the outer product basis(view direction) x (d loss / d rgb); every rank knows every rank's camera, so ranks
+    # all-reduce the 11 N geometry floats, all-gather 3 N rgb-gradient floats each and rebuild the coefficient
+    # gradient locally (summed in rank order: bit-identical on every rank).
+    factored = dist is not None and args.exchange == "factored"
+    if factored:
+        vm_all = torch.stack([scene.make_camera(r, world) for r in range(world)]).to(dev)
+        vr_all = torch.zeros(world, n, 3, device=dev)
+        vr_mine = vr_all[rank]
 
     def step():
         for t in leaves:
@@ -143,9 +159,16 @@ def main() -> None:
         # the backward pass writes every gradient element straight into the bucket (no zero-fill, no copy)
         r, a, meta = gsplat_amd.rasterization(leaves[0], leaves[1], leaves[2], opac[:, 0], leaves[4], vm, K, width,
                                               height, sh_degree=deg, backgrounds=bg, cull_mode=args.cull_mode,
-                                              grad_out=grad_views)
+                                              grad_out=grad_views, sh_grad_factored=vr_mine if factored else None)
         r.backward(v_render)
-        if dist is not None:  # view-parallel exchange: sum the gaussian gradients over ranks (RCCL over xGMI)
+        if factored:
+            dist.all_reduce(flat_grad[:11 * n])
+            if dist.get_backend() == "nccl":
+                dist.all_gather_into_tensor(vr_all, vr_mine)
+            else:
+                dist.all_gather(list(vr_all.unbind(0)), vr_mine)
+            stages.sh_grad_expand(leaves[0], deg, vm_all, K, vr_all, grad_views[4])
+        elif dist is not None:  # one all-reduce of the whole 59 N-float bucket (RCCL over xGMI)
             dist.all_reduce(flat_grad)
         info["M"] = meta["n_isects"]
 
@@ -179,6 +202,7 @@ def main() -> None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    grad_l1 = float(flat_grad.double().abs().sum())   # of the last step's exchanged gradient (same on every rank)
     if rank == 0:
         m, p = info["M"], width * height
         ms_per_step = elapsed / args.steps * 1e3
@@ -207,8 +231,10 @@ def main() -> None:
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {n} gaussians, {width}x{height}, SH degree {deg}, "
                                    f"1 view per GPU per step, forward+backward"
-                                   + (", RCCL all-reduce of 59N-float grads" if world > 1 else ""),
-                       "intersections_M": m, "cull_mode": stages.DEFAULT_CULL_MODE if args.cull_mode is None else args.cull_mode},
+                                   + ((", RCCL all-reduce of 11N geometry grads + all-gather of 3N rgb grads per rank,"
+                                       " SH gradient rebuilt locally" if factored else
+                                       ", RCCL all-reduce of 59N-float grads") if world > 1 else ""),
+                       "intersections_M": m, "grad_l1": round(grad_l1, 3), "cull_mode": stages.DEFAULT_CULL_MODE if args.cull_mode is None else args.cull_mode},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg[dominant], "avg_launch_ms": round(per[dominant], 4)},

@@ -172,6 +172,22 @@ int gsa_project_bwd_acc(int n, const float *means, const float *quats, const flo
                         float *v_quats, float *v_scales, float *v_opacities, float *v_colors,
                         int accumulate, gsa_stream_t stream);
 
+/* Factored colour gradient for the view-parallel exchange.  The SH-coefficient gradient of one view is the outer
+ * product  v_colors[g][k][c] = basis_k(dir(g, view)) * v_rgb[g][c]  (48 of the 59 gradient floats per gaussian), and every
+ * rank can evaluate the basis of every view.  gsa_project_bwd_factored writes v_rgb[N,3] (d loss / d rgb after the
+ * clamp mask; zeros for culled gaussians) instead of v_colors; gsa_sh_grad_expand rebuilds
+ *   v_colors (+)= sum over n_views of basis(viewmats[v]) (x) v_rgb[v]        (v_rgb: [n_views, N, 3])
+ * so ranks exchange 11 N floats by all-reduce plus 3 N floats per rank by all-gather instead of all-reducing 59 N. */
+int gsa_project_bwd_factored(int n, const float *means, const float *quats, const float *scales,
+                             const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
+                             const float *viewmat, const float *intrin, int width, int height,
+                             const float *splat, const int32_t *radii, const float *v_splat, float *v_means,
+                             float *v_quats, float *v_scales, float *v_opacities, float *v_rgb,
+                             int accumulate, gsa_stream_t stream);
+int gsa_sh_grad_expand(int n, const float *means, int sh_degree, int sh_coeffs, int n_views,
+                       const float *viewmats, const float *intrin, const float *v_rgb, float *v_colors,
+                       int accumulate, gsa_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Training-step stages around the rasterizer.
  *

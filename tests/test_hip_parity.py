@@ -523,6 +523,48 @@ def test_grad_accumulate_sums_views_into_one_bucket(gsa, deg):
         gsa.rasterization(*base, views[0], K, W, H, sh_degree=deg, grad_accumulate=True)
 
 
+@pytest.mark.parametrize("deg", [3, 1])
+def test_factored_sh_gradient_rebuilds_the_coefficient_gradient(gsa, deg):
+    """``sh_grad_factored``: the backward pass leaves d loss / d rgb [N,3] per view; ``stages.sh_grad_expand`` over the
+    stacked views rebuilds the sum of the per-view [N,K,3] coefficient gradients of the default path (the form the
+    view-parallel ranks exchange: all-gather of 3 N floats instead of all-reducing 48 N).  The geometry gradients
+    (incl. the view-direction term of the mean) are those of the default path."""
+    from gsplat_amd import scene, stages
+    W, H, n = 160, 96, 3000
+    sc = {k: v.cuda() for k, v in _scene(n, seed=4).items()}
+    K = scene.make_intrinsics(W, H).cuda()[None]
+    views = [scene.make_camera(v, 7).cuda()[None] for v in (0, 2, 5)]
+    w = torch.linspace(0.5, 1.5, 3, device="cuda")
+    base = [sc["means3D"], sc["rotations"], sc["scales"], sc["opacities"][:, 0].contiguous(), sc["shs"]]
+    ref = [torch.zeros_like(t) for t in base]
+    for vm in views:
+        leaves = [t.clone().requires_grad_(True) for t in base]
+        r, _, _ = gsa.rasterization(*leaves, vm, K, W, H, sh_degree=deg)
+        (r * w).sum().backward()
+        for acc, t in zip(ref, leaves):
+            acc += t.grad
+    bucket = [torch.full_like(t, float("nan")) for t in base]
+    vr_all = torch.full((3, n, 3), float("nan"), device="cuda")
+    leaves = [t.clone().requires_grad_(True) for t in base]
+    for i, vm in enumerate(views):
+        r, _, _ = gsa.rasterization(*leaves, vm, K, W, H, sh_degree=deg, grad_out=bucket, grad_accumulate=i > 0,
+                                    sh_grad_factored=vr_all[i])
+        (r * w).sum().backward()
+    assert leaves[4].grad is None and torch.isnan(bucket[4]).all()        # the coefficient gradient is not written
+    assert not torch.isnan(vr_all).any()
+    stages.sh_grad_expand(leaves[0].detach(), deg, torch.cat(views), K, vr_all, bucket[4])
+    for name, a, b in zip(NAMES, bucket, ref):
+        assert not torch.isnan(a).any(), name
+        assert _rel(a.reshape(-1).cpu(), b.reshape(-1).cpu()) < 1e-5, name
+    # accumulate=True adds on top; coefficients above the active degree stay zero
+    twice = bucket[4].clone()
+    stages.sh_grad_expand(leaves[0].detach(), deg, torch.cat(views), K, vr_all, twice, accumulate=True)
+    assert _rel(twice.cpu(), 2.0 * ref[4].cpu()) < 1e-5
+    assert float(bucket[4][:, (deg + 1) ** 2:, :].abs().max()) == 0.0 if deg < 3 else True
+    with pytest.raises(ValueError):
+        gsa.rasterization(*base, views[0], K, W, H, sh_degree=deg, sh_grad_factored=vr_all[0])   # needs grad_out
+
+
 def test_full_size_properties_c3_1m_1080p(gsa):
     """BASELINE config C3 size (1M gaussians, 1920x1080, degree 3), where the CPU oracle is out of reach: properties
     that hold at any size.  (a) the forward image is bit-reproducible; (b) the backward pass is linear in the
