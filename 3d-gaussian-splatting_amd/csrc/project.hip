@@ -42,7 +42,7 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(
     const float *__restrict__ opacities, const float *__restrict__ colors, int sh_coeffs,
     const float *__restrict__ viewmat, const float *__restrict__ intrin, int width, int height, int tile_w,
     int tile_h, int cull_mode, float *__restrict__ splat, int32_t *__restrict__ radii,
-    int32_t *__restrict__ tiles_touched, uint32_t *__restrict__ depth_keys) {
+    int32_t *__restrict__ tiles_touched, uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ tile_rects) {
     __shared__ float4 sh_lds[STAGE ? kBlock * kRowQPad : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long i = (long)blockIdx.x * kBlock + threadIdx.x;
@@ -93,6 +93,7 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(
         radii[2 * i] = 0; radii[2 * i + 1] = 0;
         tiles_touched[i] = 0;
         depth_keys[i] = 0xFFFFFFFFu;
+        if (tile_rects) tile_rects[i] = 0u;
         return;
     }
 
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(
     radii[2 * i] = rx; radii[2 * i + 1] = ry;
     tiles_touched[i] = count;
     depth_keys[i] = __float_as_uint(p.z);
+    if (tile_rects) tile_rects[i] = count > 0 ? rect : 0u;   // dense copy for the fused binning (gathered in depth order)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -417,17 +419,17 @@ template <int DEG>
 int launch_fwd(bool stage, int n, const float *means, const float *quats, const float *scales,
                const float *opacities, const float *colors, int sh_coeffs, const float *viewmat,
                const float *intrin, int width, int height, int cull_mode, float *splat, int32_t *radii,
-               int32_t *tiles_touched, uint32_t *depth_keys, hipStream_t s) {
+               int32_t *tiles_touched, uint32_t *depth_keys, uint32_t *tile_rects, hipStream_t s) {
     int tile_w = gsa_div_up(width, GSA_TILE_SIZE), tile_h = gsa_div_up(height, GSA_TILE_SIZE);
     dim3 grid(gsa_div_up(n, kBlock)), block(kBlock);
     if (stage)
         project_fwd_kernel<DEG, true><<<grid, block, 0, s>>>(n, means, quats, scales, opacities, colors, sh_coeffs,
                                                              viewmat, intrin, width, height, tile_w, tile_h, cull_mode,
-                                                             splat, radii, tiles_touched, depth_keys);
+                                                             splat, radii, tiles_touched, depth_keys, tile_rects);
     else
         project_fwd_kernel<DEG, false><<<grid, block, 0, s>>>(n, means, quats, scales, opacities, colors, sh_coeffs,
                                                               viewmat, intrin, width, height, tile_w, tile_h,
-                                                              cull_mode, splat, radii, tiles_touched, depth_keys);
+                                                              cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }
@@ -466,7 +468,7 @@ extern "C" int gsa_project_fwd(int n, const float *means, const float *quats, co
                                const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
                                const float *viewmat, const float *intrin, int width, int height, int cull_mode,
                                float *splat, int32_t *radii, int32_t *tiles_touched, uint32_t *depth_keys,
-                               gsa_stream_t stream) {
+                               uint32_t *tile_rects, gsa_stream_t stream) {
     GSA_RETURN_IF(n < 0 || width <= 0 || height <= 0, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_degree < -1 || sh_degree > 3, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_degree >= 0 && sh_coeffs < (sh_degree + 1) * (sh_degree + 1), GSA_ERR_INVALID_ARGUMENT);
@@ -480,7 +482,7 @@ extern "C" int gsa_project_fwd(int n, const float *means, const float *quats, co
     bool stage = can_stage(colors, sh_degree, sh_coeffs) && sh_degree >= 1;
 #define GSA_FWD(D)                                                                                              \
     return launch_fwd<D>(stage, n, means, quats, scales, opacities, colors, sh_coeffs, viewmat, intrin, width, \
-                         height, cull_mode, splat, radii, tiles_touched, depth_keys, s)
+                         height, cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects, s)
     switch (sh_degree) {
         case -1: GSA_FWD(-1);
         case 0: GSA_FWD(0);

@@ -24,6 +24,7 @@ constexpr int kSortThreads = 256;
 constexpr int kSortItems = GSA_SORT_ITEMS;               // keys per thread
 constexpr int kSortChunk = kSortThreads * kSortItems;   // keys per block
 constexpr int kRadix = 256;
+static_assert(kSortChunk == GSA_BIN_BLOCK, "the fused binning's block-owner table is laid out in blocks of GSA_BIN_BLOCK record slots");
 
 // Item counts may live on the device (the record count M is produced by the scan and the host does not wait for
 // it): kernels are launched for a CAPACITY and clamp to *n_dev when it is given.  Uniform address -> scalar load.
@@ -34,8 +35,9 @@ __device__ __forceinline__ int resolve_count(int n_cap, const uint32_t *__restri
 // ---- pass 1: per-block digit histogram, written digit-major: hist[d * nblocks + block] -------------
 // Plain per-lane LDS atomics: measured faster than aggregating same-digit lanes with ballots first (the LDS
 // resolves same-address adds of one instruction cheaply; the 8 ballots per key cost more than they save).
+template <typename KeyT>
 __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(int n_cap, const uint32_t *__restrict__ n_dev,
-                                                                  const uint32_t *__restrict__ keys,
+                                                                  const KeyT *__restrict__ keys,
                                                                   int shift, int nblocks,
                                                                   uint32_t *__restrict__ hist) {
     __shared__ uint32_t h[kRadix];
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(int n_cap, con
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         long i = base + r * kSortThreads + threadIdx.x;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & (kRadix - 1)], 1u);
+        if (i < n) atomicAdd(&h[((uint32_t)keys[i] >> shift) & (kRadix - 1)], 1u);
     }
     __syncthreads();
     hist[(long)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
@@ -106,15 +108,17 @@ __global__ __launch_bounds__(kSortThreads) void radix_scan_rows_kernel(int nbloc
 //   3. Items are placed in LDS in block-sorted order, then written out: consecutive threads write consecutive
 //      addresses inside each digit's run, so HBM sees 64-B+ runs instead of one 4-B store per 64-B line (the
 //      low-digit pass of a tile sort scatters neighbouring records to 256 different buckets).
+template <typename KeyT>
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
-    int n_cap, const uint32_t *__restrict__ n_dev, const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-    uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int shift, int nblocks,
+    int n_cap, const uint32_t *__restrict__ n_dev, const KeyT *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+    KeyT *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int shift, int nblocks,
     const uint32_t *__restrict__ hist, const uint32_t *__restrict__ digit_total) {
     __shared__ uint32_t scratch[4];
     __shared__ uint32_t gbase[kRadix];        // global slot of this block's first item of digit d
     __shared__ uint32_t lexcl[kRadix];        // slot of that item in the block-sorted order
     __shared__ uint32_t wave_cnt[4][kRadix];  // items of digit d wave w has ranked so far; then: its first block-sorted slot
-    __shared__ uint32_t s_key[kSortChunk], s_val[kSortChunk];
+    __shared__ KeyT s_key[kSortChunk];
+    __shared__ uint32_t s_val[kSortChunk];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n = resolve_count(n_cap, n_dev);
     if ((long)blockIdx.x * kSortChunk >= n) return;   // whole block beyond the live items (capacity launch)
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         long i = base + r * 64 + lane;
-        k[r] = i < n ? keys_in[i] : 0xFFFFFFFFu;
+        k[r] = i < n ? (uint32_t)keys_in[i] : 0xFFFFFFFFu;
         v[r] = i < n ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
     }
     __syncthreads();
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
         if (base + r * 64 + lane < n) {
             const uint32_t d = (k[r] >> shift) & (kRadix - 1);
             const uint32_t lp = cnt[d] + rk[r];
-            s_key[lp] = k[r];
+            s_key[lp] = (KeyT)k[r];
             s_val[lp] = v[r];
         }
     }
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
             uint32_t key = s_key[lp];
             uint32_t d = (key >> shift) & (kRadix - 1);
             uint32_t pos = gbase[d] + ((uint32_t)lp - lexcl[d]);
-            keys_out[pos] = key;
+            keys_out[pos] = (KeyT)key;
             vals_out[pos] = s_val[lp];
         }
     }
@@ -208,14 +212,21 @@ __device__ __forceinline__ uint32_t scan_load(const int32_t *__restrict__ tiles_
 __global__ __launch_bounds__(kSortThreads) void scan_reduce_kernel(int n, const int32_t *__restrict__ tiles_touched,
                                                                    const uint32_t *__restrict__ order,
                                                                    uint32_t *__restrict__ block_sums,
-                                                                   uint32_t *__restrict__ gathered) {
+                                                                   uint32_t *__restrict__ gathered,
+                                                                   const uint32_t *__restrict__ tile_rects,
+                                                                   uint32_t *__restrict__ rects) {
     __shared__ uint32_t scratch[4];
     long base = (long)blockIdx.x * kScanChunk + threadIdx.x * kScanItems;
     uint32_t s = 0;
 #pragma unroll
     for (int j = 0; j < kScanItems; ++j) {
         const uint32_t c = scan_load(tiles_touched, order, base + j, n);
-        if (base + j < n) gathered[base + j] = c;
+        if (base + j < n) {
+            gathered[base + j] = c;
+            // the packed tile rectangle, brought into depth order for the fused emit (a second 4-B gather from a dense
+            // N-word array, beside the one of the count)
+            if (rects) rects[base + j] = tile_rects[order[base + j]];
+        }
         s += c;
     }
     uint32_t total;
@@ -239,8 +250,12 @@ __global__ __launch_bounds__(kSortThreads) void scan_blocks_kernel(int nblocks, 
 }
 
 // in place: offsets[] holds the depth-ordered counts on entry (scan_reduce_kernel), their exclusive prefix on exit
+// block_owner (optional): the gaussian whose record list covers slot b * kSortChunk, for every record block b below
+// n_owner_blocks -- the fused emit starts from it instead of searching `offsets`
 __global__ __launch_bounds__(kSortThreads) void scan_final_kernel(int n, const uint32_t *__restrict__ block_sums,
-                                                                  uint32_t *__restrict__ offsets) {
+                                                                  uint32_t *__restrict__ offsets,
+                                                                  int32_t *__restrict__ block_owner, int n_owner_blocks,
+                                                                  const uint32_t *__restrict__ m_total) {
     __shared__ uint32_t scratch[4];
     long base = (long)blockIdx.x * kScanChunk + threadIdx.x * kScanItems;
     uint32_t v[kScanItems], s = 0;
@@ -253,7 +268,16 @@ __global__ __launch_bounds__(kSortThreads) void scan_final_kernel(int n, const u
     uint32_t ex = block_excl_scan(s, scratch, total) + block_sums[blockIdx.x];
 #pragma unroll
     for (int j = 0; j < kScanItems; ++j) {
-        if (base + j < n) offsets[base + j] = ex;
+        if (base + j < n) {
+            offsets[base + j] = ex;
+            if (block_owner && v[j] > 0u) {   // slots [ex, ex + v): owner of every block boundary inside
+                const uint32_t b0 = (ex + (uint32_t)kSortChunk - 1u) / (uint32_t)kSortChunk;
+                const uint32_t b1 = min((ex + v[j] - 1u) / (uint32_t)kSortChunk, (uint32_t)n_owner_blocks - 1u);
+                for (uint32_t b = b0; b <= b1 && (int)b < n_owner_blocks; ++b) block_owner[b] = (int32_t)(base + j);
+                // one entry more: the LAST gaussian that has records (culled gaussians sort behind it)
+                if (ex + v[j] == *m_total) block_owner[n_owner_blocks] = (int32_t)(base + j);
+            }
+        }
         ex += v[j];
     }
 }
@@ -358,8 +382,9 @@ __global__ __launch_bounds__(kSortThreads) void tile_emit_coop_kernel(
 
 // tile_offsets[t] = first index i with sorted_tile[i] >= t,  t in [0, n_tiles]
 // tile_offsets[t] = first index i with sorted_tile[i] >= t,  t in [0, n_tiles]
+template <typename KeyT>
 __global__ __launch_bounds__(kSortThreads) void tile_offsets_kernel(uint32_t m_cap, const uint32_t *__restrict__ m_dev,
-                                                                    const uint32_t *__restrict__ sorted_tile,
+                                                                    const KeyT *__restrict__ sorted_tile,
                                                                     int n_tiles, int32_t *__restrict__ tile_offsets) {
     const uint32_t m = m_dev ? min(m_cap, *m_dev) : m_cap;
     long i = (long)blockIdx.x * kSortThreads + threadIdx.x;
@@ -371,8 +396,9 @@ __global__ __launch_bounds__(kSortThreads) void tile_offsets_kernel(uint32_t m_c
 
 // the same by binary search, one thread per tile: for long lists (M >> n_tiles) 27 dependent loads per tile beat
 // streaming all M keys
+template <typename KeyT>
 __global__ __launch_bounds__(kSortThreads) void tile_offsets_bsearch_kernel(uint32_t m_cap, const uint32_t *__restrict__ m_dev,
-                                                                            const uint32_t *__restrict__ sorted_tile,
+                                                                            const KeyT *__restrict__ sorted_tile,
                                                                             int n_tiles, int32_t *__restrict__ tile_offsets) {
     const uint32_t m = m_dev ? min(m_cap, *m_dev) : m_cap;
     int t = blockIdx.x * kSortThreads + threadIdx.x;
@@ -380,9 +406,198 @@ __global__ __launch_bounds__(kSortThreads) void tile_offsets_bsearch_kernel(uint
     uint32_t lo = 0, hi = m;  // first index with key >= t
     while (lo < hi) {
         uint32_t mid = lo + ((hi - lo) >> 1);
-        if (sorted_tile[mid] < (uint32_t)t) lo = mid + 1; else hi = mid;
+        if ((uint32_t)sorted_tile[mid] < (uint32_t)t) lo = mid + 1; else hi = mid;
     }
     tile_offsets[t] = (int32_t)lo;
+}
+
+// ---- fused emit + first tile-sort pass ---------------------------------------------------------------
+// cull_mode 0, tile grid below 1024 x 1024 and at most 65535 tiles (16-bit tile ids).  The records are never written
+// in emission order: the first (low-digit) pass of the tile sort GENERATES them from the depth-ordered rectangles --
+// once to count digits (emit_hist_kernel), once to place them (emit_scatter_kernel) -- which drops the emit kernel's
+// 8 B/record store and the first pass's 8 B/record load, and the keys travel as 16-bit tile ids from there on.
+//
+// A block owns the kSortChunk record slots [slot0, slot0 + kSortChunk).  slot -> gaussian: the scan noted the owner of
+// the block's first slot (block_owner); the gaussians whose list starts inside the block mark their start slot in LDS (atomicMax: gaussians without records share the start of the
+// next one that has some, the last one wins), a max-scan carries the owner forward; slot -> tile: the rectangle
+// arithmetic of tile_emit_coop_kernel.
+struct EmitBlock { uint32_t slot0, live; int k_lo; };   // live: slots of this block below the record count
+
+__device__ __forceinline__ EmitBlock emit_owners(int n, const uint32_t *__restrict__ offsets,
+                                                  const int32_t *__restrict__ block_owner, int n_owner_blocks,
+                                                  uint32_t m_total, uint32_t *__restrict__ s_own,
+                                                  uint32_t *__restrict__ scratch) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    EmitBlock eb;
+    eb.slot0 = blockIdx.x * (uint32_t)kSortChunk;
+    eb.live = min((uint32_t)kSortChunk, m_total - eb.slot0);
+    const uint32_t slot_end = eb.slot0 + eb.live;
+    // owner of the first slot (noted by the scan), and the last gaussian that can start inside this block: the owner
+    // of the next block's first slot, or the last gaussian with records when this is the last live block
+    eb.k_lo = block_owner[blockIdx.x];
+    const int k_hi = slot_end < m_total ? block_owner[blockIdx.x + 1] : block_owner[n_owner_blocks];
+    uint4 *own4 = reinterpret_cast<uint4 *>(s_own) + t * (kSortItems / 4);
+#pragma unroll
+    for (int q = 0; q < kSortItems / 4; ++q) own4[q] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    for (int k = eb.k_lo + 1 + t; k <= k_hi; k += kSortThreads) {
+        const uint32_t o = offsets[k] - eb.slot0;   // (gaussians without records at the block's end start at slot_end)
+        if (o < eb.live) atomicMax(&s_own[o], (uint32_t)(k - eb.k_lo));
+    }
+    __syncthreads();
+    uint32_t v[kSortItems], run = 0;
+#pragma unroll
+    for (int q = 0; q < kSortItems / 4; ++q) {
+        const uint4 x = own4[q];
+        v[4 * q] = run = max(run, x.x); v[4 * q + 1] = run = max(run, x.y);
+        v[4 * q + 2] = run = max(run, x.z); v[4 * q + 3] = run = max(run, x.w);
+    }
+    uint32_t inc = run;   // inclusive max-scan over the block's threads
+#pragma unroll
+    for (int d = 1; d < GSA_WAVE; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d);
+        if (lane >= d) inc = max(inc, o);
+    }
+    if (lane == 63) scratch[wave] = inc;
+    uint32_t before = __shfl_up(inc, 1);
+    if (lane == 0) before = 0;
+    __syncthreads();
+    for (int w = 0; w < wave; ++w) before = max(before, scratch[w]);
+#pragma unroll
+    for (int q = 0; q < kSortItems / 4; ++q)
+        own4[q] = make_uint4(max(v[4 * q], before), max(v[4 * q + 1], before), max(v[4 * q + 2], before),
+                             max(v[4 * q + 3], before));
+    __syncthreads();
+    return eb;
+}
+
+// the record of block slot `slot` (< eb.live): tile id and gaussian index
+__device__ __forceinline__ void emit_record(const EmitBlock &eb, uint32_t slot, const uint32_t *__restrict__ s_own,
+                                            const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ rects,
+                                            const uint32_t *__restrict__ order, int tile_w, uint32_t &tile,
+                                            uint32_t &gid) {
+    const int k = eb.k_lo + (int)s_own[slot];
+    const uint32_t rect = rects[k];
+    const uint32_t j = eb.slot0 + slot - offsets[k];
+    const int x0 = (int)(rect & 1023u), y0 = (int)((rect >> 10) & 1023u), wl = max((int)(rect >> 20), 1);
+    const int row = (int)(((float)j + 0.5f) / (float)wl);   // exact: j, wl < 2^15
+    const int col = (int)j - row * wl;
+    tile = (uint32_t)((y0 + row) * tile_w + x0 + col);
+    gid = order[k];
+}
+
+__global__ __launch_bounds__(kSortThreads) void emit_hist_kernel(int n, const uint32_t *__restrict__ order,
+                                                                 const uint32_t *__restrict__ offsets,
+                                                                 const uint32_t *__restrict__ rects,
+                                                                 const int32_t *__restrict__ block_owner, int tile_w,
+                                                                 uint32_t m_cap, const uint32_t *__restrict__ m_dev,
+                                                                 int nblocks, uint32_t *__restrict__ hist) {
+    __shared__ uint32_t scratch[4];
+    __shared__ uint32_t h[kRadix];
+    __shared__ __attribute__((aligned(16))) uint32_t s_own[kSortChunk];
+    const uint32_t m_total = m_dev ? min(m_cap, *m_dev) : m_cap;
+    if ((uint64_t)blockIdx.x * kSortChunk >= m_total) {
+        hist[(long)threadIdx.x * nblocks + blockIdx.x] = 0;
+        return;
+    }
+    h[threadIdx.x] = 0;
+    const EmitBlock eb = emit_owners(n, offsets, block_owner, nblocks, m_total, s_own, scratch);
+#pragma unroll 4
+    for (int r = 0; r < kSortItems; ++r) {
+        const uint32_t slot = r * kSortThreads + threadIdx.x;
+        if (slot < eb.live) {
+            uint32_t tile, gid;
+            emit_record(eb, slot, s_own, offsets, rects, order, tile_w, tile, gid);
+            atomicAdd(&h[tile & (kRadix - 1)], 1u);
+        }
+    }
+    __syncthreads();
+    hist[(long)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// radix_scatter_kernel (shift 0) with generated instead of loaded items; keys leave as 16-bit tile ids
+__global__ __launch_bounds__(kSortThreads) void emit_scatter_kernel(
+    int n, const uint32_t *__restrict__ order, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ rects,
+    const int32_t *__restrict__ block_owner, int tile_w, uint32_t m_cap, const uint32_t *__restrict__ m_dev,
+    uint16_t *__restrict__ keys_out,
+    uint32_t *__restrict__ vals_out, int nblocks, const uint32_t *__restrict__ hist,
+    const uint32_t *__restrict__ digit_total) {
+    __shared__ uint32_t scratch[4];
+    __shared__ uint32_t gbase[kRadix];
+    __shared__ uint32_t lexcl[kRadix];
+    __shared__ uint32_t wave_cnt[4][kRadix];
+    __shared__ uint16_t s_key[kSortChunk];
+    __shared__ __attribute__((aligned(16))) uint32_t s_val[kSortChunk];   // first: the slot owners
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t m_total = m_dev ? min(m_cap, *m_dev) : m_cap;
+    if ((uint64_t)blockIdx.x * kSortChunk >= m_total) return;
+    {
+        uint32_t tot, dt = digit_total[t];
+        const uint32_t mine = hist[(long)t * nblocks + blockIdx.x];
+        const uint32_t next = (int)blockIdx.x + 1 < nblocks ? hist[(long)t * nblocks + blockIdx.x + 1] : dt;
+        const uint32_t dbase = block_excl_scan(dt, scratch, tot);
+        const uint32_t lbase = block_excl_scan(next - mine, scratch, tot);
+        gbase[t] = dbase + mine;
+        lexcl[t] = lbase;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) wave_cnt[w][t] = 0;
+    }
+    const EmitBlock eb = emit_owners(n, offsets, block_owner, nblocks, m_total, s_val, scratch);
+    const uint32_t wbase = wave * (kSortChunk / 4);
+    uint32_t k[kSortItems], v[kSortItems], rk[kSortItems];
+#pragma unroll 4
+    for (int r = 0; r < kSortItems; ++r) {
+        const uint32_t slot = wbase + r * 64 + lane;
+        k[r] = 0xFFFFu; v[r] = 0u;
+        if (slot < eb.live) emit_record(eb, slot, s_val, offsets, rects, order, tile_w, k[r], v[r]);
+    }
+    __syncthreads();   // owners consumed: s_val is free for the reorder
+
+    uint32_t *cnt = wave_cnt[wave];
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const bool valid = wbase + r * 64 + lane < eb.live;
+        const uint32_t d = k[r] & (kRadix - 1);
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            unsigned long long m = __ballot((d >> b) & 1);
+            peers &= ((d >> b) & 1) ? m : ~m;
+        }
+        const uint32_t below = __popcll(peers & ((1ull << lane) - 1ull));
+        const uint32_t seen = cnt[d];
+        rk[r] = seen + below;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (valid && below == 0) cnt[d] = seen + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __syncthreads();
+    {
+        uint32_t c0 = wave_cnt[0][t], c1 = wave_cnt[1][t], c2 = wave_cnt[2][t];
+        const uint32_t o = lexcl[t];
+        wave_cnt[0][t] = o; wave_cnt[1][t] = o + c0; wave_cnt[2][t] = o + c0 + c1; wave_cnt[3][t] = o + c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        if (wbase + r * 64 + lane < eb.live) {
+            const uint32_t lp = cnt[k[r] & (kRadix - 1)] + rk[r];
+            s_key[lp] = (uint16_t)k[r];
+            s_val[lp] = v[r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const uint32_t lp = r * kSortThreads + t;
+        if (lp < eb.live) {
+            const uint32_t key = s_key[lp];
+            const uint32_t d = key & (kRadix - 1);
+            const uint32_t pos = gbase[d] + (lp - lexcl[d]);
+            keys_out[pos] = (uint16_t)key;
+            vals_out[pos] = s_val[lp];
+        }
+    }
 }
 
 int sort_blocks(int n) { return gsa_div_up(n, kSortChunk); }
@@ -416,11 +631,12 @@ static int sort_pairs_impl(int n, const uint32_t *n_dev, const uint32_t *keys_in
         uint32_t *kout = to_out ? keys_out : keys_tmp;
         uint32_t *vout = to_out ? vals_out : vals_tmp;
         int shift = begin_bit + 8 * p;
-        radix_hist_kernel<<<nblocks, kSortThreads, 0, s>>>(n, n_dev, kin, shift, nblocks, hist);
+        radix_hist_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(n, n_dev, kin, shift, nblocks, hist);
         GSA_LAUNCH_CHECK();
         radix_scan_rows_kernel<<<kRadix, kSortThreads, 0, s>>>(nblocks, hist, digit_total);
         GSA_LAUNCH_CHECK();
-        radix_scatter_kernel<<<nblocks, kSortThreads, 0, s>>>(n, n_dev, kin, vin, kout, vout, shift, nblocks, hist, digit_total);
+        radix_scatter_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(n, n_dev, kin, vin, kout, vout, shift, nblocks, hist,
+                                                                        digit_total);
         GSA_LAUNCH_CHECK();
         kin = kout;
         vin = vout;
@@ -444,8 +660,9 @@ extern "C" int gsa_sort_pairs_u32_dev(int capacity, const uint32_t *n_dev, const
                            end_bit, workspace, workspace_bytes, stream);
 }
 
-extern "C" int gsa_scan_tiles(int n, const int32_t *tiles_touched, const uint32_t *order, uint32_t *offsets,
-                              uint32_t *total, void *workspace, size_t workspace_bytes, gsa_stream_t stream) {
+static int scan_tiles_impl(int n, const int32_t *tiles_touched, const uint32_t *order, const uint32_t *tile_rects,
+                           uint32_t *offsets, uint32_t *rects, int32_t *block_owner, int n_owner_blocks,
+                           uint32_t *total, void *workspace, size_t workspace_bytes, gsa_stream_t stream) {
     GSA_RETURN_IF(n < 0, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(!total, GSA_ERR_INVALID_ARGUMENT);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -454,16 +671,34 @@ extern "C" int gsa_scan_tiles(int n, const int32_t *tiles_touched, const uint32_
         return (int)e;
     }
     GSA_RETURN_IF(!tiles_touched || !order || !offsets || !workspace, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(rects && !tile_rects, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(workspace_bytes < gsa_sort_workspace_bytes(n), GSA_ERR_WORKSPACE_TOO_SMALL);
     uint32_t *block_sums = static_cast<uint32_t *>(workspace);
     int nblocks = gsa_div_up(n, kScanChunk);
-    scan_reduce_kernel<<<nblocks, kSortThreads, 0, s>>>(n, tiles_touched, order, block_sums, offsets);
+    scan_reduce_kernel<<<nblocks, kSortThreads, 0, s>>>(n, tiles_touched, order, block_sums, offsets, tile_rects, rects);
     GSA_LAUNCH_CHECK();
     scan_blocks_kernel<<<1, kSortThreads, 0, s>>>(nblocks, block_sums, total);
     GSA_LAUNCH_CHECK();
-    scan_final_kernel<<<nblocks, kSortThreads, 0, s>>>(n, block_sums, offsets);
+    scan_final_kernel<<<nblocks, kSortThreads, 0, s>>>(n, block_sums, offsets, n_owner_blocks > 0 ? block_owner : nullptr,
+                                                       n_owner_blocks, total);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
+}
+
+extern "C" int gsa_scan_tiles(int n, const int32_t *tiles_touched, const uint32_t *order, uint32_t *offsets,
+                              uint32_t *total, void *workspace, size_t workspace_bytes, gsa_stream_t stream) {
+    return scan_tiles_impl(n, tiles_touched, order, nullptr, offsets, nullptr, nullptr, 0, total, workspace,
+                           workspace_bytes, stream);
+}
+
+extern "C" int gsa_scan_tiles_rect(int n, const int32_t *tiles_touched, const uint32_t *order,
+                                   const uint32_t *tile_rects, uint32_t *offsets, uint32_t *rects,
+                                   int32_t *block_owner, int n_blocks, uint32_t *total, void *workspace,
+                                   size_t workspace_bytes, gsa_stream_t stream) {
+    GSA_RETURN_IF(n > 0 && (!tile_rects || !rects), GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(n_blocks < 0 || (n_blocks > 0 && !block_owner), GSA_ERR_INVALID_ARGUMENT);
+    return scan_tiles_impl(n, tiles_touched, order, tile_rects, offsets, rects, block_owner, n_blocks, total, workspace,
+                           workspace_bytes, stream);
 }
 
 static int tile_emit_impl(int n, const uint32_t *order, const uint32_t *offsets, const float *splat,
@@ -502,17 +737,18 @@ extern "C" int gsa_tile_emit_dev(int n, const uint32_t *order, const uint32_t *o
                           isect_gid, stream);
 }
 
-static int tile_offsets_impl(uint32_t m, const uint32_t *m_dev, const uint32_t *sorted_tile, int n_tiles,
+template <typename KeyT>
+static int tile_offsets_impl(uint32_t m, const uint32_t *m_dev, const KeyT *sorted_tile, int n_tiles,
                              int32_t *tile_offsets, gsa_stream_t stream) {
     GSA_RETURN_IF(n_tiles <= 0 || !tile_offsets, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(m > 0 && !sorted_tile, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(m >= 0x7FFFFFFFu, GSA_ERR_UNSUPPORTED);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if ((long long)m > 1024LL * n_tiles)
-        tile_offsets_bsearch_kernel<<<gsa_div_up(n_tiles + 1, kSortThreads), kSortThreads, 0, s>>>(
+        tile_offsets_bsearch_kernel<KeyT><<<gsa_div_up(n_tiles + 1, kSortThreads), kSortThreads, 0, s>>>(
             m, m_dev, sorted_tile, n_tiles, tile_offsets);
     else
-        tile_offsets_kernel<<<gsa_div_up((long long)m + 1, kSortThreads), kSortThreads, 0, s>>>(
+        tile_offsets_kernel<KeyT><<<gsa_div_up((long long)m + 1, kSortThreads), kSortThreads, 0, s>>>(
             m, m_dev, sorted_tile, n_tiles, tile_offsets);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
@@ -520,11 +756,60 @@ static int tile_offsets_impl(uint32_t m, const uint32_t *m_dev, const uint32_t *
 
 extern "C" int gsa_tile_offsets(uint32_t m, const uint32_t *sorted_tile, int n_tiles, int32_t *tile_offsets,
                                 gsa_stream_t stream) {
-    return tile_offsets_impl(m, nullptr, sorted_tile, n_tiles, tile_offsets, stream);
+    return tile_offsets_impl<uint32_t>(m, nullptr, sorted_tile, n_tiles, tile_offsets, stream);
 }
 
 extern "C" int gsa_tile_offsets_dev(uint32_t m_capacity, const uint32_t *m_dev, const uint32_t *sorted_tile,
                                     int n_tiles, int32_t *tile_offsets, gsa_stream_t stream) {
     GSA_RETURN_IF(!m_dev, GSA_ERR_INVALID_ARGUMENT);
-    return tile_offsets_impl(m_capacity, m_dev, sorted_tile, n_tiles, tile_offsets, stream);
+    return tile_offsets_impl<uint32_t>(m_capacity, m_dev, sorted_tile, n_tiles, tile_offsets, stream);
+}
+
+extern "C" int gsa_tile_bin16_supported(int width, int height) {
+    if (width <= 0 || height <= 0) return 0;
+    const long tile_w = gsa_div_up(width, GSA_TILE_SIZE), tile_h = gsa_div_up(height, GSA_TILE_SIZE);
+    return tile_w < 1024 && tile_h < 1024 && tile_w * tile_h <= 65535 ? 1 : 0;
+}
+
+extern "C" int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offsets, const uint32_t *rects,
+                              const int32_t *block_owner, int width, int height, uint32_t m_capacity,
+                              const uint32_t *m_dev, uint16_t *tile_tmp,
+                              uint32_t *gid_tmp, uint16_t *sorted_tile, uint32_t *sorted_gid, int32_t *tile_offsets,
+                              void *workspace, size_t workspace_bytes, gsa_stream_t stream) {
+    GSA_RETURN_IF(n < 0 || !tile_offsets, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(!gsa_tile_bin16_supported(width, height), GSA_ERR_UNSUPPORTED);
+    GSA_RETURN_IF(m_capacity >= 0x7FFFFFFFu - (uint32_t)kSortChunk, GSA_ERR_UNSUPPORTED);
+    const int tile_w = gsa_div_up(width, GSA_TILE_SIZE), tile_h = gsa_div_up(height, GSA_TILE_SIZE);
+    const int n_tiles = tile_w * tile_h;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n == 0 || m_capacity == 0) {   // no records: every tile's list is empty
+        return (int)hipMemsetAsync(tile_offsets, 0, sizeof(int32_t) * ((size_t)n_tiles + 1), s);
+    }
+    GSA_RETURN_IF(!order || !offsets || !rects || !block_owner || !sorted_tile || !sorted_gid || !workspace,
+                  GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(workspace_bytes < gsa_sort_workspace_bytes((int)m_capacity), GSA_ERR_WORKSPACE_TOO_SMALL);
+    const bool two = n_tiles > kRadix;   // tile ids above 8 bits: a second (high-digit) pass
+    GSA_RETURN_IF(two && (!tile_tmp || !gid_tmp), GSA_ERR_INVALID_ARGUMENT);
+    const int nblocks = sort_blocks((int)m_capacity);
+    uint32_t *hist = static_cast<uint32_t *>(workspace);
+    uint32_t *digit_total = hist + (size_t)kRadix * nblocks;
+    emit_hist_kernel<<<nblocks, kSortThreads, 0, s>>>(n, order, offsets, rects, block_owner, tile_w, m_capacity, m_dev,
+                                                      nblocks, hist);
+    GSA_LAUNCH_CHECK();
+    radix_scan_rows_kernel<<<kRadix, kSortThreads, 0, s>>>(nblocks, hist, digit_total);
+    GSA_LAUNCH_CHECK();
+    emit_scatter_kernel<<<nblocks, kSortThreads, 0, s>>>(n, order, offsets, rects, block_owner, tile_w, m_capacity, m_dev,
+                                                         two ? tile_tmp : sorted_tile, two ? gid_tmp : sorted_gid,
+                                                         nblocks, hist, digit_total);
+    GSA_LAUNCH_CHECK();
+    if (two) {
+        radix_hist_kernel<uint16_t><<<nblocks, kSortThreads, 0, s>>>((int)m_capacity, m_dev, tile_tmp, 8, nblocks, hist);
+        GSA_LAUNCH_CHECK();
+        radix_scan_rows_kernel<<<kRadix, kSortThreads, 0, s>>>(nblocks, hist, digit_total);
+        GSA_LAUNCH_CHECK();
+        radix_scatter_kernel<uint16_t><<<nblocks, kSortThreads, 0, s>>>((int)m_capacity, m_dev, tile_tmp, gid_tmp, sorted_tile,
+                                                                        sorted_gid, 8, nblocks, hist, digit_total);
+        GSA_LAUNCH_CHECK();
+    }
+    return tile_offsets_impl<uint16_t>(m_capacity, m_dev, sorted_tile, n_tiles, tile_offsets, stream);
 }

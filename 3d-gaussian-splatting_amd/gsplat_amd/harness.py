@@ -328,18 +328,19 @@ class ViewParallelTrainer:
                 group["lr"] = lr
         return lr
 
-    def _all_reduce(self, t: torch.Tensor) -> None:
+    def _all_reduce(self, t: torch.Tensor, async_op: bool = False):
         if self.world > 1:
             import torch.distributed as dist
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        return None
 
-    def _all_gather_slabs(self, slabs: torch.Tensor) -> None:
-        """In-place all-gather: rank r owns ``slabs[r]``; afterwards every rank holds every slab."""
+    def _all_gather_slabs(self, slabs: torch.Tensor):
+        """In-place all-gather (asynchronous: returns the work handle): rank r owns ``slabs[r]``; afterwards every rank
+        holds every slab."""
         import torch.distributed as dist
         if dist.get_backend(self.group) == "nccl":
-            dist.all_gather_into_tensor(slabs, slabs[self.rank], group=self.group)
-        else:
-            dist.all_gather(list(slabs.unbind(0)), slabs[self.rank].clone(), group=self.group)
+            return dist.all_gather_into_tensor(slabs, slabs[self.rank], group=self.group, async_op=True)
+        return dist.all_gather(list(slabs.unbind(0)), slabs[self.rank].clone(), group=self.group, async_op=True)
 
     def training_step(self, batch: Sequence[Dict]) -> Dict[str, float]:
         """``batch``: B dicts {image [H,W,3], pose [4,4] world->camera, width, height} -- the SAME list on every
@@ -447,13 +448,17 @@ class ViewParallelTrainer:
         if factored:
             # the exchange: 3 N floats per view gathered, 11 N floats summed (xyz | opacity, scaling, rotation are the
             # two ends of the bucket), the SH-coefficient gradient of the whole batch rebuilt locally
-            self._all_gather_slabs(vr_all)
-            self._all_reduce(m.flat_grad[:3 * n])
-            self._all_reduce(m.flat_grad[51 * n:])
+            # (gathered first, so that the local rebuild runs beside the two all-reduces)
+            gathered = self._all_gather_slabs(vr_all)
+            summed = [self._all_reduce(m.flat_grad[:3 * n], async_op=True),
+                      self._all_reduce(m.flat_grad[51 * n:], async_op=True)]
+            gathered.wait()
             S.sh_grad_expand(leaves[0].detach(), degree, poses_all.view(-1, 4, 4), K, vr_all.view(-1, n, 3), g_shs)
             with torch.no_grad():
                 m.features_dc.grad.copy_(g_shs[:, :1])
                 m.features_rest.grad.copy_(g_shs[:, 1:])
+            for work in summed:
+                work.wait()
         else:
             self._all_reduce(m.flat_grad)  # the one exchange step: 59*N floats, SUM
         self.optimizer.step()

@@ -33,16 +33,18 @@ class _RasterizeOneCamera(torch.autograd.Function):
         view_c, K_c = S.f32c(viewmat, "viewmats"), S.f32c(Kmat, "Ks")
         bg_c = None if background is None else S.f32c(background, "backgrounds")
 
-        splat, radii, tiles_touched, depth_keys = S.project_fwd(means_c, quats_c, scales_c, opac_c, colors_c,
-                                                                sh_degree, view_c, K_c, width, height, cull_mode)
+        splat, radii, tiles_touched, depth_keys, rects = S.project_fwd(means_c, quats_c, scales_c, opac_c, colors_c,
+                                                                       sh_degree, view_c, K_c, width, height, cull_mode,
+                                                                       return_rects=True)
         # the host does not wait for the record count: bins are sized for a remembered capacity, the compositor is
         # queued, and only then is the count (long since copied back) checked -- a miss repeats with exact sizes
-        bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode)
+        bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, tile_rects=rects)
         tile_order = S.tile_schedule(bins.tile_offsets, width, height)   # longest record lists first (speed only)
         render, alpha, final_T, last_id = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg_c, width,
                                                           height, channels, tile_order)
         if not bins.finalize()[1]:
-            bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, exact=True)
+            bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, exact=True,
+                               tile_rects=rects)
             tile_order = S.tile_schedule(bins.tile_offsets, width, height)
             render, alpha, final_T, last_id = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg_c,
                                                               width, height, channels, tile_order)
@@ -221,7 +223,7 @@ def _isect_ids(per_cam, n_tiles: int) -> torch.Tensor:
     for c, pc in enumerate(per_cam):
         depth_bits = pc[0][:, 9].contiguous().view(torch.int32).long() & 0xFFFFFFFF
         gid = pc[4].long()
-        parts.append((c << (32 + tile_bits)) | (pc[3].long() << 32) | depth_bits[gid])
+        parts.append((c << (32 + tile_bits)) | (S.tile_ids(pc[3]) << 32) | depth_bits[gid])
     return torch.cat(parts)
 
 

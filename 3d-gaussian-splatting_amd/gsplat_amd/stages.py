@@ -6,6 +6,7 @@ one at a time."""
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -13,6 +14,7 @@ import torch
 from ._lib import SPLAT_STRIDE, check, lib
 
 TILE_SIZE = 16
+BIN_BLOCK = 4096        # GSA_BIN_BLOCK: record slots per block of the fused binning's owner table
 DEFAULT_CULL_MODE = 0  # 0: published tile rectangle; 1: + exact ellipse-vs-tile test (rasterization docstring)
 
 
@@ -83,17 +85,21 @@ def _pinned_scalar(dev):
 
 
 def project_fwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat, Kmat, width: int, height: int,
-                cull_mode: int = 0):
-    """-> splat [N,16], radii [N,2] i32, tiles_touched [N] i32, depth_keys [N] (uint32 bits in int32 storage)."""
+                cull_mode: int = 0, return_rects: bool = False):
+    """-> splat [N,16], radii [N,2] i32, tiles_touched [N] i32, depth_keys [N] (uint32 bits in int32 storage)
+    [, tile_rects [N] i32: the packed tile rectangles the fused binning reads, with ``return_rects``]."""
     dev, N = means.device, means.shape[0]
     sh_coeffs = colors.shape[1] if sh_degree >= 0 else 0
     splat = torch.empty(N, SPLAT_STRIDE, dtype=torch.float32, device=dev)
     radii = torch.empty(N, 2, dtype=torch.int32, device=dev)
     tiles_touched = torch.empty(N, dtype=torch.int32, device=dev)
     depth_keys = torch.empty(N, dtype=torch.int32, device=dev)
+    tile_rects = torch.empty(N, dtype=torch.int32, device=dev) if return_rects else None
     _call("gsa_project_fwd", lib.gsa_project_fwd, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
           _ptr(colors), sh_degree, sh_coeffs, _ptr(viewmat), _ptr(Kmat), width, height, cull_mode, _ptr(splat),
-          _ptr(radii), _ptr(tiles_touched), _ptr(depth_keys), _stream())
+          _ptr(radii), _ptr(tiles_touched), _ptr(depth_keys), _ptr(tile_rects), _stream())
+    if return_rects:
+        return splat, radii, tiles_touched, depth_keys, tile_rects
     return splat, radii, tiles_touched, depth_keys
 
 
@@ -145,6 +151,13 @@ class TileBins:
         return self._gid[:self.finalize()[0]]
 
 
+def tile_ids(sorted_tile: torch.Tensor) -> torch.Tensor:
+    """Tile ids of ``TileBins.sorted_tile`` as int64, whichever width the binning path stored them in."""
+    t = sorted_tile.long()
+    return t & 0xFFFF if sorted_tile.dtype == torch.int16 else t
+
+
+_BIN_FUSED_DEFAULT = os.environ.get("GSPLAT_AMD_BIN_FUSED", "1") != "0"
 _CAPACITY = {}   # (device, N, W, H, cull_mode) -> record capacity the next call allocates (tracks the scene)
 
 
@@ -155,9 +168,10 @@ def _note_count(key, m: int) -> None:
 
 
 def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, cull_mode: int = 0,
-              exact: bool = False) -> TileBins:
+              exact: bool = False, fused: Optional[bool] = None, tile_rects=None) -> TileBins:
     """Depth-order the gaussians, emit their tile records in that order, stable-sort the records by tile.
-    -> TileBins(sorted_tile, sorted_gid, tile_offsets [n_tiles+1] i32).
+    -> TileBins(sorted_tile, sorted_gid, tile_offsets [n_tiles+1] i32).  ``sorted_tile`` holds 16-bit tile ids (an
+    int16 tensor of uint16 bit patterns) on the fused path, int32 otherwise: read it through ``tile_ids``.
 
     The record count M is only known on the device.  Steady state (a capacity is remembered per scene shape): all
     kernels are queued for that capacity and read the live count from device memory, the host never waits; the
@@ -173,18 +187,55 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
     total = torch.empty(1, dtype=torch.int32, device=dev)
     ws_bytes = lib.gsa_sort_workspace_bytes(N)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    _call("gsa_scan_tiles", lib.gsa_scan_tiles, N, _ptr(tiles_touched), _ptr(order), _ptr(offsets), _ptr(total),
-          _ptr(ws), ws_bytes, st)
+    # fused path (every tile of the rectangle is a record, 16-bit tile ids): the records are generated inside the
+    # first pass of the tile sort from the depth-ordered rectangles, never written in emission order
+    can_fuse = cull_mode == 0 and bool(lib.gsa_tile_bin16_supported(width, height))
+    if fused and not can_fuse:
+        raise ValueError("bin_tiles(fused=True): needs cull_mode 0 and a tile grid gsa_tile_bin16_supported accepts")
+    if fused is None:   # (GSPLAT_AMD_BIN_FUSED=0: the emit + 32-bit sort path, kept for A/B timing)
+        fused = can_fuse and _BIN_FUSED_DEFAULT
+    cap = None if exact else _CAPACITY.get(key)
+    if fused:
+        if tile_rects is None:   # callers that did not keep project_fwd's dense copy: word 11 of the records
+            tile_rects = torch.where(tiles_touched > 0, splat[:, 11].contiguous().view(torch.int32), 0)
+        rects = torch.empty(N, dtype=torch.int32, device=dev)
+
+        def scan(capacity):   # the scan also notes the owner of every 4096-slot record block (+ the last owner)
+            n_blocks = 0 if capacity is None else (capacity + BIN_BLOCK - 1) // BIN_BLOCK
+            owner = torch.empty(n_blocks + 1, dtype=torch.int32, device=dev)
+            _call("gsa_scan_tiles", lib.gsa_scan_tiles_rect, N, _ptr(tiles_touched), _ptr(order), _ptr(tile_rects),
+                  _ptr(offsets), _ptr(rects), _ptr(owner), n_blocks, _ptr(total), _ptr(ws), ws_bytes, st)
+            return owner
+
+        block_owner = scan(cap)
+    else:
+        _call("gsa_scan_tiles", lib.gsa_scan_tiles, N, _ptr(tiles_touched), _ptr(order), _ptr(offsets), _ptr(total),
+              _ptr(ws), ws_bytes, st)
     m_host, m_event = _pinned_scalar(dev)
     m_host.copy_(total, non_blocking=True)
     m_event.record()
     m_known = None
-    cap = None if exact else _CAPACITY.get(key)
     if cap is None:
         m_event.synchronize()
         m_known = int(m_host[0]) & 0xFFFFFFFF
         _note_count(key, m_known)
         cap = m_known
+        if fused:   # first call of a scene shape / repair: the block table needs the count, scan once more
+            block_owner = scan(cap)
+    tile_offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+    if fused:
+        sorted_tile = torch.empty(cap, dtype=torch.int16, device=dev)       # uint16 tile ids (see tile_ids)
+        sorted_gid = torch.empty(cap, dtype=torch.int32, device=dev)
+        two = n_tiles > 256
+        k_tmp = torch.empty(cap if two else 0, dtype=torch.int16, device=dev)
+        v_tmp = torch.empty(cap if two else 0, dtype=torch.int32, device=dev)
+        ws2_bytes = lib.gsa_sort_workspace_bytes(cap)
+        ws2 = torch.empty(ws2_bytes, dtype=torch.uint8, device=dev)
+        _call("gsa_tile_bin16", lib.gsa_tile_bin16, N, _ptr(order), _ptr(offsets), _ptr(rects), _ptr(block_owner), width,
+              height, cap,
+              _ptr(total), _ptr(k_tmp), _ptr(v_tmp), _ptr(sorted_tile), _ptr(sorted_gid), _ptr(tile_offsets), _ptr(ws2),
+              ws2_bytes, st)
+        return TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key)
     isect_tile = torch.empty(cap, dtype=torch.int32, device=dev)
     isect_gid = torch.empty(cap, dtype=torch.int32, device=dev)
     _call("gsa_tile_emit", lib.gsa_tile_emit_dev, N, _ptr(order), _ptr(offsets), _ptr(splat), _ptr(radii), width,
@@ -200,7 +251,6 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
               _ptr(sorted_tile), _ptr(sorted_gid), _ptr(k_tmp), _ptr(v_tmp), 0, tile_bits, _ptr(ws2), ws2_bytes, st)
     else:
         sorted_tile, sorted_gid = isect_tile, isect_gid
-    tile_offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
     _call("gsa_tile_offsets", lib.gsa_tile_offsets_dev, cap, _ptr(total), _ptr(sorted_tile), n_tiles,
           _ptr(tile_offsets), st)
     return TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key)

@@ -162,12 +162,15 @@ def main() -> None:
                                               grad_out=grad_views, sh_grad_factored=vr_mine if factored else None)
         r.backward(v_render)
         if factored:
-            dist.all_reduce(flat_grad[:11 * n])
+            # gather first, so the local rebuild of the SH gradient runs beside the geometry all-reduce
             if dist.get_backend() == "nccl":
-                dist.all_gather_into_tensor(vr_all, vr_mine)
+                gathered = dist.all_gather_into_tensor(vr_all, vr_mine, async_op=True)
             else:
-                dist.all_gather(list(vr_all.unbind(0)), vr_mine)
+                gathered = dist.all_gather(list(vr_all.unbind(0)), vr_mine.clone(), async_op=True)
+            summed = dist.all_reduce(flat_grad[:11 * n], async_op=True)
+            gathered.wait()
             stages.sh_grad_expand(leaves[0], deg, vm_all, K, vr_all, grad_views[4])
+            summed.wait()
         elif dist is not None:  # one all-reduce of the whole 59 N-float bucket (RCCL over xGMI)
             dist.all_reduce(flat_grad)
         info["M"] = meta["n_isects"]

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSA_ABI_VERSION 2
+#define GSA_ABI_VERSION 3
 #define GSA_SPLAT_STRIDE 16
 
 #define GSA_OK 0
@@ -70,13 +70,16 @@ const char *gsa_error_string(int code);
  *             1 = additionally drop tiles whose pixel centres the alpha >= 1/255 ellipse cannot reach
  *                 (same image and gradients, fewer records).
  * Outputs: splat[N,16] (record above; zero rows for culled gaussians), radii[N,2] int32 (0 = culled),
- *          tiles_touched[N] int32, depth_keys[N] uint32 (float bits of depth; 0xFFFFFFFF if culled).
+ *          tiles_touched[N] int32, depth_keys[N] uint32 (float bits of depth; 0xFFFFFFFF if culled),
+ *          tile_rects[N] uint32 (optional, may be NULL): the tile rectangle packed as x0 | y0 << 10 | width << 20
+ *          (what record word 11 holds), 0 for gaussians without records or tile grids of 1024+ tiles a side --
+ *          the dense input of the fused binning (gsa_scan_tiles_rect).
  */
 int gsa_project_fwd(int n, const float *means, const float *quats, const float *scales,
                     const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
                     const float *viewmat, const float *intrin, int width, int height, int cull_mode,
                     float *splat, int32_t *radii, int32_t *tiles_touched, uint32_t *depth_keys,
-                    gsa_stream_t stream);
+                    uint32_t *tile_rects, gsa_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stage 2 (row a3.3): tile binning.  Replaces gsplat's isect_tiles + 64-bit radix sort +
@@ -96,6 +99,28 @@ int gsa_sort_pairs_u32(int n, const uint32_t *keys_in, const uint32_t *vals_in, 
  * workspace: gsa_sort_workspace_bytes(n). */
 int gsa_scan_tiles(int n, const int32_t *tiles_touched, const uint32_t *order, uint32_t *offsets,
                    uint32_t *total, void *workspace, size_t workspace_bytes, gsa_stream_t stream);
+
+/* Fused binning for cull_mode 0 and 16-bit tile ids (gsa_tile_bin16_supported: tile grid below 1024 x 1024 and at
+ * most 65535 tiles).  gsa_scan_tiles_rect is gsa_scan_tiles that also brings the packed tile rectangles
+ * (gsa_project_fwd's tile_rects) into depth order -- rects[k] for g = order[k] -- and notes which gaussian owns the
+ * first record slot of every block of GSA_BIN_BLOCK slots: block_owner[b] = last k with offsets[k] <= b *
+ * GSA_BIN_BLOCK, for b < n_blocks (entries of blocks at or beyond the record count are not written), and
+ * block_owner[n_blocks] = the last gaussian (in depth order) that has records: n_blocks + 1 entries.
+ * gsa_tile_bin16 then produces what gsa_tile_emit + gsa_sort_pairs_u32 + gsa_tile_offsets produce -- sorted_tile
+ * (as uint16), sorted_gid, tile_offsets[n_tiles + 1] -- without ever writing the records in emission order: the
+ * first pass of the tile sort generates them from the rectangles.  m_dev: live record count on the device (NULL:
+ * m_capacity is the count); block_owner: from a scan with n_blocks == ceil(m_capacity / GSA_BIN_BLOCK); tile_tmp / gid_tmp:
+ * m_capacity elements each (unused for at most 256 tiles); workspace: gsa_sort_workspace_bytes(m_capacity). */
+#define GSA_BIN_BLOCK 4096
+int gsa_tile_bin16_supported(int width, int height);
+int gsa_scan_tiles_rect(int n, const int32_t *tiles_touched, const uint32_t *order, const uint32_t *tile_rects,
+                        uint32_t *offsets, uint32_t *rects, int32_t *block_owner, int n_blocks, uint32_t *total,
+                        void *workspace, size_t workspace_bytes, gsa_stream_t stream);
+int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offsets, const uint32_t *rects,
+                   const int32_t *block_owner, int width, int height, uint32_t m_capacity, const uint32_t *m_dev,
+                   uint16_t *tile_tmp,
+                   uint32_t *gid_tmp, uint16_t *sorted_tile, uint32_t *sorted_gid, int32_t *tile_offsets,
+                   void *workspace, size_t workspace_bytes, gsa_stream_t stream);
 
 /* For k in depth order, g = order[k]: write that gaussian's tile ids and its index g at
  * [offsets[k], offsets[k] + tiles_touched[g]).  Must use the cull_mode of gsa_project_fwd. */

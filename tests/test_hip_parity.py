@@ -523,6 +523,40 @@ def test_grad_accumulate_sums_views_into_one_bucket(gsa, deg):
         gsa.rasterization(*base, views[0], K, W, H, sh_degree=deg, grad_accumulate=True)
 
 
+@pytest.mark.parametrize("W,H,N,s_max", [(640, 360, 30_000, 0.05), (160, 96, 4000, 0.3), (1920, 1080, 50_000, 0.02),
+                                          (40, 24, 500, 0.5)])
+def test_fused_binning_equals_emit_and_sort(gsa, W, H, N, s_max):
+    """gsa_scan_tiles_rect + gsa_tile_bin16 (records generated inside the first tile-sort pass, 16-bit tile ids) ==
+    gsa_tile_emit + gsa_sort_pairs_u32 + gsa_tile_offsets, bit for bit: tile ids, gaussian ids, tile offsets.
+    Covers one- and two-digit tile grids, gaussians without records between ones that have some (the off-screen
+    5 %), and a remembered capacity smaller than the record count (reported by finalize(); the caller re-runs)."""
+    from gsplat_amd import scene, stages as S
+    sc = _scene(N, seed=21, s_min=0.002, s_max=s_max)
+    vm, K = scene.make_camera(2, 5).cuda(), scene.make_intrinsics(W, H).cuda()
+    d = {k: v.cuda().contiguous() for k, v in sc.items()}
+    splat, radii, tiles, keys = S.project_fwd(d["means3D"], d["rotations"], d["scales"], d["opacities"][:, 0].contiguous(),
+                                              d["shs"], 3, vm, K, W, H, 0)
+    assert int((tiles == 0).sum()) > 0 and int((tiles > 0).sum()) > 0
+    a = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, fused=False)
+    b = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, fused=True)
+    assert b.sorted_tile.dtype == torch.int16 and a.sorted_tile.dtype == torch.int32
+    m = a.finalize()[0]
+    assert m == b.finalize()[0] == int(tiles.sum()) and m > 0
+    assert torch.equal(S.tile_ids(b.sorted_tile), S.tile_ids(a.sorted_tile))
+    assert torch.equal(b.sorted_gid, a.sorted_gid)
+    assert torch.equal(b.tile_offsets, a.tile_offsets)
+    # steady state with a remembered capacity (device-side count) gives the same bins
+    c = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, fused=True)
+    assert c.finalize() == (m, True)
+    assert torch.equal(c.sorted_gid, a.sorted_gid) and torch.equal(c.tile_offsets, a.tile_offsets)
+    key = ("cuda", torch.cuda.current_device(), N, W, H, 0)
+    S._CAPACITY[key] = max(1, m // 3)                      # too small: kernels clamp to it, finalize() says so
+    t = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, fused=True)
+    assert t.finalize() == (m, False) and int(t.tile_offsets.max()) <= t.capacity
+    e = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, fused=True)
+    assert torch.equal(e.sorted_gid, a.sorted_gid) and torch.equal(e.tile_offsets, a.tile_offsets)
+
+
 @pytest.mark.parametrize("deg", [3, 1])
 def test_factored_sh_gradient_rebuilds_the_coefficient_gradient(gsa, deg):
     """``sh_grad_factored``: the backward pass leaves d loss / d rgb [N,3] per view; ``stages.sh_grad_expand`` over the
