@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(
         radii[2 * i] = 0; radii[2 * i + 1] = 0;
         tiles_touched[i] = 0;
         depth_keys[i] = 0xFFFFFFFFu;
-        if (tile_rects) tile_rects[i] = 0u;
+        if (tile_rects) reinterpret_cast<uint2 *>(tile_rects)[i] = make_uint2(0u, 0u);
         return;
     }
 
@@ -156,7 +156,8 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(
     radii[2 * i] = rx; radii[2 * i + 1] = ry;
     tiles_touched[i] = count;
     depth_keys[i] = __float_as_uint(p.z);
-    if (tile_rects) tile_rects[i] = count > 0 ? rect : 0u;   // dense copy for the fused binning (gathered in depth order)
+    // dense (rectangle, count) pairs for the fused binning: one 8-B gather per gaussian brings both into depth order
+    if (tile_rects) reinterpret_cast<uint2 *>(tile_rects)[i] = make_uint2(count > 0 ? rect : 0u, (uint32_t)count);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -473,6 +474,7 @@ extern "C" int gsa_project_fwd(int n, const float *means, const float *quats, co
     GSA_RETURN_IF(sh_degree < -1 || sh_degree > 3, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_degree >= 0 && sh_coeffs < (sh_degree + 1) * (sh_degree + 1), GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(cull_mode != 0 && cull_mode != 1, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF((reinterpret_cast<uintptr_t>(tile_rects) & 7) != 0, GSA_ERR_INVALID_ARGUMENT);
     if (n == 0) return GSA_OK;
     GSA_RETURN_IF(!means || !quats || !scales || !opacities || !colors || !viewmat || !intrin || !splat || !radii ||
                       !tiles_touched || !depth_keys,

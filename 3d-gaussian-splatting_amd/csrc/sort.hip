@@ -49,10 +49,26 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(int n_cap, con
     }
     h[threadIdx.x] = 0;
     __syncthreads();
+    if constexpr (sizeof(KeyT) == 2) {   // two keys per 4-B load (the block's base is a multiple of kSortChunk keys)
+        const uint32_t *pairs = reinterpret_cast<const uint32_t *>(keys + base);
 #pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
-        long i = base + r * kSortThreads + threadIdx.x;
-        if (i < n) atomicAdd(&h[((uint32_t)keys[i] >> shift) & (kRadix - 1)], 1u);
+        for (int r = 0; r < kSortItems / 2; ++r) {
+            const int p = r * kSortThreads + threadIdx.x;
+            const long i = base + 2 * p;
+            if (i + 1 < n) {
+                const uint32_t kk = pairs[p];
+                atomicAdd(&h[((kk & 0xFFFFu) >> shift) & (kRadix - 1)], 1u);
+                atomicAdd(&h[((kk >> 16) >> shift) & (kRadix - 1)], 1u);
+            } else if (i < n) {
+                atomicAdd(&h[((uint32_t)keys[i] >> shift) & (kRadix - 1)], 1u);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < kSortItems; ++r) {
+            long i = base + r * kSortThreads + threadIdx.x;
+            if (i < n) atomicAdd(&h[((uint32_t)keys[i] >> shift) & (kRadix - 1)], 1u);
+        }
     }
     __syncthreads();
     hist[(long)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
@@ -207,25 +223,30 @@ __device__ __forceinline__ uint32_t scan_load(const int32_t *__restrict__ tiles_
     return i < n ? (uint32_t)tiles_touched[order[i]] : 0u;
 }
 
+
 // `gathered` (the offsets buffer itself): the counts in depth order, so that the final pass streams them instead of
 // repeating the random gather through `order`
 __global__ __launch_bounds__(kSortThreads) void scan_reduce_kernel(int n, const int32_t *__restrict__ tiles_touched,
                                                                    const uint32_t *__restrict__ order,
                                                                    uint32_t *__restrict__ block_sums,
                                                                    uint32_t *__restrict__ gathered,
-                                                                   const uint32_t *__restrict__ tile_rects,
+                                                                   const uint2 *__restrict__ tile_rects,
                                                                    uint32_t *__restrict__ rects) {
     __shared__ uint32_t scratch[4];
     long base = (long)blockIdx.x * kScanChunk + threadIdx.x * kScanItems;
     uint32_t s = 0;
 #pragma unroll
     for (int j = 0; j < kScanItems; ++j) {
-        const uint32_t c = scan_load(tiles_touched, order, base + j, n);
+        uint32_t c = 0;
         if (base + j < n) {
+            if (rects) {   // fused binning: ONE 8-B gather brings the packed rectangle and the count into depth order
+                const uint2 rc = tile_rects[order[base + j]];
+                rects[base + j] = rc.x;
+                c = rc.y;
+            } else {
+                c = (uint32_t)tiles_touched[order[base + j]];
+            }
             gathered[base + j] = c;
-            // the packed tile rectangle, brought into depth order for the fused emit (a second 4-B gather from a dense
-            // N-word array, beside the one of the count)
-            if (rects) rects[base + j] = tile_rects[order[base + j]];
         }
         s += c;
     }
@@ -422,11 +443,17 @@ __global__ __launch_bounds__(kSortThreads) void tile_offsets_bsearch_kernel(uint
 // next one that has some, the last one wins), a max-scan carries the owner forward; slot -> tile: the rectangle
 // arithmetic of tile_emit_coop_kernel.
 struct EmitBlock { uint32_t slot0, live; int k_lo; };   // live: slots of this block below the record count
+constexpr int kEmitStage = 1024;   // gaussians per block whose (offset, rectangle, index) are staged in LDS
 
-__device__ __forceinline__ EmitBlock emit_owners(int n, const uint32_t *__restrict__ offsets,
+// s_off / s_rect / s_gid [kEmitStage]: the data of the first kEmitStage gaussians of the block, read once (coalesced)
+// while their starts are marked; owners beyond (a block of gaussians with fewer than four records each) are looked
+// up in global memory.  s_gid may be null (the histogram does not need the indices).
+__device__ __forceinline__ EmitBlock emit_owners(const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ rects,
+                                                  const uint32_t *__restrict__ order,
                                                   const int32_t *__restrict__ block_owner, int n_owner_blocks,
                                                   uint32_t m_total, uint32_t *__restrict__ s_own,
-                                                  uint32_t *__restrict__ scratch) {
+                                                  uint32_t *__restrict__ s_off, uint32_t *__restrict__ s_rect,
+                                                  uint32_t *__restrict__ s_gid, uint32_t *__restrict__ scratch) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     EmitBlock eb;
     eb.slot0 = blockIdx.x * (uint32_t)kSortChunk;
@@ -440,9 +467,15 @@ __device__ __forceinline__ EmitBlock emit_owners(int n, const uint32_t *__restri
 #pragma unroll
     for (int q = 0; q < kSortItems / 4; ++q) own4[q] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
-    for (int k = eb.k_lo + 1 + t; k <= k_hi; k += kSortThreads) {
-        const uint32_t o = offsets[k] - eb.slot0;   // (gaussians without records at the block's end start at slot_end)
-        if (o < eb.live) atomicMax(&s_own[o], (uint32_t)(k - eb.k_lo));
+    for (int k = eb.k_lo + t; k <= k_hi; k += kSortThreads) {
+        const uint32_t off = offsets[k], i = (uint32_t)(k - eb.k_lo);
+        if (i < (uint32_t)kEmitStage) {
+            s_off[i] = off;
+            s_rect[i] = rects[k];
+            if (s_gid) s_gid[i] = order[k];
+        }
+        const uint32_t o = off - eb.slot0;   // (gaussians without records at the block's end start at slot_end)
+        if (i > 0u && o < eb.live) atomicMax(&s_own[o], i);
     }
     __syncthreads();
     uint32_t v[kSortItems], run = 0;
@@ -472,18 +505,27 @@ __device__ __forceinline__ EmitBlock emit_owners(int n, const uint32_t *__restri
 }
 
 // the record of block slot `slot` (< eb.live): tile id and gaussian index
+template <bool WANT_GID>
 __device__ __forceinline__ void emit_record(const EmitBlock &eb, uint32_t slot, const uint32_t *__restrict__ s_own,
-                                            const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ rects,
-                                            const uint32_t *__restrict__ order, int tile_w, uint32_t &tile,
-                                            uint32_t &gid) {
-    const int k = eb.k_lo + (int)s_own[slot];
-    const uint32_t rect = rects[k];
-    const uint32_t j = eb.slot0 + slot - offsets[k];
+                                            const uint32_t *__restrict__ s_off, const uint32_t *__restrict__ s_rect,
+                                            const uint32_t *__restrict__ s_gid, const uint32_t *__restrict__ offsets,
+                                            const uint32_t *__restrict__ rects, const uint32_t *__restrict__ order,
+                                            int tile_w, uint32_t &tile, uint32_t &gid) {
+    const uint32_t i = s_own[slot];
+    uint32_t rect, off;
+    if (i < (uint32_t)kEmitStage) {
+        rect = s_rect[i]; off = s_off[i];
+        if (WANT_GID) gid = s_gid[i];
+    } else {
+        const int k = eb.k_lo + (int)i;
+        rect = rects[k]; off = offsets[k];
+        if (WANT_GID) gid = order[k];
+    }
+    const uint32_t j = eb.slot0 + slot - off;
     const int x0 = (int)(rect & 1023u), y0 = (int)((rect >> 10) & 1023u), wl = max((int)(rect >> 20), 1);
     const int row = (int)(((float)j + 0.5f) / (float)wl);   // exact: j, wl < 2^15
     const int col = (int)j - row * wl;
     tile = (uint32_t)((y0 + row) * tile_w + x0 + col);
-    gid = order[k];
 }
 
 __global__ __launch_bounds__(kSortThreads) void emit_hist_kernel(int n, const uint32_t *__restrict__ order,
@@ -495,19 +537,21 @@ __global__ __launch_bounds__(kSortThreads) void emit_hist_kernel(int n, const ui
     __shared__ uint32_t scratch[4];
     __shared__ uint32_t h[kRadix];
     __shared__ __attribute__((aligned(16))) uint32_t s_own[kSortChunk];
+    __shared__ uint32_t s_off[kEmitStage], s_rect[kEmitStage];
     const uint32_t m_total = m_dev ? min(m_cap, *m_dev) : m_cap;
     if ((uint64_t)blockIdx.x * kSortChunk >= m_total) {
         hist[(long)threadIdx.x * nblocks + blockIdx.x] = 0;
         return;
     }
     h[threadIdx.x] = 0;
-    const EmitBlock eb = emit_owners(n, offsets, block_owner, nblocks, m_total, s_own, scratch);
-#pragma unroll 4
+    const EmitBlock eb = emit_owners(offsets, rects, order, block_owner, nblocks, m_total, s_own, s_off, s_rect, nullptr,
+                                     scratch);
+#pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         const uint32_t slot = r * kSortThreads + threadIdx.x;
         if (slot < eb.live) {
-            uint32_t tile, gid;
-            emit_record(eb, slot, s_own, offsets, rects, order, tile_w, tile, gid);
+            uint32_t tile, gid = 0;
+            emit_record<false>(eb, slot, s_own, s_off, s_rect, nullptr, offsets, rects, order, tile_w, tile, gid);
             atomicAdd(&h[tile & (kRadix - 1)], 1u);
         }
     }
@@ -525,9 +569,14 @@ __global__ __launch_bounds__(kSortThreads) void emit_scatter_kernel(
     __shared__ uint32_t scratch[4];
     __shared__ uint32_t gbase[kRadix];
     __shared__ uint32_t lexcl[kRadix];
-    __shared__ uint32_t wave_cnt[4][kRadix];
-    __shared__ uint16_t s_key[kSortChunk];
-    __shared__ __attribute__((aligned(16))) uint32_t s_val[kSortChunk];   // first: the slot owners
+    // three regions, each with two lives: the generation's (slot owners | staged offsets + rectangles | staged
+    // gaussian indices) and the scatter's (values | 16-bit keys | wave-private digit counters)
+    __shared__ __attribute__((aligned(16))) uint32_t s_val[kSortChunk];
+    __shared__ __attribute__((aligned(16))) uint32_t s_keyraw[kSortChunk / 2];
+    __shared__ uint32_t s_cntraw[4 * kRadix];
+    static_assert(2 * kEmitStage <= kSortChunk / 2 && kEmitStage <= 4 * kRadix, "staging must fit the aliased regions");
+    uint16_t *s_key = reinterpret_cast<uint16_t *>(s_keyraw);
+    uint32_t(*wave_cnt)[kRadix] = reinterpret_cast<uint32_t(*)[kRadix]>(s_cntraw);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t m_total = m_dev ? min(m_cap, *m_dev) : m_cap;
     if ((uint64_t)blockIdx.x * kSortChunk >= m_total) return;
@@ -539,19 +588,23 @@ __global__ __launch_bounds__(kSortThreads) void emit_scatter_kernel(
         const uint32_t lbase = block_excl_scan(next - mine, scratch, tot);
         gbase[t] = dbase + mine;
         lexcl[t] = lbase;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) wave_cnt[w][t] = 0;
     }
-    const EmitBlock eb = emit_owners(n, offsets, block_owner, nblocks, m_total, s_val, scratch);
+    const EmitBlock eb = emit_owners(offsets, rects, order, block_owner, nblocks, m_total, s_val, s_keyraw,
+                                     s_keyraw + kEmitStage, s_cntraw, scratch);
     const uint32_t wbase = wave * (kSortChunk / 4);
     uint32_t k[kSortItems], v[kSortItems], rk[kSortItems];
-#pragma unroll 4
+#pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         const uint32_t slot = wbase + r * 64 + lane;
         k[r] = 0xFFFFu; v[r] = 0u;
-        if (slot < eb.live) emit_record(eb, slot, s_val, offsets, rects, order, tile_w, k[r], v[r]);
+        if (slot < eb.live)
+            emit_record<true>(eb, slot, s_val, s_keyraw, s_keyraw + kEmitStage, s_cntraw, offsets, rects, order, tile_w,
+                              k[r], v[r]);
     }
-    __syncthreads();   // owners consumed: s_val is free for the reorder
+    __syncthreads();   // owners and staged data consumed: the regions start their second life
+#pragma unroll
+    for (int w = 0; w < 4; ++w) wave_cnt[w][t] = 0;
+    __syncthreads();
 
     uint32_t *cnt = wave_cnt[wave];
 #pragma unroll
@@ -660,7 +713,7 @@ extern "C" int gsa_sort_pairs_u32_dev(int capacity, const uint32_t *n_dev, const
                            end_bit, workspace, workspace_bytes, stream);
 }
 
-static int scan_tiles_impl(int n, const int32_t *tiles_touched, const uint32_t *order, const uint32_t *tile_rects,
+static int scan_tiles_impl(int n, const int32_t *tiles_touched, const uint32_t *order, const uint2 *tile_rects,
                            uint32_t *offsets, uint32_t *rects, int32_t *block_owner, int n_owner_blocks,
                            uint32_t *total, void *workspace, size_t workspace_bytes, gsa_stream_t stream) {
     GSA_RETURN_IF(n < 0, GSA_ERR_INVALID_ARGUMENT);
@@ -670,8 +723,8 @@ static int scan_tiles_impl(int n, const int32_t *tiles_touched, const uint32_t *
         hipError_t e = hipMemsetAsync(total, 0, sizeof(uint32_t), s);
         return (int)e;
     }
-    GSA_RETURN_IF(!tiles_touched || !order || !offsets || !workspace, GSA_ERR_INVALID_ARGUMENT);
-    GSA_RETURN_IF(rects && !tile_rects, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(!order || !offsets || !workspace, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(rects ? !tile_rects : !tiles_touched, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(workspace_bytes < gsa_sort_workspace_bytes(n), GSA_ERR_WORKSPACE_TOO_SMALL);
     uint32_t *block_sums = static_cast<uint32_t *>(workspace);
     int nblocks = gsa_div_up(n, kScanChunk);
@@ -691,14 +744,14 @@ extern "C" int gsa_scan_tiles(int n, const int32_t *tiles_touched, const uint32_
                            workspace_bytes, stream);
 }
 
-extern "C" int gsa_scan_tiles_rect(int n, const int32_t *tiles_touched, const uint32_t *order,
-                                   const uint32_t *tile_rects, uint32_t *offsets, uint32_t *rects,
-                                   int32_t *block_owner, int n_blocks, uint32_t *total, void *workspace,
-                                   size_t workspace_bytes, gsa_stream_t stream) {
+extern "C" int gsa_scan_tiles_rect(int n, const uint32_t *order, const uint32_t *tile_rects, uint32_t *offsets,
+                                   uint32_t *rects, int32_t *block_owner, int n_blocks, uint32_t *total,
+                                   void *workspace, size_t workspace_bytes, gsa_stream_t stream) {
     GSA_RETURN_IF(n > 0 && (!tile_rects || !rects), GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF((reinterpret_cast<uintptr_t>(tile_rects) & 7) != 0, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(n_blocks < 0 || (n_blocks > 0 && !block_owner), GSA_ERR_INVALID_ARGUMENT);
-    return scan_tiles_impl(n, tiles_touched, order, tile_rects, offsets, rects, block_owner, n_blocks, total, workspace,
-                           workspace_bytes, stream);
+    return scan_tiles_impl(n, nullptr, order, reinterpret_cast<const uint2 *>(tile_rects), offsets, rects, block_owner,
+                           n_blocks, total, workspace, workspace_bytes, stream);
 }
 
 static int tile_emit_impl(int n, const uint32_t *order, const uint32_t *offsets, const float *splat,
@@ -789,7 +842,8 @@ extern "C" int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offs
                   GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(workspace_bytes < gsa_sort_workspace_bytes((int)m_capacity), GSA_ERR_WORKSPACE_TOO_SMALL);
     const bool two = n_tiles > kRadix;   // tile ids above 8 bits: a second (high-digit) pass
-    GSA_RETURN_IF(two && (!tile_tmp || !gid_tmp), GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(two && (!tile_tmp || !gid_tmp || (reinterpret_cast<uintptr_t>(tile_tmp) & 3) != 0),
+                  GSA_ERR_INVALID_ARGUMENT);
     const int nblocks = sort_blocks((int)m_capacity);
     uint32_t *hist = static_cast<uint32_t *>(workspace);
     uint32_t *digit_total = hist + (size_t)kRadix * nblocks;

@@ -27,7 +27,7 @@ SIGNATURES = {
     "gsa_sort_pairs_u32": (c_int, [c_int, P, P, P, P, P, P, c_int, c_int, P, c_size_t, P]),
     "gsa_scan_tiles": (c_int, [c_int, P, P, P, P, P, c_size_t, P]),
     "gsa_tile_bin16_supported": (c_int, [c_int, c_int]),
-    "gsa_scan_tiles_rect": (c_int, [c_int, P, P, P, P, P, P, c_int, P, P, c_size_t, P]),
+    "gsa_scan_tiles_rect": (c_int, [c_int, P, P, P, P, P, c_int, P, P, c_size_t, P]),
     "gsa_tile_bin16": (c_int, [c_int, P, P, P, P, c_int, c_int, c_uint32, P, P, P, P, P, P, P, c_size_t, P]),
     "gsa_tile_emit": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_uint32, P, P, P]),
     "gsa_tile_offsets": (c_int, [c_uint32, P, c_int, P, P]),

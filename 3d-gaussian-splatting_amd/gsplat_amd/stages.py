@@ -87,14 +87,15 @@ def _pinned_scalar(dev):
 def project_fwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat, Kmat, width: int, height: int,
                 cull_mode: int = 0, return_rects: bool = False):
     """-> splat [N,16], radii [N,2] i32, tiles_touched [N] i32, depth_keys [N] (uint32 bits in int32 storage)
-    [, tile_rects [N] i32: the packed tile rectangles the fused binning reads, with ``return_rects``]."""
+    [, tile_rects [N,2] i32: (packed tile rectangle, record count) pairs the fused binning reads, with
+    ``return_rects``]."""
     dev, N = means.device, means.shape[0]
     sh_coeffs = colors.shape[1] if sh_degree >= 0 else 0
     splat = torch.empty(N, SPLAT_STRIDE, dtype=torch.float32, device=dev)
     radii = torch.empty(N, 2, dtype=torch.int32, device=dev)
     tiles_touched = torch.empty(N, dtype=torch.int32, device=dev)
     depth_keys = torch.empty(N, dtype=torch.int32, device=dev)
-    tile_rects = torch.empty(N, dtype=torch.int32, device=dev) if return_rects else None
+    tile_rects = torch.empty(N, 2, dtype=torch.int32, device=dev) if return_rects else None
     _call("gsa_project_fwd", lib.gsa_project_fwd, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
           _ptr(colors), sh_degree, sh_coeffs, _ptr(viewmat), _ptr(Kmat), width, height, cull_mode, _ptr(splat),
           _ptr(radii), _ptr(tiles_touched), _ptr(depth_keys), _ptr(tile_rects), _stream())
@@ -197,14 +198,14 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
     cap = None if exact else _CAPACITY.get(key)
     if fused:
         if tile_rects is None:   # callers that did not keep project_fwd's dense copy: word 11 of the records
-            tile_rects = torch.where(tiles_touched > 0, splat[:, 11].contiguous().view(torch.int32), 0)
+            tile_rects = torch.stack([torch.where(tiles_touched > 0, splat[:, 11].contiguous().view(torch.int32), 0),
+                                      tiles_touched], dim=1).contiguous()
         rects = torch.empty(N, dtype=torch.int32, device=dev)
 
         def scan(capacity):   # the scan also notes the owner of every 4096-slot record block (+ the last owner)
             n_blocks = 0 if capacity is None else (capacity + BIN_BLOCK - 1) // BIN_BLOCK
             owner = torch.empty(n_blocks + 1, dtype=torch.int32, device=dev)
-            _call("gsa_scan_tiles", lib.gsa_scan_tiles_rect, N, _ptr(tiles_touched), _ptr(order), _ptr(tile_rects),
-                  _ptr(offsets), _ptr(rects), _ptr(owner), n_blocks, _ptr(total), _ptr(ws), ws_bytes, st)
+            _call("gsa_scan_tiles", lib.gsa_scan_tiles_rect, N, _ptr(order), _ptr(tile_rects), _ptr(offsets), _ptr(rects), _ptr(owner), n_blocks, _ptr(total), _ptr(ws), ws_bytes, st)
             return owner
 
         block_owner = scan(cap)

@@ -157,7 +157,8 @@ def main() -> None:
         for t in leaves:
             t.grad = None
         # the backward pass writes every gradient element straight into the bucket (no zero-fill, no copy)
-        r, a, meta = gsplat_amd.rasterization(leaves[0], leaves[1], leaves[2], opac[:, 0], leaves[4], vm, K, width,
+        # (opacities [N,1] -> [N] as the reference backend does it, gsplat_backend.py:157-158)
+        r, a, meta = gsplat_amd.rasterization(leaves[0], leaves[1], leaves[2], opac.squeeze(-1), leaves[4], vm, K, width,
                                               height, sh_degree=deg, backgrounds=bg, cull_mode=args.cull_mode,
                                               grad_out=grad_views, sh_grad_factored=vr_mine if factored else None)
         r.backward(v_render)

@@ -71,9 +71,10 @@ const char *gsa_error_string(int code);
  *                 (same image and gradients, fewer records).
  * Outputs: splat[N,16] (record above; zero rows for culled gaussians), radii[N,2] int32 (0 = culled),
  *          tiles_touched[N] int32, depth_keys[N] uint32 (float bits of depth; 0xFFFFFFFF if culled),
- *          tile_rects[N] uint32 (optional, may be NULL): the tile rectangle packed as x0 | y0 << 10 | width << 20
- *          (what record word 11 holds), 0 for gaussians without records or tile grids of 1024+ tiles a side --
- *          the dense input of the fused binning (gsa_scan_tiles_rect).
+ *          tile_rects[N,2] uint32 (optional, may be NULL; 8-byte aligned): per gaussian the tile rectangle packed
+ *          as x0 | y0 << 10 | width << 20 (what record word 11 holds; 0 without records or for tile grids of 1024+
+ *          tiles a side) and the record count (== tiles_touched) -- the dense input of the fused binning
+ *          (gsa_scan_tiles_rect).
  */
 int gsa_project_fwd(int n, const float *means, const float *quats, const float *scales,
                     const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
@@ -101,8 +102,8 @@ int gsa_scan_tiles(int n, const int32_t *tiles_touched, const uint32_t *order, u
                    uint32_t *total, void *workspace, size_t workspace_bytes, gsa_stream_t stream);
 
 /* Fused binning for cull_mode 0 and 16-bit tile ids (gsa_tile_bin16_supported: tile grid below 1024 x 1024 and at
- * most 65535 tiles).  gsa_scan_tiles_rect is gsa_scan_tiles that also brings the packed tile rectangles
- * (gsa_project_fwd's tile_rects) into depth order -- rects[k] for g = order[k] -- and notes which gaussian owns the
+ * most 65535 tiles).  gsa_scan_tiles_rect is gsa_scan_tiles on the counts in gsa_project_fwd's tile_rects[N,2] that
+ * also brings the packed rectangles into depth order -- rects[k] for g = order[k] -- and notes which gaussian owns the
  * first record slot of every block of GSA_BIN_BLOCK slots: block_owner[b] = last k with offsets[k] <= b *
  * GSA_BIN_BLOCK, for b < n_blocks (entries of blocks at or beyond the record count are not written), and
  * block_owner[n_blocks] = the last gaussian (in depth order) that has records: n_blocks + 1 entries.
@@ -113,9 +114,9 @@ int gsa_scan_tiles(int n, const int32_t *tiles_touched, const uint32_t *order, u
  * m_capacity elements each (unused for at most 256 tiles); workspace: gsa_sort_workspace_bytes(m_capacity). */
 #define GSA_BIN_BLOCK 4096
 int gsa_tile_bin16_supported(int width, int height);
-int gsa_scan_tiles_rect(int n, const int32_t *tiles_touched, const uint32_t *order, const uint32_t *tile_rects,
-                        uint32_t *offsets, uint32_t *rects, int32_t *block_owner, int n_blocks, uint32_t *total,
-                        void *workspace, size_t workspace_bytes, gsa_stream_t stream);
+int gsa_scan_tiles_rect(int n, const uint32_t *order, const uint32_t *tile_rects, uint32_t *offsets,
+                        uint32_t *rects, int32_t *block_owner, int n_blocks, uint32_t *total, void *workspace,
+                        size_t workspace_bytes, gsa_stream_t stream);
 int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offsets, const uint32_t *rects,
                    const int32_t *block_owner, int width, int height, uint32_t m_capacity, const uint32_t *m_dev,
                    uint16_t *tile_tmp,
