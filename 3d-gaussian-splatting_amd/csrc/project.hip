@@ -71,13 +71,13 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(
         }
         wave_lds_sync();
     }
-    if (i >= n) return;
+    const bool inside = i < n;   // lanes beyond n stay for the wave-cooperative record store below
 
     GsaCamera cam = gsa_load_camera(viewmat, intrin);
     GsaProj p = gsa_project_one(cam, g_mean, g_quat, g_scale, width, height);
     const float opac = g_opac;
 
-    bool visible = p.ok && (opac >= GSA_ALPHA_THRESHOLD);
+    bool visible = inside && p.ok && (opac >= GSA_ALPHA_THRESHOLD);
     float sig_max = logf(fmaxf(opac, GSA_ALPHA_THRESHOLD) * 255.0f);  // alpha >= 1/255  <=>  sigma <= ln(255 o)
     float ext = fminf(GSA_RADIUS_EXTEND, sqrtf(2.0f * sig_max));
     float rxf = ceilf(ext * sqrtf(fmaxf(p.c00, 0.f)));
@@ -86,17 +86,11 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(
     visible = visible && !(p.mx + rxf <= 0.f || p.mx - rxf >= (float)width || p.my + ryf <= 0.f ||
                            p.my - ryf >= (float)height);
 
-    float4 *out = reinterpret_cast<float4 *>(splat + i * GSA_SPLAT_STRIDE);
-    if (!visible) {
-        float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        out[0] = z4; out[1] = z4; out[2] = z4; out[3] = z4;
-        radii[2 * i] = 0; radii[2 * i + 1] = 0;
-        tiles_touched[i] = 0;
-        depth_keys[i] = 0xFFFFFFFFu;
-        if (tile_rects) reinterpret_cast<uint2 *>(tile_rects)[i] = make_uint2(0u, 0u);
-        return;
-    }
-
+    // what a culled gaussian leaves: a zero record, zero radii / count, the largest depth key
+    float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0, o2 = o0;
+    int rx = 0, ry = 0, count = 0;
+    uint32_t key = 0xFFFFFFFFu, rect = 0u;
+    if (visible) {
     // ---- colour (A.3)
     float r, g, b;
     if constexpr (DEG < 0) {
@@ -133,9 +127,8 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(
     }
 
     // ---- tile count (A.4)
-    int rx = (int)rxf, ry = (int)ryf;
+    rx = (int)rxf; ry = (int)ryf;
     GsaTileRect tr = gsa_tile_rect(p.mx, p.my, rx, ry, tile_w, tile_h);
-    int count;
     if (cull_mode == 0) {
         count = (tr.x1 - tr.x0) * (tr.y1 - tr.y0);
     } else {
@@ -144,18 +137,39 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(
             for (int tx = tr.x0; tx < tr.x1; ++tx)
                 count += gsa_quadrant_mask(p.mx, p.my, p.qa, p.qb, p.qc, sig_max, tx, ty) != 0u ? 1 : 0;
     }
-
-    out[0] = make_float4(p.mx, p.my, p.qa, p.qb);
-    out[1] = make_float4(p.qc, opac, r, g);
     // record word 11: the tile rectangle, packed (x0 | y0 << 10 | width << 20; 0 when a coordinate needs more than
     // 10 bits) -- tile_emit then needs this one line per gaussian instead of the mean AND the radii
     const bool packable = tile_w < 1024 && tile_h < 1024;
-    const uint32_t rect = packable ? ((uint32_t)tr.x0 | ((uint32_t)tr.y0 << 10) | ((uint32_t)(tr.x1 - tr.x0) << 20)) : 0u;
-    out[2] = make_float4(b, p.z, sig_max, __uint_as_float(rect));
-    out[3] = make_float4(0.f, 0.f, 0.f, 0.f);
-    radii[2 * i] = rx; radii[2 * i + 1] = ry;
+    rect = packable ? ((uint32_t)tr.x0 | ((uint32_t)tr.y0 << 10) | ((uint32_t)(tr.x1 - tr.x0) << 20)) : 0u;
+    o0 = make_float4(p.mx, p.my, p.qa, p.qb);
+    o1 = make_float4(p.qc, opac, r, g);
+    o2 = make_float4(b, p.z, sig_max, __uint_as_float(rect));
+    key = __float_as_uint(p.z);
+    }   // visible
+
+    // ---- the 64-B records: through the wave's (now free) LDS rows, so that every store instruction writes 1 KB of
+    // consecutive addresses instead of 16 B at a 64-B stride
+    if constexpr (STAGE && DEG >= 1) {
+        const long wave_base = (long)blockIdx.x * kBlock + wave * 64;
+        const int rows = (int)min((long)64, (long)n - wave_base);
+        float4 *wl = &sh_lds[(wave * 64) * kRowQPad];
+        wave_lds_sync();   // every lane has read its SH row
+        wl[lane * 4 + 0] = o0; wl[lane * 4 + 1] = o1; wl[lane * 4 + 2] = o2; wl[lane * 4 + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        wave_lds_sync();
+        float4 *outw = reinterpret_cast<float4 *>(splat + wave_base * GSA_SPLAT_STRIDE);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = k * 64 + lane;
+            if (idx < rows * 4) outw[idx] = wl[idx];
+        }
+    } else if (inside) {
+        float4 *out = reinterpret_cast<float4 *>(splat + i * GSA_SPLAT_STRIDE);
+        out[0] = o0; out[1] = o1; out[2] = o2; out[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (!inside) return;
+    *reinterpret_cast<int2 *>(radii + 2 * i) = make_int2(rx, ry);
     tiles_touched[i] = count;
-    depth_keys[i] = __float_as_uint(p.z);
+    depth_keys[i] = key;
     // dense (rectangle, count) pairs for the fused binning: one 8-B gather per gaussian brings both into depth order
     if (tile_rects) reinterpret_cast<uint2 *>(tile_rects)[i] = make_uint2(count > 0 ? rect : 0u, (uint32_t)count);
 }
@@ -474,7 +488,9 @@ extern "C" int gsa_project_fwd(int n, const float *means, const float *quats, co
     GSA_RETURN_IF(sh_degree < -1 || sh_degree > 3, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_degree >= 0 && sh_coeffs < (sh_degree + 1) * (sh_degree + 1), GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(cull_mode != 0 && cull_mode != 1, GSA_ERR_INVALID_ARGUMENT);
-    GSA_RETURN_IF((reinterpret_cast<uintptr_t>(tile_rects) & 7) != 0, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF((reinterpret_cast<uintptr_t>(tile_rects) & 7) != 0 || (reinterpret_cast<uintptr_t>(radii) & 7) != 0 ||
+                      (reinterpret_cast<uintptr_t>(splat) & 15) != 0,
+                  GSA_ERR_INVALID_ARGUMENT);
     if (n == 0) return GSA_OK;
     GSA_RETURN_IF(!means || !quats || !scales || !opacities || !colors || !viewmat || !intrin || !splat || !radii ||
                       !tiles_touched || !depth_keys,
