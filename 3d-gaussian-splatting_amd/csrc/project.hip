@@ -574,7 +574,9 @@ __global__ __launch_bounds__(256) void sh_grad_expand_kernel(int n, const float 
                                                              int n_views, const float *__restrict__ viewmats,
                                                              const float *__restrict__ intrin,
                                                              const float *__restrict__ v_rgb, float *__restrict__ v_colors,
-                                                             int accumulate) {
+                                                             int accumulate, float *__restrict__ v_rest) {
+    // v_rest (optional): split output -- v_colors is then the [N,1,3] gradient of the DC coefficient and v_rest the
+    // [N, sh_coeffs - 1, 3] gradient of the others (the reference model keeps them as two parameters)
     constexpr int NB = (DEG + 1) * (DEG + 1);
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -593,6 +595,14 @@ __global__ __launch_bounds__(256) void sh_grad_expand_kernel(int n, const float 
         gsa_sh_basis<DEG>(dx * inv, dy * inv, dz * inv, B);
 #pragma unroll
         for (int k = 0; k < NB; ++k) { acc[3 * k] += B[k] * r; acc[3 * k + 1] += B[k] * g; acc[3 * k + 2] += B[k] * b; }
+    }
+    if (v_rest) {
+        float *dc = v_colors + i * 3, *rest = v_rest + i * (long)(sh_coeffs - 1) * 3;
+        dc[0] = acc[0]; dc[1] = acc[1]; dc[2] = acc[2];
+#pragma unroll
+        for (int k = 3; k < NB * 3; ++k) rest[k - 3] = acc[k];
+        for (int k = NB * 3; k < sh_coeffs * 3; ++k) rest[k - 3] = 0.f;
+        return;
     }
     float *row = v_colors + i * (long)sh_coeffs * 3;
     if (accumulate) {
@@ -619,9 +629,9 @@ extern "C" int gsa_project_bwd_factored(int n, const float *means, const float *
                             radii, v_splat, v_means, v_quats, v_scales, v_opacities, nullptr, accumulate, v_rgb, stream);
 }
 
-extern "C" int gsa_sh_grad_expand(int n, const float *means, int sh_degree, int sh_coeffs, int n_views,
-                                  const float *viewmats, const float *intrin, const float *v_rgb, float *v_colors,
-                                  int accumulate, gsa_stream_t stream) {
+static int sh_grad_expand_impl(int n, const float *means, int sh_degree, int sh_coeffs, int n_views,
+                               const float *viewmats, const float *intrin, const float *v_rgb, float *v_colors,
+                               int accumulate, float *v_rest, gsa_stream_t stream) {
     GSA_RETURN_IF(n < 0 || n_views < 1 || sh_degree < 0 || sh_degree > 3, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_coeffs < (sh_degree + 1) * (sh_degree + 1), GSA_ERR_INVALID_ARGUMENT);
     if (n == 0) return GSA_OK;
@@ -630,7 +640,7 @@ extern "C" int gsa_sh_grad_expand(int n, const float *means, int sh_degree, int 
     const int grid = gsa_div_up(n, 256);
 #define GSA_EXP(D)                                                                                                \
     sh_grad_expand_kernel<D><<<grid, 256, 0, s>>>(n, means, sh_coeffs, n_views, viewmats, intrin, v_rgb, v_colors, \
-                                                  accumulate ? 1 : 0);                                            \
+                                                  accumulate ? 1 : 0, v_rest);                                    \
     break
     switch (sh_degree) {
         case 0: GSA_EXP(0);
@@ -641,4 +651,18 @@ extern "C" int gsa_sh_grad_expand(int n, const float *means, int sh_degree, int 
 #undef GSA_EXP
     GSA_LAUNCH_CHECK();
     return GSA_OK;
+}
+
+extern "C" int gsa_sh_grad_expand(int n, const float *means, int sh_degree, int sh_coeffs, int n_views,
+                                  const float *viewmats, const float *intrin, const float *v_rgb, float *v_colors,
+                                  int accumulate, gsa_stream_t stream) {
+    return sh_grad_expand_impl(n, means, sh_degree, sh_coeffs, n_views, viewmats, intrin, v_rgb, v_colors, accumulate,
+                               nullptr, stream);
+}
+
+extern "C" int gsa_sh_grad_expand_split(int n, const float *means, int sh_degree, int sh_coeffs, int n_views,
+                                        const float *viewmats, const float *intrin, const float *v_rgb, float *v_dc,
+                                        float *v_rest, gsa_stream_t stream) {
+    GSA_RETURN_IF(n > 0 && (!v_rest || sh_coeffs < 2), GSA_ERR_INVALID_ARGUMENT);
+    return sh_grad_expand_impl(n, means, sh_degree, sh_coeffs, n_views, viewmats, intrin, v_rgb, v_dc, 0, v_rest, stream);
 }

@@ -266,6 +266,89 @@ __global__ __launch_bounds__(kThreads) void densify_gather_kernel(
     }
 }
 
+// ---- activations of the raw parameters and their derivatives -------------------
+// The reference activates per render (gaussian_model.py:86-108 via trainer.py:399-406): scales = exp(scaling),
+// quats = normalize(rotation), opacities = sigmoid(opacity), shs = cat(features_dc, features_rest).  In torch that is
+// five kernels forward and a dozen backward per step; here one each way.
+
+// thread q < 12 n: one float4 of the [N,16,3] SH table (48 floats per gaussian, so a float4 never straddles two
+// gaussians); thread i < n additionally the geometry of gaussian i
+__global__ __launch_bounds__(kThreads) void activate_fwd_kernel(long n, const float *__restrict__ scaling,
+                                                                const float *__restrict__ rotation,
+                                                                const float *__restrict__ opacity,
+                                                                const float *__restrict__ f_dc,
+                                                                const float *__restrict__ f_rest,
+                                                                float *__restrict__ scales, float *__restrict__ quats,
+                                                                float *__restrict__ opac, float *__restrict__ shs) {
+    const long q = (long)blockIdx.x * kThreads + threadIdx.x;
+    if (q < 12 * n) {
+        const long g = q / 12;
+        const int j0 = (int)(q - g * 12) * 4;
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u;
+            v[u] = j < 3 ? f_dc[g * 3 + j] : f_rest[g * 45 + (j - 3)];
+        }
+        reinterpret_cast<float4 *>(shs)[q] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    if (q < n) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) scales[q * 3 + k] = expf(scaling[q * 3 + k]);
+        // (scalar loads: the rotation segment of the flat bucket starts at float 55 n -- 16-B aligned only if 4 | n)
+        const float4 r = make_float4(rotation[q * 4], rotation[q * 4 + 1], rotation[q * 4 + 2], rotation[q * 4 + 3]);
+        const float inv = 1.0f / fmaxf(sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w), 1e-12f);   // F.normalize's eps
+        *reinterpret_cast<float4 *>(quats + q * 4) = make_float4(r.x * inv, r.y * inv, r.z * inv, r.w * inv);
+        opac[q] = 1.0f / (1.0f + expf(-opacity[q]));
+    }
+}
+
+// raw-parameter gradients from the activated ones, plus the scale-ratio regulariser (trainer.py:434-445):
+//   reg = weight * mean(max(ratio, max_ratio) - max_ratio),  ratio = max(scales) / max(min(scales), 1e-8)
+// Its hinge sum goes to reg_partials[block] (double); its gradient is added when add_reg_grad (rank 0 only in the
+// view-parallel step).  Ties of the max / min share the gradient evenly, as torch's amax / amin do.
+__global__ __launch_bounds__(kThreads) void activate_bwd_kernel(long n, const float *__restrict__ scaling,
+                                                                const float *__restrict__ rotation,
+                                                                const float *__restrict__ opacity,
+                                                                const float *__restrict__ v_scales,
+                                                                const float *__restrict__ v_quats,
+                                                                const float *__restrict__ v_opac, float max_ratio,
+                                                                float reg_scale, int add_reg_grad,
+                                                                float *__restrict__ v_scaling, float *__restrict__ v_rotation,
+                                                                float *__restrict__ v_opacity, double *__restrict__ reg_partials) {
+    const long i = (long)blockIdx.x * kThreads + threadIdx.x;
+    double hinge = 0.0;
+    if (i < n) {
+        float s[3], gs[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { s[k] = expf(scaling[i * 3 + k]); gs[k] = v_scales[i * 3 + k]; }
+        const float smax = fmaxf(s[0], fmaxf(s[1], s[2])), smin = fminf(s[0], fminf(s[1], s[2]));
+        const float smin_c = fmaxf(smin, 1e-8f);
+        const float ratio = smax / smin_c;
+        hinge = (double)(fmaxf(ratio, max_ratio) - max_ratio);
+        if (add_reg_grad && ratio >= max_ratio) {   // clamp(min=) passes the gradient at equality, like torch
+            const float n_max = (float)((s[0] == smax) + (s[1] == smax) + (s[2] == smax));
+            const float n_min = (float)((s[0] == smin) + (s[1] == smin) + (s[2] == smin));
+            const float d_max = reg_scale / smin_c / n_max;
+            const float d_min = smin >= 1e-8f ? -reg_scale * smax / (smin_c * smin_c) / n_min : 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gs[k] += (s[k] == smax ? d_max : 0.f) + (s[k] == smin ? d_min : 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v_scaling[i * 3 + k] = gs[k] * s[k];
+        const float4 r = make_float4(rotation[i * 4], rotation[i * 4 + 1], rotation[i * 4 + 2], rotation[i * 4 + 3]);
+        const float4 g = *reinterpret_cast<const float4 *>(v_quats + i * 4);
+        const float inv = 1.0f / fmaxf(sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w), 1e-12f);
+        const float qx = r.x * inv, qy = r.y * inv, qz = r.z * inv, qw = r.w * inv;
+        const float dot = g.x * qx + g.y * qy + g.z * qz + g.w * qw;
+        v_rotation[i * 4] = (g.x - dot * qx) * inv; v_rotation[i * 4 + 1] = (g.y - dot * qy) * inv;
+        v_rotation[i * 4 + 2] = (g.z - dot * qz) * inv; v_rotation[i * 4 + 3] = (g.w - dot * qw) * inv;
+        const float o = 1.0f / (1.0f + expf(-opacity[i]));
+        v_opacity[i] = v_opac[i] * (o * (1.0f - o));
+    }
+    block_add3(hinge, 0.0, 0.0, reg_partials);   // -> reg_partials[3 * block] (the other two words stay zero)
+}
+
 }  // namespace
 
 extern "C" int gsa_densify_gather(long long n_old, long long n_new, int n_fields, const int *field_width, int xyz_field,
@@ -357,6 +440,44 @@ extern "C" int gsa_adam_step(long long n, float *param, const float *grad, float
                                                                         (float)(1.0 - beta1), (float)beta2,
                                                                         (float)(1.0 - beta2), (float)eps,
                                                                         (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+    GSA_LAUNCH_CHECK();
+    return GSA_OK;
+}
+
+extern "C" size_t gsa_activate_partials(long long n) {   // doubles gsa_activate_bwd's reg_partials must hold
+    return n <= 0 ? 0 : 3 * (size_t)gsa_div_up(n, kThreads);
+}
+
+extern "C" int gsa_activate_fwd(long long n, const float *scaling, const float *rotation, const float *opacity,
+                                const float *features_dc, const float *features_rest, float *scales, float *quats,
+                                float *opacities, float *shs, gsa_stream_t stream) {
+    GSA_RETURN_IF(n < 0, GSA_ERR_INVALID_ARGUMENT);
+    if (n == 0) return GSA_OK;
+    GSA_RETURN_IF(!scaling || !rotation || !opacity || !features_dc || !features_rest || !scales || !quats ||
+                      !opacities || !shs,
+                  GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(((reinterpret_cast<uintptr_t>(quats) | reinterpret_cast<uintptr_t>(shs)) & 15) != 0,
+                  GSA_ERR_INVALID_ARGUMENT);
+    activate_fwd_kernel<<<gsa_div_up(12 * n, kThreads), kThreads, 0, static_cast<hipStream_t>(stream)>>>(
+        (long)n, scaling, rotation, opacity, features_dc, features_rest, scales, quats, opacities, shs);
+    GSA_LAUNCH_CHECK();
+    return GSA_OK;
+}
+
+extern "C" int gsa_activate_bwd(long long n, const float *scaling, const float *rotation, const float *opacity,
+                                const float *v_scales, const float *v_quats, const float *v_opacities,
+                                float reg_max_ratio, float reg_weight, int add_reg_grad, float *v_scaling,
+                                float *v_rotation, float *v_opacity, double *reg_partials, gsa_stream_t stream) {
+    GSA_RETURN_IF(n < 0, GSA_ERR_INVALID_ARGUMENT);
+    if (n == 0) return GSA_OK;
+    GSA_RETURN_IF(!scaling || !rotation || !opacity || !v_scales || !v_quats || !v_opacities || !v_scaling ||
+                      !v_rotation || !v_opacity || !reg_partials,
+                  GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF((reinterpret_cast<uintptr_t>(v_quats) & 15) != 0, GSA_ERR_INVALID_ARGUMENT);
+    // d reg / d ratio of one gaussian: weight / n  (the mean)
+    activate_bwd_kernel<<<gsa_div_up(n, kThreads), kThreads, 0, static_cast<hipStream_t>(stream)>>>(
+        (long)n, scaling, rotation, opacity, v_scales, v_quats, v_opacities, reg_max_ratio,
+        (float)((double)reg_weight / (double)n), add_reg_grad ? 1 : 0, v_scaling, v_rotation, v_opacity, reg_partials);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }

@@ -306,8 +306,9 @@ class ViewParallelTrainer:
         self.fused = bool(fused)
         if self.fused and not model.flat.is_cuda:
             raise RuntimeError("ViewParallelTrainer(fused=True) needs the model on a HIP device (no CPU path)")
-        # fused, world > 1: exchange the SH-coefficient gradient in factored form (see _training_step_fused)
-        self.factored = (self.fused and world_size > 1) if factored_exchange is None else bool(factored_exchange)
+        # fused: the SH-coefficient gradient is kept (and, for world > 1, exchanged) in factored form
+        # (see _training_step_fused)
+        self.factored = self.fused if factored_exchange is None else bool(factored_exchange)
         if self.factored and not self.fused:
             raise ValueError("factored_exchange needs fused=True (it is a property of the HIP backward pass)")
         groups = _adam_groups(model, self.cfg)
@@ -386,11 +387,13 @@ class ViewParallelTrainer:
         activation derivatives are applied once, writing the raw-parameter gradients into ``flat_grad``.
         One host read-back, at the end (the metrics).
 
-        world > 1 (``factored``): 48 of the 59 gradient floats per gaussian are the SH-coefficient gradient, and per
-        view that is the outer product SH-basis(view direction) x d loss / d rgb.  Every rank holds the whole batch's
-        poses, so the ranks all-gather 3 N floats per view, all-reduce only the 11 N geometry floats, and each
-        rebuilds the coefficient gradient of the whole batch itself (``gsa_sh_grad_expand``; summed in batch order, so
-        bit-identical on every rank) -- instead of all-reducing 59 N floats."""
+        ``factored`` (default): 48 of the 59 gradient floats per gaussian are the SH-coefficient gradient, and per view
+        that is the outer product SH-basis(view direction) x d loss / d rgb.  The backward passes therefore leave only
+        those 3 floats per gaussian and view, and ONE kernel rebuilds the coefficient gradient of the whole batch
+        (``gsa_sh_grad_expand``) -- no 48-float read-modify-write per view.  world > 1: every rank holds the whole
+        batch's poses, so the ranks all-gather the 3 N floats per view, all-reduce only the 11 N geometry floats, and
+        each rebuilds the coefficient gradient itself (summed in batch order, so bit-identical on every rank) --
+        instead of all-reducing 59 N floats."""
         from . import stages as S
         from .rasterization import rasterization
         m, c = self.model, self.cfg
@@ -399,12 +402,8 @@ class ViewParallelTrainer:
         n, n_views = m.n, len(batch)
         K = self.backend.K.to(dev)[None]
         bg = torch.zeros(1, 3, device=dev)
-        with torch.no_grad():
-            scales = torch.exp(m.scaling)
-            rot_norm = m.rotation.norm(dim=-1, keepdim=True).clamp_min(1e-12)     # F.normalize's eps
-            quats = m.rotation / rot_norm
-            opac = torch.sigmoid(m.opacity)
-            shs = torch.cat([m.features_dc, m.features_rest], dim=1)
+        # activations (trainer.py:399-406), once, without a graph: one kernel
+        scales, quats, opac, shs = S.activate_fwd(m.scaling, m.rotation, m.opacity, m.features_dc, m.features_rest)
         # gradient bucket of the ACTIVATED parameters; the xyz part IS the raw xyz gradient (identity activation)
         if getattr(self, "_act_grad", None) is None or self._act_grad[1].shape[0] != n:
             self._act_grad = (None, torch.empty(n, 4, device=dev), torch.empty(n, 3, device=dev),
@@ -412,8 +411,8 @@ class ViewParallelTrainer:
         g_means = m.xyz.grad
         _, g_quats, g_scales, g_opac, g_shs = self._act_grad
         grad_out = [g_means, g_quats, g_scales, g_opac, g_shs]
-        leaves = [t.detach().requires_grad_(True) for t in (m.xyz, quats, scales, opac[:, 0], shs)]
-        factored = self.factored and self.world > 1
+        leaves = [t.requires_grad_(True) for t in (m.xyz.detach(), quats, scales, opac, shs)]
+        factored = self.factored
         if factored:  # slot (r, j) = the j-th view of rank r; ranks with fewer views leave zeros (skipped by the expand)
             slots = -(-n_views // self.world)
             vr_all = torch.zeros(self.world, slots, n, 3, device=dev)
@@ -431,39 +430,39 @@ class ViewParallelTrainer:
             r.backward(v[None])
             sums.append(s3 / float(v.numel()))            # -> l1, ssim, mse of this view
             first = False
-        with torch.no_grad():
-            if first:                                      # this rank rendered nothing
-                m.flat_grad.zero_()
-            else:                                          # chain rule of the activations, once (trainer.py:399-406)
-                m.scaling.grad.copy_(g_scales * scales)
-                dot = (g_quats * quats).sum(dim=-1, keepdim=True)
-                m.rotation.grad.copy_((g_quats - dot * quats) / rot_norm)
-                m.opacity.grad.copy_((g_opac * (opac[:, 0] * (1.0 - opac[:, 0])))[:, None])
-                if not factored:
-                    m.features_dc.grad.copy_(g_shs[:, :1])
-                    m.features_rest.grad.copy_(g_shs[:, 1:])
-        reg = scale_ratio_reg(torch.exp(m.scaling), c.scale_reg_max_ratio, c.scale_reg_weight)
-        if self.rank == 0:
-            reg.backward()                                 # adds into scaling.grad (a view of flat_grad)
+        if first:                                          # this rank rendered nothing
+            m.flat_grad.zero_()
+            for g in (g_quats, g_scales, g_opac):
+                g.zero_()
+        # chain rule of the activations + the scale regulariser (value everywhere, gradient on rank 0), one kernel,
+        # written straight into the raw-parameter gradient views of flat_grad
+        reg = S.activate_bwd(m.scaling, m.rotation, m.opacity, g_scales, g_quats, g_opac, m.scaling.grad, m.rotation.grad,
+                             m.opacity.grad, c.scale_reg_max_ratio, c.scale_reg_weight, add_reg_grad=self.rank == 0)
         if factored:
-            # the exchange: 3 N floats per view gathered, 11 N floats summed (xyz | opacity, scaling, rotation are the
-            # two ends of the bucket), the SH-coefficient gradient of the whole batch rebuilt locally
-            # (gathered first, so that the local rebuild runs beside the two all-reduces)
-            gathered = self._all_gather_slabs(vr_all)
-            summed = [self._all_reduce(m.flat_grad[:3 * n], async_op=True),
-                      self._all_reduce(m.flat_grad[51 * n:], async_op=True)]
-            gathered.wait()
-            S.sh_grad_expand(leaves[0].detach(), degree, poses_all.view(-1, 4, 4), K, vr_all.view(-1, n, 3), g_shs)
-            with torch.no_grad():
-                m.features_dc.grad.copy_(g_shs[:, :1])
-                m.features_rest.grad.copy_(g_shs[:, 1:])
+            # the SH-coefficient gradient of the whole batch, rebuilt from the 3 floats per gaussian and view the
+            # backward passes left (summed in batch order), straight into features_dc.grad / features_rest.grad.
+            # world > 1: those 3 N floats per view are all-gathered and only the 11 N geometry floats are summed (xyz |
+            # opacity, scaling, rotation are the two ends of the bucket); the rebuild runs beside the all-reduces.
+            summed = []
+            if self.world > 1:
+                gathered = self._all_gather_slabs(vr_all)
+                summed = [self._all_reduce(m.flat_grad[:3 * n], async_op=True),
+                          self._all_reduce(m.flat_grad[51 * n:], async_op=True)]
+                gathered.wait()
+            S.sh_grad_expand(leaves[0].detach(), degree, poses_all.view(-1, 4, 4), K, vr_all.view(-1, n, 3),
+                             m.features_dc.grad, v_rest=m.features_rest.grad)
             for work in summed:
                 work.wait()
         else:
+            with torch.no_grad():
+                if first:
+                    g_shs.zero_()
+                m.features_dc.grad.copy_(g_shs[:, :1])
+                m.features_rest.grad.copy_(g_shs[:, 1:])
             self._all_reduce(m.flat_grad)  # the one exchange step: 59*N floats, SUM
         self.optimizer.step()
 
-        report = torch.zeros(4, dtype=torch.float64, device=dev)  # l1, ssim, psnr sums over local views; loss share
+        report = torch.zeros(5, dtype=torch.float64, device=dev)  # l1, ssim, psnr sums over local views; loss share; reg
         if sums:
             per_view = torch.stack(sums)                           # [B_local, 3]
             mse = per_view[:, 2]
@@ -471,9 +470,9 @@ class ViewParallelTrainer:
             loss_v = (1.0 - c.lambda_dssim) * per_view[:, 0] + c.lambda_dssim * (1.0 - per_view[:, 1])
             report[0], report[1], report[2] = per_view[:, 0].sum(), per_view[:, 1].sum(), psnr_v.sum()
             report[3] = loss_v.sum() / n_views
-        if self.rank == 0:
+        if self.rank == 0:                                         # (the regulariser is the same on every rank)
             report[3] += reg.detach().double()
+            report[4] = reg.detach().double()
         self._all_reduce(report)
-        r = report.tolist()
-        return {"loss": r[3], "l1": r[0] / n_views, "ssim": r[1] / n_views, "psnr": r[2] / n_views,
-                "scale_reg": float(reg.detach())}
+        r = report.tolist()                                        # the step's one host read-back
+        return {"loss": r[3], "l1": r[0] / n_views, "ssim": r[1] / n_views, "psnr": r[2] / n_views, "scale_reg": r[4]}

@@ -414,13 +414,55 @@ def densify_gather(n_old: int, field_width, xyz_field: int, scaling_field: int, 
     return new_p, new_m, new_v
 
 
-def sh_grad_expand(means, sh_degree: int, viewmats, Kmat, v_rgb_all, v_colors, accumulate: bool = False) -> None:
+def sh_grad_expand(means, sh_degree: int, viewmats, Kmat, v_rgb_all, v_colors, accumulate: bool = False,
+                   v_rest=None) -> None:
     """v_colors [N,K,3] (+)= sum over views of SH-basis(view) (x) v_rgb_all[view]  (v_rgb_all: [V,N,3]; viewmats [V,4,4]).
-    Rebuilds the SH-coefficient gradient from the factored form ``project_bwd(v_rgb_out=...)`` leaves."""
+    Rebuilds the SH-coefficient gradient from the factored form ``project_bwd(v_rgb_out=...)`` leaves.
+    With ``v_rest`` [N,K-1,3] the output is split the way the reference model stores the coefficients: ``v_colors``
+    [N,1,3] receives the DC part (both overwritten)."""
     N = means.shape[0]
     V = viewmats.shape[0]
     if v_rgb_all.shape != (V, N, 3) or not v_rgb_all.is_contiguous() or not v_colors.is_contiguous():
         raise ValueError("sh_grad_expand: v_rgb_all must be contiguous [V,N,3], v_colors contiguous [N,K,3]")
+    if v_rest is not None:
+        if accumulate or not v_rest.is_contiguous() or v_colors.shape[1] != 1:
+            raise ValueError("sh_grad_expand(v_rest=...): overwrite only; v_colors [N,1,3], v_rest [N,K-1,3] contiguous")
+        _call("gsa_sh_grad_expand", lib.gsa_sh_grad_expand_split, N, _ptr(f32c(means, "means")), sh_degree,
+              v_rest.shape[1] + 1, V, _ptr(f32c(viewmats, "viewmats")), _ptr(f32c(Kmat, "Ks")), _ptr(v_rgb_all),
+              _ptr(v_colors), _ptr(v_rest), _stream())
+        return
     _call("gsa_sh_grad_expand", lib.gsa_sh_grad_expand, N, _ptr(f32c(means, "means")), sh_degree, v_colors.shape[1], V,
           _ptr(f32c(viewmats, "viewmats")), _ptr(f32c(Kmat, "Ks")), _ptr(v_rgb_all), _ptr(v_colors),
           1 if accumulate else 0, _stream())
+
+
+def activate_fwd(scaling, rotation, opacity, features_dc, features_rest):
+    """Raw parameters of the reference model -> (scales [N,3], quats [N,4], opacities [N], shs [N,16,3]) in one pass
+    (gaussian_model.py:86-108)."""
+    n, dev = scaling.shape[0], scaling.device
+    if features_dc.shape[1:] != (1, 3) or features_rest.shape[1:] != (15, 3):
+        raise ValueError("activate_fwd: features_dc [N,1,3] and features_rest [N,15,3] expected")
+    scales = torch.empty(n, 3, device=dev)
+    quats = torch.empty(n, 4, device=dev)
+    opac = torch.empty(n, device=dev)
+    shs = torch.empty(n, 16, 3, device=dev)
+    _call("gsa_activate_fwd", lib.gsa_activate_fwd, n, _ptr(f32c(scaling, "scaling")), _ptr(f32c(rotation, "rotation")),
+          _ptr(f32c(opacity, "opacity")), _ptr(f32c(features_dc, "features_dc")), _ptr(f32c(features_rest, "features_rest")),
+          _ptr(scales), _ptr(quats), _ptr(opac), _ptr(shs), _stream())
+    return scales, quats, opac, shs
+
+
+def activate_bwd(scaling, rotation, opacity, v_scales, v_quats, v_opac, out_scaling, out_rotation, out_opacity,
+                 reg_max_ratio: float, reg_weight: float, add_reg_grad: bool) -> torch.Tensor:
+    """Chain rule of ``activate_fwd`` into the raw-parameter gradient buffers (overwritten) + the scale-ratio
+    regulariser (trainer.py:434-445): its gradient is added when ``add_reg_grad``; returns its value (0-d, fp64)."""
+    n = scaling.shape[0]
+    for t, name in ((out_scaling, "out_scaling"), (out_rotation, "out_rotation"), (out_opacity, "out_opacity")):
+        if not (t.is_contiguous() and t.dtype == torch.float32):
+            raise ValueError(f"activate_bwd: `{name}` must be a contiguous fp32 buffer")
+    partials = torch.empty(lib.gsa_activate_partials(n), dtype=torch.float64, device=scaling.device)
+    _call("gsa_activate_bwd", lib.gsa_activate_bwd, n, _ptr(f32c(scaling, "scaling")), _ptr(f32c(rotation, "rotation")),
+          _ptr(f32c(opacity, "opacity")), _ptr(f32c(v_scales, "v_scales")), _ptr(f32c(v_quats, "v_quats")),
+          _ptr(f32c(v_opac, "v_opacities")), float(reg_max_ratio), float(reg_weight), 1 if add_reg_grad else 0,
+          _ptr(out_scaling), _ptr(out_rotation), _ptr(out_opacity), _ptr(partials), _stream())
+    return partials.sum() * (float(reg_weight) / max(n, 1))

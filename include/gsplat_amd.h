@@ -214,6 +214,12 @@ int gsa_sh_grad_expand(int n, const float *means, int sh_degree, int sh_coeffs, 
                        const float *viewmats, const float *intrin, const float *v_rgb, float *v_colors,
                        int accumulate, gsa_stream_t stream);
 
+/* gsa_sh_grad_expand with the output split the way the reference model stores the coefficients: v_dc [N,1,3] and
+ * v_rest [N, sh_coeffs - 1, 3] (both overwritten). */
+int gsa_sh_grad_expand_split(int n, const float *means, int sh_degree, int sh_coeffs, int n_views,
+                             const float *viewmats, const float *intrin, const float *v_rgb, float *v_dc,
+                             float *v_rest, gsa_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Training-step stages around the rasterizer.
  *
@@ -248,6 +254,26 @@ int gsa_view_loss(int width, int height, const float *render, const float *targe
 int gsa_adam_step(long long n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                   int n_segments, const long long *segment_end, const float *segment_lr, double beta1,
                   double beta2, double eps, int step, gsa_stream_t stream);
+
+/* Activations of the reference model's raw parameters (src/gaussians/gaussian_model.py:86-108 as the trainer calls them,
+ * trainer.py:399-406) in one pass: scales = exp(scaling) [N,3], quats = rotation / max(|rotation|, 1e-12) [N,4],
+ * opacities = sigmoid(opacity) [N], shs = cat(features_dc [N,1,3], features_rest [N,15,3]) [N,16,3].
+ * quats and shs must be 16-byte aligned. */
+int gsa_activate_fwd(long long n, const float *scaling, const float *rotation, const float *opacity,
+                     const float *features_dc, const float *features_rest, float *scales, float *quats,
+                     float *opacities, float *shs, gsa_stream_t stream);
+
+/* The derivatives of those activations applied to the gradients of the activated parameters (v_scales [N,3],
+ * v_quats [N,4], v_opacities [N]) -> v_scaling [N,3], v_rotation [N,4], v_opacity [N] (overwritten), together with
+ * the scale-ratio regulariser of trainer.py:434-445,
+ *   reg = reg_weight * mean(max(ratio, reg_max_ratio) - reg_max_ratio),  ratio = max(scales) / max(min(scales), 1e-8):
+ * its gradient is added to v_scaling when add_reg_grad != 0, and the per-block sums of the hinge term are written to
+ * reg_partials[gsa_activate_partials(n)] (doubles; reg = reg_weight * sum(reg_partials) / n). */
+size_t gsa_activate_partials(long long n);
+int gsa_activate_bwd(long long n, const float *scaling, const float *rotation, const float *opacity,
+                     const float *v_scales, const float *v_quats, const float *v_opacities, float reg_max_ratio,
+                     float reg_weight, int add_reg_grad, float *v_scaling, float *v_rotation, float *v_opacity,
+                     double *reg_partials, gsa_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -175,6 +175,50 @@ def test_fused_training_step_matches_reference_trainer(gold):
     _check_against_golden(gold, model, trainer, batch, tol_metric=2e-5, tol_grad=2e-3, tol_param=2e-4)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1000, 4099])
+def test_activation_kernels_match_torch_autograd(n):
+    """gsa_activate_fwd / gsa_activate_bwd vs the torch formulation of the reference's activations and scale-ratio
+    regulariser (gaussian_model.py:86-108, trainer.py:434-445) differentiated by autograd in fp64: values, the three
+    raw-parameter gradients with and without the regulariser's share, and its value.  Covers tied largest / smallest
+    scales (gradient shared evenly), scales below the 1e-8 floor, ratios on both sides of the hinge, and a bucket
+    whose rotation segment is not 16-byte aligned (odd n)."""
+    import torch.nn.functional as F
+    from gsplat_amd import stages as S
+    from gsplat_amd.harness import SplatModel, scale_ratio_reg
+    g = torch.Generator().manual_seed(n)
+    model = SplatModel(n, device="cuda")
+    with torch.no_grad():
+        model.scaling.copy_((torch.rand(n, 3, generator=g) * 6 - 5).cuda())
+        model.scaling[:50, 1] = model.scaling[:50, 0]                     # tied pairs
+        model.scaling[50:80] = model.scaling[50:80, :1]                   # all three equal: ratio 1
+        model.scaling[80:100, 2] = -21.0                                  # exp() below the 1e-8 floor
+        model.rotation.copy_(torch.randn(n, 4, generator=g).cuda())
+        model.opacity.copy_((torch.randn(n, 1, generator=g) * 3).cuda())
+        model.features_dc.copy_(torch.randn(n, 1, 3, generator=g).cuda())
+        model.features_rest.copy_(torch.randn(n, 15, 3, generator=g).cuda())
+    scales, quats, opac, shs = S.activate_fwd(model.scaling, model.rotation, model.opacity, model.features_dc,
+                                              model.features_rest)
+    assert torch.allclose(scales, torch.exp(model.scaling.detach()), rtol=2e-6, atol=0)
+    assert torch.allclose(quats, F.normalize(model.rotation.detach(), dim=-1), rtol=0, atol=2e-7)
+    assert torch.allclose(opac, torch.sigmoid(model.opacity.detach())[:, 0], rtol=0, atol=2e-7)
+    assert torch.equal(shs, torch.cat([model.features_dc, model.features_rest], dim=1).detach())
+    gs, gq, go = (torch.randn(n, k, generator=g).cuda() for k in (3, 4, 1))
+    max_ratio, weight = 10.0, 0.1
+    for with_reg in (True, False):
+        raw = [t.detach().double().requires_grad_(True) for t in (model.scaling, model.rotation, model.opacity)]
+        sc = torch.exp(raw[0])
+        reg = scale_ratio_reg(sc, max_ratio, weight)
+        total = (sc * gs).sum() + (F.normalize(raw[1], dim=-1) * gq).sum() + (torch.sigmoid(raw[2]) * go).sum()
+        (total + reg if with_reg else total).backward()
+        out = [torch.full_like(t, float("nan")) for t in (model.scaling, model.rotation, model.opacity)]
+        val = S.activate_bwd(model.scaling, model.rotation, model.opacity, gs, gq, go[:, 0].contiguous(), out[0], out[1],
+                             out[2], max_ratio, weight, add_reg_grad=with_reg)
+        assert abs(float(val) - float(reg)) <= 1e-6 * max(1.0, abs(float(reg)))
+        for name, a, b in zip(("scaling", "rotation", "opacity"), out, raw):
+            assert _rel(a.double().cpu().numpy(), b.grad.cpu().numpy()) < 2e-6, (with_reg, name)
+
+
 def _fused_rank_main(rank, world, port, factored):
     """One rank of the fused HIP trainer; the ranks share the box's one GPU and talk over gloo (the collectives'
     call pattern is the RCCL one; tests/ never launches more ranks on the card than this)."""
