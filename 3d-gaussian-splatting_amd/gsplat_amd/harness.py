@@ -298,12 +298,13 @@ class ViewParallelTrainer:
 
     def __init__(self, model: SplatModel, backend, config: Optional[StepConfig] = None,
                  process_group=None, rank: int = 0, world_size: int = 1, fused: bool = False,
-                 factored_exchange: Optional[bool] = None):
+                 factored_exchange: Optional[bool] = None, overlap_views: bool = True):
         self.model, self.backend = model, backend
         self.cfg = config or StepConfig()
         self.group, self.rank, self.world = process_group, rank, world_size
         self.iteration = 0
         self.fused = bool(fused)
+        self.overlap_views = bool(overlap_views)   # fused step: next view's front end on a side stream
         if self.fused and not model.flat.is_cuda:
             raise RuntimeError("ViewParallelTrainer(fused=True) needs the model on a HIP device (no CPU path)")
         # fused: the SH-coefficient gradient is kept (and, for world > 1, exchanged) in factored form
@@ -395,7 +396,6 @@ class ViewParallelTrainer:
         each rebuilds the coefficient gradient itself (summed in batch order, so bit-identical on every rank) --
         instead of all-reducing 59 N floats."""
         from . import stages as S
-        from .rasterization import rasterization
         m, c = self.model, self.cfg
         degree = self.active_sh_degree()
         dev = m.flat.device
@@ -411,7 +411,7 @@ class ViewParallelTrainer:
         g_means = m.xyz.grad
         _, g_quats, g_scales, g_opac, g_shs = self._act_grad
         grad_out = [g_means, g_quats, g_scales, g_opac, g_shs]
-        leaves = [t.requires_grad_(True) for t in (m.xyz.detach(), quats, scales, opac, shs)]
+        leaves = [m.xyz.detach(), quats, scales, opac, shs]
         factored = self.factored
         if factored:  # slot (r, j) = the j-th view of rank r; ranks with fewer views leave zeros (skipped by the expand)
             slots = -(-n_views // self.world)
@@ -420,14 +420,54 @@ class ViewParallelTrainer:
             for r_ in range(self.world):
                 for j, view in enumerate(batch[r_::self.world]):
                     poses_all[r_, j] = view["pose"]
+        # The views of the batch are independent until their gradients meet in the bucket, and a view's front end
+        # (projection + binning: HBM- and latency-bound, ~25 short kernels) uses what its sweep (compositor forward,
+        # loss, compositor backward: VALU-bound) leaves idle.  So view j + 1's front end runs on a side stream while
+        # view j is swept on the main one.  No autograd here: the stages are called directly.
+        main = torch.cuda.current_stream()
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=dev)
+        side = self._side if self.overlap_views else main
+        cull = S.DEFAULT_CULL_MODE
+        Kc, bgc = K[0].contiguous(), bg[0].contiguous()
+        params_ready = torch.cuda.Event()
+        params_ready.record(main)
+
+        def front(view, exact=False):
+            with torch.cuda.stream(side):
+                side.wait_event(params_ready)
+                pose = view["pose"].to(torch.float32).contiguous()
+                W, H = view["width"], view["height"]
+                splat, radii, tiles, keys, rects = S.project_fwd(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4],
+                                                                 degree, pose, Kc, W, H, cull, return_rects=True)
+                bins = S.bin_tiles(splat, radii, tiles, keys, W, H, cull, tile_rects=rects, exact=exact)
+                order = S.tile_schedule(bins.tile_offsets, W, H)
+                done = torch.cuda.Event()
+                done.record(side)
+                if side is not main:   # the sweep reads these on the main stream: keep their memory until it has
+                    for t in (pose, splat, radii, bins.sorted_gid_buffer, bins.tile_offsets, order):
+                        t.record_stream(main)
+            return pose, splat, radii, bins, order, done
+
+        mine = list(batch[self.rank::self.world])
         sums, first = [], True
-        for j, view in enumerate(batch[self.rank::self.world]):
-            r, _, _ = rasterization(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], view["pose"][None], K,
-                                    view["width"], view["height"], sh_degree=degree, backgrounds=bg,
-                                    grad_out=grad_out, grad_accumulate=not first,
-                                    sh_grad_factored=vr_all[self.rank, j] if factored else None)
-            s3, v = S.view_loss(r[0].detach(), view["image"], c.lambda_dssim, grad_scale=1.0 / n_views)
-            r.backward(v[None])
+        ahead = front(mine[0]) if mine else None
+        for j, view in enumerate(mine):
+            pose, splat, radii, bins, order, done = ahead
+            if not bins.finalize()[1]:       # record capacity missed (the scene grew): bin again with exact sizes
+                pose, splat, radii, bins, order, done = front(view, exact=True)
+                bins.finalize()
+            ahead = front(mine[j + 1]) if j + 1 < len(mine) else None
+            main.wait_event(done)
+            W, H = view["width"], view["height"]
+            render, _, final_T, last_id = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bgc, W, H, 3,
+                                                          order)
+            s3, v = S.view_loss(render, view["image"], c.lambda_dssim, grad_scale=1.0 / n_views)
+            v_splat = S.composite_bwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bgc, final_T, last_id, v, None,
+                                      W, H, 3, order)
+            S.project_bwd(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], degree, pose, Kc, W, H, splat, radii,
+                          v_splat, out=grad_out, accumulate=not first,
+                          v_rgb_out=vr_all[self.rank, j] if factored else None)
             sums.append(s3 / float(v.numel()))            # -> l1, ssim, mse of this view
             first = False
         if first:                                          # this rank rendered nothing
