@@ -162,6 +162,9 @@ def main() -> None:
                                               height, sh_degree=deg, backgrounds=bg, cull_mode=args.cull_mode,
                                               grad_out=grad_views, sh_grad_factored=vr_mine if factored else None)
         r.backward(v_render)
+        if dist is not None and stages.TIMER.enabled:   # instrumented pass: time the whole exchange on the stream
+            x0 = torch.cuda.Event(enable_timing=True)
+            x0.record()
         if factored:
             # gather first, so the local rebuild of the SH gradient runs beside the geometry all-reduce
             if dist.get_backend() == "nccl":
@@ -174,6 +177,10 @@ def main() -> None:
             summed.wait()
         elif dist is not None:  # one all-reduce of the whole 59 N-float bucket (RCCL over xGMI)
             dist.all_reduce(flat_grad)
+        if dist is not None and stages.TIMER.enabled:
+            x1 = torch.cuda.Event(enable_timing=True)
+            x1.record()
+            stages.TIMER.records.append(("exchange", x0, x1))
         info["M"] = meta["n_isects"]
 
     def fence():
@@ -215,7 +222,8 @@ def main() -> None:
         # per C-ABI stage: average device time per step (binning = sorts + scan + emit + offsets)
         per = {}
         for name, (calls, total) in stage_ms.items():
-            key = name if name in alg else "binning"
+            key = name if name in alg or name == "exchange" else (
+                "sh_grad_rebuild" if name == "gsa_sh_grad_expand" else "binning")   # (exchange includes the rebuild)
             per[key] = per.get(key, 0.0) + total / args.steps
         # the dominant KERNEL: "binning" is a stage of ~24 short launches (sorts, scan, emit, offsets), the other
         # four stages are one kernel launch each
