@@ -164,13 +164,17 @@ def test_training_step_on_hip_backend_matches_reference_trainer(gold):
 
 
 @pytest.mark.gpu
-def test_fused_training_step_matches_reference_trainer(gold):
-    """The same two steps with the HIP rasterizer AND the fused HIP loss (gsa_view_loss) and Adam (gsa_adam_step)
-    kernels: still the reference trainer's metrics, gradients, parameters and Adam moments."""
+@pytest.mark.parametrize("overlap,factored", [(True, True), (False, True), (True, False)])
+def test_fused_training_step_matches_reference_trainer(gold, overlap, factored):
+    """The same two steps on HIP kernels end to end -- rasterizer stages called directly, activations
+    (gsa_activate_fwd / _bwd), loss (gsa_view_loss), SH-gradient rebuild (gsa_sh_grad_expand_split) and Adam
+    (gsa_adam_step): still the reference trainer's metrics, gradients, parameters and Adam moments.  With and without
+    the next view's front end on a side stream, and with the plain 48-float SH-gradient accumulation."""
     import gsplat_amd
     from gsplat_amd.harness import ViewParallelTrainer
     model, batch = _model_and_batch(gold, "cuda")
-    trainer = ViewParallelTrainer(model, gsplat_amd.HipBackend(_t(gold["K"], "cuda")), fused=True)
+    trainer = ViewParallelTrainer(model, gsplat_amd.HipBackend(_t(gold["K"], "cuda")), fused=True,
+                                  overlap_views=overlap, factored_exchange=factored)
     trainer.iteration = int(gold["step_iteration"])
     _check_against_golden(gold, model, trainer, batch, tol_metric=2e-5, tol_grad=2e-3, tol_param=2e-4)
 
