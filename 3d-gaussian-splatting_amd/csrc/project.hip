@@ -180,11 +180,14 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(
 template <int DEG, bool STAGE, bool FACTORED>
 __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
     int n, const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
-    const float *__restrict__ colors, int sh_coeffs, const float *__restrict__ viewmat,
-    const float *__restrict__ intrin, int width, int height, const float *__restrict__ splat,
+    const float *__restrict__ opacities, const float *__restrict__ colors, int sh_coeffs,
+    const float *__restrict__ viewmat, const float *__restrict__ intrin, int width, int height,
     const int32_t *__restrict__ radii, const float *__restrict__ v_splat, float *__restrict__ v_means,
     float *__restrict__ v_quats, float *__restrict__ v_scales, float *__restrict__ v_opacities,
     float *__restrict__ v_colors, int accumulate, float *__restrict__ v_rgb_out) {
+    // The forward's splat records are NOT read back (64 MB of lines at 1 M for 32 B of use each): the projection is
+    // recomputed from the raw parameters anyway, the opacity is an input, and the colour clamp mask is re-derived
+    // from the SH sum evaluated exactly as the forward evaluates it.
     // v_rgb_out (optional, [N,3]): FACTORED colour gradient -- instead of the [N,K,3] SH-coefficient gradient
     // (v_colors, then unused) write only d loss / d rgb after the clamp mask.  The SH gradient is the outer product of
     // the view's SH basis with it (gsa_sh_grad_expand), so 3 floats per gaussian carry what 48 would.
@@ -199,7 +202,8 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
     const bool active = i < n;
     float g_mean[3] = {0.f, 0.f, 0.f}, g_quat[4] = {1.f, 0.f, 0.f, 0.f}, g_scale[3] = {1.f, 1.f, 1.f};
     int g_rx = 0, g_ry = 0;
-    float4 g_v0 = make_float4(0.f, 0.f, 0.f, 0.f), g_v1 = g_v0, g_v2 = g_v0, g_s1 = g_v0, g_s2 = g_v0;
+    float4 g_v0 = make_float4(0.f, 0.f, 0.f, 0.f), g_v1 = g_v0, g_v2 = g_v0;
+    float g_opac = 1.f;
     if (active) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) { g_mean[k] = means[i * 3 + k]; g_scale[k] = scales[i * 3 + k]; }
@@ -208,8 +212,7 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
         g_rx = radii[2 * i]; g_ry = radii[2 * i + 1];
         const float4 *vrow = reinterpret_cast<const float4 *>(v_splat + i * GSA_SPLAT_STRIDE);
         g_v0 = vrow[0]; g_v1 = vrow[1]; g_v2 = vrow[2];
-        const float4 *srow = reinterpret_cast<const float4 *>(splat + i * GSA_SPLAT_STRIDE);
-        g_s1 = srow[1]; g_s2 = srow[2];
+        g_opac = opacities[i];
     }
 
     if constexpr (STAGE && DEG >= 1) {
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
         // The sweep leaves the raw moments of u = d loss / d sigma over d = mean2d - pixel (composite.hip):
         // sigma = (a dx^2 + c dy^2) / 2 + b dx dy and alpha = o * exp(-sigma) make every gradient linear in them.
         const float m_dx = v0.x, m_dy = v0.y, m_dxdx = v0.z, m_dxdy = v0.w, m_dydy = v1.x, m_u = v1.y;
-        const float s_opac = g_s1.y;
+        const float s_opac = g_opac;
         float v_mx = p.qa * m_dx + p.qb * m_dy, v_my = p.qb * m_dx + p.qc * m_dy;
         float v_a = 0.5f * m_dxdx, v_b = m_dxdy, v_c = 0.5f * m_dydy;
         vo = -m_u / s_opac;   // d alpha / d o = alpha / o  and  u = -alpha * v_alpha
@@ -326,38 +329,44 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
         if constexpr (DEG < 0) {
             vc[0] = v_rgb[0]; vc[1] = v_rgb[1]; vc[2] = v_rgb[2];
         } else {
-            const float4 s1 = g_s1, s2 = g_s2;
-            float vr[3] = {s1.z > 0.f ? v_rgb[0] : 0.f, s1.w > 0.f ? v_rgb[1] : 0.f, s2.x > 0.f ? v_rgb[2] : 0.f};
-            vr_keep[0] = vr[0]; vr_keep[1] = vr[1]; vr_keep[2] = vr[2];
             float dx = g_mean[0] - cam.campos[0], dy = g_mean[1] - cam.campos[1], dz = g_mean[2] - cam.campos[2];
             float inv = rsqrtf(dx * dx + dy * dy + dz * dz);
             float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+            float B[NB];
+            gsa_sh_basis<DEG>(ux, uy, uz, B);
+            float cf[NB * 3];
+            if constexpr (STAGE && DEG >= 1) {
+                constexpr int NQ = sh_needed_q<DEG>();
+                const float4 *row = &sh_lds[threadIdx.x * kRowQPad];
+#pragma unroll
+                for (int k = 0; k < NQ; ++k) {
+                    float4 v = row[k];
+                    if (4 * k + 0 < NB * 3) cf[4 * k + 0] = v.x;
+                    if (4 * k + 1 < NB * 3) cf[4 * k + 1] = v.y;
+                    if (4 * k + 2 < NB * 3) cf[4 * k + 2] = v.z;
+                    if (4 * k + 3 < NB * 3) cf[4 * k + 3] = v.w;
+                }
+            } else {
+                const float *row = colors + i * (long)sh_coeffs * 3;
+#pragma unroll
+                for (int k = 0; k < NB * 3; ++k) cf[k] = row[k];
+            }
+            // clamp mask of the forward's  max(sum_j B_j c_j + 0.5, 0)  (same loop, same order, same contraction)
+            float cr = 0.f, cg = 0.f, cb = 0.f;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                cr += B[j] * cf[3 * j]; cg += B[j] * cf[3 * j + 1]; cb += B[j] * cf[3 * j + 2];
+            }
+            float vr[3] = {fmaxf(cr + 0.5f, 0.f) > 0.f ? v_rgb[0] : 0.f, fmaxf(cg + 0.5f, 0.f) > 0.f ? v_rgb[1] : 0.f,
+                           fmaxf(cb + 0.5f, 0.f) > 0.f ? v_rgb[2] : 0.f};
+            vr_keep[0] = vr[0]; vr_keep[1] = vr[1]; vr_keep[2] = vr[2];
             if constexpr (!FACTORED) {
-                float B[NB];
-                gsa_sh_basis<DEG>(ux, uy, uz, B);
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
                     vc[3 * j] = B[j] * vr[0]; vc[3 * j + 1] = B[j] * vr[1]; vc[3 * j + 2] = B[j] * vr[2];
                 }
             }
             if constexpr (DEG >= 1) {
-                float cf[NB * 3];
-                if constexpr (STAGE) {
-                    constexpr int NQ = sh_needed_q<DEG>();
-                    const float4 *row = &sh_lds[threadIdx.x * kRowQPad];
-#pragma unroll
-                    for (int k = 0; k < NQ; ++k) {
-                        float4 v = row[k];
-                        if (4 * k + 0 < NB * 3) cf[4 * k + 0] = v.x;
-                        if (4 * k + 1 < NB * 3) cf[4 * k + 1] = v.y;
-                        if (4 * k + 2 < NB * 3) cf[4 * k + 2] = v.z;
-                        if (4 * k + 3 < NB * 3) cf[4 * k + 3] = v.w;
-                    }
-                } else {
-                    const float *row = colors + i * (long)sh_coeffs * 3;
-#pragma unroll
-                    for (int k = 0; k < NB * 3; ++k) cf[k] = row[k];
-                }
                 float vB[NB];
 #pragma unroll
                 for (int j = 0; j < NB; ++j)
@@ -450,15 +459,15 @@ int launch_fwd(bool stage, int n, const float *means, const float *quats, const 
 }
 
 template <int DEG>
-int launch_bwd(bool stage, int n, const float *means, const float *quats, const float *scales,
+int launch_bwd(bool stage, int n, const float *means, const float *quats, const float *scales, const float *opacities,
                const float *colors, int sh_coeffs, const float *viewmat, const float *intrin, int width,
-               int height, const float *splat, const int32_t *radii, const float *v_splat, float *v_means,
+               int height, const int32_t *radii, const float *v_splat, float *v_means,
                float *v_quats, float *v_scales, float *v_opacities, float *v_colors, int accumulate, float *v_rgb_out,
                hipStream_t s) {
     dim3 grid(gsa_div_up(n, kBlock)), block(kBlock);
 #define GSA_BWD_LAUNCH(ST, FA)                                                                                        \
-    project_bwd_kernel<DEG, ST, FA><<<grid, block, 0, s>>>(n, means, quats, scales, colors, sh_coeffs, viewmat, intrin,  \
-                                                           width, height, splat, radii, v_splat, v_means, v_quats,      \
+    project_bwd_kernel<DEG, ST, FA><<<grid, block, 0, s>>>(n, means, quats, scales, opacities, colors, sh_coeffs, viewmat, \
+                                                           intrin, width, height, radii, v_splat, v_means, v_quats,      \
                                                            v_scales, v_opacities, v_colors, accumulate, v_rgb_out)
     if constexpr (DEG >= 0) {
         if (v_rgb_out) {
@@ -511,16 +520,16 @@ extern "C" int gsa_project_fwd(int n, const float *means, const float *quats, co
 #undef GSA_FWD
 }
 
-static int project_bwd_impl(int n, const float *means, const float *quats, const float *scales, const float *colors,
-                            int sh_degree, int sh_coeffs, const float *viewmat, const float *intrin, int width, int height,
-                            const float *splat, const int32_t *radii, const float *v_splat, float *v_means,
+static int project_bwd_impl(int n, const float *means, const float *quats, const float *scales, const float *opacities,
+                            const float *colors, int sh_degree, int sh_coeffs, const float *viewmat, const float *intrin,
+                            int width, int height, const int32_t *radii, const float *v_splat, float *v_means,
                             float *v_quats, float *v_scales, float *v_opacities, float *v_colors, int accumulate,
                             float *v_rgb_out, gsa_stream_t stream) {
     GSA_RETURN_IF(n < 0 || width <= 0 || height <= 0, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_degree < -1 || sh_degree > 3, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_degree >= 0 && sh_coeffs < (sh_degree + 1) * (sh_degree + 1), GSA_ERR_INVALID_ARGUMENT);
     if (n == 0) return GSA_OK;
-    GSA_RETURN_IF(!means || !quats || !scales || !colors || !viewmat || !intrin || !splat || !radii || !v_splat ||
+    GSA_RETURN_IF(!means || !quats || !scales || !opacities || !colors || !viewmat || !intrin || !radii || !v_splat ||
                       !v_means || !v_quats || !v_scales || !v_opacities || (!v_colors && !v_rgb_out),
                   GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(v_rgb_out && sh_degree < 0, GSA_ERR_INVALID_ARGUMENT);   // factored form: SH colours only
@@ -528,7 +537,7 @@ static int project_bwd_impl(int n, const float *means, const float *quats, const
     bool stage = can_stage(colors, sh_degree, sh_coeffs) &&
                  (v_rgb_out || (reinterpret_cast<uintptr_t>(v_colors) & 15) == 0);
 #define GSA_BWD(D)                                                                                                  \
-    return launch_bwd<D>(stage, n, means, quats, scales, colors, sh_coeffs, viewmat, intrin, width, height, splat, \
+    return launch_bwd<D>(stage, n, means, quats, scales, opacities, colors, sh_coeffs, viewmat, intrin, width, height, \
                          radii, v_splat, v_means, v_quats, v_scales, v_opacities, v_colors, accumulate ? 1 : 0, v_rgb_out, s)
     switch (sh_degree) {
         case -1: GSA_BWD(-1);
@@ -546,8 +555,8 @@ extern "C" int gsa_project_bwd(int n, const float *means, const float *quats, co
                                const float *splat, const int32_t *radii, const float *v_splat, float *v_means,
                                float *v_quats, float *v_scales, float *v_opacities, float *v_colors,
                                gsa_stream_t stream) {
-    (void)opacities;
-    return project_bwd_impl(n, means, quats, scales, colors, sh_degree, sh_coeffs, viewmat, intrin, width, height, splat,
+    (void)splat;   // kept in the signature: the backward no longer reads the forward's records (see the kernel)
+    return project_bwd_impl(n, means, quats, scales, opacities, colors, sh_degree, sh_coeffs, viewmat, intrin, width, height,
                             radii, v_splat, v_means, v_quats, v_scales, v_opacities, v_colors, 0, nullptr, stream);
 }
 
@@ -557,8 +566,8 @@ extern "C" int gsa_project_bwd_acc(int n, const float *means, const float *quats
                                    const float *splat, const int32_t *radii, const float *v_splat, float *v_means,
                                    float *v_quats, float *v_scales, float *v_opacities, float *v_colors,
                                    int accumulate, gsa_stream_t stream) {
-    (void)opacities;
-    return project_bwd_impl(n, means, quats, scales, colors, sh_degree, sh_coeffs, viewmat, intrin, width, height, splat,
+    (void)splat;   // kept in the signature: the backward no longer reads the forward's records (see the kernel)
+    return project_bwd_impl(n, means, quats, scales, opacities, colors, sh_degree, sh_coeffs, viewmat, intrin, width, height,
                             radii, v_splat, v_means, v_quats, v_scales, v_opacities, v_colors, accumulate, nullptr, stream);
 }
 
@@ -623,9 +632,9 @@ extern "C" int gsa_project_bwd_factored(int n, const float *means, const float *
                                         const float *splat, const int32_t *radii, const float *v_splat, float *v_means,
                                         float *v_quats, float *v_scales, float *v_opacities, float *v_rgb,
                                         int accumulate, gsa_stream_t stream) {
-    (void)opacities;
+    (void)splat;
     GSA_RETURN_IF(!v_rgb, GSA_ERR_INVALID_ARGUMENT);
-    return project_bwd_impl(n, means, quats, scales, colors, sh_degree, sh_coeffs, viewmat, intrin, width, height, splat,
+    return project_bwd_impl(n, means, quats, scales, opacities, colors, sh_degree, sh_coeffs, viewmat, intrin, width, height,
                             radii, v_splat, v_means, v_quats, v_scales, v_opacities, nullptr, accumulate, v_rgb, stream);
 }
 

@@ -177,10 +177,11 @@ int gsa_composite_bwd(int width, int height, int channels, const float *splat,
                       const float *v_render, const float *v_alpha, float *v_splat, gsa_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Stage 5 (row a3.6): projection + SH backward.  Reads the sweep's moment records (stage 4) and the saved
- * forward record / radii; writes EVERY element of v_means[N,3], v_quats[N,4], v_scales[N,3],
+ * Stage 5 (row a3.6): projection + SH backward.  Reads the sweep's moment records (stage 4), the raw
+ * parameters and the saved radii; writes EVERY element of v_means[N,3], v_quats[N,4], v_scales[N,3],
  * v_opacities[N] and v_colors (same shape as colors; zeros above the active degree and for
- * culled gaussians).
+ * culled gaussians).  `splat` is not read (the projection is recomputed, the colour clamp mask re-derived);
+ * it stays in the signature and may be NULL.
  */
 int gsa_project_bwd(int n, const float *means, const float *quats, const float *scales,
                     const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
