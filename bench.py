@@ -47,6 +47,23 @@ def algorithmic_bytes(n: int, m: int, p: int, sh_degree: int):
     }
 
 
+def measured_copy_peak(dev) -> float:
+    """Practical HBM ceiling of THIS box (SURVEY.md section 8d asks for it beside the nominal 8 TB/s): a 1 GiB
+    device-to-device copy, bytes read + written over the best of 5 HIP-event timings, in GB/s."""
+    import torch
+    src = torch.empty(1 << 28, dtype=torch.float32, device=dev).fill_(1.0)
+    dst = torch.empty_like(src)
+    best = float("inf")
+    for _ in range(6):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        dst.copy_(src)
+        b.record()
+        torch.cuda.synchronize()
+        best = min(best, a.elapsed_time(b))
+    return 2.0 * src.numel() * 4 / (best * 1e-3) / 1e9
+
+
 def host_cores() -> int:
     """CPU threads this process may use (the GPU box gives one GPU a 16-core share)."""
     try:
@@ -214,6 +231,7 @@ def main() -> None:
         elapsed = float(tmax.item())
 
     grad_l1 = float(flat_grad.double().abs().sum())   # of the last step's exchanged gradient (same on every rank)
+    copy_peak = measured_copy_peak(dev) if rank == 0 else 0.0   # after the timed regions
     if rank == 0:
         m, p = info["M"], width * height
         ms_per_step = elapsed / args.steps * 1e3
@@ -249,6 +267,7 @@ def main() -> None:
                        "intersections_M": m, "grad_l1": round(grad_l1, 3), "cull_mode": stages.DEFAULT_CULL_MODE if args.cull_mode is None else args.cull_mode},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "measured_copy_peak": round(copy_peak, 1),
                          "algorithmic_bytes_per_launch": alg[dominant], "avg_launch_ms": round(per[dominant], 4)},
             "roofline_whole_step": {"algorithmic_bytes": total_bytes,
                                     "achieved_GBs": round(total_bytes / (ms_per_step * 1e-3) / 1e9, 2),
