@@ -103,12 +103,24 @@ __global__ __launch_bounds__(kSortThreads) void radix_scan_rows_kernel(int nbloc
     __shared__ uint32_t scratch[4];
     uint32_t *row = hist + (long)blockIdx.x * nblocks;
     uint32_t carry = 0;
-    for (int base = 0; base < nblocks; base += kSortThreads) {
-        int i = base + threadIdx.x;
-        uint32_t v = i < nblocks ? row[i] : 0;
+    // four consecutive entries per thread and trip: a long row (27 k blocks at 112 M records) is a chain of trips, each
+    // two barriers and a memory round trip long
+    constexpr int kPer = 4;
+    for (int base = 0; base < nblocks; base += kSortThreads * kPer) {
+        const int i0 = base + threadIdx.x * kPer;
+        uint32_t v[kPer], sum = 0;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            v[j] = i0 + j < nblocks ? row[i0 + j] : 0u;
+            sum += v[j];
+        }
         uint32_t total;
-        uint32_t ex = block_excl_scan(v, scratch, total);
-        if (i < nblocks) row[i] = carry + ex;
+        uint32_t ex = carry + block_excl_scan(sum, scratch, total);
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            if (i0 + j < nblocks) row[i0 + j] = ex;
+            ex += v[j];
+        }
         carry += total;
     }
     if (threadIdx.x == 0) digit_total[blockIdx.x] = carry;
