@@ -523,20 +523,25 @@ def test_grad_accumulate_sums_views_into_one_bucket(gsa, deg):
         gsa.rasterization(*base, views[0], K, W, H, sh_degree=deg, grad_accumulate=True)
 
 
-@pytest.mark.parametrize("W,H,N,s_max", [(640, 360, 30_000, 0.05), (160, 96, 4000, 0.3), (1920, 1080, 50_000, 0.02),
-                                          (40, 24, 500, 0.5)])
-def test_fused_binning_equals_emit_and_sort(gsa, W, H, N, s_max):
+@pytest.mark.parametrize("W,H,N,s_max,giants", [(640, 360, 30_000, 0.05, 0), (160, 96, 4000, 0.3, 0),
+                                                 (1920, 1080, 50_000, 0.02, 5), (40, 24, 500, 0.5, 0)])
+def test_fused_binning_equals_emit_and_sort(gsa, W, H, N, s_max, giants):
     """gsa_scan_tiles_rect + gsa_tile_bin16 (records generated inside the first tile-sort pass, 16-bit tile ids) ==
     gsa_tile_emit + gsa_sort_pairs_u32 + gsa_tile_offsets, bit for bit: tile ids, gaussian ids, tile offsets.
     Covers one- and two-digit tile grids, gaussians without records between ones that have some (the off-screen
     5 %), and a remembered capacity smaller than the record count (reported by finalize(); the caller re-runs)."""
     from gsplat_amd import scene, stages as S
     sc = _scene(N, seed=21, s_min=0.002, s_max=s_max)
+    if giants:   # splats whose rectangle is the whole tile grid: one record list spans several 4096-slot blocks
+        sc["scales"][7:7 + giants] = 4.0
+        sc["means3D"][7:7 + giants] *= 0.2
     vm, K = scene.make_camera(2, 5).cuda(), scene.make_intrinsics(W, H).cuda()
     d = {k: v.cuda().contiguous() for k, v in sc.items()}
     splat, radii, tiles, keys = S.project_fwd(d["means3D"], d["rotations"], d["scales"], d["opacities"][:, 0].contiguous(),
                                               d["shs"], 3, vm, K, W, H, 0)
     assert int((tiles == 0).sum()) > 0 and int((tiles > 0).sum()) > 0
+    if giants:
+        assert int(tiles.max()) == S.tile_grid(W, H)[0] * S.tile_grid(W, H)[1] > S.BIN_BLOCK   # the whole grid
     a = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, fused=False)
     b = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, fused=True)
     assert b.sorted_tile.dtype == torch.int16 and a.sorted_tile.dtype == torch.int32
