@@ -204,10 +204,16 @@ __device__ __forceinline__ float scaled_sigma(const float4 &q0, const float4 &q1
 // The 0.999 cap is only compiled in for batches that hold an opacity above it (exp2(-s) <= 1 otherwise keeps
 // alpha <= o).
 template <bool CLAMP>
-__device__ __forceinline__ float record_alpha(float s, float smax, float opacity, uint32_t off_bit, float &raw) {
+__device__ __forceinline__ float record_alpha(float s, float smax, float opacity, uint32_t off_bit, float &raw, bool &hit) {
     raw = opacity * __builtin_amdgcn_exp2f(-s);
     const float al = CLAMP ? fminf(GSA_MAX_ALPHA, raw) : raw;
-    return ((__float_as_uint(s) | off_bit) <= __float_as_uint(smax)) ? al : 0.f;
+    hit = (__float_as_uint(s) | off_bit) <= __float_as_uint(smax);
+    return hit ? al : 0.f;
+}
+template <bool CLAMP>
+__device__ __forceinline__ float record_alpha(float s, float smax, float opacity, uint32_t off_bit, float &raw) {
+    bool hit;
+    return record_alpha<CLAMP>(s, smax, opacity, off_bit, raw, hit);
 }
 
 template <int F4>
@@ -228,6 +234,9 @@ struct FwdPixel {
     int last;
 };
 
+#ifndef GSA_LIST_MODE
+#define GSA_LIST_MODE 2      // forward lists for the backward sweep: 1 = reach-test survivors, 2 = blended records only
+#endif
 #ifndef GSA_FWD_GROUP
 #define GSA_FWD_GROUP 4      // records per trip of the forward walk (2 or 4)
 #endif
@@ -242,7 +251,8 @@ struct FwdPixel {
 // list positions.
 template <int CH, int F4, bool CLAMP, int G>
 __device__ __forceinline__ void eval_group(const Staged<F4> &st, int i, float pxf, float pyf, uint32_t dead,
-                                           float (&a)[G], float (&col)[G][CH], int (&idx)[G]) {
+                                           float (&a)[G], float (&col)[G][CH], int (&idx)[G],
+                                           unsigned long long (&passed)[G]) {
     // one LDS broadcast gives G list entries
     uint32_t off[G];
     if (G == 4) {
@@ -258,16 +268,34 @@ __device__ __forceinline__ void eval_group(const Staged<F4> &st, int i, float px
         const float4 q0 = p[0], q1 = p[1], q2 = p[2];
         const float dx = q0.x - pxf, dy = q0.y - pyf;
         float raw;
-        a[e] = record_alpha<CLAMP>(scaled_sigma(q0, q1, dx, dy), q2.y, q1.y, dead, raw);
+        bool hit;
+        a[e] = record_alpha<CLAMP>(scaled_sigma(q0, q1, dx, dy), q2.y, q1.y, dead, raw, hit);
+        passed[e] = __ballot(hit);   // the compare's own lane mask: which pixels take this record (no extra VALU)
         col[e][0] = q1.z; col[e][1] = q1.w; col[e][2] = q2.x;
         if (CH == 4) col[e][CH - 1] = p[F4 - 1].x;
         idx[e] = __float_as_int(q2.z);
     }
 }
 
+// contrib |= (taken != 0) << index, on the scalar unit (written as SALU instructions: left to itself the compiler keeps
+// the 64-bit set in VGPRs and spends ~6 vector instructions per record on it -- in a VALU-bound loop).
+__device__ __forceinline__ void note_taken(unsigned long long &contrib, unsigned long long taken, int index) {
+    unsigned long long bit;
+    asm volatile("s_lshl_b64 %1, 1, %3\n\t"
+                 "s_cmp_lg_u64 %2, 0\n\t"
+                 "s_cselect_b64 %1, %1, 0\n\t"
+                 "s_or_b64 %0, %0, %1"
+                 : "+s"(contrib), "=&s"(bit)
+                 : "s"(taken), "s"(index)
+                 : "scc");
+}
+
 // Walks n list entries.  Returns false when all 64 pixels of the wave are finished.
-template <int CH, int F4, bool CLAMP>
-__device__ __forceinline__ bool walk_fwd(const Staged<F4> &st, int n, float pxf, float pyf, FwdPixel<CH> &px) {
+// LISTS: `contrib` receives one bit per list entry that was BLENDED at one pixel of the quadrant at least (alpha test
+// passed, pixel live and not stopping there) -- the records the backward sweep has to visit here.
+template <int CH, int F4, bool CLAMP, int LISTS>
+__device__ __forceinline__ bool walk_fwd(const Staged<F4> &st, int n, float pxf, float pyf, FwdPixel<CH> &px,
+                                         unsigned long long &contrib) {
     constexpr int G = GSA_FWD_GROUP;
     int i = 0;
     while (i < n) {
@@ -276,11 +304,16 @@ __device__ __forceinline__ bool walk_fwd(const Staged<F4> &st, int n, float pxf,
         for (; i < n; i += G) {
             float a[G], col[G][CH], t[G + 1];
             int idx[G];
-            eval_group<CH, F4, CLAMP, G>(st, i, pxf, pyf, px.dead, a, col, idx);
+            unsigned long long passed[G];
+            eval_group<CH, F4, CLAMP, G>(st, i, pxf, pyf, px.dead, a, col, idx, passed);
             t[0] = px.T;
 #pragma unroll
             for (int e = 0; e < G; ++e) t[e + 1] = t[e] * (1.f - a[e]);
             if (__ballot(t[G] > GSA_TRANSMITTANCE_EPS) != ~0ull) break;
+            if (LISTS == 2) {   // (no pixel stops in this group: taking a record = blending it)
+#pragma unroll
+                for (int e = 0; e < G; ++e) note_taken(contrib, passed[e], i + e);
+            }
 #pragma unroll
             for (int e = 0; e < G; ++e) {
                 const float wgt = a[e] * t[e];
@@ -296,13 +329,15 @@ __device__ __forceinline__ bool walk_fwd(const Staged<F4> &st, int n, float pxf,
         {
             float a[G], col[G][CH];
             int idx[G];
-            eval_group<CH, F4, CLAMP, G>(st, i, pxf, pyf, px.dead, a, col, idx);
+            unsigned long long passed[G];
+            eval_group<CH, F4, CLAMP, G>(st, i, pxf, pyf, px.dead, a, col, idx, passed);
 #pragma unroll
             for (int e = 0; e < G; ++e) {
                 const float ae = px.dead ? 0.f : a[e];      // a pixel that stopped earlier in this group
                 const float nT = px.T * (1.f - ae);
                 const bool ok = nT > GSA_TRANSMITTANCE_EPS; // finished pixels: alpha 0, T = 1 -> true, no effect
                 const float wgt = ok ? ae * px.T : 0.f;
+                if (LISTS == 2) note_taken(contrib, __ballot(wgt != 0.f), i + e);
 #pragma unroll
                 for (int k = 0; k < CH; ++k) px.acc[k] = __builtin_fmaf(col[e][k], wgt, px.acc[k]);
                 px.last = (ok && !px.dead) ? idx[e] : px.last;
@@ -317,12 +352,17 @@ __device__ __forceinline__ bool walk_fwd(const Staged<F4> &st, int n, float pxf,
     return true;
 }
 
-template <int CH>
+// LISTS: additionally writes, per quadrant, the list positions of the records that were blended there
+// (quad_list[4 * start + q * (end - start) ...], ascending) and their number (quad_count[4 * tile + q]): in a dense
+// scene ~45 % of the records a quadrant walks pass its reach test and ~90 % of those blend somewhere -- the backward
+// sweep then visits exactly those, without a reach test and in full batches.
+template <int CH, int LISTS>
 __global__ __launch_bounds__(kWave, GSA_FWD_WAVES) void composite_fwd_kernel(
     int width, int height, int tile_w, int n_tiles, const float *__restrict__ splat,
     const uint32_t *__restrict__ sorted_gid, const int32_t *__restrict__ tile_offsets,
     const float *__restrict__ background, const int32_t *__restrict__ tile_order, float *__restrict__ render,
-    float *__restrict__ alpha_out, float *__restrict__ final_T, int32_t *__restrict__ last_id) {
+    float *__restrict__ alpha_out, float *__restrict__ final_T, int32_t *__restrict__ last_id,
+    uint32_t *__restrict__ quad_list, int32_t *__restrict__ quad_count) {
     constexpr int F4 = CH == 4 ? 4 : 3;
     __shared__ Staged<F4> st;
 
@@ -343,6 +383,8 @@ __global__ __launch_bounds__(kWave, GSA_FWD_WAVES) void composite_fwd_kernel(
     px.T = 1.f; px.Tend = 1.f; px.dead = inside ? 0u : kSign; px.last = -1;
 #pragma unroll
     for (int k = 0; k < CH; ++k) px.acc[k] = 0.f;
+    int listed = 0;   // LISTS: entries written to this quadrant's list so far (wave-uniform)
+    uint32_t *my_list = LISTS ? quad_list + 4 * (size_t)start + (size_t)q * (size_t)(end - start) : nullptr;
 
     if (__ballot(inside) != 0ull && start < end) {
         // software pipeline, two batches deep: ids of batch j+2 and records of batch j+1 are in flight while
@@ -364,8 +406,17 @@ __global__ __launch_bounds__(kWave, GSA_FWD_WAVES) void composite_fwd_kernel(
             row = load_row(splat, gid_next, idx + kBatch < end);
             gid_next = load_gid(j + 2);
             GSA_TRACE_COUNT(n);
-            const bool live = any_cap ? walk_fwd<CH, F4, true>(st, n, pxf, pyf, px)
-                                      : walk_fwd<CH, F4, false>(st, n, pxf, pyf, px);
+            unsigned long long contrib = 0ull;
+            const bool live = any_cap ? walk_fwd<CH, F4, true, LISTS>(st, n, pxf, pyf, px, contrib)
+                                      : walk_fwd<CH, F4, false, LISTS>(st, n, pxf, pyf, px, contrib);
+            if (LISTS == 1) contrib = ~0ull;                   // every record the reach test kept
+            contrib &= n >= 64 ? ~0ull : (1ull << n) - 1ull;   // the padding (null) entries "pass" with alpha 0
+            if (LISTS && contrib) {   // lane i < n <-> list entry i: append the blended ones, in list order
+                const bool mine = (contrib >> lane) & 1ull;
+                const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(contrib >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)contrib, 0));
+                if (mine) my_list[listed + rank] = (uint32_t)__float_as_int(rec_at(st, st.list[lane])[2].z);
+                listed += __builtin_popcountll(contrib);
+            }
             GSA_TRACE_MARK(4);
             if (!live) break;
         }
@@ -380,6 +431,7 @@ __global__ __launch_bounds__(kWave, GSA_FWD_WAVES) void composite_fwd_kernel(
         final_T[pix] = Tf;  // kept beside alpha: 1 - (1 - T) loses the low bits of a small T
         last_id[pix] = px.last;
     }
+    if (LISTS && lane == 0) quad_count[4 * tile + q] = listed;
     GSA_TRACE_MARK(6);
     GSA_TRACE_END(0, tile * 4 + q, end - start);
 }
@@ -585,6 +637,109 @@ __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_kernel(
     GSA_TRACE_END(1, tile * 4 + q, qmax + 1 - start);
 }
 
+// The same sweep over the forward pass's per-quadrant lists of BLENDED records (composite_fwd_kernel<CH, true>): no
+// reach test, no compaction, every staged record is walked -- full batches of 64, and none of the ~10 % of reach-test
+// survivors that blend nowhere.  Lane l of batch j holds list entry count - 1 - 64 j - l (walk order = reverse).
+template <int F4>
+__device__ __forceinline__ int stage_listed(Staged<F4> &st, int lane, const Row &row, bool valid, int idx, bool &any_cap) {
+    const float4 r0 = row.r0, r1 = row.r1, r2 = row.r2;
+    st.rec[F4 * lane + 0] = make_float4(r0.x, r0.y, 0.5f * kLog2e * r0.z, kLog2e * r0.w);
+    st.rec[F4 * lane + 1] = make_float4(0.5f * kLog2e * r1.x, r1.y, r1.z, r1.w);
+    st.rec[F4 * lane + 2] = make_float4(r2.x, fmaxf(0.f, kLog2e * r2.z), __int_as_float(idx), __uint_as_float(row.gid));
+    if (F4 == 4) st.rec[F4 * lane + 3] = make_float4(r2.y, 0.f, 0.f, 0.f);
+    const unsigned long long b = __ballot(valid);          // valid lanes are a prefix: lane < n
+    any_cap = __ballot(valid && r1.y > GSA_MAX_ALPHA) != 0ull;
+    const int n = __builtin_popcountll(b);
+    st.list[lane] = (uint16_t)(lane * Staged<F4>::kRecBytes);
+    if (lane < 3) st.list[n + lane] = (uint16_t)(kBatch * Staged<F4>::kRecBytes);
+    const int last_idx = __builtin_amdgcn_readlane(idx, n ? n - 1 : 0);
+    if (lane < F4) {
+        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane == 2) z.z = __int_as_float(last_idx);
+        st.rec[kBatch * F4 + lane] = z;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return n;
+}
+
+template <int CH>
+__global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_list_kernel(
+    int width, int height, int tile_w, int n_tiles, const float *__restrict__ splat,
+    const uint32_t *__restrict__ sorted_gid, const int32_t *__restrict__ tile_offsets,
+    const float *__restrict__ background, const int32_t *__restrict__ tile_order, const float *__restrict__ final_T,
+    const int32_t *__restrict__ last_id, const float *__restrict__ v_render, const float *__restrict__ v_alpha,
+    const uint32_t *__restrict__ quad_list, const int32_t *__restrict__ quad_count, float *__restrict__ v_splat) {
+    constexpr int F4 = CH == 4 ? 4 : 3;
+    constexpr int NF = 6 + CH;
+    __shared__ Staged<F4> st;
+
+    int tile, q;
+    wave_unit(blockIdx.x, n_tiles, tile_order, tile, q);
+    if (tile >= n_tiles) return;
+    const int lane = threadIdx.x;
+    const int count = __builtin_amdgcn_readfirstlane(quad_count[4 * tile + q]);
+    if (count <= 0) return;
+    const int start = __builtin_amdgcn_readfirstlane(tile_offsets[tile]);
+    const int end = __builtin_amdgcn_readfirstlane(tile_offsets[tile + 1]);
+    const uint32_t *my_list = quad_list + 4 * (size_t)start + (size_t)q * (size_t)(end - start);
+    GSA_TRACE_BEGIN();
+    const int tx = tile % tile_w, ty = tile / tile_w;
+    const int qx = tx * kTile + (q & 1) * 8, qy = ty * kTile + (q >> 1) * 8;
+    const int px = qx + (lane & 7), py = qy + (lane >> 3);
+    const bool inside = px < width && py < height;
+    const float pxf = px + 0.5f, pyf = py + 0.5f;
+
+    const size_t pix = inside ? (size_t)py * width + px : 0;
+    const int binf = inside ? last_id[pix] : -1;   // last list position the pixel saw while live
+
+    // software pipeline three deep: list entries of batch j+2, ids of batch j+1, records of batch j
+    auto load_pos = [&](int j) -> int {
+        const int e = count - 1 - j * kBatch - lane;
+        return e >= 0 ? (int)my_list[e] : -1;
+    };
+    auto load_gid = [&](int pos) -> uint32_t { return pos >= 0 ? sorted_gid[pos] : 0u; };
+    int pos_cur = load_pos(0);
+    int pos_next = load_pos(1);
+    uint32_t gid_cur = load_gid(pos_cur);
+    const float Tf = inside ? final_T[pix] : 1.f;
+    float T = Tf;
+    float vout[CH], bgdot = 0.f;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        vout[k] = inside ? v_render[pix * CH + k] : 0.f;
+        if (background) bgdot += background[k] * vout[k];
+    }
+    float Wd = Tf * (((inside && v_alpha) ? v_alpha[pix] : 0.f) - bgdot);
+    Row row = load_row(splat, gid_cur, pos_cur >= 0);
+    uint32_t gid_next = load_gid(pos_next);
+    int pos_next2 = load_pos(2);
+
+    const int my_r = (lane & 1) ? 2 : ((lane >> 1) & 1);
+    const int my_field = 2 * (2 * my_r + ((lane >> 4) & 1)) + ((lane >> 5) & 1);
+    const bool my_add = my_field < NF && (!(lane & 1) || !(lane & (2 | 16)));
+
+    GSA_TRACE_MARK(0);
+    for (int done = 0, j = 0; done < count; done += kBatch, ++j) {
+        bool any_cap;
+        const int n = stage_listed(st, lane, row, pos_cur >= 0, pos_cur, any_cap);
+        GSA_TRACE_MARK(1);
+        row = load_row(splat, gid_next, pos_next >= 0);
+        pos_cur = pos_next;
+        gid_next = load_gid(pos_next2);
+        pos_next = pos_next2;
+        pos_next2 = load_pos(j + 3);
+        GSA_TRACE_COUNT(n);
+        if (any_cap)
+            walk_bwd<CH, F4, true>(st, n, lane, pxf, pyf, binf, vout, T, Wd, my_field, my_add, v_splat);
+        else
+            walk_bwd<CH, F4, false>(st, n, lane, pxf, pyf, binf, vout, T, Wd, my_field, my_add, v_splat);
+        GSA_TRACE_MARK(4);
+    }
+    GSA_TRACE_END(1, tile * 4 + q, count);
+}
+
 // ------------------------------------------------------------------------------------------------
 // launch order: longest record lists first, inside each XCD band
 // ------------------------------------------------------------------------------------------------
@@ -632,19 +787,24 @@ extern "C" int gsa_debug_set_trace(unsigned long long *buf) {
 extern "C" int gsa_composite_fwd(int width, int height, int channels, const float *splat,
                                  const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
                                  const int32_t *tile_order, float *render, float *alpha, float *final_T,
-                                 int32_t *last_id, gsa_stream_t stream) {
+                                 int32_t *last_id, uint32_t *quad_list, int32_t *quad_count, gsa_stream_t stream) {
     GSA_RETURN_IF(width <= 0 || height <= 0 || (channels != 3 && channels != 4), GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(!tile_offsets || !render || !alpha || !final_T || !last_id, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF((quad_list == nullptr) != (quad_count == nullptr), GSA_ERR_INVALID_ARGUMENT);
     const int tile_w = gsa_div_up(width, kTile), tile_h = gsa_div_up(height, kTile);
     const int n_tiles = tile_w * tile_h;
     const int grid = 32 * gsa_div_up(n_tiles, 8);   // one wave per (tile, quadrant)
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (channels == 3)
-        composite_fwd_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid, tile_offsets,
-                                                      background, tile_order, render, alpha, final_T, last_id);
-    else
-        composite_fwd_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid, tile_offsets,
-                                                      background, tile_order, render, alpha, final_T, last_id);
+#define GSA_FWD_LAUNCH(C, L)                                                                                          \
+    composite_fwd_kernel<C, L><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid, tile_offsets, \
+                                                     background, tile_order, render, alpha, final_T, last_id,         \
+                                                     quad_list, quad_count)
+    if (quad_list) {
+        if (channels == 3) GSA_FWD_LAUNCH(3, GSA_LIST_MODE); else GSA_FWD_LAUNCH(4, GSA_LIST_MODE);
+    } else {
+        if (channels == 3) GSA_FWD_LAUNCH(3, 0); else GSA_FWD_LAUNCH(4, 0);
+    }
+#undef GSA_FWD_LAUNCH
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }
@@ -665,6 +825,31 @@ extern "C" int gsa_composite_bwd(int width, int height, int channels, const floa
     else
         composite_bwd_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid, tile_offsets,
                                                       background, tile_order, final_T, last_id, v_render, v_alpha, v_splat);
+    GSA_LAUNCH_CHECK();
+    return GSA_OK;
+}
+
+extern "C" int gsa_composite_bwd_lists(int width, int height, int channels, const float *splat,
+                                       const uint32_t *sorted_gid, const int32_t *tile_offsets,
+                                       const float *background, const int32_t *tile_order, const float *final_T,
+                                       const int32_t *last_id, const float *v_render, const float *v_alpha,
+                                       const uint32_t *quad_list, const int32_t *quad_count, float *v_splat,
+                                       gsa_stream_t stream) {
+    GSA_RETURN_IF(width <= 0 || height <= 0 || (channels != 3 && channels != 4), GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(!tile_offsets || !final_T || !last_id || !v_render || !v_splat || !quad_list || !quad_count,
+                  GSA_ERR_INVALID_ARGUMENT);
+    const int tile_w = gsa_div_up(width, kTile), tile_h = gsa_div_up(height, kTile);
+    const int n_tiles = tile_w * tile_h;
+    const int grid = 32 * gsa_div_up(n_tiles, 8);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (channels == 3)
+        composite_bwd_list_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid, tile_offsets,
+                                                           background, tile_order, final_T, last_id, v_render, v_alpha,
+                                                           quad_list, quad_count, v_splat);
+    else
+        composite_bwd_list_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid, tile_offsets,
+                                                           background, tile_order, final_T, last_id, v_render, v_alpha,
+                                                           quad_list, quad_count, v_splat);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }

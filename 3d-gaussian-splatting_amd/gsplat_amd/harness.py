@@ -460,11 +460,11 @@ class ViewParallelTrainer:
             ahead = front(mine[j + 1]) if j + 1 < len(mine) else None
             main.wait_event(done)
             W, H = view["width"], view["height"]
-            render, _, final_T, last_id = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bgc, W, H, 3,
-                                                          order)
+            render, _, final_T, last_id, lists = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bgc, W,
+                                                                 H, 3, order, want_lists=True)
             s3, v = S.view_loss(render, view["image"], c.lambda_dssim, grad_scale=1.0 / n_views)
             v_splat = S.composite_bwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bgc, final_T, last_id, v, None,
-                                      W, H, 3, order)
+                                      W, H, 3, order, quad_lists=lists)
             S.project_bwd(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], degree, pose, Kc, W, H, splat, radii,
                           v_splat, out=grad_out, accumulate=not first,
                           v_rgb_out=vr_all[self.rank, j] if factored else None)

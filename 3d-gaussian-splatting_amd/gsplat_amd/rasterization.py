@@ -40,18 +40,23 @@ class _RasterizeOneCamera(torch.autograd.Function):
         # queued, and only then is the count (long since copied back) checked -- a miss repeats with exact sizes
         bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, tile_rects=rects)
         tile_order = S.tile_schedule(bins.tile_offsets, width, height)   # longest record lists first (speed only)
-        render, alpha, final_T, last_id = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg_c, width,
-                                                          height, channels, tile_order)
+        # with a backward pass to come, the forward sweep also notes per 8x8 quadrant which records it blended: the
+        # reverse sweep then visits exactly those
+        want_lists = any(ctx.needs_input_grad[:5])
+        out = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg_c, width, height, channels,
+                              tile_order, want_lists=want_lists)
         if not bins.finalize()[1]:
             bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, exact=True,
                                tile_rects=rects)
             tile_order = S.tile_schedule(bins.tile_offsets, width, height)
-            render, alpha, final_T, last_id = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg_c,
-                                                              width, height, channels, tile_order)
+            out = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg_c, width, height, channels,
+                                  tile_order, want_lists=want_lists)
+        render, alpha, final_T, last_id = out[:4]
+        quad_list, quad_count = out[4] if want_lists else (None, None)
         sorted_tile, sorted_gid, tile_offsets = bins.sorted_tile, bins.sorted_gid, bins.tile_offsets
 
         ctx.save_for_backward(means_c, quats_c, scales_c, opac_c, colors_c, view_c, K_c, bg_c, splat, radii,
-                              sorted_gid, tile_offsets, final_T, last_id, tile_order)
+                              sorted_gid, tile_offsets, final_T, last_id, tile_order, quad_list, quad_count)
         ctx.dims = (width, height, sh_degree, channels)
         ctx.grad_out = grad_out
         ctx.grad_accumulate = bool(grad_accumulate)
@@ -65,14 +70,15 @@ class _RasterizeOneCamera(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_render, v_alpha, *unused):
         (means_c, quats_c, scales_c, opac_c, colors_c, view_c, K_c, bg_c, splat, radii, sorted_gid, tile_offsets,
-         final_T, last_id, tile_order) = ctx.saved_tensors
+         final_T, last_id, tile_order, quad_list, quad_count) = ctx.saved_tensors
         width, height, sh_degree, channels = ctx.dims
         if v_render is None:
             v_render = torch.zeros(height, width, channels, dtype=torch.float32, device=means_c.device)
         v_render = v_render.to(torch.float32).contiguous()
         v_alpha_c = None if v_alpha is None else v_alpha.to(torch.float32).contiguous()
         v_splat = S.composite_bwd(splat, sorted_gid, tile_offsets, bg_c, final_T, last_id, v_render, v_alpha_c,
-                                  width, height, channels, tile_order)
+                                  width, height, channels, tile_order,
+                                  quad_lists=None if quad_list is None else (quad_list, quad_count))
         grads = S.project_bwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
                               splat, radii, v_splat, out=ctx.grad_out, accumulate=ctx.grad_accumulate,
                               v_rgb_out=ctx.sh_grad_factored)

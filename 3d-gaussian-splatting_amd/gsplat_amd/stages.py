@@ -268,16 +268,25 @@ def tile_schedule(tile_offsets: torch.Tensor, width: int, height: int) -> torch.
 
 
 def composite_fwd(splat, sorted_gid, tile_offsets, background, width: int, height: int, channels: int,
-                  tile_order=None):
-    """-> render [H,W,channels], alpha [H,W,1], final_T [H,W], last_id [H,W] i32."""
+                  tile_order=None, want_lists: bool = False):
+    """-> render [H,W,channels], alpha [H,W,1], final_T [H,W], last_id [H,W] i32
+    [, (quad_list [4 * len(sorted_gid)] i32, quad_count [n_tiles,4] i32) with ``want_lists``: per 8x8 quadrant the
+    records that were blended there -- what ``composite_bwd(..., quad_lists=...)`` sweeps]."""
     dev = splat.device
     render = torch.empty(height, width, channels, dtype=torch.float32, device=dev)
     alpha = torch.empty(height, width, 1, dtype=torch.float32, device=dev)
     final_T = torch.empty(height, width, dtype=torch.float32, device=dev)
     last_id = torch.empty(height, width, dtype=torch.int32, device=dev)
+    quad_list = quad_count = None
+    if want_lists:
+        tile_w, tile_h = tile_grid(width, height)
+        quad_list = torch.empty(4 * max(int(sorted_gid.numel()), 1), dtype=torch.int32, device=dev)
+        quad_count = torch.empty(tile_w * tile_h, 4, dtype=torch.int32, device=dev)
     _call("gsa_composite_fwd", lib.gsa_composite_fwd, width, height, channels, _ptr(splat), _ptr(sorted_gid),
           _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(render), _ptr(alpha), _ptr(final_T),
-          _ptr(last_id), _stream())
+          _ptr(last_id), _ptr(quad_list), _ptr(quad_count), _stream())
+    if want_lists:
+        return render, alpha, final_T, last_id, (quad_list, quad_count)
     return render, alpha, final_T, last_id
 
 
@@ -311,11 +320,17 @@ def record_grads_to_moments(splat: torch.Tensor, g: torch.Tensor) -> torch.Tenso
 
 
 def composite_bwd(splat, sorted_gid, tile_offsets, background, final_T, last_id, v_render, v_alpha, width: int,
-                  height: int, channels: int, tile_order=None):
+                  height: int, channels: int, tile_order=None, quad_lists=None):
     """-> v_splat [N,16]: per gaussian the raw moments of u = d loss / d sigma over d = mean2d - pixel
     (sum u dx, u dy, u dx^2, u dx dy, u dy^2, u) and sum fac * v_out per channel -- the gradient record
     ``project_bwd`` consumes (``moments_to_record_grads`` gives the mean / conic / opacity gradients)."""
     v_splat = torch.zeros_like(splat)
+    if quad_lists is not None:   # sweep the forward pass's lists of blended records (same result, fewer visits)
+        quad_list, quad_count = quad_lists
+        _call("gsa_composite_bwd", lib.gsa_composite_bwd_lists, width, height, channels, _ptr(splat), _ptr(sorted_gid),
+              _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(final_T), _ptr(last_id), _ptr(v_render),
+              _ptr(v_alpha), _ptr(quad_list), _ptr(quad_count), _ptr(v_splat), _stream())
+        return v_splat
     _call("gsa_composite_bwd", lib.gsa_composite_bwd, width, height, channels, _ptr(splat), _ptr(sorted_gid),
           _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(final_T), _ptr(last_id), _ptr(v_render),
           _ptr(v_alpha), _ptr(v_splat), _stream())

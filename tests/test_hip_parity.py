@@ -523,6 +523,49 @@ def test_grad_accumulate_sums_views_into_one_bucket(gsa, deg):
         gsa.rasterization(*base, views[0], K, W, H, sh_degree=deg, grad_accumulate=True)
 
 
+@pytest.mark.parametrize("W,H,N,cull_mode,channels", [(640, 360, 20_000, 0, 3), (250, 130, 3000, 1, 4),
+                                                       (1920, 1080, 60_000, 0, 3)])
+def test_backward_sweep_over_blended_record_lists(gsa, W, H, N, cull_mode, channels):
+    """The forward sweep can note, per 8x8 quadrant, which records it blended (gsa_composite_fwd's quad_list /
+    quad_count); gsa_composite_bwd_lists sweeps exactly those.  The forward outputs do not depend on the option (bit
+    for bit); the lists hold ascending positions inside the tile's slice, none beyond what a pixel of the quadrant
+    saw; the backward result equals the plain sweep's up to the order of the float atomics."""
+    from gsplat_amd import scene, stages as S
+    big = N == 3000
+    sc = _scene(N, seed=31, s_min=0.05 if big else 0.004, s_max=0.5 if big else 0.05)
+    vm, K = scene.make_camera(3, 7), scene.make_intrinsics(W, H)
+    _, splat, radii, sorted_gid, tile_offsets = _hip_front_end(sc, vm, K, W, H, 3, cull_mode)
+    if channels == 4:   # the depth channel rides in the fourth float4 of the staged record
+        splat = splat.clone()
+    bg = torch.tensor([0.3, 0.6, 0.1, 0.0][:channels]).cuda()
+    rng = np.random.default_rng(7)
+    v_r = torch.from_numpy(rng.uniform(-1, 1, (H, W, channels)).astype(np.float32)).cuda()
+    v_a = torch.from_numpy(rng.uniform(-1, 1, (H, W)).astype(np.float32)).cuda()
+    r0, a0, T0, l0 = S.composite_fwd(splat, sorted_gid, tile_offsets, bg, W, H, channels)
+    r1, a1, T1, l1, (qlist, qcount) = S.composite_fwd(splat, sorted_gid, tile_offsets, bg, W, H, channels, want_lists=True)
+    assert torch.equal(r0, r1) and torch.equal(a0, a1) and torch.equal(T0, T1) and torch.equal(l0, l1)
+    tw, th = S.tile_grid(W, H)
+    offs = tile_offsets.cpu().numpy()
+    qc, ql, last = qcount.cpu().numpy(), qlist.cpu().numpy(), l0.cpu().numpy()
+    assert qc.min() >= 0 and 0 < qc.sum() < 4 * sorted_gid.numel()
+    for t in np.random.default_rng(1).choice(tw * th, size=40, replace=False):
+        s0, e0 = int(offs[t]), int(offs[t + 1])
+        ty, tx = divmod(int(t), tw)
+        for q in range(4):
+            n = int(qc[t, q])
+            assert n <= e0 - s0
+            lst = ql[4 * s0 + q * (e0 - s0): 4 * s0 + q * (e0 - s0) + n]
+            y0, x0 = ty * 16 + (q >> 1) * 8, tx * 16 + (q & 1) * 8
+            seen = last[y0:y0 + 8, x0:x0 + 8]
+            if n:
+                assert np.all(np.diff(lst.astype(np.int64)) > 0) and lst[0] >= s0 and lst[-1] < e0
+                assert seen.size and int(lst[-1]) <= int(seen.max())
+    g0 = S.composite_bwd(splat, sorted_gid, tile_offsets, bg, T0, l0, v_r, v_a, W, H, channels)
+    g1 = S.composite_bwd(splat, sorted_gid, tile_offsets, bg, T0, l0, v_r, v_a, W, H, channels, quad_lists=(qlist, qcount))
+    scale = g0.abs().amax(0).clamp_min(1e-30)
+    assert float(((g0 - g1).abs().amax(0) / scale).max()) < 2e-5
+
+
 @pytest.mark.parametrize("W,H,N,s_max,giants", [(640, 360, 30_000, 0.05, 0), (160, 96, 4000, 0.3, 0),
                                                  (1920, 1080, 50_000, 0.02, 5), (40, 24, 500, 0.5, 0)])
 def test_fused_binning_equals_emit_and_sort(gsa, W, H, N, s_max, giants):
