@@ -15,7 +15,8 @@ fetch = last_dispatch(glob.glob(f"{out_dir}/fetch/*/*counter_collection.csv")[0]
 write = last_dispatch(glob.glob(f"{out_dir}/write/*/*counter_collection.csv")[0], "composite|project")
 cal_f = last_dispatch(glob.glob(f"{out_dir}/fetch_cal/*/*counter_collection.csv")[0], "reduce_kernel")
 cal_w = last_dispatch(glob.glob(f"{out_dir}/write_cal/*/*counter_collection.csv")[0], "FillFunctor|vectorized_elementwise")
-names = {"composite_bwd_kernel": "gsa_composite_bwd", "composite_fwd_kernel": "gsa_composite_fwd",
+names = {"composite_bwd_kernel": "gsa_composite_bwd", "composite_bwd_list_kernel": "gsa_composite_bwd",
+         "composite_fwd_kernel": "gsa_composite_fwd",
          "project_fwd_kernel": "gsa_project_fwd", "project_bwd_kernel": "gsa_project_bwd"}
 res = {"_about": f"HBM traffic per launch from rocprofv3 --pmc (separate passes: FETCH_SIZE; WRITE_SIZE + TCC_EA0_ATOMIC_sum), "
                  f"bench.py C3 workload, {tag} build; last dispatch of each kernel. FETCH_SIZE (KB) is doubled per "
@@ -24,6 +25,8 @@ res = {"_about": f"HBM traffic per launch from rocprofv3 --pmc (separate passes:
                  f"compositor's 16-B gathers that factor is an upper bound. WRITE_SIZE (KB) is exact for streaming stores and counts "
                  f"64 B per float-atomic request.", "kernels": {}}
 for k, nice in names.items():
+    if k not in fetch and k not in write:
+        continue
     f = fetch.get(k, {}).get("FETCH_SIZE", 0.0) * 1024.0
     w = write.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0
     a = write.get(k, {}).get("TCC_EA0_ATOMIC_sum", 0.0)
