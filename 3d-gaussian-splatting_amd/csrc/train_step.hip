@@ -1,10 +1,10 @@
 // train_step.hip -- the two stages that follow the rasterizer in a training step:
 //
-//   gsa_view_loss   the reference's per-view photometric loss AND its gradient with respect to the render, in two
-//                   streaming passes:  loss = (1 - lambda) L1 + lambda (1 - SSIM_3x3)  on the straight-through-clamped
+//   gsa_view_loss   the reference's per-view photometric loss AND its gradient with respect to the render, in one
+//                   streaming pass:  loss = (1 - lambda) L1 + lambda (1 - SSIM_3x3)  on the straight-through-clamped
 //                   render (/root/reference/src/training/trainer.py:485-492 with _stclamp :102-107 and _compute_ssim
 //                   :354-371; PSNR's mse :70-75 comes out of the same pass).  The torch formulation makes ~10
-//                   full-image passes forward and as many backward; here the image is read once per pass.
+//                   full-image passes forward and as many backward; here render and target are read once.
 //   gsa_adam_step   one fused Adam update over the flat 59 N parameter bucket with per-segment learning rates
 //                   (torch.optim.Adam as configured at trainer.py:331-340: betas 0.9 / 0.999, eps 1e-15, no weight
 //                   decay, no amsgrad): 4 arrays read, 3 written, once.
@@ -83,23 +83,53 @@ __device__ __forceinline__ void stage_tile(float *__restrict__ lds, const float 
     }
 }
 
-// Pass 1: 3x3 box statistics (zero padding, divisor 9 -- avg_pool2d(3, 1, padding=1) with count_include_pad) of
-// a = clamp(render) and b = target per channel; the SSIM value and its partial derivatives with respect to the
-// three a-dependent statistics mu_a, E[a^2], E[ab] go to `partials` [H,W,3,3].
-__global__ __launch_bounds__(kThreads) void loss_stats_kernel(int width, int height, const float *__restrict__ render,
-                                                              const float *__restrict__ target,
-                                                              float *__restrict__ partials, double *__restrict__ block_sums) {
-    __shared__ float sa[kHaloH * kHaloW * 3], sb[kHaloH * kHaloW * 3];
+// One pass: a block stages its 32x8 tile of a = clamp(render) and b = target with a TWO-pixel halo, computes the 3x3
+// box statistics (zero padding, divisor 9 -- avg_pool2d(3, 1, padding=1) with count_include_pad) and from them the SSIM
+// value and its partial derivatives with respect to mu_a, E[a^2], E[ab] for the tile plus its ONE-pixel halo into LDS,
+// then every tile pixel applies the adjoint of the box filter to those partials:
+//   v_render = grad_scale * [ (1 - lambda) sign(a - b) - lambda * d SSIM ] / (3 H W)     (straight-through clamp).
+// The partials never travel through HBM (as a two-kernel version they were 36 B per pixel out and back).
+constexpr int kHalo2W = kTileW + 4, kHalo2H = kTileH + 4;
+
+template <bool CLAMP>
+__device__ __forceinline__ void stage_tile2(float *__restrict__ lds, const float *__restrict__ src, int x0, int y0, int width,
+                                            int height) {
+    const int row_floats = kHalo2W * 3;
+    for (int i = threadIdx.x; i < kHalo2H * row_floats; i += kThreads) {
+        const int yy = i / row_floats, rest = i - yy * row_floats;
+        const int y = y0 - 2 + yy, xf = (x0 - 2) * 3 + rest;
+        float v = 0.f;
+        if (y >= 0 && y < height && xf >= 0 && xf < width * 3) {
+            v = src[(long)y * width * 3 + xf];
+            if (CLAMP) v = clamp01(v);
+        }
+        lds[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void loss_fused_kernel(int width, int height, const float *__restrict__ render,
+                                                              const float *__restrict__ target, float lambda_dssim,
+                                                              float grad_scale, float *__restrict__ v_render,
+                                                              double *__restrict__ block_sums) {
+    __shared__ float sa[kHalo2H * kHalo2W * 3], sb[kHalo2H * kHalo2W * 3];
+    __shared__ float sp[kHaloH * kHaloW * 9];
     const int tiles_x = (width + kTileW - 1) / kTileW;
     const int x0 = (blockIdx.x % tiles_x) * kTileW, y0 = (blockIdx.x / tiles_x) * kTileH;
-    stage_tile<true>(sa, render, 3, x0, y0, width, height);
-    stage_tile<false>(sb, target, 3, x0, y0, width, height);
+    stage_tile2<true>(sa, render, x0, y0, width, height);
+    stage_tile2<false>(sb, target, x0, y0, width, height);
     __syncthreads();
-    const int lx = threadIdx.x % kTileW, ly = threadIdx.x / kTileW;
-    const int x = x0 + lx, y = y0 + ly;
     double l1 = 0, ssim = 0, mse = 0;
-    if (x < width && y < height) {
-        const long p = (long)y * width + x;
+    // partials of the tile and its one-pixel halo (positions outside the image have no window: zeros)
+    for (int i = threadIdx.x; i < kHaloH * kHaloW; i += kThreads) {
+        const int hy = i / kHaloW, hx = i - hy * kHaloW;
+        const int x = x0 - 1 + hx, y = y0 - 1 + hy;
+        float *out = sp + i * 9;
+        if (x < 0 || x >= width || y < 0 || y >= height) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) out[k] = 0.f;
+            continue;
+        }
+        const bool interior = hx >= 1 && hx <= kTileW && hy >= 1 && hy <= kTileH;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float s_a = 0.f, s_b = 0.f, saa = 0.f, sbb = 0.f, sab = 0.f;
@@ -107,7 +137,7 @@ __global__ __launch_bounds__(kThreads) void loss_stats_kernel(int width, int hei
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
-                    const int q = ((ly + dy) * kHaloW + lx + dx) * 3 + c;
+                    const int q = ((hy + dy) * kHalo2W + hx + dx) * 3 + c;
                     const float a = sa[q], b = sb[q];
                     s_a += a; s_b += b; saa += a * a; sbb += b * b; sab += a * b;
                 }
@@ -121,30 +151,18 @@ __global__ __launch_bounds__(kThreads) void loss_stats_kernel(int width, int hei
             const float S = A1 * A2 * inv;
             // d S / d mu_a with E[a^2], E[ab] held fixed: var_a and cov depend on mu_a too
             const float dA1 = 2.f * mu_b, dA2 = -2.f * mu_b, dB1 = 2.f * mu_a, dB2 = -2.f * mu_a;
-            const float dmu = ((dA1 * A2 + A1 * dA2) - S * (dB1 * B2 + B1 * dB2)) * inv;
-            const float dEaa = -S / B2;          // B2 contains + E[a^2]
-            const float dEab = 2.f * A1 * inv;   // A2 contains + 2 E[ab]
-            float *out = partials + (p * 3 + c) * 3;
-            out[0] = dmu; out[1] = dEaa; out[2] = dEab;
-            const int q0 = ((ly + 1) * kHaloW + lx + 1) * 3 + c;
-            const float d0 = sa[q0] - sb[q0];
-            l1 += fabsf(d0); mse += (double)d0 * d0; ssim += S;
+            out[c * 3 + 0] = ((dA1 * A2 + A1 * dA2) - S * (dB1 * B2 + B1 * dB2)) * inv;
+            out[c * 3 + 1] = -S / B2;            // B2 contains + E[a^2]
+            out[c * 3 + 2] = 2.f * A1 * inv;     // A2 contains + 2 E[ab]
+            if (interior) {
+                const int q0 = ((hy + 1) * kHalo2W + hx + 1) * 3 + c;
+                const float d0 = sa[q0] - sb[q0];
+                l1 += fabsf(d0); mse += (double)d0 * d0; ssim += S;
+            }
         }
     }
-    block_add3(l1, ssim, mse, block_sums);
-}
-
-// Pass 2: v_render = grad_scale * [ (1 - lambda) sign(a - b) - lambda * adjoint of the box filter applied to the
-// partials ] / (3 H W); the clamp is straight-through (identity gradient).
-__global__ __launch_bounds__(kThreads) void loss_grad_kernel(int width, int height, const float *__restrict__ render,
-                                                             const float *__restrict__ target,
-                                                             const float *__restrict__ partials, float lambda_dssim,
-                                                             float grad_scale, float *__restrict__ v_render) {
-    __shared__ float sp[kHaloH * kHaloW * 9];
-    const int tiles_x = (width + kTileW - 1) / kTileW;
-    const int x0 = (blockIdx.x % tiles_x) * kTileW, y0 = (blockIdx.x / tiles_x) * kTileH;
-    stage_tile<false>(sp, partials, 9, x0, y0, width, height);   // outside the image: no window there, zeros
-    __syncthreads();
+    block_add3(l1, ssim, mse, block_sums);   // (contains the barrier that publishes sp)
+    if (!v_render) return;
     const int lx = threadIdx.x % kTileW, ly = threadIdx.x / kTileW;
     const int x = x0 + lx, y = y0 + ly;
     if (x >= width || y >= height) return;
@@ -160,12 +178,12 @@ __global__ __launch_bounds__(kThreads) void loss_grad_kernel(int width, int heig
                 const float *in = sp + (((ly + dy) * kHaloW + lx + dx) * 3 + c) * 3;
                 s_mu += in[0]; s_aa += in[1]; s_ab += in[2];
             }
-        const long q = p * 3 + c;
-        const float a = clamp01(render[q]), b = target[q];
+        const int q0 = ((ly + 2) * kHalo2W + lx + 2) * 3 + c;
+        const float a = sa[q0], b = sb[q0];
         const float d_ssim = (s_mu + 2.f * a * s_aa + b * s_ab) * (1.f / 9.f);
         const float d = a - b;
         const float sign = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-        v_render[q] = inv_count * ((1.f - lambda_dssim) * sign - lambda_dssim * d_ssim);
+        v_render[p * 3 + c] = inv_count * ((1.f - lambda_dssim) * sign - lambda_dssim * d_ssim);
     }
 }
 
@@ -384,14 +402,10 @@ extern "C" int gsa_densify_gather(long long n_old, long long n_new, int n_fields
     return GSA_OK;
 }
 
-static size_t loss_partials_bytes(int width, int height) {   // [H,W,3,3] floats, rounded up to 8 B for the doubles behind
-    return (((size_t)width * height * 9 * sizeof(float)) + 7) & ~(size_t)7;
-}
-
 extern "C" size_t gsa_view_loss_workspace_bytes(int width, int height) {
     if (width <= 0 || height <= 0) return 0;
     const size_t blocks = (size_t)gsa_div_up(width, kTileW) * gsa_div_up(height, kTileH);
-    return loss_partials_bytes(width, height) + blocks * 3 * sizeof(double);
+    return blocks * 3 * sizeof(double);   // the per-block sums
 }
 
 extern "C" int gsa_view_loss(int width, int height, const float *render, const float *target, float lambda_dssim,
@@ -399,19 +413,15 @@ extern "C" int gsa_view_loss(int width, int height, const float *render, const f
                              gsa_stream_t stream) {
     GSA_RETURN_IF(width <= 0 || height <= 0 || !render || !target || !workspace || !sums, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(workspace_bytes < gsa_view_loss_workspace_bytes(width, height), GSA_ERR_WORKSPACE_TOO_SMALL);
+    GSA_RETURN_IF((reinterpret_cast<uintptr_t>(workspace) & 7) != 0, GSA_ERR_INVALID_ARGUMENT);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int grid = gsa_div_up(width, kTileW) * gsa_div_up(height, kTileH);
-    float *partials = static_cast<float *>(workspace);
-    double *block_sums = reinterpret_cast<double *>(static_cast<char *>(workspace) + loss_partials_bytes(width, height));
-    loss_stats_kernel<<<grid, kThreads, 0, s>>>(width, height, render, target, partials, block_sums);
+    double *block_sums = static_cast<double *>(workspace);
+    loss_fused_kernel<<<grid, kThreads, 0, s>>>(width, height, render, target, lambda_dssim, grad_scale, v_render,
+                                               block_sums);
     GSA_LAUNCH_CHECK();
     loss_finalize_kernel<<<1, kThreads, 0, s>>>(grid, block_sums, sums);
     GSA_LAUNCH_CHECK();
-    if (v_render) {
-        loss_grad_kernel<<<grid, kThreads, 0, s>>>(width, height, render, target, partials, lambda_dssim, grad_scale,
-                                                  v_render);
-        GSA_LAUNCH_CHECK();
-    }
     return GSA_OK;
 }
 

@@ -373,7 +373,7 @@ def project_bwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat
 # ---- training-step stages around the rasterizer ------------------------------------
 def view_loss(render: torch.Tensor, target: torch.Tensor, lambda_dssim: float, grad_scale: float = 1.0,
               want_grad: bool = True):
-    """The reference's per-view loss (trainer.py:485-492) and its gradient in two streaming passes.
+    """The reference's per-view loss (trainer.py:485-492) and its gradient in one pass over render and target.
     render / target: [H,W,3] fp32 on the device.  -> (sums [3] float64 on the device: sum |d|, sum SSIM map,
     sum d^2 over the 3HW elements; v_render [H,W,3] = grad_scale * d loss / d render, or None)."""
     if render.shape != target.shape or render.dim() != 3 or render.shape[2] != 3:
