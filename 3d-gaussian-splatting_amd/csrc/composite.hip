@@ -130,15 +130,14 @@ __device__ __forceinline__ Row load_row(const float *__restrict__ splat, uint32_
     return r;
 }
 
-// Can the alpha >= 1/255 region of a splat reach a pixel CENTRE of the 8x8 quadrant whose first centre is
-// (x0, y0)?  Smallest sigma over the rectangle of centres (convex quadratic: inside -> 0, else the best point of
+// Can the alpha >= 1/255 region of a splat reach a pixel CENTRE in the rectangle of centres [x0, x1] x [y0, y1] (the
+// 8x8 quadrant, or the bounding box of its pixels that are still accumulating)?  Smallest sigma over that rectangle (convex quadratic: inside -> 0, else the best point of
 // the four edges) against ln(255 o) with a conservative margin.  The edge minimiser uses v_rcp: an error there
 // only moves the evaluated point ALONG the edge, which raises the value by a second-order amount the margin
 // covers.  Both kernels call this one function, so they always build the same lists.
 __device__ __forceinline__ bool quadrant_reach(float mx, float my, float a, float b, float c, float sig_max,
-                                               float x0, float y0) {
+                                               float x0, float y0, float x1, float y1) {
     const float thr = sig_max * 1.0001f + 1e-4f;
-    const float x1 = x0 + 7.f, y1 = y0 + 7.f;
     if (mx >= x0 && mx <= x1 && my >= y0 && my <= y1) return true;
     const float nb_c = -b * __builtin_amdgcn_rcpf(c), nb_a = -b * __builtin_amdgcn_rcpf(a);
     const float dlo = my - y1, dhi = my - y0, elo = mx - x1, ehi = mx - x0;
@@ -160,13 +159,13 @@ __device__ __forceinline__ bool quadrant_reach(float mx, float my, float a, floa
 // `any_cap` tells whether a listed record's opacity exceeds the 0.999 alpha cap.
 template <int F4>
 __device__ __forceinline__ int stage_batch(Staged<F4> &st, int lane, const Row &row, bool valid, int idx, float qx0,
-                                           float qy0, bool &any_cap) {
+                                           float qy0, float qx1, float qy1, bool &any_cap) {
     const float4 r0 = row.r0, r1 = row.r1, r2 = row.r2;
     st.rec[F4 * lane + 0] = make_float4(r0.x, r0.y, 0.5f * kLog2e * r0.z, kLog2e * r0.w);
     st.rec[F4 * lane + 1] = make_float4(0.5f * kLog2e * r1.x, r1.y, r1.z, r1.w);
     st.rec[F4 * lane + 2] = make_float4(r2.x, fmaxf(0.f, kLog2e * r2.z), __int_as_float(idx), __uint_as_float(row.gid));
     if (F4 == 4) st.rec[F4 * lane + 3] = make_float4(r2.y, 0.f, 0.f, 0.f);
-    const bool hit = valid && quadrant_reach(r0.x, r0.y, r0.z, r0.w, r1.x, r2.z, qx0, qy0);
+    const bool hit = valid && quadrant_reach(r0.x, r0.y, r0.z, r0.w, r1.x, r2.z, qx0, qy0, qx1, qy1);
     const unsigned long long b = __ballot(hit);
     any_cap = __ballot(hit && r1.y > GSA_MAX_ALPHA) != 0ull;
     int n = __builtin_popcountll(b);
@@ -400,7 +399,14 @@ __global__ __launch_bounds__(kWave, GSA_FWD_WAVES) void composite_fwd_kernel(
         for (int base = start, j = 0; base < end; base += kBatch, ++j) {
             const int idx = base + lane;
             bool any_cap;
-            const int n = stage_batch(st, lane, row, idx < end, idx, qx0, qy0, any_cap);
+            // reach test against the bounding box of the pixels that are still accumulating (lane = 8 y + x): as the
+            // quadrant saturates -- and at the image border -- fewer records can reach anything that still matters
+            const unsigned long long alive = __ballot(px.dead == 0u);
+            const uint32_t cols8 = (uint32_t)alive | (uint32_t)(alive >> 32);
+            const uint32_t cols = (cols8 | (cols8 >> 16) | (cols8 >> 8) | (cols8 >> 24)) & 0xFFu;
+            const float bx0 = qx0 + (float)__builtin_ctz(cols), bx1 = qx0 + (float)(31 - __builtin_clz(cols));
+            const float by0 = qy0 + (float)(__builtin_ctzll(alive) >> 3), by1 = qy0 + (float)((63 - __builtin_clzll(alive)) >> 3);
+            const int n = stage_batch(st, lane, row, idx < end, idx, bx0, by0, bx1, by1, any_cap);
             GSA_TRACE_MARK(1);
             // prefetch: the records of the next batch (their ids arrived during the previous walk), the ids after
             row = load_row(splat, gid_next, idx + kBatch < end);
@@ -623,7 +629,7 @@ __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_kernel(
     for (int top = qmax, j = 0; top >= start; top -= kBatch, ++j) {
         const int idx = top - lane;
         bool any_cap;
-        const int n = stage_batch(st, lane, row, idx >= start, idx, qx0, qy0, any_cap);
+        const int n = stage_batch(st, lane, row, idx >= start, idx, qx0, qy0, qx0 + 7.f, qy0 + 7.f, any_cap);
         GSA_TRACE_MARK(1);
         row = load_row(splat, gid_next, idx - kBatch >= start);
         gid_next = load_gid(j + 2);
