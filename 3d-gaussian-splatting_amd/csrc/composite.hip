@@ -775,7 +775,57 @@ __global__ __launch_bounds__(kSchedThreads) void tile_schedule_kernel(int n_tile
     for (int t = max(hi, lo) + threadIdx.x; t < lo + chunk; t += kSchedThreads) tile_order[t] = -1;   // padding
 }
 
+// Start of a backward pass over the forward's lists: ONE launch zero-fills the gradient records (the sweep
+// accumulates into them with atomics) and, in its first eight workgroups, orders each band's tiles by the number of
+// records their four quadrants blended -- the exact work of the sweep, known since the forward pass (list length is
+// a poor proxy for it in a dense scene: the pixels saturate long before the lists end).
+constexpr int kPrepThreads = 1024, kPrepBuckets = 256;
+__global__ __launch_bounds__(kPrepThreads) void bwd_prepare_kernel(long n_rows, float4 *__restrict__ v_splat4, int n_tiles,
+                                                                   const int32_t *__restrict__ quad_count,
+                                                                   int32_t *__restrict__ tile_order) {
+    if (blockIdx.x >= 8) {   // kPrepThreads records of 64 B per workgroup, written as consecutive 16-B words
+        const long base = ((long)blockIdx.x - 8) * kPrepThreads * 4, end = 4 * n_rows;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long i = base + k * kPrepThreads + threadIdx.x;
+            if (i < end) v_splat4[i] = z;
+        }
+        return;
+    }
+    __shared__ int cnt[kPrepBuckets], first[kPrepBuckets];
+    const int chunk = (n_tiles + 7) >> 3;
+    const int lo = blockIdx.x * chunk, hi = min(n_tiles, lo + chunk);
+    if (threadIdx.x < kPrepBuckets) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    auto bucket = [&](int t) {
+        const int4 w = *reinterpret_cast<const int4 *>(quad_count + 4 * (long)t);
+        return kPrepBuckets - 1 - min(kPrepBuckets - 1, (w.x + w.y + w.z + w.w) >> 2);   // bucket 0 = most work
+    };
+    for (int t = lo + threadIdx.x; t < hi; t += kPrepThreads) atomicAdd(&cnt[bucket(t)], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int k = 0; k < kPrepBuckets; ++k) { first[k] = run; run += cnt[k]; }
+    }
+    __syncthreads();
+    for (int t = lo + threadIdx.x; t < hi; t += kPrepThreads) tile_order[lo + atomicAdd(&first[bucket(t)], 1)] = t;
+    for (int t = max(hi, lo) + threadIdx.x; t < lo + chunk; t += kPrepThreads) tile_order[t] = -1;   // padding
+}
+
 }  // namespace
+
+extern "C" int gsa_composite_bwd_prepare(long long n, float *v_splat, int n_tiles, const int32_t *quad_count,
+                                         int32_t *tile_order, gsa_stream_t stream) {
+    GSA_RETURN_IF(n < 0 || n_tiles <= 0 || !quad_count || !tile_order || (n > 0 && !v_splat), GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(((reinterpret_cast<uintptr_t>(v_splat) | reinterpret_cast<uintptr_t>(quad_count)) & 15) != 0,
+                  GSA_ERR_INVALID_ARGUMENT);
+    const long grid = 8 + (n + kPrepThreads - 1) / kPrepThreads;
+    bwd_prepare_kernel<<<(unsigned)grid, kPrepThreads, 0, static_cast<hipStream_t>(stream)>>>(
+        (long)n, reinterpret_cast<float4 *>(v_splat), n_tiles, quad_count, tile_order);
+    GSA_LAUNCH_CHECK();
+    return GSA_OK;
+}
 
 extern "C" int gsa_tile_schedule(int n_tiles, const int32_t *tile_offsets, int32_t *tile_order, gsa_stream_t stream) {
     GSA_RETURN_IF(n_tiles <= 0 || !tile_offsets || !tile_order, GSA_ERR_INVALID_ARGUMENT);

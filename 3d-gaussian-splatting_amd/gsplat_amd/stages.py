@@ -324,13 +324,20 @@ def composite_bwd(splat, sorted_gid, tile_offsets, background, final_T, last_id,
     """-> v_splat [N,16]: per gaussian the raw moments of u = d loss / d sigma over d = mean2d - pixel
     (sum u dx, u dy, u dx^2, u dx dy, u dy^2, u) and sum fac * v_out per channel -- the gradient record
     ``project_bwd`` consumes (``moments_to_record_grads`` gives the mean / conic / opacity gradients)."""
-    v_splat = torch.zeros_like(splat)
     if quad_lists is not None:   # sweep the forward pass's lists of blended records (same result, fewer visits)
         quad_list, quad_count = quad_lists
+        # one launch: zero the gradient records and order the tiles by the work the lists hold (exact, unlike the
+        # list lengths `tile_order` was built from before the forward pass)
+        v_splat = torch.empty_like(splat)
+        tile_w, tile_h = tile_grid(width, height)
+        tile_order = torch.empty(8 * ((tile_w * tile_h + 7) // 8), dtype=torch.int32, device=splat.device)
+        _call("gsa_composite_bwd_prepare", lib.gsa_composite_bwd_prepare, splat.shape[0], _ptr(v_splat), tile_w * tile_h,
+              _ptr(quad_count), _ptr(tile_order), _stream())
         _call("gsa_composite_bwd", lib.gsa_composite_bwd_lists, width, height, channels, _ptr(splat), _ptr(sorted_gid),
               _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(final_T), _ptr(last_id), _ptr(v_render),
               _ptr(v_alpha), _ptr(quad_list), _ptr(quad_count), _ptr(v_splat), _stream())
         return v_splat
+    v_splat = torch.zeros_like(splat)
     _call("gsa_composite_bwd", lib.gsa_composite_bwd, width, height, channels, _ptr(splat), _ptr(sorted_gid),
           _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(final_T), _ptr(last_id), _ptr(v_render),
           _ptr(v_alpha), _ptr(v_splat), _stream())

@@ -240,8 +240,8 @@ def main() -> None:
         # per C-ABI stage: average device time per step (binning = sorts + scan + emit + offsets)
         per = {}
         for name, (calls, total) in stage_ms.items():
-            key = name if name in alg or name == "exchange" else (
-                "sh_grad_rebuild" if name == "gsa_sh_grad_expand" else "binning")   # (exchange includes the rebuild)
+            other = {"gsa_sh_grad_expand": "sh_grad_rebuild", "gsa_composite_bwd_prepare": "bwd_prepare"}
+            key = name if name in alg or name == "exchange" else other.get(name, "binning")   # (exchange incl. rebuild)
             per[key] = per.get(key, 0.0) + total / args.steps
         # the dominant KERNEL: "binning" is a stage of ~24 short launches (sorts, scan, emit, offsets), the other
         # four stages are one kernel launch each

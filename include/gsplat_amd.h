@@ -180,6 +180,12 @@ int gsa_composite_bwd(int width, int height, int channels, const float *splat,
                       const int32_t *tile_order, const float *final_T, const int32_t *last_id,
                       const float *v_render, const float *v_alpha, float *v_splat, gsa_stream_t stream);
 
+/* First launch of a backward pass over the forward's lists: zero-fills v_splat[N,16] (the sweep accumulates into it) and
+ * writes the launch order for gsa_composite_bwd_lists -- per tile band, the tiles whose quadrants blended the most
+ * records first (tile_order[8 * ceil(n_tiles / 8)], as gsa_tile_schedule). */
+int gsa_composite_bwd_prepare(long long n, float *v_splat, int n_tiles, const int32_t *quad_count,
+                              int32_t *tile_order, gsa_stream_t stream);
+
 /* gsa_composite_bwd over the per-quadrant lists of blended records the forward pass left (quad_list / quad_count of
  * gsa_composite_fwd): same result, but no reach test and no record that blends nowhere in the quadrant (in a dense
  * scene ~10 % of what the plain sweep walks), in full batches of 64. */
