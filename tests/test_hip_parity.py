@@ -523,6 +523,41 @@ def test_grad_accumulate_sums_views_into_one_bucket(gsa, deg):
         gsa.rasterization(*base, views[0], K, W, H, sh_degree=deg, grad_accumulate=True)
 
 
+def test_random_shapes_fused_paths_agree_with_plain_ones(gsa):
+    """Twelve seeded random (image size, gaussian count, scale range, camera) combinations -- odd sizes, images smaller
+    than a tile, partial border tiles, one- and two-digit tile grids: the fused binning equals emit + sort bit for
+    bit, the forward image does not depend on the list option, and the backward sweep over the lists equals the plain
+    one up to the order of the float atomics."""
+    from gsplat_amd import scene, stages as S
+    rng = np.random.default_rng(2024)
+    for trial in range(12):
+        W, H = int(rng.integers(9, 700)), int(rng.integers(5, 400))
+        N = int(rng.integers(50, 20_000))
+        s_max = float(10 ** rng.uniform(-2.0, -0.3))
+        sc = _scene(N, seed=100 + trial, s_min=s_max * 0.05, s_max=s_max)
+        vm, K = scene.make_camera(int(rng.integers(0, 9)), 9).cuda(), scene.make_intrinsics(W, H).cuda()
+        d = {k: v.cuda().contiguous() for k, v in sc.items()}
+        splat, radii, tiles, keys, rects = S.project_fwd(d["means3D"], d["rotations"], d["scales"],
+                                                         d["opacities"][:, 0].contiguous(), d["shs"], 3, vm, K, W, H, 0,
+                                                         return_rects=True)
+        a = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, fused=False)
+        b = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, fused=True, tile_rects=rects)
+        tag = (trial, W, H, N, s_max)
+        assert a.finalize()[0] == b.finalize()[0] == int(tiles.sum()), tag
+        assert torch.equal(b.sorted_gid, a.sorted_gid) and torch.equal(b.tile_offsets, a.tile_offsets), tag
+        assert torch.equal(S.tile_ids(b.sorted_tile), S.tile_ids(a.sorted_tile)), tag
+        bg = torch.tensor([0.2, 0.4, 0.6]).cuda()
+        gid, offs = b.sorted_gid_buffer, b.tile_offsets
+        r0, a0, T0, l0 = S.composite_fwd(splat, gid, offs, bg, W, H, 3)
+        r1, a1, T1, l1, lists = S.composite_fwd(splat, gid, offs, bg, W, H, 3, S.tile_schedule(offs, W, H), want_lists=True)
+        assert torch.equal(r0, r1) and torch.equal(T0, T1) and torch.equal(a0, a1), tag
+        v_r = torch.from_numpy(rng.uniform(-1, 1, (H, W, 3)).astype(np.float32)).cuda()
+        g0 = S.composite_bwd(splat, gid, offs, bg, T0, l0, v_r, None, W, H, 3)
+        g1 = S.composite_bwd(splat, gid, offs, bg, T1, l1, v_r, None, W, H, 3, quad_lists=lists)
+        scale = g0.abs().amax(0).clamp_min(1e-30)
+        assert float(((g0 - g1).abs().amax(0) / scale).max()) < 5e-5, tag
+
+
 @pytest.mark.parametrize("W,H,N,cull_mode,channels", [(640, 360, 20_000, 0, 3), (250, 130, 3000, 1, 4),
                                                        (1920, 1080, 60_000, 0, 3)])
 def test_backward_sweep_over_blended_record_lists(gsa, W, H, N, cull_mode, channels):
