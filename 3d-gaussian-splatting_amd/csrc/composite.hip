@@ -550,15 +550,29 @@ __device__ __forceinline__ void walk_bwd(const Staged<F4> &st, int n, int lane, 
             if (CH == 4) v[36 + e] = fac * vout[CH - 1];
         }
         // one transpose-reduce and one atomic instruction (four 64-B requests) per FOUR records
+#ifdef GSA_EXP_NOREDUCE   // ablation (profiles/r02_bwd_ablation.md): per-pixel math kept alive, no cross-lane sum
+#pragma unroll
+        for (int k = 0; k < 4 * NF; ++k) asm volatile("" ::"v"(v[k]));
+        const float total = v[0];
+#else
         const float total = reduce_quad<NF>(v, lane);
+#endif
         // this lane's record: e = 2 b2 + b3 -> its list entry -> the gaussian id stored with the staged record
         const uint32_t word = (lane & 4) ? o4.y : o4.x;
         const uint32_t my_off = (lane & 8) ? word >> 16 : word & 0xFFFFu;
         const int e = ((lane >> 2) & 1) * 2 + ((lane >> 3) & 1);
+#ifdef GSA_EXP_NOATOMIC   // ablation: everything but the atomic instruction (the sum stays alive)
+        asm volatile("" ::"v"(total), "v"(my_off), "v"(e));
+#else
         if (my_add && i + e < n) {
             const uint32_t g = __float_as_uint(rec_at(st, my_off)[2].w);
+#ifdef GSA_EXP_STORE      // ablation: a plain store in the atomic's place (wrong sums; prices the atomic itself)
+            v_splat[(size_t)g * GSA_SPLAT_STRIDE + my_field] = total;
+#else
             atomicAdd(v_splat + (size_t)g * GSA_SPLAT_STRIDE + my_field, total);
+#endif
         }
+#endif
     }
 }
 

@@ -3,7 +3,8 @@
 Counterpart of the reference's per-step logic -- ``GaussianTrainer._training_step``
 (/root/reference/src/training/trainer.py:447-519) with its helpers ``_gaussian_params`` (:399-406),
 ``_stclamp`` (:102-107), ``_compute_ssim`` (:354-371), ``_psnr`` (:70-75), ``_scale_ratio_reg`` (:434-445),
-``_setup_optimizer`` (:331-340), ``_update_learning_rate`` (:373-382), ``_active_sh_degree`` (:77-87) -- written
+``_setup_optimizer`` (:331-340), ``_update_learning_rate`` (:373-382), ``_active_sh_degree`` (:77-87) -- and of the
+optimisation loop around it (``GaussianTrainer.train``, trainer.py:782-859: ``ViewParallelTrainer.run``) -- written
 for one-process-per-GPU execution:
 
 * the six parameter tensors of the scene model (/root/reference/src/gaussians/gaussian_model.py:59-88) are views
@@ -46,6 +47,25 @@ class StepConfig:
     position_lr_max_steps: float = 3e5
 
 
+@dataclass
+class LoopConfig:
+    """The fields of the reference's ``TrainingConfig`` that shape the loop around the step
+    (/root/reference/src/gaussians/training_config.py:21-39,54); same defaults.  ``densify_after`` is the constant
+    the reference hard-codes (``self.iteration > 5000``, trainer.py:795)."""
+    iterations: int = 300_000
+    densify_after: int = 5000
+    densify_interval: int = 100
+    opacity_reset_interval: int = 5000
+    opacity_reset_ceiling: float = 0.01
+    densify_grads_threshold: float = 5e-4
+    densify_min_opacity: float = 0.005
+    densify_max_screen_size: float = 12.0
+    densify_clone_extent_ratio: float = 0.1
+    densify_prune_extent_ratio: float = 2.0
+    scale_clamp_ratio: float = 0.2
+    max_gaussians: int = 10_000_000
+
+
 class SplatModel:
     """Scene parameters with the reference model's names, shapes and activations
     (gaussian_model.py:59-108), stored as views of one flat buffer (+ one flat gradient bucket)."""
@@ -82,7 +102,8 @@ class SplatModel:
         self.xyz_gradient_count += 1
 
     @torch.no_grad()
-    def densify_and_prune(self, grads_threshold: float, min_opacity: float, extent: float, optimizer=None,
+    def densify_and_prune(self, grads_threshold: float, min_opacity: float, extent: float,
+                          max_screen_size: Optional[float] = None, optimizer=None,
                           clone_extent_ratio: float = 0.1, prune_extent_ratio: float = 2.0,
                           max_gaussians: Optional[int] = None, noise: Optional[torch.Tensor] = None) -> Dict:
         """Counterpart of ``GaussianModel.densify_and_prune`` (gaussian_model.py:110-231) with the same selection
@@ -90,7 +111,9 @@ class SplatModel:
         population ([survivors] + [clones] + [first children] + [second children], minus the pruned rows), and
         ``gsa_densify_gather`` builds the new 59 N' bucket and both Adam moment buckets from it.
         ``noise``: [2 * n_split, 3] standard-normal draws for the split offsets (gaussian_model.py:302; default:
-        drawn on the device).  ``optimizer``: ``FusedBucketAdam`` or ``torch.optim.Adam`` over this model, or None."""
+        drawn on the device).  ``optimizer``: ``FusedBucketAdam`` or ``torch.optim.Adam`` over this model, or None.
+        ``max_screen_size`` is accepted in the reference's position (its loop passes it by keyword, trainer.py:798-807)
+        and, as in the reference's body, not used."""
         from . import stages as S
         if not self.flat.is_cuda:
             raise RuntimeError("SplatModel.densify_and_prune runs on the HIP device only (no CPU path)")
@@ -123,6 +146,8 @@ class SplatModel:
         src = torch.cat([idx_keep, idx_clone, idx_split, idx_split])
         kind = torch.cat([torch.zeros_like(idx_keep), torch.ones_like(idx_clone),
                           torch.full((2 * n_split,), 2, dtype=idx_split.dtype, device=dev)])
+        if isinstance(noise, _LazyNoise):
+            noise = noise.draw(n_split)
         if noise is None:
             noise = torch.randn(2 * n_split, 3, device=dev)
         noise = noise.to(dev, torch.float32).reshape(2 * n_split, 3)
@@ -172,6 +197,34 @@ class SplatModel:
 
     def parameters(self) -> List[torch.Tensor]:
         return [getattr(self, name) for name, _ in FIELDS]
+
+    def check_bound(self) -> None:
+        """Every parameter (and its gradient) must still be a view of the flat buckets: the fused Adam step, the
+        exchange and the densify gather work on ``flat`` / ``flat_grad``.  Rebinding ``p.data`` -- what the reference's
+        opacity reset does (trainer.py:850) -- detaches a parameter silently; use ``reset_opacity`` /
+        ``clamp_scaling`` (in place) instead."""
+        off, item = 0, self.flat.element_size()
+        for name, shape in FIELDS:
+            p = getattr(self, name)
+            cnt = self.n * math.prod(shape)
+            if p.data_ptr() != self.flat.data_ptr() + off * item or p.numel() != cnt:
+                raise RuntimeError(f"SplatModel.{name} no longer lives in the flat parameter bucket (was .data rebound?)")
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + off * item:
+                raise RuntimeError(f"SplatModel.{name}.grad no longer lives in the flat gradient bucket")
+            off += cnt
+
+    @torch.no_grad()
+    def reset_opacity(self, ceiling: float = 0.01) -> None:
+        """The reference's periodic opacity reset (trainer.py:841-850): every opacity becomes min(current, ceiling),
+        clamped to [1e-6, 1 - 1e-6] before the inverse sigmoid -- written IN PLACE into the bucket view."""
+        current = torch.sigmoid(self.opacity)
+        target = torch.minimum(current, torch.full_like(current, ceiling)).clamp(min=1e-6, max=1.0 - 1e-6)
+        self.opacity.copy_(torch.logit(target))
+
+    @torch.no_grad()
+    def clamp_scaling(self, extent: float, scale_clamp_ratio: float) -> None:
+        """The reference's per-step ceiling on the log-scale (trainer.py:857-859), in place."""
+        self.scaling.clamp_(max=math.log(extent * scale_clamp_ratio + 1e-9))
 
     @torch.no_grad()
     def load(self, **tensors: torch.Tensor) -> "SplatModel":
@@ -233,6 +286,16 @@ def view_loss(rendered: torch.Tensor, target: torch.Tensor, lambda_dssim: float)
     # off by more than its own magnitude; exact once the view is made contiguous).  Same values either way.
     ssim = ssim_3x3(img.permute(2, 0, 1)[None].contiguous(), target.permute(2, 0, 1)[None].contiguous())
     return (1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - ssim), l1, ssim
+
+
+class _LazyNoise:
+    """Split noise that is drawn once the number of split gaussians is known (``ViewParallelTrainer.run``)."""
+
+    def __init__(self, fn, iteration: int):
+        self.fn, self.iteration = fn, iteration
+
+    def draw(self, n_split: int) -> torch.Tensor:
+        return self.fn(self.iteration, n_split)
 
 
 def _adam_groups(model: SplatModel, c: StepConfig):
@@ -329,6 +392,57 @@ class ViewParallelTrainer:
             if group.get("name") == "xyz":
                 group["lr"] = lr
         return lr
+
+    def run(self, loader, extent: float, loop: Optional[LoopConfig] = None, split_noise=None, on_step=None) -> SplatModel:
+        """The reference's optimisation loop (``GaussianTrainer.train``, trainer.py:782-859 and :989) from
+        ``self.iteration`` up to ``loop.iterations``, in the reference's order per iteration:
+
+          1. ``batch = next(loader)``; ``training_step(batch)``                                   (:783-784)
+          2. xyz-gradient accumulation from the EXCHANGED gradient                                (:786-791)
+          3. densify / prune when ``iteration > densify_after and iteration % densify_interval == 0`` (:794-807)
+          4. opacity reset when ``iteration % opacity_reset_interval == 0 and iteration > 0``     (:841-850)
+          5. learning-rate update                                                                 (:852)
+          6. scale clamp                                                                          (:857-859)
+          7. ``iteration += 1``                                                                   (:989)
+
+        ``loader``: an iterator of view batches -- the SAME sequence on every rank.  ``extent``: the scene extent the
+        thresholds scale with (trainer.py:659-661).  ``split_noise(iteration, n_split) -> [2 n_split, 3]``: the
+        standard-normal draws of a densify event; by default drawn on the device from a generator seeded with the
+        iteration, hence identical on every rank (the reference draws from the global generator,
+        gaussian_model.py:302).  ``on_step(iteration, n_before_step, metrics, densify_stats or None)`` is called after
+        every iteration (logging / tests).  Steady state has no host wait besides the step's metric read-back;
+        a densify event reads back the population counts, as the reference does."""
+        loop = loop or LoopConfig()
+        m = self.model
+        while self.iteration < loop.iterations:
+            m.check_bound()
+            batch = next(loader)
+            n_before = m.n
+            metrics = self.training_step(batch)
+            m.accumulate_xyz_grad()
+            stats = None
+            if self.iteration > loop.densify_after and self.iteration % loop.densify_interval == 0:
+                noise_fn = split_noise if split_noise is not None else self._default_split_noise
+                stats = m.densify_and_prune(
+                    grads_threshold=loop.densify_grads_threshold, min_opacity=loop.densify_min_opacity, extent=extent,
+                    max_screen_size=loop.densify_max_screen_size, optimizer=self.optimizer,
+                    clone_extent_ratio=loop.densify_clone_extent_ratio,
+                    prune_extent_ratio=loop.densify_prune_extent_ratio, max_gaussians=int(loop.max_gaussians),
+                    noise=_LazyNoise(noise_fn, self.iteration))
+            if self.iteration % loop.opacity_reset_interval == 0 and self.iteration > 0:
+                m.reset_opacity(loop.opacity_reset_ceiling)
+            self.update_learning_rate()
+            m.clamp_scaling(extent, loop.scale_clamp_ratio)
+            if on_step is not None:
+                on_step(self.iteration, n_before, metrics, stats)
+            self.iteration += 1
+        return m
+
+    def _default_split_noise(self, iteration: int, n_split: int) -> torch.Tensor:
+        dev = self.model.flat.device
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(0x5EED0000 + int(iteration))
+        return torch.randn(2 * n_split, 3, device=dev, generator=gen)
 
     def _all_reduce(self, t: torch.Tensor, async_op: bool = False):
         if self.world > 1:

@@ -58,9 +58,11 @@ def save_checkpoint(path: str, model: SplatModel, optimizer=None, iteration: Opt
                     "optimizer_state": _optimizer_state_dict(model, optimizer), "n_gaussians": model.n}, path)
 
 
-def load_state(path: str) -> Tuple[Dict[str, torch.Tensor], dict]:
-    """-> (model state dict, the wrapper's other entries); accepts bare and wrapped files (eval.py:24-38)."""
-    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+def load_state(path: str, allow_pickle: bool = False) -> Tuple[Dict[str, torch.Tensor], dict]:
+    """-> (model state dict, the wrapper's other entries); accepts bare and wrapped files (eval.py:24-38).
+    Both formats hold only tensors, numbers and plain containers, so the file is read with ``weights_only=True``
+    (no arbitrary unpickling); ``allow_pickle=True`` is the explicit opt-in for a trusted file that needs more."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=not allow_pickle)
     extra = {}
     if isinstance(ckpt, dict):
         for k in ("model_state", "state_dict"):

@@ -44,6 +44,10 @@ TIMER = StageTimer()
 
 def _call(name: str, fn, *args) -> None:
     """Launch one C-ABI stage on the current stream; raise on a non-zero return code."""
+    if _GUARD_DEVICE[0] is not None and torch.cuda.current_device() != _GUARD_DEVICE[0]:
+        raise RuntimeError(f"gsplat_amd: {name} was given tensors on cuda:{_GUARD_DEVICE[0]} while the current device is "
+                           f"cuda:{torch.cuda.current_device()}; launches go to the current device's stream -- call "
+                           "torch.cuda.set_device(tensor.device) (one process per GPU) or use torch.cuda.device(...)")
     if TIMER.enabled:
         start = torch.cuda.Event(enable_timing=True)
         start.record()
@@ -54,8 +58,17 @@ def _call(name: str, fn, *args) -> None:
         TIMER.records.append((name, start, end))
 
 
+_GUARD_DEVICE = [None]   # index of the device the tensors of the stage being launched live on (set by _ptr)
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
-    return None if t is None else t.data_ptr()
+    """Device pointer of a tensor argument; notes its device so that ``_call`` can refuse a launch whose tensors are
+    not on the current device (the stream handed to the library is the CURRENT device's)."""
+    if t is None:
+        return None
+    if t.is_cuda:
+        _GUARD_DEVICE[0] = t.device.index
+    return t.data_ptr()
 
 
 def _stream() -> int:
@@ -74,14 +87,20 @@ def tile_grid(width: int, height: int) -> Tuple[int, int]:
 
 
 _PINNED = {}
+_PINNED_SLOTS = 16   # record-count read-backs that may be in flight per device before a slot is reused
 
 
 def _pinned_scalar(dev):
-    """One pinned int32 + event per device for the record-count read-back (allocated once)."""
+    """A pinned int32 + event for ONE record-count read-back: every ``TileBins`` gets its own slot of a small ring per
+    device (allocated once), so bins that are finalized late or out of order -- a deeper look-ahead, stage-level use,
+    two host threads -- never read another view's count."""
     key = (dev.type, dev.index)
     if key not in _PINNED:
-        _PINNED[key] = (torch.empty(1, dtype=torch.int32, pin_memory=True), torch.cuda.Event())
-    return _PINNED[key]
+        _PINNED[key] = [torch.empty(_PINNED_SLOTS, dtype=torch.int32, pin_memory=True),
+                        [torch.cuda.Event() for _ in range(_PINNED_SLOTS)], 0]
+    words, events, nxt = _PINNED[key]
+    _PINNED[key][2] = (nxt + 1) % _PINNED_SLOTS
+    return words[nxt:nxt + 1], events[nxt]
 
 
 def project_fwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat, Kmat, width: int, height: int,
@@ -122,9 +141,9 @@ class TileBins:
     """Result of ``bin_tiles``: record buffers sized for a CAPACITY, the live record count on the device, and
     ``finalize()`` which the caller runs after it has queued the work that consumes the bins."""
 
-    def __init__(self, sorted_tile, sorted_gid, tile_offsets, capacity, m_known, key):
+    def __init__(self, sorted_tile, sorted_gid, tile_offsets, capacity, m_known, key, slot=None, n=0):
         self._tile, self._gid, self.tile_offsets = sorted_tile, sorted_gid, tile_offsets
-        self.capacity, self._m, self._key = capacity, m_known, key
+        self.capacity, self._m, self._key, self._slot, self._n = capacity, m_known, key, slot, n
 
     @property
     def sorted_gid_buffer(self):   # what the compositor kernels read (they only follow tile_offsets)
@@ -134,10 +153,10 @@ class TileBins:
         """-> (M, ok).  Waits for the record count (copied to pinned memory right after the scan, long finished by
         the time the compositor has been queued) and checks it against the capacity the kernels ran with."""
         if self._m is None:
-            m_host, m_event = _pinned_scalar(self._gid.device)
+            m_host, m_event = self._slot
             m_event.synchronize()
-            self._m = int(m_host[0])
-            _note_count(self._key, self._m)
+            self._m = int(m_host[0]) & 0xFFFFFFFF
+            _note_count(self._key, self._n, self._m)
         return self._m, self._m <= self.capacity
 
     def __iter__(self):   # sorted_tile, sorted_gid, tile_offsets = bin_tiles(...)
@@ -159,13 +178,38 @@ def tile_ids(sorted_tile: torch.Tensor) -> torch.Tensor:
 
 
 _BIN_FUSED_DEFAULT = os.environ.get("GSPLAT_AMD_BIN_FUSED", "1") != "0"
-_CAPACITY = {}   # (device, N, W, H, cull_mode) -> record capacity the next call allocates (tracks the scene)
+# (device, W, H, cull_mode) -> [records per gaussian the next call provisions for, consecutive low counts].
+# Keyed WITHOUT N: densify / prune changes N every 100 iterations (trainer.py:794-797) and a changed N predicts its
+# capacity from the remembered ratio instead of costing a blocking read-back.  Grows at once, shrinks only after many
+# consecutive low counts (the views of one batch differ; alternating shrink / miss would re-run the binning).
+_CAPACITY = {}
+_CAPACITY_MAX_KEYS = 64
+_SHRINK_AFTER = 32
 
 
-def _note_count(key, m: int) -> None:
-    cap = _CAPACITY.get(key, 0)
-    if m > 0.9 * cap or m < 0.4 * cap:   # keep ~25 % head-room; shrink when the scene got much smaller
-        _CAPACITY[key] = max(4096, int(m * 1.25) + 1024)
+def _capacity_for(key, n: int) -> Optional[int]:
+    ent = _CAPACITY.get(key)
+    if ent is None:
+        return None
+    return max(4096, int(ent[0] * max(n, 1) * 1.25) + 1024)
+
+
+def _note_count(key, n: int, m: int) -> None:
+    ratio = m / max(n, 1)
+    ent = _CAPACITY.get(key)
+    if ent is None:
+        while len(_CAPACITY) >= _CAPACITY_MAX_KEYS:      # bounded: forget the oldest scene shape
+            _CAPACITY.pop(next(iter(_CAPACITY)))
+        _CAPACITY[key] = [ratio, 0]
+    elif ratio > ent[0]:                                 # grow immediately (the head-room absorbs small growth)
+        ent[0], ent[1] = ratio, 0
+    elif ratio < 0.5 * ent[0]:
+        ent[1] += 1
+        if ent[1] >= _SHRINK_AFTER:
+            ent[0], ent[1] = ratio, 0
+    else:
+        ent[0] = max(ratio, 0.98 * ent[0])               # decayed maximum
+        ent[1] = 0
 
 
 def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, cull_mode: int = 0,
@@ -182,7 +226,7 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
     tile_w, tile_h = tile_grid(width, height)
     n_tiles = tile_w * tile_h
     st = _stream()
-    key = (dev.type, dev.index, N, width, height, cull_mode)
+    key = (dev.type, dev.index, width, height, cull_mode)
     _, order = sort_pairs(N, depth_keys, None, 0, 32)  # ties keep index order; culled gaussians sort last
     offsets = torch.empty(N, dtype=torch.int32, device=dev)
     total = torch.empty(1, dtype=torch.int32, device=dev)
@@ -195,7 +239,7 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
         raise ValueError("bin_tiles(fused=True): needs cull_mode 0 and a tile grid gsa_tile_bin16_supported accepts")
     if fused is None:   # (GSPLAT_AMD_BIN_FUSED=0: the emit + 32-bit sort path, kept for A/B timing)
         fused = can_fuse and _BIN_FUSED_DEFAULT
-    cap = None if exact else _CAPACITY.get(key)
+    cap = None if exact else _capacity_for(key, N)
     if fused:
         if tile_rects is None:   # callers that did not keep project_fwd's dense copy: word 11 of the records
             tile_rects = torch.stack([torch.where(tiles_touched > 0, splat[:, 11].contiguous().view(torch.int32), 0),
@@ -212,14 +256,15 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
     else:
         _call("gsa_scan_tiles", lib.gsa_scan_tiles, N, _ptr(tiles_touched), _ptr(order), _ptr(offsets), _ptr(total),
               _ptr(ws), ws_bytes, st)
-    m_host, m_event = _pinned_scalar(dev)
+    slot = _pinned_scalar(dev)
+    m_host, m_event = slot
     m_host.copy_(total, non_blocking=True)
     m_event.record()
     m_known = None
     if cap is None:
         m_event.synchronize()
         m_known = int(m_host[0]) & 0xFFFFFFFF
-        _note_count(key, m_known)
+        _note_count(key, N, m_known)
         cap = m_known
         if fused:   # first call of a scene shape / repair: the block table needs the count, scan once more
             block_owner = scan(cap)
@@ -236,7 +281,7 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
               height, cap,
               _ptr(total), _ptr(k_tmp), _ptr(v_tmp), _ptr(sorted_tile), _ptr(sorted_gid), _ptr(tile_offsets), _ptr(ws2),
               ws2_bytes, st)
-        return TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key)
+        return TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key, slot, N)
     isect_tile = torch.empty(cap, dtype=torch.int32, device=dev)
     isect_gid = torch.empty(cap, dtype=torch.int32, device=dev)
     _call("gsa_tile_emit", lib.gsa_tile_emit_dev, N, _ptr(order), _ptr(offsets), _ptr(splat), _ptr(radii), width,
@@ -254,7 +299,7 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
         sorted_tile, sorted_gid = isect_tile, isect_gid
     _call("gsa_tile_offsets", lib.gsa_tile_offsets_dev, cap, _ptr(total), _ptr(sorted_tile), n_tiles,
           _ptr(tile_offsets), st)
-    return TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key)
+    return TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key, slot, N)
 
 
 def tile_schedule(tile_offsets: torch.Tensor, width: int, height: int) -> torch.Tensor:

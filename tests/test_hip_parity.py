@@ -354,14 +354,44 @@ def test_record_capacity_miss_is_repaired(gsa):
         r0, a0, m0 = gsa.rasterization(*args, W, H, sh_degree=3)          # first call: exact sizes
         ids0 = m0["flatten_ids"].clone()
         r1, a1, m1 = gsa.rasterization(*args, W, H, sh_degree=3)          # steady state: capacity + device count
-        key = ("cuda", torch.cuda.current_device(), N, W, H, S.DEFAULT_CULL_MODE)
-        assert S._CAPACITY[key] >= m0["n_isects"]
-        S._CAPACITY[key] = m0["n_isects"] // 3                             # pretend the scene grew threefold
+        key = ("cuda", torch.cuda.current_device(), W, H, S.DEFAULT_CULL_MODE)
+        assert S._capacity_for(key, N) >= m0["n_isects"]
+        S._CAPACITY[key][0] = m0["n_isects"] / N / 3                       # pretend the scene grew threefold
         r2, a2, m2 = gsa.rasterization(*args, W, H, sh_degree=3)
     for r, a, m in ((r1, a1, m1), (r2, a2, m2)):
         assert torch.equal(r, r0) and torch.equal(a, a0)
         assert m["n_isects"] == m0["n_isects"] and torch.equal(m["flatten_ids"], ids0)
-    assert S._CAPACITY[key] >= m0["n_isects"]                              # the miss re-learned the capacity
+    assert S._capacity_for(key, N) >= m0["n_isects"]                       # the miss re-learned the capacity
+
+
+def test_population_change_keeps_the_pipeline_asynchronous(gsa):
+    """Densify / prune changes N every 100 iterations (/root/reference/src/training/trainer.py:794-797): the record
+    capacity is remembered per scene SHAPE as records per gaussian, so a population 5 % larger or smaller is binned
+    without a blocking read-back (no exact-size pass, no second scan), and the cache stays bounded."""
+    from gsplat_amd import scene, stages as S
+    W, H, N = 320, 200, 20_000
+    sc = _scene(N + N // 20, seed=3, s_min=0.005, s_max=0.08)
+    K, vm = scene.make_intrinsics(W, H).cuda(), scene.make_camera(1, 5).cuda()
+    key = ("cuda", torch.cuda.current_device(), W, H, 0)
+    S._CAPACITY.pop(key, None)
+
+    def bins(n):
+        t = [sc[k][:n].cuda().contiguous() for k in ("means3D", "rotations", "scales", "opacities", "shs")]
+        splat, radii, tiles, keys, rects = S.project_fwd(t[0], t[1], t[2], t[3][:, 0].contiguous(), t[4], 3, vm, K, W, H, 0,
+                                                         return_rects=True)
+        return S.bin_tiles(splat, radii, tiles, keys, W, H, 0, tile_rects=rects), int(tiles.sum())
+
+    first, m = bins(N)
+    assert first._m == m                        # first call of a shape: the one blocking read-back (exact sizes)
+    for n in (N + N // 20, N - N // 20, N):
+        b, m = bins(n)
+        assert b._m is None, "a changed population must not cost a blocking read-back"
+        assert b.capacity >= m and b.finalize() == (m, True)
+    assert len(S._CAPACITY) <= S._CAPACITY_MAX_KEYS
+    # two bins left un-finalized have their own read-back slots
+    b1, m1 = bins(N)
+    b2, m2 = bins(N - N // 20)
+    assert m1 != m2 and b2.finalize()[0] == m2 and b1.finalize()[0] == m1
 
 
 @pytest.mark.parametrize("mode", ["D", "ED", "RGB+D", "RGB+ED"])
@@ -632,9 +662,12 @@ def test_fused_binning_equals_emit_and_sort(gsa, W, H, N, s_max, giants):
     c = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, fused=True)
     assert c.finalize() == (m, True)
     assert torch.equal(c.sorted_gid, a.sorted_gid) and torch.equal(c.tile_offsets, a.tile_offsets)
-    key = ("cuda", torch.cuda.current_device(), N, W, H, 0)
-    S._CAPACITY[key] = max(1, m // 3)                      # too small: kernels clamp to it, finalize() says so
-    t = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, fused=True)
+    real = S._capacity_for
+    S._capacity_for = lambda key, n: max(1, m // 3)        # too small: kernels clamp to it, finalize() says so
+    try:
+        t = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, fused=True)
+    finally:
+        S._capacity_for = real
     assert t.finalize() == (m, False) and int(t.tile_offsets.max()) <= t.capacity
     e = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, fused=True)
     assert torch.equal(e.sorted_gid, a.sorted_gid) and torch.equal(e.tile_offsets, a.tile_offsets)
