@@ -146,8 +146,8 @@ class SplatModel:
         src = torch.cat([idx_keep, idx_clone, idx_split, idx_split])
         kind = torch.cat([torch.zeros_like(idx_keep), torch.ones_like(idx_clone),
                           torch.full((2 * n_split,), 2, dtype=idx_split.dtype, device=dev)])
-        if isinstance(noise, _LazyNoise):
-            noise = noise.draw(n_split)
+        if isinstance(noise, _LazyNoise):   # (the reference draws nothing when no gaussian is split, :288-289)
+            noise = noise.draw(n_split) if n_split else torch.zeros(0, 3, device=dev)
         if noise is None:
             noise = torch.randn(2 * n_split, 3, device=dev)
         noise = noise.to(dev, torch.float32).reshape(2 * n_split, 3)

@@ -9,6 +9,9 @@ Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+``python bench.py --gpus N`` with N > 1 and no launcher environment starts the N ranks itself (a child
+``torch.distributed.run`` on 127.0.0.1, before this process touches the GPU) and relays rank 0's JSON line.
 """
 
 from __future__ import annotations
@@ -16,6 +19,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -101,6 +106,70 @@ def cpu_baseline(n: int, width: int, height: int, sh_degree: int, crop=(1280, 72
                       f"oracle (tile batches checkpointed), 1 run of {dt:.1f} s, M={meta['flatten_ids'].numel()}"}
 
 
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_protocol():
+    """BASELINE.md section 3 / SURVEY.md section 8d: the CPU oracle at C1 and C2 sizes, forward-only and
+    forward+backward, 1 warm-up + median of 5, Mpix/s, with the core count and CPU model."""
+    from gsplat_amd import scene
+    from oracle import rasterization as oracle_rasterization
+
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    rows = {}
+    for name, (n, w, h, deg) in (("C1", (10_000, 256, 256, 0)), ("C2", WORKLOADS["C2"])):
+        sc = scene.make_scene(n, seed=0, sh_degree=deg)
+        K, vm, v = scene.make_intrinsics(w, h), scene.make_camera(0, 1), scene.make_v_render(w, h)
+        for mode in ("fwd", "fwd+bwd"):
+            times = []
+            for _ in range(6):
+                grad = mode == "fwd+bwd"
+                leaves = [sc[k].clone().requires_grad_(grad) for k in ("means3D", "rotations", "scales", "opacities", "shs")]
+                t0 = time.perf_counter()
+                with torch.set_grad_enabled(grad):
+                    r, _, meta = oracle_rasterization(leaves[0], leaves[1], leaves[2], leaves[3][:, 0], leaves[4], vm[None],
+                                                      K[None], w, h, sh_degree=deg, backgrounds=torch.zeros(1, 3),
+                                                      checkpoint=grad)
+                    if grad:
+                        (r[0] * v).sum().backward()
+                times.append(time.perf_counter() - t0)
+            med = sorted(times[1:])[2]
+            rows[f"{name}_{mode}"] = {"Mpix/s": round(w * h / med / 1e6, 4), "median_s": round(med, 3),
+                                      "M": int(meta["flatten_ids"].numel())}
+    return {"what": "CPU restatement of the reference's gsplat contract (oracle/, torch fp32) -- a reported baseline, "
+                    "not the target; 1 warm-up + median of 5", "cores": cores, "cpu_model": cpu_model(), "runs": rows}
+
+
+def self_launch(args) -> int:
+    """``--gpus N`` without a launcher environment: start N ranks with torch.distributed.run as a CHILD process
+    (nothing in this process has touched the GPU yet), relay its output, return its exit code."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print(f"[bench] WORLD_SIZE unset: launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def percentiles(xs):
+    xs = sorted(xs)
+    pick = lambda q: xs[min(len(xs) - 1, max(0, int(round(q * (len(xs) - 1)))))]  # noqa: E731
+    return {"mean": round(sum(xs) / len(xs), 4), "median": round(pick(0.5), 4), "p10": round(pick(0.1), 4),
+            "p90": round(pick(0.9), 4)}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,11 +182,13 @@ def main() -> None:
                     help="N > 1: how ranks sum the gaussian gradients (see DESIGN.md section 6)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size must equal --gpus")
     # "nccl" is RCCL; GSPLAT_AMD_BENCH_BACKEND=gloo only exists to rehearse the N > 1 code path on a one-GPU box
     # (the ranks then share the card)
     backend = os.environ.get("GSPLAT_AMD_BENCH_BACKEND", "nccl")
@@ -165,12 +236,12 @@ def main() -> None:
     # all-reduce the 11 N geometry floats, all-gather 3 N rgb-gradient floats each and rebuild the coefficient
     # gradient locally (summed in rank order: bit-identical on every rank).
     factored = dist is not None and args.exchange == "factored"
-    if factored:
+    if dist is not None:
         vm_all = torch.stack([scene.make_camera(r, world) for r in range(world)]).to(dev)
         vr_all = torch.zeros(world, n, 3, device=dev)
         vr_mine = vr_all[rank]
 
-    def step():
+    def step(factored=factored):
         for t in leaves:
             t.grad = None
         # the backward pass writes every gradient element straight into the bucket (no zero-fill, no copy)
@@ -206,15 +277,29 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    # the timed region: exactly `steps` steps, nothing else on the stream
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    def timed(form):
+        """`warmup` untimed steps, then exactly `steps` steps between two fences; one event per step boundary on the
+        launch stream gives the per-step device times (median / p10 / p90 beside the mean)."""
+        for _ in range(args.warmup):
+            step(form)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        fence()
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(args.steps):
+            step(form)
+            marks[i + 1].record()
+        fence()
+        dt = time.perf_counter() - t0
+        return dt, [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+
+    # the timed region `value` comes from: the default exchange form of this run
+    elapsed, per_step_ms = timed(factored)
+    other_elapsed = None
+    if dist is not None:   # the same steps with the other exchange form, for the comparison figure only
+        other_elapsed, _ = timed(not factored)
+        for _ in range(2):
+            step()
     # a second, instrumented pass of the same steps gives the per-stage device times for the roofline object
     # (HIP events around every C-ABI stage on the launch stream; the event records themselves cost a few percent,
     # which is why this pass is not the one `value` is computed from)
@@ -226,9 +311,9 @@ def main() -> None:
     stages.TIMER.reset(enabled=False)
 
     if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed, other_elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed, other_elapsed = (float(x) for x in tmax.tolist())
 
     grad_l1 = float(flat_grad.double().abs().sum())   # of the last step's exchanged gradient (same on every rank)
     copy_peak = measured_copy_peak(dev) if rank == 0 else 0.0   # after the timed regions
@@ -248,13 +333,19 @@ def main() -> None:
         dominant = max((k for k in per if k in alg and k != "binning"), key=lambda k: per[k])
         ach = alg[dominant] / (per[dominant] * 1e-3) / 1e9
         total_bytes = sum(alg.values())
-        traffic = None  # measured HBM bytes per launch of the dominant kernel (separate rocprofv3 --pmc passes)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
-                if args.workload == "C3":
-                    traffic = json.load(fh)["kernels"][dominant]["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            traffic = None
+        # measured per launch of the dominant kernel, from separate rocprofv3 --pmc passes of this command
+        # (profiles/*_traffic.json, tools/make_traffic_json.py): HBM bytes, VALU utilisation, float-atomic requests,
+        # and the bound the counters point at
+        traffic, counters = None, {}
+        for fname in ("r02_traffic.json", "r01_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", fname)) as fh:
+                    if args.workload == "C3":
+                        counters = json.load(fh)["kernels"][dominant]
+                        traffic = counters["hbm_bytes_per_launch"]
+                        break
+            except (OSError, KeyError, ValueError):
+                continue
         line = {
             "metric": "Mpix/s fwd+bwd @1M gaussians/1080p", "value": round(value, 3), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -265,20 +356,35 @@ def main() -> None:
                                        " SH gradient rebuilt locally" if factored else
                                        ", RCCL all-reduce of 59N-float grads") if world > 1 else ""),
                        "intersections_M": m, "grad_l1": round(grad_l1, 3), "cull_mode": stages.DEFAULT_CULL_MODE if args.cull_mode is None else args.cull_mode},
+            # `bound`: the roofline `achieved` / `peak` are priced against is HBM (no MFMA on this path);
+            # `limiter`: what the PMC counters say the dominant kernel actually waits for
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "limiter": counters.get("limiter"), "valu_util": counters.get("valu_util"),
+                         "atomic_requests": counters.get("atomic_requests"),
                          "measured_copy_peak": round(copy_peak, 1),
                          "algorithmic_bytes_per_launch": alg[dominant], "avg_launch_ms": round(per[dominant], 4)},
+            "step_ms": percentiles(per_step_ms),
             "roofline_whole_step": {"algorithmic_bytes": total_bytes,
                                     "achieved_GBs": round(total_bytes / (ms_per_step * 1e-3) / 1e9, 2),
                                     "frac": round(total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
             "stage_ms": {k: round(v, 4) for k, v in sorted(per.items())},
             "stage_algorithmic_GBs": {k: round(alg[k] / (per[k] * 1e-3) / 1e9, 1) for k in sorted(per) if k in alg},
         }
+        if dist is not None:
+            other_value = world * p * args.steps / other_elapsed / 1e6
+            line["exchange"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                                "form": "factored" if factored else "allreduce",
+                                "exchange_ms": round(per.get("exchange", 0.0), 4),
+                                "value_factored": round(value if factored else other_value, 3),
+                                "value_allreduce": round(other_value if factored else value, 3)}
         if world == 1 and not args.no_cpu_baseline and args.workload == "C3":
             print(f"[bench] GPU leg done ({ms_per_step:.3f} ms/step); timing the CPU oracle on a bounded sample ...",
                   file=sys.stderr, flush=True)
             line["cpu_baseline"] = cpu_baseline(n, width, height, deg)
+            line["cpu_baseline"]["cpu_model"] = cpu_model()
+            print("[bench] CPU oracle at C1 / C2 sizes, fwd and fwd+bwd, median of 5 ...", file=sys.stderr, flush=True)
+            line["cpu_baseline"]["protocol"] = cpu_baseline_protocol()
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
