@@ -33,6 +33,8 @@
 // /root/reference/src/backends/gsplat_backend.py:168-182.
 
 #include "project_math.h"
+#include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -761,6 +763,399 @@ __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_list_kerne
 }
 
 // ------------------------------------------------------------------------------------------------
+// backward, record-parallel: lanes = (4 pixels) x (16 records), transmittance by a prefix scan over the records
+// ------------------------------------------------------------------------------------------------
+// The pixel-parallel sweep above sums 9 (10) moment contributions per record over the 64 pixel lanes: ~20 cross-lane
+// instructions per record -- 29 % of that kernel (profiles/r02_bwd_ablation.md).  Here a row of 16 lanes holds 16
+// consecutive records of the quadrant's list (walk order) and the four rows work on four different pixels.  What a
+// pixel needs from the records in front of it is a PREFIX: the transmittance in front of record m is
+// T_carry * prod_{m' <= m} 1 / (1 - alpha_m'), and the colour still to come behind it is Wd_carry - sum_{m' < m}
+// fac_m' (c_m' . v_out): two inclusive scans over the 16 lanes of a row (4 row_shr DPP steps each), the carries kept
+// per pixel in LDS.  Every lane then ACCUMULATES its record's moments over the pixels it visits in registers (plain
+// fused multiply-adds, no cross-lane traffic); per 16 records one short fold over the four rows (2 levels) and one
+// transposition through LDS turn them into four atomic instructions of four whole 64-B gradient records each.
+// The pixel loop only visits the pixels that can still be behind a record of the sub-batch (last list position the
+// pixel saw >= smallest position in the sub-batch): the sweep starts at the deep end of the lists, where few pixels
+// are left.  alpha is recomputed with the forward's expression (scaled_sigma / record_alpha), so both passes take
+// identical decisions.
+template <int CH>
+struct PixState {              // per-wave pixel table; entry kWave is a NULL pixel (sees no record) padding the lists
+    float4 a[kWave + 1];       // v_out r, g, b; bits of the last list position the pixel saw while live
+    float4 b[kWave + 1];       // T behind the current record, Wd (see composite_bwd_kernel), pixel centre x, y
+    float d[kWave + 1];        // v_out of the depth channel (CH == 4)
+    float tile[16 * 16];       // epilogue: [record][field] totals of one sub-batch
+    uint8_t plist[kWave + 8];  // the sub-batch's live pixels, compacted
+};
+
+// inclusive scans over the 16 lanes of a DPP row; a lane without a source keeps its own value (no bound_ctrl: the
+// instruction is disabled there), which is the scan's identity step.  s_nop 1: see fold8.
+__device__ __forceinline__ float row_scan_mul(float x) {
+    asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf"
+                 : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ float row_scan_add(float x) {
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf"
+                 : "+v"(x));
+    return x;
+}
+
+// One sub-batch: the 16 records st.rec[s0 .. s0 + nv) against the `iters` groups of four live pixels in ps.plist.
+// acc[f]: this lane's share (its row's pixels) of field f of ITS record (lane & 15).
+template <int CH, int F4, bool CLAMP>
+__device__ __forceinline__ void sweep16(const Staged<F4> &st, PixState<CH> &ps, int lane, int s0, int nv, int iters,
+                                        float (&acc)[6 + CH]) {
+    const int m = lane & 15, rowi = lane >> 4;
+    // invalid lanes of a short sub-batch hold the null record (opacity 0: alpha 0 everywhere)
+    const float4 *p = &st.rec[F4 * (m < nv ? s0 + m : kBatch)];
+    const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+    const float depth = CH == 4 ? p[F4 - 1].x : 0.f;
+    const int pos = __float_as_int(q2.z);
+    for (int i = 0; i < iters; ++i) {
+        const int pi = ps.plist[4 * i + rowi];
+        const float4 A = ps.a[pi], B = ps.b[pi];
+        const float dx = q0.x - B.z, dy = q0.y - B.w;
+        const uint32_t off_bit = (uint32_t)(__float_as_int(A.w) - pos) & kSign;   // the pixel stopped in front of it
+        float raw;
+        const float a = record_alpha<CLAMP>(scaled_sigma(q0, q1, dx, dy), q2.y, q1.y, off_bit, raw);
+        const float ra = __builtin_amdgcn_rcpf(1.f - a);      // a == 0: 1
+        const float Tn = B.x * row_scan_mul(ra);              // transmittance in front of this record
+        const float fac = a * Tn;
+        float cv = q1.z * A.x + q1.w * A.y + q2.x * A.z;
+        if (CH == 4) cv += depth * ps.d[pi];
+        const float fc = fac * cv;
+        const float S = row_scan_add(fc);                     // inclusive: fac (c . v_out) of the records up to this one
+        const float v_a = Tn * cv + ra * (B.y - (S - fc));
+        const float u = CLAMP ? ((a == raw) ? -raw * v_a : 0.f) : -a * v_a;
+        const float udx = u * dx, udy = u * dy;
+        acc[0] = __builtin_fmaf(u, dx, acc[0]);
+        acc[1] = __builtin_fmaf(u, dy, acc[1]);
+        acc[2] = __builtin_fmaf(udx, dx, acc[2]);
+        acc[3] = __builtin_fmaf(udx, dy, acc[3]);
+        acc[4] = __builtin_fmaf(udy, dy, acc[4]);
+        acc[5] += u;
+        acc[6] = __builtin_fmaf(fac, A.x, acc[6]);
+        acc[7] = __builtin_fmaf(fac, A.y, acc[7]);
+        acc[8] = __builtin_fmaf(fac, A.z, acc[8]);
+        if (CH == 4) acc[6 + CH - 1] = __builtin_fmaf(fac, ps.d[pi], acc[6 + CH - 1]);
+        if (m == 15) {   // the row's last lane holds the pixel's state behind the whole sub-batch
+            float2 *carry = reinterpret_cast<float2 *>(&ps.b[pi]);
+            *carry = make_float2(Tn, B.y - S);
+        }
+    }
+}
+
+template <int CH>
+__global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_scan_kernel(
+    int width, int height, int tile_w, int n_tiles, const float *__restrict__ splat,
+    const uint32_t *__restrict__ sorted_gid, const int32_t *__restrict__ tile_offsets,
+    const float *__restrict__ background, const int32_t *__restrict__ tile_order, const float *__restrict__ final_T,
+    const int32_t *__restrict__ last_id, const float *__restrict__ v_render, const float *__restrict__ v_alpha,
+    const uint32_t *__restrict__ quad_list, const int32_t *__restrict__ quad_count, float *__restrict__ v_splat) {
+    constexpr int F4 = CH == 4 ? 4 : 3;
+    constexpr int NF = 6 + CH;
+    __shared__ Staged<F4> st;
+    __shared__ PixState<CH> ps;
+
+    int tile, q;
+    wave_unit(blockIdx.x, n_tiles, tile_order, tile, q);
+    if (tile >= n_tiles) return;
+    const int lane = threadIdx.x;
+    const int count = __builtin_amdgcn_readfirstlane(quad_count[4 * tile + q]);
+    if (count <= 0) return;
+    const int start = __builtin_amdgcn_readfirstlane(tile_offsets[tile]);
+    const int end = __builtin_amdgcn_readfirstlane(tile_offsets[tile + 1]);
+    const uint32_t *my_list = quad_list + 4 * (size_t)start + (size_t)q * (size_t)(end - start);
+    const int tx = tile % tile_w, ty = tile / tile_w;
+    const int qx = tx * kTile + (q & 1) * 8, qy = ty * kTile + (q >> 1) * 8;
+    const int px = qx + (lane & 7), py = qy + (lane >> 3);
+    const bool inside = px < width && py < height;
+
+    // software pipeline three deep, as in composite_bwd_list_kernel
+    auto load_pos = [&](int j) -> int {
+        const int e = count - 1 - j * kBatch - lane;
+        return e >= 0 ? (int)my_list[e] : -1;
+    };
+    auto load_gid = [&](int pos) -> uint32_t { return pos >= 0 ? sorted_gid[pos] : 0u; };
+    int pos_cur = load_pos(0);
+    int pos_next = load_pos(1);
+    uint32_t gid_cur = load_gid(pos_cur);
+
+    // pixel table (lane p = pixel p of the quadrant)
+    const size_t pix = inside ? (size_t)py * width + px : 0;
+    const int binf = inside ? last_id[pix] : -1;   // last list position the pixel saw while live
+    {
+        const float Tf = inside ? final_T[pix] : 1.f;
+        float vout[CH], bgdot = 0.f;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            vout[k] = inside ? v_render[pix * CH + k] : 0.f;
+            if (background) bgdot += background[k] * vout[k];
+        }
+        const float Wd = Tf * (((inside && v_alpha) ? v_alpha[pix] : 0.f) - bgdot);
+        ps.a[lane] = make_float4(vout[0], vout[1], vout[2], __int_as_float(binf));
+        ps.b[lane] = make_float4(Tf, Wd, px + 0.5f, py + 0.5f);
+        if (CH == 4) ps.d[lane] = vout[CH - 1];
+        if (lane == 0) {
+            ps.a[kWave] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+            ps.b[kWave] = make_float4(1.f, 0.f, 0.f, 0.f);
+            if (CH == 4) ps.d[kWave] = 0.f;
+        }
+    }
+    Row row = load_row(splat, gid_cur, pos_cur >= 0);
+    uint32_t gid_next = load_gid(pos_next);
+    int pos_next2 = load_pos(2);
+    const int m = lane & 15, rowi = lane >> 4;
+    const int fb = 2 * (rowi & 1) + (rowi >> 1);   // after the row fold this lane holds fields fb, fb + 4, fb + 8
+
+    for (int done = 0, j = 0; done < count; done += kBatch, ++j) {
+        bool any_cap;
+        const int n = stage_listed(st, lane, row, pos_cur >= 0, pos_cur, any_cap);
+        row = load_row(splat, gid_next, pos_next >= 0);
+        pos_cur = pos_next;
+        gid_next = load_gid(pos_next2);
+        pos_next = pos_next2;
+        pos_next2 = load_pos(j + 3);
+        for (int s0 = 0; s0 < n; s0 += 16) {
+            const int nv = min(16, n - s0);
+            // live pixels of this sub-batch: those whose last seen position is not in front of all its records
+            const int pos_lo = __builtin_amdgcn_readfirstlane(__float_as_int(st.rec[F4 * (s0 + nv - 1) + 2].z));
+            const unsigned long long lv = __ballot(binf >= pos_lo);
+            if (lv == 0ull) continue;
+            const int np = __builtin_popcountll(lv);
+            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(lv >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lv, 0));
+            if ((lv >> lane) & 1ull) ps.plist[rank] = (uint8_t)lane;
+            if (lane < 3) ps.plist[np + lane] = (uint8_t)kWave;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float acc[NF];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) acc[f] = 0.f;
+            const int iters = (np + 3) >> 2;
+            if (any_cap) sweep16<CH, F4, true>(st, ps, lane, s0, nv, iters, acc);
+            else sweep16<CH, F4, false>(st, ps, lane, s0, nv, iters, acc);
+            // sum over the four rows (lanes with equal record): fold32 leaves sum(field 2 i + half) in each half,
+            // fold16 sum(field 4 k + 2 (row & 1) + half) in each row
+            const float a9 = NF == 10 ? acc[NF - 1] : 0.f;
+            const float n0 = fold32(acc[0], acc[1]), n1 = fold32(acc[2], acc[3]), n2 = fold32(acc[4], acc[5]),
+                        n3 = fold32(acc[6], acc[7]), n4 = fold32(acc[8], a9);
+            const float r0 = fold16(n0, n1), r1 = fold16(n2, n3), r2 = fold16(n4, n4);
+            ps.tile[16 * m + fb] = r0;
+            ps.tile[16 * m + fb + 4] = r1;
+            ps.tile[16 * m + fb + 8] = r2;       // fields 8 .. 11: those >= NF are never read back
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // one atomic instruction per four records: lanes (record 4 t + row, field m) cover four 64-B records
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int r = 4 * t + rowi;
+                if (4 * t < nv) {
+                    const float total = ps.tile[64 * t + lane];
+                    if (m < NF && r < nv) {
+                        const uint32_t g = __float_as_uint(st.rec[F4 * (s0 + r) + 2].w);
+                        atomicAdd(v_splat + (size_t)g * GSA_SPLAT_STRIDE + m, total);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, two phases per 8 records: pixel-parallel recurrence, record-parallel moment sums
+// ------------------------------------------------------------------------------------------------
+// What the pixel-parallel sweep spends on the cross-lane sums of the moments (~20 of its ~58 vector instructions per
+// record, profiles/r02_bwd_ablation.md) is avoided by changing the lane mapping between the two halves of the work:
+//   phase A, lane = pixel: the sequential part -- alpha, T, Wd -- for 8 records; per (pixel, record) only the two
+//            scalars the moments are linear in, u = d loss / d sigma and fac = alpha T, go to an LDS matrix
+//            [pixel][record] (rows padded to 9 entries: conflict-free 8-B stores and loads);
+//   phase B, lane = (pixel column x = lane >> 3, record = lane & 7), 8 steps over the pixel rows y: every lane reads its
+//            record's (u, fac) at pixel (x, y) and ACCUMULATES the nine moments in registers with plain FMAs
+//            (d = mean - pixel is a per-lane constant in x and a per-step constant in y);
+//   then one short fold over the 8 lanes of a record (3 levels) and a transposition through LDS give two atomic
+//   instructions of four whole 64-B gradient records each.
+// Same arithmetic per (pixel, record) as composite_bwd_list_kernel (the sums are taken in a different order).
+constexpr int kSub = 8;                 // records per sub-batch
+constexpr int kMatPitch = kSub + 1;     // float2 entries per pixel row of the LDS matrix
+template <int CH>
+struct TwoPhase {
+    float2 mat[kWave * kMatPitch];      // [pixel][record] (u, fac)
+    float tile[kSub * 16];              // epilogue: [record][field] totals
+};
+
+template <int CH>
+__global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_2p_kernel(
+    int width, int height, int tile_w, int n_tiles, const float *__restrict__ splat,
+    const uint32_t *__restrict__ sorted_gid, const int32_t *__restrict__ tile_offsets,
+    const float *__restrict__ background, const int32_t *__restrict__ tile_order, const float *__restrict__ final_T,
+    const int32_t *__restrict__ last_id, const float *__restrict__ v_render, const float *__restrict__ v_alpha,
+    const uint32_t *__restrict__ quad_list, const int32_t *__restrict__ quad_count, float *__restrict__ v_splat) {
+    constexpr int F4 = CH == 4 ? 4 : 3;
+    constexpr int NF = 6 + CH;
+    __shared__ Staged<F4> st;
+    __shared__ TwoPhase<CH> tp;
+
+    int tile, q;
+    wave_unit(blockIdx.x, n_tiles, tile_order, tile, q);
+    if (tile >= n_tiles) return;
+    const int lane = threadIdx.x;
+    const int count = __builtin_amdgcn_readfirstlane(quad_count[4 * tile + q]);
+    if (count <= 0) return;
+    const int start = __builtin_amdgcn_readfirstlane(tile_offsets[tile]);
+    const int end = __builtin_amdgcn_readfirstlane(tile_offsets[tile + 1]);
+    const uint32_t *my_list = quad_list + 4 * (size_t)start + (size_t)q * (size_t)(end - start);
+    const int tx = tile % tile_w, ty = tile / tile_w;
+    const int qx = tx * kTile + (q & 1) * 8, qy = ty * kTile + (q >> 1) * 8;
+    const int px = qx + (lane & 7), py = qy + (lane >> 3);
+    const bool inside = px < width && py < height;
+    const float pxf = px + 0.5f, pyf = py + 0.5f;
+
+    // software pipeline three deep, as in composite_bwd_list_kernel
+    auto load_pos = [&](int j) -> int {
+        const int e = count - 1 - j * kBatch - lane;
+        return e >= 0 ? (int)my_list[e] : -1;
+    };
+    auto load_gid = [&](int pos) -> uint32_t { return pos >= 0 ? sorted_gid[pos] : 0u; };
+    int pos_cur = load_pos(0);
+    int pos_next = load_pos(1);
+    uint32_t gid_cur = load_gid(pos_cur);
+
+    // phase A state (lane = pixel): as in composite_bwd_kernel
+    const size_t pix = inside ? (size_t)py * width + px : 0;
+    const int binf = inside ? last_id[pix] : -1;
+    const float Tf = inside ? final_T[pix] : 1.f;
+    float T = Tf;
+    float vout[CH], bgdot = 0.f;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        vout[k] = inside ? v_render[pix * CH + k] : 0.f;
+        if (background) bgdot += background[k] * vout[k];
+    }
+    float Wd = Tf * (((inside && v_alpha) ? v_alpha[pix] : 0.f) - bgdot);
+    Row row = load_row(splat, gid_cur, pos_cur >= 0);
+    uint32_t gid_next = load_gid(pos_next);
+    int pos_next2 = load_pos(2);
+
+    // phase B roles: record = lane & 7 of the sub-batch, pixel column = lane >> 3, one pixel row per step
+    const int rec = lane & 7, col = lane >> 3;
+    const float colx = qx + col + 0.5f, rowy0 = qy + 0.5f;
+    float vcol[8][CH];   // v_out of this lane's pixel column (registers: the LDS pipe is the scarcer resource here)
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+        const bool in = qx + col < width && qy + y < height;
+        const size_t pp = in ? (size_t)(qy + y) * width + qx + col : 0;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) vcol[y][k] = in ? v_render[pp * CH + k] : 0.f;
+    }
+    const int f0 = 4 * ((lane >> 5) & 1) + 2 * ((lane >> 4) & 1) + ((lane >> 3) & 1);   // field this lane ends up with
+
+    for (int done = 0, j = 0; done < count; done += kBatch, ++j) {
+        bool any_cap;
+        const int n = stage_listed(st, lane, row, pos_cur >= 0, pos_cur, any_cap);
+        row = load_row(splat, gid_next, pos_next >= 0);
+        pos_cur = pos_next;
+        gid_next = load_gid(pos_next2);
+        pos_next = pos_next2;
+        pos_next2 = load_pos(j + 3);
+        for (int s0 = 0; s0 < n; s0 += kSub) {
+            const int nv = min(kSub, n - s0);
+            // ---- phase A: lane = pixel, the records of the sub-batch in walk order
+            auto phase_a = [&](auto clamp_tag) {
+                constexpr bool CLAMP = decltype(clamp_tag)::value;
+#pragma unroll
+                for (int r = 0; r < kSub; ++r) {
+                    float u = 0.f, fac = 0.f;
+                    if (r < nv) {   // (uniform)
+                        const float4 *p = &st.rec[F4 * (s0 + r)];
+                        const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+                        const float dx = q0.x - pxf, dy = q0.y - pyf;
+                        const uint32_t off_bit = (uint32_t)(binf - __float_as_int(q2.z)) & kSign;
+                        float raw;
+                        const float a = record_alpha<CLAMP>(scaled_sigma(q0, q1, dx, dy), q2.y, q1.y, off_bit, raw);
+                        const float ra = __builtin_amdgcn_rcpf(1.f - a);   // a == 0: ra = 1, fac = 0, u = 0
+                        const float Tn = T * ra;
+                        fac = a * Tn;
+                        float cv = q1.z * vout[0] + q1.w * vout[1] + q2.x * vout[2];
+                        if (CH == 4) cv += p[F4 - 1].x * vout[CH - 1];
+                        const float v_a = Tn * cv + ra * Wd;
+                        Wd -= fac * cv;
+                        T = Tn;
+                        u = CLAMP ? ((a == raw) ? -raw * v_a : 0.f) : -a * v_a;
+                    }
+                    tp.mat[lane * kMatPitch + r] = make_float2(u, fac);
+                }
+            };
+            if (any_cap) phase_a(std::true_type{}); else phase_a(std::false_type{});
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- phase B: lane = (pixel column, record); the moments of ITS record over ITS column
+            float acc[10];
+#pragma unroll
+            for (int f = 0; f < 10; ++f) acc[f] = 0.f;
+            {
+                const float2 mean = *reinterpret_cast<const float2 *>(&st.rec[F4 * (rec < nv ? s0 + rec : kBatch)]);
+                const float dx = mean.x - colx, dy0 = mean.y - rowy0;
+#pragma unroll
+                for (int y = 0; y < 8; ++y) {
+                    const float2 uf = tp.mat[(8 * y + col) * kMatPitch + rec];
+                    const float dy = dy0 - (float)y;
+                    const float u = uf.x, fac = uf.y;
+                    const float udx = u * dx, udy = u * dy;
+                    acc[0] += udx;
+                    acc[1] += udy;
+                    acc[2] = __builtin_fmaf(udx, dx, acc[2]);
+                    acc[3] = __builtin_fmaf(udx, dy, acc[3]);
+                    acc[4] = __builtin_fmaf(udy, dy, acc[4]);
+                    acc[5] += u;
+                    acc[6] = __builtin_fmaf(fac, vcol[y][0], acc[6]);
+                    acc[7] = __builtin_fmaf(fac, vcol[y][1], acc[7]);
+                    acc[8] = __builtin_fmaf(fac, vcol[y][2], acc[8]);
+                    if (CH == 4) acc[9] = __builtin_fmaf(fac, vcol[y][CH - 1], acc[9]);
+                }
+            }
+            // fold over the 8 lanes of a record (lane bits 3, 4, 5): after fold8 a lane holds field 2 i + b3 in slot i,
+            // after fold16 field 4 j + 2 b4 + b3 in slot j, after fold32 field 8 t + 4 b5 + 2 b4 + b3 in slot t
+            const float k0 = fold8(acc[0], acc[1]), k1 = fold8(acc[2], acc[3]), k2 = fold8(acc[4], acc[5]),
+                        k3 = fold8(acc[6], acc[7]), k4 = fold8(acc[8], acc[9]);
+            const float m0 = fold16(k0, k1), m1 = fold16(k2, k3), m2 = fold16(k4, k4);
+            const float t0 = fold32(m0, m1), t1 = fold32(m2, m2);
+            tp.tile[16 * rec + f0] = t0;
+            tp.tile[16 * rec + 8 + f0] = t1;       // fields >= NF are never read back
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // one atomic instruction per four records: lanes (record 4 t + (lane >> 4), field lane & 15)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int r = 4 * t + (lane >> 4), f = lane & 15;
+                if (4 * t < nv) {
+                    const float total = tp.tile[64 * t + lane];
+                    if (f < NF && r < nv) {
+                        const uint32_t g = __float_as_uint(st.rec[F4 * (s0 + r) + 2].w);
+                        atomicAdd(v_splat + (size_t)g * GSA_SPLAT_STRIDE + f, total);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch order: longest record lists first, inside each XCD band
 // ------------------------------------------------------------------------------------------------
 // One workgroup per band: counting sort of the band's tiles by list length (64 buckets of 64 records, longest
@@ -912,6 +1307,34 @@ extern "C" int gsa_composite_bwd_lists(int width, int height, int channels, cons
     const int n_tiles = tile_w * tile_h;
     const int grid = 32 * gsa_div_up(n_tiles, 8);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // GSPLAT_AMD_BWD_MODE (developer A/B; same results up to summation order): 2 = two-phase sweep (default),
+    // 1 = record-parallel sweep with prefix scans, 0 = pixel-parallel sweep with the transpose-reduce
+    const char *mode_env = getenv("GSPLAT_AMD_BWD_MODE");   // (read per call: tests switch it)
+    const int mode = mode_env ? atoi(mode_env) : 2;
+    if (mode == 2) {
+        if (channels == 3)
+            composite_bwd_2p_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid,
+                                                             tile_offsets, background, tile_order, final_T, last_id,
+                                                             v_render, v_alpha, quad_list, quad_count, v_splat);
+        else
+            composite_bwd_2p_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid,
+                                                             tile_offsets, background, tile_order, final_T, last_id,
+                                                             v_render, v_alpha, quad_list, quad_count, v_splat);
+        GSA_LAUNCH_CHECK();
+        return GSA_OK;
+    }
+    if (mode == 1) {
+        if (channels == 3)
+            composite_bwd_scan_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid,
+                                                               tile_offsets, background, tile_order, final_T, last_id,
+                                                               v_render, v_alpha, quad_list, quad_count, v_splat);
+        else
+            composite_bwd_scan_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid,
+                                                               tile_offsets, background, tile_order, final_T, last_id,
+                                                               v_render, v_alpha, quad_list, quad_count, v_splat);
+        GSA_LAUNCH_CHECK();
+        return GSA_OK;
+    }
     if (channels == 3)
         composite_bwd_list_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid, tile_offsets,
                                                            background, tile_order, final_T, last_id, v_render, v_alpha,

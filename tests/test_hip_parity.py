@@ -19,6 +19,8 @@ Integer outputs (radii, tile counts, sorted ids, offsets) are compared exactly, 
 whose ceil() lands on the other side of an fp32 rounding."""
 import math
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -626,9 +628,17 @@ def test_backward_sweep_over_blended_record_lists(gsa, W, H, N, cull_mode, chann
                 assert np.all(np.diff(lst.astype(np.int64)) > 0) and lst[0] >= s0 and lst[-1] < e0
                 assert seen.size and int(lst[-1]) <= int(seen.max())
     g0 = S.composite_bwd(splat, sorted_gid, tile_offsets, bg, T0, l0, v_r, v_a, W, H, channels)
-    g1 = S.composite_bwd(splat, sorted_gid, tile_offsets, bg, T0, l0, v_r, v_a, W, H, channels, quad_lists=(qlist, qcount))
     scale = g0.abs().amax(0).clamp_min(1e-30)
-    assert float(((g0 - g1).abs().amax(0) / scale).max()) < 2e-5
+    # the three sweeps over the lists (developer switch GSPLAT_AMD_BWD_MODE): 2 = two-phase (default), 1 = record-
+    # parallel with prefix scans over the records, 0 = pixel-parallel with the transpose-reduce
+    try:
+        for mode in ("2", "1", "0"):
+            os.environ["GSPLAT_AMD_BWD_MODE"] = mode
+            g1 = S.composite_bwd(splat, sorted_gid, tile_offsets, bg, T0, l0, v_r, v_a, W, H, channels,
+                                 quad_lists=(qlist, qcount))
+            assert float(((g0 - g1).abs().amax(0) / scale).max()) < 2e-5, mode
+    finally:
+        os.environ.pop("GSPLAT_AMD_BWD_MODE", None)
 
 
 @pytest.mark.parametrize("W,H,N,s_max,giants", [(640, 360, 30_000, 0.05, 0), (160, 96, 4000, 0.3, 0),
