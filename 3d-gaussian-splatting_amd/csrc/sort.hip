@@ -35,12 +35,16 @@ __device__ __forceinline__ int resolve_count(int n_cap, const uint32_t *__restri
 // ---- pass 1: per-block digit histogram, written digit-major: hist[d * nblocks + block] -------------
 // Plain per-lane LDS atomics: measured faster than aggregating same-digit lanes with ballots first (the LDS
 // resolves same-address adds of one instruction cheaply; the 8 ballots per key cost more than they save).
+// block_range (optional, [2][nblocks]): min and max of the block's keys below the culled sentinel 0xFFFFFFFF -- the
+// depth sort's first pass leaves them so that the caller can check how many key bits the visible gaussians differ in.
 template <typename KeyT>
 __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(int n_cap, const uint32_t *__restrict__ n_dev,
                                                                   const KeyT *__restrict__ keys,
                                                                   int shift, int nblocks,
-                                                                  uint32_t *__restrict__ hist) {
+                                                                  uint32_t *__restrict__ hist,
+                                                                  uint32_t *__restrict__ block_range) {
     __shared__ uint32_t h[kRadix];
+    __shared__ uint32_t s_lo, s_hi;
     const int n = resolve_count(n_cap, n_dev);
     const long base = (long)blockIdx.x * kSortChunk;
     if (base >= n) {   // capacity launch: nothing live in this block
@@ -48,6 +52,8 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(int n_cap, con
         return;
     }
     h[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { s_lo = 0xFFFFFFFFu; s_hi = 0u; }
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
     __syncthreads();
     if constexpr (sizeof(KeyT) == 2) {   // two keys per 4-B load (the block's base is a multiple of kSortChunk keys)
         const uint32_t *pairs = reinterpret_cast<const uint32_t *>(keys + base);
@@ -67,11 +73,24 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(int n_cap, con
 #pragma unroll
         for (int r = 0; r < kSortItems; ++r) {
             long i = base + r * kSortThreads + threadIdx.x;
-            if (i < n) atomicAdd(&h[((uint32_t)keys[i] >> shift) & (kRadix - 1)], 1u);
+            if (i < n) {
+                const uint32_t kk = (uint32_t)keys[i];
+                atomicAdd(&h[(kk >> shift) & (kRadix - 1)], 1u);
+                if (kk != 0xFFFFFFFFu) { lo = min(lo, kk); hi = max(hi, kk); }
+            }
         }
+    }
+    if (block_range) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            lo = min(lo, (uint32_t)__shfl_xor((int)lo, d));
+            hi = max(hi, (uint32_t)__shfl_xor((int)hi, d));
+        }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
     }
     __syncthreads();
     hist[(long)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    if (block_range && threadIdx.x == 0) { block_range[blockIdx.x] = s_lo; block_range[nblocks + blockIdx.x] = s_hi; }
 }
 
 // ---- pass 2: one block per digit: exclusive scan of its row in place, row total out -----------------
@@ -99,8 +118,24 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *scratc
 }
 
 __global__ __launch_bounds__(kSortThreads) void radix_scan_rows_kernel(int nblocks, uint32_t *__restrict__ hist,
-                                                                       uint32_t *__restrict__ digit_total) {
+                                                                       uint32_t *__restrict__ digit_total,
+                                                                       const uint32_t *__restrict__ block_range = nullptr,
+                                                                       uint32_t *__restrict__ key_range = nullptr) {
     __shared__ uint32_t scratch[4];
+    if (key_range && blockIdx.x == 0) {   // min / max over the per-block ranges the histogram pass left
+        __shared__ uint32_t r_lo, r_hi;
+        if (threadIdx.x == 0) { r_lo = 0xFFFFFFFFu; r_hi = 0u; }
+        __syncthreads();
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+        for (int b = threadIdx.x; b < nblocks; b += kSortThreads) {
+            lo = min(lo, block_range[b]);
+            hi = max(hi, block_range[nblocks + b]);
+        }
+        atomicMin(&r_lo, lo);
+        atomicMax(&r_hi, hi);
+        __syncthreads();
+        if (threadIdx.x == 0) { key_range[0] = r_lo; key_range[1] = r_hi; }
+    }
     uint32_t *row = hist + (long)blockIdx.x * nblocks;
     uint32_t carry = 0;
     // four consecutive entries per thread and trip: a long row (27 k blocks at 112 M records) is a chain of trips, each
@@ -136,11 +171,16 @@ __global__ __launch_bounds__(kSortThreads) void radix_scan_rows_kernel(int nbloc
 //   3. Items are placed in LDS in block-sorted order, then written out: consecutive threads write consecutive
 //      addresses inside each digit's run, so HBM sees 64-B+ runs instead of one 4-B store per 64-B line (the
 //      low-digit pass of a tile sort scatters neighbouring records to 256 different buckets).
+// keys_out may be null (last pass of a sort whose keys nobody reads).  pairs (optional, [n] uint2 indexed by VALUE):
+// the last pass of the depth sort also leaves pairs[value].x / .y in output order (pair_x_out / pair_y_out) -- the
+// packed tile rectangle and the record count of each gaussian, which the scan would otherwise gather through `order`.
 template <typename KeyT>
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     int n_cap, const uint32_t *__restrict__ n_dev, const KeyT *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
     KeyT *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int shift, int nblocks,
-    const uint32_t *__restrict__ hist, const uint32_t *__restrict__ digit_total) {
+    const uint32_t *__restrict__ hist, const uint32_t *__restrict__ digit_total,
+    const uint2 *__restrict__ pairs = nullptr, uint32_t *__restrict__ pair_x_out = nullptr,
+    uint32_t *__restrict__ pair_y_out = nullptr) {
     __shared__ uint32_t scratch[4];
     __shared__ uint32_t gbase[kRadix];        // global slot of this block's first item of digit d
     __shared__ uint32_t lexcl[kRadix];        // slot of that item in the block-sorted order
@@ -220,8 +260,14 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
             uint32_t key = s_key[lp];
             uint32_t d = (key >> shift) & (kRadix - 1);
             uint32_t pos = gbase[d] + ((uint32_t)lp - lexcl[d]);
-            keys_out[pos] = (KeyT)key;
-            vals_out[pos] = s_val[lp];
+            if (keys_out) keys_out[pos] = (KeyT)key;
+            const uint32_t val = s_val[lp];
+            vals_out[pos] = val;
+            if (pairs) {
+                const uint2 pr = pairs[val];
+                pair_x_out[pos] = pr.x;
+                pair_y_out[pos] = pr.y;
+            }
         }
     }
 }
@@ -251,14 +297,16 @@ __global__ __launch_bounds__(kSortThreads) void scan_reduce_kernel(int n, const 
     for (int j = 0; j < kScanItems; ++j) {
         uint32_t c = 0;
         if (base + j < n) {
-            if (rects) {   // fused binning: ONE 8-B gather brings the packed rectangle and the count into depth order
+            if (!order) {  // the depth sort's last pass already left the counts in depth order (in `gathered`)
+                c = gathered[base + j];
+            } else if (rects) {   // fused binning: ONE 8-B gather brings the packed rectangle and the count into depth order
                 const uint2 rc = tile_rects[order[base + j]];
                 rects[base + j] = rc.x;
                 c = rc.y;
             } else {
                 c = (uint32_t)tiles_touched[order[base + j]];
             }
-            gathered[base + j] = c;
+            if (order) gathered[base + j] = c;
         }
         s += c;
     }
@@ -696,7 +744,7 @@ static int sort_pairs_impl(int n, const uint32_t *n_dev, const uint32_t *keys_in
         uint32_t *kout = to_out ? keys_out : keys_tmp;
         uint32_t *vout = to_out ? vals_out : vals_tmp;
         int shift = begin_bit + 8 * p;
-        radix_hist_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(n, n_dev, kin, shift, nblocks, hist);
+        radix_hist_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(n, n_dev, kin, shift, nblocks, hist, nullptr);
         GSA_LAUNCH_CHECK();
         radix_scan_rows_kernel<<<kRadix, kSortThreads, 0, s>>>(nblocks, hist, digit_total);
         GSA_LAUNCH_CHECK();
@@ -735,8 +783,8 @@ static int scan_tiles_impl(int n, const int32_t *tiles_touched, const uint32_t *
         hipError_t e = hipMemsetAsync(total, 0, sizeof(uint32_t), s);
         return (int)e;
     }
-    GSA_RETURN_IF(!order || !offsets || !workspace, GSA_ERR_INVALID_ARGUMENT);
-    GSA_RETURN_IF(rects ? !tile_rects : !tiles_touched, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(!offsets || !workspace, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(order && (rects ? !tile_rects : !tiles_touched), GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(workspace_bytes < gsa_sort_workspace_bytes(n), GSA_ERR_WORKSPACE_TOO_SMALL);
     uint32_t *block_sums = static_cast<uint32_t *>(workspace);
     int nblocks = gsa_div_up(n, kScanChunk);
@@ -764,6 +812,61 @@ extern "C" int gsa_scan_tiles_rect(int n, const uint32_t *order, const uint32_t 
     GSA_RETURN_IF(n_blocks < 0 || (n_blocks > 0 && !block_owner), GSA_ERR_INVALID_ARGUMENT);
     return scan_tiles_impl(n, nullptr, order, reinterpret_cast<const uint2 *>(tile_rects), offsets, rects, block_owner,
                            n_blocks, total, workspace, workspace_bytes, stream);
+}
+
+extern "C" int gsa_scan_tiles_sorted(int n, uint32_t *counts_offsets, int32_t *block_owner, int n_blocks, uint32_t *total,
+                                     void *workspace, size_t workspace_bytes, gsa_stream_t stream) {
+    GSA_RETURN_IF(n_blocks < 0 || (n_blocks > 0 && !block_owner), GSA_ERR_INVALID_ARGUMENT);
+    return scan_tiles_impl(n, nullptr, nullptr, nullptr, counts_offsets, nullptr, block_owner, n_blocks, total, workspace,
+                           workspace_bytes, stream);
+}
+
+extern "C" size_t gsa_depth_order_workspace_bytes(int n) {
+    if (n < 0) n = 0;
+    // two key and two value ping-pong buffers, the per-block key ranges, the sort's histograms
+    return (size_t)4 * n * sizeof(uint32_t) + (size_t)2 * ((size_t)sort_blocks(n) + 1) * sizeof(uint32_t) +
+           gsa_sort_workspace_bytes(n);
+}
+
+extern "C" int gsa_depth_order(int n, const uint32_t *depth_keys, const uint32_t *tile_rects, int key_bits,
+                               uint32_t *order, uint32_t *rects, uint32_t *counts, uint32_t *key_range, void *workspace,
+                               size_t workspace_bytes, gsa_stream_t stream) {
+    GSA_RETURN_IF(n < 0 || key_bits < 1 || key_bits > 32 || !key_range, GSA_ERR_INVALID_ARGUMENT);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n == 0) {
+        hipError_t e = hipMemsetAsync(key_range, 0xFF, sizeof(uint32_t), s);
+        if (e == hipSuccess) e = hipMemsetAsync(key_range + 1, 0, sizeof(uint32_t), s);
+        return (int)e;
+    }
+    GSA_RETURN_IF(!depth_keys || !tile_rects || !order || !rects || !counts || !workspace, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF((reinterpret_cast<uintptr_t>(tile_rects) & 7) != 0, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(workspace_bytes < gsa_depth_order_workspace_bytes(n), GSA_ERR_WORKSPACE_TOO_SMALL);
+    const int nblocks = sort_blocks(n);
+    uint32_t *buf = static_cast<uint32_t *>(workspace);
+    uint32_t *kbuf[2] = {buf, buf + n}, *vbuf[2] = {buf + 2 * (size_t)n, buf + 3 * (size_t)n};
+    uint32_t *block_range = buf + 4 * (size_t)n;
+    uint32_t *hist = block_range + 2 * ((size_t)nblocks + 1);
+    uint32_t *digit_total = hist + (size_t)kRadix * nblocks;
+    const int passes = (key_bits + 7) / 8;
+    const uint32_t *kin = depth_keys, *vin = nullptr;
+    for (int p = 0; p < passes; ++p) {
+        const bool last = p == passes - 1;
+        uint32_t *kout = last ? nullptr : kbuf[p & 1];
+        uint32_t *vout = last ? order : vbuf[p & 1];
+        radix_hist_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(n, nullptr, kin, 8 * p, nblocks, hist,
+                                                                     p == 0 ? block_range : nullptr);
+        GSA_LAUNCH_CHECK();
+        radix_scan_rows_kernel<<<kRadix, kSortThreads, 0, s>>>(nblocks, hist, digit_total, p == 0 ? block_range : nullptr,
+                                                               p == 0 ? key_range : nullptr);
+        GSA_LAUNCH_CHECK();
+        radix_scatter_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(
+            n, nullptr, kin, vin, kout, vout, 8 * p, nblocks, hist, digit_total,
+            last ? reinterpret_cast<const uint2 *>(tile_rects) : nullptr, last ? rects : nullptr, last ? counts : nullptr);
+        GSA_LAUNCH_CHECK();
+        kin = kout;
+        vin = vout;
+    }
+    return GSA_OK;
 }
 
 static int tile_emit_impl(int n, const uint32_t *order, const uint32_t *offsets, const float *splat,
@@ -869,7 +972,7 @@ extern "C" int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offs
                                                          nblocks, hist, digit_total);
     GSA_LAUNCH_CHECK();
     if (two) {
-        radix_hist_kernel<uint16_t><<<nblocks, kSortThreads, 0, s>>>((int)m_capacity, m_dev, tile_tmp, 8, nblocks, hist);
+        radix_hist_kernel<uint16_t><<<nblocks, kSortThreads, 0, s>>>((int)m_capacity, m_dev, tile_tmp, 8, nblocks, hist, nullptr);
         GSA_LAUNCH_CHECK();
         radix_scan_rows_kernel<<<kRadix, kSortThreads, 0, s>>>(nblocks, hist, digit_total);
         GSA_LAUNCH_CHECK();

@@ -91,16 +91,16 @@ _PINNED_SLOTS = 16   # record-count read-backs that may be in flight per device 
 
 
 def _pinned_scalar(dev):
-    """A pinned int32 + event for ONE record-count read-back: every ``TileBins`` gets its own slot of a small ring per
+    """Four pinned int32 (record count, min / max depth key, spare) + an event for ONE read-back of a view's control words: every ``TileBins`` gets its own slot of a small ring per
     device (allocated once), so bins that are finalized late or out of order -- a deeper look-ahead, stage-level use,
     two host threads -- never read another view's count."""
     key = (dev.type, dev.index)
     if key not in _PINNED:
-        _PINNED[key] = [torch.empty(_PINNED_SLOTS, dtype=torch.int32, pin_memory=True),
+        _PINNED[key] = [torch.empty(_PINNED_SLOTS, 4, dtype=torch.int32, pin_memory=True),
                         [torch.cuda.Event() for _ in range(_PINNED_SLOTS)], 0]
     words, events, nxt = _PINNED[key]
     _PINNED[key][2] = (nxt + 1) % _PINNED_SLOTS
-    return words[nxt:nxt + 1], events[nxt]
+    return words[nxt], events[nxt]
 
 
 def project_fwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat, Kmat, width: int, height: int,
@@ -141,23 +141,29 @@ class TileBins:
     """Result of ``bin_tiles``: record buffers sized for a CAPACITY, the live record count on the device, and
     ``finalize()`` which the caller runs after it has queued the work that consumes the bins."""
 
-    def __init__(self, sorted_tile, sorted_gid, tile_offsets, capacity, m_known, key, slot=None, n=0):
+    def __init__(self, sorted_tile, sorted_gid, tile_offsets, capacity, m_known, key, slot=None, n=0, key_bits=32,
+                 keys_ok=True):
         self._tile, self._gid, self.tile_offsets = sorted_tile, sorted_gid, tile_offsets
         self.capacity, self._m, self._key, self._slot, self._n = capacity, m_known, key, slot, n
+        self.key_bits, self._keys_ok = key_bits, keys_ok   # depth-sort bits the kernels ran with; range check result
 
     @property
     def sorted_gid_buffer(self):   # what the compositor kernels read (they only follow tile_offsets)
         return self._gid
 
     def finalize(self):
-        """-> (M, ok).  Waits for the record count (copied to pinned memory right after the scan, long finished by
-        the time the compositor has been queued) and checks it against the capacity the kernels ran with."""
+        """-> (M, ok).  Waits for the control words (record count and depth-key range, copied to pinned memory right
+        after the scan, long finished by the time the compositor has been queued) and checks them against what the
+        kernels ran with: the record capacity, and the number of depth-key bits that were sorted."""
         if self._m is None:
-            m_host, m_event = self._slot
-            m_event.synchronize()
-            self._m = int(m_host[0]) & 0xFFFFFFFF
+            ctl_host, ctl_event = self._slot
+            ctl_event.synchronize()
+            self._m = int(ctl_host[0]) & 0xFFFFFFFF
             _note_count(self._key, self._n, self._m)
-        return self._m, self._m <= self.capacity
+            if self.key_bits is not None:   # (the unfused path sorts all 32 bits and leaves no range)
+                self._keys_ok = _note_keys(self._key, int(ctl_host[1]) & 0xFFFFFFFF, int(ctl_host[2]) & 0xFFFFFFFF,
+                                           self.key_bits)
+        return self._m, self._m <= self.capacity and self._keys_ok
 
     def __iter__(self):   # sorted_tile, sorted_gid, tile_offsets = bin_tiles(...)
         return iter((self.sorted_tile, self.sorted_gid, self.tile_offsets))
@@ -185,6 +191,33 @@ _BIN_FUSED_DEFAULT = os.environ.get("GSPLAT_AMD_BIN_FUSED", "1") != "0"
 _CAPACITY = {}
 _CAPACITY_MAX_KEYS = 64
 _SHRINK_AFTER = 32
+
+
+_KEY_BITS = {}   # scene shape -> depth-key bits the next depth sort covers (grows at once, shrinks slowly)
+
+
+def _key_bits_needed(lo: int, hi: int) -> int:
+    """Whole 8-bit passes that order keys in [lo, hi] completely: the bits in which the two ends differ."""
+    if lo > hi:           # no visible gaussian
+        return 8
+    return max(8, 8 * (((lo ^ hi).bit_length() + 7) // 8))
+
+
+def _note_keys(key, lo: int, hi: int, used_bits: int) -> bool:
+    """Remember the depth-key range of this view; -> whether the sort that ran (on `used_bits` bits) was complete."""
+    need = _key_bits_needed(lo, hi)
+    ent = _KEY_BITS.get(key)
+    if ent is None or need > ent[0]:
+        _KEY_BITS[key] = [need, 0]
+    elif need < ent[0]:
+        ent[1] += 1
+        if ent[1] >= _SHRINK_AFTER:
+            _KEY_BITS[key] = [need, 0]
+    else:
+        ent[1] = 0
+    while len(_KEY_BITS) > _CAPACITY_MAX_KEYS:
+        _KEY_BITS.pop(next(iter(_KEY_BITS)))
+    return need <= used_bits
 
 
 def _capacity_for(key, n: int) -> Optional[int]:
@@ -227,9 +260,9 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
     n_tiles = tile_w * tile_h
     st = _stream()
     key = (dev.type, dev.index, width, height, cull_mode)
-    _, order = sort_pairs(N, depth_keys, None, 0, 32)  # ties keep index order; culled gaussians sort last
     offsets = torch.empty(N, dtype=torch.int32, device=dev)
-    total = torch.empty(1, dtype=torch.int32, device=dev)
+    ctl = torch.empty(4, dtype=torch.int32, device=dev)   # record count M, min / max visible depth key, spare
+    total = ctl[0:1]
     ws_bytes = lib.gsa_sort_workspace_bytes(N)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     # fused path (every tile of the rectangle is a record, 16-bit tile ids): the records are generated inside the
@@ -240,33 +273,50 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
     if fused is None:   # (GSPLAT_AMD_BIN_FUSED=0: the emit + 32-bit sort path, kept for A/B timing)
         fused = can_fuse and _BIN_FUSED_DEFAULT
     cap = None if exact else _capacity_for(key, N)
+    key_bits, keys_ok = 32, True
     if fused:
         if tile_rects is None:   # callers that did not keep project_fwd's dense copy: word 11 of the records
             tile_rects = torch.stack([torch.where(tiles_touched > 0, splat[:, 11].contiguous().view(torch.int32), 0),
                                       tiles_touched], dim=1).contiguous()
+        # depth order: only the key bits the visible gaussians of this scene shape were seen to differ in are sorted
+        # (their range is checked after the fact, like the record capacity); the last pass also brings the packed
+        # rectangles and the record counts into depth order
+        if not exact and key in _KEY_BITS:
+            key_bits = _KEY_BITS[key][0]
+        order = torch.empty(N, dtype=torch.int32, device=dev)
         rects = torch.empty(N, dtype=torch.int32, device=dev)
+        dws_bytes = lib.gsa_depth_order_workspace_bytes(N)
+        dws = torch.empty(dws_bytes, dtype=torch.uint8, device=dev)
+        _call("gsa_depth_order", lib.gsa_depth_order, N, _ptr(depth_keys), _ptr(tile_rects), key_bits, _ptr(order),
+              _ptr(rects), _ptr(offsets), _ptr(ctl[1:3]), _ptr(dws), dws_bytes, st)
 
         def scan(capacity):   # the scan also notes the owner of every 4096-slot record block (+ the last owner)
             n_blocks = 0 if capacity is None else (capacity + BIN_BLOCK - 1) // BIN_BLOCK
             owner = torch.empty(n_blocks + 1, dtype=torch.int32, device=dev)
-            _call("gsa_scan_tiles", lib.gsa_scan_tiles_rect, N, _ptr(order), _ptr(tile_rects), _ptr(offsets), _ptr(rects), _ptr(owner), n_blocks, _ptr(total), _ptr(ws), ws_bytes, st)
+            _call("gsa_scan_tiles", lib.gsa_scan_tiles_sorted, N, _ptr(offsets), _ptr(owner), n_blocks, _ptr(total), _ptr(ws),
+                  ws_bytes, st)
             return owner
 
+        counts_copy = offsets.clone() if cap is None else None   # the scan is in place; a second scan needs the counts
         block_owner = scan(cap)
     else:
+        _, order = sort_pairs(N, depth_keys, None, 0, 32)  # ties keep index order; culled gaussians sort last
         _call("gsa_scan_tiles", lib.gsa_scan_tiles, N, _ptr(tiles_touched), _ptr(order), _ptr(offsets), _ptr(total),
               _ptr(ws), ws_bytes, st)
     slot = _pinned_scalar(dev)
     m_host, m_event = slot
-    m_host.copy_(total, non_blocking=True)
+    m_host.copy_(ctl, non_blocking=True)
     m_event.record()
     m_known = None
     if cap is None:
         m_event.synchronize()
         m_known = int(m_host[0]) & 0xFFFFFFFF
         _note_count(key, N, m_known)
+        if fused:
+            keys_ok = _note_keys(key, int(m_host[1]) & 0xFFFFFFFF, int(m_host[2]) & 0xFFFFFFFF, key_bits)
         cap = m_known
         if fused:   # first call of a scene shape / repair: the block table needs the count, scan once more
+            offsets.copy_(counts_copy)
             block_owner = scan(cap)
     tile_offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
     if fused:
@@ -281,7 +331,7 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
               height, cap,
               _ptr(total), _ptr(k_tmp), _ptr(v_tmp), _ptr(sorted_tile), _ptr(sorted_gid), _ptr(tile_offsets), _ptr(ws2),
               ws2_bytes, st)
-        return TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key, slot, N)
+        return TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key, slot, N, key_bits, keys_ok)
     isect_tile = torch.empty(cap, dtype=torch.int32, device=dev)
     isect_gid = torch.empty(cap, dtype=torch.int32, device=dev)
     _call("gsa_tile_emit", lib.gsa_tile_emit_dev, N, _ptr(order), _ptr(offsets), _ptr(splat), _ptr(radii), width,
@@ -299,7 +349,7 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
         sorted_tile, sorted_gid = isect_tile, isect_gid
     _call("gsa_tile_offsets", lib.gsa_tile_offsets_dev, cap, _ptr(total), _ptr(sorted_tile), n_tiles,
           _ptr(tile_offsets), st)
-    return TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key, slot, N)
+    return TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key, slot, N, None, True)
 
 
 def tile_schedule(tile_offsets: torch.Tensor, width: int, height: int) -> torch.Tensor:

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSA_ABI_VERSION 4
+#define GSA_ABI_VERSION 5
 #define GSA_SPLAT_STRIDE 16
 
 #define GSA_OK 0
@@ -117,6 +117,23 @@ int gsa_tile_bin16_supported(int width, int height);
 int gsa_scan_tiles_rect(int n, const uint32_t *order, const uint32_t *tile_rects, uint32_t *offsets,
                         uint32_t *rects, int32_t *block_owner, int n_blocks, uint32_t *total, void *workspace,
                         size_t workspace_bytes, gsa_stream_t stream);
+/* ABI 5 -- depth ordering for the fused binning.  gsa_depth_order: stable LSD radix sort of the n gaussians by bits
+ * [0, key_bits) of their depth keys (key_bits in 1..32, rounded up to whole 8-bit passes): key_bits is how many low
+ * bits the caller expects the keys of the VISIBLE gaussians to differ in (culled gaussians carry 0xFFFFFFFF and fall
+ * behind every visible key in each digit; they have no records, so their place among equal low bits is immaterial).
+ * Besides order[n] it leaves, in depth order, rects[k] / counts[k] = tile_rects[order[k]] (what gsa_scan_tiles_rect
+ * gathers), and key_range[0..1] = min / max key over the visible gaussians (0xFFFFFFFF / 0 when there is none): the
+ * order is the full 32-bit order iff ((key_range[0] ^ key_range[1]) >> passes * 8) == 0 -- the caller checks that
+ * after the fact (like the record capacity) and repeats with key_bits = 32 on a miss.
+ * gsa_scan_tiles_sorted: the exclusive scan + block-owner table of gsa_scan_tiles_rect on counts that are already in
+ * depth order (in place: counts in, offsets out).  workspace: gsa_depth_order_workspace_bytes(n) /
+ * gsa_sort_workspace_bytes(n). */
+size_t gsa_depth_order_workspace_bytes(int n);
+int gsa_depth_order(int n, const uint32_t *depth_keys, const uint32_t *tile_rects, int key_bits, uint32_t *order,
+                    uint32_t *rects, uint32_t *counts, uint32_t *key_range, void *workspace, size_t workspace_bytes,
+                    gsa_stream_t stream);
+int gsa_scan_tiles_sorted(int n, uint32_t *counts_offsets, int32_t *block_owner, int n_blocks, uint32_t *total,
+                          void *workspace, size_t workspace_bytes, gsa_stream_t stream);
 int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offsets, const uint32_t *rects,
                    const int32_t *block_owner, int width, int height, uint32_t m_capacity, const uint32_t *m_dev,
                    uint16_t *tile_tmp,
