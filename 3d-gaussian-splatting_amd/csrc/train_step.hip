@@ -199,7 +199,9 @@ struct AdamSegments {
 __global__ __launch_bounds__(kThreads) void adam_kernel(long n, float *__restrict__ param, const float *__restrict__ grad,
                                                         float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq,
                                                         AdamSegments seg, float w1, float beta2, float w2, float eps,
-                                                        float inv_bc1, float inv_sqrt_bc2) {   // w = 1 - beta
+                                                        float inv_bc1, float inv_sqrt_bc2,   // w = 1 - beta
+                                                        const uint32_t *__restrict__ skip_if_nonzero) {
+    if (skip_if_nonzero && *skip_if_nonzero) return;   // a non-finite gradient was found: the step is skipped whole
     const long i0 = ((long)blockIdx.x * kThreads + threadIdx.x) * 4;
     if (i0 >= n) return;
     if (i0 + 4 <= n) {
@@ -427,7 +429,7 @@ extern "C" int gsa_view_loss(int width, int height, const float *render, const f
 
 extern "C" int gsa_adam_step(long long n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                              int n_segments, const long long *segment_end, const float *segment_lr, double beta1,
-                             double beta2, double eps, int step, gsa_stream_t stream) {
+                             double beta2, double eps, int step, const uint32_t *skip_if_nonzero, gsa_stream_t stream) {
     GSA_RETURN_IF(n < 0 || n_segments < 1 || n_segments > 8 || step < 1, GSA_ERR_INVALID_ARGUMENT);
     if (n == 0) return GSA_OK;
     GSA_RETURN_IF(!param || !grad || !exp_avg || !exp_avg_sq || !segment_end || !segment_lr, GSA_ERR_INVALID_ARGUMENT);
@@ -449,7 +451,39 @@ extern "C" int gsa_adam_step(long long n, float *param, const float *grad, float
     adam_kernel<<<grid, kThreads, 0, static_cast<hipStream_t>(stream)>>>((long)n, param, grad, exp_avg, exp_avg_sq, seg,
                                                                         (float)(1.0 - beta1), (float)beta2,
                                                                         (float)(1.0 - beta2), (float)eps,
-                                                                        (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+                                                                        (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)),
+                                                                        skip_if_nonzero);
+    GSA_LAUNCH_CHECK();
+    return GSA_OK;
+}
+
+// Loss-scale bookkeeping of a mixed-precision step (torch's GradScaler.unscale_, trainer.py:505-511): grad *= inv_scale
+// in place; *found_inf (accumulated: zero it first) becomes 1 if any element is not finite.
+__global__ __launch_bounds__(kThreads) void unscale_kernel(long n, float *__restrict__ grad, float inv_scale,
+                                                           uint32_t *__restrict__ found_inf) {
+    const long i0 = ((long)blockIdx.x * kThreads + threadIdx.x) * 4;
+    bool bad = false;
+    if (i0 + 4 <= n) {
+        float4 g = *reinterpret_cast<float4 *>(grad + i0);
+        bad = !(isfinite(g.x) && isfinite(g.y) && isfinite(g.z) && isfinite(g.w));
+        g.x *= inv_scale; g.y *= inv_scale; g.z *= inv_scale; g.w *= inv_scale;
+        *reinterpret_cast<float4 *>(grad + i0) = g;
+    } else {
+        for (long i = i0; i < n; ++i) {
+            const float g = grad[i];
+            bad = bad || !isfinite(g);
+            grad[i] = g * inv_scale;
+        }
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(found_inf, 1u);
+}
+
+extern "C" int gsa_grad_unscale(long long n, float *grad, float inv_scale, uint32_t *found_inf, gsa_stream_t stream) {
+    GSA_RETURN_IF(n < 0 || !found_inf, GSA_ERR_INVALID_ARGUMENT);
+    if (n == 0) return GSA_OK;
+    GSA_RETURN_IF(!grad || (reinterpret_cast<uintptr_t>(grad) & 15) != 0, GSA_ERR_INVALID_ARGUMENT);
+    const int grid = gsa_div_up((n + 3) / 4, kThreads);
+    unscale_kernel<<<grid, kThreads, 0, static_cast<hipStream_t>(stream)>>>((long)n, grad, inv_scale, found_inf);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }

@@ -45,7 +45,8 @@ SIGNATURES = {
     "gsa_densify_gather": (c_int, [c_longlong, c_longlong, c_int, P, c_int, c_int, c_float, P, P, P, P, P, P, P, P, P, P]),
     "gsa_view_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
     "gsa_view_loss": (c_int, [c_int, c_int, P, P, c_float, c_float, P, c_size_t, P, P, P]),
-    "gsa_adam_step": (c_int, [c_longlong, P, P, P, P, c_int, P, P, c_double, c_double, c_double, c_int, P]),
+    "gsa_adam_step": (c_int, [c_longlong, P, P, P, P, c_int, P, P, c_double, c_double, c_double, c_int, P, P]),
+    "gsa_grad_unscale": (c_int, [c_longlong, P, c_float, P, P]),
     "gsa_project_bwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, P, P, P, P, P, P, P, P, P]),
     "gsa_project_bwd_factored": (c_int, [c_int, P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, P, P, P, P, P, P, P, P, c_int, P]),
     "gsa_sh_grad_expand_split": (c_int, [c_int, P, c_int, c_int, c_int, P, P, P, P, P, P]),

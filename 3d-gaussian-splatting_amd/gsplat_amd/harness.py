@@ -45,6 +45,13 @@ class StepConfig:
     position_lr_init: float = 1.6e-4
     position_lr_final: float = 1.6e-7
     position_lr_max_steps: float = 3e5
+    # The reference's default is True (training_config.py:63: autocast around the render call + GradScaler,
+    # trainer.py:31,468-470,505-511).  The rasterizer computes in fp32 either way (its inputs are fp32), so what
+    # mixed precision changes is that the backward pass sees an upstream gradient multiplied by the loss scale
+    # (65536 at the start) and that a step with a non-finite gradient is skipped.  Off by default HERE because the
+    # reference's goldens can only be captured with it off (CPU); with it on, the step reproduces them too
+    # (tests/test_amp.py).  Ignored on a CPU device.
+    use_mixed_precision: bool = False
 
 
 @dataclass
@@ -345,12 +352,15 @@ class FusedBucketAdam:
             self.segment_end.append(off)
         assert off == model.flat.numel()
 
-    def step(self) -> None:
+    def step(self, skip_if_nonzero: Optional[torch.Tensor] = None) -> None:
+        """``skip_if_nonzero`` (int32 [1] on the device): the update is skipped when it is set -- the caller then takes
+        ``step_count`` back by one once it has read the flag (GradScaler.step does not call the optimizer at all)."""
         from . import stages as S
         self.step_count += 1
         with torch.no_grad():
             S.adam_step(self.model.flat, self.model.flat_grad, self.exp_avg, self.exp_avg_sq, self.segment_end,
-                        [g["lr"] for g in self.param_groups], self.step_count, self.betas[0], self.betas[1], self.eps)
+                        [g["lr"] for g in self.param_groups], self.step_count, self.betas[0], self.betas[1], self.eps,
+                        skip_if_nonzero=skip_if_nonzero)
 
 
 class ViewParallelTrainer:
@@ -380,6 +390,11 @@ class ViewParallelTrainer:
             self.optimizer = FusedBucketAdam(model, groups)
         else:
             self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)  # trainer.py:331-340
+        # mixed precision (trainer.py:31): torch's GradScaler on the autograd path; the fused path keeps the same
+        # state itself (init 65536, x2 after 2000 good steps, x0.5 after a non-finite gradient: GradScaler's defaults)
+        self.amp = bool(self.cfg.use_mixed_precision) and model.flat.is_cuda
+        self.scaler = torch.amp.GradScaler("cuda") if self.amp and not self.fused else None
+        self.loss_scale, self._good_steps, self.skipped_steps = 65536.0, 0, 0
 
     def active_sh_degree(self) -> int:
         return min(int(self.iteration // self.cfg.sh_increment_interval), int(self.cfg.sh_degree_max))
@@ -475,8 +490,9 @@ class ViewParallelTrainer:
         for view in batch[self.rank::self.world]:
             viewpoint = {"world_view_transform": view["pose"], "image_width": view["width"],
                          "image_height": view["height"]}
-            out = self.backend.render_with_depth(params, viewpoint, bg_color=torch.zeros(3, device=dev),
-                                                 render_mode="RGB", device=str(dev), sh_degree=degree)
+            with torch.autocast(device_type=dev.type, enabled=self.amp):   # trainer.py:468-470
+                out = self.backend.render_with_depth(params, viewpoint, bg_color=torch.zeros(3, device=dev),
+                                                     render_mode="RGB", device=str(dev), sh_degree=degree)
             rendered, target = out["render"], view["image"]
             loss, l1, ssim = view_loss(rendered, target, c.lambda_dssim)
             total = total + loss
@@ -486,9 +502,18 @@ class ViewParallelTrainer:
         reg = scale_ratio_reg(params["scales"], c.scale_reg_max_ratio, c.scale_reg_weight)
         if self.rank == 0:
             total = total + reg
-        total.backward()
-        self._all_reduce(m.flat_grad)  # the one exchange step: 59*N floats, SUM
-        self.optimizer.step()
+        if self.scaler is not None:      # trainer.py:505-508; the exchange sums the SCALED gradients, so every rank
+            self.scaler.scale(total).backward()   # unscales the same numbers and takes the same skip decision
+            self._all_reduce(m.flat_grad)
+            before = self.scaler.get_scale()
+            self.scaler.step(self.optimizer)      # unscale_ (in place, on the bucket views) + inf check + Adam
+            self.scaler.update()
+            self.loss_scale = self.scaler.get_scale()
+            self.skipped_steps += int(self.loss_scale < before)
+        else:
+            total.backward()
+            self._all_reduce(m.flat_grad)  # the one exchange step: 59*N floats, SUM
+            self.optimizer.step()
 
         report = torch.cat([stats, total.detach().double()[None]])
         self._all_reduce(report)
@@ -564,6 +589,7 @@ class ViewParallelTrainer:
             return pose, splat, radii, bins, order, done
 
         mine = list(batch[self.rank::self.world])
+        scale = self.loss_scale if self.amp else 1.0   # loss scale: the backward passes see v_render times it
         sums, first = [], True
         ahead = front(mine[0]) if mine else None
         for j, view in enumerate(mine):
@@ -576,7 +602,7 @@ class ViewParallelTrainer:
             W, H = view["width"], view["height"]
             render, _, final_T, last_id, lists = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bgc, W,
                                                                  H, 3, order, want_lists=True)
-            s3, v = S.view_loss(render, view["image"], c.lambda_dssim, grad_scale=1.0 / n_views)
+            s3, v = S.view_loss(render, view["image"], c.lambda_dssim, grad_scale=scale / n_views)
             v_splat = S.composite_bwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bgc, final_T, last_id, v, None,
                                       W, H, 3, order, quad_lists=lists)
             S.project_bwd(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], degree, pose, Kc, W, H, splat, radii,
@@ -591,7 +617,8 @@ class ViewParallelTrainer:
         # chain rule of the activations + the scale regulariser (value everywhere, gradient on rank 0), one kernel,
         # written straight into the raw-parameter gradient views of flat_grad
         reg = S.activate_bwd(m.scaling, m.rotation, m.opacity, g_scales, g_quats, g_opac, m.scaling.grad, m.rotation.grad,
-                             m.opacity.grad, c.scale_reg_max_ratio, c.scale_reg_weight, add_reg_grad=self.rank == 0)
+                             m.opacity.grad, c.scale_reg_max_ratio, c.scale_reg_weight * scale,
+                             add_reg_grad=self.rank == 0) / scale
         if factored:
             # the SH-coefficient gradient of the whole batch, rebuilt from the 3 floats per gaussian and view the
             # backward passes left (summed in batch order), straight into features_dc.grad / features_rest.grad.
@@ -614,7 +641,11 @@ class ViewParallelTrainer:
                 m.features_dc.grad.copy_(g_shs[:, :1])
                 m.features_rest.grad.copy_(g_shs[:, 1:])
             self._all_reduce(m.flat_grad)  # the one exchange step: 59*N floats, SUM
-        self.optimizer.step()
+        found_inf = None
+        if self.amp:   # GradScaler.unscale_ + the skip decision, on the exchanged bucket (identical on every rank)
+            found_inf = torch.zeros(1, dtype=torch.int32, device=dev)
+            S.grad_unscale(m.flat_grad, 1.0 / scale, found_inf)
+        self.optimizer.step(skip_if_nonzero=found_inf)
 
         report = torch.zeros(5, dtype=torch.float64, device=dev)  # l1, ssim, psnr sums over local views; loss share; reg
         if sums:
@@ -628,5 +659,16 @@ class ViewParallelTrainer:
             report[3] += reg.detach().double()
             report[4] = reg.detach().double()
         self._all_reduce(report)
+        if found_inf is not None:
+            report = torch.cat([report, found_inf.double()])
         r = report.tolist()                                        # the step's one host read-back
+        if found_inf is not None:                                  # GradScaler.update()
+            if r[5] != 0.0:
+                self.optimizer.step_count -= 1                     # the update was skipped on the device
+                self.loss_scale, self._good_steps = self.loss_scale * 0.5, 0
+                self.skipped_steps += 1
+            else:
+                self._good_steps += 1
+                if self._good_steps >= 2000:
+                    self.loss_scale, self._good_steps = self.loss_scale * 2.0, 0
         return {"loss": r[3], "l1": r[0] / n_views, "ssim": r[1] / n_views, "psnr": r[2] / n_views, "scale_reg": r[4]}

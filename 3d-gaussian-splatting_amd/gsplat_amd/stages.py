@@ -491,9 +491,19 @@ def view_loss(render: torch.Tensor, target: torch.Tensor, lambda_dssim: float, g
     return sums, v
 
 
+def grad_unscale(grad: torch.Tensor, inv_scale: float, found_inf: torch.Tensor) -> None:
+    """grad *= inv_scale in place; ``found_inf`` (int32 [1] on the device, accumulated) becomes 1 if an element is not
+    finite -- GradScaler.unscale_ for the flat gradient bucket."""
+    if not (grad.is_cuda and grad.dtype == torch.float32 and grad.is_contiguous()):
+        raise ValueError("grad_unscale needs a contiguous fp32 device tensor")
+    _call("gsa_grad_unscale", lib.gsa_grad_unscale, grad.numel(), _ptr(grad), float(inv_scale), _ptr(found_inf), _stream())
+
+
 def adam_step(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
-              segment_end, segment_lr, step: int, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-15) -> None:
-    """One fused Adam update of a flat fp32 bucket in place (torch.optim.Adam arithmetic, per-segment lr)."""
+              segment_end, segment_lr, step: int, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-15,
+              skip_if_nonzero: Optional[torch.Tensor] = None) -> None:
+    """One fused Adam update of a flat fp32 bucket in place (torch.optim.Adam arithmetic, per-segment lr).
+    ``skip_if_nonzero``: int32 [1] on the device; a non-zero value skips the whole update (GradScaler.step)."""
     import ctypes
     n = param.numel()
     for t in (param, grad, exp_avg, exp_avg_sq):
@@ -503,7 +513,8 @@ def adam_step(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, ex
     ends = (ctypes.c_longlong * k)(*[int(e) for e in segment_end])
     lrs = (ctypes.c_float * k)(*[float(x) for x in segment_lr])
     _call("gsa_adam_step", lib.gsa_adam_step, n, _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), k,
-          ctypes.cast(ends, ctypes.c_void_p), ctypes.cast(lrs, ctypes.c_void_p), beta1, beta2, eps, int(step), _stream())
+          ctypes.cast(ends, ctypes.c_void_p), ctypes.cast(lrs, ctypes.c_void_p), beta1, beta2, eps, int(step),
+          _ptr(skip_if_nonzero), _stream())
 
 
 def densify_gather(n_old: int, field_width, xyz_field: int, scaling_field: int, log_split: float, src_row: torch.Tensor,

@@ -271,7 +271,8 @@ int gsa_sh_grad_expand_split(int n, const float *means, int sh_degree, int sh_co
  * gsa_adam_step: one torch.optim.Adam step (no weight decay, no amsgrad) over a flat bucket of n floats split into
  *   n_segments (<= 8) consecutive segments, segment k = [segment_end[k-1], segment_end[k]) with learning rate
  *   segment_lr[k] (host arrays; segment_end[n_segments-1] == n) -- the six parameter groups of
- *   trainer.py:331-340 laid out in one 59 N buffer.  step = 1 for the first update. */
+ *   trainer.py:331-340 laid out in one 59 N buffer.  step = 1 for the first update.  skip_if_nonzero: see
+ *   gsa_grad_unscale. */
 /* gsa_densify_gather: the data movement of GaussianModel.densify_and_prune
  * (src/gaussians/gaussian_model.py:110-366: clone, split into two, prune, with the Adam moments spliced through,
  * :9-50) as ONE pass.  Buckets are field-major (field f of width field_width[f] occupies a contiguous block of
@@ -290,7 +291,13 @@ int gsa_view_loss(int width, int height, const float *render, const float *targe
                   gsa_stream_t stream);
 int gsa_adam_step(long long n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                   int n_segments, const long long *segment_end, const float *segment_lr, double beta1,
-                  double beta2, double eps, int step, gsa_stream_t stream);
+                  double beta2, double eps, int step, const uint32_t *skip_if_nonzero, gsa_stream_t stream);
+/* Mixed-precision bookkeeping (the reference trains with GradScaler, src/training/trainer.py:31,505-511: the upstream
+ * gradient of the rasterizer arrives multiplied by the loss scale): grad *= inv_scale in place, and *found_inf
+ * (uint32 on the device, ACCUMULATED: zero it first) becomes 1 if any element is not finite -- torch's
+ * GradScaler.unscale_.  gsa_adam_step's skip_if_nonzero (may be NULL) then skips the whole update, as
+ * GradScaler.step does. */
+int gsa_grad_unscale(long long n, float *grad, float inv_scale, uint32_t *found_inf, gsa_stream_t stream);
 
 /* Activations of the reference model's raw parameters (src/gaussians/gaussian_model.py:86-108 as the trainer calls them,
  * trainer.py:399-406) in one pass: scales = exp(scaling) [N,3], quats = rotation / max(|rotation|, 1e-12) [N,4],
