@@ -99,11 +99,11 @@ def test_training_step_with_mixed_precision_matches_reference_trainer(gold, fuse
         ref = gold[f"step{step}_metrics"]
         assert np.all(np.abs(got - ref) <= 2e-5 * np.maximum(1.0, np.abs(ref))), (step, got, ref)
         for k in LEAVES:   # .grad holds the UNSCALED gradient after the step, as with GradScaler.step
-            assert _rel(getattr(model, k).grad.cpu().numpy(), gold[f"step{step}_grad_{k}"]) < 2e-3, (step, k)
-            assert _rel(getattr(model, k).detach().cpu().numpy(), gold[f"step{step}_param_{k}"]) < 2e-4, (step, k)
+            assert _rel(getattr(model, k).grad.cpu().numpy(), gold[f"step{step}_grad_{k}"]) < 1e-4, (step, k)
+            assert _rel(getattr(model, k).detach().cpu().numpy(), gold[f"step{step}_param_{k}"]) < 5e-5, (step, k)
     assert tr.skipped_steps == 0 and tr.loss_scale == 65536.0
     st = tr.optimizer.state[model.xyz]
-    assert _rel(st["exp_avg"].cpu().numpy(), gold["step2_adam_exp_avg_xyz"]) < 2e-3
+    assert _rel(st["exp_avg"].cpu().numpy(), gold["step2_adam_exp_avg_xyz"]) < 1e-4
 
 
 @pytest.mark.gpu
@@ -133,7 +133,7 @@ def test_non_finite_gradient_skips_the_step_and_halves_the_scale(gold, fused):
     got = np.asarray([metrics[k] for k in ("loss", "l1", "ssim", "psnr", "scale_reg")])
     assert np.all(np.abs(got - gold["step1_metrics"]) <= 2e-5 * np.maximum(1.0, np.abs(gold["step1_metrics"])))
     for k in LEAVES:
-        assert _rel(getattr(model, k).detach().cpu().numpy(), gold[f"step1_param_{k}"]) < 2e-4, k
+        assert _rel(getattr(model, k).detach().cpu().numpy(), gold[f"step1_param_{k}"]) < 5e-5, k
     assert tr.skipped_steps == 1 and tr.loss_scale == 32768.0
 
 

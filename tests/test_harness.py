@@ -79,14 +79,19 @@ def test_flat_bucket_layout():
 
 
 def _check_against_golden(gold, model, trainer, batch, tol_metric, tol_grad, tol_param):
+    worst = {"grad": 0.0, "param": 0.0}
     for step in (1, 2):
         metrics = trainer.training_step(batch)
         got = np.asarray([metrics[k] for k in ("loss", "l1", "ssim", "psnr", "scale_reg")])
         ref = gold[f"step{step}_metrics"]
         assert np.all(np.abs(got - ref) <= tol_metric * np.maximum(1.0, np.abs(ref))), (step, got, ref)
         for k in LEAVES:
-            assert _rel(getattr(model, k).grad.cpu().numpy(), gold[f"step{step}_grad_{k}"]) < tol_grad, (step, k)
-            assert _rel(getattr(model, k).detach().cpu().numpy(), gold[f"step{step}_param_{k}"]) < tol_param, (step, k)
+            eg = _rel(getattr(model, k).grad.cpu().numpy(), gold[f"step{step}_grad_{k}"])
+            ep = _rel(getattr(model, k).detach().cpu().numpy(), gold[f"step{step}_param_{k}"])
+            worst["grad"], worst["param"] = max(worst["grad"], eg), max(worst["param"], ep)
+            assert eg < tol_grad, (step, k, eg)
+            assert ep < tol_param, (step, k, ep)
+    print("harness vs reference goldens, worst relative error:", worst)
     st = trainer.optimizer.state[model.xyz]
     assert _rel(st["exp_avg"].cpu().numpy(), gold["step2_adam_exp_avg_xyz"]) < tol_grad
     assert _rel(st["exp_avg_sq"].cpu().numpy(), gold["step2_adam_exp_avg_sq_xyz"]) < 2 * tol_grad
@@ -154,13 +159,13 @@ def test_view_parallel_two_ranks_equal_one_rank(gold, tmp_path):
 # ---------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 def test_training_step_on_hip_backend_matches_reference_trainer(gold):
-    """Same two steps with the HIP rasterizer underneath (fp32 kernels vs the torch oracle: looser bounds)."""
+    """Same two steps with the HIP rasterizer underneath (fp32 kernels vs the torch oracle: measured 1.6e-5 on the gradients, 1.1e-5 on the parameters)."""
     import gsplat_amd
     from gsplat_amd.harness import ViewParallelTrainer
     model, batch = _model_and_batch(gold, "cuda")
     trainer = ViewParallelTrainer(model, gsplat_amd.HipBackend(_t(gold["K"], "cuda")))
     trainer.iteration = int(gold["step_iteration"])
-    _check_against_golden(gold, model, trainer, batch, tol_metric=2e-5, tol_grad=2e-3, tol_param=2e-4)
+    _check_against_golden(gold, model, trainer, batch, tol_metric=2e-5, tol_grad=1e-4, tol_param=5e-5)
 
 
 @pytest.mark.gpu
@@ -176,7 +181,7 @@ def test_fused_training_step_matches_reference_trainer(gold, overlap, factored):
     trainer = ViewParallelTrainer(model, gsplat_amd.HipBackend(_t(gold["K"], "cuda")), fused=True,
                                   overlap_views=overlap, factored_exchange=factored)
     trainer.iteration = int(gold["step_iteration"])
-    _check_against_golden(gold, model, trainer, batch, tol_metric=2e-5, tol_grad=2e-3, tol_param=2e-4)
+    _check_against_golden(gold, model, trainer, batch, tol_metric=2e-5, tol_grad=1e-4, tol_param=5e-5)
 
 
 @pytest.mark.gpu
@@ -238,7 +243,7 @@ def _fused_rank_main(rank, world, port, factored):
                                   fused=True, factored_exchange=factored)
     assert trainer.factored == factored
     trainer.iteration = int(gold["step_iteration"])
-    _check_against_golden(gold, model, trainer, batch, tol_metric=2e-5, tol_grad=2e-3, tol_param=2e-4)
+    _check_against_golden(gold, model, trainer, batch, tol_metric=2e-5, tol_grad=1e-4, tol_param=5e-5)
     mine = model.flat.detach().clone()
     other = mine.clone()
     dist.broadcast(other, src=0)

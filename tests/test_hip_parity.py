@@ -9,16 +9,17 @@ as max|a-b| / max|b| per tensor (``REL_TOL``).  Two properties of the function i
   (a bounded, reported fraction) are excluded from the image comparison and their upstream gradient is zeroed
   on BOTH sides; everything else is compared.
 * End to end it is ILL-CONDITIONED in fp32: mean2d is an fp32 pixel coordinate (ulp 1.2e-4 at x > 1024) and
-  d alpha / alpha = conic * d * (error of mean2d), so at 1080p two fp32 evaluations of the same formulas already
-  differ by more than 1e-4 in places.  The end-to-end tests therefore measure BOTH the HIP path and the fp32
-  oracle against the fp64 oracle and require  err(HIP) <= max(1e-4, 2 * err(fp32 oracle)).
-  The stage-level tests feed the oracle the same intermediates the kernels consume, are well conditioned,
-  and hold the plain 1e-4 (or tighter).
+  d alpha / alpha = conic * d * (error of mean2d).  The end-to-end tests therefore measure BOTH the HIP path and the
+  fp32 oracle against the fp64 oracle.  The bound on the HIP path is the plain 1e-4 on every tensor, outright -- it
+  holds everywhere (measured: <= 3e-5 at C2, profiles/r02_parity_c2.json; <= 4e-6 on the small scenes); the fp32
+  oracle's own distance from the fp64 one is reported beside it for scale.  ``_compare(relaxed=...)`` can name
+  tensors that get max(1e-4, 2 x fp32-oracle error) instead; no test needs it.
+  The stage-level tests feed the oracle the same intermediates the kernels consume and hold 1e-4 or tighter.
 
 Integer outputs (radii, tile counts, sorted ids, offsets) are compared exactly, up to the handful of gaussians
 whose ceil() lands on the other side of an fp32 rounding."""
+import json
 import math
-
 import os
 
 import numpy as np
@@ -63,8 +64,10 @@ def _run(fn, dev, dtype, sc, vm, K, W, H, deg, bg, v_r, v_a, keep=None, **kw):
     return outs, meta, keep
 
 
-def _compare(sc, vm, K, W, H, deg, bg, seed=2, use_v_alpha=True, checkpoint=False, **kw):
-    """HIP and the fp32 oracle, both against the fp64 oracle; see the module docstring."""
+def _compare(sc, vm, K, W, H, deg, bg, seed=2, use_v_alpha=True, checkpoint=False, relaxed=(), **kw):
+    """HIP and the fp32 oracle, both against the fp64 oracle; see the module docstring.  Every tensor must be within
+    REL_TOL of the fp64 oracle OUTRIGHT, except those named in ``relaxed``: for them (ill-conditioned in fp32 on that
+    scene: the fp32 oracle itself is further than 1e-4 from the fp64 one) the bound is max(1e-4, 2 x fp32-oracle error)."""
     import gsplat_amd
     from oracle import rasterization as oracle_rasterization
 
@@ -83,9 +86,11 @@ def _compare(sc, vm, K, W, H, deg, bg, seed=2, use_v_alpha=True, checkpoint=Fals
     for k in o64:
         e32, eh = _rel(o32[k], o64[k]), _rel(hip[k], o64[k])
         report[k] = (eh, e32)
-        if not eh <= max(REL_TOL, 2.0 * e32):
+        bound = max(REL_TOL, 2.0 * e32) if k in relaxed else REL_TOL
+        if not eh <= bound:
             bad[k] = (eh, e32)
-    assert not bad, f"HIP error vs fp64 oracle exceeds max(1e-4, 2 x fp32-oracle error): {bad}; all: {report}"
+    print("parity report:", report)
+    assert not bad, f"HIP error vs fp64 oracle exceeds its bound (1e-4; `relaxed` tensors max(1e-4, 2 x fp32-oracle error)): {bad}; all: {report}"
     return m1, m32, report
 
 
@@ -487,6 +492,21 @@ def test_config_c2_100k_1080p_deg3(gsa):
     m1, m0, errs = _compare(sc, scene.make_camera(0, 1), scene.make_intrinsics(W, H), W, H, 3,
                             bg=torch.zeros(3), use_v_alpha=False, checkpoint=True)
     print("C2 (err HIP vs fp64, err fp32-oracle vs fp64):", errs, "M =", m1["flatten_ids"].numel())
+    # evidence: per tensor (err of HIP vs the fp64 oracle, err of the fp32 oracle vs the fp64 oracle), the masked
+    # pixel fraction -- written where the GPU run's artefacts are collected (committed copy: profiles/r02_parity_c2.json)
+    record = {"config": "C2: 100000 gaussians, 1920x1080, SH degree 3, forward+backward, view 0",
+              "metric": "max|a - b| / max|b| per tensor, b = fp64 oracle; pixels whose threshold comparisons are "
+                        "ambiguous in the fp64 oracle are masked on both sides",
+              "masked_pixel_fraction": errs["ambiguous_fraction"], "intersections_M": int(m1["flatten_ids"].numel()),
+              "tensors": {k: {"err_hip": v[0], "err_fp32_oracle": v[1]} for k, v in errs.items() if k != "ambiguous_fraction"}}
+    try:
+        out_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
+                               "gpurun_out")
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "parity_c2.json"), "w") as fh:
+            json.dump(record, fh, indent=1)
+    except OSError:
+        pass
     assert 0 < m1["flatten_ids"].numel() <= m0["flatten_ids"].numel() + 64  # default cull_mode drops unreachable tiles
 
 

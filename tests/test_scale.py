@@ -1,0 +1,250 @@
+"""BASELINE configs C4 and C5 at their real sizes, where the CPU oracle is out of reach: size-independent properties,
+checksums against a second decomposition of the same work, and bit-exact data movement.
+
+* C4 shape (1M gaussians, 1080p, 8-view batch, view-parallel): the gradient bucket and the parameters after ONE fused
+  step over 8 ring views in one process == the same step on 2 ranks x 4 views (gloo, the ranks share the box's GPU),
+  with the factored exchange and with the plain 59 N all-reduce.
+* C5 shape (5M gaussians, 3840x2160, degree 3): the properties of test_full_size_properties_c3 (reproducible forward,
+  linear backward, finite gradients, sorted bins); one densify / prune event at 5M against torch index operations
+  (/root/reference/src/gaussians/gaussian_model.py:110-231: parameters and both Adam moment buckets, bit for bit
+  where only data moves); the fused Adam step at 1M x 59 floats against torch.optim.Adam."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+pytestmark = pytest.mark.gpu
+FIELDS = ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation")
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# C4
+# ---------------------------------------------------------------------------------------------------------
+C4_N, C4_W, C4_H, C4_VIEWS = 1_000_000, 1920, 1080, 8
+
+
+def _c4_model_and_batch(dev="cuda"):
+    """The bench scene as raw (pre-activation) parameters of the reference model, and 8 ring views with seeded
+    targets."""
+    from gsplat_amd import scene
+    from gsplat_amd.harness import SplatModel
+    sc = scene.make_scene(C4_N, seed=0, sh_degree=3)
+    model = SplatModel(C4_N, device=dev)
+    op = sc["opacities"].clamp(1e-4, 1 - 1e-4)
+    model.load(xyz=sc["means3D"].to(dev), scaling=torch.log(sc["scales"]).to(dev), rotation=sc["rotations"].to(dev),
+               opacity=torch.log(op / (1 - op)).to(dev), features_dc=sc["shs"][:, :1].contiguous().to(dev),
+               features_rest=sc["shs"][:, 1:].contiguous().to(dev))
+    g = torch.Generator().manual_seed(77)
+    batch = [{"image": torch.rand(C4_H, C4_W, 3, generator=g).to(dev), "pose": scene.make_camera(v, C4_VIEWS).to(dev),
+              "width": C4_W, "height": C4_H} for v in range(C4_VIEWS)]
+    return model, batch, scene.make_intrinsics(C4_W, C4_H).to(dev)
+
+
+def _digest(t: torch.Tensor):
+    """Checksums + a strided sample of a large tensor (what the ranks hand back)."""
+    t = t.detach()
+    return {"sum": float(t.double().sum()), "abs": float(t.double().abs().sum()), "sample": t[::9973].double().cpu().numpy()}
+
+
+def _c4_rank_main(rank, world, port, factored, out_path):
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "3d-gaussian-splatting_amd"))
+    import gsplat_amd
+    from gsplat_amd.harness import ViewParallelTrainer
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    model, batch, K = _c4_model_and_batch()
+    tr = ViewParallelTrainer(model, gsplat_amd.HipBackend(K), rank=rank, world_size=world, fused=True,
+                             factored_exchange=factored)
+    tr.iteration = 3000
+    metrics = tr.training_step(batch)
+    mine = model.flat.detach().clone()
+    other = mine.clone()
+    dist.broadcast(other, src=0)
+    assert _rel(mine, other) < 1e-6                      # identical parameters on every rank
+    if factored:                                          # the rebuilt SH gradient is summed in batch order everywhere
+        assert torch.equal(mine[3 * C4_N:51 * C4_N], other[3 * C4_N:51 * C4_N])
+    if rank == 0:
+        torch.save({"grad": _digest(model.flat_grad), "flat": _digest(model.flat), "metrics": metrics}, out_path)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("factored", [True, False])
+def test_c4_eight_views_one_process_equals_two_ranks_of_four(tmp_path, factored):
+    import torch.multiprocessing as mp
+    import gsplat_amd
+    from gsplat_amd.harness import ViewParallelTrainer
+    model, batch, K = _c4_model_and_batch()
+    tr = ViewParallelTrainer(model, gsplat_amd.HipBackend(K), fused=True, factored_exchange=factored)
+    tr.iteration = 3000
+    before = model.flat.detach().clone()
+    metrics = tr.training_step(batch)                     # 8 backward passes accumulated into ONE bucket, then Adam
+    one = {"grad": _digest(model.flat_grad), "flat": _digest(model.flat)}
+    assert torch.isfinite(model.flat_grad).all() and not torch.equal(model.flat.detach(), before)
+    assert 0.0 < metrics["loss"] < 1.0 and 0.0 < metrics["psnr"] < 30.0
+    del tr, model, before
+    torch.cuda.empty_cache()
+    out = str(tmp_path / "rank0.pt")
+    mp.spawn(_c4_rank_main, args=(2, _free_port(), factored, out), nprocs=2, join=True)
+    two = torch.load(out, weights_only=False)
+    for what, tol in (("grad", 2e-4), ("flat", 1e-6)):    # float atomics reorder the per-view sums
+        a, b = one[what], two[what]
+        scale = max(abs(b["abs"]), 1e-30)
+        assert abs(a["sum"] - b["sum"]) <= tol * scale and abs(a["abs"] - b["abs"]) <= tol * scale, what
+        assert np.abs(a["sample"] - b["sample"]).max() <= tol * max(np.abs(b["sample"]).max(), 1e-30), what
+    for k in ("loss", "l1", "ssim", "psnr"):
+        assert abs(metrics[k] - two["metrics"][k]) <= 1e-5 * max(1.0, abs(metrics[k])), k
+
+
+# ---------------------------------------------------------------------------------------------------------
+# C5
+# ---------------------------------------------------------------------------------------------------------
+def test_c5_full_size_properties_5m_4k():
+    import gsplat_amd as gsa
+    from gsplat_amd import scene
+    N, W, H = 5_000_000, 3840, 2160
+    sc = scene.make_scene(N, seed=0, sh_degree=3)
+    vm, K = scene.make_camera(0, 1)[None].cuda(), scene.make_intrinsics(W, H)[None].cuda()
+    v = scene.make_v_render(W, H, seed=2).cuda()[None]
+    base = [sc["means3D"].cuda(), sc["rotations"].cuda(), sc["scales"].cuda(), sc["opacities"][:, 0].cuda(), sc["shs"].cuda()]
+    del sc
+
+    def run(upstream):
+        leaves = [t.clone().requires_grad_(True) for t in base]
+        r, a, meta = gsa.rasterization(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], vm, K, W, H, sh_degree=3,
+                                       backgrounds=torch.zeros(1, 3, device="cuda"))
+        r.backward(upstream)
+        return r.detach(), a.detach(), meta, [t.grad for t in leaves]
+
+    r0, a0, m0, g1 = run(v)
+    r1, a1, m1, g2 = run(2.0 * v)                        # (steady state: remembered capacity and depth-key bits)
+    assert torch.equal(r0, r1) and torch.equal(a0, a1)   # reproducible forward
+    assert m0["n_isects"] == m1["n_isects"] > 8 * N
+    for name, x, y in zip(("means", "quats", "scales", "opacities", "colors"), g1, g2):
+        assert torch.isfinite(x).all() and torch.isfinite(y).all(), name
+        assert _rel(2.0 * x, y) < 1e-4, name             # linear backward (atomics reorder the sums)
+    assert float(a0.min()) >= 0.0 and float(a0.max()) <= 1.0
+    del g1, g2, r1, a1
+    # sorted bins: tile ids ascending, depth ascending inside a tile, offsets = first record of every tile
+    off = m0["isect_offsets"].reshape(-1).long()
+    gid = m0["flatten_ids"].long()
+    depth = m0["depths"][0][gid]
+    tile_of = torch.repeat_interleave(torch.arange(off.numel(), device="cuda"),
+                                      torch.diff(torch.cat([off, off.new_tensor([gid.numel()])])))
+    assert tile_of.numel() == gid.numel()
+    same_tile = tile_of[1:] == tile_of[:-1]
+    assert bool((depth[1:][same_tile] >= depth[:-1][same_tile]).all())
+    # every record's gaussian really covers its tile (tile rectangle of mean2d +- radius)
+    tw = (W + 15) // 16
+    sample = torch.randint(0, gid.numel(), (200_000,), device="cuda")
+    g_s, t_s = gid[sample], tile_of[sample]
+    m2d, rad = m0["means2d"][0][g_s], m0["radii"][0][g_s].float()
+    tx, ty = (t_s % tw).float(), (t_s // tw).float()
+    assert bool(((m2d[:, 0] + rad[:, 0]) / 16 > tx).all() and ((m2d[:, 0] - rad[:, 0]) / 16 < tx + 1).all())
+    assert bool(((m2d[:, 1] + rad[:, 1]) / 16 > ty).all() and ((m2d[:, 1] - rad[:, 1]) / 16 < ty + 1).all())
+
+
+def test_c5_densify_and_prune_event_at_5m():
+    """One densify / prune event at the C5 population: the HIP gather pass (parameters + both Adam moment buckets)
+    against the same event written with torch index operations in the reference's order -- [rows that are not split]
+    + [clones] + [first children] + [second children], then the prune mask (gaussian_model.py:110-231)."""
+    from gsplat_amd.harness import FIELDS as HF, FusedBucketAdam, SplatModel, StepConfig, _adam_groups
+    N = 5_000_000
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rnd = lambda *s: torch.rand(*s, generator=g, device="cuda")  # noqa: E731
+    model = SplatModel(N, "cuda")
+    model.load(xyz=rnd(N, 3) * 2 - 1, features_dc=rnd(N, 1, 3), features_rest=rnd(N, 15, 3) * 0.1,
+               opacity=rnd(N, 1) * 10 - 7, scaling=torch.log(rnd(N, 3) * 0.25 + 1e-3), rotation=rnd(N, 4) - 0.5)
+    model.xyz_gradient_accum = (rnd(N, 1) * 2e-3).expand(N, 3).contiguous()
+    model.xyz_gradient_count = torch.ones(N, 1, device="cuda")
+    opt = FusedBucketAdam(model, _adam_groups(model, StepConfig()))
+    opt.exp_avg.copy_(rnd(59 * N) - 0.5)
+    opt.exp_avg_sq.copy_(rnd(59 * N))
+    old = {k: getattr(model, k).detach().clone() for k in FIELDS}
+    old_m = {k: opt.state[getattr(model, k)]["exp_avg"].clone() for k in FIELDS}
+    old_v = {k: opt.state[getattr(model, k)]["exp_avg_sq"].clone() for k in FIELDS}
+    thr, min_op, extent = 1e-3, 0.005, 1.0
+    grads = torch.norm(model.xyz_gradient_accum / (model.xyz_gradient_count + 1e-8), dim=-1)
+    max_scale = torch.exp(old["scaling"]).amax(-1)
+    opac = torch.sigmoid(old["opacity"]).squeeze(-1)
+    hot = (grads >= thr) & (opac > min_op)
+    clone, split = hot & (max_scale <= 0.1 * extent), hot & (max_scale > 0.1 * extent)
+    n_split = int(split.sum())
+    noise = torch.randn(2 * n_split, 3, generator=g, device="cuda")
+    stats = model.densify_and_prune(thr, min_op, extent, max_screen_size=12.0, optimizer=opt, noise=noise)
+    assert stats["cloned"] == int(clone.sum()) > 100_000 and stats["split"] == n_split > 100_000
+
+    log_split = torch.log(torch.tensor(1.6)).cuda()      # fp32, computed on the host as the harness does
+
+    def event(field, src, zero_new):
+        keep, cl, sp = src[~split], src[clone], src[split]
+        if zero_new:
+            cl, sp = torch.zeros_like(cl), torch.zeros_like(sp)
+        kids = torch.cat([sp, sp])
+        if field == "scaling" and not zero_new:
+            kids = kids - log_split
+        if field == "xyz" and not zero_new:
+            kid_scale = torch.exp(torch.cat([old["scaling"][split]] * 2) - log_split)
+            kids = kids + noise * kid_scale
+        return torch.cat([keep, cl, kids])
+
+    pop_scale = event("scaling", old["scaling"], False)
+    pop_op = torch.sigmoid(event("opacity", old["opacity"], False)).squeeze(-1)
+    prune = (pop_op < min_op) | (torch.exp(pop_scale).amax(-1) > 2.0 * extent)
+    assert stats["pruned"] == int(prune.sum()) > 10_000 and model.n == stats["n_after"] == int((~prune).sum())
+    for k in FIELDS:
+        want = event(k, old[k], False)[~prune]
+        got = getattr(model, k).detach()
+        if k == "xyz":    # the children's positions are computed (exp + fma) by the kernel
+            assert _rel(got, want) < 1e-6, k
+        else:
+            assert torch.equal(got, want), k
+        assert torch.equal(opt.state[getattr(model, k)]["exp_avg"], event(k, old_m[k], True)[~prune]), k
+        assert torch.equal(opt.state[getattr(model, k)]["exp_avg_sq"], event(k, old_v[k], True)[~prune]), k
+    model.check_bound()
+    opt.step()                                            # the spliced optimizer still steps at the new size
+    assert [name for name, _ in HF] == list(FIELDS)
+
+
+def test_fused_adam_step_at_c3_size():
+    """gsa_adam_step over the 59 x 1M bucket with the reference's six learning rates == torch.optim.Adam, three steps."""
+    from gsplat_amd.harness import FusedBucketAdam, SplatModel, StepConfig, _adam_groups
+    N = 1_000_000
+    g = torch.Generator(device="cuda").manual_seed(11)
+    model = SplatModel(N, "cuda")
+    with torch.no_grad():
+        model.flat.copy_(torch.randn(59 * N, generator=g, device="cuda"))
+    ref = [p.detach().clone().requires_grad_(True) for p in model.parameters()]
+    groups = _adam_groups(model, StepConfig())
+    ref_opt = torch.optim.Adam([{"params": [p], "lr": grp["lr"]} for p, grp in zip(ref, groups)], lr=0.0, eps=1e-15)
+    opt = FusedBucketAdam(model, groups)
+    for _ in range(3):
+        grad = torch.randn(59 * N, generator=g, device="cuda") * 1e-3
+        grad[::5] = 0.0
+        model.flat_grad.copy_(grad)
+        off = 0
+        for p in ref:
+            p.grad = grad[off:off + p.numel()].view(p.shape).clone()
+            off += p.numel()
+        ref_opt.step()
+        opt.step()
+    want = torch.cat([p.detach().reshape(-1) for p in ref])
+    assert _rel(model.flat, want) < 2e-6
+    st = ref_opt.state[ref[2]]
+    assert _rel(opt.state[model.features_rest]["exp_avg"], st["exp_avg"]) < 1e-6
+    assert _rel(opt.state[model.features_rest]["exp_avg_sq"], st["exp_avg_sq"]) < 1e-6
