@@ -32,6 +32,19 @@ __device__ __forceinline__ int resolve_count(int n_cap, const uint32_t *__restri
     return n_dev ? (int)min((uint32_t)n_cap, *n_dev) : n_cap;
 }
 
+// Digit of a key in one radix pass.  Plain: bits [shift, shift + 8).  MSD bucketing of depth keys (msd_sub != 0 or
+// msd flag): bucket = (key - sub) >> shift clamped to 254, and the culled sentinel 0xFFFFFFFF alone in bucket 255 --
+// monotone in the key, so buckets are depth ranges (gsa_depth_order_msd).
+struct RadixDigit {
+    int shift;
+    uint32_t sub;
+    int msd;
+};
+__device__ __forceinline__ uint32_t digit_of(uint32_t key, const RadixDigit &dg) {
+    if (dg.msd) return key == 0xFFFFFFFFu ? 255u : min((key - dg.sub) >> dg.shift, 254u);
+    return (key >> dg.shift) & (kRadix - 1);
+}
+
 // ---- pass 1: per-block digit histogram, written digit-major: hist[d * nblocks + block] -------------
 // Plain per-lane LDS atomics: measured faster than aggregating same-digit lanes with ballots first (the LDS
 // resolves same-address adds of one instruction cheaply; the 8 ballots per key cost more than they save).
@@ -40,9 +53,10 @@ __device__ __forceinline__ int resolve_count(int n_cap, const uint32_t *__restri
 template <typename KeyT>
 __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(int n_cap, const uint32_t *__restrict__ n_dev,
                                                                   const KeyT *__restrict__ keys,
-                                                                  int shift, int nblocks,
+                                                                  RadixDigit dg, int nblocks,
                                                                   uint32_t *__restrict__ hist,
                                                                   uint32_t *__restrict__ block_range) {
+    const int shift = dg.shift;
     __shared__ uint32_t h[kRadix];
     __shared__ uint32_t s_lo, s_hi;
     const int n = resolve_count(n_cap, n_dev);
@@ -75,7 +89,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(int n_cap, con
             long i = base + r * kSortThreads + threadIdx.x;
             if (i < n) {
                 const uint32_t kk = (uint32_t)keys[i];
-                atomicAdd(&h[(kk >> shift) & (kRadix - 1)], 1u);
+                atomicAdd(&h[digit_of(kk, dg)], 1u);
                 if (kk != 0xFFFFFFFFu) { lo = min(lo, kk); hi = max(hi, kk); }
             }
         }
@@ -120,8 +134,12 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *scratc
 __global__ __launch_bounds__(kSortThreads) void radix_scan_rows_kernel(int nblocks, uint32_t *__restrict__ hist,
                                                                        uint32_t *__restrict__ digit_total,
                                                                        const uint32_t *__restrict__ block_range = nullptr,
-                                                                       uint32_t *__restrict__ key_range = nullptr) {
+                                                                       uint32_t *__restrict__ key_range = nullptr,
+                                                                       uint32_t *__restrict__ zero_words = nullptr,
+                                                                       int n_zero = 0) {
     __shared__ uint32_t scratch[4];
+    if (zero_words && blockIdx.x == 1)   // control words of the kernel that follows (polled there: must start at zero)
+        for (int i = threadIdx.x; i < n_zero; i += kSortThreads) zero_words[i] = 0u;
     if (key_range && blockIdx.x == 0) {   // min / max over the per-block ranges the histogram pass left
         __shared__ uint32_t r_lo, r_hi;
         if (threadIdx.x == 0) { r_lo = 0xFFFFFFFFu; r_hi = 0u; }
@@ -134,7 +152,11 @@ __global__ __launch_bounds__(kSortThreads) void radix_scan_rows_kernel(int nbloc
         atomicMin(&r_lo, lo);
         atomicMax(&r_hi, hi);
         __syncthreads();
-        if (threadIdx.x == 0) { key_range[0] = r_lo; key_range[1] = r_hi; }
+        if (threadIdx.x == 0) {
+            key_range[0] = r_lo;
+            key_range[1] = r_hi;
+            if (zero_words) key_range[2] = 0u;   // (gsa_depth_order_msd: the status word behind the range)
+        }
     }
     uint32_t *row = hist + (long)blockIdx.x * nblocks;
     uint32_t carry = 0;
@@ -177,7 +199,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scan_rows_kernel(int nbloc
 template <typename KeyT>
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     int n_cap, const uint32_t *__restrict__ n_dev, const KeyT *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-    KeyT *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int shift, int nblocks,
+    KeyT *__restrict__ keys_out, uint32_t *__restrict__ vals_out, RadixDigit dg, int nblocks,
     const uint32_t *__restrict__ hist, const uint32_t *__restrict__ digit_total,
     const uint2 *__restrict__ pairs = nullptr, uint32_t *__restrict__ pair_x_out = nullptr,
     uint32_t *__restrict__ pair_y_out = nullptr) {
@@ -218,7 +240,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         const bool valid = base + r * 64 + lane < n;
-        const uint32_t d = (k[r] >> shift) & (kRadix - 1);
+        const uint32_t d = digit_of(k[r], dg);
         // lanes of this wave holding the same digit
         unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -245,7 +267,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         if (base + r * 64 + lane < n) {
-            const uint32_t d = (k[r] >> shift) & (kRadix - 1);
+            const uint32_t d = digit_of(k[r], dg);
             const uint32_t lp = cnt[d] + rk[r];
             s_key[lp] = (KeyT)k[r];
             s_val[lp] = v[r];
@@ -258,7 +280,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
         int lp = r * kSortThreads + t;
         if (lp < m) {
             uint32_t key = s_key[lp];
-            uint32_t d = (key >> shift) & (kRadix - 1);
+            uint32_t d = digit_of(key, dg);
             uint32_t pos = gbase[d] + ((uint32_t)lp - lexcl[d]);
             if (keys_out) keys_out[pos] = (KeyT)key;
             const uint32_t val = s_val[lp];
@@ -744,12 +766,12 @@ static int sort_pairs_impl(int n, const uint32_t *n_dev, const uint32_t *keys_in
         uint32_t *kout = to_out ? keys_out : keys_tmp;
         uint32_t *vout = to_out ? vals_out : vals_tmp;
         int shift = begin_bit + 8 * p;
-        radix_hist_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(n, n_dev, kin, shift, nblocks, hist, nullptr);
+        radix_hist_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(n, n_dev, kin, RadixDigit{shift, 0u, 0}, nblocks, hist, nullptr);
         GSA_LAUNCH_CHECK();
         radix_scan_rows_kernel<<<kRadix, kSortThreads, 0, s>>>(nblocks, hist, digit_total);
         GSA_LAUNCH_CHECK();
-        radix_scatter_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(n, n_dev, kin, vin, kout, vout, shift, nblocks, hist,
-                                                                        digit_total);
+        radix_scatter_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(n, n_dev, kin, vin, kout, vout, RadixDigit{shift, 0u, 0},
+                                                                        nblocks, hist, digit_total);
         GSA_LAUNCH_CHECK();
         kin = kout;
         vin = vout;
@@ -853,19 +875,276 @@ extern "C" int gsa_depth_order(int n, const uint32_t *depth_keys, const uint32_t
         const bool last = p == passes - 1;
         uint32_t *kout = last ? nullptr : kbuf[p & 1];
         uint32_t *vout = last ? order : vbuf[p & 1];
-        radix_hist_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(n, nullptr, kin, 8 * p, nblocks, hist,
+        radix_hist_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(n, nullptr, kin, RadixDigit{8 * p, 0u, 0}, nblocks, hist,
                                                                      p == 0 ? block_range : nullptr);
         GSA_LAUNCH_CHECK();
         radix_scan_rows_kernel<<<kRadix, kSortThreads, 0, s>>>(nblocks, hist, digit_total, p == 0 ? block_range : nullptr,
                                                                p == 0 ? key_range : nullptr);
         GSA_LAUNCH_CHECK();
         radix_scatter_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(
-            n, nullptr, kin, vin, kout, vout, 8 * p, nblocks, hist, digit_total,
+            n, nullptr, kin, vin, kout, vout, RadixDigit{8 * p, 0u, 0}, nblocks, hist, digit_total,
             last ? reinterpret_cast<const uint2 *>(tile_rects) : nullptr, last ? rects : nullptr, last ? counts : nullptr);
         GSA_LAUNCH_CHECK();
         kin = kout;
         vin = vout;
     }
+    return GSA_OK;
+}
+
+// ---- depth order by buckets: one MSD pass + a local sort per bucket, fused with the scan ------------------------------
+// The LSD depth sort costs three launches per 8 key bits, each at its latency floor for 1 M keys (~29 us per pass at
+// C3).  With the range of the visible keys known beforehand (remembered per scene shape, checked after the fact), ONE
+// global pass buckets the keys by depth range -- digit = (key - key_min) >> shift, 255 buckets of equal key width, the
+// culled sentinel alone in bucket 255 -- and ONE launch finishes the job with a workgroup per bucket: it sorts its
+// bucket in LDS on the remaining `shift` (<= 16) low bits (stable counting sort, 8 bits per pass, wave64 ballot
+// ranking), gathers the packed tile rectangles and record counts of its gaussians, scans the counts, learns the
+// records of the buckets in front of it from their published totals (one 8-byte {ready, count, last} granule per
+// bucket, relaxed agent-scope atomics, bounded spin; bucket ids are handed out by an atomic ticket, so a waiting block's
+// predecessors are always running or finished) and writes order / rects / offsets / block owners.
+// A bucket larger than the LDS capacity, or a key outside the assumed range, is REPORTED (ctl[3] / the key range in
+// ctl[1..2]); the caller then repeats with the LSD path.
+constexpr int kLocalThreads = 1024, kLocalWaves = kLocalThreads / 64, kLocalCap = 8192;
+constexpr unsigned long long kGranuleReady = 1ull << 63;
+constexpr uint32_t kStatusOverflow = 1u, kStatusTimeout = 2u;
+
+struct BucketLds {
+    uint32_t val[2][kLocalCap];           // gaussian ids, ping-pong; after the sort the idle half holds the record counts
+    uint16_t key[2][kLocalCap];           // the `shift` low bits of (key - key_min)
+    uint16_t rk[kLocalCap];               // rank of an item among the items of its digit in its wave's range
+    uint32_t wcnt[kLocalWaves][kRadix];   // per wave range and digit: count, then first slot
+    uint32_t dbase[kRadix];
+    uint32_t scratch[kLocalWaves + 2];
+};
+
+__device__ __forceinline__ uint32_t block1024_excl_scan(uint32_t v, uint32_t *scratch, uint32_t &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_incl_scan(v, lane);
+    if (lane == 63) scratch[wave] = inc;
+    __syncthreads();
+    uint32_t off = 0, sum = 0;
+#pragma unroll
+    for (int w = 0; w < kLocalWaves; ++w) {
+        const uint32_t c = scratch[w];
+        if (w < wave) off += c;
+        sum += c;
+    }
+    total = sum;
+    __syncthreads();
+    return off + inc - v;
+}
+
+__device__ __forceinline__ uint32_t block1024_max(uint32_t v, uint32_t *scratch) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t m = 0;
+#pragma unroll
+    for (int w = 0; w < kLocalWaves; ++w) m = max(m, scratch[w]);
+    __syncthreads();
+    return m;
+}
+
+// one stable counting-sort pass over the mm items of L.key/val[src] on key bits [bs, bs + 8) into [src ^ 1]
+__device__ __forceinline__ void bucket_local_pass(BucketLds &L, int src, int mm, int bs) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int R = ((mm + kLocalThreads - 1) / kLocalThreads) * 64;   // items per wave range (a multiple of 64)
+    for (int i = t; i < kLocalWaves * kRadix; i += kLocalThreads) (&L.wcnt[0][0])[i] = 0u;
+    __syncthreads();
+    {
+        uint32_t *cnt = L.wcnt[wave];
+        const int end = min(mm, (wave + 1) * R);
+        for (int i0 = wave * R; i0 < end; i0 += 64) {
+            const int i = i0 + lane;
+            const bool valid = i < end;
+            const uint32_t d = valid ? ((uint32_t)L.key[src][i] >> bs) & (kRadix - 1) : 0u;
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const unsigned long long mk = __ballot((d >> b) & 1);
+                peers &= ((d >> b) & 1) ? mk : ~mk;
+            }
+            const uint32_t below = __popcll(peers & ((1ull << lane) - 1ull));
+            const uint32_t seen = cnt[d];
+            if (valid) L.rk[i] = (uint16_t)(seen + below);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if (valid && below == 0) cnt[d] = seen + (uint32_t)__popcll(peers);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    __syncthreads();
+    uint32_t total = 0;
+    if (t < kRadix) {   // digit t: first slot of every wave range's items inside the digit; digit total
+#pragma unroll
+        for (int w = 0; w < kLocalWaves; ++w) {
+            const uint32_t c = L.wcnt[w][t];
+            L.wcnt[w][t] = total;
+            total += c;
+        }
+    }
+    uint32_t all;
+    const uint32_t ex = block1024_excl_scan(t < kRadix ? total : 0u, L.scratch, all);   // (threads >= 256 add zeros behind)
+    if (t < kRadix) L.dbase[t] = ex;
+    __syncthreads();
+    for (int i = t; i < mm; i += kLocalThreads) {
+        const uint32_t k = L.key[src][i];
+        const uint32_t d = (k >> bs) & (kRadix - 1);
+        const uint32_t pos = L.dbase[d] + L.wcnt[i / R][d] + L.rk[i];
+        L.key[src ^ 1][pos] = (uint16_t)k;
+        L.val[src ^ 1][pos] = L.val[src][i];
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
+    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, const uint32_t *__restrict__ digit_total,
+    uint32_t key_min, int shift, const uint2 *__restrict__ tile_rects, uint32_t *__restrict__ order,
+    uint32_t *__restrict__ rects, uint32_t *__restrict__ offsets, int32_t *__restrict__ block_owner, int n_owner_blocks,
+    unsigned long long *granule, uint32_t *ticket, uint32_t *__restrict__ ctl) {
+    __shared__ BucketLds L;
+    __shared__ uint32_t s_bucket;
+    const int t = threadIdx.x;
+    if (t == 0) s_bucket = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const int d = (int)s_bucket;                       // this block's bucket, in order of arrival
+    // bucket d = items [lo, lo + m) of the first pass's output
+    uint32_t all;
+    const uint32_t dt = t < kRadix ? digit_total[t] : 0u;
+    const uint32_t lo_t = block1024_excl_scan(dt, L.scratch, all);   // (thread t: start of bucket t)
+    if (t == d) { L.dbase[0] = lo_t; L.dbase[1] = dt; }
+    __syncthreads();
+    const uint32_t lo = L.dbase[0], m = L.dbase[1];
+    __syncthreads();
+    const bool culled_bucket = d == kRadix - 1;        // their entries of order / rects / offsets are never read
+    const int mm = culled_bucket ? 0 : (int)min(m, (uint32_t)kLocalCap);
+    if (!culled_bucket && m > (uint32_t)kLocalCap && t == 0) atomicOr(&ctl[3], kStatusOverflow);
+
+    int cur = 0;
+    const uint32_t mask = shift >= 16 ? 0xFFFFu : ((1u << shift) - 1u);
+    for (int i = t; i < mm; i += kLocalThreads) {
+        L.key[0][i] = (uint16_t)((keys_in[lo + i] - key_min) & mask);
+        L.val[0][i] = vals_in[lo + i];
+    }
+    __syncthreads();
+    if (mm > 0 && shift > 0) { bucket_local_pass(L, cur, mm, 0); cur ^= 1; }   // (mm, shift: uniform)
+    if (mm > 0 && shift > 8) { bucket_local_pass(L, cur, mm, 8); cur ^= 1; }
+
+    // rectangles and record counts of the bucket's gaussians, now in depth order
+    uint32_t *cnt = L.val[cur ^ 1];
+    for (int i = t; i < mm; i += kLocalThreads) {
+        const uint32_t g = L.val[cur][i];
+        const uint2 pr = tile_rects[g];
+        order[lo + i] = g;
+        rects[lo + i] = pr.x;
+        cnt[i] = pr.y;
+    }
+    __syncthreads();
+    // exclusive scan of the counts: 8 consecutive items per thread
+    constexpr int kPer = kLocalCap / kLocalThreads;
+    uint32_t c[kPer], sum = 0, last = 0;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int i = t * kPer + j;
+        c[j] = i < mm ? cnt[i] : 0u;
+        sum += c[j];
+        if (c[j]) last = (uint32_t)i + 1u;
+    }
+    uint32_t bucket_total;
+    uint32_t ex = block1024_excl_scan(sum, L.scratch, bucket_total);
+    const uint32_t last_local = block1024_max(last, L.scratch);   // 1 + index of the bucket's last gaussian with records
+    if (t == 0)
+        __hip_atomic_store(&granule[d], kGranuleReady | ((unsigned long long)bucket_total << 32) | last_local,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // records of the buckets in front: thread t < d waits for bucket t's granule (bounded)
+    uint32_t before = 0, last_k = 0;
+    if (t < d) {
+        unsigned long long gr = 0;
+        for (int spin = 0; spin < (1 << 22); ++spin) {
+            gr = __hip_atomic_load(&granule[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gr & kGranuleReady) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (!(gr & kGranuleReady)) atomicOr(&ctl[3], kStatusTimeout);
+        before = (uint32_t)((gr >> 32) & 0x7FFFFFFFu);
+        const uint32_t lk = (uint32_t)gr;
+        if (lk) last_k = lo_t + lk;                    // 1 + global index (depth order) of bucket t's last owner
+    }
+    uint32_t base_total;
+    block1024_excl_scan(before, L.scratch, base_total);
+    const uint32_t base = base_total;                  // records in front of this bucket
+    if (culled_bucket) {                               // the last bucket: it has seen every other one
+        const uint32_t lk = block1024_max(last_k, L.scratch);
+        if (t == 0) {
+            ctl[0] = base;                             // M
+            if (block_owner && n_owner_blocks > 0 && lk) block_owner[n_owner_blocks] = (int32_t)(lk - 1u);
+        }
+        return;
+    }
+    ex += base;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int i = t * kPer + j;
+        if (i < mm) {
+            offsets[lo + i] = ex;
+            if (block_owner && n_owner_blocks > 0 && c[j] > 0u) {   // owner of every record-block boundary inside [ex, ex + c)
+                const uint32_t b0 = (ex + (uint32_t)kSortChunk - 1u) / (uint32_t)kSortChunk;
+                const uint32_t b1 = min((ex + c[j] - 1u) / (uint32_t)kSortChunk, (uint32_t)n_owner_blocks - 1u);
+                for (uint32_t b = b0; b <= b1 && (int)b < n_owner_blocks; ++b) block_owner[b] = (int32_t)(lo + i);
+            }
+        }
+        ex += c[j];
+    }
+}
+
+extern "C" size_t gsa_depth_order_msd_workspace_bytes(int n) {
+    if (n < 0) n = 0;
+    // first-pass output (keys, values), per-block key ranges, histograms, granules + ticket
+    return (size_t)2 * n * sizeof(uint32_t) + (size_t)2 * ((size_t)sort_blocks(n) + 1) * sizeof(uint32_t) +
+           gsa_sort_workspace_bytes(n) + (size_t)(2 * kRadix + 16) * sizeof(uint32_t) + 16;
+}
+
+extern "C" int gsa_depth_order_msd_max_shift(void) { return 16; }
+
+extern "C" int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint32_t *tile_rects, uint32_t key_min,
+                                   int shift, uint32_t *order, uint32_t *rects, uint32_t *offsets, int32_t *block_owner,
+                                   int n_blocks, uint32_t *ctl, void *workspace, size_t workspace_bytes,
+                                   gsa_stream_t stream) {
+    GSA_RETURN_IF(n < 0 || shift < 0 || shift > 16 || !ctl || n_blocks < 0 || (n_blocks > 0 && !block_owner),
+                  GSA_ERR_INVALID_ARGUMENT);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n == 0) {
+        hipError_t e = hipMemsetAsync(ctl, 0, 4 * sizeof(uint32_t), s);
+        if (e == hipSuccess) e = hipMemsetAsync(ctl + 1, 0xFF, sizeof(uint32_t), s);
+        return (int)e;
+    }
+    GSA_RETURN_IF(!depth_keys || !tile_rects || !order || !rects || !offsets || !workspace, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF((reinterpret_cast<uintptr_t>(tile_rects) & 7) != 0, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(workspace_bytes < gsa_depth_order_msd_workspace_bytes(n), GSA_ERR_WORKSPACE_TOO_SMALL);
+    const int nblocks = sort_blocks(n);
+    uint32_t *buf = static_cast<uint32_t *>(workspace);
+    uint32_t *kbuf = buf, *vbuf = buf + n;
+    uint32_t *block_range = buf + 2 * (size_t)n;
+    uint32_t *hist = block_range + 2 * ((size_t)nblocks + 1);
+    uint32_t *digit_total = hist + (size_t)kRadix * nblocks;
+    uintptr_t g = reinterpret_cast<uintptr_t>(digit_total + kRadix);
+    g = (g + 15) & ~(uintptr_t)15;
+    unsigned long long *granule = reinterpret_cast<unsigned long long *>(g);
+    uint32_t *ticket = reinterpret_cast<uint32_t *>(granule + kRadix);
+    const RadixDigit dg{shift, key_min, 1};
+    radix_hist_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(n, nullptr, depth_keys, dg, nblocks, hist, block_range);
+    GSA_LAUNCH_CHECK();
+    // (block 0 also reduces the key range into ctl[1..2]; block 1 zeroes the granules, the ticket and ctl[3])
+    radix_scan_rows_kernel<<<kRadix, kSortThreads, 0, s>>>(nblocks, hist, digit_total, block_range, ctl + 1,
+                                                           reinterpret_cast<uint32_t *>(granule), 2 * kRadix + 4);
+    GSA_LAUNCH_CHECK();
+    radix_scatter_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(n, nullptr, depth_keys, nullptr, kbuf, vbuf, dg, nblocks,
+                                                                    hist, digit_total);
+    GSA_LAUNCH_CHECK();
+    depth_bucket_sort_kernel<<<kRadix, kLocalThreads, 0, s>>>(kbuf, vbuf, digit_total, key_min, shift,
+                                                              reinterpret_cast<const uint2 *>(tile_rects), order, rects,
+                                                              offsets, n_blocks > 0 ? block_owner : nullptr, n_blocks,
+                                                              granule, ticket, ctl);
+    GSA_LAUNCH_CHECK();
     return GSA_OK;
 }
 
@@ -972,12 +1251,13 @@ extern "C" int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offs
                                                          nblocks, hist, digit_total);
     GSA_LAUNCH_CHECK();
     if (two) {
-        radix_hist_kernel<uint16_t><<<nblocks, kSortThreads, 0, s>>>((int)m_capacity, m_dev, tile_tmp, 8, nblocks, hist, nullptr);
+        radix_hist_kernel<uint16_t><<<nblocks, kSortThreads, 0, s>>>((int)m_capacity, m_dev, tile_tmp, RadixDigit{8, 0u, 0}, nblocks, hist, nullptr);
         GSA_LAUNCH_CHECK();
         radix_scan_rows_kernel<<<kRadix, kSortThreads, 0, s>>>(nblocks, hist, digit_total);
         GSA_LAUNCH_CHECK();
         radix_scatter_kernel<uint16_t><<<nblocks, kSortThreads, 0, s>>>((int)m_capacity, m_dev, tile_tmp, gid_tmp, sorted_tile,
-                                                                        sorted_gid, 8, nblocks, hist, digit_total);
+                                                                        sorted_gid, RadixDigit{8, 0u, 0}, nblocks, hist,
+                                                                        digit_total);
         GSA_LAUNCH_CHECK();
     }
     return tile_offsets_impl<uint16_t>(m_capacity, m_dev, sorted_tile, n_tiles, tile_offsets, stream);

@@ -145,7 +145,9 @@ class TileBins:
                  keys_ok=True):
         self._tile, self._gid, self.tile_offsets = sorted_tile, sorted_gid, tile_offsets
         self.capacity, self._m, self._key, self._slot, self._n = capacity, m_known, key, slot, n
-        self.key_bits, self._keys_ok = key_bits, keys_ok   # depth-sort bits the kernels ran with; range check result
+        # what the depth ordering assumed about the visible keys -- bits an LSD sort covered, or (key_min, shift) of the
+        # bucketed one; None: nothing to check -- and the result of the check
+        self.key_bits, self._keys_ok = key_bits, keys_ok
 
     @property
     def sorted_gid_buffer(self):   # what the compositor kernels read (they only follow tile_offsets)
@@ -162,7 +164,7 @@ class TileBins:
             _note_count(self._key, self._n, self._m)
             if self.key_bits is not None:   # (the unfused path sorts all 32 bits and leaves no range)
                 self._keys_ok = _note_keys(self._key, int(ctl_host[1]) & 0xFFFFFFFF, int(ctl_host[2]) & 0xFFFFFFFF,
-                                           self.key_bits)
+                                           self.key_bits, int(ctl_host[3]) if isinstance(self.key_bits, tuple) else 0)
         return self._m, self._m <= self.capacity and self._keys_ok
 
     def __iter__(self):   # sorted_tile, sorted_gid, tile_offsets = bin_tiles(...)
@@ -193,7 +195,12 @@ _CAPACITY_MAX_KEYS = 64
 _SHRINK_AFTER = 32
 
 
-_KEY_BITS = {}   # scene shape -> depth-key bits the next depth sort covers (grows at once, shrinks slowly)
+# scene shape -> [lo, hi, consecutive much-narrower views]: the union of the visible depth-key ranges seen so far
+# (grows at once, is reset after many consecutive views that need less than half of it).  The depth ordering is
+# launched for this range and the view's actual range is checked afterwards, like the record capacity.
+_KEY_RANGE = {}
+_MSD_MAX_SHIFT = int(lib.gsa_depth_order_msd_max_shift())
+_DEPTH_MSD_DEFAULT = os.environ.get("GSPLAT_AMD_DEPTH_MSD", "1") != "0"
 
 
 def _key_bits_needed(lo: int, hi: int) -> int:
@@ -203,21 +210,41 @@ def _key_bits_needed(lo: int, hi: int) -> int:
     return max(8, 8 * (((lo ^ hi).bit_length() + 7) // 8))
 
 
-def _note_keys(key, lo: int, hi: int, used_bits: int) -> bool:
-    """Remember the depth-key range of this view; -> whether the sort that ran (on `used_bits` bits) was complete."""
-    need = _key_bits_needed(lo, hi)
-    ent = _KEY_BITS.get(key)
-    if ent is None or need > ent[0]:
-        _KEY_BITS[key] = [need, 0]
-    elif need < ent[0]:
-        ent[1] += 1
-        if ent[1] >= _SHRINK_AFTER:
-            _KEY_BITS[key] = [need, 0]
-    else:
-        ent[1] = 0
-    while len(_KEY_BITS) > _CAPACITY_MAX_KEYS:
-        _KEY_BITS.pop(next(iter(_KEY_BITS)))
-    return need <= used_bits
+def _msd_plan(lo: int, hi: int):
+    """-> (key_min, shift) of the bucketed depth ordering for keys in [lo, hi] with 1/8 of the span as margin on both
+    sides, or None when the local sorts would need more than 16 bits."""
+    if lo > hi:
+        return None
+    margin = ((hi - lo) >> 3) + 1
+    a, b = max(0, lo - margin), min(0xFFFFFFFE, hi + margin)
+    shift = max(0, (b - a).bit_length() - 8)
+    if ((b - a) >> shift) > 254:
+        shift += 1
+    return (a, shift) if shift <= _MSD_MAX_SHIFT else None
+
+
+def _note_keys(key, lo: int, hi: int, assumed, status: int = 0) -> bool:
+    """Remember the depth-key range of this view; -> whether the ordering that ran was complete.  ``assumed``: the
+    number of key bits an LSD sort covered, or (key_min, shift) of a bucketed one."""
+    ent = _KEY_RANGE.get(key)
+    if lo <= hi:
+        if ent is None:
+            while len(_KEY_RANGE) >= _CAPACITY_MAX_KEYS:
+                _KEY_RANGE.pop(next(iter(_KEY_RANGE)))
+            _KEY_RANGE[key] = [lo, hi, 0]
+        else:
+            if lo < ent[0] or hi > ent[1]:
+                ent[0], ent[1], ent[2] = min(lo, ent[0]), max(hi, ent[1]), 0
+            elif 2 * (hi - lo) < ent[1] - ent[0]:
+                ent[2] += 1
+                if ent[2] >= _SHRINK_AFTER:
+                    ent[0], ent[1], ent[2] = lo, hi, 0
+            else:
+                ent[2] = 0
+    if isinstance(assumed, tuple):
+        kmin, shift = assumed
+        return status == 0 and (lo > hi or (lo >= kmin and ((hi - kmin) >> shift) <= 254))
+    return _key_bits_needed(lo, hi) <= assumed
 
 
 def _capacity_for(key, n: int) -> Optional[int]:
@@ -246,7 +273,7 @@ def _note_count(key, n: int, m: int) -> None:
 
 
 def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, cull_mode: int = 0,
-              exact: bool = False, fused: Optional[bool] = None, tile_rects=None) -> TileBins:
+              exact: bool = False, fused: Optional[bool] = None, tile_rects=None, depth_msd: Optional[bool] = None) -> TileBins:
     """Depth-order the gaussians, emit their tile records in that order, stable-sort the records by tile.
     -> TileBins(sorted_tile, sorted_gid, tile_offsets [n_tiles+1] i32).  ``sorted_tile`` holds 16-bit tile ids (an
     int16 tensor of uint16 bit patterns) on the fused path, int32 otherwise: read it through ``tile_ids``.
@@ -278,27 +305,40 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
         if tile_rects is None:   # callers that did not keep project_fwd's dense copy: word 11 of the records
             tile_rects = torch.stack([torch.where(tiles_touched > 0, splat[:, 11].contiguous().view(torch.int32), 0),
                                       tiles_touched], dim=1).contiguous()
-        # depth order: only the key bits the visible gaussians of this scene shape were seen to differ in are sorted
-        # (their range is checked after the fact, like the record capacity); the last pass also brings the packed
-        # rectangles and the record counts into depth order
-        if not exact and key in _KEY_BITS:
-            key_bits = _KEY_BITS[key][0]
+        # depth order.  The range of the visible depth keys is remembered per scene shape (and checked after the fact,
+        # like the record capacity).  Steady state: ONE global pass buckets the keys by depth range and ONE launch sorts
+        # every bucket in LDS, gathers rectangles and counts, scans them and writes offsets + block owners
+        # (gsa_depth_order_msd).  Otherwise (first call of a shape, repair, range too wide for 16-bit local sorts): LSD
+        # passes over the key bits the visible gaussians differ in, then the scan.
         order = torch.empty(N, dtype=torch.int32, device=dev)
         rects = torch.empty(N, dtype=torch.int32, device=dev)
-        dws_bytes = lib.gsa_depth_order_workspace_bytes(N)
-        dws = torch.empty(dws_bytes, dtype=torch.uint8, device=dev)
-        _call("gsa_depth_order", lib.gsa_depth_order, N, _ptr(depth_keys), _ptr(tile_rects), key_bits, _ptr(order),
-              _ptr(rects), _ptr(offsets), _ptr(ctl[1:3]), _ptr(dws), dws_bytes, st)
+        rng = None if exact else _KEY_RANGE.get(key)
+        plan = _msd_plan(rng[0], rng[1]) if (rng is not None and cap is not None and _DEPTH_MSD_DEFAULT and depth_msd is not False) else None
+        if plan is not None:
+            key_bits = plan
+            n_blocks = (cap + BIN_BLOCK - 1) // BIN_BLOCK
+            block_owner = torch.empty(n_blocks + 1, dtype=torch.int32, device=dev)
+            dws_bytes = lib.gsa_depth_order_msd_workspace_bytes(N)
+            dws = torch.empty(dws_bytes, dtype=torch.uint8, device=dev)
+            _call("gsa_depth_order", lib.gsa_depth_order_msd, N, _ptr(depth_keys), _ptr(tile_rects), plan[0], plan[1],
+                  _ptr(order), _ptr(rects), _ptr(offsets), _ptr(block_owner), n_blocks, _ptr(ctl), _ptr(dws), dws_bytes, st)
+        else:
+            if rng is not None:
+                key_bits = _key_bits_needed(rng[0], rng[1])
+            dws_bytes = lib.gsa_depth_order_workspace_bytes(N)
+            dws = torch.empty(dws_bytes, dtype=torch.uint8, device=dev)
+            _call("gsa_depth_order", lib.gsa_depth_order, N, _ptr(depth_keys), _ptr(tile_rects), key_bits, _ptr(order),
+                  _ptr(rects), _ptr(offsets), _ptr(ctl[1:3]), _ptr(dws), dws_bytes, st)
 
-        def scan(capacity):   # the scan also notes the owner of every 4096-slot record block (+ the last owner)
-            n_blocks = 0 if capacity is None else (capacity + BIN_BLOCK - 1) // BIN_BLOCK
-            owner = torch.empty(n_blocks + 1, dtype=torch.int32, device=dev)
-            _call("gsa_scan_tiles", lib.gsa_scan_tiles_sorted, N, _ptr(offsets), _ptr(owner), n_blocks, _ptr(total), _ptr(ws),
-                  ws_bytes, st)
-            return owner
+            def scan(capacity):   # the scan also notes the owner of every 4096-slot record block (+ the last owner)
+                n_blocks = 0 if capacity is None else (capacity + BIN_BLOCK - 1) // BIN_BLOCK
+                owner = torch.empty(n_blocks + 1, dtype=torch.int32, device=dev)
+                _call("gsa_scan_tiles", lib.gsa_scan_tiles_sorted, N, _ptr(offsets), _ptr(owner), n_blocks, _ptr(total),
+                      _ptr(ws), ws_bytes, st)
+                return owner
 
-        counts_copy = offsets.clone() if cap is None else None   # the scan is in place; a second scan needs the counts
-        block_owner = scan(cap)
+            counts_copy = offsets.clone() if cap is None else None   # the scan is in place; a second scan needs the counts
+            block_owner = scan(cap)
     else:
         _, order = sort_pairs(N, depth_keys, None, 0, 32)  # ties keep index order; culled gaussians sort last
         _call("gsa_scan_tiles", lib.gsa_scan_tiles, N, _ptr(tiles_touched), _ptr(order), _ptr(offsets), _ptr(total),
@@ -313,7 +353,8 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
         m_known = int(m_host[0]) & 0xFFFFFFFF
         _note_count(key, N, m_known)
         if fused:
-            keys_ok = _note_keys(key, int(m_host[1]) & 0xFFFFFFFF, int(m_host[2]) & 0xFFFFFFFF, key_bits)
+            keys_ok = _note_keys(key, int(m_host[1]) & 0xFFFFFFFF, int(m_host[2]) & 0xFFFFFFFF, key_bits,
+                                 int(m_host[3]) if isinstance(key_bits, tuple) else 0)
         cap = m_known
         if fused:   # first call of a scene shape / repair: the block table needs the count, scan once more
             offsets.copy_(counts_copy)

@@ -132,6 +132,23 @@ size_t gsa_depth_order_workspace_bytes(int n);
 int gsa_depth_order(int n, const uint32_t *depth_keys, const uint32_t *tile_rects, int key_bits, uint32_t *order,
                     uint32_t *rects, uint32_t *counts, uint32_t *key_range, void *workspace, size_t workspace_bytes,
                     gsa_stream_t stream);
+/* gsa_depth_order_msd: the same outputs as gsa_depth_order + gsa_scan_tiles_sorted -- order, rects, offsets (exclusive
+ * scan of the record counts in depth order), block_owner (n_blocks + 1 entries as gsa_scan_tiles_rect leaves them) and
+ * ctl[0] = M -- in four launches whatever the key width, for callers that know the range of the visible depth keys
+ * beforehand: ONE global radix pass buckets the keys by depth range (bucket = (key - key_min) >> shift, clamped to
+ * 254; the culled sentinel alone in bucket 255), then one workgroup per bucket sorts its keys in LDS on the remaining
+ * `shift` (0..gsa_depth_order_msd_max_shift() = 16) low bits, gathers rectangles and counts, scans them and adds the
+ * records of the buckets in front (published per bucket through one 8-byte granule; bounded spin).
+ * ctl[1..2] = min / max key over the visible gaussians as measured, ctl[3] = status (0 ok; bit 0: a bucket exceeded the
+ * LDS capacity of 8192 keys; bit 1: a wait timed out).  The result is valid iff ctl[3] == 0, ctl[1] >= key_min and
+ * (ctl[2] - key_min) >> shift <= 254 -- checked by the caller after the fact; otherwise it repeats with
+ * gsa_depth_order(key_bits = 32).  Entries of order / rects / offsets that belong to culled gaussians (they sort behind
+ * every visible one and have no records) are not written.  workspace: gsa_depth_order_msd_workspace_bytes(n). */
+size_t gsa_depth_order_msd_workspace_bytes(int n);
+int gsa_depth_order_msd_max_shift(void);
+int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint32_t *tile_rects, uint32_t key_min, int shift,
+                        uint32_t *order, uint32_t *rects, uint32_t *offsets, int32_t *block_owner, int n_blocks,
+                        uint32_t *ctl, void *workspace, size_t workspace_bytes, gsa_stream_t stream);
 int gsa_scan_tiles_sorted(int n, uint32_t *counts_offsets, int32_t *block_owner, int n_blocks, uint32_t *total,
                           void *workspace, size_t workspace_bytes, gsa_stream_t stream);
 int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offsets, const uint32_t *rects,

@@ -797,3 +797,98 @@ def test_full_size_properties_c3_1m_1080p(gsa):
     tiles = (ids >> 32)
     first = torch.searchsorted(tiles, torch.arange(offs.numel(), device=tiles.device))
     assert torch.equal(first, offs)
+
+
+@pytest.mark.parametrize("n,dist", [(200_000, "uniform"), (1_000_003, "bench"), (5000, "uniform"), (70_000, "ties"),
+                                    (300, "uniform"), (50_000, "all_culled")])
+def test_bucketed_depth_order_equals_lsd_sort(gsa, n, dist):
+    """gsa_depth_order_msd (one global bucket pass + a local LDS sort per bucket fused with the scan) == gsa_depth_order
+    + gsa_scan_tiles_sorted (LSD passes, separate scan), bit for bit, on every entry that belongs to a visible gaussian:
+    order, rectangles, offsets, block owners, record count, key range; ties keep index order."""
+    from gsplat_amd import stages as S
+    from gsplat_amd._lib import check, lib
+    g = torch.Generator().manual_seed(n)
+    if dist == "bench":      # float bits of depths in [3, 5]: twice as dense above 4.0
+        keys = (torch.rand(n, generator=g) * 2 + 3).to(torch.float32).view(torch.int32).long()
+    elif dist == "ties":     # many equal keys: stability
+        keys = torch.randint(0x40400000, 0x40400000 + 3000, (n,), generator=g)
+    else:
+        keys = torch.randint(0x40000000, 0x40C00000, (n,), generator=g)
+    culled = torch.rand(n, generator=g) < (1.0 if dist == "all_culled" else 0.08)
+    keys[culled] = 0xFFFFFFFF
+    counts = torch.randint(0, 20, (n,), generator=g)
+    counts[culled] = 0
+    counts[torch.rand(n, generator=g) < 0.05] = 0          # visible gaussians without records
+    if n > 100_000:
+        counts[12345] = 9000                               # one record list spanning several 4096-slot blocks
+    rect_words = torch.randint(1, 2 ** 30, (n,), generator=g)
+    pairs = torch.stack([rect_words, counts], dim=1).to(torch.int32).contiguous().cuda()
+    k32 = torch.where(keys >= 2 ** 31, keys - 2 ** 32, keys).to(torch.int32).cuda()
+    m_true = int(counts.sum())
+    n_blocks = (m_true + S.BIN_BLOCK - 1) // S.BIN_BLOCK + 3
+    st = S._stream()
+
+    def buffers():
+        return (torch.full((n,), -1, dtype=torch.int32, device="cuda"), torch.full((n,), -1, dtype=torch.int32, device="cuda"),
+                torch.full((n,), -1, dtype=torch.int32, device="cuda"), torch.full((n_blocks + 1,), -7, dtype=torch.int32, device="cuda"),
+                torch.full((4,), -1, dtype=torch.int32, device="cuda"))
+
+    # reference: LSD over all 32 bits + scan
+    o0, r0, f0, b0, c0 = buffers()
+    ws = torch.empty(lib.gsa_depth_order_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    check(lib.gsa_depth_order(n, k32.data_ptr(), pairs.data_ptr(), 32, o0.data_ptr(), r0.data_ptr(), f0.data_ptr(),
+                              c0[1:3].data_ptr(), ws.data_ptr(), ws.numel(), st), "gsa_depth_order")
+    ws2 = torch.empty(lib.gsa_sort_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    check(lib.gsa_scan_tiles_sorted(n, f0.data_ptr(), b0.data_ptr(), n_blocks, c0[0:1].data_ptr(), ws2.data_ptr(), ws2.numel(), st),
+          "gsa_scan_tiles_sorted")
+    n_vis = int((~culled).sum())
+    vis_keys = keys[~culled]
+    lo, hi = (int(vis_keys.min()), int(vis_keys.max())) if n_vis else (0xFFFFFFFF, 0)
+    assert (int(c0[0]) & 0xFFFFFFFF, int(c0[1]) & 0xFFFFFFFF, int(c0[2]) & 0xFFFFFFFF) == (m_true, lo, hi)
+    ref_order = torch.sort(keys, stable=True).indices
+    assert torch.equal(o0.cpu().long()[:n_vis], ref_order[:n_vis])
+    # bucketed ordering for the range a caller would have remembered
+    plan = S._msd_plan(lo, hi) if n_vis else (0x3F000000, 16)
+    assert plan is not None
+    o1, r1, f1, b1, c1 = buffers()
+    ws = torch.empty(lib.gsa_depth_order_msd_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    check(lib.gsa_depth_order_msd(n, k32.data_ptr(), pairs.data_ptr(), plan[0], plan[1], o1.data_ptr(), r1.data_ptr(),
+                                  f1.data_ptr(), b1.data_ptr(), n_blocks, c1.data_ptr(), ws.data_ptr(), ws.numel(), st),
+          "gsa_depth_order_msd")
+    torch.cuda.synchronize()
+    assert [int(x) & 0xFFFFFFFF for x in c1] == [m_true, lo, hi, 0]
+    assert torch.equal(o1[:n_vis], o0[:n_vis]) and torch.equal(r1[:n_vis], r0[:n_vis]) and torch.equal(f1[:n_vis], f0[:n_vis])
+    live_blocks = (m_true + S.BIN_BLOCK - 1) // S.BIN_BLOCK
+    assert torch.equal(b1[:live_blocks], b0[:live_blocks])
+    if m_true:
+        assert int(b1[n_blocks]) == int(b0[n_blocks])
+
+
+def test_bucketed_depth_order_reports_what_it_cannot_do(gsa):
+    """A bucket beyond the LDS capacity (a depth cluster) and keys outside the assumed range are REPORTED through the
+    control words -- the caller (stages.bin_tiles) then repeats with the LSD path -- and nothing hangs or faults."""
+    from gsplat_amd import stages as S
+    from gsplat_amd._lib import check, lib
+    n = 60_000
+    g = torch.Generator().manual_seed(1)
+    keys = torch.randint(0x40000000, 0x40800000, (n,), generator=g)
+    keys[:20_000] = 0x40400000 + torch.randint(0, 50, (20_000,), generator=g)     # 20 k keys in one bucket
+    pairs = torch.stack([torch.ones(n, dtype=torch.int64), torch.ones(n, dtype=torch.int64)], dim=1).to(torch.int32).cuda()
+    k32 = keys.to(torch.int32).cuda()
+    st = S._stream()
+    out = [torch.empty(n, dtype=torch.int32, device="cuda") for _ in range(3)]
+    owner = torch.empty(64, dtype=torch.int32, device="cuda")
+    ctl = torch.empty(4, dtype=torch.int32, device="cuda")
+    ws = torch.empty(lib.gsa_depth_order_msd_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    plan = S._msd_plan(int(keys.min()), int(keys.max()))
+    check(lib.gsa_depth_order_msd(n, k32.data_ptr(), pairs.data_ptr(), plan[0], plan[1], out[0].data_ptr(), out[1].data_ptr(),
+                                  out[2].data_ptr(), owner.data_ptr(), 63, ctl.data_ptr(), ws.data_ptr(), ws.numel(), st), "msd")
+    assert int(ctl[3]) & 1, "bucket overflow must be reported"
+    assert not S._note_keys(("t", 0), int(ctl[1]), int(ctl[2]), plan, int(ctl[3]))
+    # keys below the assumed minimum: the measured range tells
+    narrow = (0x40400000, 8)
+    check(lib.gsa_depth_order_msd(n, k32.data_ptr(), pairs.data_ptr(), narrow[0], narrow[1], out[0].data_ptr(), out[1].data_ptr(),
+                                  out[2].data_ptr(), owner.data_ptr(), 63, ctl.data_ptr(), ws.data_ptr(), ws.numel(), st), "msd")
+    assert not S._note_keys(("t", 1), int(ctl[1]), int(ctl[2]), narrow, int(ctl[3]))
+    S._KEY_RANGE.pop(("t", 0), None)
+    S._KEY_RANGE.pop(("t", 1), None)
