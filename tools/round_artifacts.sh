@@ -14,6 +14,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python3
 echo "rocprof stats done"
 cd $R
 python tools/prof_summary.py $O/stats/p_kernel_stats.csv 45 > $O/summary_table.md
+echo "summary done"
 bash tools/collect_pmc.sh gpurun_out/$tag/pmc > $O/pmc.log 2>&1
 echo "pmc done"
 python tools/make_traffic_json.py $O/pmc "$tag" $O/traffic.json > $O/traffic.log
