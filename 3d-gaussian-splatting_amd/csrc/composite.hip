@@ -1071,8 +1071,9 @@ __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_2p_kernel(
         for (int s0 = 0; s0 < n; s0 += kSub) {
             const int nv = min(kSub, n - s0);
             // ---- phase A: lane = pixel, the records of the sub-batch in walk order
-            auto phase_a = [&](auto clamp_tag) {
+            auto phase_a = [&](auto clamp_tag, auto all_on_tag) {
                 constexpr bool CLAMP = decltype(clamp_tag)::value;
+                constexpr bool ALL_ON = decltype(all_on_tag)::value;   // every pixel is behind every record of the sub-batch
 #pragma unroll
                 for (int r = 0; r < kSub; ++r) {
                     float u = 0.f, fac = 0.f;
@@ -1080,7 +1081,7 @@ __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_2p_kernel(
                         const float4 *p = &st.rec[F4 * (s0 + r)];
                         const float4 q0 = p[0], q1 = p[1], q2 = p[2];
                         const float dx = q0.x - pxf, dy = q0.y - pyf;
-                        const uint32_t off_bit = (uint32_t)(binf - __float_as_int(q2.z)) & kSign;
+                        const uint32_t off_bit = ALL_ON ? 0u : (uint32_t)(binf - __float_as_int(q2.z)) & kSign;
                         float raw;
                         const float a = record_alpha<CLAMP>(scaled_sigma(q0, q1, dx, dy), q2.y, q1.y, off_bit, raw);
                         const float ra = __builtin_amdgcn_rcpf(1.f - a);   // a == 0: ra = 1, fac = 0, u = 0
@@ -1096,7 +1097,15 @@ __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_2p_kernel(
                     tp.mat[lane * kMatPitch + r] = make_float2(u, fac);
                 }
             };
-            if (any_cap) phase_a(std::true_type{}); else phase_a(std::false_type{});
+            // the lists are walked from the deep end: once every pixel of the quadrant has reached its last position (the
+            // sub-batch's first record is its deepest) the "pixel stopped in front of this record" test is dead code
+            const int pos_hi = __builtin_amdgcn_readfirstlane(__float_as_int(st.rec[F4 * s0 + 2].z));
+            const bool all_on = __ballot(binf >= pos_hi) == ~0ull;
+            if (any_cap) {
+                if (all_on) phase_a(std::true_type{}, std::true_type{}); else phase_a(std::true_type{}, std::false_type{});
+            } else {
+                if (all_on) phase_a(std::false_type{}, std::true_type{}); else phase_a(std::false_type{}, std::false_type{});
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1105,25 +1114,31 @@ __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_2p_kernel(
 #pragma unroll
             for (int f = 0; f < 10; ++f) acc[f] = 0.f;
             {
+                // d = mean - pixel is constant in x for this lane and, per step, a compile-time offset in y: the lane sums
+                // u, u y', u y'^2 (y' = y - 3.5: three FMAs per step) and expands the five moments of u once per sub-batch
                 const float2 mean = *reinterpret_cast<const float2 *>(&st.rec[F4 * (rec < nv ? s0 + rec : kBatch)]);
-                const float dx = mean.x - colx, dy0 = mean.y - rowy0;
+                const float dx = mean.x - colx, dyc = mean.y - (rowy0 + 3.5f);   // dy = dyc - y'
+                float su = 0.f, suy = 0.f, suyy = 0.f;
 #pragma unroll
                 for (int y = 0; y < 8; ++y) {
                     const float2 uf = tp.mat[(8 * y + col) * kMatPitch + rec];
-                    const float dy = dy0 - (float)y;
+                    const float yc = (float)y - 3.5f;
                     const float u = uf.x, fac = uf.y;
-                    const float udx = u * dx, udy = u * dy;
-                    acc[0] += udx;
-                    acc[1] += udy;
-                    acc[2] = __builtin_fmaf(udx, dx, acc[2]);
-                    acc[3] = __builtin_fmaf(udx, dy, acc[3]);
-                    acc[4] = __builtin_fmaf(udy, dy, acc[4]);
-                    acc[5] += u;
+                    su += u;
+                    suy = __builtin_fmaf(u, yc, suy);
+                    suyy = __builtin_fmaf(u, yc * yc, suyy);
                     acc[6] = __builtin_fmaf(fac, vcol[y][0], acc[6]);
                     acc[7] = __builtin_fmaf(fac, vcol[y][1], acc[7]);
                     acc[8] = __builtin_fmaf(fac, vcol[y][2], acc[8]);
                     if (CH == 4) acc[9] = __builtin_fmaf(fac, vcol[y][CH - 1], acc[9]);
                 }
+                const float sudy = __builtin_fmaf(dyc, su, -suy);                      // sum u dy
+                acc[0] = dx * su;                                                       // sum u dx
+                acc[1] = sudy;
+                acc[2] = dx * acc[0];                                                   // sum u dx^2
+                acc[3] = dx * sudy;                                                     // sum u dx dy
+                acc[4] = __builtin_fmaf(dyc, sudy, __builtin_fmaf(-dyc, suy, suyy));    // sum u dy^2 = dyc (dyc su - suy) - dyc suy + suyy
+                acc[5] = su;
             }
             // fold over the 8 lanes of a record (lane bits 3, 4, 5): after fold8 a lane holds field 2 i + b3 in slot i,
             // after fold16 field 4 j + 2 b4 + b3 in slot j, after fold32 field 8 t + 4 b5 + 2 b4 + b3 in slot t
