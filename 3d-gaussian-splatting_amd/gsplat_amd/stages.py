@@ -201,6 +201,8 @@ _SHRINK_AFTER = 32
 _KEY_RANGE = {}
 _MSD_MAX_SHIFT = int(lib.gsa_depth_order_msd_max_shift())
 _DEPTH_MSD_DEFAULT = os.environ.get("GSPLAT_AMD_DEPTH_MSD", "1") != "0"
+_MSD_MIN_N = 32768        # below this the 256 x 1024-thread bucket launch costs more than the LSD passes it replaces
+_MSD_BACKOFF = {}         # scene shape -> calls left before the bucketed ordering is tried again after an overflow
 
 
 def _key_bits_needed(lo: int, hi: int) -> int:
@@ -243,6 +245,8 @@ def _note_keys(key, lo: int, hi: int, assumed, status: int = 0) -> bool:
                 ent[2] = 0
     if isinstance(assumed, tuple):
         kmin, shift = assumed
+        if status & 1:     # a depth cluster overflowed a bucket's LDS: every such call costs a repair, so back off
+            _MSD_BACKOFF[key] = 64
         return status == 0 and (lo > hi or (lo >= kmin and ((hi - kmin) >> shift) <= 254))
     return _key_bits_needed(lo, hi) <= assumed
 
@@ -313,7 +317,11 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
         order = torch.empty(N, dtype=torch.int32, device=dev)
         rects = torch.empty(N, dtype=torch.int32, device=dev)
         rng = None if exact else _KEY_RANGE.get(key)
-        plan = _msd_plan(rng[0], rng[1]) if (rng is not None and cap is not None and _DEPTH_MSD_DEFAULT and depth_msd is not False) else None
+        backoff = _MSD_BACKOFF.get(key, 0)
+        if backoff:
+            _MSD_BACKOFF[key] = backoff - 1
+        use_msd = depth_msd if depth_msd is not None else (_DEPTH_MSD_DEFAULT and N >= _MSD_MIN_N and backoff == 0)
+        plan = _msd_plan(rng[0], rng[1]) if (rng is not None and cap is not None and use_msd) else None
         if plan is not None:
             key_bits = plan
             n_blocks = (cap + BIN_BLOCK - 1) // BIN_BLOCK

@@ -892,3 +892,45 @@ def test_bucketed_depth_order_reports_what_it_cannot_do(gsa):
     assert not S._note_keys(("t", 1), int(ctl[1]), int(ctl[2]), narrow, int(ctl[3]))
     S._KEY_RANGE.pop(("t", 0), None)
     S._KEY_RANGE.pop(("t", 1), None)
+
+
+def test_depth_cluster_falls_back_to_the_lsd_path(gsa):
+    """``stages.bin_tiles`` end to end on a population with a depth cluster (20 k of 100 k keys in one bucket): the
+    bucketed ordering reports the overflow, ``finalize()`` says so, the exact repeat gives the first call's bins, and
+    the shape then stays on the LSD path for a while instead of paying a repair per call."""
+    from gsplat_amd import stages as S
+    W, H, N = 640, 368, 100_000
+    tw, th = S.tile_grid(W, H)
+    g = torch.Generator().manual_seed(4)
+    keys = torch.randint(0x40000000, 0x40800000, (N,), generator=g)
+    keys[:20_000] = 0x40400000 + torch.randint(0, 64, (20_000,), generator=g)
+    x0 = torch.randint(0, tw - 2, (N,), generator=g)
+    y0 = torch.randint(0, th - 2, (N,), generator=g)
+    rect = (x0 | (y0 << 10) | (2 << 20)).to(torch.int32)                     # 2 x 2 tiles each
+    counts = torch.full((N,), 4, dtype=torch.int32)
+    pairs = torch.stack([rect, counts], dim=1).contiguous().cuda()
+    splat = torch.zeros(N, 16, device="cuda")
+    radii = torch.ones(N, 2, dtype=torch.int32, device="cuda")
+    k32 = keys.to(torch.int32).cuda()
+    key = ("cuda", torch.cuda.current_device(), W, H, 0)
+    for d in (S._CAPACITY, S._KEY_RANGE, S._MSD_BACKOFF):
+        d.pop(key, None)
+
+    def bins(**kw):
+        return S.bin_tiles(splat, radii, counts.cuda(), k32, W, H, 0, tile_rects=pairs, **kw)
+
+    first = bins()                                     # first call of the shape: LSD, exact sizes, learns the range
+    m, ok = first.finalize()
+    assert ok and m == 4 * N and first.key_bits == 32
+    ref_gid, ref_off = first.sorted_gid.clone(), first.tile_offsets.clone()
+    second = bins()                                    # steady state: bucketed ordering for the remembered range
+    assert isinstance(second.key_bits, tuple)
+    assert second.finalize()[1] is False, "the overflowing bucket must surface through finalize()"   # (its M is garbage)
+    repair = bins(exact=True)
+    assert repair.finalize() == (m, True)
+    assert torch.equal(repair.sorted_gid, ref_gid) and torch.equal(repair.tile_offsets, ref_off)
+    third = bins()                                     # backed off: LSD on the bits the keys differ in
+    assert not isinstance(third.key_bits, tuple) and third.finalize() == (m, True)
+    assert torch.equal(third.sorted_gid, ref_gid) and torch.equal(third.tile_offsets, ref_off)
+    for d in (S._CAPACITY, S._KEY_RANGE, S._MSD_BACKOFF):
+        d.pop(key, None)
