@@ -202,6 +202,7 @@ _KEY_RANGE = {}
 _MSD_MAX_SHIFT = int(lib.gsa_depth_order_msd_max_shift())
 _DEPTH_MSD_DEFAULT = os.environ.get("GSPLAT_AMD_DEPTH_MSD", "1") != "0"
 _MSD_MIN_N = 32768        # below this the 256 x 1024-thread bucket launch costs more than the LSD passes it replaces
+_MSD_MAX_N = 1_400_000    # above this an average bucket (N / 255, x1.5 for skew) no longer fits the 8192-key LDS capacity
 _MSD_BACKOFF = {}         # scene shape -> calls left before the bucketed ordering is tried again after an overflow
 
 
@@ -320,7 +321,7 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
         backoff = _MSD_BACKOFF.get(key, 0)
         if backoff:
             _MSD_BACKOFF[key] = backoff - 1
-        use_msd = depth_msd if depth_msd is not None else (_DEPTH_MSD_DEFAULT and N >= _MSD_MIN_N and backoff == 0)
+        use_msd = depth_msd if depth_msd is not None else (_DEPTH_MSD_DEFAULT and _MSD_MIN_N <= N <= _MSD_MAX_N and backoff == 0)
         plan = _msd_plan(rng[0], rng[1]) if (rng is not None and cap is not None and use_msd) else None
         if plan is not None:
             key_bits = plan
