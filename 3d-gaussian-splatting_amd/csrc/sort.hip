@@ -525,17 +525,23 @@ __global__ __launch_bounds__(kSortThreads) void tile_offsets_bsearch_kernel(uint
 // next one that has some, the last one wins), a max-scan carries the owner forward; slot -> tile: the rectangle
 // arithmetic of tile_emit_coop_kernel.
 struct EmitBlock { uint32_t slot0, live; int k_lo; };   // live: slots of this block below the record count
-constexpr int kEmitStage = 1024;   // gaussians per block whose (offset, rectangle, index) are staged in LDS
+constexpr int kEmitStage = 768;    // gaussians per block whose (offset, rectangle, index, 1 / width) are staged in LDS
 
-// s_off / s_rect / s_gid [kEmitStage]: the data of the first kEmitStage gaussians of the block, read once (coalesced)
+// the packed 16-B entry of a staged gaussian: ONE LDS read per record instead of three, and the division by the
+// rectangle's width becomes a multiplication (exact for the operands in range: see emit_record)
+__device__ __forceinline__ uint4 emit_entry(uint32_t off, uint32_t rect, uint32_t gid) {
+    const int wl = max((int)(rect >> 20), 1);
+    return make_uint4(off, rect, gid, __float_as_uint(__builtin_amdgcn_rcpf((float)wl)));
+}
+
+// s_g [kEmitStage]: the packed entries of the first kEmitStage gaussians of the block, read once (coalesced)
 // while their starts are marked; owners beyond (a block of gaussians with fewer than four records each) are looked
-// up in global memory.  s_gid may be null (the histogram does not need the indices).
+// up in global memory.  want_gid: the histogram does not need the gaussian indices.
 __device__ __forceinline__ EmitBlock emit_owners(const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ rects,
                                                   const uint32_t *__restrict__ order,
                                                   const int32_t *__restrict__ block_owner, int n_owner_blocks,
                                                   uint32_t m_total, uint32_t *__restrict__ s_own,
-                                                  uint32_t *__restrict__ s_off, uint32_t *__restrict__ s_rect,
-                                                  uint32_t *__restrict__ s_gid, uint32_t *__restrict__ scratch) {
+                                                  uint4 *__restrict__ s_g, bool want_gid, uint32_t *__restrict__ scratch) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     EmitBlock eb;
     eb.slot0 = blockIdx.x * (uint32_t)kSortChunk;
@@ -551,11 +557,7 @@ __device__ __forceinline__ EmitBlock emit_owners(const uint32_t *__restrict__ of
     __syncthreads();
     for (int k = eb.k_lo + t; k <= k_hi; k += kSortThreads) {
         const uint32_t off = offsets[k], i = (uint32_t)(k - eb.k_lo);
-        if (i < (uint32_t)kEmitStage) {
-            s_off[i] = off;
-            s_rect[i] = rects[k];
-            if (s_gid) s_gid[i] = order[k];
-        }
+        if (i < (uint32_t)kEmitStage) s_g[i] = emit_entry(off, rects[k], want_gid ? order[k] : 0u);
         const uint32_t o = off - eb.slot0;   // (gaussians without records at the block's end start at slot_end)
         if (i > 0u && o < eb.live) atomicMax(&s_own[o], i);
     }
@@ -589,23 +591,23 @@ __device__ __forceinline__ EmitBlock emit_owners(const uint32_t *__restrict__ of
 // the record of block slot `slot` (< eb.live): tile id and gaussian index
 template <bool WANT_GID>
 __device__ __forceinline__ void emit_record(const EmitBlock &eb, uint32_t slot, const uint32_t *__restrict__ s_own,
-                                            const uint32_t *__restrict__ s_off, const uint32_t *__restrict__ s_rect,
-                                            const uint32_t *__restrict__ s_gid, const uint32_t *__restrict__ offsets,
+                                            const uint4 *__restrict__ s_g, const uint32_t *__restrict__ offsets,
                                             const uint32_t *__restrict__ rects, const uint32_t *__restrict__ order,
                                             int tile_w, uint32_t &tile, uint32_t &gid) {
     const uint32_t i = s_own[slot];
-    uint32_t rect, off;
+    uint4 e;
     if (i < (uint32_t)kEmitStage) {
-        rect = s_rect[i]; off = s_off[i];
-        if (WANT_GID) gid = s_gid[i];
-    } else {
+        e = s_g[i];
+    } else {   // (a block of gaussians with fewer than ~5 records each: the tail is looked up in global memory)
         const int k = eb.k_lo + (int)i;
-        rect = rects[k]; off = offsets[k];
-        if (WANT_GID) gid = order[k];
+        e = emit_entry(offsets[k], rects[k], WANT_GID ? order[k] : 0u);
     }
-    const uint32_t j = eb.slot0 + slot - off;
-    const int x0 = (int)(rect & 1023u), y0 = (int)((rect >> 10) & 1023u), wl = max((int)(rect >> 20), 1);
-    const int row = (int)(((float)j + 0.5f) / (float)wl);   // exact: j, wl < 2^15
+    if (WANT_GID) gid = e.z;
+    const uint32_t j = eb.slot0 + slot - e.x;
+    const int x0 = (int)(e.y & 1023u), y0 = (int)((e.y >> 10) & 1023u), wl = max((int)(e.y >> 20), 1);
+    // row = floor(j / wl) as (int)((j + 0.5) * (1 / wl)): j, wl < 2^15, so (j + 0.5) / wl is at least 0.5 / wl away from
+    // an integer -- a relative 2^-16 or more -- while v_rcp and the product are good to ~2^-22: exact
+    const int row = (int)(((float)j + 0.5f) * __uint_as_float(e.w));
     const int col = (int)j - row * wl;
     tile = (uint32_t)((y0 + row) * tile_w + x0 + col);
 }
@@ -619,21 +621,20 @@ __global__ __launch_bounds__(kSortThreads) void emit_hist_kernel(int n, const ui
     __shared__ uint32_t scratch[4];
     __shared__ uint32_t h[kRadix];
     __shared__ __attribute__((aligned(16))) uint32_t s_own[kSortChunk];
-    __shared__ uint32_t s_off[kEmitStage], s_rect[kEmitStage];
+    __shared__ uint4 s_g[kEmitStage];
     const uint32_t m_total = m_dev ? min(m_cap, *m_dev) : m_cap;
     if ((uint64_t)blockIdx.x * kSortChunk >= m_total) {
         hist[(long)threadIdx.x * nblocks + blockIdx.x] = 0;
         return;
     }
     h[threadIdx.x] = 0;
-    const EmitBlock eb = emit_owners(offsets, rects, order, block_owner, nblocks, m_total, s_own, s_off, s_rect, nullptr,
-                                     scratch);
+    const EmitBlock eb = emit_owners(offsets, rects, order, block_owner, nblocks, m_total, s_own, s_g, false, scratch);
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         const uint32_t slot = r * kSortThreads + threadIdx.x;
         if (slot < eb.live) {
             uint32_t tile, gid = 0;
-            emit_record<false>(eb, slot, s_own, s_off, s_rect, nullptr, offsets, rects, order, tile_w, tile, gid);
+            emit_record<false>(eb, slot, s_own, s_g, offsets, rects, order, tile_w, tile, gid);
             atomicAdd(&h[tile & (kRadix - 1)], 1u);
         }
     }
@@ -651,14 +652,14 @@ __global__ __launch_bounds__(kSortThreads) void emit_scatter_kernel(
     __shared__ uint32_t scratch[4];
     __shared__ uint32_t gbase[kRadix];
     __shared__ uint32_t lexcl[kRadix];
-    // three regions, each with two lives: the generation's (slot owners | staged offsets + rectangles | staged
-    // gaussian indices) and the scatter's (values | 16-bit keys | wave-private digit counters)
+    // two regions, each with two lives: the generation's (slot owners | staged gaussians) and the scatter's (values |
+    // 16-bit keys + wave-private digit counters)
     __shared__ __attribute__((aligned(16))) uint32_t s_val[kSortChunk];
-    __shared__ __attribute__((aligned(16))) uint32_t s_keyraw[kSortChunk / 2];
-    __shared__ uint32_t s_cntraw[4 * kRadix];
-    static_assert(2 * kEmitStage <= kSortChunk / 2 && kEmitStage <= 4 * kRadix, "staging must fit the aliased regions");
-    uint16_t *s_key = reinterpret_cast<uint16_t *>(s_keyraw);
-    uint32_t(*wave_cnt)[kRadix] = reinterpret_cast<uint32_t(*)[kRadix]>(s_cntraw);
+    __shared__ __attribute__((aligned(16))) uint32_t s_pool[kSortChunk / 2 + 4 * kRadix];
+    static_assert(4 * kEmitStage <= kSortChunk / 2 + 4 * kRadix, "the staged gaussians must fit the aliased region");
+    uint4 *s_g = reinterpret_cast<uint4 *>(s_pool);
+    uint16_t *s_key = reinterpret_cast<uint16_t *>(s_pool);
+    uint32_t(*wave_cnt)[kRadix] = reinterpret_cast<uint32_t(*)[kRadix]>(s_pool + kSortChunk / 2);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t m_total = m_dev ? min(m_cap, *m_dev) : m_cap;
     if ((uint64_t)blockIdx.x * kSortChunk >= m_total) return;
@@ -671,8 +672,7 @@ __global__ __launch_bounds__(kSortThreads) void emit_scatter_kernel(
         gbase[t] = dbase + mine;
         lexcl[t] = lbase;
     }
-    const EmitBlock eb = emit_owners(offsets, rects, order, block_owner, nblocks, m_total, s_val, s_keyraw,
-                                     s_keyraw + kEmitStage, s_cntraw, scratch);
+    const EmitBlock eb = emit_owners(offsets, rects, order, block_owner, nblocks, m_total, s_val, s_g, true, scratch);
     const uint32_t wbase = wave * (kSortChunk / 4);
     uint32_t k[kSortItems], v[kSortItems], rk[kSortItems];
 #pragma unroll
@@ -680,8 +680,7 @@ __global__ __launch_bounds__(kSortThreads) void emit_scatter_kernel(
         const uint32_t slot = wbase + r * 64 + lane;
         k[r] = 0xFFFFu; v[r] = 0u;
         if (slot < eb.live)
-            emit_record<true>(eb, slot, s_val, s_keyraw, s_keyraw + kEmitStage, s_cntraw, offsets, rects, order, tile_w,
-                              k[r], v[r]);
+            emit_record<true>(eb, slot, s_val, s_g, offsets, rects, order, tile_w, k[r], v[r]);
     }
     __syncthreads();   // owners and staged data consumed: the regions start their second life
 #pragma unroll
