@@ -15,6 +15,24 @@
 
 #include "project_math.h"
 
+#ifdef GSA_TRACE   // developer build: per-workgroup phase times of the binning kernels (tools/trace_sort.py)
+__device__ unsigned long long *g_sort_trace = nullptr;
+#define SORT_TRACE_BEGIN() unsigned long long st_t0 = 0, st_mark = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
+    if (threadIdx.x == 0) st_t0 = st_mark = __builtin_amdgcn_s_memrealtime()
+#define SORT_TRACE_MARK(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
+    st_acc[k] += now_ - st_mark; st_mark = now_; } } while (0)
+#define SORT_TRACE_END(kernel) do { if (g_sort_trace && threadIdx.x == 0 && blockIdx.x < 32768) { \
+    unsigned long long *r_ = g_sort_trace + ((size_t)(kernel) * 32768 + blockIdx.x) * 16; \
+    r_[0] = st_t0; r_[1] = __builtin_amdgcn_s_memrealtime(); for (int k_ = 0; k_ < 8; ++k_) r_[2 + k_] = st_acc[k_]; } } while (0)
+extern "C" int gsa_debug_set_sort_trace(unsigned long long *buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_sort_trace), &buf, sizeof(buf));
+}
+#else
+#define SORT_TRACE_BEGIN()
+#define SORT_TRACE_MARK(k)
+#define SORT_TRACE_END(kernel)
+#endif
+
 namespace {
 
 constexpr int kSortThreads = 256;
@@ -183,6 +201,31 @@ __global__ __launch_bounds__(kSortThreads) void radix_scan_rows_kernel(int nbloc
     if (threadIdx.x == 0) digit_total[blockIdx.x] = carry;
 }
 
+// Rank of this lane's item among the items of its digit that the wave has seen so far (earlier rounds: cnt[d]; this
+// round: the lanes below it holding the same digit).  The lanes of a digit find one another through one 64-bit word
+// per digit in LDS: every lane ORs its bit in (ds_or_b64) and reads the word back -- LDS operations of one wave
+// complete in order, so the word then holds exactly the round's lanes of that digit -- and the lowest of them clears
+// it again and advances cnt[d].  About ten vector and five LDS instructions per round; ranking by eight ballots with
+// per-lane mask selects cost ~55 vector instructions per round and was the largest phase of every scatter kernel
+// (tools/trace_sort.py).  mask: 256 zeroed words private to the wave.  The fences only pin the compiler's order.
+__device__ __forceinline__ uint32_t wave_rank_round(unsigned long long *mask, uint32_t *cnt, uint32_t d, bool valid,
+                                                    int lane) {
+    const unsigned long long bit = 1ull << lane;
+    if (valid) atomicOr(&mask[d], bit);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const unsigned long long peers = valid ? mask[d] : 0ull;
+    const uint32_t below = __popcll(peers & (bit - 1ull));
+    const uint32_t seen = cnt[d];                       // same value for all peers (read before the update)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (valid && below == 0) {
+        cnt[d] = seen + (uint32_t)__popcll(peers);
+        mask[d] = 0ull;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return seen + below;
+}
+
 // ---- pass 3: stable scatter ---------------------------------------------------------------------
 // A block owns kSortChunk consecutive items, wave w the w-th quarter of them (16 rounds of 64 consecutive items).
 //   1. Each wave ranks its own items against WAVE-PRIVATE digit counters in LDS: per round 8 ballots give the
@@ -208,10 +251,11 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     __shared__ uint32_t lexcl[kRadix];        // slot of that item in the block-sorted order
     __shared__ uint32_t wave_cnt[4][kRadix];  // items of digit d wave w has ranked so far; then: its first block-sorted slot
     __shared__ KeyT s_key[kSortChunk];
-    __shared__ uint32_t s_val[kSortChunk];
+    __shared__ __attribute__((aligned(16))) uint32_t s_val[kSortChunk];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n = resolve_count(n_cap, n_dev);
     if ((long)blockIdx.x * kSortChunk >= n) return;   // whole block beyond the live items (capacity launch)
+    SORT_TRACE_BEGIN();
 
     {   // digit t: global base (exclusive scan of digit totals + offset of this block inside the digit) and
         // block-local base (exclusive scan of this block's own digit counts, recovered from the scanned rows)
@@ -223,7 +267,10 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
         gbase[t] = dbase + mine;
         lexcl[t] = lbase;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) wave_cnt[w][t] = 0;
+        for (int w = 0; w < 4; ++w) {
+            wave_cnt[w][t] = 0;
+            reinterpret_cast<unsigned long long *>(s_val)[w * kRadix + t] = 0ull;
+        }
     }
 
     const long base = (long)blockIdx.x * kSortChunk + wave * (kSortChunk / 4);
@@ -235,29 +282,16 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
         v[r] = i < n ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
     }
     __syncthreads();
+    SORT_TRACE_MARK(0);   // prologue: histogram columns, block scans, key / value loads
 
     uint32_t *cnt = wave_cnt[wave];
+    // (the value staging area is idle until the reorder: its first 8 KB are the four waves' peer masks, zeroed above)
+    unsigned long long *mask = reinterpret_cast<unsigned long long *>(s_val) + wave * kRadix;
 #pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
-        const bool valid = base + r * 64 + lane < n;
-        const uint32_t d = digit_of(k[r], dg);
-        // lanes of this wave holding the same digit
-        unsigned long long peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            unsigned long long m = __ballot((d >> b) & 1);
-            peers &= ((d >> b) & 1) ? m : ~m;
-        }
-        const uint32_t below = __popcll(peers & ((1ull << lane) - 1ull));
-        const uint32_t seen = cnt[d];                       // same value for all peers (read before the update)
-        rk[r] = seen + below;
-        // LDS operations of one wave complete in order: the read above precedes this write, the next round's read
-        // follows it; the fence only keeps the compiler from reordering them
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        if (valid && below == 0) cnt[d] = seen + (uint32_t)__popcll(peers);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
+    for (int r = 0; r < kSortItems; ++r)
+        rk[r] = wave_rank_round(mask, cnt, digit_of(k[r], dg), base + r * 64 + lane < n, lane);
     __syncthreads();
+    SORT_TRACE_MARK(1);   // ranking
     {   // digit t: first block-sorted slot of each wave's items = lexcl + counts of the waves before it
         uint32_t c0 = wave_cnt[0][t], c1 = wave_cnt[1][t], c2 = wave_cnt[2][t];
         const uint32_t o = lexcl[t];
@@ -274,6 +308,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
         }
     }
     __syncthreads();
+    SORT_TRACE_MARK(2);   // reorder through LDS
     const int m = (int)min((long)kSortChunk, (long)n - (long)blockIdx.x * kSortChunk);
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
@@ -292,6 +327,8 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
             }
         }
     }
+    SORT_TRACE_MARK(3);   // output stores (issue)
+    SORT_TRACE_END(sizeof(KeyT) == 2 ? 1 : 0);
 }
 
 // ---- exclusive scan of tiles_touched in depth order ------------------------------------------------
@@ -663,6 +700,7 @@ __global__ __launch_bounds__(kSortThreads) void emit_scatter_kernel(
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t m_total = m_dev ? min(m_cap, *m_dev) : m_cap;
     if ((uint64_t)blockIdx.x * kSortChunk >= m_total) return;
+    SORT_TRACE_BEGIN();
     {
         uint32_t tot, dt = digit_total[t];
         const uint32_t mine = hist[(long)t * nblocks + blockIdx.x];
@@ -672,7 +710,9 @@ __global__ __launch_bounds__(kSortThreads) void emit_scatter_kernel(
         gbase[t] = dbase + mine;
         lexcl[t] = lbase;
     }
+    SORT_TRACE_MARK(0);   // histogram columns + block scans
     const EmitBlock eb = emit_owners(offsets, rects, order, block_owner, nblocks, m_total, s_val, s_g, true, scratch);
+    SORT_TRACE_MARK(1);   // slot owners
     const uint32_t wbase = wave * (kSortChunk / 4);
     uint32_t k[kSortItems], v[kSortItems], rk[kSortItems];
 #pragma unroll
@@ -683,29 +723,21 @@ __global__ __launch_bounds__(kSortThreads) void emit_scatter_kernel(
             emit_record<true>(eb, slot, s_val, s_g, offsets, rects, order, tile_w, k[r], v[r]);
     }
     __syncthreads();   // owners and staged data consumed: the regions start their second life
+    SORT_TRACE_MARK(2);   // record generation
 #pragma unroll
-    for (int w = 0; w < 4; ++w) wave_cnt[w][t] = 0;
+    for (int w = 0; w < 4; ++w) {
+        wave_cnt[w][t] = 0;
+        reinterpret_cast<unsigned long long *>(s_val)[w * kRadix + t] = 0ull;   // peer masks, in the idle value area
+    }
     __syncthreads();
 
     uint32_t *cnt = wave_cnt[wave];
+    unsigned long long *mask = reinterpret_cast<unsigned long long *>(s_val) + wave * kRadix;   // (zeroed above)
 #pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
-        const bool valid = wbase + r * 64 + lane < eb.live;
-        const uint32_t d = k[r] & (kRadix - 1);
-        unsigned long long peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            unsigned long long m = __ballot((d >> b) & 1);
-            peers &= ((d >> b) & 1) ? m : ~m;
-        }
-        const uint32_t below = __popcll(peers & ((1ull << lane) - 1ull));
-        const uint32_t seen = cnt[d];
-        rk[r] = seen + below;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        if (valid && below == 0) cnt[d] = seen + (uint32_t)__popcll(peers);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
+    for (int r = 0; r < kSortItems; ++r)
+        rk[r] = wave_rank_round(mask, cnt, k[r] & (kRadix - 1), wbase + r * 64 + lane < eb.live, lane);
     __syncthreads();
+    SORT_TRACE_MARK(3);   // ranking
     {
         uint32_t c0 = wave_cnt[0][t], c1 = wave_cnt[1][t], c2 = wave_cnt[2][t];
         const uint32_t o = lexcl[t];
@@ -721,6 +753,7 @@ __global__ __launch_bounds__(kSortThreads) void emit_scatter_kernel(
         }
     }
     __syncthreads();
+    SORT_TRACE_MARK(4);   // reorder through LDS
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         const uint32_t lp = r * kSortThreads + t;
@@ -732,6 +765,8 @@ __global__ __launch_bounds__(kSortThreads) void emit_scatter_kernel(
             vals_out[pos] = s_val[lp];
         }
     }
+    SORT_TRACE_MARK(5);   // output stores (issue)
+    SORT_TRACE_END(2);
 }
 
 int sort_blocks(int n) { return gsa_div_up(n, kSortChunk); }
@@ -948,27 +983,24 @@ __device__ __forceinline__ uint32_t block1024_max(uint32_t v, uint32_t *scratch)
 __device__ __forceinline__ void bucket_local_pass(BucketLds &L, int src, int mm, int bs) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int R = ((mm + kLocalThreads - 1) / kLocalThreads) * 64;   // items per wave range (a multiple of 64)
-    for (int i = t; i < kLocalWaves * kRadix; i += kLocalThreads) (&L.wcnt[0][0])[i] = 0u;
+    // (the destination half of the value buffer is idle until the placement: it holds the 16 waves' peer masks)
+    unsigned long long *masks = reinterpret_cast<unsigned long long *>(L.val[src ^ 1]);
+    static_assert(sizeof(L.val[0]) >= sizeof(unsigned long long) * kLocalWaves * kRadix, "peer masks must fit");
+    for (int i = t; i < kLocalWaves * kRadix; i += kLocalThreads) {
+        (&L.wcnt[0][0])[i] = 0u;
+        masks[i] = 0ull;
+    }
     __syncthreads();
     {
         uint32_t *cnt = L.wcnt[wave];
+        unsigned long long *mask = masks + wave * kRadix;
         const int end = min(mm, (wave + 1) * R);
         for (int i0 = wave * R; i0 < end; i0 += 64) {
             const int i = i0 + lane;
             const bool valid = i < end;
             const uint32_t d = valid ? ((uint32_t)L.key[src][i] >> bs) & (kRadix - 1) : 0u;
-            unsigned long long peers = __ballot(valid);
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const unsigned long long mk = __ballot((d >> b) & 1);
-                peers &= ((d >> b) & 1) ? mk : ~mk;
-            }
-            const uint32_t below = __popcll(peers & ((1ull << lane) - 1ull));
-            const uint32_t seen = cnt[d];
-            if (valid) L.rk[i] = (uint16_t)(seen + below);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            if (valid && below == 0) cnt[d] = seen + (uint32_t)__popcll(peers);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t rank = wave_rank_round(mask, cnt, d, valid, lane);
+            if (valid) L.rk[i] = (uint16_t)rank;
         }
     }
     __syncthreads();
