@@ -17,8 +17,21 @@ namespace {
 #define GSA_PROJ_BLOCK 256
 #endif
 constexpr int kBlock = GSA_PROJ_BLOCK;
+#ifndef GSA_EXP_AUX
+#define GSA_EXP_AUX 0
+#endif
+#ifndef GSA_PROJ_FWD_REVERSE
+#define GSA_PROJ_FWD_REVERSE 1
+#endif
+#ifndef GSA_PROJ_FWD_WAVES
+#define GSA_PROJ_FWD_WAVES 1   // minimum waves per SIMD the forward kernel is compiled for (register budget)
+#endif
 constexpr int kRowQ = 12;      // float4 per [16,3] SH row
 constexpr int kRowQPad = 13;   // padded LDS row (52 floats): conflict-free ds_read_b128 across lanes
+// Half-row staging (forward; backward with the digest): a wave moves its 64 rows through LDS in two column halves of at
+// most 6 float4, rows padded to 7 (28 dwords: 16 consecutive lanes start in 16 different 4-bank groups).  28 KB per
+// 256-thread block instead of 52: five blocks a CU fit where three did, and these kernels wait on memory.
+constexpr int kHalfQ = 6, kHalfPad = 7;
 
 // Every wave stages and reads back ONLY its own 64 rows of the LDS image, so no workgroup barrier is needed: LDS
 // operations of one wave complete in order; the fences keep the compiler from reordering across the hand-over.
@@ -33,19 +46,47 @@ __host__ __device__ constexpr int sh_needed_q() {  // float4 per row that hold t
     return DEG < 0 ? 0 : (3 * (DEG + 1) * (DEG + 1) + 3) / 4;
 }
 
+// One column half (HW float4 columns starting at column OFF) of a wave's 64 coefficient rows, from the registers the
+// whole-wave loads filled (stg) through the wave's LDS image into row-per-lane order (c).  All indices are compile-time
+// constants: a dynamically indexed stg / c would be demoted to scratch memory.
+template <int OFF, int HW, int NQ, int NC>
+__device__ __forceinline__ void half_rows_to_lanes(float4 *wrows, int lane, const float (&stg)[4 * NQ], float (&c)[NC]) {
+#pragma unroll
+    for (int k = 0; k < HW; ++k) {
+        const int idx = k * 64 + lane, row = idx / HW, col = idx - row * HW;
+        wrows[row * kHalfPad + col] = make_float4(stg[4 * (OFF + k)], stg[4 * (OFF + k) + 1], stg[4 * (OFF + k) + 2],
+                                                  stg[4 * (OFF + k) + 3]);
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < HW; ++k) {
+        const float4 v = wrows[lane * kHalfPad + k];
+        if (4 * (OFF + k) + 0 < NC) c[4 * (OFF + k) + 0] = v.x;
+        if (4 * (OFF + k) + 1 < NC) c[4 * (OFF + k) + 1] = v.y;
+        if (4 * (OFF + k) + 2 < NC) c[4 * (OFF + k) + 2] = v.z;
+        if (4 * (OFF + k) + 3 < NC) c[4 * (OFF + k) + 3] = v.w;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
 template <int DEG, bool STAGE>
-__global__ __launch_bounds__(kBlock) void project_fwd_kernel(
+__global__ __launch_bounds__(kBlock, GSA_PROJ_FWD_WAVES) void project_fwd_kernel(
     int n, const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
     const float *__restrict__ opacities, const float *__restrict__ colors, int sh_coeffs,
     const float *__restrict__ viewmat, const float *__restrict__ intrin, int width, int height, int tile_w,
     int tile_h, int cull_mode, float *__restrict__ splat, int32_t *__restrict__ radii,
-    int32_t *__restrict__ tiles_touched, uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ tile_rects) {
-    __shared__ float4 sh_lds[STAGE ? kBlock * kRowQPad : 1];
+    int32_t *__restrict__ tiles_touched, uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ tile_rects,
+    float *__restrict__ sh_aux) {
+    __shared__ float4 sh_lds[STAGE ? kBlock * kHalfPad : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    // Blocks walk the gaussians from the LAST to the first (GSA_PROJ_FWD_REVERSE): the kernel that ran before this one in
+    // a training loop is the previous view's project_bwd, which streamed the same parameter arrays front to back -- the
+    // 256-MB memory-side cache then still holds the rows of the last ~0.45 M gaussians, and reading those first hits
+    // them before this kernel's own traffic pushes them out (front to back they would be gone by the time it got there).
+    const long blk = GSA_PROJ_FWD_REVERSE ? (long)gridDim.x - 1 - blockIdx.x : (long)blockIdx.x;
+    const long i = blk * kBlock + threadIdx.x;
 
     // geometry first: these loads are in flight while the SH rows are staged (one memory round trip per wave less;
     // the kernel is latency-bound: ~80 % of its wave-cycles are waits on memory)
@@ -58,18 +99,29 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(
         g_opac = opacities[i];
     }
 
+    // SH rows: all of the wave's loads are issued now (two column halves, each a set of whole-wave loads of 96-B row
+    // segments); they pass through LDS half by half further down, when the coefficients are needed
+    constexpr int NQ = sh_needed_q<DEG>();
+    constexpr int H0 = NQ < kHalfQ ? NQ : kHalfQ, H1 = NQ - H0;   // float4 columns of the two halves
+    float stg[(STAGE && DEG >= 1) ? 4 * NQ : 4];   // (plain floats: an array of float4 this size is demoted to scratch)
     if constexpr (STAGE && DEG >= 1) {
-        constexpr int NQ = sh_needed_q<DEG>();
-        const long wave_base = (long)blockIdx.x * kBlock + wave * 64;
-        const long rows = min((long)64, (long)n - wave_base);
+        // (row indices are CLAMPED to the wave's last row instead of predicated: predicated loads compile to one
+        // branch + s_waitcnt vmcnt(0) each, i.e. twelve serial memory round trips)
+        const long wave_base = min(blk * kBlock + wave * 64, (long)n - 1);
+        const int last = (int)min((long)63, (long)n - 1 - wave_base);
         const float4 *src = reinterpret_cast<const float4 *>(colors) + wave_base * kRowQ;
 #pragma unroll
-        for (int k = 0; k < NQ; ++k) {
-            int idx = k * 64 + lane;
-            int row = idx / NQ, col = idx - row * NQ;
-            if (row < rows) sh_lds[(wave * 64 + row) * kRowQPad + col] = src[row * kRowQ + col];
+        for (int k = 0; k < H0; ++k) {
+            const int idx = k * 64 + lane, row = min(idx / H0, last), col = idx % H0;
+            const float4 v = src[row * kRowQ + col];
+            stg[4 * k] = v.x; stg[4 * k + 1] = v.y; stg[4 * k + 2] = v.z; stg[4 * k + 3] = v.w;
         }
-        wave_lds_sync();
+#pragma unroll
+        for (int k = 0; k < H1; ++k) {
+            const int idx = k * 64 + lane, row = min(idx / (H1 > 0 ? H1 : 1), last), col = idx % (H1 > 0 ? H1 : 1);
+            const float4 v = src[row * kRowQ + H0 + col];
+            stg[4 * (H0 + k)] = v.x; stg[4 * (H0 + k) + 1] = v.y; stg[4 * (H0 + k) + 2] = v.z; stg[4 * (H0 + k) + 3] = v.w;
+        }
     }
     const bool inside = i < n;   // lanes beyond n stay for the wave-cooperative record store below
 
@@ -86,8 +138,22 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(
     visible = visible && !(p.mx + rxf <= 0.f || p.mx - rxf >= (float)width || p.my + ryf <= 0.f ||
                            p.my - ryf >= (float)height);
 
+    // the coefficient rows, through the wave's LDS image half by half: lane l ends up with row l (every lane takes
+    // part, visible or not; a wave only touches its own 64 rows, so no workgroup barrier)
+    constexpr int NC = DEG < 0 ? 1 : 3 * (DEG + 1) * (DEG + 1);
+    float c[NC];
+    if constexpr (STAGE && DEG >= 1) {
+        float4 *wrows = &sh_lds[(wave * 64) * kHalfPad];
+        half_rows_to_lanes<0, H0, NQ, NC>(wrows, lane, stg, c);
+        if constexpr (H1 > 0) {
+            wave_lds_sync();   // every lane has read its first half
+            half_rows_to_lanes<H0, H1, NQ, NC>(wrows, lane, stg, c);
+        }
+    }
+
     // what a culled gaussian leaves: a zero record, zero radii / count, the largest depth key
     float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0, o2 = o0;
+    float4 aux[3] = {o0, o0, o0};
     int rx = 0, ry = 0, count = 0;
     uint32_t key = 0xFFFFFFFFu, rect = 0u;
     if (visible) {
@@ -101,19 +167,7 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(
         float inv = rsqrtf(dx * dx + dy * dy + dz * dz);
         float B[NB];
         gsa_sh_basis<DEG>(dx * inv, dy * inv, dz * inv, B);
-        float c[NB * 3];
-        if constexpr (STAGE && DEG >= 1) {
-            constexpr int NQ = sh_needed_q<DEG>();
-            const float4 *row = &sh_lds[threadIdx.x * kRowQPad];
-#pragma unroll
-            for (int k = 0; k < NQ; ++k) {
-                float4 v = row[k];
-                if (4 * k + 0 < NB * 3) c[4 * k + 0] = v.x;
-                if (4 * k + 1 < NB * 3) c[4 * k + 1] = v.y;
-                if (4 * k + 2 < NB * 3) c[4 * k + 2] = v.z;
-                if (4 * k + 3 < NB * 3) c[4 * k + 3] = v.w;
-            }
-        } else {
+        if constexpr (!(STAGE && DEG >= 1)) {
             const float *row = colors + i * (long)sh_coeffs * 3;
 #pragma unroll
             for (int k = 0; k < NB * 3; ++k) c[k] = row[k];
@@ -124,6 +178,31 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(
             r += B[j] * c[3 * j]; g += B[j] * c[3 * j + 1]; b += B[j] * c[3 * j + 2];
         }
         r = fmaxf(r + 0.5f, 0.f); g = fmaxf(g + 0.5f, 0.f); b = fmaxf(b + 0.5f, 0.f);
+        if constexpr (DEG >= 1) {
+            // sh_aux (optional, [N,12]): per channel d colour / d mean through the view direction (the SH sum's
+            // gradient in the unit direction, projected off it, over the distance) and the clamp flag -- everything the
+            // backward needs of the 192-B coefficient row, in 48 B (the coefficients are in registers here anyway)
+#if GSA_EXP_AUX == 2   // experiment: stores without the computation
+            if (sh_aux) aux[0] = aux[1] = aux[2] = make_float4(r, g, b, 1.f);
+            if (false) {
+#else
+            if (sh_aux) {
+#endif
+                const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+                const float pre[3] = {r, g, b};
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    float vB[NB];
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) vB[j] = c[3 * j + ch];
+                    float hx, hy, hz;
+                    gsa_sh_basis_vjp<DEG>(ux, uy, uz, vB, hx, hy, hz);
+                    const float dd = hx * ux + hy * uy + hz * uz;
+                    aux[ch] = make_float4((hx - dd * ux) * inv, (hy - dd * uy) * inv, (hz - dd * uz) * inv,
+                                          pre[ch] > 0.f ? 1.f : 0.f);
+                }
+            }
+        }
     }
 
     // ---- tile count (A.4)
@@ -150,9 +229,9 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(
     // ---- the 64-B records: through the wave's (now free) LDS rows, so that every store instruction writes 1 KB of
     // consecutive addresses instead of 16 B at a 64-B stride
     if constexpr (STAGE && DEG >= 1) {
-        const long wave_base = (long)blockIdx.x * kBlock + wave * 64;
+        const long wave_base = blk * kBlock + wave * 64;
         const int rows = (int)min((long)64, (long)n - wave_base);
-        float4 *wl = &sh_lds[(wave * 64) * kRowQPad];
+        float4 *wl = &sh_lds[(wave * 64) * kHalfPad];
         wave_lds_sync();   // every lane has read its SH row
         wl[lane * 4 + 0] = o0; wl[lane * 4 + 1] = o1; wl[lane * 4 + 2] = o2; wl[lane * 4 + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
         wave_lds_sync();
@@ -162,7 +241,26 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(
             const int idx = k * 64 + lane;
             if (idx < rows * 4) outw[idx] = wl[idx];
         }
+#if GSA_EXP_AUX == 1   // experiment: the computation without the stores
+        if (DEG >= 1 && sh_aux && n == 12345) {
+#else
+        if (DEG >= 1 && sh_aux) {   // the digest rows leave the same way (zeros for culled gaussians)
+#endif
+            wave_lds_sync();
+            wl[lane * 3 + 0] = aux[0]; wl[lane * 3 + 1] = aux[1]; wl[lane * 3 + 2] = aux[2];
+            wave_lds_sync();
+            float4 *auxw = reinterpret_cast<float4 *>(sh_aux) + wave_base * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int idx = k * 64 + lane;
+                if (idx < rows * 3) auxw[idx] = wl[idx];
+            }
+        }
     } else if (inside) {
+        if (DEG >= 1 && sh_aux) {
+            float4 *arow = reinterpret_cast<float4 *>(sh_aux) + i * 3;
+            arow[0] = aux[0]; arow[1] = aux[1]; arow[2] = aux[2];
+        }
         float4 *out = reinterpret_cast<float4 *>(splat + i * GSA_SPLAT_STRIDE);
         out[0] = o0; out[1] = o1; out[2] = o2; out[3] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -177,26 +275,28 @@ __global__ __launch_bounds__(kBlock) void project_fwd_kernel(
 // ------------------------------------------------------------------------------------------------
 // backward (A.7)
 // ------------------------------------------------------------------------------------------------
-template <int DEG, bool STAGE, bool FACTORED>
+template <int DEG, bool STAGE, bool FACTORED, bool AUX>
 __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
     int n, const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
     const float *__restrict__ opacities, const float *__restrict__ colors, int sh_coeffs,
     const float *__restrict__ viewmat, const float *__restrict__ intrin, int width, int height,
     const int32_t *__restrict__ radii, const float *__restrict__ v_splat, float *__restrict__ v_means,
     float *__restrict__ v_quats, float *__restrict__ v_scales, float *__restrict__ v_opacities,
-    float *__restrict__ v_colors, int accumulate, float *__restrict__ v_rgb_out) {
+    float *__restrict__ v_colors, int accumulate, float *__restrict__ v_rgb_out, const float *__restrict__ sh_aux) {
     // The forward's splat records are NOT read back (64 MB of lines at 1 M for 32 B of use each): the projection is
     // recomputed from the raw parameters anyway, the opacity is an input, and the colour clamp mask is re-derived
     // from the SH sum evaluated exactly as the forward evaluates it.
+    // AUX: the forward left sh_aux[N,12] (see there): the coefficient rows are not read at all (48 B instead of 192).
     // v_rgb_out (optional, [N,3]): FACTORED colour gradient -- instead of the [N,K,3] SH-coefficient gradient
     // (v_colors, then unused) write only d loss / d rgb after the clamp mask.  The SH gradient is the outer product of
     // the view's SH basis with it (gsa_sh_grad_expand), so 3 floats per gaussian carry what 48 would.
-    __shared__ float4 sh_lds[STAGE ? kBlock * kRowQPad : 1];
+    __shared__ float4 sh_lds[!STAGE || (AUX && FACTORED) ? 1 : kBlock * (AUX ? kHalfPad : kRowQPad)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long i = (long)blockIdx.x * kBlock + threadIdx.x;
     const long wave_base = (long)blockIdx.x * kBlock + wave * 64;
     const long rows = min((long)64, (long)n - wave_base);
     constexpr int NB = DEG < 0 ? 1 : (DEG + 1) * (DEG + 1);
+    static_assert(!AUX || DEG >= 1, "sh_aux only exists for view-dependent colour");
 
     // per-gaussian inputs first: in flight while the SH rows are staged (see the forward kernel)
     const bool active = i < n;
@@ -204,6 +304,7 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
     int g_rx = 0, g_ry = 0;
     float4 g_v0 = make_float4(0.f, 0.f, 0.f, 0.f), g_v1 = g_v0, g_v2 = g_v0;
     float g_opac = 1.f;
+    float4 g_aux[3] = {g_v0, g_v0, g_v0};
     if (active) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) { g_mean[k] = means[i * 3 + k]; g_scale[k] = scales[i * 3 + k]; }
@@ -213,16 +314,34 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
         const float4 *vrow = reinterpret_cast<const float4 *>(v_splat + i * GSA_SPLAT_STRIDE);
         g_v0 = vrow[0]; g_v1 = vrow[1]; g_v2 = vrow[2];
         g_opac = opacities[i];
+        if constexpr (AUX) {
+            const float4 *arow = reinterpret_cast<const float4 *>(sh_aux) + i * 3;
+            g_aux[0] = arow[0]; g_aux[1] = arow[1]; g_aux[2] = arow[2];
+        }
+    }
+    if constexpr (AUX) {
+        // Every load above is issued HERE, together: left alone the compiler sinks all but the radii below the
+        // visibility test (they are only used there), which makes two dependent memory round trips out of one.
+        asm volatile("" : "+v"(g_mean[0]), "+v"(g_scale[0]), "+v"(g_quat[0]), "+v"(g_v0.x), "+v"(g_v1.x), "+v"(g_v2.x),
+                          "+v"(g_opac), "+v"(g_aux[0].x), "+v"(g_aux[1].x), "+v"(g_aux[2].x), "+v"(g_rx));
     }
 
-    if constexpr (STAGE && DEG >= 1) {
+    if constexpr (STAGE && DEG >= 1 && !AUX) {
         constexpr int NQ = sh_needed_q<DEG>();
-        const float4 *src = reinterpret_cast<const float4 *>(colors) + wave_base * kRowQ;
+        // (source rows clamped, not predicated -- see the forward kernel: all loads of the wave in flight at once)
+        const long src_base = min(wave_base, (long)n - 1);
+        const int last = (int)min((long)63, (long)n - 1 - src_base);
+        const float4 *src = reinterpret_cast<const float4 *>(colors) + src_base * kRowQ;
+        float4 tmp[NQ];
 #pragma unroll
         for (int k = 0; k < NQ; ++k) {
-            int idx = k * 64 + lane;
-            int row = idx / NQ, col = idx - row * NQ;
-            if (row < rows) sh_lds[(wave * 64 + row) * kRowQPad + col] = src[row * kRowQ + col];
+            const int idx = k * 64 + lane, row = idx / NQ, col = idx - row * NQ;
+            tmp[k] = src[min(row, last) * kRowQ + col];
+        }
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int idx = k * 64 + lane, row = idx / NQ, col = idx - row * NQ;
+            sh_lds[(wave * 64 + row) * kRowQPad + col] = tmp[k];
         }
         wave_lds_sync();
     }
@@ -334,6 +453,20 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
             float ux = dx * inv, uy = dy * inv, uz = dz * inv;
             float B[NB];
             gsa_sh_basis<DEG>(ux, uy, uz, B);
+            if constexpr (AUX) {
+                float vr[3] = {g_aux[0].w != 0.f ? v_rgb[0] : 0.f, g_aux[1].w != 0.f ? v_rgb[1] : 0.f,
+                               g_aux[2].w != 0.f ? v_rgb[2] : 0.f};
+                vr_keep[0] = vr[0]; vr_keep[1] = vr[1]; vr_keep[2] = vr[2];
+                if constexpr (!FACTORED) {
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        vc[3 * j] = B[j] * vr[0]; vc[3 * j + 1] = B[j] * vr[1]; vc[3 * j + 2] = B[j] * vr[2];
+                    }
+                }
+                vm[0] += g_aux[0].x * vr[0] + g_aux[1].x * vr[1] + g_aux[2].x * vr[2];
+                vm[1] += g_aux[0].y * vr[0] + g_aux[1].y * vr[1] + g_aux[2].y * vr[2];
+                vm[2] += g_aux[0].z * vr[0] + g_aux[1].z * vr[1] + g_aux[2].z * vr[2];
+            } else {
             float cf[NB * 3];
             if constexpr (STAGE && DEG >= 1) {
                 constexpr int NQ = sh_needed_q<DEG>();
@@ -376,6 +509,7 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
                 float dd = hx * ux + hy * uy + hz * uz;
                 vm[0] += (hx - dd * ux) * inv; vm[1] += (hy - dd * uy) * inv; vm[2] += (hz - dd * uz) * inv;
             }
+            }   // !AUX
         }
     }
 
@@ -402,6 +536,47 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
         if (active) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) v_colors[i * 3 + k] = vc[k] + (accumulate ? v_colors[i * 3 + k] : 0.f);
+        }
+    } else if constexpr (STAGE && AUX) {
+        // rows leave through the wave's LDS image in two column halves (see kHalfPad): whole-wave stores of 96-B row
+        // segments
+        float4 *wrows = &sh_lds[(wave * 64) * kHalfPad];
+        float4 *dst = reinterpret_cast<float4 *>(v_colors) + wave_base * kRowQ;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1) wave_lds_sync();   // the first half has left
+#pragma unroll
+            for (int k = 0; k < kHalfQ; ++k) {
+                const int e = 4 * (h * kHalfQ + k);
+                float4 v;
+                v.x = e + 0 < NB * 3 ? vc[(e + 0) % (NB * 3)] : 0.f;
+                v.y = e + 1 < NB * 3 ? vc[(e + 1) % (NB * 3)] : 0.f;
+                v.z = e + 2 < NB * 3 ? vc[(e + 2) % (NB * 3)] : 0.f;
+                v.w = e + 3 < NB * 3 ? vc[(e + 3) % (NB * 3)] : 0.f;
+                wrows[lane * kHalfPad + k] = v;
+            }
+            wave_lds_sync();
+            float old[4 * kHalfQ];
+            if (accumulate && rows > 0) {   // (wave-uniform; rows clamped, not predicated: all six loads in flight at once)
+#pragma unroll
+                for (int k = 0; k < kHalfQ; ++k) {
+                    const int idx = k * 64 + lane, r_ = min(idx / kHalfQ, (int)rows - 1), c_ = idx % kHalfQ;
+                    const float4 o = dst[r_ * kRowQ + h * kHalfQ + c_];
+                    old[4 * k] = o.x; old[4 * k + 1] = o.y; old[4 * k + 2] = o.z; old[4 * k + 3] = o.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4 * kHalfQ; ++k) old[k] = 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < kHalfQ; ++k) {
+                const int idx = k * 64 + lane, r_ = idx / kHalfQ, c_ = idx - r_ * kHalfQ;
+                if (r_ < rows) {
+                    float4 v = wrows[r_ * kHalfPad + c_];
+                    v.x += old[4 * k]; v.y += old[4 * k + 1]; v.z += old[4 * k + 2]; v.w += old[4 * k + 3];
+                    dst[r_ * kRowQ + h * kHalfQ + c_] = v;
+                }
+            }
         }
     } else if (STAGE) {
         wave_lds_sync();  // all lanes have consumed their coefficient rows
@@ -443,17 +618,18 @@ template <int DEG>
 int launch_fwd(bool stage, int n, const float *means, const float *quats, const float *scales,
                const float *opacities, const float *colors, int sh_coeffs, const float *viewmat,
                const float *intrin, int width, int height, int cull_mode, float *splat, int32_t *radii,
-               int32_t *tiles_touched, uint32_t *depth_keys, uint32_t *tile_rects, hipStream_t s) {
+               int32_t *tiles_touched, uint32_t *depth_keys, uint32_t *tile_rects, float *sh_aux, hipStream_t s) {
     int tile_w = gsa_div_up(width, GSA_TILE_SIZE), tile_h = gsa_div_up(height, GSA_TILE_SIZE);
     dim3 grid(gsa_div_up(n, kBlock)), block(kBlock);
     if (stage)
         project_fwd_kernel<DEG, true><<<grid, block, 0, s>>>(n, means, quats, scales, opacities, colors, sh_coeffs,
                                                              viewmat, intrin, width, height, tile_w, tile_h, cull_mode,
-                                                             splat, radii, tiles_touched, depth_keys, tile_rects);
+                                                             splat, radii, tiles_touched, depth_keys, tile_rects, sh_aux);
     else
         project_fwd_kernel<DEG, false><<<grid, block, 0, s>>>(n, means, quats, scales, opacities, colors, sh_coeffs,
                                                               viewmat, intrin, width, height, tile_w, tile_h,
-                                                              cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects);
+                                                              cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects,
+                                                              sh_aux);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }
@@ -463,20 +639,30 @@ int launch_bwd(bool stage, int n, const float *means, const float *quats, const 
                const float *colors, int sh_coeffs, const float *viewmat, const float *intrin, int width,
                int height, const int32_t *radii, const float *v_splat, float *v_means,
                float *v_quats, float *v_scales, float *v_opacities, float *v_colors, int accumulate, float *v_rgb_out,
-               hipStream_t s) {
+               const float *sh_aux, hipStream_t s) {
     dim3 grid(gsa_div_up(n, kBlock)), block(kBlock);
-#define GSA_BWD_LAUNCH(ST, FA)                                                                                        \
-    project_bwd_kernel<DEG, ST, FA><<<grid, block, 0, s>>>(n, means, quats, scales, opacities, colors, sh_coeffs, viewmat, \
-                                                           intrin, width, height, radii, v_splat, v_means, v_quats,      \
-                                                           v_scales, v_opacities, v_colors, accumulate, v_rgb_out)
-    if constexpr (DEG >= 0) {
-        if (v_rgb_out) {
-            if (stage) GSA_BWD_LAUNCH(true, true); else GSA_BWD_LAUNCH(false, true);
+#define GSA_BWD_LAUNCH(ST, FA, AU)                                                                                    \
+    project_bwd_kernel<DEG, ST, FA, AU><<<grid, block, 0, s>>>(n, means, quats, scales, opacities, colors, sh_coeffs,    \
+                                                               viewmat, intrin, width, height, radii, v_splat, v_means, \
+                                                               v_quats, v_scales, v_opacities, v_colors, accumulate,    \
+                                                               v_rgb_out, sh_aux)
+    if constexpr (DEG >= 1) {
+        if (sh_aux) {   // the forward's 48-B digest of the coefficient row replaces the row
+            if (v_rgb_out) GSA_BWD_LAUNCH(false, true, true);
+            else if (stage) GSA_BWD_LAUNCH(true, false, true);
+            else GSA_BWD_LAUNCH(false, false, true);
             GSA_LAUNCH_CHECK();
             return GSA_OK;
         }
     }
-    if (stage) GSA_BWD_LAUNCH(true, false); else GSA_BWD_LAUNCH(false, false);
+    if constexpr (DEG >= 0) {
+        if (v_rgb_out) {
+            if (stage) GSA_BWD_LAUNCH(true, true, false); else GSA_BWD_LAUNCH(false, true, false);
+            GSA_LAUNCH_CHECK();
+            return GSA_OK;
+        }
+    }
+    if (stage) GSA_BWD_LAUNCH(true, false, false); else GSA_BWD_LAUNCH(false, false, false);
 #undef GSA_BWD_LAUNCH
     GSA_LAUNCH_CHECK();
     return GSA_OK;
@@ -492,13 +678,13 @@ extern "C" int gsa_project_fwd(int n, const float *means, const float *quats, co
                                const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
                                const float *viewmat, const float *intrin, int width, int height, int cull_mode,
                                float *splat, int32_t *radii, int32_t *tiles_touched, uint32_t *depth_keys,
-                               uint32_t *tile_rects, gsa_stream_t stream) {
+                               uint32_t *tile_rects, float *sh_aux, gsa_stream_t stream) {
     GSA_RETURN_IF(n < 0 || width <= 0 || height <= 0, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_degree < -1 || sh_degree > 3, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_degree >= 0 && sh_coeffs < (sh_degree + 1) * (sh_degree + 1), GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(cull_mode != 0 && cull_mode != 1, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF((reinterpret_cast<uintptr_t>(tile_rects) & 7) != 0 || (reinterpret_cast<uintptr_t>(radii) & 7) != 0 ||
-                      (reinterpret_cast<uintptr_t>(splat) & 15) != 0,
+                      (reinterpret_cast<uintptr_t>(splat) & 15) != 0 || (reinterpret_cast<uintptr_t>(sh_aux) & 15) != 0,
                   GSA_ERR_INVALID_ARGUMENT);
     if (n == 0) return GSA_OK;
     GSA_RETURN_IF(!means || !quats || !scales || !opacities || !colors || !viewmat || !intrin || !splat || !radii ||
@@ -509,7 +695,7 @@ extern "C" int gsa_project_fwd(int n, const float *means, const float *quats, co
     bool stage = can_stage(colors, sh_degree, sh_coeffs) && sh_degree >= 1;
 #define GSA_FWD(D)                                                                                              \
     return launch_fwd<D>(stage, n, means, quats, scales, opacities, colors, sh_coeffs, viewmat, intrin, width, \
-                         height, cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects, s)
+                         height, cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects, sh_aux, s)
     switch (sh_degree) {
         case -1: GSA_FWD(-1);
         case 0: GSA_FWD(0);
@@ -524,7 +710,7 @@ static int project_bwd_impl(int n, const float *means, const float *quats, const
                             const float *colors, int sh_degree, int sh_coeffs, const float *viewmat, const float *intrin,
                             int width, int height, const int32_t *radii, const float *v_splat, float *v_means,
                             float *v_quats, float *v_scales, float *v_opacities, float *v_colors, int accumulate,
-                            float *v_rgb_out, gsa_stream_t stream) {
+                            float *v_rgb_out, const float *sh_aux, gsa_stream_t stream) {
     GSA_RETURN_IF(n < 0 || width <= 0 || height <= 0, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_degree < -1 || sh_degree > 3, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_degree >= 0 && sh_coeffs < (sh_degree + 1) * (sh_degree + 1), GSA_ERR_INVALID_ARGUMENT);
@@ -533,12 +719,15 @@ static int project_bwd_impl(int n, const float *means, const float *quats, const
                       !v_means || !v_quats || !v_scales || !v_opacities || (!v_colors && !v_rgb_out),
                   GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(v_rgb_out && sh_degree < 0, GSA_ERR_INVALID_ARGUMENT);   // factored form: SH colours only
+    GSA_RETURN_IF((reinterpret_cast<uintptr_t>(sh_aux) & 15) != 0, GSA_ERR_INVALID_ARGUMENT);
+    if (sh_degree < 1) sh_aux = nullptr;   // no view dependence: nothing the forward could have left
     hipStream_t s = static_cast<hipStream_t>(stream);
     bool stage = can_stage(colors, sh_degree, sh_coeffs) &&
                  (v_rgb_out || (reinterpret_cast<uintptr_t>(v_colors) & 15) == 0);
 #define GSA_BWD(D)                                                                                                  \
     return launch_bwd<D>(stage, n, means, quats, scales, opacities, colors, sh_coeffs, viewmat, intrin, width, height, \
-                         radii, v_splat, v_means, v_quats, v_scales, v_opacities, v_colors, accumulate ? 1 : 0, v_rgb_out, s)
+                         radii, v_splat, v_means, v_quats, v_scales, v_opacities, v_colors, accumulate ? 1 : 0, v_rgb_out, \
+                         sh_aux, s)
     switch (sh_degree) {
         case -1: GSA_BWD(-1);
         case 0: GSA_BWD(0);
@@ -554,10 +743,10 @@ extern "C" int gsa_project_bwd(int n, const float *means, const float *quats, co
                                const float *viewmat, const float *intrin, int width, int height,
                                const float *splat, const int32_t *radii, const float *v_splat, float *v_means,
                                float *v_quats, float *v_scales, float *v_opacities, float *v_colors,
-                               gsa_stream_t stream) {
+                               const float *sh_aux, gsa_stream_t stream) {
     (void)splat;   // kept in the signature: the backward no longer reads the forward's records (see the kernel)
     return project_bwd_impl(n, means, quats, scales, opacities, colors, sh_degree, sh_coeffs, viewmat, intrin, width, height,
-                            radii, v_splat, v_means, v_quats, v_scales, v_opacities, v_colors, 0, nullptr, stream);
+                            radii, v_splat, v_means, v_quats, v_scales, v_opacities, v_colors, 0, nullptr, sh_aux, stream);
 }
 
 extern "C" int gsa_project_bwd_acc(int n, const float *means, const float *quats, const float *scales,
@@ -565,10 +754,11 @@ extern "C" int gsa_project_bwd_acc(int n, const float *means, const float *quats
                                    const float *viewmat, const float *intrin, int width, int height,
                                    const float *splat, const int32_t *radii, const float *v_splat, float *v_means,
                                    float *v_quats, float *v_scales, float *v_opacities, float *v_colors,
-                                   int accumulate, gsa_stream_t stream) {
+                                   int accumulate, const float *sh_aux, gsa_stream_t stream) {
     (void)splat;   // kept in the signature: the backward no longer reads the forward's records (see the kernel)
     return project_bwd_impl(n, means, quats, scales, opacities, colors, sh_degree, sh_coeffs, viewmat, intrin, width, height,
-                            radii, v_splat, v_means, v_quats, v_scales, v_opacities, v_colors, accumulate, nullptr, stream);
+                            radii, v_splat, v_means, v_quats, v_scales, v_opacities, v_colors, accumulate, nullptr, sh_aux,
+                            stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -685,11 +875,12 @@ extern "C" int gsa_project_bwd_factored(int n, const float *means, const float *
                                         const float *viewmat, const float *intrin, int width, int height,
                                         const float *splat, const int32_t *radii, const float *v_splat, float *v_means,
                                         float *v_quats, float *v_scales, float *v_opacities, float *v_rgb,
-                                        int accumulate, gsa_stream_t stream) {
+                                        int accumulate, const float *sh_aux, gsa_stream_t stream) {
     (void)splat;
     GSA_RETURN_IF(!v_rgb, GSA_ERR_INVALID_ARGUMENT);
     return project_bwd_impl(n, means, quats, scales, opacities, colors, sh_degree, sh_coeffs, viewmat, intrin, width, height,
-                            radii, v_splat, v_means, v_quats, v_scales, v_opacities, nullptr, accumulate, v_rgb, stream);
+                            radii, v_splat, v_means, v_quats, v_scales, v_opacities, nullptr, accumulate, v_rgb, sh_aux,
+                            stream);
 }
 
 static int sh_grad_expand_impl(int n, const float *means, int sh_degree, int sh_coeffs, int n_views,

@@ -13,6 +13,8 @@
 // Replaces gsplat's isect_tiles / radix sort / isect_offset_encode behind
 // /root/reference/src/backends/gsplat_backend.py:168-182.
 
+#include <cstdlib>
+
 #include "project_math.h"
 
 #ifdef GSA_TRACE   // developer build: per-workgroup phase times of the binning kernels (tools/trace_sort.py)
@@ -87,19 +89,42 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(int n_cap, con
     if (threadIdx.x == 0) { s_lo = 0xFFFFFFFFu; s_hi = 0u; }
     uint32_t lo = 0xFFFFFFFFu, hi = 0u;
     __syncthreads();
+    // A block with all kSortChunk keys live (all but the last one) issues its loads TOGETHER, then counts: loads
+    // predicated on i < n compile to one branch + s_waitcnt vmcnt(0) each -- sixteen serial memory round trips.
+    const bool full = base + kSortChunk <= n;
     if constexpr (sizeof(KeyT) == 2) {   // two keys per 4-B load (the block's base is a multiple of kSortChunk keys)
         const uint32_t *pairs = reinterpret_cast<const uint32_t *>(keys + base);
+        if (full) {
+            uint32_t kk[kSortItems / 2];
 #pragma unroll
-        for (int r = 0; r < kSortItems / 2; ++r) {
-            const int p = r * kSortThreads + threadIdx.x;
-            const long i = base + 2 * p;
-            if (i + 1 < n) {
-                const uint32_t kk = pairs[p];
-                atomicAdd(&h[((kk & 0xFFFFu) >> shift) & (kRadix - 1)], 1u);
-                atomicAdd(&h[((kk >> 16) >> shift) & (kRadix - 1)], 1u);
-            } else if (i < n) {
-                atomicAdd(&h[((uint32_t)keys[i] >> shift) & (kRadix - 1)], 1u);
+            for (int r = 0; r < kSortItems / 2; ++r) kk[r] = pairs[r * kSortThreads + threadIdx.x];
+#pragma unroll
+            for (int r = 0; r < kSortItems / 2; ++r) {
+                atomicAdd(&h[((kk[r] & 0xFFFFu) >> shift) & (kRadix - 1)], 1u);
+                atomicAdd(&h[((kk[r] >> 16) >> shift) & (kRadix - 1)], 1u);
             }
+        } else {
+#pragma unroll
+            for (int r = 0; r < kSortItems / 2; ++r) {
+                const int p = r * kSortThreads + threadIdx.x;
+                const long i = base + 2 * p;
+                if (i + 1 < n) {
+                    const uint32_t kk = pairs[p];
+                    atomicAdd(&h[((kk & 0xFFFFu) >> shift) & (kRadix - 1)], 1u);
+                    atomicAdd(&h[((kk >> 16) >> shift) & (kRadix - 1)], 1u);
+                } else if (i < n) {
+                    atomicAdd(&h[((uint32_t)keys[i] >> shift) & (kRadix - 1)], 1u);
+                }
+            }
+        }
+    } else if (full) {
+        uint32_t kk[kSortItems];
+#pragma unroll
+        for (int r = 0; r < kSortItems; ++r) kk[r] = (uint32_t)keys[base + r * kSortThreads + threadIdx.x];
+#pragma unroll
+        for (int r = 0; r < kSortItems; ++r) {
+            atomicAdd(&h[digit_of(kk[r], dg)], 1u);
+            if (kk[r] != 0xFFFFFFFFu) { lo = min(lo, kk[r]); hi = max(hi, kk[r]); }
         }
     } else {
 #pragma unroll
@@ -257,6 +282,16 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     if ((long)blockIdx.x * kSortChunk >= n) return;   // whole block beyond the live items (capacity launch)
     SORT_TRACE_BEGIN();
 
+    // (keys and values first: their latency hides behind the histogram columns and the two block scans)
+    const long base = (long)blockIdx.x * kSortChunk + wave * (kSortChunk / 4);
+    uint32_t k[kSortItems], v[kSortItems], rk[kSortItems];
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        long i = base + r * 64 + lane;
+        k[r] = i < n ? (uint32_t)keys_in[i] : 0xFFFFFFFFu;
+        v[r] = i < n ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
+    }
+
     {   // digit t: global base (exclusive scan of digit totals + offset of this block inside the digit) and
         // block-local base (exclusive scan of this block's own digit counts, recovered from the scanned rows)
         uint32_t tot, dt = digit_total[t];
@@ -271,15 +306,6 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
             wave_cnt[w][t] = 0;
             reinterpret_cast<unsigned long long *>(s_val)[w * kRadix + t] = 0ull;
         }
-    }
-
-    const long base = (long)blockIdx.x * kSortChunk + wave * (kSortChunk / 4);
-    uint32_t k[kSortItems], v[kSortItems], rk[kSortItems];
-#pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
-        long i = base + r * 64 + lane;
-        k[r] = i < n ? (uint32_t)keys_in[i] : 0xFFFFFFFFu;
-        v[r] = i < n ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
     }
     __syncthreads();
     SORT_TRACE_MARK(0);   // prologue: histogram columns, block scans, key / value loads
@@ -654,7 +680,8 @@ __global__ __launch_bounds__(kSortThreads) void emit_hist_kernel(int n, const ui
                                                                  const uint32_t *__restrict__ rects,
                                                                  const int32_t *__restrict__ block_owner, int tile_w,
                                                                  uint32_t m_cap, const uint32_t *__restrict__ m_dev,
-                                                                 int nblocks, uint32_t *__restrict__ hist) {
+                                                                 int nblocks, uint32_t *__restrict__ hist,
+                                                                 uint32_t low_mask) {
     __shared__ uint32_t scratch[4];
     __shared__ uint32_t h[kRadix];
     __shared__ __attribute__((aligned(16))) uint32_t s_own[kSortChunk];
@@ -672,7 +699,7 @@ __global__ __launch_bounds__(kSortThreads) void emit_hist_kernel(int n, const ui
         if (slot < eb.live) {
             uint32_t tile, gid = 0;
             emit_record<false>(eb, slot, s_own, s_g, offsets, rects, order, tile_w, tile, gid);
-            atomicAdd(&h[tile & (kRadix - 1)], 1u);
+            atomicAdd(&h[tile & low_mask], 1u);
         }
     }
     __syncthreads();
@@ -685,7 +712,7 @@ __global__ __launch_bounds__(kSortThreads) void emit_scatter_kernel(
     const int32_t *__restrict__ block_owner, int tile_w, uint32_t m_cap, const uint32_t *__restrict__ m_dev,
     uint16_t *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, int nblocks, const uint32_t *__restrict__ hist,
-    const uint32_t *__restrict__ digit_total) {
+    const uint32_t *__restrict__ digit_total, uint32_t low_mask) {
     __shared__ uint32_t scratch[4];
     __shared__ uint32_t gbase[kRadix];
     __shared__ uint32_t lexcl[kRadix];
@@ -735,7 +762,7 @@ __global__ __launch_bounds__(kSortThreads) void emit_scatter_kernel(
     unsigned long long *mask = reinterpret_cast<unsigned long long *>(s_val) + wave * kRadix;   // (zeroed above)
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r)
-        rk[r] = wave_rank_round(mask, cnt, k[r] & (kRadix - 1), wbase + r * 64 + lane < eb.live, lane);
+        rk[r] = wave_rank_round(mask, cnt, k[r] & low_mask, wbase + r * 64 + lane < eb.live, lane);
     __syncthreads();
     SORT_TRACE_MARK(3);   // ranking
     {
@@ -747,7 +774,7 @@ __global__ __launch_bounds__(kSortThreads) void emit_scatter_kernel(
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         if (wbase + r * 64 + lane < eb.live) {
-            const uint32_t lp = cnt[k[r] & (kRadix - 1)] + rk[r];
+            const uint32_t lp = cnt[k[r] & low_mask] + rk[r];
             s_key[lp] = (uint16_t)k[r];
             s_val[lp] = v[r];
         }
@@ -759,7 +786,7 @@ __global__ __launch_bounds__(kSortThreads) void emit_scatter_kernel(
         const uint32_t lp = r * kSortThreads + t;
         if (lp < eb.live) {
             const uint32_t key = s_key[lp];
-            const uint32_t d = key & (kRadix - 1);
+            const uint32_t d = key & low_mask;
             const uint32_t pos = gbase[d] + (lp - lexcl[d]);
             keys_out[pos] = (uint16_t)key;
             vals_out[pos] = s_val[lp];
@@ -1267,27 +1294,38 @@ extern "C" int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offs
                   GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(workspace_bytes < gsa_sort_workspace_bytes((int)m_capacity), GSA_ERR_WORKSPACE_TOO_SMALL);
     const bool two = n_tiles > kRadix;   // tile ids above 8 bits: a second (high-digit) pass
+    // Two passes split the id bits EVENLY (13 bits: 7 + 6, not 8 + 5): a block's 4096 records then leave the first
+    // pass in 128 runs of ~32 (full 128-B lines of values) instead of 256 runs of ~16, and the second pass still writes
+    // runs of 64+.
+    int id_bits = 0;
+    while ((1 << id_bits) < n_tiles) ++id_bits;
+    int low_bits = two ? (id_bits + 1) / 2 : 8;
+    if (const char *e = getenv("GSPLAT_AMD_TILE_LOW_BITS")) {   // (experiments: 8 = the former 8 + 5 split)
+        const int b = atoi(e);
+        if (two && b >= id_bits - 8 && b <= 8) low_bits = b;
+    }
+    const uint32_t low_mask = (1u << low_bits) - 1u;
     GSA_RETURN_IF(two && (!tile_tmp || !gid_tmp || (reinterpret_cast<uintptr_t>(tile_tmp) & 3) != 0),
                   GSA_ERR_INVALID_ARGUMENT);
     const int nblocks = sort_blocks((int)m_capacity);
     uint32_t *hist = static_cast<uint32_t *>(workspace);
     uint32_t *digit_total = hist + (size_t)kRadix * nblocks;
     emit_hist_kernel<<<nblocks, kSortThreads, 0, s>>>(n, order, offsets, rects, block_owner, tile_w, m_capacity, m_dev,
-                                                      nblocks, hist);
+                                                      nblocks, hist, low_mask);
     GSA_LAUNCH_CHECK();
     radix_scan_rows_kernel<<<kRadix, kSortThreads, 0, s>>>(nblocks, hist, digit_total);
     GSA_LAUNCH_CHECK();
     emit_scatter_kernel<<<nblocks, kSortThreads, 0, s>>>(n, order, offsets, rects, block_owner, tile_w, m_capacity, m_dev,
                                                          two ? tile_tmp : sorted_tile, two ? gid_tmp : sorted_gid,
-                                                         nblocks, hist, digit_total);
+                                                         nblocks, hist, digit_total, low_mask);
     GSA_LAUNCH_CHECK();
     if (two) {
-        radix_hist_kernel<uint16_t><<<nblocks, kSortThreads, 0, s>>>((int)m_capacity, m_dev, tile_tmp, RadixDigit{8, 0u, 0}, nblocks, hist, nullptr);
+        radix_hist_kernel<uint16_t><<<nblocks, kSortThreads, 0, s>>>((int)m_capacity, m_dev, tile_tmp, RadixDigit{low_bits, 0u, 0}, nblocks, hist, nullptr);
         GSA_LAUNCH_CHECK();
         radix_scan_rows_kernel<<<kRadix, kSortThreads, 0, s>>>(nblocks, hist, digit_total);
         GSA_LAUNCH_CHECK();
         radix_scatter_kernel<uint16_t><<<nblocks, kSortThreads, 0, s>>>((int)m_capacity, m_dev, tile_tmp, gid_tmp, sorted_tile,
-                                                                        sorted_gid, RadixDigit{8, 0u, 0}, nblocks, hist,
+                                                                        sorted_gid, RadixDigit{low_bits, 0u, 0}, nblocks, hist,
                                                                         digit_total);
         GSA_LAUNCH_CHECK();
     }

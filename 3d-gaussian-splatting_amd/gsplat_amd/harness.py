@@ -577,25 +577,27 @@ class ViewParallelTrainer:
                 side.wait_event(params_ready)
                 pose = view["pose"].to(torch.float32).contiguous()
                 W, H = view["width"], view["height"]
-                splat, radii, tiles, keys, rects = S.project_fwd(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4],
-                                                                 degree, pose, Kc, W, H, cull, return_rects=True)
+                splat, radii, tiles, keys, rects, aux = S.project_fwd(leaves[0], leaves[1], leaves[2], leaves[3],
+                                                                      leaves[4], degree, pose, Kc, W, H, cull,
+                                                                      return_rects=True, return_aux=True)
                 bins = S.bin_tiles(splat, radii, tiles, keys, W, H, cull, tile_rects=rects, exact=exact)
                 order = S.tile_schedule(bins.tile_offsets, W, H)
                 done = torch.cuda.Event()
                 done.record(side)
                 if side is not main:   # the sweep reads these on the main stream: keep their memory until it has
-                    for t in (pose, splat, radii, bins.sorted_gid_buffer, bins.tile_offsets, order):
-                        t.record_stream(main)
-            return pose, splat, radii, bins, order, done
+                    for t in (pose, splat, radii, bins.sorted_gid_buffer, bins.tile_offsets, order, aux):
+                        if t is not None:
+                            t.record_stream(main)
+            return pose, splat, radii, bins, order, done, aux
 
         mine = list(batch[self.rank::self.world])
         scale = self.loss_scale if self.amp else 1.0   # loss scale: the backward passes see v_render times it
         sums, first = [], True
         ahead = front(mine[0]) if mine else None
         for j, view in enumerate(mine):
-            pose, splat, radii, bins, order, done = ahead
+            pose, splat, radii, bins, order, done, aux = ahead
             if not bins.finalize()[1]:       # record capacity missed (the scene grew): bin again with exact sizes
-                pose, splat, radii, bins, order, done = front(view, exact=True)
+                pose, splat, radii, bins, order, done, aux = front(view, exact=True)
                 bins.finalize()
             ahead = front(mine[j + 1]) if j + 1 < len(mine) else None
             main.wait_event(done)
@@ -607,7 +609,7 @@ class ViewParallelTrainer:
                                       W, H, 3, order, quad_lists=lists)
             S.project_bwd(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], degree, pose, Kc, W, H, splat, radii,
                           v_splat, out=grad_out, accumulate=not first,
-                          v_rgb_out=vr_all[self.rank, j] if factored else None)
+                          v_rgb_out=vr_all[self.rank, j] if factored else None, sh_aux=aux)
             sums.append(s3 / float(v.numel()))            # -> l1, ssim, mse of this view
             first = False
         if first:                                          # this rank rendered nothing

@@ -33,16 +33,17 @@ class _RasterizeOneCamera(torch.autograd.Function):
         view_c, K_c = S.f32c(viewmat, "viewmats"), S.f32c(Kmat, "Ks")
         bg_c = None if background is None else S.f32c(background, "backgrounds")
 
-        splat, radii, tiles_touched, depth_keys, rects = S.project_fwd(means_c, quats_c, scales_c, opac_c, colors_c,
-                                                                       sh_degree, view_c, K_c, width, height, cull_mode,
-                                                                       return_rects=True)
+        # with a backward pass to come, the forward sweep also notes per 8x8 quadrant which records it blended (the
+        # reverse sweep then visits exactly those) and the projection leaves its 48-B digest of every coefficient row
+        want_lists = any(ctx.needs_input_grad[:5])
+        proj = S.project_fwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
+                             cull_mode, return_rects=True, return_aux=want_lists)
+        splat, radii, tiles_touched, depth_keys, rects = proj[:5]
+        sh_aux = proj[5] if want_lists else None
         # the host does not wait for the record count: bins are sized for a remembered capacity, the compositor is
         # queued, and only then is the count (long since copied back) checked -- a miss repeats with exact sizes
         bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, tile_rects=rects)
         tile_order = S.tile_schedule(bins.tile_offsets, width, height)   # longest record lists first (speed only)
-        # with a backward pass to come, the forward sweep also notes per 8x8 quadrant which records it blended: the
-        # reverse sweep then visits exactly those
-        want_lists = any(ctx.needs_input_grad[:5])
         out = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg_c, width, height, channels,
                               tile_order, want_lists=want_lists)
         if not bins.finalize()[1]:
@@ -56,7 +57,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
         sorted_tile, sorted_gid, tile_offsets = bins.sorted_tile, bins.sorted_gid, bins.tile_offsets
 
         ctx.save_for_backward(means_c, quats_c, scales_c, opac_c, colors_c, view_c, K_c, bg_c, splat, radii,
-                              sorted_gid, tile_offsets, final_T, last_id, tile_order, quad_list, quad_count)
+                              sorted_gid, tile_offsets, final_T, last_id, tile_order, quad_list, quad_count, sh_aux)
         ctx.dims = (width, height, sh_degree, channels)
         ctx.grad_out = grad_out
         ctx.grad_accumulate = bool(grad_accumulate)
@@ -70,7 +71,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_render, v_alpha, *unused):
         (means_c, quats_c, scales_c, opac_c, colors_c, view_c, K_c, bg_c, splat, radii, sorted_gid, tile_offsets,
-         final_T, last_id, tile_order, quad_list, quad_count) = ctx.saved_tensors
+         final_T, last_id, tile_order, quad_list, quad_count, sh_aux) = ctx.saved_tensors
         width, height, sh_degree, channels = ctx.dims
         if v_render is None:
             v_render = torch.zeros(height, width, channels, dtype=torch.float32, device=means_c.device)
@@ -81,7 +82,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
                                   quad_lists=None if quad_list is None else (quad_list, quad_count))
         grads = S.project_bwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
                               splat, radii, v_splat, out=ctx.grad_out, accumulate=ctx.grad_accumulate,
-                              v_rgb_out=ctx.sh_grad_factored)
+                              v_rgb_out=ctx.sh_grad_factored, sh_aux=sh_aux)
         if ctx.grad_accumulate:   # the sums live in the caller's buffers; autograd gets nothing to accumulate
             return (None,) * 16
         need = ctx.needs_input_grad

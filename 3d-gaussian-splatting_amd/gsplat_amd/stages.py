@@ -103,11 +103,19 @@ def _pinned_scalar(dev):
     return words[nxt], events[nxt]
 
 
+# GSPLAT_AMD_SH_AUX=1: project_fwd leaves its 48-B digest of every coefficient row and project_bwd reads that instead
+# of the 192-B row.  OFF by default: it cuts 96 MB of HBM traffic per 1 M gaussians, but with steps back to back the
+# next project_fwd finds half of the rows the previous project_bwd streamed still in the 256-MB memory-side cache --
+# without those reads it runs cold (measured at 1 M / 1080p: fwd 0.072 -> 0.102 ms, bwd 0.095 -> 0.088 ms).
+_SH_AUX = os.environ.get("GSPLAT_AMD_SH_AUX", "0") == "1"
+
+
 def project_fwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat, Kmat, width: int, height: int,
-                cull_mode: int = 0, return_rects: bool = False):
+                cull_mode: int = 0, return_rects: bool = False, return_aux: bool = False):
     """-> splat [N,16], radii [N,2] i32, tiles_touched [N] i32, depth_keys [N] (uint32 bits in int32 storage)
     [, tile_rects [N,2] i32: (packed tile rectangle, record count) pairs the fused binning reads, with
-    ``return_rects``]."""
+    ``return_rects``] [, sh_aux [N,12] f32 or None (sh_degree < 1): the 48-B digest of each coefficient row that lets
+    ``project_bwd`` skip the rows, with ``return_aux``]."""
     dev, N = means.device, means.shape[0]
     sh_coeffs = colors.shape[1] if sh_degree >= 0 else 0
     splat = torch.empty(N, SPLAT_STRIDE, dtype=torch.float32, device=dev)
@@ -115,12 +123,16 @@ def project_fwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat
     tiles_touched = torch.empty(N, dtype=torch.int32, device=dev)
     depth_keys = torch.empty(N, dtype=torch.int32, device=dev)
     tile_rects = torch.empty(N, 2, dtype=torch.int32, device=dev) if return_rects else None
+    sh_aux = torch.empty(N, 12, dtype=torch.float32, device=dev) if (return_aux and sh_degree >= 1 and _SH_AUX) else None
     _call("gsa_project_fwd", lib.gsa_project_fwd, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
           _ptr(colors), sh_degree, sh_coeffs, _ptr(viewmat), _ptr(Kmat), width, height, cull_mode, _ptr(splat),
-          _ptr(radii), _ptr(tiles_touched), _ptr(depth_keys), _ptr(tile_rects), _stream())
+          _ptr(radii), _ptr(tiles_touched), _ptr(depth_keys), _ptr(tile_rects), _ptr(sh_aux), _stream())
+    out = (splat, radii, tiles_touched, depth_keys)
     if return_rects:
-        return splat, radii, tiles_touched, depth_keys, tile_rects
-    return splat, radii, tiles_touched, depth_keys
+        out += (tile_rects,)
+    if return_aux:
+        out += (sh_aux,)
+    return out
 
 
 def sort_pairs(n: int, keys: torch.Tensor, vals: Optional[torch.Tensor], begin_bit: int, end_bit: int):
@@ -490,9 +502,10 @@ def composite_bwd(splat, sorted_gid, tile_offsets, background, final_T, last_id,
 
 
 def project_bwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat, Kmat, width: int, height: int,
-                splat, radii, v_splat, out=None, accumulate: bool = False, v_rgb_out=None):
+                splat, radii, v_splat, out=None, accumulate: bool = False, v_rgb_out=None, sh_aux=None):
     """-> v_means, v_quats, v_scales, v_opacities, v_colors (every element written).  ``out``: five preallocated
-    contiguous fp32 tensors to write into instead (e.g. views of one flat all-reduce bucket)."""
+    contiguous fp32 tensors to write into instead (e.g. views of one flat all-reduce bucket).  ``sh_aux``: the digest
+    ``project_fwd(return_aux=True)`` left for this view (the coefficient rows are then not read)."""
     N = means.shape[0]
     sh_coeffs = colors.shape[1] if sh_degree >= 0 else 0
     if out is None:
@@ -506,6 +519,9 @@ def project_bwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat
                 raise ValueError("grad_out tensors must be contiguous fp32, sized like the inputs, on their device")
     if accumulate and out is None:
         raise ValueError("project_bwd(accumulate=True) needs the `out` buffers it adds to")
+    if sh_aux is not None and (sh_aux.shape != (N, 12) or sh_aux.dtype != torch.float32 or not sh_aux.is_contiguous()
+                               or sh_aux.device != means.device):
+        raise ValueError("sh_aux must be the contiguous fp32 [N,12] tensor project_fwd returned")
     if v_rgb_out is not None:
         # factored form: d loss / d rgb [N,3] instead of the [N,K,3] coefficient gradient (v_colors is not written)
         if v_rgb_out.shape != (N, 3) or v_rgb_out.dtype != torch.float32 or not v_rgb_out.is_contiguous():
@@ -513,12 +529,12 @@ def project_bwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat
         _call("gsa_project_bwd", lib.gsa_project_bwd_factored, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
               _ptr(colors), sh_degree, sh_coeffs, _ptr(viewmat), _ptr(Kmat), width, height, _ptr(splat), _ptr(radii),
               _ptr(v_splat), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac), _ptr(v_rgb_out),
-              1 if accumulate else 0, _stream())
+              1 if accumulate else 0, _ptr(sh_aux), _stream())
         return v_means, v_quats, v_scales, v_opac, None
     _call("gsa_project_bwd", lib.gsa_project_bwd_acc, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
           _ptr(colors), sh_degree, sh_coeffs, _ptr(viewmat), _ptr(Kmat), width, height, _ptr(splat), _ptr(radii),
           _ptr(v_splat), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac), _ptr(v_colors),
-          1 if accumulate else 0, _stream())
+          1 if accumulate else 0, _ptr(sh_aux), _stream())
     return v_means, v_quats, v_scales, v_opac, v_colors
 
 

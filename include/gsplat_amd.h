@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSA_ABI_VERSION 5
+#define GSA_ABI_VERSION 6
 #define GSA_SPLAT_STRIDE 16
 
 #define GSA_OK 0
@@ -75,12 +75,16 @@ const char *gsa_error_string(int code);
  *          as x0 | y0 << 10 | width << 20 (what record word 11 holds; 0 without records or for tile grids of 1024+
  *          tiles a side) and the record count (== tiles_touched) -- the dense input of the fused binning
  *          (gsa_scan_tiles_rect).
+ *          sh_aux[N,12] float (optional, may be NULL; 16-byte aligned; written for sh_degree >= 1, zero rows for
+ *          culled gaussians): what stage 5 needs of the 192-B coefficient row, in 48 B -- per colour channel
+ *          d colour / d mean through the view direction (x, y, z) and the clamp flag (1 = the channel was not clamped
+ *          at 0).  Handed to gsa_project_bwd*, it spares that stage the coefficient rows.
  */
 int gsa_project_fwd(int n, const float *means, const float *quats, const float *scales,
                     const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
                     const float *viewmat, const float *intrin, int width, int height, int cull_mode,
                     float *splat, int32_t *radii, int32_t *tiles_touched, uint32_t *depth_keys,
-                    uint32_t *tile_rects, gsa_stream_t stream);
+                    uint32_t *tile_rects, float *sh_aux, gsa_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stage 2 (row a3.3): tile binning.  Replaces gsplat's isect_tiles + 64-bit radix sort +
@@ -234,14 +238,16 @@ int gsa_composite_bwd_lists(int width, int height, int channels, const float *sp
  * parameters and the saved radii; writes EVERY element of v_means[N,3], v_quats[N,4], v_scales[N,3],
  * v_opacities[N] and v_colors (same shape as colors; zeros above the active degree and for
  * culled gaussians).  `splat` is not read (the projection is recomputed, the colour clamp mask re-derived);
- * it stays in the signature and may be NULL.
+ * it stays in the signature and may be NULL.  sh_aux (may be NULL): the [N,12] digest gsa_project_fwd left for THIS
+ * view and these parameters; with it `colors` is not read for sh_degree >= 1 (same gradients to rounding: the
+ * direction term is summed per channel first instead of per basis function first).
  */
 int gsa_project_bwd(int n, const float *means, const float *quats, const float *scales,
                     const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
                     const float *viewmat, const float *intrin, int width, int height,
                     const float *splat, const int32_t *radii, const float *v_splat, float *v_means,
                     float *v_quats, float *v_scales, float *v_opacities, float *v_colors,
-                    gsa_stream_t stream);
+                    const float *sh_aux, gsa_stream_t stream);
 
 /* The same with `accumulate` != 0: ADD to what the five output buffers hold (which must then be fully initialised)
  * instead of overwriting them -- the views of a batch sum into one gradient bucket without a separate pass. */
@@ -250,7 +256,7 @@ int gsa_project_bwd_acc(int n, const float *means, const float *quats, const flo
                         const float *viewmat, const float *intrin, int width, int height,
                         const float *splat, const int32_t *radii, const float *v_splat, float *v_means,
                         float *v_quats, float *v_scales, float *v_opacities, float *v_colors,
-                        int accumulate, gsa_stream_t stream);
+                        int accumulate, const float *sh_aux, gsa_stream_t stream);
 
 /* Factored colour gradient for the view-parallel exchange.  The SH-coefficient gradient of one view is the outer
  * product  v_colors[g][k][c] = basis_k(dir(g, view)) * v_rgb[g][c]  (48 of the 59 gradient floats per gaussian), and every
@@ -263,7 +269,7 @@ int gsa_project_bwd_factored(int n, const float *means, const float *quats, cons
                              const float *viewmat, const float *intrin, int width, int height,
                              const float *splat, const int32_t *radii, const float *v_splat, float *v_means,
                              float *v_quats, float *v_scales, float *v_opacities, float *v_rgb,
-                             int accumulate, gsa_stream_t stream);
+                             int accumulate, const float *sh_aux, gsa_stream_t stream);
 int gsa_sh_grad_expand(int n, const float *means, int sh_degree, int sh_coeffs, int n_views,
                        const float *viewmats, const float *intrin, const float *v_rgb, float *v_colors,
                        int accumulate, gsa_stream_t stream);

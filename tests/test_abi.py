@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(raw, n), f"{n} declared in gsplat_amd.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes binding and header disagree"
-    assert gsplat_amd.lib.gsa_abi_version() == gsplat_amd.ABI_VERSION == 5
+    assert gsplat_amd.lib.gsa_abi_version() == gsplat_amd.ABI_VERSION == 6
 
 
 def test_header_cites_reference_boundary():
@@ -41,9 +41,9 @@ def test_error_codes_and_strings():
     assert b"invalid" in lib.gsa_error_string(-1)
     assert b"workspace" in lib.gsa_error_string(-2)
     # argument validation happens on the host before any launch
-    assert lib.gsa_project_fwd(-1, None, None, None, None, None, 3, 16, None, None, 64, 64, 0, None, None, None, None, None, None) == -1
-    assert lib.gsa_project_fwd(10, None, None, None, None, None, 3, 16, None, None, 64, 64, 0, None, None, None, None, None, None) == -1
-    assert lib.gsa_project_fwd(10, None, None, None, None, None, 7, 16, None, None, 64, 64, 0, None, None, None, None, None, None) == -1
+    assert lib.gsa_project_fwd(-1, None, None, None, None, None, 3, 16, None, None, 64, 64, 0, None, None, None, None, None, None, None) == -1
+    assert lib.gsa_project_fwd(10, None, None, None, None, None, 3, 16, None, None, 64, 64, 0, None, None, None, None, None, None, None) == -1
+    assert lib.gsa_project_fwd(10, None, None, None, None, None, 7, 16, None, None, 64, 64, 0, None, None, None, None, None, None, None) == -1
     assert lib.gsa_composite_fwd(64, 64, 5, None, None, None, None, None, None, None, None, None, None, None, None) == -1
     assert lib.gsa_tile_schedule(0, None, None, None) == -1
     assert lib.gsa_sort_pairs_u32(16, None, None, None, None, None, None, 0, 40, None, 0, None) == -1

@@ -255,10 +255,13 @@ def test_stage_composite_fwd_bwd(gsa, W, H, N, cull_mode, with_bg):
         assert int((last >= 0).sum()) > 0.9 * W * H
 
 
+@pytest.mark.parametrize("aux", [False, True])
 @pytest.mark.parametrize("deg", [None, 0, 1, 2, 3])
-def test_stage_project_bwd(gsa, deg):
+def test_stage_project_bwd(gsa, deg, aux):
     """Projection + SH backward alone (row a3.6): HIP vs autograd through oracle.project / sh_colors for the
-    same record gradient, fp64-calibrated (the conic VJP shares the determinant cancellation of the forward)."""
+    same record gradient, fp64-calibrated (the conic VJP shares the determinant cancellation of the forward).
+    aux: with the forward's 48-B digest of the coefficient rows (the rows themselves are then not read; handed NaN
+    rows here to prove it)."""
     from gsplat_amd import scene, stages as S
     from oracle import torch_oracle as orc
     W, H, N = 320, 200, 8000
@@ -268,7 +271,8 @@ def test_stage_project_bwd(gsa, deg):
     colors_d = d["shs"] if deg is not None else (d["shs"][:, 0, :] * 0.28 + 0.5).contiguous()
     hdeg = -1 if deg is None else deg
     args = (d["means3D"], d["rotations"], d["scales"], d["opacities"][:, 0].contiguous(), colors_d)
-    splat, radii, _, _ = S.project_fwd(*args, hdeg, vm.cuda(), K.cuda(), W, H, 0)
+    splat, radii, _, _, sh_aux = S.project_fwd(*args, hdeg, vm.cuda(), K.cuda(), W, H, 0, return_aux=True)
+    assert (sh_aux is None) == (hdeg < 1)
     vis = (radii > 0).all(-1).cpu()
     g = torch.Generator().manual_seed(3)
     v = torch.randn(N, 16, generator=g)
@@ -277,7 +281,19 @@ def test_stage_project_bwd(gsa, deg):
     # project_bwd consumes the sweep's raw moments: hand it the moments whose implied record gradient is v
     mom = S.record_grads_to_moments(splat.double().cpu(), v.double()).float()
     mom[~vis] = 0
-    got = S.project_bwd(*args, hdeg, vm.cuda(), K.cuda(), W, H, splat, radii, mom.cuda())
+    if aux and sh_aux is not None:
+        poisoned = args[:4] + (torch.full_like(colors_d, float("nan")),)
+        got = S.project_bwd(*poisoned, hdeg, vm.cuda(), K.cuda(), W, H, splat, radii, mom.cuda(), sh_aux=sh_aux)
+        v_rgb = torch.empty(N, 3, device="cuda")
+        fact = S.project_bwd(*poisoned, hdeg, vm.cuda(), K.cuda(), W, H, splat, radii, mom.cuda(), v_rgb_out=v_rgb,
+                             sh_aux=sh_aux)
+        v_rgb0 = torch.empty(N, 3, device="cuda")
+        fact0 = S.project_bwd(*args, hdeg, vm.cuda(), K.cuda(), W, H, splat, radii, mom.cuda(), v_rgb_out=v_rgb0)
+        assert torch.equal(v_rgb, v_rgb0)                              # same clamp flags, same d loss / d rgb
+        for a, b, c in zip(fact[:4], fact0[:4], got[:4]):
+            assert _rel(a, c) < 1e-6 and _rel(a, b) < 1e-5                # factored == full; digest == rows to rounding
+    else:
+        got = S.project_bwd(*args, hdeg, vm.cuda(), K.cuda(), W, H, splat, radii, mom.cuda())
 
     def oracle(dtype):
         leaves = [sc[k].to(dtype).clone().requires_grad_(True) for k in NAMES]
