@@ -23,17 +23,14 @@ constexpr int kBlock = GSA_PROJ_BLOCK;
 #ifndef GSA_PROJ_FWD_REVERSE
 #define GSA_PROJ_FWD_REVERSE 1
 #endif
+#ifndef GSA_PROJ_BWD_WAVES
+#define GSA_PROJ_BWD_WAVES 4   // the backward kernel's register budget: 128 VGPRs, four waves a SIMD (LDS allows five)
+#endif
 #ifndef GSA_PROJ_FWD_WAVES
 #define GSA_PROJ_FWD_WAVES 1   // minimum waves per SIMD the forward kernel is compiled for (register budget)
 #endif
 constexpr int kRowQ = 12;      // float4 per [16,3] SH row
-constexpr int kRowQPad = 13;   // padded LDS row (52 floats): conflict-free ds_read_b128 across lanes
-// Half-row staging (forward; backward with the digest): a wave moves its 64 rows through LDS in two column halves of at
-// most 6 float4, rows padded to 7 (28 dwords: 16 consecutive lanes start in 16 different 4-bank groups).  28 KB per
-// 256-thread block instead of 52: five blocks a CU fit where three did, and these kernels wait on memory.
-constexpr int kHalfQ = 6, kHalfPad = 7;
-
-// Every wave stages and reads back ONLY its own 64 rows of the LDS image, so no workgroup barrier is needed: LDS
+// Every wave stages and reads back ONLY its own rows of the LDS image, so no workgroup barrier is needed: LDS
 // operations of one wave complete in order; the fences keep the compiler from reordering across the hand-over.
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -46,25 +43,63 @@ __host__ __device__ constexpr int sh_needed_q() {  // float4 per row that hold t
     return DEG < 0 ? 0 : (3 * (DEG + 1) * (DEG + 1) + 3) / 4;
 }
 
-// One column half (HW float4 columns starting at column OFF) of a wave's 64 coefficient rows, from the registers the
-// whole-wave loads filled (stg) through the wave's LDS image into row-per-lane order (c).  All indices are compile-time
-// constants: a dynamically indexed stg / c would be demoted to scratch memory.
-template <int OFF, int HW, int NQ, int NC>
-__device__ __forceinline__ void half_rows_to_lanes(float4 *wrows, int lane, const float (&stg)[4 * NQ], float (&c)[NC]) {
+// Row staging: a wave moves its 64 coefficient rows through LDS in two passes of 32 WHOLE rows (rows padded to 13
+// float4 = 52 dwords: 16 consecutive lanes start in 16 different 4-bank groups), so every global access is a run of
+// whole 128-B lines (column halves were tried: the 96-B row segments they write cost the gradient store a quarter of
+// its speed).  26 KB per 256-thread block instead of 52 for all 64 rows at once: five blocks a CU fit, not three.
+constexpr int kPassRows = 32, kRowPad = 13;
+constexpr int kWaveLds = kPassRows * kRowPad;   // float4 per wave
+template <int NQ>
+__host__ __device__ constexpr int row_loads_per_lane() { return (kPassRows * NQ + 63) / 64; }   // per pass
+
+// All of a wave's row loads, issued together (two passes x NPL whole-wave loads of consecutive float4; the row index
+// is CLAMPED to the wave's last live row instead of predicated: predicated loads compile to one branch +
+// s_waitcnt vmcnt(0) each, i.e. a dozen serial memory round trips).  stg is a plain float array with compile-time
+// indices only: an array of float4 this size, or any dynamic index, is demoted to scratch memory.
+template <int NQ>
+__device__ __forceinline__ void issue_row_loads(const float4 *__restrict__ src_wave, int last_row, int lane,
+                                                float (&stg)[8 * row_loads_per_lane<NQ>()]) {
+    constexpr int NPL = row_loads_per_lane<NQ>();
 #pragma unroll
-    for (int k = 0; k < HW; ++k) {
-        const int idx = k * 64 + lane, row = idx / HW, col = idx - row * HW;
-        wrows[row * kHalfPad + col] = make_float4(stg[4 * (OFF + k)], stg[4 * (OFF + k) + 1], stg[4 * (OFF + k) + 2],
-                                                  stg[4 * (OFF + k) + 3]);
-    }
-    wave_lds_sync();
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
-    for (int k = 0; k < HW; ++k) {
-        const float4 v = wrows[lane * kHalfPad + k];
-        if (4 * (OFF + k) + 0 < NC) c[4 * (OFF + k) + 0] = v.x;
-        if (4 * (OFF + k) + 1 < NC) c[4 * (OFF + k) + 1] = v.y;
-        if (4 * (OFF + k) + 2 < NC) c[4 * (OFF + k) + 2] = v.z;
-        if (4 * (OFF + k) + 3 < NC) c[4 * (OFF + k) + 3] = v.w;
+        for (int k = 0; k < NPL; ++k) {
+            const int idx = min(k * 64 + lane, kPassRows * NQ - 1);
+            const int row = min(p * kPassRows + idx / NQ, last_row), col = idx % NQ;
+            const float4 v = src_wave[row * kRowQ + col];
+            const int o = 4 * (p * NPL + k);
+            stg[o] = v.x; stg[o + 1] = v.y; stg[o + 2] = v.z; stg[o + 3] = v.w;
+        }
+}
+
+// ... and through the wave's LDS image into row-per-lane order: lane l ends up with row l in c (every lane takes part;
+// a wave only touches its own image, so no workgroup barrier).
+template <int NQ, int NC>
+__device__ __forceinline__ void rows_to_lanes(float4 *wrows, int lane, const float (&stg)[8 * row_loads_per_lane<NQ>()],
+                                              float (&c)[NC]) {
+    constexpr int NPL = row_loads_per_lane<NQ>();
+#pragma unroll
+    for (int k = 0; k < NC; ++k) c[k] = 0.f;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if (p == 1) wave_lds_sync();   // the first 32 lanes have read their rows
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const int idx = k * 64 + lane, o = 4 * (p * NPL + k);
+            if (idx < kPassRows * NQ)
+                wrows[(idx / NQ) * kRowPad + idx % NQ] = make_float4(stg[o], stg[o + 1], stg[o + 2], stg[o + 3]);
+        }
+        wave_lds_sync();
+        if ((lane >> 5) == p) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const float4 v = wrows[(lane & 31) * kRowPad + q];
+                if (4 * q + 0 < NC) c[4 * q + 0] = v.x;
+                if (4 * q + 1 < NC) c[4 * q + 1] = v.y;
+                if (4 * q + 2 < NC) c[4 * q + 2] = v.z;
+                if (4 * q + 3 < NC) c[4 * q + 3] = v.w;
+            }
+        }
     }
 }
 
@@ -79,7 +114,7 @@ __global__ __launch_bounds__(kBlock, GSA_PROJ_FWD_WAVES) void project_fwd_kernel
     int tile_h, int cull_mode, float *__restrict__ splat, int32_t *__restrict__ radii,
     int32_t *__restrict__ tiles_touched, uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ tile_rects,
     float *__restrict__ sh_aux) {
-    __shared__ float4 sh_lds[STAGE ? kBlock * kHalfPad : 1];
+    __shared__ float4 sh_lds[STAGE ? (kBlock / 64) * kWaveLds : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Blocks walk the gaussians from the LAST to the first (GSA_PROJ_FWD_REVERSE): the kernel that ran before this one in
     // a training loop is the previous view's project_bwd, which streamed the same parameter arrays front to back -- the
@@ -99,29 +134,15 @@ __global__ __launch_bounds__(kBlock, GSA_PROJ_FWD_WAVES) void project_fwd_kernel
         g_opac = opacities[i];
     }
 
-    // SH rows: all of the wave's loads are issued now (two column halves, each a set of whole-wave loads of 96-B row
-    // segments); they pass through LDS half by half further down, when the coefficients are needed
+    // SH rows: all of the wave's loads are issued now; they pass through LDS further down, when the coefficients are
+    // needed
     constexpr int NQ = sh_needed_q<DEG>();
-    constexpr int H0 = NQ < kHalfQ ? NQ : kHalfQ, H1 = NQ - H0;   // float4 columns of the two halves
-    float stg[(STAGE && DEG >= 1) ? 4 * NQ : 4];   // (plain floats: an array of float4 this size is demoted to scratch)
-    if constexpr (STAGE && DEG >= 1) {
-        // (row indices are CLAMPED to the wave's last row instead of predicated: predicated loads compile to one
-        // branch + s_waitcnt vmcnt(0) each, i.e. twelve serial memory round trips)
+    constexpr bool ROWS_IN = STAGE && DEG >= 1;
+    float stg[ROWS_IN ? 8 * row_loads_per_lane<NQ>() : 8];
+    if constexpr (ROWS_IN) {
         const long wave_base = min(blk * kBlock + wave * 64, (long)n - 1);
         const int last = (int)min((long)63, (long)n - 1 - wave_base);
-        const float4 *src = reinterpret_cast<const float4 *>(colors) + wave_base * kRowQ;
-#pragma unroll
-        for (int k = 0; k < H0; ++k) {
-            const int idx = k * 64 + lane, row = min(idx / H0, last), col = idx % H0;
-            const float4 v = src[row * kRowQ + col];
-            stg[4 * k] = v.x; stg[4 * k + 1] = v.y; stg[4 * k + 2] = v.z; stg[4 * k + 3] = v.w;
-        }
-#pragma unroll
-        for (int k = 0; k < H1; ++k) {
-            const int idx = k * 64 + lane, row = min(idx / (H1 > 0 ? H1 : 1), last), col = idx % (H1 > 0 ? H1 : 1);
-            const float4 v = src[row * kRowQ + H0 + col];
-            stg[4 * (H0 + k)] = v.x; stg[4 * (H0 + k) + 1] = v.y; stg[4 * (H0 + k) + 2] = v.z; stg[4 * (H0 + k) + 3] = v.w;
-        }
+        issue_row_loads<NQ>(reinterpret_cast<const float4 *>(colors) + wave_base * kRowQ, last, lane, stg);
     }
     const bool inside = i < n;   // lanes beyond n stay for the wave-cooperative record store below
 
@@ -142,14 +163,7 @@ __global__ __launch_bounds__(kBlock, GSA_PROJ_FWD_WAVES) void project_fwd_kernel
     // part, visible or not; a wave only touches its own 64 rows, so no workgroup barrier)
     constexpr int NC = DEG < 0 ? 1 : 3 * (DEG + 1) * (DEG + 1);
     float c[NC];
-    if constexpr (STAGE && DEG >= 1) {
-        float4 *wrows = &sh_lds[(wave * 64) * kHalfPad];
-        half_rows_to_lanes<0, H0, NQ, NC>(wrows, lane, stg, c);
-        if constexpr (H1 > 0) {
-            wave_lds_sync();   // every lane has read its first half
-            half_rows_to_lanes<H0, H1, NQ, NC>(wrows, lane, stg, c);
-        }
-    }
+    if constexpr (ROWS_IN) rows_to_lanes<NQ, NC>(&sh_lds[wave * kWaveLds], lane, stg, c);
 
     // what a culled gaussian leaves: a zero record, zero radii / count, the largest depth key
     float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0, o2 = o0;
@@ -167,7 +181,7 @@ __global__ __launch_bounds__(kBlock, GSA_PROJ_FWD_WAVES) void project_fwd_kernel
         float inv = rsqrtf(dx * dx + dy * dy + dz * dz);
         float B[NB];
         gsa_sh_basis<DEG>(dx * inv, dy * inv, dz * inv, B);
-        if constexpr (!(STAGE && DEG >= 1)) {
+        if constexpr (!ROWS_IN) {
             const float *row = colors + i * (long)sh_coeffs * 3;
 #pragma unroll
             for (int k = 0; k < NB * 3; ++k) c[k] = row[k];
@@ -231,7 +245,7 @@ __global__ __launch_bounds__(kBlock, GSA_PROJ_FWD_WAVES) void project_fwd_kernel
     if constexpr (STAGE && DEG >= 1) {
         const long wave_base = blk * kBlock + wave * 64;
         const int rows = (int)min((long)64, (long)n - wave_base);
-        float4 *wl = &sh_lds[(wave * 64) * kHalfPad];
+        float4 *wl = &sh_lds[wave * kWaveLds];
         wave_lds_sync();   // every lane has read its SH row
         wl[lane * 4 + 0] = o0; wl[lane * 4 + 1] = o1; wl[lane * 4 + 2] = o2; wl[lane * 4 + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
         wave_lds_sync();
@@ -276,7 +290,7 @@ __global__ __launch_bounds__(kBlock, GSA_PROJ_FWD_WAVES) void project_fwd_kernel
 // backward (A.7)
 // ------------------------------------------------------------------------------------------------
 template <int DEG, bool STAGE, bool FACTORED, bool AUX>
-__global__ __launch_bounds__(kBlock) void project_bwd_kernel(
+__global__ __launch_bounds__(kBlock, GSA_PROJ_BWD_WAVES) void project_bwd_kernel(
     int n, const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
     const float *__restrict__ opacities, const float *__restrict__ colors, int sh_coeffs,
     const float *__restrict__ viewmat, const float *__restrict__ intrin, int width, int height,
@@ -290,7 +304,7 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
     // v_rgb_out (optional, [N,3]): FACTORED colour gradient -- instead of the [N,K,3] SH-coefficient gradient
     // (v_colors, then unused) write only d loss / d rgb after the clamp mask.  The SH gradient is the outer product of
     // the view's SH basis with it (gsa_sh_grad_expand), so 3 floats per gaussian carry what 48 would.
-    __shared__ float4 sh_lds[!STAGE || (AUX && FACTORED) ? 1 : kBlock * (AUX ? kHalfPad : kRowQPad)];
+    __shared__ float4 sh_lds[STAGE && ((DEG >= 1 && !AUX) || !FACTORED) ? (kBlock / 64) * kWaveLds : 1];   // rows in, rows out
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long i = (long)blockIdx.x * kBlock + threadIdx.x;
     const long wave_base = (long)blockIdx.x * kBlock + wave * 64;
@@ -319,43 +333,101 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
             g_aux[0] = arow[0]; g_aux[1] = arow[1]; g_aux[2] = arow[2];
         }
     }
-    if constexpr (AUX) {
-        // Every load above is issued HERE, together: left alone the compiler sinks all but the radii below the
-        // visibility test (they are only used there), which makes two dependent memory round trips out of one.
-        asm volatile("" : "+v"(g_mean[0]), "+v"(g_scale[0]), "+v"(g_quat[0]), "+v"(g_v0.x), "+v"(g_v1.x), "+v"(g_v2.x),
-                          "+v"(g_opac), "+v"(g_aux[0].x), "+v"(g_aux[1].x), "+v"(g_aux[2].x), "+v"(g_rx));
-    }
-
-    if constexpr (STAGE && DEG >= 1 && !AUX) {
-        constexpr int NQ = sh_needed_q<DEG>();
-        // (source rows clamped, not predicated -- see the forward kernel: all loads of the wave in flight at once)
+    // SH rows (staged, without the forward's digest): the wave's loads are issued now, in two column halves (see the
+    // forward kernel), and pass through LDS below
+    constexpr int NQ = sh_needed_q<DEG>();
+    constexpr bool ROWS_IN = STAGE && DEG >= 1 && !AUX;
+    float stg[ROWS_IN ? 8 * row_loads_per_lane<NQ>() : 8];
+    if constexpr (ROWS_IN) {
         const long src_base = min(wave_base, (long)n - 1);
         const int last = (int)min((long)63, (long)n - 1 - src_base);
-        const float4 *src = reinterpret_cast<const float4 *>(colors) + src_base * kRowQ;
-        float4 tmp[NQ];
-#pragma unroll
-        for (int k = 0; k < NQ; ++k) {
-            const int idx = k * 64 + lane, row = idx / NQ, col = idx - row * NQ;
-            tmp[k] = src[min(row, last) * kRowQ + col];
-        }
-#pragma unroll
-        for (int k = 0; k < NQ; ++k) {
-            const int idx = k * 64 + lane, row = idx / NQ, col = idx - row * NQ;
-            sh_lds[(wave * 64 + row) * kRowQPad + col] = tmp[k];
-        }
-        wave_lds_sync();
+        issue_row_loads<NQ>(reinterpret_cast<const float4 *>(colors) + src_base * kRowQ, last, lane, stg);
     }
+    // Every per-gaussian load above is issued HERE, together: left alone the compiler sinks all but the radii below the
+    // visibility test (they are only used there), which makes two dependent memory round trips out of one.
+    if constexpr (AUX)
+        asm volatile("" : "+v"(g_mean[0]), "+v"(g_scale[0]), "+v"(g_quat[0]), "+v"(g_v0.x), "+v"(g_v1.x), "+v"(g_v2.x),
+                          "+v"(g_opac), "+v"(g_aux[0].x), "+v"(g_aux[1].x), "+v"(g_aux[2].x), "+v"(g_rx));
+    else
+        asm volatile("" : "+v"(g_mean[0]), "+v"(g_scale[0]), "+v"(g_quat[0]), "+v"(g_v0.x), "+v"(g_v1.x), "+v"(g_v2.x),
+                          "+v"(g_opac), "+v"(g_rx));
+
+    constexpr int NC = DEG < 0 ? 1 : 3 * (DEG + 1) * (DEG + 1);
+    float cf[NC];
+    if constexpr (ROWS_IN) rows_to_lanes<NQ, NC>(&sh_lds[wave * kWaveLds], lane, stg, cf);
 
     bool visible = active && g_rx > 0 && g_ry > 0;
     float vm[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f}, vo = 0.f;
-    float vc[NB * 3], vr_keep[3] = {0.f, 0.f, 0.f};
+    float vc[NB * 3], vr_keep[3] = {0.f, 0.f, 0.f};   // (vc: only the unstaged path keeps the whole row in registers)
+    float ud[3] = {0.f, 0.f, 0.f};   // unit view direction (the staged output re-evaluates the SH basis from it: 3 live
+                                     // registers across the projection chain instead of 16)
 #pragma unroll
     for (int k = 0; k < NB * 3; ++k) vc[k] = 0.f;
 
     if (visible) {
         GsaCamera cam = gsa_load_camera(viewmat, intrin);
-        GsaProj p = gsa_project_one(cam, g_mean, g_quat, g_scale, width, height);
         const float4 v0 = g_v0, v1 = g_v1, v2 = g_v2;
+        float v_rgb[3] = {v1.z, v1.w, v2.x};
+        // ---- colour FIRST: the coefficient row (48 registers) is dead before the projection chain needs its own
+        float vdir[3] = {0.f, 0.f, 0.f};   // d loss / d mean through the view direction
+        if constexpr (DEG < 0) {
+            vc[0] = v_rgb[0]; vc[1] = v_rgb[1]; vc[2] = v_rgb[2];
+        } else {
+            float dx = g_mean[0] - cam.campos[0], dy = g_mean[1] - cam.campos[1], dz = g_mean[2] - cam.campos[2];
+            float inv = rsqrtf(dx * dx + dy * dy + dz * dz);
+            float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+            ud[0] = ux; ud[1] = uy; ud[2] = uz;
+            float B[NB];
+            gsa_sh_basis<DEG>(ux, uy, uz, B);
+            if constexpr (AUX) {
+                float vr[3] = {g_aux[0].w != 0.f ? v_rgb[0] : 0.f, g_aux[1].w != 0.f ? v_rgb[1] : 0.f,
+                               g_aux[2].w != 0.f ? v_rgb[2] : 0.f};
+                vr_keep[0] = vr[0]; vr_keep[1] = vr[1]; vr_keep[2] = vr[2];
+                if constexpr (!FACTORED && !STAGE) {
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        vc[3 * j] = B[j] * vr[0]; vc[3 * j + 1] = B[j] * vr[1]; vc[3 * j + 2] = B[j] * vr[2];
+                    }
+                }
+                vdir[0] += g_aux[0].x * vr[0] + g_aux[1].x * vr[1] + g_aux[2].x * vr[2];
+                vdir[1] += g_aux[0].y * vr[0] + g_aux[1].y * vr[1] + g_aux[2].y * vr[2];
+                vdir[2] += g_aux[0].z * vr[0] + g_aux[1].z * vr[1] + g_aux[2].z * vr[2];
+            } else {
+            if constexpr (!ROWS_IN) {
+                const float *row = colors + i * (long)sh_coeffs * 3;
+#pragma unroll
+                for (int k = 0; k < NB * 3; ++k) cf[k] = row[k];
+            }
+            // clamp mask of the forward's  max(sum_j B_j c_j + 0.5, 0)  (same loop, same order, same contraction)
+            float cr = 0.f, cg = 0.f, cb = 0.f;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                cr += B[j] * cf[3 * j]; cg += B[j] * cf[3 * j + 1]; cb += B[j] * cf[3 * j + 2];
+            }
+            float vr[3] = {fmaxf(cr + 0.5f, 0.f) > 0.f ? v_rgb[0] : 0.f, fmaxf(cg + 0.5f, 0.f) > 0.f ? v_rgb[1] : 0.f,
+                           fmaxf(cb + 0.5f, 0.f) > 0.f ? v_rgb[2] : 0.f};
+            vr_keep[0] = vr[0]; vr_keep[1] = vr[1]; vr_keep[2] = vr[2];
+            if constexpr (!FACTORED && !(STAGE && DEG >= 1)) {
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    vc[3 * j] = B[j] * vr[0]; vc[3 * j + 1] = B[j] * vr[1]; vc[3 * j + 2] = B[j] * vr[2];
+                }
+            }
+            if constexpr (DEG >= 1) {
+                float vB[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    vB[j] = cf[3 * j] * vr[0] + cf[3 * j + 1] * vr[1] + cf[3 * j + 2] * vr[2];
+                float hx, hy, hz;
+                gsa_sh_basis_vjp<DEG>(ux, uy, uz, vB, hx, hy, hz);
+                float dd = hx * ux + hy * uy + hz * uz;
+                vdir[0] += (hx - dd * ux) * inv; vdir[1] += (hy - dd * uy) * inv; vdir[2] += (hz - dd * uz) * inv;
+            }
+            }   // !AUX
+        }
+        __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from interleaving the two chains: register pressure)
+
+        GsaProj p = gsa_project_one(cam, g_mean, g_quat, g_scale, width, height);
         // The sweep leaves the raw moments of u = d loss / d sigma over d = mean2d - pixel (composite.hip):
         // sigma = (a dx^2 + c dy^2) / 2 + b dx dy and alpha = o * exp(-sigma) make every gradient linear in them.
         const float m_dx = v0.x, m_dy = v0.y, m_dxdx = v0.z, m_dxdy = v0.w, m_dydy = v1.x, m_u = v1.y;
@@ -363,8 +435,8 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
         float v_mx = p.qa * m_dx + p.qb * m_dy, v_my = p.qb * m_dx + p.qc * m_dy;
         float v_a = 0.5f * m_dxdx, v_b = m_dxdy, v_c = 0.5f * m_dydy;
         vo = -m_u / s_opac;   // d alpha / d o = alpha / o  and  u = -alpha * v_alpha
-        float v_rgb[3] = {v1.z, v1.w, v2.x};
         float v_depth = v2.y;
+
 
         // ---- conic -> blurred cov2d:  G = -Q V Q,  V = [[v_a, v_b/2], [v_b/2, v_c]]
         float a = p.qa, b = p.qb, c = p.qc, hb = 0.5f * v_b;
@@ -401,6 +473,7 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
         vm[0] = R[0] * vx + R[3] * vy + R[6] * vz;
         vm[1] = R[1] * vx + R[4] * vy + R[7] * vz;
         vm[2] = R[2] * vx + R[5] * vy + R[8] * vz;
+        vm[0] += vdir[0]; vm[1] += vdir[1]; vm[2] += vdir[2];
 
         // ---- Sigma_c = R Sigma R^T  ->  vSig = R^T vSc R
         float U00 = vS00 * R[0] + vS01 * R[3] + vS02 * R[6], U01 = vS00 * R[1] + vS01 * R[4] + vS02 * R[7],
@@ -444,73 +517,6 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
         vq[0] = (gw - dotq * w) * p.qinv; vq[1] = (gx - dotq * x) * p.qinv;
         vq[2] = (gy - dotq * y) * p.qinv; vq[3] = (gz - dotq * z) * p.qinv;
 
-        // ---- colour
-        if constexpr (DEG < 0) {
-            vc[0] = v_rgb[0]; vc[1] = v_rgb[1]; vc[2] = v_rgb[2];
-        } else {
-            float dx = g_mean[0] - cam.campos[0], dy = g_mean[1] - cam.campos[1], dz = g_mean[2] - cam.campos[2];
-            float inv = rsqrtf(dx * dx + dy * dy + dz * dz);
-            float ux = dx * inv, uy = dy * inv, uz = dz * inv;
-            float B[NB];
-            gsa_sh_basis<DEG>(ux, uy, uz, B);
-            if constexpr (AUX) {
-                float vr[3] = {g_aux[0].w != 0.f ? v_rgb[0] : 0.f, g_aux[1].w != 0.f ? v_rgb[1] : 0.f,
-                               g_aux[2].w != 0.f ? v_rgb[2] : 0.f};
-                vr_keep[0] = vr[0]; vr_keep[1] = vr[1]; vr_keep[2] = vr[2];
-                if constexpr (!FACTORED) {
-#pragma unroll
-                    for (int j = 0; j < NB; ++j) {
-                        vc[3 * j] = B[j] * vr[0]; vc[3 * j + 1] = B[j] * vr[1]; vc[3 * j + 2] = B[j] * vr[2];
-                    }
-                }
-                vm[0] += g_aux[0].x * vr[0] + g_aux[1].x * vr[1] + g_aux[2].x * vr[2];
-                vm[1] += g_aux[0].y * vr[0] + g_aux[1].y * vr[1] + g_aux[2].y * vr[2];
-                vm[2] += g_aux[0].z * vr[0] + g_aux[1].z * vr[1] + g_aux[2].z * vr[2];
-            } else {
-            float cf[NB * 3];
-            if constexpr (STAGE && DEG >= 1) {
-                constexpr int NQ = sh_needed_q<DEG>();
-                const float4 *row = &sh_lds[threadIdx.x * kRowQPad];
-#pragma unroll
-                for (int k = 0; k < NQ; ++k) {
-                    float4 v = row[k];
-                    if (4 * k + 0 < NB * 3) cf[4 * k + 0] = v.x;
-                    if (4 * k + 1 < NB * 3) cf[4 * k + 1] = v.y;
-                    if (4 * k + 2 < NB * 3) cf[4 * k + 2] = v.z;
-                    if (4 * k + 3 < NB * 3) cf[4 * k + 3] = v.w;
-                }
-            } else {
-                const float *row = colors + i * (long)sh_coeffs * 3;
-#pragma unroll
-                for (int k = 0; k < NB * 3; ++k) cf[k] = row[k];
-            }
-            // clamp mask of the forward's  max(sum_j B_j c_j + 0.5, 0)  (same loop, same order, same contraction)
-            float cr = 0.f, cg = 0.f, cb = 0.f;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                cr += B[j] * cf[3 * j]; cg += B[j] * cf[3 * j + 1]; cb += B[j] * cf[3 * j + 2];
-            }
-            float vr[3] = {fmaxf(cr + 0.5f, 0.f) > 0.f ? v_rgb[0] : 0.f, fmaxf(cg + 0.5f, 0.f) > 0.f ? v_rgb[1] : 0.f,
-                           fmaxf(cb + 0.5f, 0.f) > 0.f ? v_rgb[2] : 0.f};
-            vr_keep[0] = vr[0]; vr_keep[1] = vr[1]; vr_keep[2] = vr[2];
-            if constexpr (!FACTORED) {
-#pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    vc[3 * j] = B[j] * vr[0]; vc[3 * j + 1] = B[j] * vr[1]; vc[3 * j + 2] = B[j] * vr[2];
-                }
-            }
-            if constexpr (DEG >= 1) {
-                float vB[NB];
-#pragma unroll
-                for (int j = 0; j < NB; ++j)
-                    vB[j] = cf[3 * j] * vr[0] + cf[3 * j + 1] * vr[1] + cf[3 * j + 2] * vr[2];
-                float hx, hy, hz;
-                gsa_sh_basis_vjp<DEG>(ux, uy, uz, vB, hx, hy, hz);
-                float dd = hx * ux + hy * uy + hz * uz;
-                vm[0] += (hx - dd * ux) * inv; vm[1] += (hy - dd * uy) * inv; vm[2] += (hz - dd * uz) * inv;
-            }
-            }   // !AUX
-        }
     }
 
     // accumulate (wave-uniform): add to what the output buffers hold instead of overwriting them -- the views of a
@@ -537,72 +543,50 @@ __global__ __launch_bounds__(kBlock) void project_bwd_kernel(
 #pragma unroll
             for (int k = 0; k < 3; ++k) v_colors[i * 3 + k] = vc[k] + (accumulate ? v_colors[i * 3 + k] : 0.f);
         }
-    } else if constexpr (STAGE && AUX) {
-        // rows leave through the wave's LDS image in two column halves (see kHalfPad): whole-wave stores of 96-B row
-        // segments
-        float4 *wrows = &sh_lds[(wave * 64) * kHalfPad];
+    } else if constexpr (STAGE) {
+        // rows leave through the wave's LDS image, 32 whole rows a pass: whole-wave stores of consecutive float4;
+        // element e = 3 j + c of a row is basis_j * (d loss / d rgb_c), formed here
+        float4 *wrows = &sh_lds[wave * kWaveLds];
         float4 *dst = reinterpret_cast<float4 *>(v_colors) + wave_base * kRowQ;
+        float B[NB];
+        gsa_sh_basis<DEG>(ud[0], ud[1], ud[2], B);   // (culled gaussians: vr_keep is zero)
+        auto elem = [&](int e) { return e < NB * 3 ? B[(e / 3) % NB] * vr_keep[e % 3] : 0.f; };
+        if constexpr (ROWS_IN) wave_lds_sync();   // all lanes have consumed their coefficient rows
+        // (an opaque copy of the lane index: the row / column arithmetic below repeats the staging-in's, and sharing it
+        // would keep a dozen 64-bit addresses alive across the whole kernel -- spilled at this register budget)
+        int lane = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane));
+        constexpr int NPL = kPassRows * kRowQ / 64;   // 6 float4 per lane and pass
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (h == 1) wave_lds_sync();   // the first half has left
+        for (int p = 0; p < 2; ++p) {
+            if (p == 1) wave_lds_sync();   // the first 32 rows have left
+            if ((lane >> 5) == p) {
 #pragma unroll
-            for (int k = 0; k < kHalfQ; ++k) {
-                const int e = 4 * (h * kHalfQ + k);
-                float4 v;
-                v.x = e + 0 < NB * 3 ? vc[(e + 0) % (NB * 3)] : 0.f;
-                v.y = e + 1 < NB * 3 ? vc[(e + 1) % (NB * 3)] : 0.f;
-                v.z = e + 2 < NB * 3 ? vc[(e + 2) % (NB * 3)] : 0.f;
-                v.w = e + 3 < NB * 3 ? vc[(e + 3) % (NB * 3)] : 0.f;
-                wrows[lane * kHalfPad + k] = v;
+                for (int q = 0; q < kRowQ; ++q)
+                    wrows[(lane & 31) * kRowPad + q] = make_float4(elem(4 * q), elem(4 * q + 1), elem(4 * q + 2), elem(4 * q + 3));
             }
             wave_lds_sync();
-            float old[4 * kHalfQ];
-            if (accumulate && rows > 0) {   // (wave-uniform; rows clamped, not predicated: all six loads in flight at once)
+            const int live = (int)rows - p * kPassRows;   // rows of this pass that exist (wave-uniform)
+            float old[4 * NPL];
+            if (accumulate && live > 0) {   // (rows clamped, not predicated: all six loads in flight at once)
 #pragma unroll
-                for (int k = 0; k < kHalfQ; ++k) {
-                    const int idx = k * 64 + lane, r_ = min(idx / kHalfQ, (int)rows - 1), c_ = idx % kHalfQ;
-                    const float4 o = dst[r_ * kRowQ + h * kHalfQ + c_];
+                for (int k = 0; k < NPL; ++k) {
+                    const int idx = k * 64 + lane, r_ = min(idx / kRowQ, live - 1), c_ = idx % kRowQ;
+                    const float4 o = dst[(p * kPassRows + r_) * kRowQ + c_];
                     old[4 * k] = o.x; old[4 * k + 1] = o.y; old[4 * k + 2] = o.z; old[4 * k + 3] = o.w;
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < 4 * kHalfQ; ++k) old[k] = 0.f;
+                for (int k = 0; k < 4 * NPL; ++k) old[k] = 0.f;
             }
 #pragma unroll
-            for (int k = 0; k < kHalfQ; ++k) {
-                const int idx = k * 64 + lane, r_ = idx / kHalfQ, c_ = idx - r_ * kHalfQ;
-                if (r_ < rows) {
-                    float4 v = wrows[r_ * kHalfPad + c_];
+            for (int k = 0; k < NPL; ++k) {
+                const int idx = k * 64 + lane, r_ = idx / kRowQ, c_ = idx - r_ * kRowQ;
+                if (r_ < live) {
+                    float4 v = wrows[r_ * kRowPad + c_];
                     v.x += old[4 * k]; v.y += old[4 * k + 1]; v.z += old[4 * k + 2]; v.w += old[4 * k + 3];
-                    dst[r_ * kRowQ + h * kHalfQ + c_] = v;
+                    dst[(p * kPassRows) * kRowQ + idx] = v;
                 }
-            }
-        }
-    } else if (STAGE) {
-        wave_lds_sync();  // all lanes have consumed their coefficient rows
-        float4 *row = &sh_lds[threadIdx.x * kRowQPad];
-#pragma unroll
-        for (int k = 0; k < kRowQ; ++k) {
-            float4 v;
-            v.x = 4 * k + 0 < NB * 3 ? vc[(4 * k + 0) % (NB * 3)] : 0.f;
-            v.y = 4 * k + 1 < NB * 3 ? vc[(4 * k + 1) % (NB * 3)] : 0.f;
-            v.z = 4 * k + 2 < NB * 3 ? vc[(4 * k + 2) % (NB * 3)] : 0.f;
-            v.w = 4 * k + 3 < NB * 3 ? vc[(4 * k + 3) % (NB * 3)] : 0.f;
-            row[k] = v;
-        }
-        wave_lds_sync();
-        float4 *dst = reinterpret_cast<float4 *>(v_colors) + wave_base * kRowQ;
-#pragma unroll
-        for (int k = 0; k < kRowQ; ++k) {
-            int idx = k * 64 + lane;
-            int r_ = idx / kRowQ, c_ = idx - r_ * kRowQ;
-            if (r_ < rows) {
-                float4 v = sh_lds[(wave * 64 + r_) * kRowQPad + c_];
-                if (accumulate) {
-                    const float4 o = dst[idx];
-                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                }
-                dst[idx] = v;
             }
         }
     } else if (active) {

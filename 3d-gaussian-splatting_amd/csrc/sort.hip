@@ -560,21 +560,30 @@ __global__ __launch_bounds__(kSortThreads) void tile_offsets_kernel(uint32_t m_c
     for (long t = lo; t <= hi; ++t) tile_offsets[t] = (int32_t)i;
 }
 
-// the same by binary search, one thread per tile: for long lists (M >> n_tiles) 27 dependent loads per tile beat
-// streaming all M keys
+// the same by searching, for long lists (M >> n_tiles: a handful of dependent loads per tile beat streaming all M keys).
+// One WAVE per tile: a 64-ary search (each round the lanes probe 64 evenly spaced keys of the remaining range; the
+// ballot of "key < tile" says which sixty-fourth holds the boundary) -- 4 dependent memory round trips for 8 M records
+// where a per-thread binary search takes 23.
 template <typename KeyT>
 __global__ __launch_bounds__(kSortThreads) void tile_offsets_bsearch_kernel(uint32_t m_cap, const uint32_t *__restrict__ m_dev,
                                                                             const KeyT *__restrict__ sorted_tile,
                                                                             int n_tiles, int32_t *__restrict__ tile_offsets) {
     const uint32_t m = m_dev ? min(m_cap, *m_dev) : m_cap;
-    int t = blockIdx.x * kSortThreads + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * (kSortThreads / 64) + (threadIdx.x >> 6);   // wave-uniform
     if (t > n_tiles) return;
-    uint32_t lo = 0, hi = m;  // first index with key >= t
+    uint32_t lo = 0, hi = m;   // the first index with key >= t lies in [lo, hi] (hi: "none below hi")
     while (lo < hi) {
-        uint32_t mid = lo + ((hi - lo) >> 1);
-        if ((uint32_t)sorted_tile[mid] < (uint32_t)t) lo = mid + 1; else hi = mid;
+        const uint32_t step = (hi - lo + 63u) / 64u;
+        const uint64_t probe = (uint64_t)lo + (uint64_t)(lane + 1) * step - 1u;
+        const bool below = probe < hi && (uint32_t)sorted_tile[probe] < (uint32_t)t;
+        const uint32_t c = (uint32_t)__builtin_popcountll(__ballot(below));   // monotone: the first c probes are below
+        const uint64_t nlo = (uint64_t)lo + (uint64_t)c * step;                // the answer lies past probe c - 1 ...
+        hi = (uint32_t)min((uint64_t)hi, nlo + step - 1u);                     // ... and at or before probe c
+        lo = (uint32_t)min(nlo, (uint64_t)hi);
+        if (step == 1u) break;   // probes were consecutive: lo is the answer
     }
-    tile_offsets[t] = (int32_t)lo;
+    if (lane == 0) tile_offsets[t] = (int32_t)lo;
 }
 
 // ---- fused emit + first tile-sort pass ---------------------------------------------------------------
@@ -597,32 +606,64 @@ __device__ __forceinline__ uint4 emit_entry(uint32_t off, uint32_t rect, uint32_
     return make_uint4(off, rect, gid, __float_as_uint(__builtin_amdgcn_rcpf((float)wl)));
 }
 
+// The block's gaussians [k_lo, k_hi] (owner of its first slot .. last one that can start inside it) and the global loads
+// of the first kEmitStage of them (three per thread), ISSUED here and consumed in emit_owners: the caller puts its own
+// prologue (histogram columns, block scans) between the two, under the loads' latency.
+static_assert(kEmitStage % kSortThreads == 0, "whole strides of the block's threads are staged");
+struct EmitLoads {
+    int k_lo, k_hi;
+    uint32_t off[kEmitStage / kSortThreads], rect[kEmitStage / kSortThreads], gid[kEmitStage / kSortThreads];
+};
+__device__ __forceinline__ EmitLoads emit_owner_loads(const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ rects,
+                                                      const uint32_t *__restrict__ order,
+                                                      const int32_t *__restrict__ block_owner, int n_owner_blocks,
+                                                      uint32_t m_total, bool want_gid) {
+    EmitLoads el;
+    const uint32_t slot0 = blockIdx.x * (uint32_t)kSortChunk;
+    const uint32_t slot_end = slot0 + min((uint32_t)kSortChunk, m_total - slot0);
+    // owner of the first slot (noted by the scan), and the last gaussian that can start inside this block: the owner
+    // of the next block's first slot, or the last gaussian with records when this is the last live block
+    el.k_lo = block_owner[blockIdx.x];
+    el.k_hi = slot_end < m_total ? block_owner[blockIdx.x + 1] : block_owner[n_owner_blocks];
+#pragma unroll
+    for (int j = 0; j < kEmitStage / kSortThreads; ++j) {
+        const int k = min(el.k_lo + j * kSortThreads + (int)threadIdx.x, el.k_hi);   // (clamped, not predicated)
+        el.off[j] = offsets[k];
+        el.rect[j] = rects[k];
+        el.gid[j] = want_gid ? order[k] : 0u;
+    }
+    return el;
+}
+
 // s_g [kEmitStage]: the packed entries of the first kEmitStage gaussians of the block, read once (coalesced)
 // while their starts are marked; owners beyond (a block of gaussians with fewer than four records each) are looked
 // up in global memory.  want_gid: the histogram does not need the gaussian indices.
-__device__ __forceinline__ EmitBlock emit_owners(const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ rects,
-                                                  const uint32_t *__restrict__ order,
-                                                  const int32_t *__restrict__ block_owner, int n_owner_blocks,
+__device__ __forceinline__ EmitBlock emit_owners(const EmitLoads &el, const uint32_t *__restrict__ offsets,
                                                   uint32_t m_total, uint32_t *__restrict__ s_own,
-                                                  uint4 *__restrict__ s_g, bool want_gid, uint32_t *__restrict__ scratch) {
+                                                  uint4 *__restrict__ s_g, uint32_t *__restrict__ scratch) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     EmitBlock eb;
     eb.slot0 = blockIdx.x * (uint32_t)kSortChunk;
     eb.live = min((uint32_t)kSortChunk, m_total - eb.slot0);
-    const uint32_t slot_end = eb.slot0 + eb.live;
-    // owner of the first slot (noted by the scan), and the last gaussian that can start inside this block: the owner
-    // of the next block's first slot, or the last gaussian with records when this is the last live block
-    eb.k_lo = block_owner[blockIdx.x];
-    const int k_hi = slot_end < m_total ? block_owner[blockIdx.x + 1] : block_owner[n_owner_blocks];
+    eb.k_lo = el.k_lo;
+    const int k_hi = el.k_hi;
     uint4 *own4 = reinterpret_cast<uint4 *>(s_own) + t * (kSortItems / 4);
 #pragma unroll
     for (int q = 0; q < kSortItems / 4; ++q) own4[q] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
-    for (int k = eb.k_lo + t; k <= k_hi; k += kSortThreads) {
-        const uint32_t off = offsets[k], i = (uint32_t)(k - eb.k_lo);
-        if (i < (uint32_t)kEmitStage) s_g[i] = emit_entry(off, rects[k], want_gid ? order[k] : 0u);
-        const uint32_t o = off - eb.slot0;   // (gaussians without records at the block's end start at slot_end)
-        if (i > 0u && o < eb.live) atomicMax(&s_own[o], i);
+#pragma unroll
+    for (int j = 0; j < kEmitStage / kSortThreads; ++j) {
+        const int k = eb.k_lo + j * kSortThreads + t;
+        if (k <= k_hi) {
+            const uint32_t i = (uint32_t)(k - eb.k_lo);
+            s_g[i] = emit_entry(el.off[j], el.rect[j], el.gid[j]);
+            const uint32_t o = el.off[j] - eb.slot0;   // (gaussians without records at the block's end start at slot_end)
+            if (i > 0u && o < eb.live) atomicMax(&s_own[o], i);
+        }
+    }
+    for (int k = eb.k_lo + kEmitStage + t; k <= k_hi; k += kSortThreads) {   // (rare: more than kEmitStage gaussians)
+        const uint32_t o = offsets[k] - eb.slot0;
+        if (o < eb.live) atomicMax(&s_own[o], (uint32_t)(k - eb.k_lo));
     }
     __syncthreads();
     uint32_t v[kSortItems], run = 0;
@@ -692,7 +733,8 @@ __global__ __launch_bounds__(kSortThreads) void emit_hist_kernel(int n, const ui
         return;
     }
     h[threadIdx.x] = 0;
-    const EmitBlock eb = emit_owners(offsets, rects, order, block_owner, nblocks, m_total, s_own, s_g, false, scratch);
+    const EmitLoads el = emit_owner_loads(offsets, rects, order, block_owner, nblocks, m_total, false);
+    const EmitBlock eb = emit_owners(el, offsets, m_total, s_own, s_g, scratch);
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         const uint32_t slot = r * kSortThreads + threadIdx.x;
@@ -728,6 +770,8 @@ __global__ __launch_bounds__(kSortThreads) void emit_scatter_kernel(
     const uint32_t m_total = m_dev ? min(m_cap, *m_dev) : m_cap;
     if ((uint64_t)blockIdx.x * kSortChunk >= m_total) return;
     SORT_TRACE_BEGIN();
+    const EmitLoads el = emit_owner_loads(offsets, rects, order, block_owner, nblocks, m_total, true);   // (in flight
+                                                                                                          // under the scans)
     {
         uint32_t tot, dt = digit_total[t];
         const uint32_t mine = hist[(long)t * nblocks + blockIdx.x];
@@ -738,7 +782,7 @@ __global__ __launch_bounds__(kSortThreads) void emit_scatter_kernel(
         lexcl[t] = lbase;
     }
     SORT_TRACE_MARK(0);   // histogram columns + block scans
-    const EmitBlock eb = emit_owners(offsets, rects, order, block_owner, nblocks, m_total, s_val, s_g, true, scratch);
+    const EmitBlock eb = emit_owners(el, offsets, m_total, s_val, s_g, scratch);
     SORT_TRACE_MARK(1);   // slot owners
     const uint32_t wbase = wave * (kSortChunk / 4);
     uint32_t k[kSortItems], v[kSortItems], rk[kSortItems];
@@ -1250,7 +1294,7 @@ static int tile_offsets_impl(uint32_t m, const uint32_t *m_dev, const KeyT *sort
     GSA_RETURN_IF(m >= 0x7FFFFFFFu, GSA_ERR_UNSUPPORTED);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if ((long long)m > 1024LL * n_tiles)
-        tile_offsets_bsearch_kernel<KeyT><<<gsa_div_up(n_tiles + 1, kSortThreads), kSortThreads, 0, s>>>(
+        tile_offsets_bsearch_kernel<KeyT><<<gsa_div_up(n_tiles + 1, kSortThreads / 64), kSortThreads, 0, s>>>(
             m, m_dev, sorted_tile, n_tiles, tile_offsets);
     else
         tile_offsets_kernel<KeyT><<<gsa_div_up((long long)m + 1, kSortThreads), kSortThreads, 0, s>>>(

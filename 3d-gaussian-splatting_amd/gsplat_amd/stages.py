@@ -103,11 +103,12 @@ def _pinned_scalar(dev):
     return words[nxt], events[nxt]
 
 
-# GSPLAT_AMD_SH_AUX=1: project_fwd leaves its 48-B digest of every coefficient row and project_bwd reads that instead
-# of the 192-B row.  OFF by default: it cuts 96 MB of HBM traffic per 1 M gaussians, but with steps back to back the
-# next project_fwd finds half of the rows the previous project_bwd streamed still in the 256-MB memory-side cache --
-# without those reads it runs cold (measured at 1 M / 1080p: fwd 0.072 -> 0.102 ms, bwd 0.095 -> 0.088 ms).
-_SH_AUX = os.environ.get("GSPLAT_AMD_SH_AUX", "0") == "1"
+# GSPLAT_AMD_SH_AUX=0: project_fwd leaves no digest of the coefficient rows and project_bwd reads the 192-B rows again
+# (for A/B timing).  With the digest (48 B per gaussian written by the forward, read by the backward instead of the row)
+# a 1 M-gaussian / 1080p view measured fwd 0.089 + bwd 0.072 ms against 0.073 + 0.101 ms without.  (Without it the
+# forward looks faster than it is: back to back, it finds half of the rows the previous view's backward streamed
+# still in the 256-MB memory-side cache.)
+_SH_AUX = os.environ.get("GSPLAT_AMD_SH_AUX", "1") != "0"
 
 
 def project_fwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat, Kmat, width: int, height: int,

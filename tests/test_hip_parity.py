@@ -271,7 +271,12 @@ def test_stage_project_bwd(gsa, deg, aux):
     colors_d = d["shs"] if deg is not None else (d["shs"][:, 0, :] * 0.28 + 0.5).contiguous()
     hdeg = -1 if deg is None else deg
     args = (d["means3D"], d["rotations"], d["scales"], d["opacities"][:, 0].contiguous(), colors_d)
-    splat, radii, _, _, sh_aux = S.project_fwd(*args, hdeg, vm.cuda(), K.cuda(), W, H, 0, return_aux=True)
+    was = S._SH_AUX
+    S._SH_AUX = True   # (GSPLAT_AMD_SH_AUX=0 in the environment must not switch this test's subject off)
+    try:
+        splat, radii, _, _, sh_aux = S.project_fwd(*args, hdeg, vm.cuda(), K.cuda(), W, H, 0, return_aux=True)
+    finally:
+        S._SH_AUX = was
     assert (sh_aux is None) == (hdeg < 1)
     vis = (radii > 0).all(-1).cpu()
     g = torch.Generator().manual_seed(3)
