@@ -1123,9 +1123,28 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
 
     int cur = 0;
     const uint32_t mask = shift >= 16 ? 0xFFFFu : ((1u << shift) - 1u);
-    for (int i = t; i < mm; i += kLocalThreads) {
-        L.key[0][i] = (uint16_t)((keys_in[lo + i] - key_min) & mask);
-        L.val[0][i] = vals_in[lo + i];
+    // (loads in groups of four strides with CLAMPED indices, all of a group in flight at once: a plain strided loop
+    // waits for every load before it issues the next -- one memory round trip per 1024 items)
+    constexpr int kStrides = kLocalCap / kLocalThreads;
+    static_assert(kStrides % 4 == 0, "groups of four strides");
+#pragma unroll
+    for (int g4 = 0; g4 < kStrides; g4 += 4) {
+        if (g4 * kLocalThreads >= mm) break;   // (uniform)
+        uint32_t kk[4], vv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = min((g4 + j) * kLocalThreads + t, mm - 1);
+            kk[j] = keys_in[lo + i];
+            vv[j] = vals_in[lo + i];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = (g4 + j) * kLocalThreads + t;
+            if (i < mm) {
+                L.key[0][i] = (uint16_t)((kk[j] - key_min) & mask);
+                L.val[0][i] = vv[j];
+            }
+        }
     }
     __syncthreads();
     if (mm > 0 && shift > 0) { bucket_local_pass(L, cur, mm, 0); cur ^= 1; }   // (mm, shift: uniform)
@@ -1133,16 +1152,29 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
 
     // rectangles and record counts of the bucket's gaussians, now in depth order
     uint32_t *cnt = L.val[cur ^ 1];
-    for (int i = t; i < mm; i += kLocalThreads) {
-        const uint32_t g = L.val[cur][i];
-        const uint2 pr = tile_rects[g];
-        order[lo + i] = g;
-        rects[lo + i] = pr.x;
-        cnt[i] = pr.y;
+#pragma unroll
+    for (int g4 = 0; g4 < kStrides; g4 += 4) {   // (the random 8-B gathers: four in flight per thread, as above)
+        if (g4 * kLocalThreads >= mm) break;
+        uint32_t gg[4];
+        uint2 pr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            gg[j] = L.val[cur][min((g4 + j) * kLocalThreads + t, mm - 1)];
+            pr[j] = tile_rects[gg[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = (g4 + j) * kLocalThreads + t;
+            if (i < mm) {
+                order[lo + i] = gg[j];
+                rects[lo + i] = pr[j].x;
+                cnt[i] = pr[j].y;
+            }
+        }
     }
     __syncthreads();
     // exclusive scan of the counts: 8 consecutive items per thread
-    constexpr int kPer = kLocalCap / kLocalThreads;
+    constexpr int kPer = kStrides;
     uint32_t c[kPer], sum = 0, last = 0;
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
