@@ -1102,7 +1102,8 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, const uint32_t *__restrict__ digit_total,
     uint32_t key_min, int shift, const uint2 *__restrict__ tile_rects, uint32_t *__restrict__ order,
     uint32_t *__restrict__ rects, uint32_t *__restrict__ offsets, int32_t *__restrict__ block_owner, int n_owner_blocks,
-    unsigned long long *granule, uint32_t *ticket, uint32_t *__restrict__ ctl) {
+    unsigned long long *granule, uint32_t *ticket, uint32_t *__restrict__ ctl, uint32_t *__restrict__ ctl_host,
+    uint32_t token) {
     __shared__ BucketLds L;
     __shared__ uint32_t s_bucket;
     const int t = threadIdx.x;
@@ -1119,7 +1120,10 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
     __syncthreads();
     const bool culled_bucket = d == kRadix - 1;        // their entries of order / rects / offsets are never read
     const int mm = culled_bucket ? 0 : (int)min(m, (uint32_t)kLocalCap);
-    if (!culled_bucket && m > (uint32_t)kLocalCap && t == 0) atomicOr(&ctl[3], kStatusOverflow);
+    if (!culled_bucket && m > (uint32_t)kLocalCap && t == 0) {
+        atomicOr(&ctl[3], kStatusOverflow);
+        __threadfence();   // (ahead of this block's granule: the last block reads the status after it has seen them all)
+    }
 
     int cur = 0;
     const uint32_t mask = shift >= 16 ? 0xFFFFu : ((1u << shift) - 1u);
@@ -1211,6 +1215,19 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
         if (t == 0) {
             ctl[0] = base;                             // M
             if (block_owner && n_owner_blocks > 0 && lk) block_owner[n_owner_blocks] = (int32_t)(lk - 1u);
+            // The control words go straight to the caller's pinned host slot (no copy kernel, no event on the stream):
+            // count and key range first, then -- released at system scope -- the status tagged with the caller's token,
+            // which the host polls for.  (A block can only time out on a granule this block waits for as well, so the
+            // status read here is final.)
+            if (ctl_host) {
+                __threadfence();
+                const uint32_t st = __hip_atomic_load(&ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ctl_host[0] = base;
+                ctl_host[1] = ctl[1];
+                ctl_host[2] = ctl[2];
+                __threadfence_system();
+                __hip_atomic_store(&ctl_host[3], (st & 0xFFu) | (token << 8), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         return;
     }
@@ -1241,14 +1258,19 @@ extern "C" int gsa_depth_order_msd_max_shift(void) { return 16; }
 
 extern "C" int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint32_t *tile_rects, uint32_t key_min,
                                    int shift, uint32_t *order, uint32_t *rects, uint32_t *offsets, int32_t *block_owner,
-                                   int n_blocks, uint32_t *ctl, void *workspace, size_t workspace_bytes,
-                                   gsa_stream_t stream) {
+                                   int n_blocks, uint32_t *ctl, uint32_t *ctl_host, uint32_t token, void *workspace,
+                                   size_t workspace_bytes, gsa_stream_t stream) {
     GSA_RETURN_IF(n < 0 || shift < 0 || shift > 16 || !ctl || n_blocks < 0 || (n_blocks > 0 && !block_owner),
                   GSA_ERR_INVALID_ARGUMENT);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    GSA_RETURN_IF(token > 0xFFFFFFu, GSA_ERR_INVALID_ARGUMENT);
     if (n == 0) {
         hipError_t e = hipMemsetAsync(ctl, 0, 4 * sizeof(uint32_t), s);
         if (e == hipSuccess) e = hipMemsetAsync(ctl + 1, 0xFF, sizeof(uint32_t), s);
+        if (ctl_host) {   // (no kernel runs: the host slot -- host memory -- is filled right here)
+            ctl_host[0] = 0u; ctl_host[1] = 0xFFFFFFFFu; ctl_host[2] = 0u;
+            __atomic_store_n(&ctl_host[3], token << 8, __ATOMIC_RELEASE);
+        }
         return (int)e;
     }
     GSA_RETURN_IF(!depth_keys || !tile_rects || !order || !rects || !offsets || !workspace, GSA_ERR_INVALID_ARGUMENT);
@@ -1277,7 +1299,7 @@ extern "C" int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint
     depth_bucket_sort_kernel<<<kRadix, kLocalThreads, 0, s>>>(kbuf, vbuf, digit_total, key_min, shift,
                                                               reinterpret_cast<const uint2 *>(tile_rects), order, rects,
                                                               offsets, n_blocks > 0 ? block_owner : nullptr, n_blocks,
-                                                              granule, ticket, ctl);
+                                                              granule, ticket, ctl, ctl_host, token);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }

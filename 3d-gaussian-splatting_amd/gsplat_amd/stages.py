@@ -5,8 +5,10 @@ one at a time."""
 
 from __future__ import annotations
 
+import ctypes
 import math
 import os
+import time
 from typing import Optional, Tuple
 
 import torch
@@ -96,11 +98,36 @@ def _pinned_scalar(dev):
     two host threads -- never read another view's count."""
     key = (dev.type, dev.index)
     if key not in _PINNED:
-        _PINNED[key] = [torch.empty(_PINNED_SLOTS, 4, dtype=torch.int32, pin_memory=True),
+        _PINNED[key] = [torch.zeros(_PINNED_SLOTS, 4, dtype=torch.int32, pin_memory=True),
                         [torch.cuda.Event() for _ in range(_PINNED_SLOTS)], 0]
     words, events, nxt = _PINNED[key]
     _PINNED[key][2] = (nxt + 1) % _PINNED_SLOTS
     return words[nxt], events[nxt]
+
+
+_TOKEN = [0]
+
+
+def _next_token() -> int:
+    """A 24-bit tag (never 0) for one read-back that a KERNEL writes into a pinned slot (gsa_depth_order_msd): the host
+    polls word 3 of the slot until it carries the tag -- no copy and no event on the stream."""
+    _TOKEN[0] = _TOKEN[0] % 0xFFFFFF + 1
+    return _TOKEN[0]
+
+
+def _wait_slot(slot) -> None:
+    """Blocks until the slot's control words are there: an event (copied slots) or the kernel-written token."""
+    words, event, token = slot
+    if token is None:
+        event.synchronize()
+        return
+    spins, t0 = 0, time.monotonic()
+    while ((int(words[3]) >> 8) & 0xFFFFFF) != token:
+        spins += 1
+        if spins > 200 and time.monotonic() - t0 > 10.0:   # (never seen: the kernel is queued ahead of whatever the
+            torch.cuda.synchronize()                       # caller did since; a device fault would surface here)
+            if ((int(words[3]) >> 8) & 0xFFFFFF) != token:
+                raise RuntimeError("gsplat_amd: the depth ordering never reported its control words")
 
 
 # GSPLAT_AMD_SH_AUX=0: project_fwd leaves no digest of the coefficient rows and project_bwd reads the 192-B rows again
@@ -167,17 +194,18 @@ class TileBins:
         return self._gid
 
     def finalize(self):
-        """-> (M, ok).  Waits for the control words (record count and depth-key range, copied to pinned memory right
-        after the scan, long finished by the time the compositor has been queued) and checks them against what the
+        """-> (M, ok).  Waits for the control words (record count and depth-key range: written to pinned memory by the
+        depth-ordering kernel itself, or copied there right after the scan -- long done by the time the compositor has
+        been queued) and checks them against what the
         kernels ran with: the record capacity, and the number of depth-key bits that were sorted."""
         if self._m is None:
-            ctl_host, ctl_event = self._slot
-            ctl_event.synchronize()
+            _wait_slot(self._slot)
+            ctl_host = self._slot[0]
             self._m = int(ctl_host[0]) & 0xFFFFFFFF
             _note_count(self._key, self._n, self._m)
             if self.key_bits is not None:   # (the unfused path sorts all 32 bits and leaves no range)
                 self._keys_ok = _note_keys(self._key, int(ctl_host[1]) & 0xFFFFFFFF, int(ctl_host[2]) & 0xFFFFFFFF,
-                                           self.key_bits, int(ctl_host[3]) if isinstance(self.key_bits, tuple) else 0)
+                                           self.key_bits, int(ctl_host[3]) & 0xFF if isinstance(self.key_bits, tuple) else 0)
         return self._m, self._m <= self.capacity and self._keys_ok
 
     def __iter__(self):   # sorted_tile, sorted_gid, tile_offsets = bin_tiles(...)
@@ -318,7 +346,7 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
     if fused is None:   # (GSPLAT_AMD_BIN_FUSED=0: the emit + 32-bit sort path, kept for A/B timing)
         fused = can_fuse and _BIN_FUSED_DEFAULT
     cap = None if exact else _capacity_for(key, N)
-    key_bits, keys_ok = 32, True
+    key_bits, keys_ok, slot = 32, True, None
     if fused:
         if tile_rects is None:   # callers that did not keep project_fwd's dense copy: word 11 of the records
             tile_rects = torch.stack([torch.where(tiles_touched > 0, splat[:, 11].contiguous().view(torch.int32), 0),
@@ -342,8 +370,14 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
             block_owner = torch.empty(n_blocks + 1, dtype=torch.int32, device=dev)
             dws_bytes = lib.gsa_depth_order_msd_workspace_bytes(N)
             dws = torch.empty(dws_bytes, dtype=torch.uint8, device=dev)
+            # the kernel leaves the control words in a pinned slot itself (tagged with a token the host polls for)
+            m_host, m_event = _pinned_scalar(dev)
+            token = _next_token()
+            m_host[3] = 0
+            slot = (m_host, m_event, token)
             _call("gsa_depth_order", lib.gsa_depth_order_msd, N, _ptr(depth_keys), _ptr(tile_rects), plan[0], plan[1],
-                  _ptr(order), _ptr(rects), _ptr(offsets), _ptr(block_owner), n_blocks, _ptr(ctl), _ptr(dws), dws_bytes, st)
+                  _ptr(order), _ptr(rects), _ptr(offsets), _ptr(block_owner), n_blocks, _ptr(ctl),
+                  ctypes.c_void_p(m_host.data_ptr()), token, _ptr(dws), dws_bytes, st)
         else:
             if rng is not None:
                 key_bits = _key_bits_needed(rng[0], rng[1])
@@ -365,13 +399,14 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
         _, order = sort_pairs(N, depth_keys, None, 0, 32)  # ties keep index order; culled gaussians sort last
         _call("gsa_scan_tiles", lib.gsa_scan_tiles, N, _ptr(tiles_touched), _ptr(order), _ptr(offsets), _ptr(total),
               _ptr(ws), ws_bytes, st)
-    slot = _pinned_scalar(dev)
-    m_host, m_event = slot
-    m_host.copy_(ctl, non_blocking=True)
-    m_event.record()
+    if slot is None:   # (every path but the bucketed ordering: a 16-byte copy behind the scan, and an event)
+        m_host, m_event = _pinned_scalar(dev)
+        m_host.copy_(ctl, non_blocking=True)
+        m_event.record()
+        slot = (m_host, m_event, None)
     m_known = None
     if cap is None:
-        m_event.synchronize()
+        _wait_slot(slot)
         m_known = int(m_host[0]) & 0xFFFFFFFF
         _note_count(key, N, m_known)
         if fused:

@@ -277,27 +277,31 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed(form):
-        """`warmup` untimed steps, then exactly `steps` steps between two fences; one event per step boundary on the
-        launch stream gives the per-step device times (median / p10 / p90 beside the mean)."""
-        for _ in range(args.warmup):
+    def timed(form, warmup, per_step=False):
+        """`warmup` untimed steps, then exactly `steps` steps between two fences.  per_step: one event per step
+        boundary on the launch stream gives the per-step device times (median / p10 / p90) -- in a pass of its own:
+        an event record leaves a ~6 us bubble on the stream (rocprof kernel trace), 0.8 % of a step."""
+        for _ in range(warmup):
             step(form)
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if per_step else None
         fence()
         t0 = time.perf_counter()
-        marks[0].record()
+        if per_step:
+            marks[0].record()
         for i in range(args.steps):
             step(form)
-            marks[i + 1].record()
+            if per_step:
+                marks[i + 1].record()
         fence()
         dt = time.perf_counter() - t0
-        return dt, [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+        return dt, ([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)] if per_step else None)
 
     # the timed region `value` comes from: the default exchange form of this run
-    elapsed, per_step_ms = timed(factored)
+    elapsed, _ = timed(factored, args.warmup)
+    _, per_step_ms = timed(factored, 0, per_step=True)   # the same steps again, one event per step: the distribution
     other_elapsed = None
     if dist is not None:   # the same steps with the other exchange form, for the comparison figure only
-        other_elapsed, _ = timed(not factored)
+        other_elapsed, _ = timed(not factored, args.warmup)
         for _ in range(2):
             step()
     # a second, instrumented pass of the same steps gives the per-stage device times for the roofline object

@@ -147,12 +147,17 @@ int gsa_depth_order(int n, const uint32_t *depth_keys, const uint32_t *tile_rect
  * LDS capacity of 8192 keys; bit 1: a wait timed out).  The result is valid iff ctl[3] == 0, ctl[1] >= key_min and
  * (ctl[2] - key_min) >> shift <= 254 -- checked by the caller after the fact; otherwise it repeats with
  * gsa_depth_order(key_bits = 32).  Entries of order / rects / offsets that belong to culled gaussians (they sort behind
- * every visible one and have no records) are not written.  workspace: gsa_depth_order_msd_workspace_bytes(n). */
+ * every visible one and have no records) are not written.  workspace: gsa_depth_order_msd_workspace_bytes(n).
+ * ctl_host (optional): four words of PINNED, device-mapped HOST memory (hipHostMalloc).  The last workgroup stores
+ * ctl[0..2] there and then, released at system scope, word 3 = status | token << 8 (token < 2^24, chosen by the caller,
+ * different from what the word holds): the caller polls word 3 for its token instead of queueing a 16-byte copy and an
+ * event behind the kernel (on the bench step those cost a 4-us copy kernel and a 6-us bubble on the stream). */
 size_t gsa_depth_order_msd_workspace_bytes(int n);
 int gsa_depth_order_msd_max_shift(void);
 int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint32_t *tile_rects, uint32_t key_min, int shift,
                         uint32_t *order, uint32_t *rects, uint32_t *offsets, int32_t *block_owner, int n_blocks,
-                        uint32_t *ctl, void *workspace, size_t workspace_bytes, gsa_stream_t stream);
+                        uint32_t *ctl, uint32_t *ctl_host, uint32_t token, void *workspace, size_t workspace_bytes,
+                        gsa_stream_t stream);
 int gsa_scan_tiles_sorted(int n, uint32_t *counts_offsets, int32_t *block_owner, int n_blocks, uint32_t *total,
                           void *workspace, size_t workspace_bytes, gsa_stream_t stream);
 int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offsets, const uint32_t *rects,

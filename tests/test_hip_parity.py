@@ -873,9 +873,15 @@ def test_bucketed_depth_order_equals_lsd_sort(gsa, n, dist):
     assert plan is not None
     o1, r1, f1, b1, c1 = buffers()
     ws = torch.empty(lib.gsa_depth_order_msd_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    # (the control words also go to a pinned host slot, written by the kernel itself and tagged with the caller's token)
+    host = torch.zeros(4, dtype=torch.int32, pin_memory=True)
+    token = 0xABCDE
     check(lib.gsa_depth_order_msd(n, k32.data_ptr(), pairs.data_ptr(), plan[0], plan[1], o1.data_ptr(), r1.data_ptr(),
-                                  f1.data_ptr(), b1.data_ptr(), n_blocks, c1.data_ptr(), ws.data_ptr(), ws.numel(), st),
+                                  f1.data_ptr(), b1.data_ptr(), n_blocks, c1.data_ptr(), host.data_ptr(), token, ws.data_ptr(),
+                                  ws.numel(), st),
           "gsa_depth_order_msd")
+    S._wait_slot((host, None, token))                     # polls word 3 for the token: no event, no copy
+    assert [int(x) & 0xFFFFFFFF for x in host] == [m_true, lo, hi, token << 8]
     torch.cuda.synchronize()
     assert [int(x) & 0xFFFFFFFF for x in c1] == [m_true, lo, hi, 0]
     assert torch.equal(o1[:n_vis], o0[:n_vis]) and torch.equal(r1[:n_vis], r0[:n_vis]) and torch.equal(f1[:n_vis], f0[:n_vis])
@@ -903,13 +909,13 @@ def test_bucketed_depth_order_reports_what_it_cannot_do(gsa):
     ws = torch.empty(lib.gsa_depth_order_msd_workspace_bytes(n), dtype=torch.uint8, device="cuda")
     plan = S._msd_plan(int(keys.min()), int(keys.max()))
     check(lib.gsa_depth_order_msd(n, k32.data_ptr(), pairs.data_ptr(), plan[0], plan[1], out[0].data_ptr(), out[1].data_ptr(),
-                                  out[2].data_ptr(), owner.data_ptr(), 63, ctl.data_ptr(), ws.data_ptr(), ws.numel(), st), "msd")
+                                  out[2].data_ptr(), owner.data_ptr(), 63, ctl.data_ptr(), None, 0, ws.data_ptr(), ws.numel(), st), "msd")
     assert int(ctl[3]) & 1, "bucket overflow must be reported"
     assert not S._note_keys(("t", 0), int(ctl[1]), int(ctl[2]), plan, int(ctl[3]))
     # keys below the assumed minimum: the measured range tells
     narrow = (0x40400000, 8)
     check(lib.gsa_depth_order_msd(n, k32.data_ptr(), pairs.data_ptr(), narrow[0], narrow[1], out[0].data_ptr(), out[1].data_ptr(),
-                                  out[2].data_ptr(), owner.data_ptr(), 63, ctl.data_ptr(), ws.data_ptr(), ws.numel(), st), "msd")
+                                  out[2].data_ptr(), owner.data_ptr(), 63, ctl.data_ptr(), None, 0, ws.data_ptr(), ws.numel(), st), "msd")
     assert not S._note_keys(("t", 1), int(ctl[1]), int(ctl[2]), narrow, int(ctl[3]))
     S._KEY_RANGE.pop(("t", 0), None)
     S._KEY_RANGE.pop(("t", 1), None)
