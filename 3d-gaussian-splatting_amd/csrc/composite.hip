@@ -363,9 +363,18 @@ __global__ __launch_bounds__(kWave, GSA_FWD_WAVES) void composite_fwd_kernel(
     const uint32_t *__restrict__ sorted_gid, const int32_t *__restrict__ tile_offsets,
     const float *__restrict__ background, const int32_t *__restrict__ tile_order, float *__restrict__ render,
     float *__restrict__ alpha_out, float *__restrict__ final_T, int32_t *__restrict__ last_id,
-    uint32_t *__restrict__ quad_list, int32_t *__restrict__ quad_count) {
+    uint32_t *__restrict__ quad_list, int32_t *__restrict__ quad_count, float4 *__restrict__ zero4, long n_zero4) {
     constexpr int F4 = CH == 4 ? 4 : 3;
     __shared__ Staged<F4> st;
+
+    // zero4 (optional): the gradient records the backward sweep will accumulate into.  Every wave clears its share on
+    // the way in -- two fire-and-forget stores per lane under a walk that is bound by vector issue -- instead of a
+    // 64-MB fill pass of its own in front of the backward sweep.
+    if (zero4) {
+        const long per = (n_zero4 + gridDim.x - 1) / gridDim.x;
+        const long z0 = (long)blockIdx.x * per, z1 = min(n_zero4, z0 + per);
+        for (long i = z0 + threadIdx.x; i < z1; i += kWave) zero4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 
     int tile, q;
     wave_unit(blockIdx.x, n_tiles, tile_order, tile, q);
@@ -1241,6 +1250,7 @@ __global__ __launch_bounds__(kPrepThreads) void bwd_prepare_kernel(long n_rows, 
 
 extern "C" int gsa_composite_bwd_prepare(long long n, float *v_splat, int n_tiles, const int32_t *quad_count,
                                          int32_t *tile_order, gsa_stream_t stream) {
+    // (n == 0: the records were cleared already -- gsa_composite_fwd's v_splat_zero -- and only the tiles are ordered)
     GSA_RETURN_IF(n < 0 || n_tiles <= 0 || !quad_count || !tile_order || (n > 0 && !v_splat), GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(((reinterpret_cast<uintptr_t>(v_splat) | reinterpret_cast<uintptr_t>(quad_count)) & 15) != 0,
                   GSA_ERR_INVALID_ARGUMENT);
@@ -1267,10 +1277,14 @@ extern "C" int gsa_debug_set_trace(unsigned long long *buf) {
 extern "C" int gsa_composite_fwd(int width, int height, int channels, const float *splat,
                                  const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
                                  const int32_t *tile_order, float *render, float *alpha, float *final_T,
-                                 int32_t *last_id, uint32_t *quad_list, int32_t *quad_count, gsa_stream_t stream) {
+                                 int32_t *last_id, uint32_t *quad_list, int32_t *quad_count, float *v_splat_zero,
+                                 long long n_zero_rows, gsa_stream_t stream) {
     GSA_RETURN_IF(width <= 0 || height <= 0 || (channels != 3 && channels != 4), GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(!tile_offsets || !render || !alpha || !final_T || !last_id, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF((quad_list == nullptr) != (quad_count == nullptr), GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(n_zero_rows < 0 || (reinterpret_cast<uintptr_t>(v_splat_zero) & 15) != 0, GSA_ERR_INVALID_ARGUMENT);
+    float4 *zero4 = n_zero_rows > 0 ? reinterpret_cast<float4 *>(v_splat_zero) : nullptr;
+    const long n_zero4 = (long)n_zero_rows * (GSA_SPLAT_STRIDE / 4);
     const int tile_w = gsa_div_up(width, kTile), tile_h = gsa_div_up(height, kTile);
     const int n_tiles = tile_w * tile_h;
     const int grid = 32 * gsa_div_up(n_tiles, 8);   // one wave per (tile, quadrant)
@@ -1278,7 +1292,7 @@ extern "C" int gsa_composite_fwd(int width, int height, int channels, const floa
 #define GSA_FWD_LAUNCH(C, L)                                                                                          \
     composite_fwd_kernel<C, L><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid, tile_offsets, \
                                                      background, tile_order, render, alpha, final_T, last_id,         \
-                                                     quad_list, quad_count)
+                                                     quad_list, quad_count, zero4, n_zero4)
     if (quad_list) {
         if (channels == 3) GSA_FWD_LAUNCH(3, GSA_LIST_MODE); else GSA_FWD_LAUNCH(4, GSA_LIST_MODE);
     } else {

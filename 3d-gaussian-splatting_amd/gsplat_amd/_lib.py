@@ -40,7 +40,7 @@ SIGNATURES = {
     "gsa_sort_pairs_u32_dev": (c_int, [c_int, P, P, P, P, P, P, P, c_int, c_int, P, c_size_t, P]),
     "gsa_tile_emit_dev": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_uint32, P, P, P, P]),
     "gsa_tile_offsets_dev": (c_int, [c_uint32, P, P, c_int, P, P]),
-    "gsa_composite_fwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "gsa_composite_fwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, c_longlong, P]),
     "gsa_composite_bwd_prepare": (c_int, [c_longlong, P, c_int, P, P, P]),
     "gsa_composite_bwd_lists": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "gsa_tile_schedule": (c_int, [c_int, P, P, P]),

@@ -54,6 +54,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
                                   tile_order, want_lists=want_lists)
         render, alpha, final_T, last_id = out[:4]
         quad_list, quad_count = out[4] if want_lists else (None, None)
+        ctx.zeroed_records = out[4].zeroed if want_lists else None   # cleared by the forward kernel; used once
         sorted_tile, sorted_gid, tile_offsets = bins.sorted_tile, bins.sorted_gid, bins.tile_offsets
 
         ctx.save_for_backward(means_c, quats_c, scales_c, opac_c, colors_c, view_c, K_c, bg_c, splat, radii,
@@ -77,9 +78,13 @@ class _RasterizeOneCamera(torch.autograd.Function):
             v_render = torch.zeros(height, width, channels, dtype=torch.float32, device=means_c.device)
         v_render = v_render.to(torch.float32).contiguous()
         v_alpha_c = None if v_alpha is None else v_alpha.to(torch.float32).contiguous()
+        lists = None
+        if quad_list is not None:
+            lists = S.QuadLists((quad_list, quad_count))
+            lists.zeroed, ctx.zeroed_records = ctx.zeroed_records, None
         v_splat = S.composite_bwd(splat, sorted_gid, tile_offsets, bg_c, final_T, last_id, v_render, v_alpha_c,
                                   width, height, channels, tile_order,
-                                  quad_lists=None if quad_list is None else (quad_list, quad_count))
+                                  quad_lists=lists)
         grads = S.project_bwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
                               splat, radii, v_splat, out=ctx.grad_out, accumulate=ctx.grad_accumulate,
                               v_rgb_out=ctx.sh_grad_factored, sh_aux=sh_aux)

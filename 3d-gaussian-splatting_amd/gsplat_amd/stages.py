@@ -460,26 +460,37 @@ def tile_schedule(tile_offsets: torch.Tensor, width: int, height: int) -> torch.
     return order
 
 
+class QuadLists(tuple):
+    """(quad_list, quad_count) of ``composite_fwd(want_lists=True)``, plus ``zeroed``: the [N,16] gradient-record buffer
+    the forward kernel cleared on the side -- ``composite_bwd`` accumulates into it ONCE (a second backward pass over
+    the same lists clears a buffer of its own)."""
+    zeroed = None
+
+
 def composite_fwd(splat, sorted_gid, tile_offsets, background, width: int, height: int, channels: int,
                   tile_order=None, want_lists: bool = False):
     """-> render [H,W,channels], alpha [H,W,1], final_T [H,W], last_id [H,W] i32
-    [, (quad_list [4 * len(sorted_gid)] i32, quad_count [n_tiles,4] i32) with ``want_lists``: per 8x8 quadrant the
-    records that were blended there -- what ``composite_bwd(..., quad_lists=...)`` sweeps]."""
+    [, QuadLists(quad_list [4 * len(sorted_gid)] i32, quad_count [n_tiles,4] i32) with ``want_lists``: per 8x8 quadrant
+    the records that were blended there -- what ``composite_bwd(..., quad_lists=...)`` sweeps]."""
     dev = splat.device
     render = torch.empty(height, width, channels, dtype=torch.float32, device=dev)
     alpha = torch.empty(height, width, 1, dtype=torch.float32, device=dev)
     final_T = torch.empty(height, width, dtype=torch.float32, device=dev)
     last_id = torch.empty(height, width, dtype=torch.int32, device=dev)
-    quad_list = quad_count = None
+    quad_list = quad_count = zeroed = None
     if want_lists:
         tile_w, tile_h = tile_grid(width, height)
         quad_list = torch.empty(4 * max(int(sorted_gid.numel()), 1), dtype=torch.int32, device=dev)
         quad_count = torch.empty(tile_w * tile_h, 4, dtype=torch.int32, device=dev)
+        zeroed = torch.empty_like(splat)   # the backward sweep's gradient records: the forward kernel clears them
     _call("gsa_composite_fwd", lib.gsa_composite_fwd, width, height, channels, _ptr(splat), _ptr(sorted_gid),
           _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(render), _ptr(alpha), _ptr(final_T),
-          _ptr(last_id), _ptr(quad_list), _ptr(quad_count), _stream())
+          _ptr(last_id), _ptr(quad_list), _ptr(quad_count), _ptr(zeroed), 0 if zeroed is None else zeroed.shape[0],
+          _stream())
     if want_lists:
-        return render, alpha, final_T, last_id, (quad_list, quad_count)
+        lists = QuadLists((quad_list, quad_count))
+        lists.zeroed = zeroed
+        return render, alpha, final_T, last_id, lists
     return render, alpha, final_T, last_id
 
 
@@ -519,13 +530,18 @@ def composite_bwd(splat, sorted_gid, tile_offsets, background, final_T, last_id,
     ``project_bwd`` consumes (``moments_to_record_grads`` gives the mean / conic / opacity gradients)."""
     if quad_lists is not None:   # sweep the forward pass's lists of blended records (same result, fewer visits)
         quad_list, quad_count = quad_lists
-        # one launch: zero the gradient records and order the tiles by the work the lists hold (exact, unlike the
-        # list lengths `tile_order` was built from before the forward pass)
-        v_splat = torch.empty_like(splat)
+        # one launch: order the tiles by the work the lists hold (exact, unlike the list lengths `tile_order` was built
+        # from before the forward pass) -- and clear the gradient records, unless the forward kernel did (QuadLists)
+        v_splat = getattr(quad_lists, "zeroed", None)
+        fill = v_splat is None or v_splat.shape != splat.shape
+        if fill:
+            v_splat = torch.empty_like(splat)
+        else:
+            quad_lists.zeroed = None   # (accumulated into once)
         tile_w, tile_h = tile_grid(width, height)
         tile_order = torch.empty(8 * ((tile_w * tile_h + 7) // 8), dtype=torch.int32, device=splat.device)
-        _call("gsa_composite_bwd_prepare", lib.gsa_composite_bwd_prepare, splat.shape[0], _ptr(v_splat), tile_w * tile_h,
-              _ptr(quad_count), _ptr(tile_order), _stream())
+        _call("gsa_composite_bwd_prepare", lib.gsa_composite_bwd_prepare, splat.shape[0] if fill else 0, _ptr(v_splat),
+              tile_w * tile_h, _ptr(quad_count), _ptr(tile_order), _stream())
         _call("gsa_composite_bwd", lib.gsa_composite_bwd_lists, width, height, channels, _ptr(splat), _ptr(sorted_gid),
               _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(final_T), _ptr(last_id), _ptr(v_render),
               _ptr(v_alpha), _ptr(quad_list), _ptr(quad_count), _ptr(v_splat), _stream())

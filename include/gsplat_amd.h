@@ -202,11 +202,15 @@ int gsa_tile_offsets(uint32_t m, const uint32_t *sorted_tile, int n_tiles, int32
  * BLENDED at one of its pixels at least, ascending, and their number: quad_count[4 * tile + q] entries at
  * quad_list[4 * tile_offsets[tile] + q * (tile_offsets[tile + 1] - tile_offsets[tile])] (quad_list holds 4 M
  * uint32, mostly unwritten).  gsa_composite_bwd_lists sweeps exactly those records.
+ * v_splat_zero / n_zero_rows (optional; NULL / 0): a [n_zero_rows,16] float buffer (16-byte aligned) the kernel fills with
+ * zeros on the side -- the gradient records of the backward sweep to come, which then needs no fill pass of its own
+ * (gsa_composite_bwd_prepare with n = 0).
  */
 int gsa_composite_fwd(int width, int height, int channels, const float *splat,
                       const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
                       const int32_t *tile_order, float *render, float *alpha, float *final_T, int32_t *last_id,
-                      uint32_t *quad_list, int32_t *quad_count, gsa_stream_t stream);
+                      uint32_t *quad_list, int32_t *quad_count, float *v_splat_zero, long long n_zero_rows,
+                      gsa_stream_t stream);
 
 /* Launch order for stages 3 and 4 (optional; speed only, never results): tile_order[8 * ceil(n_tiles / 8)] receives,
  * for each of the 8 tile bands, the band's tiles with the longest record lists first (-1 pads the last band). Pass it
@@ -225,7 +229,8 @@ int gsa_composite_bwd(int width, int height, int channels, const float *splat,
 
 /* First launch of a backward pass over the forward's lists: zero-fills v_splat[N,16] (the sweep accumulates into it) and
  * writes the launch order for gsa_composite_bwd_lists -- per tile band, the tiles whose quadrants blended the most
- * records first (tile_order[8 * ceil(n_tiles / 8)], as gsa_tile_schedule). */
+ * records first (tile_order[8 * ceil(n_tiles / 8)], as gsa_tile_schedule).  n = 0: the records are clear already
+ * (gsa_composite_fwd's v_splat_zero); only the order is written. */
 int gsa_composite_bwd_prepare(long long n, float *v_splat, int n_tiles, const int32_t *quad_count,
                               int32_t *tile_order, gsa_stream_t stream);
 
