@@ -1185,6 +1185,29 @@ __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_2p_kernel(
 // One workgroup per band: counting sort of the band's tiles by list length (64 buckets of 64 records, longest
 // first).  The order inside a bucket comes from LDS atomics and may differ between launches -- it only moves
 // work in time, never changes a result.
+// first[b] = number of tiles in the buckets before b: wave 0 scans the NB counters (a serial loop by one thread -- 256
+// dependent LDS round trips -- was most of the 7 us these single-wave-of-work kernels took)
+template <int NB>
+__device__ __forceinline__ void bucket_starts(const int *__restrict__ cnt, int *__restrict__ first) {
+    static_assert(NB % 64 == 0, "whole counters per lane");
+    if (threadIdx.x < 64) {
+        constexpr int PER = NB / 64;
+        const int lane = threadIdx.x;
+        int v[PER], s = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { v[j] = cnt[lane * PER + j]; s += v[j]; }
+        int incl = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        int run = incl - s;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { first[lane * PER + j] = run; run += v[j]; }
+    }
+}
+
 constexpr int kSchedThreads = 1024, kSchedBuckets = 64;
 __global__ __launch_bounds__(kSchedThreads) void tile_schedule_kernel(int n_tiles, const int32_t *__restrict__ tile_offsets,
                                                                       int32_t *__restrict__ tile_order) {
@@ -1199,10 +1222,7 @@ __global__ __launch_bounds__(kSchedThreads) void tile_schedule_kernel(int n_tile
     };
     for (int t = lo + threadIdx.x; t < hi; t += kSchedThreads) atomicAdd(&cnt[bucket(t)], 1);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int k = 0; k < kSchedBuckets; ++k) { first[k] = run; run += cnt[k]; }
-    }
+    bucket_starts<kSchedBuckets>(cnt, first);
     __syncthreads();
     for (int t = lo + threadIdx.x; t < hi; t += kSchedThreads) tile_order[lo + atomicAdd(&first[bucket(t)], 1)] = t;
     for (int t = max(hi, lo) + threadIdx.x; t < lo + chunk; t += kSchedThreads) tile_order[t] = -1;   // padding
@@ -1237,10 +1257,7 @@ __global__ __launch_bounds__(kPrepThreads) void bwd_prepare_kernel(long n_rows, 
     };
     for (int t = lo + threadIdx.x; t < hi; t += kPrepThreads) atomicAdd(&cnt[bucket(t)], 1);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int k = 0; k < kPrepBuckets; ++k) { first[k] = run; run += cnt[k]; }
-    }
+    bucket_starts<kPrepBuckets>(cnt, first);
     __syncthreads();
     for (int t = lo + threadIdx.x; t < hi; t += kPrepThreads) tile_order[lo + atomicAdd(&first[bucket(t)], 1)] = t;
     for (int t = max(hi, lo) + threadIdx.x; t < lo + chunk; t += kPrepThreads) tile_order[t] = -1;   // padding
