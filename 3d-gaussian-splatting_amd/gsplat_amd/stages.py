@@ -115,8 +115,20 @@ def _next_token() -> int:
     return _TOKEN[0]
 
 
+WAIT_STATS = [0, 0.0]   # read-backs waited for, seconds spent waiting: the host's slack per view (bench.py reports it)
+
+
 def _wait_slot(slot) -> None:
     """Blocks until the slot's control words are there: an event (copied slots) or the kernel-written token."""
+    t_in = time.perf_counter()
+    try:
+        _wait_slot_impl(slot)
+    finally:
+        WAIT_STATS[0] += 1
+        WAIT_STATS[1] += time.perf_counter() - t_in
+
+
+def _wait_slot_impl(slot) -> None:
     words, event, token = slot
     if token is None:
         event.synchronize()

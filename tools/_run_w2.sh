@@ -1,5 +1,2 @@
 set -o pipefail
-mkdir -p gpurun_out/r02_w12
-timeout -k 10 400 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "sort or bin or depth or order or tile or bucket or forward_backward or list" > gpurun_out/r02_w12/t.log 2>&1; tail -3 gpurun_out/r02_w12/t.log
-echo "== default"; for i in 1 2 3; do timeout -k 10 120 bash tools/bench_stages.sh; done
-timeout -k 10 200 bash tools/prof_bench.sh r02_w12/prof > /dev/null 2>&1; sed -n 3,20p gpurun_out/r02_w12/prof/summary.md | cut -c1-100
+for cfg in "10 50" "50 200" "10 50"; do set -- $cfg; python bench.py --no-cpu-baseline --warmup $1 --steps $2 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('warmup',d['warmup'],'steps',d['steps'],'ms',d['ms_per_step'],'wait',d['host_wait_ms_per_step'],'step_ms',d['step_ms'])"; done

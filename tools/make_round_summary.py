@@ -1,0 +1,83 @@
+"""Compose profiles/<name>_summary.md (+ copy <name>_kernel_stats.csv / <name>_traffic.json) from what
+tools/round_artifacts.sh TAG left under gpurun_out/TAG.
+
+usage: python tools/make_round_summary.py gpurun_out/<TAG> <name> "<title>" """
+import json
+import os
+import shutil
+import sys
+
+src, name, title = sys.argv[1], sys.argv[2], sys.argv[3]
+tag = os.path.basename(src.rstrip("/"))
+out = "profiles"
+shutil.copy(f"{src}/stats/p_kernel_stats.csv", f"{out}/{name}_kernel_stats.csv")
+shutil.copy(f"{src}/traffic.json", f"{out}/{name}_traffic.json")
+profiled = open(f"{src}/bench_profiled.json").read().strip().splitlines()[-1]
+default = open(f"{src}/bench_default.json").read().strip().splitlines()[-1]
+pj = json.loads(profiled)
+traced = pj["warmup"] + 3 * pj["steps"]   # warm-up + headline pass + per-step-event pass + instrumented pass
+table = open(f"{src}/summary_table.md").read().rstrip()
+tr = json.load(open(f"{src}/traffic.json"))
+
+
+def counters_row(label, k):
+    r = tr["kernels"][k]
+    sh = r.get("wave_cycle_shares", {})
+    vals = list(sh.values()) + [0, 0, 0]
+    return (f"| `{r['kernel']}` | {r.get('valu_insts', 0) / 1e6:.1f} M | {r.get('lds_insts', 0) / 1e6:.1f} M | "
+            f"{r.get('wave_cycles', 0) / 1e6:.0f} M | {100 * vals[2]:.0f}% | {100 * vals[1]:.0f}% | {100 * vals[0]:.0f}% | "
+            f"{100 * r.get('wait_issue_lds_frac', 0):.0f}% | {r['hbm_bytes_per_launch'] / 1e6:.0f} MB | "
+            f"{r['atomic_requests'] / 1e6:.2f} M |")
+
+
+binning = ", ".join(f"{k} {v['hbm_bytes_per_launch'] / 1e6:.1f}" for k, v in sorted(tr["binning_kernels"].items()))
+proj = ", ".join(f"{k} {tr['kernels'][k]['hbm_bytes_per_launch'] / 1e6:.0f}" for k in ("gsa_project_fwd", "gsa_project_bwd")
+                 if k in tr["kernels"])
+text = f"""# {title} -- rocprofv3 --kernel-trace --stats
+
+Produced by `tools/round_artifacts.sh {tag}` on one MI355X box (default bench, the profiled bench, the PMC passes
+behind `profiles/{name}_traffic.json`, in that order) and `tools/make_round_summary.py`.
+
+Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps {pj['steps']} --warmup {pj['warmup']} --no-cpu-baseline`
+({pj['warmup']} warm-up + {pj['steps']} timed + {pj['steps']} with one event per step + {pj['steps']} instrumented steps = {traced} steps traced;
+`profiles/{name}_kernel_stats.csv` is the raw stats file).
+
+bench.py line of the same (profiled) run:
+
+```
+{profiled}
+```
+
+Un-profiled default run (`python bench.py`, CPU baseline legs included) on the same build and box:
+
+```
+{default}
+```
+
+{table.replace('/ 45 steps', f'/ {traced} steps')}
+
+(The `sum of kernel time` line divides by the {traced} traced steps.)  The dominant kernel's average duration under the
+profiler (`composite_bwd_2p_kernel<3>`, table above) agrees with the HIP-event average bench.py reports in
+`roofline.avg_launch_ms` (un-profiled; the profiler adds a few percent).
+Binning is `radix_hist<unsigned int>` + `radix_scan_rows` + `radix_scatter<unsigned int>` (ONE global pass: depth
+buckets) + `depth_bucket_sort_kernel` (local sorts fused with the scan and the block-owner table; it also leaves the
+control words in the caller's pinned slot -- no copy kernel), then `emit_hist` + `radix_scan_rows` + `emit_scatter`
+(records generated from the depth-ordered tile rectangles; low 7 bits of the tile id) + one 16-bit hist / scan / scatter
+pass (high 6 bits) + `tile_offsets_bsearch` + `tile_schedule`: 12 launches, 17 per forward + backward view.  The `scan_*`
+kernels, `tile_offsets_kernel` and the second / third `radix_*<unsigned int>` calls belong to the first call of the scene
+shape (LSD path, which learns the key range); `__amd_rocclr_copyBuffer` is the scene upload and that first call's read-back.
+
+Counters of the compositor kernels (`profiles/{name}_traffic.json`, separate `--pmc` passes of the same command):
+
+| kernel | VALU wave-instr | LDS wave-instr | wave cycles | issuing | waiting to issue | waiting for data | of which LDS-pipe stall | HBM bytes (FETCH x2 + WRITE) | float-atomic requests |
+|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|
+{counters_row('bwd', 'gsa_composite_bwd')}
+{counters_row('fwd', 'gsa_composite_fwd')}
+
+(`composite_fwd` now also clears the 64 MB of gradient records the backward sweep accumulates into: 64 MB of its writes.)
+
+HBM traffic per launch of the projection kernels (MB): {proj}.
+HBM traffic per launch of the binning kernels (MB): {binning}.
+"""
+open(f"{out}/{name}_summary.md", "w").write(text)
+print(f"wrote {out}/{name}_summary.md ({len(text)} bytes)")
