@@ -99,10 +99,11 @@ def _pinned_scalar(dev):
     key = (dev.type, dev.index)
     if key not in _PINNED:
         _PINNED[key] = [torch.zeros(_PINNED_SLOTS, 4, dtype=torch.int32, pin_memory=True),
-                        [torch.cuda.Event() for _ in range(_PINNED_SLOTS)], 0]
-    words, events, nxt = _PINNED[key]
+                        [torch.cuda.Event() for _ in range(_PINNED_SLOTS)], 0, [0] * _PINNED_SLOTS]
+    words, events, nxt, gens = _PINNED[key]
     _PINNED[key][2] = (nxt + 1) % _PINNED_SLOTS
-    return words[nxt], events[nxt]
+    gens[nxt] += 1   # a TileBins finalized after its slot went round the ring finds another generation: an error, not
+    return words[nxt], events[nxt], (gens, nxt, gens[nxt])   # another view's count
 
 
 _TOKEN = [0]
@@ -129,7 +130,12 @@ def _wait_slot(slot) -> None:
 
 
 def _wait_slot_impl(slot) -> None:
-    words, event, token = slot
+    words, event, token = slot[:3]
+    if len(slot) > 3 and slot[3] is not None:
+        gens, idx, gen = slot[3]
+        if gens[idx] != gen:
+            raise RuntimeError(f"gsplat_amd: more than {_PINNED_SLOTS} un-finalized TileBins per device: this one's "
+                               "read-back slot has been reused")
     if token is None:
         event.synchronize()
         return
@@ -383,10 +389,10 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
             dws_bytes = lib.gsa_depth_order_msd_workspace_bytes(N)
             dws = torch.empty(dws_bytes, dtype=torch.uint8, device=dev)
             # the kernel leaves the control words in a pinned slot itself (tagged with a token the host polls for)
-            m_host, m_event = _pinned_scalar(dev)
+            m_host, m_event, guard = _pinned_scalar(dev)
             token = _next_token()
             m_host[3] = 0
-            slot = (m_host, m_event, token)
+            slot = (m_host, m_event, token, guard)
             _call("gsa_depth_order", lib.gsa_depth_order_msd, N, _ptr(depth_keys), _ptr(tile_rects), plan[0], plan[1],
                   _ptr(order), _ptr(rects), _ptr(offsets), _ptr(block_owner), n_blocks, _ptr(ctl),
                   ctypes.c_void_p(m_host.data_ptr()), token, _ptr(dws), dws_bytes, st)
@@ -412,10 +418,10 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
         _call("gsa_scan_tiles", lib.gsa_scan_tiles, N, _ptr(tiles_touched), _ptr(order), _ptr(offsets), _ptr(total),
               _ptr(ws), ws_bytes, st)
     if slot is None:   # (every path but the bucketed ordering: a 16-byte copy behind the scan, and an event)
-        m_host, m_event = _pinned_scalar(dev)
+        m_host, m_event, guard = _pinned_scalar(dev)
         m_host.copy_(ctl, non_blocking=True)
         m_event.record()
-        slot = (m_host, m_event, None)
+        slot = (m_host, m_event, None, guard)
     m_known = None
     if cap is None:
         _wait_slot(slot)

@@ -420,6 +420,12 @@ def test_population_change_keeps_the_pipeline_asynchronous(gsa):
     b1, m1 = bins(N)
     b2, m2 = bins(N - N // 20)
     assert m1 != m2 and b2.finalize()[0] == m2 and b1.finalize()[0] == m1
+    # ... and one whose slot went round the ring before it was finalized says so instead of reading another view's count
+    stale, _ = bins(N)
+    later = [bins(N)[0] for _ in range(S._PINNED_SLOTS)]
+    with pytest.raises(RuntimeError, match="un-finalized"):
+        stale.finalize()
+    assert all(b.finalize()[1] for b in later)
 
 
 @pytest.mark.parametrize("mode", ["D", "ED", "RGB+D", "RGB+ED"])
