@@ -231,6 +231,8 @@ __device__ __forceinline__ const float4 *rec_at(const Staged<F4> &st, uint32_t b
 template <int CH>
 struct FwdPixel {
     float T, Tend, acc[CH];
+    float x;          // the pixel centre's x -- NaN once the pixel is finished: sigma is then NaN, whose bit pattern fails the
+                      // one unsigned compare of the alpha test, so the walk needs no per-record "is this lane off" operand
     uint32_t dead;
     int last;
 };
@@ -251,7 +253,7 @@ struct FwdPixel {
 // One group of G list entries starting at entry i: per-record alpha (0 where skipped / pixel finished), colours,
 // list positions.
 template <int CH, int F4, bool CLAMP, int G>
-__device__ __forceinline__ void eval_group(const Staged<F4> &st, int i, float pxf, float pyf, uint32_t dead,
+__device__ __forceinline__ void eval_group(const Staged<F4> &st, int i, float pxf, float pyf,
                                            float (&a)[G], float (&col)[G][CH], int (&idx)[G],
                                            unsigned long long (&passed)[G]) {
     // one LDS broadcast gives G list entries
@@ -270,7 +272,7 @@ __device__ __forceinline__ void eval_group(const Staged<F4> &st, int i, float px
         const float dx = q0.x - pxf, dy = q0.y - pyf;
         float raw;
         bool hit;
-        a[e] = record_alpha<CLAMP>(scaled_sigma(q0, q1, dx, dy), q2.y, q1.y, dead, raw, hit);
+        a[e] = record_alpha<CLAMP>(scaled_sigma(q0, q1, dx, dy), q2.y, q1.y, 0u, raw, hit);   // (pxf is NaN for a finished pixel)
         passed[e] = __ballot(hit);   // the compare's own lane mask: which pixels take this record (no extra VALU)
         col[e][0] = q1.z; col[e][1] = q1.w; col[e][2] = q2.x;
         if (CH == 4) col[e][CH - 1] = p[F4 - 1].x;
@@ -295,7 +297,7 @@ __device__ __forceinline__ void note_taken(unsigned long long &contrib, unsigned
 // LISTS: `contrib` receives one bit per list entry that was BLENDED at one pixel of the quadrant at least (alpha test
 // passed, pixel live and not stopping there) -- the records the backward sweep has to visit here.
 template <int CH, int F4, bool CLAMP, int LISTS>
-__device__ __forceinline__ bool walk_fwd(const Staged<F4> &st, int n, float pxf, float pyf, FwdPixel<CH> &px,
+__device__ __forceinline__ bool walk_fwd(const Staged<F4> &st, int n, float pyf, FwdPixel<CH> &px,
                                          unsigned long long &contrib) {
     constexpr int G = GSA_FWD_GROUP;
     int i = 0;
@@ -306,10 +308,11 @@ __device__ __forceinline__ bool walk_fwd(const Staged<F4> &st, int n, float pxf,
             float a[G], col[G][CH], t[G + 1];
             int idx[G];
             unsigned long long passed[G];
-            eval_group<CH, F4, CLAMP, G>(st, i, pxf, pyf, px.dead, a, col, idx, passed);
+            eval_group<CH, F4, CLAMP, G>(st, i, px.x, pyf, a, col, idx, passed);
             t[0] = px.T;
+            // T (1 - alpha) as ONE fused step, here and on the careful path: the rounding must not depend on the path
 #pragma unroll
-            for (int e = 0; e < G; ++e) t[e + 1] = t[e] * (1.f - a[e]);
+            for (int e = 0; e < G; ++e) t[e + 1] = __builtin_fmaf(-a[e], t[e], t[e]);
             if (__ballot(t[G] > GSA_TRANSMITTANCE_EPS) != ~0ull) break;
             if (LISTS == 2) {   // (no pixel stops in this group: taking a record = blending it)
 #pragma unroll
@@ -331,11 +334,11 @@ __device__ __forceinline__ bool walk_fwd(const Staged<F4> &st, int n, float pxf,
             float a[G], col[G][CH];
             int idx[G];
             unsigned long long passed[G];
-            eval_group<CH, F4, CLAMP, G>(st, i, pxf, pyf, px.dead, a, col, idx, passed);
+            eval_group<CH, F4, CLAMP, G>(st, i, px.x, pyf, a, col, idx, passed);
 #pragma unroll
             for (int e = 0; e < G; ++e) {
                 const float ae = px.dead ? 0.f : a[e];      // a pixel that stopped earlier in this group
-                const float nT = px.T * (1.f - ae);
+                const float nT = __builtin_fmaf(-ae, px.T, px.T);
                 const bool ok = nT > GSA_TRANSMITTANCE_EPS; // finished pixels: alpha 0, T = 1 -> true, no effect
                 const float wgt = ok ? ae * px.T : 0.f;
                 if (LISTS == 2) note_taken(contrib, __ballot(wgt != 0.f), i + e);
@@ -344,6 +347,7 @@ __device__ __forceinline__ bool walk_fwd(const Staged<F4> &st, int n, float pxf,
                 px.last = (ok && !px.dead) ? idx[e] : px.last;
                 px.Tend = ok ? px.Tend : px.T;              // the stop rule fired: this record is not blended
                 px.dead = ok ? px.dead : kSign;
+                px.x = ok ? px.x : __builtin_nanf("");
                 px.T = ok ? nT : 1.f;
             }
             i += G;
@@ -391,6 +395,7 @@ __global__ __launch_bounds__(kWave, GSA_FWD_WAVES) void composite_fwd_kernel(
 
     FwdPixel<CH> px;
     px.T = 1.f; px.Tend = 1.f; px.dead = inside ? 0u : kSign; px.last = -1;
+    px.x = inside ? pxf : __builtin_nanf("");
 #pragma unroll
     for (int k = 0; k < CH; ++k) px.acc[k] = 0.f;
     int listed = 0;   // LISTS: entries written to this quadrant's list so far (wave-uniform)
@@ -424,8 +429,8 @@ __global__ __launch_bounds__(kWave, GSA_FWD_WAVES) void composite_fwd_kernel(
             gid_next = load_gid(j + 2);
             GSA_TRACE_COUNT(n);
             unsigned long long contrib = 0ull;
-            const bool live = any_cap ? walk_fwd<CH, F4, true, LISTS>(st, n, pxf, pyf, px, contrib)
-                                      : walk_fwd<CH, F4, false, LISTS>(st, n, pxf, pyf, px, contrib);
+            const bool live = any_cap ? walk_fwd<CH, F4, true, LISTS>(st, n, pyf, px, contrib)
+                                      : walk_fwd<CH, F4, false, LISTS>(st, n, pyf, px, contrib);
             if (LISTS == 1) contrib = ~0ull;                   // every record the reach test kept
             contrib &= n >= 64 ? ~0ull : (1ull << n) - 1ull;   // the padding (null) entries "pass" with alpha 0
             if (LISTS && contrib) {   // lane i < n <-> list entry i: append the blended ones, in list order
