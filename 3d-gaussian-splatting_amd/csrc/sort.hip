@@ -52,8 +52,10 @@ __device__ __forceinline__ int resolve_count(int n_cap, const uint32_t *__restri
     return n_dev ? (int)min((uint32_t)n_cap, *n_dev) : n_cap;
 }
 
-// Digit of a key in one radix pass.  Plain: bits [shift, shift + 8).  MSD bucketing of depth keys (msd_sub != 0 or
-// msd flag): bucket = (key - sub) >> shift clamped to 254, and the culled sentinel 0xFFFFFFFF alone in bucket 255 --
+// Digit of a key in one radix pass.  Plain: bits [shift, shift + 8).  MSD bucketing of depth keys (msd flag; `shift`
+// then holds a 32-bit SCALE): bucket = ((key - sub) * scale) >> 32 clamped to 254 -- 255 buckets of (nearly) equal key
+// width whatever the range, where a power-of-two width left a quarter of them empty and the fullest one at the LDS
+// capacity -- and the culled sentinel 0xFFFFFFFF alone in bucket 255 --
 // monotone in the key, so buckets are depth ranges (gsa_depth_order_msd).
 struct RadixDigit {
     int shift;
@@ -61,7 +63,7 @@ struct RadixDigit {
     int msd;
 };
 __device__ __forceinline__ uint32_t digit_of(uint32_t key, const RadixDigit &dg) {
-    if (dg.msd) return key == 0xFFFFFFFFu ? 255u : min((key - dg.sub) >> dg.shift, 254u);
+    if (dg.msd) return key == 0xFFFFFFFFu ? 255u : min(__umulhi(key - dg.sub, (uint32_t)dg.shift), 254u);
     return (key >> dg.shift) & (kRadix - 1);
 }
 
@@ -1002,9 +1004,9 @@ extern "C" int gsa_depth_order(int n, const uint32_t *depth_keys, const uint32_t
 // ---- depth order by buckets: one MSD pass + a local sort per bucket, fused with the scan ------------------------------
 // The LSD depth sort costs three launches per 8 key bits, each at its latency floor for 1 M keys (~29 us per pass at
 // C3).  With the range of the visible keys known beforehand (remembered per scene shape, checked after the fact), ONE
-// global pass buckets the keys by depth range -- digit = (key - key_min) >> shift, 255 buckets of equal key width, the
-// culled sentinel alone in bucket 255 -- and ONE launch finishes the job with a workgroup per bucket: it sorts its
-// bucket in LDS on the remaining `shift` (<= 16) low bits (stable counting sort, 8 bits per pass, wave64 ballot
+// global pass buckets the keys by depth range -- digit = ((key - key_min) * scale) >> 32, 255 buckets of equal key width
+// (at most 2^16), the culled sentinel alone in bucket 255 -- and ONE launch finishes the job with a workgroup per bucket:
+// it sorts its bucket in LDS on the key's offset inside the bucket (stable counting sort, 8 bits per pass, peer-mask
 // ranking), gathers the packed tile rectangles and record counts of its gaussians, scans the counts, learns the
 // records of the buckets in front of it from their published totals (one 8-byte {ready, count, last} granule per
 // bucket, relaxed agent-scope atomics, bounded spin; bucket ids are handed out by an atomic ticket, so a waiting block's
@@ -1017,7 +1019,7 @@ constexpr uint32_t kStatusOverflow = 1u, kStatusTimeout = 2u;
 
 struct BucketLds {
     uint32_t val[2][kLocalCap];           // gaussian ids, ping-pong; after the sort the idle half holds the record counts
-    uint16_t key[2][kLocalCap];           // the `shift` low bits of (key - key_min)
+    uint16_t key[2][kLocalCap];           // the key's offset inside its bucket
     uint16_t rk[kLocalCap];               // rank of an item among the items of its digit in its wave's range
     uint32_t wcnt[kLocalWaves][kRadix];   // per wave range and digit: count, then first slot
     uint32_t dbase[kRadix];
@@ -1103,7 +1105,7 @@ __device__ __forceinline__ void bucket_local_pass(BucketLds &L, int src, int mm,
 
 __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, const uint32_t *__restrict__ digit_total,
-    uint32_t key_min, int shift, const uint2 *__restrict__ tile_rects, uint32_t *__restrict__ order,
+    uint32_t key_min, uint32_t scale, const uint2 *__restrict__ tile_rects, uint32_t *__restrict__ order,
     uint32_t *__restrict__ rects, uint32_t *__restrict__ offsets, int32_t *__restrict__ block_owner, int n_owner_blocks,
     unsigned long long *granule, uint32_t *ticket, uint32_t *__restrict__ ctl, uint32_t *__restrict__ ctl_host,
     uint32_t token) {
@@ -1129,7 +1131,12 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
     }
 
     int cur = 0;
-    const uint32_t mask = shift >= 16 ? 0xFFFFu : ((1u << shift) - 1u);
+    // bucket d holds the keys x = key - key_min with (x * scale) >> 32 == d: x in [lo_d, lo_(d+1)), lo_d = ceil(d 2^32 /
+    // scale); the local sorts run on x - lo_d (< 2^16 by the caller's choice of scale; the last bucket is clamped, a key
+    // beyond the assumed range wraps there and the caller, who checks the measured range, repeats)
+    const uint32_t lo_d = (uint32_t)((((unsigned long long)d << 32) + scale - 1u) / scale);
+    const uint32_t width = (uint32_t)((((unsigned long long)(d + 1) << 32) + scale - 1u) / scale) - lo_d;
+    const uint32_t sub = key_min + lo_d, mask = 0xFFFFu;
     // (loads in groups of four strides with CLAMPED indices, all of a group in flight at once: a plain strided loop
     // waits for every load before it issues the next -- one memory round trip per 1024 items)
     constexpr int kStrides = kLocalCap / kLocalThreads;
@@ -1148,14 +1155,14 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
         for (int j = 0; j < 4; ++j) {
             const int i = (g4 + j) * kLocalThreads + t;
             if (i < mm) {
-                L.key[0][i] = (uint16_t)((kk[j] - key_min) & mask);
+                L.key[0][i] = (uint16_t)((kk[j] - sub) & mask);
                 L.val[0][i] = vv[j];
             }
         }
     }
     __syncthreads();
-    if (mm > 0 && shift > 0) { bucket_local_pass(L, cur, mm, 0); cur ^= 1; }   // (mm, shift: uniform)
-    if (mm > 0 && shift > 8) { bucket_local_pass(L, cur, mm, 8); cur ^= 1; }
+    if (mm > 0 && width > 1u) { bucket_local_pass(L, cur, mm, 0); cur ^= 1; }   // (mm, width: uniform)
+    if (mm > 0 && width > 256u) { bucket_local_pass(L, cur, mm, 8); cur ^= 1; }
 
     // rectangles and record counts of the bucket's gaussians, now in depth order
     uint32_t *cnt = L.val[cur ^ 1];
@@ -1257,13 +1264,15 @@ extern "C" size_t gsa_depth_order_msd_workspace_bytes(int n) {
            gsa_sort_workspace_bytes(n) + (size_t)(2 * kRadix + 16) * sizeof(uint32_t) + 16;
 }
 
-extern "C" int gsa_depth_order_msd_max_shift(void) { return 16; }
+extern "C" int gsa_depth_order_msd_max_width(void) { return 65536; }
 
 extern "C" int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint32_t *tile_rects, uint32_t key_min,
-                                   int shift, uint32_t *order, uint32_t *rects, uint32_t *offsets, int32_t *block_owner,
+                                   uint32_t scale, uint32_t *order, uint32_t *rects, uint32_t *offsets, int32_t *block_owner,
                                    int n_blocks, uint32_t *ctl, uint32_t *ctl_host, uint32_t token, void *workspace,
                                    size_t workspace_bytes, gsa_stream_t stream) {
-    GSA_RETURN_IF(n < 0 || shift < 0 || shift > 16 || !ctl || n_blocks < 0 || (n_blocks > 0 && !block_owner),
+    // (scale >= 2^16: a bucket is at most 2^32 / scale + 1 <= 65537 keys wide -- 16-bit local sorts; exactly 2^16 is the
+    // power-of-two case shift = 16)
+    GSA_RETURN_IF(n < 0 || scale < 65536u || !ctl || n_blocks < 0 || (n_blocks > 0 && !block_owner),
                   GSA_ERR_INVALID_ARGUMENT);
     hipStream_t s = static_cast<hipStream_t>(stream);
     GSA_RETURN_IF(token > 0xFFFFFFu, GSA_ERR_INVALID_ARGUMENT);
@@ -1289,7 +1298,7 @@ extern "C" int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint
     g = (g + 15) & ~(uintptr_t)15;
     unsigned long long *granule = reinterpret_cast<unsigned long long *>(g);
     uint32_t *ticket = reinterpret_cast<uint32_t *>(granule + kRadix);
-    const RadixDigit dg{shift, key_min, 1};
+    const RadixDigit dg{(int)scale, key_min, 1};
     radix_hist_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(n, nullptr, depth_keys, dg, nblocks, hist, block_range);
     GSA_LAUNCH_CHECK();
     // (block 0 also reduces the key range into ctl[1..2]; block 1 zeroes the granules, the ticket and ctl[3])
@@ -1299,7 +1308,7 @@ extern "C" int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint
     radix_scatter_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(n, nullptr, depth_keys, nullptr, kbuf, vbuf, dg, nblocks,
                                                                     hist, digit_total);
     GSA_LAUNCH_CHECK();
-    depth_bucket_sort_kernel<<<kRadix, kLocalThreads, 0, s>>>(kbuf, vbuf, digit_total, key_min, shift,
+    depth_bucket_sort_kernel<<<kRadix, kLocalThreads, 0, s>>>(kbuf, vbuf, digit_total, key_min, scale,
                                                               reinterpret_cast<const uint2 *>(tile_rects), order, rects,
                                                               offsets, n_blocks > 0 ? block_owner : nullptr, n_blocks,
                                                               granule, ticket, ctl, ctl_host, token);

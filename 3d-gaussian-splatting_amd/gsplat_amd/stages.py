@@ -203,7 +203,7 @@ class TileBins:
                  keys_ok=True):
         self._tile, self._gid, self.tile_offsets = sorted_tile, sorted_gid, tile_offsets
         self.capacity, self._m, self._key, self._slot, self._n = capacity, m_known, key, slot, n
-        # what the depth ordering assumed about the visible keys -- bits an LSD sort covered, or (key_min, shift) of the
+        # what the depth ordering assumed about the visible keys -- bits an LSD sort covered, or (key_min, scale) of the
         # bucketed one; None: nothing to check -- and the result of the check
         self.key_bits, self._keys_ok = key_bits, keys_ok
 
@@ -258,7 +258,7 @@ _SHRINK_AFTER = 32
 # (grows at once, is reset after many consecutive views that need less than half of it).  The depth ordering is
 # launched for this range and the view's actual range is checked afterwards, like the record capacity.
 _KEY_RANGE = {}
-_MSD_MAX_SHIFT = int(lib.gsa_depth_order_msd_max_shift())
+_MSD_MAX_WIDTH = int(lib.gsa_depth_order_msd_max_width())
 _DEPTH_MSD_DEFAULT = os.environ.get("GSPLAT_AMD_DEPTH_MSD", "1") != "0"
 _MSD_MIN_N = 32768        # below this the 256 x 1024-thread bucket launch costs more than the LSD passes it replaces
 _MSD_MAX_N = 1_400_000    # above this an average bucket (N / 255, x1.5 for skew) no longer fits the 8192-key LDS capacity
@@ -273,21 +273,27 @@ def _key_bits_needed(lo: int, hi: int) -> int:
 
 
 def _msd_plan(lo: int, hi: int):
-    """-> (key_min, shift) of the bucketed depth ordering for keys in [lo, hi] with 1/8 of the span as margin on both
-    sides, or None when the local sorts would need more than 16 bits."""
+    """-> (key_min, scale) of the bucketed depth ordering for keys in [lo, hi] with 1/16 of the span as margin on both
+    sides -- bucket = ((key - key_min) * scale) >> 32, the 255 buckets spread evenly over the range -- or None when a
+    bucket would be wider than the 16 bits the local sorts cover."""
     if lo > hi:
         return None
-    margin = ((hi - lo) >> 3) + 1
+    margin = ((hi - lo) >> 4) + 1
     a, b = max(0, lo - margin), min(0xFFFFFFFE, hi + margin)
-    shift = max(0, (b - a).bit_length() - 8)
-    if ((b - a) >> shift) > 254:
-        shift += 1
-    return (a, shift) if shift <= _MSD_MAX_SHIFT else None
+    span = max(b - a + 1, 256)
+    scale = (255 << 32) // span          # (span >= 256: scale < 2^32)
+    if scale < (1 << 32) // _MSD_MAX_WIDTH:
+        return None
+    return (a, scale)
+
+
+def _msd_bucket(x: int, scale: int) -> int:
+    return (x * scale) >> 32
 
 
 def _note_keys(key, lo: int, hi: int, assumed, status: int = 0) -> bool:
     """Remember the depth-key range of this view; -> whether the ordering that ran was complete.  ``assumed``: the
-    number of key bits an LSD sort covered, or (key_min, shift) of a bucketed one."""
+    number of key bits an LSD sort covered, or (key_min, scale) of a bucketed one."""
     ent = _KEY_RANGE.get(key)
     if lo <= hi:
         if ent is None:
@@ -304,10 +310,10 @@ def _note_keys(key, lo: int, hi: int, assumed, status: int = 0) -> bool:
             else:
                 ent[2] = 0
     if isinstance(assumed, tuple):
-        kmin, shift = assumed
+        kmin, scale = assumed
         if status & 1:     # a depth cluster overflowed a bucket's LDS: every such call costs a repair, so back off
             _MSD_BACKOFF[key] = 64
-        return status == 0 and (lo > hi or (lo >= kmin and ((hi - kmin) >> shift) <= 254))
+        return status == 0 and (lo > hi or (lo >= kmin and _msd_bucket(hi - kmin, scale) <= 254))
     return _key_bits_needed(lo, hi) <= assumed
 
 

@@ -139,13 +139,14 @@ int gsa_depth_order(int n, const uint32_t *depth_keys, const uint32_t *tile_rect
 /* gsa_depth_order_msd: the same outputs as gsa_depth_order + gsa_scan_tiles_sorted -- order, rects, offsets (exclusive
  * scan of the record counts in depth order), block_owner (n_blocks + 1 entries as gsa_scan_tiles_rect leaves them) and
  * ctl[0] = M -- in four launches whatever the key width, for callers that know the range of the visible depth keys
- * beforehand: ONE global radix pass buckets the keys by depth range (bucket = (key - key_min) >> shift, clamped to
- * 254; the culled sentinel alone in bucket 255), then one workgroup per bucket sorts its keys in LDS on the remaining
- * `shift` (0..gsa_depth_order_msd_max_shift() = 16) low bits, gathers rectangles and counts, scans them and adds the
- * records of the buckets in front (published per bucket through one 8-byte granule; bounded spin).
+ * beforehand: ONE global radix pass buckets the keys by depth range (bucket = ((key - key_min) * scale) >> 32, clamped to
+ * 254 -- 255 buckets of equal key width 2^32 / scale <= gsa_depth_order_msd_max_width() = 65536, i.e. scale >= 65536;
+ * the culled sentinel alone in bucket 255), then one workgroup per bucket sorts its keys in LDS on their offset inside
+ * the bucket, gathers rectangles and counts, scans them and adds the records of the buckets in front (published per
+ * bucket through one 8-byte granule; bounded spin).
  * ctl[1..2] = min / max key over the visible gaussians as measured, ctl[3] = status (0 ok; bit 0: a bucket exceeded the
  * LDS capacity of 8192 keys; bit 1: a wait timed out).  The result is valid iff ctl[3] == 0, ctl[1] >= key_min and
- * (ctl[2] - key_min) >> shift <= 254 -- checked by the caller after the fact; otherwise it repeats with
+ * ((ctl[2] - key_min) * scale) >> 32 <= 254 -- checked by the caller after the fact; otherwise it repeats with
  * gsa_depth_order(key_bits = 32).  Entries of order / rects / offsets that belong to culled gaussians (they sort behind
  * every visible one and have no records) are not written.  workspace: gsa_depth_order_msd_workspace_bytes(n).
  * ctl_host (optional): four words of PINNED, device-mapped HOST memory (hipHostMalloc).  The last workgroup stores
@@ -153,8 +154,8 @@ int gsa_depth_order(int n, const uint32_t *depth_keys, const uint32_t *tile_rect
  * different from what the word holds): the caller polls word 3 for its token instead of queueing a 16-byte copy and an
  * event behind the kernel (on the bench step those cost a 4-us copy kernel and a 6-us bubble on the stream). */
 size_t gsa_depth_order_msd_workspace_bytes(int n);
-int gsa_depth_order_msd_max_shift(void);
-int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint32_t *tile_rects, uint32_t key_min, int shift,
+int gsa_depth_order_msd_max_width(void);
+int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint32_t *tile_rects, uint32_t key_min, uint32_t scale,
                         uint32_t *order, uint32_t *rects, uint32_t *offsets, int32_t *block_owner, int n_blocks,
                         uint32_t *ctl, uint32_t *ctl_host, uint32_t token, void *workspace, size_t workspace_bytes,
                         gsa_stream_t stream);

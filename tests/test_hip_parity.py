@@ -875,7 +875,7 @@ def test_bucketed_depth_order_equals_lsd_sort(gsa, n, dist):
     ref_order = torch.sort(keys, stable=True).indices
     assert torch.equal(o0.cpu().long()[:n_vis], ref_order[:n_vis])
     # bucketed ordering for the range a caller would have remembered
-    plan = S._msd_plan(lo, hi) if n_vis else (0x3F000000, 16)
+    plan = S._msd_plan(lo, hi) if n_vis else (0x3F000000, 1 << 16)
     assert plan is not None
     o1, r1, f1, b1, c1 = buffers()
     ws = torch.empty(lib.gsa_depth_order_msd_workspace_bytes(n), dtype=torch.uint8, device="cuda")
@@ -919,7 +919,7 @@ def test_bucketed_depth_order_reports_what_it_cannot_do(gsa):
     assert int(ctl[3]) & 1, "bucket overflow must be reported"
     assert not S._note_keys(("t", 0), int(ctl[1]), int(ctl[2]), plan, int(ctl[3]))
     # keys below the assumed minimum: the measured range tells
-    narrow = (0x40400000, 8)
+    narrow = (0x40400000, 1 << 24)   # (buckets 256 keys wide from there)
     check(lib.gsa_depth_order_msd(n, k32.data_ptr(), pairs.data_ptr(), narrow[0], narrow[1], out[0].data_ptr(), out[1].data_ptr(),
                                   out[2].data_ptr(), owner.data_ptr(), 63, ctl.data_ptr(), None, 0, ws.data_ptr(), ws.numel(), st), "msd")
     assert not S._note_keys(("t", 1), int(ctl[1]), int(ctl[2]), narrow, int(ctl[3]))
