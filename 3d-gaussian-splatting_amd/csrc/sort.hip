@@ -1112,6 +1112,7 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
     __shared__ BucketLds L;
     __shared__ uint32_t s_bucket;
     const int t = threadIdx.x;
+    SORT_TRACE_BEGIN();
     if (t == 0) s_bucket = atomicAdd(ticket, 1u);
     __syncthreads();
     const int d = (int)s_bucket;                       // this block's bucket, in order of arrival
@@ -1161,9 +1162,11 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
         }
     }
     __syncthreads();
+    SORT_TRACE_MARK(0);   // ticket, bucket bounds, key / value loads
     if (mm > 0 && width > 1u) { bucket_local_pass(L, cur, mm, 0); cur ^= 1; }   // (mm, width: uniform)
     if (mm > 0 && width > 256u) { bucket_local_pass(L, cur, mm, 8); cur ^= 1; }
 
+    SORT_TRACE_MARK(1);   // local passes
     // rectangles and record counts of the bucket's gaussians, now in depth order
     uint32_t *cnt = L.val[cur ^ 1];
 #pragma unroll
@@ -1187,6 +1190,7 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
         }
     }
     __syncthreads();
+    SORT_TRACE_MARK(2);   // gathers + stores of order / rects
     // exclusive scan of the counts: 8 consecutive items per thread
     constexpr int kPer = kStrides;
     uint32_t c[kPer], sum = 0, last = 0;
@@ -1203,6 +1207,7 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
     if (t == 0)
         __hip_atomic_store(&granule[d], kGranuleReady | ((unsigned long long)bucket_total << 32) | last_local,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    SORT_TRACE_MARK(3);   // scan of the counts, granule published
     // records of the buckets in front: thread t < d waits for bucket t's granule (bounded)
     uint32_t before = 0, last_k = 0;
     if (t < d) {
@@ -1220,6 +1225,7 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
     uint32_t base_total;
     block1024_excl_scan(before, L.scratch, base_total);
     const uint32_t base = base_total;                  // records in front of this bucket
+    SORT_TRACE_MARK(4);   // wait for the buckets in front
     if (culled_bucket) {                               // the last bucket: it has seen every other one
         const uint32_t lk = block1024_max(last_k, L.scratch);
         if (t == 0) {
@@ -1239,6 +1245,7 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
                 __hip_atomic_store(&ctl_host[3], (st & 0xFFu) | (token << 8), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
+        SORT_TRACE_END(3);
         return;
     }
     ex += base;
@@ -1255,6 +1262,8 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
         }
         ex += c[j];
     }
+    SORT_TRACE_MARK(5);   // offsets + block owners
+    SORT_TRACE_END(3);
 }
 
 extern "C" size_t gsa_depth_order_msd_workspace_bytes(int n) {

@@ -14,7 +14,7 @@ sc = scene.make_scene(n, seed=0, sh_degree=deg)
 leaves = [sc[k].to(dev) for k in ("means3D", "rotations", "scales", "opacities", "shs")]
 K = scene.make_intrinsics(W, H).to(dev)[None]; vm = scene.make_camera(0, 1).to(dev)[None]
 bg = torch.zeros(1, 3, device=dev)
-NK = 3
+NK = 4
 buf = torch.zeros(NK * 32768 * 16, dtype=torch.int64, device=dev)
 def step():
     with torch.no_grad():
@@ -26,7 +26,8 @@ torch.cuda.synchronize(); step(); torch.cuda.synchronize()
 tr = buf.cpu().numpy().reshape(NK, 32768, 16)
 names = {0: ("radix_scatter<u32> (last call)", ["prologue", "ranking", "reorder", "stores"]),
          1: ("radix_scatter<u16>", ["prologue", "ranking", "reorder", "stores"]),
-         2: ("emit_scatter", ["hist columns", "owners", "generation", "ranking", "reorder", "stores"])}
+         2: ("emit_scatter", ["hist columns", "owners", "generation", "ranking", "reorder", "stores"]),
+         3: ("depth_bucket_sort", ["bounds + loads", "local passes", "gathers", "count scan", "wait in front", "offsets"])}
 for k, (name, phases) in names.items():
     d = tr[k]; d = d[d[:, 1] > 0]
     if not len(d): continue
