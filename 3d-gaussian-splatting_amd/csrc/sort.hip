@@ -67,6 +67,16 @@ __device__ __forceinline__ uint32_t digit_of(uint32_t key, const RadixDigit &dg)
     return (key >> dg.shift) & (kRadix - 1);
 }
 
+// Which chunk of the input a workgroup of the histogram / scatter kernels owns.  Workgroups go to the eight XCDs round
+// robin by their index, and every XCD has its own L2: with chunk = index, the 32 blocks whose histogram words share a
+// 128-B line of the digit-major table sit on 8 different XCDs -- every line of the table is pulled into 8 L2s and its
+// partial writes meet only at the memory side.  Here the workgroups of ONE XCD own CONSECUTIVE chunks (a bijection on
+// [0, gridDim.x) for any grid size).
+__device__ __forceinline__ unsigned sort_block_id() {
+    const unsigned p = blockIdx.x, nb = gridDim.x, q = nb >> 3, r = nb & 7u, x = p & 7u;
+    return x * q + min(x, r) + (p >> 3);
+}
+
 // ---- pass 1: per-block digit histogram, written digit-major: hist[d * nblocks + block] -------------
 // Plain per-lane LDS atomics: measured faster than aggregating same-digit lanes with ballots first (the LDS
 // resolves same-address adds of one instruction cheaply; the 8 ballots per key cost more than they save).
@@ -82,9 +92,9 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(int n_cap, con
     __shared__ uint32_t h[kRadix];
     __shared__ uint32_t s_lo, s_hi;
     const int n = resolve_count(n_cap, n_dev);
-    const long base = (long)blockIdx.x * kSortChunk;
+    const long base = (long)sort_block_id() * kSortChunk;
     if (base >= n) {   // capacity launch: nothing live in this block
-        hist[(long)threadIdx.x * nblocks + blockIdx.x] = 0;
+        hist[(long)threadIdx.x * nblocks + sort_block_id()] = 0;
         return;
     }
     h[threadIdx.x] = 0;
@@ -148,8 +158,8 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(int n_cap, con
         if ((threadIdx.x & 63) == 0) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
     }
     __syncthreads();
-    hist[(long)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
-    if (block_range && threadIdx.x == 0) { block_range[blockIdx.x] = s_lo; block_range[nblocks + blockIdx.x] = s_hi; }
+    hist[(long)threadIdx.x * nblocks + sort_block_id()] = h[threadIdx.x];
+    if (block_range && threadIdx.x == 0) { block_range[sort_block_id()] = s_lo; block_range[nblocks + sort_block_id()] = s_hi; }
 }
 
 // ---- pass 2: one block per digit: exclusive scan of its row in place, row total out -----------------
@@ -284,11 +294,11 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     __shared__ __attribute__((aligned(16))) uint32_t s_val[kSortChunk];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n = resolve_count(n_cap, n_dev);
-    if ((long)blockIdx.x * kSortChunk >= n) return;   // whole block beyond the live items (capacity launch)
+    if ((long)sort_block_id() * kSortChunk >= n) return;   // whole block beyond the live items (capacity launch)
     SORT_TRACE_BEGIN();
 
     // (keys and values first: their latency hides behind the histogram columns and the two block scans)
-    const long base = (long)blockIdx.x * kSortChunk + wave * (kSortChunk / 4);
+    const long base = (long)sort_block_id() * kSortChunk + wave * (kSortChunk / 4);
     uint32_t k[kSortItems], v[kSortItems], rk[kSortItems];
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
@@ -300,8 +310,8 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     {   // digit t: global base (exclusive scan of digit totals + offset of this block inside the digit) and
         // block-local base (exclusive scan of this block's own digit counts, recovered from the scanned rows)
         uint32_t tot, dt = digit_total[t];
-        const uint32_t mine = hist[(long)t * nblocks + blockIdx.x];
-        const uint32_t next = (int)blockIdx.x + 1 < nblocks ? hist[(long)t * nblocks + blockIdx.x + 1] : dt;
+        const uint32_t mine = hist[(long)t * nblocks + sort_block_id()];
+        const uint32_t next = (int)sort_block_id() + 1 < nblocks ? hist[(long)t * nblocks + sort_block_id() + 1] : dt;
         const uint32_t dbase = block_excl_scan(dt, scratch, tot);
         const uint32_t lbase = block_excl_scan(next - mine, scratch, tot);
         gbase[t] = dbase + mine;
@@ -340,7 +350,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     }
     __syncthreads();
     SORT_TRACE_MARK(2);   // reorder through LDS
-    const int m = (int)min((long)kSortChunk, (long)n - (long)blockIdx.x * kSortChunk);
+    const int m = (int)min((long)kSortChunk, (long)n - (long)sort_block_id() * kSortChunk);
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         int lp = r * kSortThreads + t;
@@ -622,14 +632,14 @@ struct EmitLoads {
 __device__ __forceinline__ EmitLoads emit_owner_loads(const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ rects,
                                                       const uint32_t *__restrict__ order,
                                                       const int32_t *__restrict__ block_owner, int n_owner_blocks,
-                                                      uint32_t m_total, bool want_gid) {
+                                                      uint32_t m_total, bool want_gid, unsigned bid) {
     EmitLoads el;
-    const uint32_t slot0 = blockIdx.x * (uint32_t)kSortChunk;
+    const uint32_t slot0 = bid * (uint32_t)kSortChunk;
     const uint32_t slot_end = slot0 + min((uint32_t)kSortChunk, m_total - slot0);
     // owner of the first slot (noted by the scan), and the last gaussian that can start inside this block: the owner
     // of the next block's first slot, or the last gaussian with records when this is the last live block
-    el.k_lo = block_owner[blockIdx.x];
-    el.k_hi = slot_end < m_total ? block_owner[blockIdx.x + 1] : block_owner[n_owner_blocks];
+    el.k_lo = block_owner[bid];
+    el.k_hi = slot_end < m_total ? block_owner[bid + 1] : block_owner[n_owner_blocks];
 #pragma unroll
     for (int j = 0; j < kEmitStage / kSortThreads; ++j) {
         const int k = min(el.k_lo + j * kSortThreads + (int)threadIdx.x, el.k_hi);   // (clamped, not predicated)
@@ -645,10 +655,10 @@ __device__ __forceinline__ EmitLoads emit_owner_loads(const uint32_t *__restrict
 // up in global memory.  want_gid: the histogram does not need the gaussian indices.
 __device__ __forceinline__ EmitBlock emit_owners(const EmitLoads &el, const uint32_t *__restrict__ offsets,
                                                   uint32_t m_total, uint32_t *__restrict__ s_own,
-                                                  uint4 *__restrict__ s_g, uint32_t *__restrict__ scratch) {
+                                                  uint4 *__restrict__ s_g, uint32_t *__restrict__ scratch, unsigned bid) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     EmitBlock eb;
-    eb.slot0 = blockIdx.x * (uint32_t)kSortChunk;
+    eb.slot0 = bid * (uint32_t)kSortChunk;
     eb.live = min((uint32_t)kSortChunk, m_total - eb.slot0);
     eb.k_lo = el.k_lo;
     const int k_hi = el.k_hi;
@@ -733,13 +743,13 @@ __global__ __launch_bounds__(kSortThreads) void emit_hist_kernel(int n, const ui
     __shared__ __attribute__((aligned(16))) uint32_t s_own[kSortChunk];
     __shared__ uint4 s_g[kEmitStage];
     const uint32_t m_total = m_dev ? min(m_cap, *m_dev) : m_cap;
-    if ((uint64_t)blockIdx.x * kSortChunk >= m_total) {
-        hist[(long)threadIdx.x * nblocks + blockIdx.x] = 0;
+    if ((uint64_t)sort_block_id() * kSortChunk >= m_total) {
+        hist[(long)threadIdx.x * nblocks + sort_block_id()] = 0;
         return;
     }
     h[threadIdx.x] = 0;
-    const EmitLoads el = emit_owner_loads(offsets, rects, order, block_owner, nblocks, m_total, false);
-    const EmitBlock eb = emit_owners(el, offsets, m_total, s_own, s_g, scratch);
+    const EmitLoads el = emit_owner_loads(offsets, rects, order, block_owner, nblocks, m_total, false, sort_block_id());
+    const EmitBlock eb = emit_owners(el, offsets, m_total, s_own, s_g, scratch, sort_block_id());
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         const uint32_t slot = r * kSortThreads + threadIdx.x;
@@ -750,7 +760,7 @@ __global__ __launch_bounds__(kSortThreads) void emit_hist_kernel(int n, const ui
         }
     }
     __syncthreads();
-    hist[(long)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    hist[(long)threadIdx.x * nblocks + sort_block_id()] = h[threadIdx.x];
 }
 
 // radix_scatter_kernel (shift 0) with generated instead of loaded items; keys leave as 16-bit tile ids
@@ -775,7 +785,9 @@ __global__ __launch_bounds__(kSortThreads) void emit_scatter_kernel(
     const uint32_t m_total = m_dev ? min(m_cap, *m_dev) : m_cap;
     if ((uint64_t)blockIdx.x * kSortChunk >= m_total) return;
     SORT_TRACE_BEGIN();
-    const EmitLoads el = emit_owner_loads(offsets, rects, order, block_owner, nblocks, m_total, true);   // (in flight
+    // (chunk = workgroup index here, not sort_block_id(): with the XCD-wise assignment this kernel's scattered run
+    // stores arrive from eight distant fronts of every digit's segment at once -- measured 41 -> 45 us)
+    const EmitLoads el = emit_owner_loads(offsets, rects, order, block_owner, nblocks, m_total, true, blockIdx.x);   // (in flight
                                                                                                           // under the scans)
     {
         uint32_t tot, dt = digit_total[t];
@@ -787,7 +799,7 @@ __global__ __launch_bounds__(kSortThreads) void emit_scatter_kernel(
         lexcl[t] = lbase;
     }
     SORT_TRACE_MARK(0);   // histogram columns + block scans
-    const EmitBlock eb = emit_owners(el, offsets, m_total, s_val, s_g, scratch);
+    const EmitBlock eb = emit_owners(el, offsets, m_total, s_val, s_g, scratch, blockIdx.x);
     SORT_TRACE_MARK(1);   // slot owners
     const uint32_t wbase = wave * (kSortChunk / 4);
     uint32_t k[kSortItems], v[kSortItems], rk[kSortItems];
