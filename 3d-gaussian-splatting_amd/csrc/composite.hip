@@ -90,6 +90,24 @@ __device__ __forceinline__ void trace_end(const TraceState &ts, int kernel, int 
 // `tile_order` (optional, gsa_tile_schedule): a permutation of each band that puts the tiles with long record
 // lists first, so that the launch ends on its short jobs (a wave runs for ~1/5 of the whole kernel on a full tile;
 // in index order the last round of waves left the chip a fifth empty).  Entries of -1 pad the last band.
+// The record list a (tile, quadrant) wave walks.  bin_shift 0: the tile's own list, tile_offsets[tile .. tile + 1], four
+// quadrant slices per list.  bin_shift 1: the records were binned into 32 x 32 BINS (half the records to sort; a wave
+// re-tests every record against its 8 x 8 quadrant anyway): the four tiles of a bin share its list, tile_offsets is
+// indexed by bin, and the bin has 16 quadrant slices (4 * sub-tile + quadrant).
+__device__ __forceinline__ void tile_list(const int32_t *__restrict__ tile_offsets, int tile, int tile_w, int bin_shift,
+                                          int q, int &start, int &end, int &slice) {
+    int idx = tile;
+    slice = q;
+    if (bin_shift) {
+        const int tx = tile % tile_w, ty = tile / tile_w, m = (1 << bin_shift) - 1;
+        const int bin_w = (tile_w + m) >> bin_shift;
+        idx = (ty >> bin_shift) * bin_w + (tx >> bin_shift);
+        slice = ((((ty & m) << bin_shift) | (tx & m)) << 2) | q;
+    }
+    start = __builtin_amdgcn_readfirstlane(tile_offsets[idx]);
+    end = __builtin_amdgcn_readfirstlane(tile_offsets[idx + 1]);
+}
+
 __device__ __forceinline__ void wave_unit(int b, int n_tiles, const int32_t *__restrict__ tile_order, int &tile, int &q) {
     const int chunk = (n_tiles + 7) >> 3;
     const int within = b >> 3;
@@ -363,7 +381,7 @@ __device__ __forceinline__ bool walk_fwd(const Staged<F4> &st, int n, float pyf,
 // sweep then visits exactly those, without a reach test and in full batches.
 template <int CH, int LISTS>
 __global__ __launch_bounds__(kWave, GSA_FWD_WAVES) void composite_fwd_kernel(
-    int width, int height, int tile_w, int n_tiles, const float *__restrict__ splat,
+    int width, int height, int tile_w, int n_tiles, int bin_shift, const float *__restrict__ splat,
     const uint32_t *__restrict__ sorted_gid, const int32_t *__restrict__ tile_offsets,
     const float *__restrict__ background, const int32_t *__restrict__ tile_order, float *__restrict__ render,
     float *__restrict__ alpha_out, float *__restrict__ final_T, int32_t *__restrict__ last_id,
@@ -390,8 +408,8 @@ __global__ __launch_bounds__(kWave, GSA_FWD_WAVES) void composite_fwd_kernel(
     const int px_ = qx + (lane & 7), py_ = qy + (lane >> 3);
     const bool inside = px_ < width && py_ < height;
     const float pxf = px_ + 0.5f, pyf = py_ + 0.5f, qx0 = qx + 0.5f, qy0 = qy + 0.5f;
-    const int start = __builtin_amdgcn_readfirstlane(tile_offsets[tile]);
-    const int end = __builtin_amdgcn_readfirstlane(tile_offsets[tile + 1]);
+    int start, end, slice;   // this tile's record list (its bin's), and which of the bin's quadrant slices is this wave's
+    tile_list(tile_offsets, tile, tile_w, bin_shift, q, start, end, slice);
 
     FwdPixel<CH> px;
     px.T = 1.f; px.Tend = 1.f; px.dead = inside ? 0u : kSign; px.last = -1;
@@ -399,7 +417,7 @@ __global__ __launch_bounds__(kWave, GSA_FWD_WAVES) void composite_fwd_kernel(
 #pragma unroll
     for (int k = 0; k < CH; ++k) px.acc[k] = 0.f;
     int listed = 0;   // LISTS: entries written to this quadrant's list so far (wave-uniform)
-    uint32_t *my_list = LISTS ? quad_list + 4 * (size_t)start + (size_t)q * (size_t)(end - start) : nullptr;
+    uint32_t *my_list = LISTS ? quad_list + (((size_t)start << 2) << (2 * bin_shift)) + (size_t)slice * (size_t)(end - start) : nullptr;
 
     if (__ballot(inside) != 0ull && start < end) {
         // software pipeline, two batches deep: ids of batch j+2 and records of batch j+1 are in flight while
@@ -599,7 +617,7 @@ __device__ __forceinline__ void walk_bwd(const Staged<F4> &st, int n, int lane, 
 // opacity gradients are linear in them (project_bwd finishes that per gaussian, once, instead of per pixel).
 template <int CH>
 __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_kernel(
-    int width, int height, int tile_w, int n_tiles, const float *__restrict__ splat,
+    int width, int height, int tile_w, int n_tiles, int bin_shift, const float *__restrict__ splat,
     const uint32_t *__restrict__ sorted_gid, const int32_t *__restrict__ tile_offsets,
     const float *__restrict__ background, const int32_t *__restrict__ tile_order, const float *__restrict__ final_T,
     const int32_t *__restrict__ last_id, const float *__restrict__ v_render, const float *__restrict__ v_alpha,
@@ -612,8 +630,8 @@ __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_kernel(
     wave_unit(blockIdx.x, n_tiles, tile_order, tile, q);
     if (tile >= n_tiles) return;
     const int lane = threadIdx.x;
-    const int start = __builtin_amdgcn_readfirstlane(tile_offsets[tile]);
-    const int end = __builtin_amdgcn_readfirstlane(tile_offsets[tile + 1]);
+    int start, end, slice;   // this tile's record list (its bin's), and which of the bin's quadrant slices is this wave's
+    tile_list(tile_offsets, tile, tile_w, bin_shift, q, start, end, slice);
     if (end <= start) return;
     GSA_TRACE_BEGIN();
     const int tx = tile % tile_w, ty = tile / tile_w;
@@ -702,7 +720,7 @@ __device__ __forceinline__ int stage_listed(Staged<F4> &st, int lane, const Row 
 
 template <int CH>
 __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_list_kernel(
-    int width, int height, int tile_w, int n_tiles, const float *__restrict__ splat,
+    int width, int height, int tile_w, int n_tiles, int bin_shift, const float *__restrict__ splat,
     const uint32_t *__restrict__ sorted_gid, const int32_t *__restrict__ tile_offsets,
     const float *__restrict__ background, const int32_t *__restrict__ tile_order, const float *__restrict__ final_T,
     const int32_t *__restrict__ last_id, const float *__restrict__ v_render, const float *__restrict__ v_alpha,
@@ -717,9 +735,9 @@ __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_list_kerne
     const int lane = threadIdx.x;
     const int count = __builtin_amdgcn_readfirstlane(quad_count[4 * tile + q]);
     if (count <= 0) return;
-    const int start = __builtin_amdgcn_readfirstlane(tile_offsets[tile]);
-    const int end = __builtin_amdgcn_readfirstlane(tile_offsets[tile + 1]);
-    const uint32_t *my_list = quad_list + 4 * (size_t)start + (size_t)q * (size_t)(end - start);
+    int start, end, slice;   // this tile's record list (its bin's), and which of the bin's quadrant slices is this wave's
+    tile_list(tile_offsets, tile, tile_w, bin_shift, q, start, end, slice);
+    const uint32_t *my_list = quad_list + (((size_t)start << 2) << (2 * bin_shift)) + (size_t)slice * (size_t)(end - start);
     GSA_TRACE_BEGIN();
     const int tx = tile % tile_w, ty = tile / tile_w;
     const int qx = tx * kTile + (q & 1) * 8, qy = ty * kTile + (q >> 1) * 8;
@@ -867,7 +885,7 @@ __device__ __forceinline__ void sweep16(const Staged<F4> &st, PixState<CH> &ps, 
 
 template <int CH>
 __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_scan_kernel(
-    int width, int height, int tile_w, int n_tiles, const float *__restrict__ splat,
+    int width, int height, int tile_w, int n_tiles, int bin_shift, const float *__restrict__ splat,
     const uint32_t *__restrict__ sorted_gid, const int32_t *__restrict__ tile_offsets,
     const float *__restrict__ background, const int32_t *__restrict__ tile_order, const float *__restrict__ final_T,
     const int32_t *__restrict__ last_id, const float *__restrict__ v_render, const float *__restrict__ v_alpha,
@@ -883,9 +901,9 @@ __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_scan_kerne
     const int lane = threadIdx.x;
     const int count = __builtin_amdgcn_readfirstlane(quad_count[4 * tile + q]);
     if (count <= 0) return;
-    const int start = __builtin_amdgcn_readfirstlane(tile_offsets[tile]);
-    const int end = __builtin_amdgcn_readfirstlane(tile_offsets[tile + 1]);
-    const uint32_t *my_list = quad_list + 4 * (size_t)start + (size_t)q * (size_t)(end - start);
+    int start, end, slice;   // this tile's record list (its bin's), and which of the bin's quadrant slices is this wave's
+    tile_list(tile_offsets, tile, tile_w, bin_shift, q, start, end, slice);
+    const uint32_t *my_list = quad_list + (((size_t)start << 2) << (2 * bin_shift)) + (size_t)slice * (size_t)(end - start);
     const int tx = tile % tile_w, ty = tile / tile_w;
     const int qx = tx * kTile + (q & 1) * 8, qy = ty * kTile + (q >> 1) * 8;
     const int px = qx + (lane & 7), py = qy + (lane >> 3);
@@ -1010,7 +1028,7 @@ struct TwoPhase {
 
 template <int CH>
 __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_2p_kernel(
-    int width, int height, int tile_w, int n_tiles, const float *__restrict__ splat,
+    int width, int height, int tile_w, int n_tiles, int bin_shift, const float *__restrict__ splat,
     const uint32_t *__restrict__ sorted_gid, const int32_t *__restrict__ tile_offsets,
     const float *__restrict__ background, const int32_t *__restrict__ tile_order, const float *__restrict__ final_T,
     const int32_t *__restrict__ last_id, const float *__restrict__ v_render, const float *__restrict__ v_alpha,
@@ -1026,9 +1044,9 @@ __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_2p_kernel(
     const int lane = threadIdx.x;
     const int count = __builtin_amdgcn_readfirstlane(quad_count[4 * tile + q]);
     if (count <= 0) return;
-    const int start = __builtin_amdgcn_readfirstlane(tile_offsets[tile]);
-    const int end = __builtin_amdgcn_readfirstlane(tile_offsets[tile + 1]);
-    const uint32_t *my_list = quad_list + 4 * (size_t)start + (size_t)q * (size_t)(end - start);
+    int start, end, slice;   // this tile's record list (its bin's), and which of the bin's quadrant slices is this wave's
+    tile_list(tile_offsets, tile, tile_w, bin_shift, q, start, end, slice);
+    const uint32_t *my_list = quad_list + (((size_t)start << 2) << (2 * bin_shift)) + (size_t)slice * (size_t)(end - start);
     const int tx = tile % tile_w, ty = tile / tile_w;
     const int qx = tx * kTile + (q & 1) * 8, qy = ty * kTile + (q >> 1) * 8;
     const int px = qx + (lane & 7), py = qy + (lane >> 3);
@@ -1215,14 +1233,17 @@ __device__ __forceinline__ void bucket_starts(const int *__restrict__ cnt, int *
 
 constexpr int kSchedThreads = 1024, kSchedBuckets = 64;
 __global__ __launch_bounds__(kSchedThreads) void tile_schedule_kernel(int n_tiles, const int32_t *__restrict__ tile_offsets,
-                                                                      int32_t *__restrict__ tile_order) {
+                                                                      int32_t *__restrict__ tile_order, int tile_w,
+                                                                      int bin_shift) {
     __shared__ int cnt[kSchedBuckets], first[kSchedBuckets];
     const int chunk = (n_tiles + 7) >> 3;
     const int lo = blockIdx.x * chunk, hi = min(n_tiles, lo + chunk);
     if (threadIdx.x < kSchedBuckets) cnt[threadIdx.x] = 0;
     __syncthreads();
     auto bucket = [&](int t) {
-        const int len = tile_offsets[t + 1] - tile_offsets[t];
+        int idx = t;   // (the list a tile walks is its bin's: see tile_list)
+        if (bin_shift) idx = ((t / tile_w) >> bin_shift) * ((tile_w + (1 << bin_shift) - 1) >> bin_shift) + ((t % tile_w) >> bin_shift);
+        const int len = tile_offsets[idx + 1] - tile_offsets[idx];
         return kSchedBuckets - 1 - min(kSchedBuckets - 1, len >> 6);   // bucket 0 = longest lists
     };
     for (int t = lo + threadIdx.x; t < hi; t += kSchedThreads) atomicAdd(&cnt[bucket(t)], 1);
@@ -1283,9 +1304,14 @@ extern "C" int gsa_composite_bwd_prepare(long long n, float *v_splat, int n_tile
     return GSA_OK;
 }
 
-extern "C" int gsa_tile_schedule(int n_tiles, const int32_t *tile_offsets, int32_t *tile_order, gsa_stream_t stream) {
-    GSA_RETURN_IF(n_tiles <= 0 || !tile_offsets || !tile_order, GSA_ERR_INVALID_ARGUMENT);
-    tile_schedule_kernel<<<8, kSchedThreads, 0, static_cast<hipStream_t>(stream)>>>(n_tiles, tile_offsets, tile_order);
+static int bin_shift_of(int bin_tile) { return bin_tile == 2 * kTile ? 1 : (bin_tile == 0 || bin_tile == kTile ? 0 : -1); }
+
+extern "C" int gsa_tile_schedule(int n_tiles, const int32_t *tile_offsets, int32_t *tile_order, int tile_w, int bin_tile,
+                                 gsa_stream_t stream) {
+    GSA_RETURN_IF(n_tiles <= 0 || !tile_offsets || !tile_order || bin_shift_of(bin_tile) < 0, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(bin_shift_of(bin_tile) > 0 && (tile_w <= 0 || n_tiles % tile_w != 0), GSA_ERR_INVALID_ARGUMENT);
+    tile_schedule_kernel<<<8, kSchedThreads, 0, static_cast<hipStream_t>(stream)>>>(n_tiles, tile_offsets, tile_order,
+                                                                                    tile_w, bin_shift_of(bin_tile));
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }
@@ -1300,8 +1326,10 @@ extern "C" int gsa_composite_fwd(int width, int height, int channels, const floa
                                  const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
                                  const int32_t *tile_order, float *render, float *alpha, float *final_T,
                                  int32_t *last_id, uint32_t *quad_list, int32_t *quad_count, float *v_splat_zero,
-                                 long long n_zero_rows, gsa_stream_t stream) {
+                                 long long n_zero_rows, int bin_tile, gsa_stream_t stream) {
     GSA_RETURN_IF(width <= 0 || height <= 0 || (channels != 3 && channels != 4), GSA_ERR_INVALID_ARGUMENT);
+    const int bin_shift = bin_shift_of(bin_tile);
+    GSA_RETURN_IF(bin_shift < 0, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(!tile_offsets || !render || !alpha || !final_T || !last_id, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF((quad_list == nullptr) != (quad_count == nullptr), GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(n_zero_rows < 0 || (reinterpret_cast<uintptr_t>(v_splat_zero) & 15) != 0, GSA_ERR_INVALID_ARGUMENT);
@@ -1312,7 +1340,7 @@ extern "C" int gsa_composite_fwd(int width, int height, int channels, const floa
     const int grid = 32 * gsa_div_up(n_tiles, 8);   // one wave per (tile, quadrant)
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define GSA_FWD_LAUNCH(C, L)                                                                                          \
-    composite_fwd_kernel<C, L><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid, tile_offsets, \
+    composite_fwd_kernel<C, L><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid, tile_offsets, \
                                                      background, tile_order, render, alpha, final_T, last_id,         \
                                                      quad_list, quad_count, zero4, n_zero4)
     if (quad_list) {
@@ -1328,18 +1356,21 @@ extern "C" int gsa_composite_fwd(int width, int height, int channels, const floa
 extern "C" int gsa_composite_bwd(int width, int height, int channels, const float *splat,
                                  const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
                                  const int32_t *tile_order, const float *final_T, const int32_t *last_id,
-                                 const float *v_render, const float *v_alpha, float *v_splat, gsa_stream_t stream) {
+                                 const float *v_render, const float *v_alpha, float *v_splat, int bin_tile,
+                                 gsa_stream_t stream) {
     GSA_RETURN_IF(width <= 0 || height <= 0 || (channels != 3 && channels != 4), GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(!tile_offsets || !final_T || !last_id || !v_render || !v_splat, GSA_ERR_INVALID_ARGUMENT);
+    const int bin_shift = bin_shift_of(bin_tile);
+    GSA_RETURN_IF(bin_shift < 0, GSA_ERR_INVALID_ARGUMENT);
     const int tile_w = gsa_div_up(width, kTile), tile_h = gsa_div_up(height, kTile);
     const int n_tiles = tile_w * tile_h;
     const int grid = 32 * gsa_div_up(n_tiles, 8);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (channels == 3)
-        composite_bwd_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid, tile_offsets,
+        composite_bwd_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid, tile_offsets,
                                                       background, tile_order, final_T, last_id, v_render, v_alpha, v_splat);
     else
-        composite_bwd_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid, tile_offsets,
+        composite_bwd_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid, tile_offsets,
                                                       background, tile_order, final_T, last_id, v_render, v_alpha, v_splat);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
@@ -1350,10 +1381,12 @@ extern "C" int gsa_composite_bwd_lists(int width, int height, int channels, cons
                                        const float *background, const int32_t *tile_order, const float *final_T,
                                        const int32_t *last_id, const float *v_render, const float *v_alpha,
                                        const uint32_t *quad_list, const int32_t *quad_count, float *v_splat,
-                                       gsa_stream_t stream) {
+                                       int bin_tile, gsa_stream_t stream) {
     GSA_RETURN_IF(width <= 0 || height <= 0 || (channels != 3 && channels != 4), GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(!tile_offsets || !final_T || !last_id || !v_render || !v_splat || !quad_list || !quad_count,
                   GSA_ERR_INVALID_ARGUMENT);
+    const int bin_shift = bin_shift_of(bin_tile);
+    GSA_RETURN_IF(bin_shift < 0, GSA_ERR_INVALID_ARGUMENT);
     const int tile_w = gsa_div_up(width, kTile), tile_h = gsa_div_up(height, kTile);
     const int n_tiles = tile_w * tile_h;
     const int grid = 32 * gsa_div_up(n_tiles, 8);
@@ -1364,11 +1397,11 @@ extern "C" int gsa_composite_bwd_lists(int width, int height, int channels, cons
     const int mode = mode_env ? atoi(mode_env) : 2;
     if (mode == 2) {
         if (channels == 3)
-            composite_bwd_2p_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid,
+            composite_bwd_2p_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid,
                                                              tile_offsets, background, tile_order, final_T, last_id,
                                                              v_render, v_alpha, quad_list, quad_count, v_splat);
         else
-            composite_bwd_2p_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid,
+            composite_bwd_2p_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid,
                                                              tile_offsets, background, tile_order, final_T, last_id,
                                                              v_render, v_alpha, quad_list, quad_count, v_splat);
         GSA_LAUNCH_CHECK();
@@ -1376,22 +1409,22 @@ extern "C" int gsa_composite_bwd_lists(int width, int height, int channels, cons
     }
     if (mode == 1) {
         if (channels == 3)
-            composite_bwd_scan_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid,
+            composite_bwd_scan_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid,
                                                                tile_offsets, background, tile_order, final_T, last_id,
                                                                v_render, v_alpha, quad_list, quad_count, v_splat);
         else
-            composite_bwd_scan_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid,
+            composite_bwd_scan_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid,
                                                                tile_offsets, background, tile_order, final_T, last_id,
                                                                v_render, v_alpha, quad_list, quad_count, v_splat);
         GSA_LAUNCH_CHECK();
         return GSA_OK;
     }
     if (channels == 3)
-        composite_bwd_list_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid, tile_offsets,
+        composite_bwd_list_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid, tile_offsets,
                                                            background, tile_order, final_T, last_id, v_render, v_alpha,
                                                            quad_list, quad_count, v_splat);
     else
-        composite_bwd_list_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, splat, sorted_gid, tile_offsets,
+        composite_bwd_list_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid, tile_offsets,
                                                            background, tile_order, final_T, last_id, v_render, v_alpha,
                                                            quad_list, quad_count, v_splat);
     GSA_LAUNCH_CHECK();

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kBlock, GSA_PROJ_FWD_WAVES) void project_fwd_kernel
     const float *__restrict__ viewmat, const float *__restrict__ intrin, int width, int height, int tile_w,
     int tile_h, int cull_mode, float *__restrict__ splat, int32_t *__restrict__ radii,
     int32_t *__restrict__ tiles_touched, uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ tile_rects,
-    float *__restrict__ sh_aux) {
+    float *__restrict__ sh_aux, int bin_tile) {
     __shared__ float4 sh_lds[STAGE ? (kBlock / 64) * kWaveLds : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Blocks walk the gaussians from the LAST to the first (GSA_PROJ_FWD_REVERSE): the kernel that ran before this one in
@@ -170,6 +170,7 @@ __global__ __launch_bounds__(kBlock, GSA_PROJ_FWD_WAVES) void project_fwd_kernel
     float4 aux[3] = {o0, o0, o0};
     int rx = 0, ry = 0, count = 0;
     uint32_t key = 0xFFFFFFFFu, rect = 0u;
+    uint2 bin_pair = make_uint2(0u, 0u);   // (packed rectangle, record count) in BIN tiles -- what the fused binning reads
     if (visible) {
     // ---- colour (A.3)
     float r, g, b;
@@ -234,6 +235,14 @@ __global__ __launch_bounds__(kBlock, GSA_PROJ_FWD_WAVES) void project_fwd_kernel
     // 10 bits) -- tile_emit then needs this one line per gaussian instead of the mean AND the radii
     const bool packable = tile_w < 1024 && tile_h < 1024;
     rect = packable ? ((uint32_t)tr.x0 | ((uint32_t)tr.y0 << 10) | ((uint32_t)(tr.x1 - tr.x0) << 20)) : 0u;
+    bin_pair = make_uint2(count > 0 ? rect : 0u, (uint32_t)count);
+    if (bin_tile != GSA_TILE_SIZE) {   // coarser bins (cull_mode 0 only): the same rule on a grid of bin_tile pixels
+        const int bw = (width + bin_tile - 1) / bin_tile, bh = (height + bin_tile - 1) / bin_tile;
+        const GsaTileRect br = gsa_tile_rect(p.mx, p.my, rx, ry, bw, bh, bin_tile);
+        const int bc = (br.x1 - br.x0) * (br.y1 - br.y0);
+        bin_pair = make_uint2(bc > 0 ? ((uint32_t)br.x0 | ((uint32_t)br.y0 << 10) | ((uint32_t)(br.x1 - br.x0) << 20)) : 0u,
+                              (uint32_t)bc);
+    }
     o0 = make_float4(p.mx, p.my, p.qa, p.qb);
     o1 = make_float4(p.qc, opac, r, g);
     o2 = make_float4(b, p.z, sig_max, __uint_as_float(rect));
@@ -283,7 +292,7 @@ __global__ __launch_bounds__(kBlock, GSA_PROJ_FWD_WAVES) void project_fwd_kernel
     tiles_touched[i] = count;
     depth_keys[i] = key;
     // dense (rectangle, count) pairs for the fused binning: one 8-B gather per gaussian brings both into depth order
-    if (tile_rects) reinterpret_cast<uint2 *>(tile_rects)[i] = make_uint2(count > 0 ? rect : 0u, (uint32_t)count);
+    if (tile_rects) reinterpret_cast<uint2 *>(tile_rects)[i] = bin_pair;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -602,18 +611,20 @@ template <int DEG>
 int launch_fwd(bool stage, int n, const float *means, const float *quats, const float *scales,
                const float *opacities, const float *colors, int sh_coeffs, const float *viewmat,
                const float *intrin, int width, int height, int cull_mode, float *splat, int32_t *radii,
-               int32_t *tiles_touched, uint32_t *depth_keys, uint32_t *tile_rects, float *sh_aux, hipStream_t s) {
+               int32_t *tiles_touched, uint32_t *depth_keys, uint32_t *tile_rects, float *sh_aux, int bin_tile,
+               hipStream_t s) {
     int tile_w = gsa_div_up(width, GSA_TILE_SIZE), tile_h = gsa_div_up(height, GSA_TILE_SIZE);
     dim3 grid(gsa_div_up(n, kBlock)), block(kBlock);
     if (stage)
         project_fwd_kernel<DEG, true><<<grid, block, 0, s>>>(n, means, quats, scales, opacities, colors, sh_coeffs,
                                                              viewmat, intrin, width, height, tile_w, tile_h, cull_mode,
-                                                             splat, radii, tiles_touched, depth_keys, tile_rects, sh_aux);
+                                                             splat, radii, tiles_touched, depth_keys, tile_rects, sh_aux,
+                                                             bin_tile);
     else
         project_fwd_kernel<DEG, false><<<grid, block, 0, s>>>(n, means, quats, scales, opacities, colors, sh_coeffs,
                                                               viewmat, intrin, width, height, tile_w, tile_h,
                                                               cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects,
-                                                              sh_aux);
+                                                              sh_aux, bin_tile);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }
@@ -662,11 +673,14 @@ extern "C" int gsa_project_fwd(int n, const float *means, const float *quats, co
                                const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
                                const float *viewmat, const float *intrin, int width, int height, int cull_mode,
                                float *splat, int32_t *radii, int32_t *tiles_touched, uint32_t *depth_keys,
-                               uint32_t *tile_rects, float *sh_aux, gsa_stream_t stream) {
+                               uint32_t *tile_rects, float *sh_aux, int bin_tile, gsa_stream_t stream) {
     GSA_RETURN_IF(n < 0 || width <= 0 || height <= 0, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_degree < -1 || sh_degree > 3, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_degree >= 0 && sh_coeffs < (sh_degree + 1) * (sh_degree + 1), GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(cull_mode != 0 && cull_mode != 1, GSA_ERR_INVALID_ARGUMENT);
+    if (bin_tile == 0) bin_tile = GSA_TILE_SIZE;
+    GSA_RETURN_IF((bin_tile != GSA_TILE_SIZE && bin_tile != 2 * GSA_TILE_SIZE) || (bin_tile != GSA_TILE_SIZE && cull_mode != 0),
+                  GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF((reinterpret_cast<uintptr_t>(tile_rects) & 7) != 0 || (reinterpret_cast<uintptr_t>(radii) & 7) != 0 ||
                       (reinterpret_cast<uintptr_t>(splat) & 15) != 0 || (reinterpret_cast<uintptr_t>(sh_aux) & 15) != 0,
                   GSA_ERR_INVALID_ARGUMENT);
@@ -679,7 +693,7 @@ extern "C" int gsa_project_fwd(int n, const float *means, const float *quats, co
     bool stage = can_stage(colors, sh_degree, sh_coeffs) && sh_degree >= 1;
 #define GSA_FWD(D)                                                                                              \
     return launch_fwd<D>(stage, n, means, quats, scales, opacities, colors, sh_coeffs, viewmat, intrin, width, \
-                         height, cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects, sh_aux, s)
+                         height, cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects, sh_aux, bin_tile, s)
     switch (sh_degree) {
         case -1: GSA_FWD(-1);
         case 0: GSA_FWD(0);

@@ -173,8 +173,11 @@ __device__ __forceinline__ void gsa_sh_basis_vjp(float x, float y, float z, cons
 // ---- tile rectangle and the optional exact ellipse-vs-tile test --------------------------------
 struct GsaTileRect { int x0, y0, x1, y1; };
 
-__device__ __forceinline__ GsaTileRect gsa_tile_rect(float mx, float my, int rx, int ry, int tile_w, int tile_h) {
-    const float inv = 1.0f / GSA_TILE_SIZE;
+// (tile_size: GSA_TILE_SIZE for the published 16 x 16 tiles; the fused binning may use coarser BIN tiles, see
+// gsa_project_fwd's bin_tile)
+__device__ __forceinline__ GsaTileRect gsa_tile_rect(float mx, float my, int rx, int ry, int tile_w, int tile_h,
+                                                     int tile_size = GSA_TILE_SIZE) {
+    const float inv = 1.0f / (float)tile_size;
     float cx = mx * inv, cy = my * inv, trx = rx * inv, try_ = ry * inv;
     GsaTileRect r;
     r.x0 = (int)fminf(fmaxf(floorf(cx - trx), 0.f), (float)tile_w);

@@ -577,11 +577,12 @@ class ViewParallelTrainer:
                 side.wait_event(params_ready)
                 pose = view["pose"].to(torch.float32).contiguous()
                 W, H = view["width"], view["height"]
+                bt = S.bin_tile_for(W, H, cull)   # 32 x 32 bins where the fused binning applies
                 splat, radii, tiles, keys, rects, aux = S.project_fwd(leaves[0], leaves[1], leaves[2], leaves[3],
                                                                       leaves[4], degree, pose, Kc, W, H, cull,
-                                                                      return_rects=True, return_aux=True)
-                bins = S.bin_tiles(splat, radii, tiles, keys, W, H, cull, tile_rects=rects, exact=exact)
-                order = S.tile_schedule(bins.tile_offsets, W, H)
+                                                                      return_rects=True, return_aux=True, bin_tile=bt)
+                bins = S.bin_tiles(splat, radii, tiles, keys, W, H, cull, tile_rects=rects, exact=exact, bin_tile=bt)
+                order = S.tile_schedule(bins.tile_offsets, W, H, bt)
                 done = torch.cuda.Event()
                 done.record(side)
                 if side is not main:   # the sweep reads these on the main stream: keep their memory until it has
@@ -602,11 +603,12 @@ class ViewParallelTrainer:
             ahead = front(mine[j + 1]) if j + 1 < len(mine) else None
             main.wait_event(done)
             W, H = view["width"], view["height"]
+            bt = bins.bin_tile
             render, _, final_T, last_id, lists = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bgc, W,
-                                                                 H, 3, order, want_lists=True)
+                                                                 H, 3, order, want_lists=True, bin_tile=bt)
             s3, v = S.view_loss(render, view["image"], c.lambda_dssim, grad_scale=scale / n_views)
             v_splat = S.composite_bwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bgc, final_T, last_id, v, None,
-                                      W, H, 3, order, quad_lists=lists)
+                                      W, H, 3, order, quad_lists=lists, bin_tile=bt)
             S.project_bwd(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], degree, pose, Kc, W, H, splat, radii,
                           v_splat, out=grad_out, accumulate=not first,
                           v_rgb_out=vr_all[self.rank, j] if factored else None, sh_aux=aux)

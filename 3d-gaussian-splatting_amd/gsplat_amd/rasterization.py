@@ -36,22 +36,26 @@ class _RasterizeOneCamera(torch.autograd.Function):
         # with a backward pass to come, the forward sweep also notes per 8x8 quadrant which records it blended (the
         # reverse sweep then visits exactly those) and the projection leaves its 48-B digest of every coefficient row
         want_lists = any(ctx.needs_input_grad[:5])
+        # the records are binned into 32 x 32 BINS where the fused binning applies (S.bin_tile_for): the four 16 x 16
+        # tiles of a bin walk the bin's list -- a compositor wave re-tests every record against its 8 x 8 quadrant anyway
+        bt = S.bin_tile_for(width, height, cull_mode)
         proj = S.project_fwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
-                             cull_mode, return_rects=True, return_aux=want_lists)
+                             cull_mode, return_rects=True, return_aux=want_lists, bin_tile=bt)
         splat, radii, tiles_touched, depth_keys, rects = proj[:5]
         sh_aux = proj[5] if want_lists else None
         # the host does not wait for the record count: bins are sized for a remembered capacity, the compositor is
         # queued, and only then is the count (long since copied back) checked -- a miss repeats with exact sizes
-        bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, tile_rects=rects)
-        tile_order = S.tile_schedule(bins.tile_offsets, width, height)   # longest record lists first (speed only)
+        bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, tile_rects=rects,
+                           bin_tile=bt)
+        tile_order = S.tile_schedule(bins.tile_offsets, width, height, bt)   # longest record lists first (speed only)
         out = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg_c, width, height, channels,
-                              tile_order, want_lists=want_lists)
+                              tile_order, want_lists=want_lists, bin_tile=bt)
         if not bins.finalize()[1]:
             bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, exact=True,
-                               tile_rects=rects)
-            tile_order = S.tile_schedule(bins.tile_offsets, width, height)
+                               tile_rects=rects, bin_tile=bt)
+            tile_order = S.tile_schedule(bins.tile_offsets, width, height, bt)
             out = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg_c, width, height, channels,
-                                  tile_order, want_lists=want_lists)
+                                  tile_order, want_lists=want_lists, bin_tile=bt)
         render, alpha, final_T, last_id = out[:4]
         quad_list, quad_count = out[4] if want_lists else (None, None)
         ctx.zeroed_records = out[4].zeroed if want_lists else None   # cleared by the forward kernel; used once
@@ -60,6 +64,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
         ctx.save_for_backward(means_c, quats_c, scales_c, opac_c, colors_c, view_c, K_c, bg_c, splat, radii,
                               sorted_gid, tile_offsets, final_T, last_id, tile_order, quad_list, quad_count, sh_aux)
         ctx.dims = (width, height, sh_degree, channels)
+        ctx.bin_tile = bt
         ctx.grad_out = grad_out
         ctx.grad_accumulate = bool(grad_accumulate)
         ctx.sh_grad_factored = sh_grad_factored
@@ -84,7 +89,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
             lists.zeroed, ctx.zeroed_records = ctx.zeroed_records, None
         v_splat = S.composite_bwd(splat, sorted_gid, tile_offsets, bg_c, final_T, last_id, v_render, v_alpha_c,
                                   width, height, channels, tile_order,
-                                  quad_lists=lists)
+                                  quad_lists=lists, bin_tile=ctx.bin_tile)
         grads = S.project_bwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
                               splat, radii, v_splat, out=ctx.grad_out, accumulate=ctx.grad_accumulate,
                               v_rgb_out=ctx.sh_grad_factored, sh_aux=sh_aux)
@@ -200,19 +205,42 @@ def rasterization(
         return per_cam[0][i][None] if C == 1 else torch.stack([pc[i] for pc in per_cam])
 
     tile_w, tile_h = S.tile_grid(width, height)
+    bt = S.bin_tile_for(width, height, cull)
     meta = _Meta({
         "camera_ids": None, "gaussian_ids": None, "opacities": opacities[None].expand(C, N),
         "tile_width": tile_w, "tile_height": tile_h, "tile_size": TILE_SIZE,
-        "width": width, "height": height, "n_cameras": C, "cull_mode": cull,
-        "n_isects": sum(int(pc[4].numel()) for pc in per_cam),
+        "width": width, "height": height, "n_cameras": C, "cull_mode": cull, "bin_tile": bt,
     })
+    tiled = {}
+
+    def tile_lists():
+        """Per camera (splat, .., sorted_tile, sorted_gid, tile_offsets, ..) on the published 16 x 16 tiles.  With 32 x 32
+        bins in the hot path these are built on first access, by binning once more (nothing in the training loop
+        reads them: the reference looks at means2d and radii, gsplat_backend.py:204-208)."""
+        if "v" not in tiled:
+            if bt == TILE_SIZE:
+                tiled["v"] = per_cam
+            else:
+                out16 = []
+                for pc in per_cam:
+                    splat, radii, tiles = pc[0], pc[1], pc[2]
+                    keys = torch.where((radii > 0).all(-1), splat[:, 9].contiguous().view(torch.int32),
+                                       torch.full_like(tiles, -1))
+                    b = S.bin_tiles(splat, radii, tiles, keys, width, height, cull, exact=True)
+                    out16.append((splat, radii, tiles, b.sorted_tile, b.sorted_gid, b.tile_offsets, pc[6]))
+                tiled["v"] = out16
+        return tiled["v"]
+
     # everything below is a view or is built on first access: the hot path pays for none of it
     meta._lazy = {
         "means2d": lambda: gather(0)[..., 0:2], "conics": lambda: gather(0)[..., 2:5],
         "depths": lambda: gather(0)[..., 9], "radii": lambda: gather(1), "tiles_per_gauss": lambda: gather(2),
-        "flatten_ids": lambda: torch.cat([pc[4] + c * N for c, pc in enumerate(per_cam)]),
-        "isect_offsets": lambda: _isect_offsets(per_cam, tile_h, tile_w),
-        "isect_ids": lambda: _isect_ids(per_cam, tile_w * tile_h),
+        "n_isects": lambda: (sum(int(pc[4].numel()) for pc in per_cam) if bt == TILE_SIZE
+                             else sum(int(pc[2].sum()) for pc in per_cam)),
+        "n_binned": lambda: sum(int(pc[4].numel()) for pc in per_cam),   # records the hot path sorted (its bins)
+        "flatten_ids": lambda: torch.cat([pc[4] + c * N for c, pc in enumerate(tile_lists())]),
+        "isect_offsets": lambda: _isect_offsets(tile_lists(), tile_h, tile_w),
+        "isect_ids": lambda: _isect_ids(tile_lists(), tile_w * tile_h),
     }
     if C == 1:
         return renders[0][None], alphas[0][None], meta

@@ -84,8 +84,24 @@ def f32c(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.detach().to(torch.float32).contiguous()
 
 
-def tile_grid(width: int, height: int) -> Tuple[int, int]:
-    return (width + TILE_SIZE - 1) // TILE_SIZE, (height + TILE_SIZE - 1) // TILE_SIZE
+def tile_grid(width: int, height: int, tile: int = TILE_SIZE) -> Tuple[int, int]:
+    return (width + tile - 1) // tile, (height + tile - 1) // tile
+
+
+# Side of the BINS the fused binning sorts the records into when the caller does not say (rasterization(), the harness):
+# 32 -- the four 16 x 16 tiles of a bin walk the bin's list (a compositor wave re-tests every record against its 8 x 8
+# quadrant anyway), about half as many records to sort; 16 (GSPLAT_AMD_BIN_TILE=16) -- one list per tile.  The stage
+# functions default to 16.
+DEFAULT_BIN_TILE = int(os.environ.get("GSPLAT_AMD_BIN_TILE", "32"))
+if DEFAULT_BIN_TILE not in (TILE_SIZE, 2 * TILE_SIZE):
+    raise ValueError("GSPLAT_AMD_BIN_TILE must be 16 or 32")
+
+
+def bin_tile_for(width: int, height: int, cull_mode: int) -> int:
+    """The bin side rasterization() uses for this view: DEFAULT_BIN_TILE where the fused binning applies, else 16."""
+    if cull_mode == 0 and _BIN_FUSED_DEFAULT and bool(lib.gsa_tile_bin16_supported(width, height)):
+        return DEFAULT_BIN_TILE
+    return TILE_SIZE
 
 
 _PINNED = {}
@@ -157,10 +173,11 @@ _SH_AUX = os.environ.get("GSPLAT_AMD_SH_AUX", "1") != "0"
 
 
 def project_fwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat, Kmat, width: int, height: int,
-                cull_mode: int = 0, return_rects: bool = False, return_aux: bool = False):
+                cull_mode: int = 0, return_rects: bool = False, return_aux: bool = False, bin_tile: int = TILE_SIZE):
     """-> splat [N,16], radii [N,2] i32, tiles_touched [N] i32, depth_keys [N] (uint32 bits in int32 storage)
     [, tile_rects [N,2] i32: (packed tile rectangle, record count) pairs the fused binning reads, with
-    ``return_rects``] [, sh_aux [N,12] f32 or None (sh_degree < 1): the 48-B digest of each coefficient row that lets
+    ``return_rects`` -- in tiles of ``bin_tile`` pixels: 16, or 32 for ``bin_tiles(..., bin_tile=32)``]
+    [, sh_aux [N,12] f32 or None (sh_degree < 1): the 48-B digest of each coefficient row that lets
     ``project_bwd`` skip the rows, with ``return_aux``]."""
     dev, N = means.device, means.shape[0]
     sh_coeffs = colors.shape[1] if sh_degree >= 0 else 0
@@ -172,7 +189,7 @@ def project_fwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat
     sh_aux = torch.empty(N, 12, dtype=torch.float32, device=dev) if (return_aux and sh_degree >= 1 and _SH_AUX) else None
     _call("gsa_project_fwd", lib.gsa_project_fwd, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
           _ptr(colors), sh_degree, sh_coeffs, _ptr(viewmat), _ptr(Kmat), width, height, cull_mode, _ptr(splat),
-          _ptr(radii), _ptr(tiles_touched), _ptr(depth_keys), _ptr(tile_rects), _ptr(sh_aux), _stream())
+          _ptr(radii), _ptr(tiles_touched), _ptr(depth_keys), _ptr(tile_rects), _ptr(sh_aux), bin_tile, _stream())
     out = (splat, radii, tiles_touched, depth_keys)
     if return_rects:
         out += (tile_rects,)
@@ -206,6 +223,10 @@ class TileBins:
         # what the depth ordering assumed about the visible keys -- bits an LSD sort covered, or (key_min, scale) of the
         # bucketed one; None: nothing to check -- and the result of the check
         self.key_bits, self._keys_ok = key_bits, keys_ok
+
+    @property
+    def bin_tile(self) -> int:   # side of the tiles these bins index (16, or 32: see bin_tiles)
+        return self._key[5] if len(self._key) > 5 else TILE_SIZE
 
     @property
     def sorted_gid_buffer(self):   # what the compositor kernels read (they only follow tile_offsets)
@@ -343,20 +364,24 @@ def _note_count(key, n: int, m: int) -> None:
 
 
 def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, cull_mode: int = 0,
-              exact: bool = False, fused: Optional[bool] = None, tile_rects=None, depth_msd: Optional[bool] = None) -> TileBins:
+              exact: bool = False, fused: Optional[bool] = None, tile_rects=None, depth_msd: Optional[bool] = None,
+              bin_tile: int = TILE_SIZE) -> TileBins:
     """Depth-order the gaussians, emit their tile records in that order, stable-sort the records by tile.
     -> TileBins(sorted_tile, sorted_gid, tile_offsets [n_tiles+1] i32).  ``sorted_tile`` holds 16-bit tile ids (an
     int16 tensor of uint16 bit patterns) on the fused path, int32 otherwise: read it through ``tile_ids``.
+    ``bin_tile`` = 32 (fused path only, ``tile_rects`` from ``project_fwd(bin_tile=32)``): the records are binned into
+    32 x 32 bins instead -- tile ids, ``tile_offsets`` and the record count are then those of the bin grid, and the
+    compositor stages must be told (their ``bin_tile``).
 
     The record count M is only known on the device.  Steady state (a capacity is remembered per scene shape): all
     kernels are queued for that capacity and read the live count from device memory, the host never waits; the
     caller runs ``finalize()`` afterwards and repeats with ``exact=True`` if the capacity was too small.
     First call / ``exact``: one host read-back of M sizes the buffers exactly."""
     dev, N = splat.device, splat.shape[0]
-    tile_w, tile_h = tile_grid(width, height)
+    tile_w, tile_h = tile_grid(width, height, bin_tile)
     n_tiles = tile_w * tile_h
     st = _stream()
-    key = (dev.type, dev.index, width, height, cull_mode)
+    key = (dev.type, dev.index, width, height, cull_mode, bin_tile)
     offsets = torch.empty(N, dtype=torch.int32, device=dev)
     ctl = torch.empty(4, dtype=torch.int32, device=dev)   # record count M, min / max visible depth key, spare
     total = ctl[0:1]
@@ -368,7 +393,9 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
     if fused and not can_fuse:
         raise ValueError("bin_tiles(fused=True): needs cull_mode 0 and a tile grid gsa_tile_bin16_supported accepts")
     if fused is None:   # (GSPLAT_AMD_BIN_FUSED=0: the emit + 32-bit sort path, kept for A/B timing)
-        fused = can_fuse and _BIN_FUSED_DEFAULT
+        fused = can_fuse and (_BIN_FUSED_DEFAULT or bin_tile != TILE_SIZE)
+    if bin_tile != TILE_SIZE and not (fused and tile_rects is not None):
+        raise ValueError("bin_tiles(bin_tile=32): needs the fused path and the tile_rects of project_fwd(bin_tile=32)")
     cap = None if exact else _capacity_for(key, N)
     key_bits, keys_ok, slot = 32, True, None
     if fused:
@@ -444,13 +471,13 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
     if fused:
         sorted_tile = torch.empty(cap, dtype=torch.int16, device=dev)       # uint16 tile ids (see tile_ids)
         sorted_gid = torch.empty(cap, dtype=torch.int32, device=dev)
-        two = n_tiles > 256
+        two = n_tiles > 256   # (n_tiles: of the bin grid)
         k_tmp = torch.empty(cap if two else 0, dtype=torch.int16, device=dev)
         v_tmp = torch.empty(cap if two else 0, dtype=torch.int32, device=dev)
         ws2_bytes = lib.gsa_sort_workspace_bytes(cap)
         ws2 = torch.empty(ws2_bytes, dtype=torch.uint8, device=dev)
         _call("gsa_tile_bin16", lib.gsa_tile_bin16, N, _ptr(order), _ptr(offsets), _ptr(rects), _ptr(block_owner), width,
-              height, cap,
+              height, bin_tile, cap,
               _ptr(total), _ptr(k_tmp), _ptr(v_tmp), _ptr(sorted_tile), _ptr(sorted_gid), _ptr(tile_offsets), _ptr(ws2),
               ws2_bytes, st)
         return TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key, slot, N, key_bits, keys_ok)
@@ -474,13 +501,13 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
     return TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key, slot, N, None, True)
 
 
-def tile_schedule(tile_offsets: torch.Tensor, width: int, height: int) -> torch.Tensor:
+def tile_schedule(tile_offsets: torch.Tensor, width: int, height: int, bin_tile: int = TILE_SIZE) -> torch.Tensor:
     """-> tile_order [8 * ceil(n_tiles / 8)] i32: per tile band, the tiles with the longest record lists first (launch
-    order of the compositor kernels; speed only)."""
+    order of the compositor kernels; speed only).  ``bin_tile``: what ``tile_offsets`` indexes (see ``bin_tiles``)."""
     tile_w, tile_h = tile_grid(width, height)
     n_tiles = tile_w * tile_h
     order = torch.empty(8 * ((n_tiles + 7) // 8), dtype=torch.int32, device=tile_offsets.device)
-    _call("gsa_tile_schedule", lib.gsa_tile_schedule, n_tiles, _ptr(tile_offsets), _ptr(order), _stream())
+    _call("gsa_tile_schedule", lib.gsa_tile_schedule, n_tiles, _ptr(tile_offsets), _ptr(order), tile_w, bin_tile, _stream())
     return order
 
 
@@ -492,7 +519,7 @@ class QuadLists(tuple):
 
 
 def composite_fwd(splat, sorted_gid, tile_offsets, background, width: int, height: int, channels: int,
-                  tile_order=None, want_lists: bool = False):
+                  tile_order=None, want_lists: bool = False, bin_tile: int = TILE_SIZE):
     """-> render [H,W,channels], alpha [H,W,1], final_T [H,W], last_id [H,W] i32
     [, QuadLists(quad_list [4 * len(sorted_gid)] i32, quad_count [n_tiles,4] i32) with ``want_lists``: per 8x8 quadrant
     the records that were blended there -- what ``composite_bwd(..., quad_lists=...)`` sweeps]."""
@@ -504,13 +531,14 @@ def composite_fwd(splat, sorted_gid, tile_offsets, background, width: int, heigh
     quad_list = quad_count = zeroed = None
     if want_lists:
         tile_w, tile_h = tile_grid(width, height)
-        quad_list = torch.empty(4 * max(int(sorted_gid.numel()), 1), dtype=torch.int32, device=dev)
+        slices = 4 * (bin_tile // TILE_SIZE) ** 2   # quadrant slices per record list (a 32 x 32 bin: four tiles' worth)
+        quad_list = torch.empty(slices * max(int(sorted_gid.numel()), 1), dtype=torch.int32, device=dev)
         quad_count = torch.empty(tile_w * tile_h, 4, dtype=torch.int32, device=dev)
         zeroed = torch.empty_like(splat)   # the backward sweep's gradient records: the forward kernel clears them
     _call("gsa_composite_fwd", lib.gsa_composite_fwd, width, height, channels, _ptr(splat), _ptr(sorted_gid),
           _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(render), _ptr(alpha), _ptr(final_T),
           _ptr(last_id), _ptr(quad_list), _ptr(quad_count), _ptr(zeroed), 0 if zeroed is None else zeroed.shape[0],
-          _stream())
+          bin_tile, _stream())
     if want_lists:
         lists = QuadLists((quad_list, quad_count))
         lists.zeroed = zeroed
@@ -548,7 +576,7 @@ def record_grads_to_moments(splat: torch.Tensor, g: torch.Tensor) -> torch.Tenso
 
 
 def composite_bwd(splat, sorted_gid, tile_offsets, background, final_T, last_id, v_render, v_alpha, width: int,
-                  height: int, channels: int, tile_order=None, quad_lists=None):
+                  height: int, channels: int, tile_order=None, quad_lists=None, bin_tile: int = TILE_SIZE):
     """-> v_splat [N,16]: per gaussian the raw moments of u = d loss / d sigma over d = mean2d - pixel
     (sum u dx, u dy, u dx^2, u dx dy, u dy^2, u) and sum fac * v_out per channel -- the gradient record
     ``project_bwd`` consumes (``moments_to_record_grads`` gives the mean / conic / opacity gradients)."""
@@ -568,12 +596,12 @@ def composite_bwd(splat, sorted_gid, tile_offsets, background, final_T, last_id,
               tile_w * tile_h, _ptr(quad_count), _ptr(tile_order), _stream())
         _call("gsa_composite_bwd", lib.gsa_composite_bwd_lists, width, height, channels, _ptr(splat), _ptr(sorted_gid),
               _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(final_T), _ptr(last_id), _ptr(v_render),
-              _ptr(v_alpha), _ptr(quad_list), _ptr(quad_count), _ptr(v_splat), _stream())
+              _ptr(v_alpha), _ptr(quad_list), _ptr(quad_count), _ptr(v_splat), bin_tile, _stream())
         return v_splat
     v_splat = torch.zeros_like(splat)
     _call("gsa_composite_bwd", lib.gsa_composite_bwd, width, height, channels, _ptr(splat), _ptr(sorted_gid),
           _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(final_T), _ptr(last_id), _ptr(v_render),
-          _ptr(v_alpha), _ptr(v_splat), _stream())
+          _ptr(v_alpha), _ptr(v_splat), bin_tile, _stream())
     return v_splat
 
 

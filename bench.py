@@ -269,7 +269,9 @@ def main() -> None:
             x1 = torch.cuda.Event(enable_timing=True)
             x1.record()
             stages.TIMER.records.append(("exchange", x0, x1))
-        info["M"] = meta["n_isects"]
+        if "M" not in info:   # (once: with 32 x 32 bins in the hot path the 16 x 16 record count is a reduction + read-back)
+            info["M"] = meta["n_isects"]
+            info["binned"] = meta["n_binned"]
 
     def fence():
         torch.cuda.synchronize()
@@ -362,7 +364,8 @@ def main() -> None:
                                    + ((", RCCL all-reduce of 11N geometry grads + all-gather of 3N rgb grads per rank,"
                                        " SH gradient rebuilt locally" if factored else
                                        ", RCCL all-reduce of 59N-float grads") if world > 1 else ""),
-                       "intersections_M": m, "grad_l1": round(grad_l1, 3), "cull_mode": stages.DEFAULT_CULL_MODE if args.cull_mode is None else args.cull_mode},
+                       "intersections_M": m, "bin_tile": stages.DEFAULT_BIN_TILE, "binned_records": info.get("binned"),
+                       "grad_l1": round(grad_l1, 3), "cull_mode": stages.DEFAULT_CULL_MODE if args.cull_mode is None else args.cull_mode},
             # `bound`: the roofline `achieved` / `peak` are priced against is HBM (no MFMA on this path);
             # `limiter`: what the PMC counters say the dominant kernel actually waits for
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,

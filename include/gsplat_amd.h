@@ -79,12 +79,17 @@ const char *gsa_error_string(int code);
  *          culled gaussians): what stage 5 needs of the 192-B coefficient row, in 48 B -- per colour channel
  *          d colour / d mean through the view direction (x, y, z) and the clamp flag (1 = the channel was not clamped
  *          at 0).  Handed to gsa_project_bwd*, it spares that stage the coefficient rows.
+ *  bin_tile: 0 / 16 -- tile_rects describes the 16 x 16 tiles; 32 (cull_mode 0 only) -- tile_rects describes 32 x 32 BINS
+ *          (rectangle and count on the grid of ceil(width / 32) x ceil(height / 32) bins): about half as many records to
+ *          sort, for a compositor that is told so (bin_tile of gsa_tile_bin16 / gsa_tile_schedule / gsa_composite_*:
+ *          the four tiles of a bin walk the bin's list; a wave re-tests every record against its 8 x 8 quadrant anyway).
+ *          splat word 11, radii and tiles_touched always describe the 16 x 16 tiles.
  */
 int gsa_project_fwd(int n, const float *means, const float *quats, const float *scales,
                     const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
                     const float *viewmat, const float *intrin, int width, int height, int cull_mode,
                     float *splat, int32_t *radii, int32_t *tiles_touched, uint32_t *depth_keys,
-                    uint32_t *tile_rects, float *sh_aux, gsa_stream_t stream);
+                    uint32_t *tile_rects, float *sh_aux, int bin_tile, gsa_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stage 2 (row a3.3): tile binning.  Replaces gsplat's isect_tiles + 64-bit radix sort +
@@ -162,8 +167,8 @@ int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint32_t *tile_
 int gsa_scan_tiles_sorted(int n, uint32_t *counts_offsets, int32_t *block_owner, int n_blocks, uint32_t *total,
                           void *workspace, size_t workspace_bytes, gsa_stream_t stream);
 int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offsets, const uint32_t *rects,
-                   const int32_t *block_owner, int width, int height, uint32_t m_capacity, const uint32_t *m_dev,
-                   uint16_t *tile_tmp,
+                   const int32_t *block_owner, int width, int height, int bin_tile, uint32_t m_capacity,
+                   const uint32_t *m_dev, uint16_t *tile_tmp,
                    uint32_t *gid_tmp, uint16_t *sorted_tile, uint32_t *sorted_gid, int32_t *tile_offsets,
                    void *workspace, size_t workspace_bytes, gsa_stream_t stream);
 
@@ -206,17 +211,23 @@ int gsa_tile_offsets(uint32_t m, const uint32_t *sorted_tile, int n_tiles, int32
  * v_splat_zero / n_zero_rows (optional; NULL / 0): a [n_zero_rows,16] float buffer (16-byte aligned) the kernel fills with
  * zeros on the side -- the gradient records of the backward sweep to come, which then needs no fill pass of its own
  * (gsa_composite_bwd_prepare with n = 0).
+ * bin_tile (here and in gsa_tile_bin16 / gsa_tile_schedule / gsa_composite_bwd*): 0 / 16 -- tile_offsets[n_tiles + 1]
+ * indexes the 16 x 16 tiles; 32 -- the records were binned into 32 x 32 bins (gsa_project_fwd's bin_tile):
+ * tile_offsets[n_bins + 1] indexes the bins (row-major on ceil(width / 32) x ceil(height / 32)), the four tiles of a bin
+ * walk its list, and quad_list holds 16 M uint32 (16 quadrant slices per bin, at 16 * offsets[bin] + (4 * sub-tile +
+ * quadrant) * list length).
  */
 int gsa_composite_fwd(int width, int height, int channels, const float *splat,
                       const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
                       const int32_t *tile_order, float *render, float *alpha, float *final_T, int32_t *last_id,
                       uint32_t *quad_list, int32_t *quad_count, float *v_splat_zero, long long n_zero_rows,
-                      gsa_stream_t stream);
+                      int bin_tile, gsa_stream_t stream);
 
 /* Launch order for stages 3 and 4 (optional; speed only, never results): tile_order[8 * ceil(n_tiles / 8)] receives,
  * for each of the 8 tile bands, the band's tiles with the longest record lists first (-1 pads the last band). Pass it
  * as `tile_order` to gsa_composite_fwd / gsa_composite_bwd, or pass NULL there for index order. */
-int gsa_tile_schedule(int n_tiles, const int32_t *tile_offsets, int32_t *tile_order, gsa_stream_t stream);
+int gsa_tile_schedule(int n_tiles, const int32_t *tile_offsets, int32_t *tile_order, int tile_w, int bin_tile,
+                      gsa_stream_t stream);
 
 /* Stage 4 (row a3.5): reverse-order gradient sweep.  v_splat[N,16] must be zero on entry and receives, per
  * gaussian, the raw moments of u = d loss / d sigma over d = mean2d - pixel:
@@ -226,7 +237,7 @@ int gsa_tile_schedule(int n_tiles, const int32_t *tile_offsets, int32_t *tile_or
 int gsa_composite_bwd(int width, int height, int channels, const float *splat,
                       const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
                       const int32_t *tile_order, const float *final_T, const int32_t *last_id,
-                      const float *v_render, const float *v_alpha, float *v_splat, gsa_stream_t stream);
+                      const float *v_render, const float *v_alpha, float *v_splat, int bin_tile, gsa_stream_t stream);
 
 /* First launch of a backward pass over the forward's lists: zero-fills v_splat[N,16] (the sweep accumulates into it) and
  * writes the launch order for gsa_composite_bwd_lists -- per tile band, the tiles whose quadrants blended the most
@@ -242,7 +253,7 @@ int gsa_composite_bwd_lists(int width, int height, int channels, const float *sp
                             const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
                             const int32_t *tile_order, const float *final_T, const int32_t *last_id,
                             const float *v_render, const float *v_alpha, const uint32_t *quad_list,
-                            const int32_t *quad_count, float *v_splat, gsa_stream_t stream);
+                            const int32_t *quad_count, float *v_splat, int bin_tile, gsa_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stage 5 (row a3.6): projection + SH backward.  Reads the sweep's moment records (stage 4), the raw

@@ -382,14 +382,14 @@ def test_record_capacity_miss_is_repaired(gsa):
         r0, a0, m0 = gsa.rasterization(*args, W, H, sh_degree=3)          # first call: exact sizes
         ids0 = m0["flatten_ids"].clone()
         r1, a1, m1 = gsa.rasterization(*args, W, H, sh_degree=3)          # steady state: capacity + device count
-        key = ("cuda", torch.cuda.current_device(), W, H, S.DEFAULT_CULL_MODE)
-        assert S._capacity_for(key, N) >= m0["n_isects"]
-        S._CAPACITY[key][0] = m0["n_isects"] / N / 3                       # pretend the scene grew threefold
+        key = ("cuda", torch.cuda.current_device(), W, H, S.DEFAULT_CULL_MODE, S.bin_tile_for(W, H, S.DEFAULT_CULL_MODE))
+        assert S._capacity_for(key, N) >= m0["n_binned"]                   # (records of the bins the hot path sorts)
+        S._CAPACITY[key][0] = m0["n_binned"] / N / 3                       # pretend the scene grew threefold
         r2, a2, m2 = gsa.rasterization(*args, W, H, sh_degree=3)
     for r, a, m in ((r1, a1, m1), (r2, a2, m2)):
         assert torch.equal(r, r0) and torch.equal(a, a0)
         assert m["n_isects"] == m0["n_isects"] and torch.equal(m["flatten_ids"], ids0)
-    assert S._capacity_for(key, N) >= m0["n_isects"]                       # the miss re-learned the capacity
+    assert S._capacity_for(key, N) >= m0["n_binned"]                       # the miss re-learned the capacity
 
 
 def test_population_change_keeps_the_pipeline_asynchronous(gsa):
@@ -400,7 +400,7 @@ def test_population_change_keeps_the_pipeline_asynchronous(gsa):
     W, H, N = 320, 200, 20_000
     sc = _scene(N + N // 20, seed=3, s_min=0.005, s_max=0.08)
     K, vm = scene.make_intrinsics(W, H).cuda(), scene.make_camera(1, 5).cuda()
-    key = ("cuda", torch.cuda.current_device(), W, H, 0)
+    key = ("cuda", torch.cuda.current_device(), W, H, 0, 16)
     S._CAPACITY.pop(key, None)
 
     def bins(n):
@@ -945,7 +945,7 @@ def test_depth_cluster_falls_back_to_the_lsd_path(gsa):
     splat = torch.zeros(N, 16, device="cuda")
     radii = torch.ones(N, 2, dtype=torch.int32, device="cuda")
     k32 = keys.to(torch.int32).cuda()
-    key = ("cuda", torch.cuda.current_device(), W, H, 0)
+    key = ("cuda", torch.cuda.current_device(), W, H, 0, 16)
     for d in (S._CAPACITY, S._KEY_RANGE, S._MSD_BACKOFF):
         d.pop(key, None)
 

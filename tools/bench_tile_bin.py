@@ -47,7 +47,7 @@ ws2 = torch.empty(lib.gsa_sort_workspace_bytes(cap), dtype=torch.uint8, device="
 
 
 def run():
-    check(lib.gsa_tile_bin16(n, order.data_ptr(), offsets.data_ptr(), rects.data_ptr(), owner.data_ptr(), W, H, cap,
+    check(lib.gsa_tile_bin16(n, order.data_ptr(), offsets.data_ptr(), rects.data_ptr(), owner.data_ptr(), W, H, 16, cap,
                              ctl[0:1].data_ptr(), k_tmp.data_ptr(), v_tmp.data_ptr(), sorted_tile.data_ptr(),
                              sorted_gid.data_ptr(), tile_offsets.data_ptr(), ws2.data_ptr(), ws2.numel(), st), "bin16")
 
