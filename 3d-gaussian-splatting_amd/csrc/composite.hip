@@ -1304,7 +1304,9 @@ extern "C" int gsa_composite_bwd_prepare(long long n, float *v_splat, int n_tile
     return GSA_OK;
 }
 
-static int bin_shift_of(int bin_tile) { return bin_tile == 2 * kTile ? 1 : (bin_tile == 0 || bin_tile == kTile ? 0 : -1); }
+static int bin_shift_of(int bin_tile) {
+    return bin_tile == 4 * kTile ? 2 : bin_tile == 2 * kTile ? 1 : (bin_tile == 0 || bin_tile == kTile ? 0 : -1);
+}
 
 extern "C" int gsa_tile_schedule(int n_tiles, const int32_t *tile_offsets, int32_t *tile_order, int tile_w, int bin_tile,
                                  gsa_stream_t stream) {

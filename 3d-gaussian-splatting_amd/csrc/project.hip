@@ -679,7 +679,8 @@ extern "C" int gsa_project_fwd(int n, const float *means, const float *quats, co
     GSA_RETURN_IF(sh_degree >= 0 && sh_coeffs < (sh_degree + 1) * (sh_degree + 1), GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(cull_mode != 0 && cull_mode != 1, GSA_ERR_INVALID_ARGUMENT);
     if (bin_tile == 0) bin_tile = GSA_TILE_SIZE;
-    GSA_RETURN_IF((bin_tile != GSA_TILE_SIZE && bin_tile != 2 * GSA_TILE_SIZE) || (bin_tile != GSA_TILE_SIZE && cull_mode != 0),
+    GSA_RETURN_IF((bin_tile != GSA_TILE_SIZE && bin_tile != 2 * GSA_TILE_SIZE && bin_tile != 4 * GSA_TILE_SIZE) ||
+                      (bin_tile != GSA_TILE_SIZE && cull_mode != 0),
                   GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF((reinterpret_cast<uintptr_t>(tile_rects) & 7) != 0 || (reinterpret_cast<uintptr_t>(radii) & 7) != 0 ||
                       (reinterpret_cast<uintptr_t>(splat) & 15) != 0 || (reinterpret_cast<uintptr_t>(sh_aux) & 15) != 0,

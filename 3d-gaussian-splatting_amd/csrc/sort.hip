@@ -1418,7 +1418,8 @@ extern "C" int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offs
     // bin_tile: the side of the tiles the records are binned into -- GSA_TILE_SIZE (0 = the same), or twice that for
     // callers whose compositor maps its 16 x 16 tiles onto 32 x 32 bins (gsa_composite_*'s bin_tile)
     if (bin_tile == 0) bin_tile = GSA_TILE_SIZE;
-    GSA_RETURN_IF(bin_tile != GSA_TILE_SIZE && bin_tile != 2 * GSA_TILE_SIZE, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(bin_tile != GSA_TILE_SIZE && bin_tile != 2 * GSA_TILE_SIZE && bin_tile != 4 * GSA_TILE_SIZE,
+                  GSA_ERR_INVALID_ARGUMENT);
     const int tile_w = gsa_div_up(width, bin_tile), tile_h = gsa_div_up(height, bin_tile);
     const int n_tiles = tile_w * tile_h;
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -93,8 +93,8 @@ def tile_grid(width: int, height: int, tile: int = TILE_SIZE) -> Tuple[int, int]
 # quadrant anyway), about half as many records to sort; 16 (GSPLAT_AMD_BIN_TILE=16) -- one list per tile.  The stage
 # functions default to 16.
 DEFAULT_BIN_TILE = int(os.environ.get("GSPLAT_AMD_BIN_TILE", "32"))
-if DEFAULT_BIN_TILE not in (TILE_SIZE, 2 * TILE_SIZE):
-    raise ValueError("GSPLAT_AMD_BIN_TILE must be 16 or 32")
+if DEFAULT_BIN_TILE not in (TILE_SIZE, 2 * TILE_SIZE, 4 * TILE_SIZE):
+    raise ValueError("GSPLAT_AMD_BIN_TILE must be 16, 32 or 64")
 
 
 def bin_tile_for(width: int, height: int, cull_mode: int) -> int:
