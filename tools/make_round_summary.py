@@ -62,8 +62,8 @@ profiler (`composite_bwd_2p_kernel<3>`, table above) agrees with the HIP-event a
 Binning is `radix_hist<unsigned int>` + `radix_scan_rows` + `radix_scatter<unsigned int>` (ONE global pass: depth
 buckets) + `depth_bucket_sort_kernel` (local sorts fused with the scan and the block-owner table; it also leaves the
 control words in the caller's pinned slot -- no copy kernel), then `emit_hist` + `radix_scan_rows` + `emit_scatter`
-(records generated from the depth-ordered tile rectangles; low 7 bits of the tile id) + one 16-bit hist / scan / scatter
-pass (high 6 bits) + `tile_offsets_bsearch` + `tile_schedule`: 12 launches, 17 per forward + backward view.  The `scan_*`
+(records generated from the depth-ordered rectangles -- of the 32 x 32 bins: {pj['config'].get('binned_records')} records where the 16 x 16
+rule has {pj['config']['intersections_M']}; low half of the bin id's bits) + one 16-bit hist / scan / scatter pass (high half) + `tile_offsets_bsearch` + `tile_schedule`: 12 launches, 17 per forward + backward view.  The `scan_*`
 kernels, `tile_offsets_kernel` and the second / third `radix_*<unsigned int>` calls belong to the first call of the scene
 shape (LSD path, which learns the key range); `__amd_rocclr_copyBuffer` is the scene upload and that first call's read-back.
 
