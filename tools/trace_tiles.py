@@ -27,6 +27,9 @@ torch.cuda.synchronize(); step(); torch.cuda.synchronize()
 tr = buf.cpu().numpy().reshape(2, 262144, 16)
 for k, name in enumerate(("fwd", "bwd")):
     d = tr[k]; d = d[d[:, 1] > 0]
+    if not len(d):   # (the two-phase backward kernel carries no trace marks; GSPLAT_AMD_BWD_MODE=0 / 1 do)
+        print(f"== {name}: no trace records")
+        continue
     t0, t1, hw, work = d[:, 0].astype(np.float64), d[:, 1].astype(np.float64), d[:, 2], d[:, 3]
     base = t0.min(); t0 = (t0 - base) / 100.0; t1 = (t1 - base) / 100.0   # us (100 MHz counter)
     dur = t1 - t0
