@@ -1401,11 +1401,15 @@ extern "C" int gsa_tile_offsets_dev(uint32_t m_capacity, const uint32_t *m_dev, 
     return tile_offsets_impl<uint32_t>(m_capacity, m_dev, sorted_tile, n_tiles, tile_offsets, stream);
 }
 
-extern "C" int gsa_tile_bin16_supported(int width, int height) {
-    if (width <= 0 || height <= 0) return 0;
-    const long tile_w = gsa_div_up(width, GSA_TILE_SIZE), tile_h = gsa_div_up(height, GSA_TILE_SIZE);
+extern "C" int gsa_tile_bins_supported(int width, int height, int bin_tile) {
+    if (bin_tile == 0) bin_tile = GSA_TILE_SIZE;
+    if (width <= 0 || height <= 0 || (bin_tile != GSA_TILE_SIZE && bin_tile != 2 * GSA_TILE_SIZE && bin_tile != 4 * GSA_TILE_SIZE))
+        return 0;
+    const long tile_w = gsa_div_up(width, bin_tile), tile_h = gsa_div_up(height, bin_tile);
     return tile_w < 1024 && tile_h < 1024 && tile_w * tile_h <= 65535 ? 1 : 0;
 }
+
+extern "C" int gsa_tile_bin16_supported(int width, int height) { return gsa_tile_bins_supported(width, height, GSA_TILE_SIZE); }
 
 extern "C" int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offsets, const uint32_t *rects,
                               const int32_t *block_owner, int width, int height, int bin_tile, uint32_t m_capacity,
@@ -1413,7 +1417,7 @@ extern "C" int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offs
                               uint32_t *gid_tmp, uint16_t *sorted_tile, uint32_t *sorted_gid, int32_t *tile_offsets,
                               void *workspace, size_t workspace_bytes, gsa_stream_t stream) {
     GSA_RETURN_IF(n < 0 || !tile_offsets, GSA_ERR_INVALID_ARGUMENT);
-    GSA_RETURN_IF(!gsa_tile_bin16_supported(width, height), GSA_ERR_UNSUPPORTED);
+    GSA_RETURN_IF(!gsa_tile_bins_supported(width, height, bin_tile), GSA_ERR_UNSUPPORTED);
     GSA_RETURN_IF(m_capacity >= 0x7FFFFFFFu - (uint32_t)kSortChunk, GSA_ERR_UNSUPPORTED);
     // bin_tile: the side of the tiles the records are binned into -- GSA_TILE_SIZE (0 = the same), or twice that for
     // callers whose compositor maps its 16 x 16 tiles onto 32 x 32 bins (gsa_composite_*'s bin_tile)

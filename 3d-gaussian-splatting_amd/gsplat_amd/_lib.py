@@ -27,6 +27,7 @@ SIGNATURES = {
     "gsa_sort_pairs_u32": (c_int, [c_int, P, P, P, P, P, P, c_int, c_int, P, c_size_t, P]),
     "gsa_scan_tiles": (c_int, [c_int, P, P, P, P, P, c_size_t, P]),
     "gsa_tile_bin16_supported": (c_int, [c_int, c_int]),
+    "gsa_tile_bins_supported": (c_int, [c_int, c_int, c_int]),
     "gsa_scan_tiles_rect": (c_int, [c_int, P, P, P, P, P, c_int, P, P, c_size_t, P]),
     "gsa_depth_order_workspace_bytes": (c_size_t, [c_int]),
     "gsa_depth_order": (c_int, [c_int, P, P, c_int, P, P, P, P, P, c_size_t, P]),

@@ -99,7 +99,7 @@ if DEFAULT_BIN_TILE not in (TILE_SIZE, 2 * TILE_SIZE, 4 * TILE_SIZE):
 
 def bin_tile_for(width: int, height: int, cull_mode: int) -> int:
     """The bin side rasterization() uses for this view: DEFAULT_BIN_TILE where the fused binning applies, else 16."""
-    if cull_mode == 0 and _BIN_FUSED_DEFAULT and bool(lib.gsa_tile_bin16_supported(width, height)):
+    if cull_mode == 0 and _BIN_FUSED_DEFAULT and bool(lib.gsa_tile_bins_supported(width, height, DEFAULT_BIN_TILE)):
         return DEFAULT_BIN_TILE
     return TILE_SIZE
 
@@ -389,7 +389,7 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     # fused path (every tile of the rectangle is a record, 16-bit tile ids): the records are generated inside the
     # first pass of the tile sort from the depth-ordered rectangles, never written in emission order
-    can_fuse = cull_mode == 0 and bool(lib.gsa_tile_bin16_supported(width, height))
+    can_fuse = cull_mode == 0 and bool(lib.gsa_tile_bins_supported(width, height, bin_tile))
     if fused and not can_fuse:
         raise ValueError("bin_tiles(fused=True): needs cull_mode 0 and a tile grid gsa_tile_bin16_supported accepts")
     if fused is None:   # (GSPLAT_AMD_BIN_FUSED=0: the emit + 32-bit sort path, kept for A/B timing)

@@ -123,6 +123,8 @@ int gsa_scan_tiles(int n, const int32_t *tiles_touched, const uint32_t *order, u
  * m_capacity elements each (unused for at most 256 tiles); workspace: gsa_sort_workspace_bytes(m_capacity). */
 #define GSA_BIN_BLOCK 4096
 int gsa_tile_bin16_supported(int width, int height);
+/* ... for bins of bin_tile pixels (16 / 32 / 64): an 8K image has too many 16 x 16 tiles for 16-bit ids, but not 32 x 32 bins */
+int gsa_tile_bins_supported(int width, int height, int bin_tile);
 int gsa_scan_tiles_rect(int n, const uint32_t *order, const uint32_t *tile_rects, uint32_t *offsets,
                         uint32_t *rects, int32_t *block_owner, int n_blocks, uint32_t *total, void *workspace,
                         size_t workspace_bytes, gsa_stream_t stream);

@@ -49,6 +49,9 @@ def test_error_codes_and_strings():
     assert lib.gsa_tile_schedule(0, None, None, 0, 0, None) == -1
     assert lib.gsa_sort_pairs_u32(16, None, None, None, None, None, None, 0, 40, None, 0, None) == -1
     assert lib.gsa_sort_workspace_bytes(1_000_000) > 0
+    # an 8K frame has too many 16 x 16 tiles for the 16-bit tile ids of the fused binning, but not 32 x 32 bins
+    assert lib.gsa_tile_bin16_supported(1920, 1080) == 1 and lib.gsa_tile_bin16_supported(7680, 4320) == 0
+    assert lib.gsa_tile_bins_supported(7680, 4320, 32) == 1 and lib.gsa_tile_bins_supported(7680, 4320, 24) == 0
     with pytest.raises(GsaError):
         check(-1, "x")
 

@@ -159,6 +159,38 @@ def test_c5_full_size_properties_5m_4k():
     assert bool(((m2d[:, 1] + rad[:, 1]) / 16 > ty).all() and ((m2d[:, 1] - rad[:, 1]) / 16 < ty + 1).all())
 
 
+def test_8k_frame_bins_32_equal_tiles_16():
+    """7680x4320: 129600 tiles of 16 x 16 (beyond the fused binning's 16-bit ids: emit + 32-bit sort path) against
+    32400 bins of 32 x 32 (fused path, what rasterization() picks) -- the same image, alpha and gradients."""
+    import gsplat_amd as gsa
+    from gsplat_amd import scene, stages as S
+    N, W, H = 20_000, 7680, 4320
+    sc = scene.make_scene(N, seed=4, sh_degree=3)
+    vm, K = scene.make_camera(0, 1)[None].cuda(), scene.make_intrinsics(W, H)[None].cuda()
+    base = [sc["means3D"].cuda(), sc["rotations"].cuda(), (sc["scales"] * 3.0).cuda(), sc["opacities"][:, 0].cuda(),
+            sc["shs"].cuda()]
+    v = scene.make_v_render(W, H, seed=2).cuda()[None]
+    assert S.bin_tile_for(W, H, 0) == 32 and not gsa.lib.gsa_tile_bin16_supported(W, H)
+
+    def run(bin_tile):
+        was, S.DEFAULT_BIN_TILE = S.DEFAULT_BIN_TILE, bin_tile
+        try:
+            leaves = [t.clone().requires_grad_(True) for t in base]
+            r, a, meta = gsa.rasterization(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], vm, K, W, H, sh_degree=3)
+            r.backward(v)
+            return r.detach(), a.detach(), [t.grad for t in leaves], meta
+        finally:
+            S.DEFAULT_BIN_TILE = was
+
+    r32, a32, g32, m32 = run(32)
+    r16, a16, g16, m16 = run(16)
+    assert m32["bin_tile"] == 32 and m16["bin_tile"] == 16 and m32["n_isects"] == m16["n_isects"] > 0
+    assert torch.equal(r32, r16) and torch.equal(a32, a16)
+    for name, x, y in zip(("means", "quats", "scales", "opacities", "colors"), g32, g16):
+        assert _rel(x, y) < 1e-5, name      # (atomics reorder the sums)
+    assert torch.equal(m32["flatten_ids"], m16["flatten_ids"])
+
+
 def test_c5_densify_and_prune_event_at_5m():
     """One densify / prune event at the C5 population: the HIP gather pass (parameters + both Adam moment buckets)
     against the same event written with torch index operations in the reference's order -- [rows that are not split]
