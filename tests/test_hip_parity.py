@@ -635,6 +635,27 @@ def test_random_shapes_fused_paths_agree_with_plain_ones(gsa):
         g1 = S.composite_bwd(splat, gid, offs, bg, T1, l1, v_r, None, W, H, 3, quad_lists=lists)
         scale = g0.abs().amax(0).clamp_min(1e-30)
         assert float(((g0 - g1).abs().amax(0) / scale).max()) < 5e-5, tag
+        # the same view through 32 x 32 (and 64 x 64) BINS: fewer records sorted, the tiles of a bin share its list -- the
+        # image bit for bit, the sweeps (all three list kernels and the plain one) up to the order of the float atomics
+        for bt in (32, 64):
+            rects_b = S.project_fwd(d["means3D"], d["rotations"], d["scales"], d["opacities"][:, 0].contiguous(), d["shs"],
+                                    3, vm, K, W, H, 0, return_rects=True, bin_tile=bt)[4]
+            bb = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, tile_rects=rects_b, bin_tile=bt)
+            assert bb.bin_tile == bt and bb.finalize()[0] <= int(tiles.sum()), tag
+            gb, ob = bb.sorted_gid_buffer, bb.tile_offsets
+            rb, ab, Tb, lb, lists_b = S.composite_fwd(splat, gb, ob, bg, W, H, 3, S.tile_schedule(ob, W, H, bt),
+                                                      want_lists=True, bin_tile=bt)
+            assert torch.equal(rb, r0) and torch.equal(Tb, T0) and torch.equal(ab, a0), (tag, bt)
+            sweeps = [S.composite_bwd(splat, gb, ob, bg, Tb, lb, v_r, None, W, H, 3, bin_tile=bt)]
+            for mode in ("2", "1", "0"):
+                os.environ["GSPLAT_AMD_BWD_MODE"] = mode
+                try:
+                    sweeps.append(S.composite_bwd(splat, gb, ob, bg, Tb, lb, v_r, None, W, H, 3, quad_lists=lists_b,
+                                                  bin_tile=bt))
+                finally:
+                    os.environ.pop("GSPLAT_AMD_BWD_MODE", None)
+            for gsw in sweeps:
+                assert float(((g0 - gsw).abs().amax(0) / scale).max()) < 5e-5, (tag, bt)
 
 
 @pytest.mark.parametrize("W,H,N,cull_mode,channels", [(640, 360, 20_000, 0, 3), (250, 130, 3000, 1, 4),
