@@ -1232,25 +1232,56 @@ __device__ __forceinline__ void bucket_starts(const int *__restrict__ cnt, int *
 }
 
 constexpr int kSchedThreads = 1024, kSchedBuckets = 64;
+template <int SHIFT>
 __global__ __launch_bounds__(kSchedThreads) void tile_schedule_kernel(int n_tiles, const int32_t *__restrict__ tile_offsets,
-                                                                      int32_t *__restrict__ tile_order, int tile_w,
-                                                                      int bin_shift) {
+                                                                      int32_t *__restrict__ tile_order, int tile_w) {
     __shared__ int cnt[kSchedBuckets], first[kSchedBuckets];
+    constexpr int SIDE = 1 << SHIFT, MEMBERS = SIDE * SIDE;
     const int chunk = (n_tiles + 7) >> 3;
     const int lo = blockIdx.x * chunk, hi = min(n_tiles, lo + chunk);
     if (threadIdx.x < kSchedBuckets) cnt[threadIdx.x] = 0;
     __syncthreads();
-    auto bucket = [&](int t) {
-        int idx = t;   // (the list a tile walks is its bin's: see tile_list)
-        if (bin_shift) idx = ((t / tile_w) >> bin_shift) * ((tile_w + (1 << bin_shift) - 1) >> bin_shift) + ((t % tile_w) >> bin_shift);
+    // One tile per thread (a band has at most kSchedThreads tiles at the sizes the compositor launches; the loops below
+    // cover more).  With bins (SHIFT > 0: the list a tile walks is its bin's, see tile_list) the tiles of one bin take
+    // CONSECUTIVE places -- their waves then run together and gather the bin's records out of the same L2 at the same
+    // time -- and the member with the smallest index inside this band speaks for its bin.
+    const int tile_h = n_tiles / max(tile_w, 1), bin_w = (tile_w + SIDE - 1) >> SHIFT;
+    auto plan = [&](int t, int (&m)[MEMBERS], int &bkt) {   // -> number of places t reserves (0: another tile speaks for it)
+        const int ty = t / max(tile_w, 1), tx = t - ty * tile_w;
+        const int idx = SHIFT ? (ty >> SHIFT) * bin_w + (tx >> SHIFT) : t;
         const int len = tile_offsets[idx + 1] - tile_offsets[idx];
-        return kSchedBuckets - 1 - min(kSchedBuckets - 1, len >> 6);   // bucket 0 = longest lists
+        bkt = kSchedBuckets - 1 - min(kSchedBuckets - 1, len >> 6);   // bucket 0 = longest lists
+        const int tx0 = (tx >> SHIFT) << SHIFT, ty0 = (ty >> SHIFT) << SHIFT;
+        int k = 0;
+#pragma unroll
+        for (int j = 0; j < MEMBERS; ++j) {
+            const int x = tx0 + (j & (SIDE - 1)), y = ty0 + (j >> SHIFT), u = y * tile_w + x;
+            const bool in = x < tile_w && y < tile_h && u >= lo && u < hi;
+#pragma unroll
+            for (int q = 0; q < MEMBERS; ++q)
+                if (q == k && in) m[q] = u;   // (compile-time indices: m stays in registers)
+            k += in ? 1 : 0;
+        }
+        return m[0] == t ? k : 0;
     };
-    for (int t = lo + threadIdx.x; t < hi; t += kSchedThreads) atomicAdd(&cnt[bucket(t)], 1);
+    for (int t = lo + threadIdx.x; t < hi; t += kSchedThreads) {
+        int m[MEMBERS], bkt;
+        const int k = plan(t, m, bkt);
+        if (k) atomicAdd(&cnt[bkt], k);
+    }
     __syncthreads();
     bucket_starts<kSchedBuckets>(cnt, first);
     __syncthreads();
-    for (int t = lo + threadIdx.x; t < hi; t += kSchedThreads) tile_order[lo + atomicAdd(&first[bucket(t)], 1)] = t;
+    for (int t = lo + threadIdx.x; t < hi; t += kSchedThreads) {
+        int m[MEMBERS], bkt;
+        const int k = plan(t, m, bkt);
+        if (k) {
+            const int at = lo + atomicAdd(&first[bkt], k);
+#pragma unroll
+            for (int j = 0; j < MEMBERS; ++j)
+                if (j < k) tile_order[at + j] = m[j];
+        }
+    }
     for (int t = max(hi, lo) + threadIdx.x; t < lo + chunk; t += kSchedThreads) tile_order[t] = -1;   // padding
 }
 
@@ -1312,8 +1343,12 @@ extern "C" int gsa_tile_schedule(int n_tiles, const int32_t *tile_offsets, int32
                                  gsa_stream_t stream) {
     GSA_RETURN_IF(n_tiles <= 0 || !tile_offsets || !tile_order || bin_shift_of(bin_tile) < 0, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(bin_shift_of(bin_tile) > 0 && (tile_w <= 0 || n_tiles % tile_w != 0), GSA_ERR_INVALID_ARGUMENT);
-    tile_schedule_kernel<<<8, kSchedThreads, 0, static_cast<hipStream_t>(stream)>>>(n_tiles, tile_offsets, tile_order,
-                                                                                    tile_w, bin_shift_of(bin_tile));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (bin_shift_of(bin_tile)) {
+        case 0: tile_schedule_kernel<0><<<8, kSchedThreads, 0, s>>>(n_tiles, tile_offsets, tile_order, tile_w); break;
+        case 1: tile_schedule_kernel<1><<<8, kSchedThreads, 0, s>>>(n_tiles, tile_offsets, tile_order, tile_w); break;
+        default: tile_schedule_kernel<2><<<8, kSchedThreads, 0, s>>>(n_tiles, tile_offsets, tile_order, tile_w); break;
+    }
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }
