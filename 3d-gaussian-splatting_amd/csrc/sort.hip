@@ -612,7 +612,13 @@ __global__ __launch_bounds__(kSortThreads) void tile_offsets_bsearch_kernel(uint
 // next one that has some, the last one wins), a max-scan carries the owner forward; slot -> tile: the rectangle
 // arithmetic of tile_emit_coop_kernel.
 struct EmitBlock { uint32_t slot0, live; int k_lo; };   // live: slots of this block below the record count
-constexpr int kEmitStage = 768;    // gaussians per block whose (offset, rectangle, index, 1 / width) are staged in LDS
+#ifndef GSA_EMIT_STAGE
+#define GSA_EMIT_STAGE 1280
+#endif
+// gaussians per block whose (offset, rectangle, index, 1 / width) are staged in LDS.  A 4096-slot block holds ~1050
+// gaussians when the records are those of 32 x 32 bins (3.9 per gaussian at the bench scene; 460 with 16 x 16 tiles):
+// with 768 staged, a quarter of the records took the per-record global look-up below
+constexpr int kEmitStage = GSA_EMIT_STAGE;
 
 // the packed 16-B entry of a staged gaussian: ONE LDS read per record instead of three, and the division by the
 // rectangle's width becomes a multiplication (exact for the operands in range: see emit_record)
@@ -776,8 +782,8 @@ __global__ __launch_bounds__(kSortThreads) void emit_scatter_kernel(
     // two regions, each with two lives: the generation's (slot owners | staged gaussians) and the scatter's (values |
     // 16-bit keys + wave-private digit counters)
     __shared__ __attribute__((aligned(16))) uint32_t s_val[kSortChunk];
-    __shared__ __attribute__((aligned(16))) uint32_t s_pool[kSortChunk / 2 + 4 * kRadix];
-    static_assert(4 * kEmitStage <= kSortChunk / 2 + 4 * kRadix, "the staged gaussians must fit the aliased region");
+    constexpr int kPoolWords = 4 * kEmitStage > kSortChunk / 2 + 4 * kRadix ? 4 * kEmitStage : kSortChunk / 2 + 4 * kRadix;
+    __shared__ __attribute__((aligned(16))) uint32_t s_pool[kPoolWords];
     uint4 *s_g = reinterpret_cast<uint4 *>(s_pool);
     uint16_t *s_key = reinterpret_cast<uint16_t *>(s_pool);
     uint32_t(*wave_cnt)[kRadix] = reinterpret_cast<uint32_t(*)[kRadix]>(s_pool + kSortChunk / 2);
