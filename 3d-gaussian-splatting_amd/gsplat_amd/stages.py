@@ -511,6 +511,11 @@ def tile_schedule(tile_offsets: torch.Tensor, width: int, height: int, bin_tile:
     return order
 
 
+# GSPLAT_AMD_BWD_REORDER=0: the backward sweep keeps the forward's launch order (by list length) instead of ordering the
+# tiles once more by the records their quadrants blended -- one launch less, a less even sweep (A/B)
+_BWD_REORDER = os.environ.get("GSPLAT_AMD_BWD_REORDER", "1") != "0"
+
+
 class QuadLists(tuple):
     """(quad_list, quad_count) of ``composite_fwd(want_lists=True)``, plus ``zeroed``: the [N,16] gradient-record buffer
     the forward kernel cleared on the side -- ``composite_bwd`` accumulates into it ONCE (a second backward pass over
@@ -591,9 +596,10 @@ def composite_bwd(splat, sorted_gid, tile_offsets, background, final_T, last_id,
         else:
             quad_lists.zeroed = None   # (accumulated into once)
         tile_w, tile_h = tile_grid(width, height)
-        tile_order = torch.empty(8 * ((tile_w * tile_h + 7) // 8), dtype=torch.int32, device=splat.device)
-        _call("gsa_composite_bwd_prepare", lib.gsa_composite_bwd_prepare, splat.shape[0] if fill else 0, _ptr(v_splat),
-              tile_w * tile_h, _ptr(quad_count), _ptr(tile_order), _stream())
+        if fill or tile_order is None or _BWD_REORDER:
+            tile_order = torch.empty(8 * ((tile_w * tile_h + 7) // 8), dtype=torch.int32, device=splat.device)
+            _call("gsa_composite_bwd_prepare", lib.gsa_composite_bwd_prepare, splat.shape[0] if fill else 0, _ptr(v_splat),
+                  tile_w * tile_h, _ptr(quad_count), _ptr(tile_order), _stream())
         _call("gsa_composite_bwd", lib.gsa_composite_bwd_lists, width, height, channels, _ptr(splat), _ptr(sorted_gid),
               _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(final_T), _ptr(last_id), _ptr(v_render),
               _ptr(v_alpha), _ptr(quad_list), _ptr(quad_count), _ptr(v_splat), bin_tile, _stream())
