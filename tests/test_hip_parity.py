@@ -428,6 +428,38 @@ def test_population_change_keeps_the_pipeline_asynchronous(gsa):
     assert all(b.finalize()[1] for b in later)
 
 
+def test_two_cameras_in_one_call_equal_two_calls(gsa):
+    """C = 2 cameras in one rasterization() call (the reference's dead ``render_batch`` shape, gsplat_backend.py:12-55):
+    images, alphas and gradients are those of two single-camera calls, and the 16 x 16 tile lists of ``meta`` (built on
+    demand when the hot path bins by 32 x 32) are the per-camera lists with the camera offset the published layout has."""
+    from gsplat_amd import scene
+    W, H, N = 200, 120, 4000
+    sc = _scene(N, seed=11)
+    vms = torch.stack([scene.make_camera(k, 5) for k in (0, 2)]).cuda()
+    Ks = torch.stack([scene.make_intrinsics(W, H)] * 2).cuda()
+    v = torch.from_numpy(np.random.default_rng(3).uniform(-1, 1, (2, H, W, 3)).astype(np.float32)).cuda()
+
+    def run(cams):
+        leaves = [sc[k].cuda().clone().requires_grad_(True) for k in NAMES]
+        r, a, meta = gsa.rasterization(leaves[0], leaves[1], leaves[2], leaves[3][:, 0], leaves[4], vms[cams], Ks[cams], W, H,
+                                       sh_degree=3, backgrounds=torch.zeros(len(cams), 3, device="cuda"))
+        (r * v[cams]).sum().backward()
+        return r.detach(), a.detach(), meta, [t.grad for t in leaves]
+
+    r2, a2, m2, g2 = run([0, 1])
+    singles = [run([k]) for k in (0, 1)]
+    assert r2.shape == (2, H, W, 3) and m2["n_cameras"] == 2
+    for k, (r1, a1, m1, _) in enumerate(singles):
+        assert torch.equal(r2[k], r1[0]) and torch.equal(a2[k], a1[0])
+        assert torch.equal(m2["radii"][k], m1["radii"][0]) and torch.equal(m2["means2d"][k], m1["means2d"][0])
+    assert m2["n_isects"] == sum(s[2]["n_isects"] for s in singles)
+    ids = torch.cat([singles[0][2]["flatten_ids"], singles[1][2]["flatten_ids"] + N])
+    assert torch.equal(m2["flatten_ids"], ids)
+    assert m2["isect_offsets"].shape == (2,) + tuple(singles[0][2]["isect_offsets"].shape[1:])
+    for name, x, y0, y1 in zip(NAMES, g2, singles[0][3], singles[1][3]):
+        assert _rel(x, y0 + y1) < 1e-5, name
+
+
 @pytest.mark.parametrize("mode", ["D", "ED", "RGB+D", "RGB+ED"])
 def test_depth_render_modes(gsa, mode):
     from gsplat_amd import scene
