@@ -34,7 +34,6 @@
 
 #include "project_math.h"
 #include <type_traits>
-#include <cstdlib>
 
 namespace {
 
@@ -718,6 +717,7 @@ __device__ __forceinline__ int stage_listed(Staged<F4> &st, int lane, const Row 
     return n;
 }
 
+#ifdef GSA_DEV_KERNELS   // superseded sweeps over the lists, kept for A/B in developer builds (gsa_debug_set_bwd_mode)
 template <int CH>
 __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_list_kernel(
     int width, int height, int tile_w, int n_tiles, int bin_shift, const float *__restrict__ splat,
@@ -1003,6 +1003,7 @@ __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_scan_kerne
         }
     }
 }
+#endif  // GSA_DEV_KERNELS
 
 // ------------------------------------------------------------------------------------------------
 // backward, two phases per 8 records: pixel-parallel recurrence, record-parallel moment sums
@@ -1413,6 +1414,11 @@ extern "C" int gsa_composite_bwd(int width, int height, int channels, const floa
     return GSA_OK;
 }
 
+#ifdef GSA_DEV_KERNELS
+static int g_dev_bwd_mode = 2;
+extern "C" int gsa_debug_set_bwd_mode(int mode) { g_dev_bwd_mode = mode; return GSA_OK; }
+#endif
+
 extern "C" int gsa_composite_bwd_lists(int width, int height, int channels, const float *splat,
                                        const uint32_t *sorted_gid, const int32_t *tile_offsets,
                                        const float *background, const int32_t *tile_order, const float *final_T,
@@ -1428,22 +1434,9 @@ extern "C" int gsa_composite_bwd_lists(int width, int height, int channels, cons
     const int n_tiles = tile_w * tile_h;
     const int grid = 32 * gsa_div_up(n_tiles, 8);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // GSPLAT_AMD_BWD_MODE (developer A/B; same results up to summation order): 2 = two-phase sweep (default),
-    // 1 = record-parallel sweep with prefix scans, 0 = pixel-parallel sweep with the transpose-reduce
-    const char *mode_env = getenv("GSPLAT_AMD_BWD_MODE");   // (read per call: tests switch it)
-    const int mode = mode_env ? atoi(mode_env) : 2;
-    if (mode == 2) {
-        if (channels == 3)
-            composite_bwd_2p_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid,
-                                                             tile_offsets, background, tile_order, final_T, last_id,
-                                                             v_render, v_alpha, quad_list, quad_count, v_splat);
-        else
-            composite_bwd_2p_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid,
-                                                             tile_offsets, background, tile_order, final_T, last_id,
-                                                             v_render, v_alpha, quad_list, quad_count, v_splat);
-        GSA_LAUNCH_CHECK();
-        return GSA_OK;
-    }
+#ifdef GSA_DEV_KERNELS   // developer builds: 1 = record-parallel sweep with prefix scans, 0 = pixel-parallel sweep with the
+                         // transpose-reduce (same results up to summation order); the product library has the two-phase sweep only
+    const int mode = g_dev_bwd_mode;
     if (mode == 1) {
         if (channels == 3)
             composite_bwd_scan_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid,
@@ -1456,14 +1449,27 @@ extern "C" int gsa_composite_bwd_lists(int width, int height, int channels, cons
         GSA_LAUNCH_CHECK();
         return GSA_OK;
     }
+    if (mode == 0) {
+        if (channels == 3)
+            composite_bwd_list_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid, tile_offsets,
+                                                               background, tile_order, final_T, last_id, v_render, v_alpha,
+                                                               quad_list, quad_count, v_splat);
+        else
+            composite_bwd_list_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid, tile_offsets,
+                                                               background, tile_order, final_T, last_id, v_render, v_alpha,
+                                                               quad_list, quad_count, v_splat);
+        GSA_LAUNCH_CHECK();
+        return GSA_OK;
+    }
+#endif
     if (channels == 3)
-        composite_bwd_list_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid, tile_offsets,
-                                                           background, tile_order, final_T, last_id, v_render, v_alpha,
-                                                           quad_list, quad_count, v_splat);
+        composite_bwd_2p_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid,
+                                                         tile_offsets, background, tile_order, final_T, last_id,
+                                                         v_render, v_alpha, quad_list, quad_count, v_splat);
     else
-        composite_bwd_list_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid, tile_offsets,
-                                                           background, tile_order, final_T, last_id, v_render, v_alpha,
-                                                           quad_list, quad_count, v_splat);
+        composite_bwd_2p_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid,
+                                                         tile_offsets, background, tile_order, final_T, last_id,
+                                                         v_render, v_alpha, quad_list, quad_count, v_splat);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }

@@ -13,8 +13,6 @@
 // Replaces gsplat's isect_tiles / radix sort / isect_offset_encode behind
 // /root/reference/src/backends/gsplat_backend.py:168-182.
 
-#include <cstdlib>
-
 #include "project_math.h"
 
 #ifdef GSA_TRACE   // developer build: per-workgroup phase times of the binning kernels (tools/trace_sort.py)
@@ -638,14 +636,15 @@ struct EmitLoads {
 __device__ __forceinline__ EmitLoads emit_owner_loads(const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ rects,
                                                       const uint32_t *__restrict__ order,
                                                       const int32_t *__restrict__ block_owner, int n_owner_blocks,
-                                                      uint32_t m_total, bool want_gid, unsigned bid) {
+                                                      uint32_t m_total, bool want_gid, unsigned bid, int n) {
     EmitLoads el;
     const uint32_t slot0 = bid * (uint32_t)kSortChunk;
     const uint32_t slot_end = slot0 + min((uint32_t)kSortChunk, m_total - slot0);
     // owner of the first slot (noted by the scan), and the last gaussian that can start inside this block: the owner
     // of the next block's first slot, or the last gaussian with records when this is the last live block
-    el.k_lo = block_owner[bid];
-    el.k_hi = slot_end < m_total ? block_owner[bid + 1] : block_owner[n_owner_blocks];
+    // (clamped to [0, n): after a reported failure of the depth ordering the table may hold anything)
+    el.k_lo = min(max(block_owner[bid], 0), n - 1);
+    el.k_hi = min(max(slot_end < m_total ? block_owner[bid + 1] : block_owner[n_owner_blocks], el.k_lo), n - 1);
 #pragma unroll
     for (int j = 0; j < kEmitStage / kSortThreads; ++j) {
         const int k = min(el.k_lo + j * kSortThreads + (int)threadIdx.x, el.k_hi);   // (clamped, not predicated)
@@ -754,7 +753,7 @@ __global__ __launch_bounds__(kSortThreads) void emit_hist_kernel(int n, const ui
         return;
     }
     h[threadIdx.x] = 0;
-    const EmitLoads el = emit_owner_loads(offsets, rects, order, block_owner, nblocks, m_total, false, sort_block_id());
+    const EmitLoads el = emit_owner_loads(offsets, rects, order, block_owner, nblocks, m_total, false, sort_block_id(), n);
     const EmitBlock eb = emit_owners(el, offsets, m_total, s_own, s_g, scratch, sort_block_id());
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
@@ -793,7 +792,7 @@ __global__ __launch_bounds__(kSortThreads) void emit_scatter_kernel(
     SORT_TRACE_BEGIN();
     // (chunk = workgroup index here, not sort_block_id(): with the XCD-wise assignment this kernel's scattered run
     // stores arrive from eight distant fronts of every digit's segment at once -- measured 41 -> 45 us)
-    const EmitLoads el = emit_owner_loads(offsets, rects, order, block_owner, nblocks, m_total, true, blockIdx.x);   // (in flight
+    const EmitLoads el = emit_owner_loads(offsets, rects, order, block_owner, nblocks, m_total, true, blockIdx.x, n);   // (in flight
                                                                                                           // under the scans)
     {
         uint32_t tot, dt = digit_total[t];
@@ -813,8 +812,10 @@ __global__ __launch_bounds__(kSortThreads) void emit_scatter_kernel(
     for (int r = 0; r < kSortItems; ++r) {
         const uint32_t slot = wbase + r * 64 + lane;
         k[r] = 0xFFFFu; v[r] = 0u;
-        if (slot < eb.live)
+        if (slot < eb.live) {
             emit_record<true>(eb, slot, s_val, s_g, offsets, rects, order, tile_w, k[r], v[r]);
+            v[r] = min(v[r], (uint32_t)n - 1u);   // (the compositor gathers splat rows by this id, unchecked)
+        }
     }
     __syncthreads();   // owners and staged data consumed: the regions start their second life
     SORT_TRACE_MARK(2);   // record generation
@@ -1280,6 +1281,14 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
         }
         ex += c[j];
     }
+    // A bucket beyond the LDS capacity (reported through ctl[3]; the caller repeats with the LSD path) still leaves every
+    // entry of its range DEFINED: the kernels queued behind this one run before the host has seen the report, and they
+    // must not chase recycled memory.  The tail entries own no records (count 0 at the bucket's end).
+    for (uint32_t i = (uint32_t)mm + (uint32_t)t; i < m; i += kLocalThreads) {
+        order[lo + i] = 0u;
+        rects[lo + i] = 0u;
+        offsets[lo + i] = base + bucket_total;
+    }
     SORT_TRACE_MARK(5);   // offsets + block owners
     SORT_TRACE_END(3);
 }
@@ -1445,11 +1454,7 @@ extern "C" int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offs
     // runs of 64+.
     int id_bits = 0;
     while ((1 << id_bits) < n_tiles) ++id_bits;
-    int low_bits = two ? (id_bits + 1) / 2 : 8;
-    if (const char *e = getenv("GSPLAT_AMD_TILE_LOW_BITS")) {   // (experiments: 8 = the former 8 + 5 split)
-        const int b = atoi(e);
-        if (two && b >= id_bits - 8 && b <= 8) low_bits = b;
-    }
+    const int low_bits = two ? (id_bits + 1) / 2 : 8;
     const uint32_t low_mask = (1u << low_bits) - 1u;
     GSA_RETURN_IF(two && (!tile_tmp || !gid_tmp || (reinterpret_cast<uintptr_t>(tile_tmp) & 3) != 0),
                   GSA_ERR_INVALID_ARGUMENT);

@@ -94,6 +94,31 @@ def _compare(sc, vm, K, W, H, deg, bg, seed=2, use_v_alpha=True, checkpoint=Fals
     return m1, m32, report
 
 
+def _bwd_modes():
+    """Backward list sweeps this build of the library has: the product library only the two-phase one (2)."""
+    import ctypes
+    from gsplat_amd._lib import LIB_PATH
+    return (2, 1, 0) if hasattr(ctypes.CDLL(LIB_PATH), "gsa_debug_set_bwd_mode") else (2,)
+
+
+class _bwd_mode:
+    def __init__(self, mode):
+        self.mode = mode
+
+    def _set(self, mode):
+        import ctypes
+        from gsplat_amd._lib import LIB_PATH
+        h = ctypes.CDLL(LIB_PATH)
+        if hasattr(h, "gsa_debug_set_bwd_mode"):
+            h.gsa_debug_set_bwd_mode(int(mode))
+
+    def __enter__(self):
+        self._set(self.mode)
+
+    def __exit__(self, *exc):
+        self._set(2)
+
+
 @pytest.fixture(scope="module")
 def gsa():
     import gsplat_amd
@@ -679,13 +704,10 @@ def test_random_shapes_fused_paths_agree_with_plain_ones(gsa):
                                                       want_lists=True, bin_tile=bt)
             assert torch.equal(rb, r0) and torch.equal(Tb, T0) and torch.equal(ab, a0), (tag, bt)
             sweeps = [S.composite_bwd(splat, gb, ob, bg, Tb, lb, v_r, None, W, H, 3, bin_tile=bt)]
-            for mode in ("2", "1", "0"):
-                os.environ["GSPLAT_AMD_BWD_MODE"] = mode
-                try:
+            for mode in _bwd_modes():
+                with _bwd_mode(mode):
                     sweeps.append(S.composite_bwd(splat, gb, ob, bg, Tb, lb, v_r, None, W, H, 3, quad_lists=lists_b,
                                                   bin_tile=bt))
-                finally:
-                    os.environ.pop("GSPLAT_AMD_BWD_MODE", None)
             for gsw in sweeps:
                 assert float(((g0 - gsw).abs().amax(0) / scale).max()) < 5e-5, (tag, bt)
 
@@ -729,16 +751,14 @@ def test_backward_sweep_over_blended_record_lists(gsa, W, H, N, cull_mode, chann
                 assert seen.size and int(lst[-1]) <= int(seen.max())
     g0 = S.composite_bwd(splat, sorted_gid, tile_offsets, bg, T0, l0, v_r, v_a, W, H, channels)
     scale = g0.abs().amax(0).clamp_min(1e-30)
-    # the three sweeps over the lists (developer switch GSPLAT_AMD_BWD_MODE): 2 = two-phase (default), 1 = record-
-    # parallel with prefix scans over the records, 0 = pixel-parallel with the transpose-reduce
-    try:
-        for mode in ("2", "1", "0"):
-            os.environ["GSPLAT_AMD_BWD_MODE"] = mode
+    # the sweep over the lists: the two-phase kernel (the only one in the product library); a developer build
+    # (-DGSA_DEV_KERNELS) also has 1 = record-parallel with prefix scans over the records and 0 = pixel-parallel with the
+    # transpose-reduce, selected through gsa_debug_set_bwd_mode
+    for mode in _bwd_modes():
+        with _bwd_mode(mode):
             g1 = S.composite_bwd(splat, sorted_gid, tile_offsets, bg, T0, l0, v_r, v_a, W, H, channels,
                                  quad_lists=(qlist, qcount))
-            assert float(((g0 - g1).abs().amax(0) / scale).max()) < 2e-5, mode
-    finally:
-        os.environ.pop("GSPLAT_AMD_BWD_MODE", None)
+        assert float(((g0 - g1).abs().amax(0) / scale).max()) < 2e-5, mode
 
 
 @pytest.mark.parametrize("W,H,N,s_max,giants", [(640, 360, 30_000, 0.05, 0), (160, 96, 4000, 0.3, 0),
@@ -1009,9 +1029,22 @@ def test_depth_cluster_falls_back_to_the_lsd_path(gsa):
     m, ok = first.finalize()
     assert ok and m == 4 * N and first.key_bits == 32
     ref_gid, ref_off = first.sorted_gid.clone(), first.tile_offsets.clone()
-    second = bins()                                    # steady state: bucketed ordering for the remembered range
+    # steady state: bucketed ordering for the remembered range.  The buffers it fills come out of the caching allocator
+    # un-initialised; here the blocks it is about to recycle hold 0xFF bytes, and -- as rasterization() and the harness
+    # do -- the compositor is queued on the bins BEFORE the host has looked at the report: every entry the overflowing
+    # bucket could not sort must still be defined (no gaussian id beyond N, no record list outside the buffers).
+    junk = [torch.full((sz,), -1, dtype=torch.int32, device="cuda") for sz in (N, N, N, 4 * N, 4 * N, 2 * N, 2 * N, N // 2)]
+    del junk
+    second = bins()
     assert isinstance(second.key_bits, tuple)
-    assert second.finalize()[1] is False, "the overflowing bucket must surface through finalize()"   # (its M is garbage)
+    order = S.tile_schedule(second.tile_offsets, W, H)
+    out = S.composite_fwd(splat, second.sorted_gid_buffer, second.tile_offsets, None, W, H, 3, order, want_lists=True)
+    torch.cuda.synchronize()                           # (a fault would surface here)
+    assert float(out[0].abs().max()) == 0.0
+    m2, ok2 = second.finalize()
+    assert ok2 is False, "the overflowing bucket must surface through finalize()"   # (its M counts the sorted part only)
+    live = second.sorted_gid_buffer[:min(m2, second.capacity)].long() & 0xFFFFFFFF
+    assert m2 < m and int(live.max()) < N
     repair = bins(exact=True)
     assert repair.finalize() == (m, True)
     assert torch.equal(repair.sorted_gid, ref_gid) and torch.equal(repair.tile_offsets, ref_off)
