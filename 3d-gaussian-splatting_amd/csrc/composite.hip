@@ -126,6 +126,7 @@ __device__ __forceinline__ void wave_unit(int b, int n_tiles, const int32_t *__r
 // quadrant, in walk order.
 template <int F4>
 struct Staged {
+    static constexpr bool kDense = false;
     static constexpr int kRecBytes = 16 * F4;
     float4 rec[(kBatch + 1) * F4];
     uint16_t list[kBatch + 8];
@@ -171,6 +172,67 @@ __device__ __forceinline__ bool quadrant_reach(float mx, float my, float a, floa
         best = fminf(best, 0.5f * (a * ex * ex + c * ey * ey) + b * ex * ey);
     }
     return best <= thr;
+}
+
+// Which 8 x 8 quadrants of a block of Q x Q quadrants (origin (X0, Y0): pixel coordinates of its first pixel) can the
+// alpha >= 1/255 region of a splat reach?  Bit order = the compositor's quadrant slices (tile_list): Q = 2: (qy << 1) | qx;
+// Q = 4 (a 32 x 32 bin): (((j >> 1) << 1 | (i >> 1)) << 2) | ((j & 1) << 1) | (i & 1) for quadrant column i, row j.
+// Per row of quadrants (a band of 8 pixel-centre rows) the reachable region is an INTERVAL in x -- the projection of
+// (ellipse intersected with the band), a convex set -- whose ends are the ellipse's right- / leftmost points when those lie
+// inside the band and lie on the band's nearer edge otherwise: two square roots per band instead of a min-sigma search
+// per quadrant.  A SUPERSET of the per-pixel rule is all the compositor needs (it re-tests what it stages, and a record
+// that passes no pixel's alpha test blends nothing): the threshold carries quadrant_reach's margin, the interval another
+// 1e-3 px, and a conic too ill-conditioned for the closed form (needle-like splats) gets every bit.
+template <int Q>
+__device__ __forceinline__ uint32_t reach_mask(float mx, float my, float a, float b, float c, float sig_max, float X0,
+                                               float Y0) {
+    constexpr uint32_t kAll = Q == 2 ? 0xFu : 0xFFFFu;
+    const float t2 = 2.f * (sig_max * 1.0001f + 1e-4f);
+    const float D = a * c - b * b;
+    if (!(D > 1e-3f * a * c) || !(t2 > 0.f)) return kAll;
+    const float ra = __builtin_amdgcn_rcpf(a), rD = __builtin_amdgcn_rcpf(D);
+    const float vmax = __builtin_sqrtf(t2 * a * rD) + 1e-3f;                  // the ellipse's extent in y
+    const float vR = -b * __builtin_sqrtf(t2 * c * rD) * __builtin_amdgcn_rcpf(c);   // y offset of its rightmost point
+    const float k = -b * ra;                                                    // centre line: u = k v
+    const float eps = 1e-3f;
+    uint32_t m = 0;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+        const float v0 = (Y0 + 8.f * j + 0.5f) - my, v1 = v0 + 7.f;            // pixel centre - mean
+        const float w0 = fmaxf(v0, -vmax), w1 = fminf(v1, vmax);
+        const bool band = w0 <= w1;
+        const float vr = fminf(fmaxf(vR, w0), w1), vl = fminf(fmaxf(-vR, w0), w1);
+        const float R = k * vr + __builtin_sqrtf(fmaxf(0.f, t2 * a - D * vr * vr)) * ra + eps;
+        const float L = k * vl - __builtin_sqrtf(fmaxf(0.f, t2 * a - D * vl * vl)) * ra - eps;
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            const float u0 = (X0 + 8.f * i + 0.5f) - mx, u1 = u0 + 7.f;
+            const int bit = Q == 2 ? ((j << 1) | i) : (((((j >> 1) << 1) | (i >> 1)) << 2) | ((j & 1) << 1) | (i & 1));
+            m |= (band && L <= u1 && R >= u0) ? (1u << bit) : 0u;
+        }
+    }
+    return m;
+}
+
+// One thread per binned record: the quadrant mask of (bin, gaussian).  The forward compositor's waves test ONE bit of it
+// per list entry before they gather anything: of the records of a 32 x 32 bin only a fifth reach a given 8 x 8 quadrant.
+template <int SHIFT>
+__global__ __launch_bounds__(256) void quadrant_mask_kernel(uint32_t m_cap, const uint32_t *__restrict__ m_dev,
+                                                            const uint16_t *__restrict__ sorted_bin,
+                                                            const uint32_t *__restrict__ sorted_gid,
+                                                            const float *__restrict__ splat, int bin_w, int n,
+                                                            uint16_t *__restrict__ mask_out) {
+    const uint32_t m = m_dev ? min(m_cap, *m_dev) : m_cap;
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= m) return;
+    const uint32_t gid = min(sorted_gid[p], (uint32_t)n - 1u);
+    const uint32_t bin = sorted_bin[p];
+    const float4 *row = reinterpret_cast<const float4 *>(splat + (size_t)gid * GSA_SPLAT_STRIDE);
+    const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+    const int by = (int)bin / bin_w, bx = (int)bin - by * bin_w;
+    constexpr int Q = 2 << SHIFT;
+    mask_out[p] = (uint16_t)reach_mask<Q>(r0.x, r0.y, r0.z, r0.w, r1.x, r2.z, (float)(bx * (kTile << SHIFT)),
+                                          (float)(by * (kTile << SHIFT)));
 }
 
 // Lane `lane` writes its record (list position idx) into slot `lane` of the wave's LDS image and tests it against
@@ -269,13 +331,15 @@ struct FwdPixel {
 
 // One group of G list entries starting at entry i: per-record alpha (0 where skipped / pixel finished), colours,
 // list positions.
-template <int CH, int F4, bool CLAMP, int G>
-__device__ __forceinline__ void eval_group(const Staged<F4> &st, int i, float pxf, float pyf,
+template <int CH, int F4, bool CLAMP, int G, typename ST>
+__device__ __forceinline__ void eval_group(const ST &st, int i, float pxf, float pyf,
                                            float (&a)[G], float (&col)[G][CH], int (&idx)[G],
                                            unsigned long long (&passed)[G]) {
-    // one LDS broadcast gives G list entries
     uint32_t off[G];
-    if (G == 4) {
+    if constexpr (ST::kDense) {   // the staged records ARE the walk list: slot i + e
+#pragma unroll
+        for (int e = 0; e < G; ++e) off[e] = (uint32_t)(i + e) * (uint32_t)(16 * F4);
+    } else if constexpr (G == 4) {   // one LDS broadcast gives G list entries
         const uint2 o4 = *reinterpret_cast<const uint2 *>(&st.list[i]);
         off[0] = o4.x & 0xFFFFu; off[1] = o4.x >> 16; off[G - 2] = o4.y & 0xFFFFu; off[G - 1] = o4.y >> 16;
     } else {
@@ -284,7 +348,7 @@ __device__ __forceinline__ void eval_group(const Staged<F4> &st, int i, float px
     }
 #pragma unroll
     for (int e = 0; e < G; ++e) {
-        const float4 *p = rec_at(st, off[e]);
+        const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(st.rec) + off[e]);
         const float4 q0 = p[0], q1 = p[1], q2 = p[2];
         const float dx = q0.x - pxf, dy = q0.y - pyf;
         float raw;
@@ -313,8 +377,8 @@ __device__ __forceinline__ void note_taken(unsigned long long &contrib, unsigned
 // Walks n list entries.  Returns false when all 64 pixels of the wave are finished.
 // LISTS: `contrib` receives one bit per list entry that was BLENDED at one pixel of the quadrant at least (alpha test
 // passed, pixel live and not stopping there) -- the records the backward sweep has to visit here.
-template <int CH, int F4, bool CLAMP, int LISTS>
-__device__ __forceinline__ bool walk_fwd(const Staged<F4> &st, int n, float pyf, FwdPixel<CH> &px,
+template <int CH, int F4, bool CLAMP, int LISTS, typename ST>
+__device__ __forceinline__ bool walk_fwd(const ST &st, int n, float pyf, FwdPixel<CH> &px,
                                          unsigned long long &contrib) {
     constexpr int G = GSA_FWD_GROUP;
     int i = 0;
@@ -374,19 +438,38 @@ __device__ __forceinline__ bool walk_fwd(const Staged<F4> &st, int n, float pyf,
     return true;
 }
 
+// ---- the forward kernel ------------------------------------------------------------------------------------------
+// A (tile, quadrant) wave walks its bin's depth-ordered record list in three decoupled steps:
+//   SCAN   128 list entries at a time: (gaussian id, quadrant mask) pairs, coalesced; the entries whose mask has this
+//          wave's quadrant bit (gsa_quadrant_masks: ~22 % in a 32 x 32 bin) are appended to a small queue in LDS -- ballot
+//          + mbcnt, about a dozen vector instructions per 64 entries, nothing gathered for the others;
+//   STAGE  64 queued candidates at a time: one 64-B splat record per lane (the gather is in flight while the previous
+//          batch is blended), re-tested against the bounding box of the pixels that are still accumulating, and the
+//          survivors written to CONSECUTIVE slots of the wave's LDS image -- so that
+//   WALK   needs no offset list: slot i of the image is entry i of the walk (walk_fwd with a dense image).
+// Without masks (sorted_mask == NULL: the 32-bit binning paths) every entry is a candidate and STAGE's test is the filter.
+constexpr int kQueue = 256;        // candidates: < 64 left over + 128 from one scan step
+constexpr int kScanWin = 2;        // windows of 64 entries per scan step
+template <int F4>
+struct Dense {
+    static constexpr bool kDense = true;
+    float4 rec[(kBatch + GSA_FWD_GROUP - 1) * F4];   // staged records, then NULL records padding the walk to whole groups
+    uint2 queue[kQueue];             // (gaussian id, list position)
+};
+
 // LISTS: additionally writes, per quadrant, the list positions of the records that were blended there
-// (quad_list[4 * start + q * (end - start) ...], ascending) and their number (quad_count[4 * tile + q]): in a dense
-// scene ~45 % of the records a quadrant walks pass its reach test and ~90 % of those blend somewhere -- the backward
+// (quad_list[4 * start + q * (end - start) ...], ascending) and their number (quad_count[4 * tile + q]): the backward
 // sweep then visits exactly those, without a reach test and in full batches.
-template <int CH, int LISTS>
+template <int CH, int LISTS, bool HAS_MASK>
 __global__ __launch_bounds__(kWave, GSA_FWD_WAVES) void composite_fwd_kernel(
     int width, int height, int tile_w, int n_tiles, int bin_shift, const float *__restrict__ splat,
-    const uint32_t *__restrict__ sorted_gid, const int32_t *__restrict__ tile_offsets,
+    const uint32_t *__restrict__ sorted_gid, const uint16_t *__restrict__ sorted_mask,
+    const int32_t *__restrict__ tile_offsets,
     const float *__restrict__ background, const int32_t *__restrict__ tile_order, float *__restrict__ render,
     float *__restrict__ alpha_out, float *__restrict__ final_T, int32_t *__restrict__ last_id,
     uint32_t *__restrict__ quad_list, int32_t *__restrict__ quad_count, float4 *__restrict__ zero4, long n_zero4) {
     constexpr int F4 = CH == 4 ? 4 : 3;
-    __shared__ Staged<F4> st;
+    __shared__ Dense<F4> st;
 
     // zero4 (optional): the gradient records the backward sweep will accumulate into.  Every wave clears its share on
     // the way in -- two fire-and-forget stores per lane under a walk that is bound by vector issue -- instead of a
@@ -409,6 +492,7 @@ __global__ __launch_bounds__(kWave, GSA_FWD_WAVES) void composite_fwd_kernel(
     const float pxf = px_ + 0.5f, pyf = py_ + 0.5f, qx0 = qx + 0.5f, qy0 = qy + 0.5f;
     int start, end, slice;   // this tile's record list (its bin's), and which of the bin's quadrant slices is this wave's
     tile_list(tile_offsets, tile, tile_w, bin_shift, q, start, end, slice);
+    const uint32_t my_bit = HAS_MASK ? 1u << slice : 1u;   // (no masks: every entry carries 0xFFFF)
 
     FwdPixel<CH> px;
     px.T = 1.f; px.Tend = 1.f; px.dead = inside ? 0u : kSign; px.last = -1;
@@ -419,41 +503,98 @@ __global__ __launch_bounds__(kWave, GSA_FWD_WAVES) void composite_fwd_kernel(
     uint32_t *my_list = LISTS ? quad_list + (((size_t)start << 2) << (2 * bin_shift)) + (size_t)slice * (size_t)(end - start) : nullptr;
 
     if (__ballot(inside) != 0ull && start < end) {
-        // software pipeline, two batches deep: ids of batch j+2 and records of batch j+1 are in flight while
-        // batch j is staged and blended (lane l of batch j holds list position start + 64 j + l)
-        auto load_gid = [&](int j) -> uint32_t {
-            const int p = start + j * kBatch + lane;
-            return p < end ? sorted_gid[p] : 0u;
+        // ---- SCAN state: the entries [p, p + 128) are in registers (loads clamped, not predicated: in flight together)
+        int p = start, head = 0, tail = 0;   // (wave-uniform)
+        uint32_t s_gid[kScanWin], s_mask[kScanWin];
+        auto scan_issue = [&]() {
+#pragma unroll
+            for (int w = 0; w < kScanWin; ++w) {
+                const int idx = p + w * kBatch + lane, ic = min(idx, end - 1);
+                s_gid[w] = sorted_gid[ic];
+                s_mask[w] = HAS_MASK ? (uint32_t)sorted_mask[ic] : 0xFFFFu;
+            }
         };
-        uint32_t gid_next = load_gid(0);
-        Row row = load_row(splat, gid_next, start + lane < end);
-        gid_next = load_gid(1);
+        auto scan_until = [&](int want) {   // append candidates until `want` are queued or the list ends
+            while (tail - head < want && p < end) {
+#pragma unroll
+                for (int w = 0; w < kScanWin; ++w) {
+                    const int idx = p + w * kBatch + lane;
+                    const bool hit = idx < end && (s_mask[w] & my_bit) != 0u;
+                    const unsigned long long b = __ballot(hit);
+                    if (b) {
+                        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
+                        if (hit) st.queue[(tail + rank) & (kQueue - 1)] = make_uint2(s_gid[w], (uint32_t)idx);
+                        tail += __builtin_popcountll(b);
+                    }
+                }
+                p += kScanWin * kBatch;
+                if (p < end) scan_issue();
+            }
+        };
+        // ---- a batch in flight: the queue's first `n` candidates, one splat record per lane
+        struct InFlight { Row row; int pos, n; };
+        auto pop = [&]() -> InFlight {
+            InFlight f;
+            f.n = min(kBatch, tail - head);
+            // (the queue writes above and this read are LDS operations of one wave: they complete in order)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint2 e = st.queue[(head + min(lane, max(f.n - 1, 0))) & (kQueue - 1)];
+            f.pos = (int)e.y;
+            f.row = load_row(splat, e.x, lane < f.n);
+            head += f.n;
+            return f;
+        };
+        scan_issue();
+        scan_until(kBatch);
+        InFlight cur = pop();
         GSA_TRACE_MARK(0);
-        for (int base = start, j = 0; base < end; base += kBatch, ++j) {
-            const int idx = base + lane;
-            bool any_cap;
-            // reach test against the bounding box of the pixels that are still accumulating (lane = 8 y + x): as the
-            // quadrant saturates -- and at the image border -- fewer records can reach anything that still matters
+        while (cur.n > 0) {
+            scan_until(kBatch);   // (vector work under the gather of `cur`)
+            // ---- STAGE: reach test against the bounding box of the pixels that are still accumulating (lane = 8 y + x) -- as
+            // the quadrant saturates, and at the image border, fewer records can reach anything that still matters --
+            // survivors to consecutive slots
             const unsigned long long alive = __ballot(px.dead == 0u);
             const uint32_t cols8 = (uint32_t)alive | (uint32_t)(alive >> 32);
             const uint32_t cols = (cols8 | (cols8 >> 16) | (cols8 >> 8) | (cols8 >> 24)) & 0xFFu;
             const float bx0 = qx0 + (float)__builtin_ctz(cols), bx1 = qx0 + (float)(31 - __builtin_clz(cols));
             const float by0 = qy0 + (float)(__builtin_ctzll(alive) >> 3), by1 = qy0 + (float)((63 - __builtin_clzll(alive)) >> 3);
-            const int n = stage_batch(st, lane, row, idx < end, idx, bx0, by0, bx1, by1, any_cap);
+            const float4 r0 = cur.row.r0, r1 = cur.row.r1, r2 = cur.row.r2;
+            const bool hit = lane < cur.n && quadrant_reach(r0.x, r0.y, r0.z, r0.w, r1.x, r2.z, bx0, by0, bx1, by1);
+            const unsigned long long hb = __ballot(hit);
+            const bool any_cap = __ballot(hit && r1.y > GSA_MAX_ALPHA) != 0ull;
+            const int n = __builtin_popcountll(hb);
+            const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0));
+            if (hit) {
+                st.rec[F4 * slot + 0] = make_float4(r0.x, r0.y, 0.5f * kLog2e * r0.z, kLog2e * r0.w);
+                st.rec[F4 * slot + 1] = make_float4(0.5f * kLog2e * r1.x, r1.y, r1.z, r1.w);
+                st.rec[F4 * slot + 2] = make_float4(r2.x, fmaxf(0.f, kLog2e * r2.z), __int_as_float(cur.pos), __uint_as_float(cur.row.gid));
+                if (F4 == 4) st.rec[F4 * slot + 3] = make_float4(r2.y, 0.f, 0.f, 0.f);
+            }
+            // NULL records (opacity 0: blend nothing) pad the walk to whole groups; they carry the list position of the
+            // last real entry (a pixel that is live behind the group has "seen" exactly that far)
+            const int last_pos = __builtin_amdgcn_readlane(cur.pos, hb ? 63 - __builtin_clzll(hb) : 0);
+            if (lane < (GSA_FWD_GROUP - 1) * F4) {
+                float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (lane % F4 == 2) z.z = __int_as_float(last_pos);
+                st.rec[F4 * n + lane] = z;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             GSA_TRACE_MARK(1);
-            // prefetch: the records of the next batch (their ids arrived during the previous walk), the ids after
-            row = load_row(splat, gid_next, idx + kBatch < end);
-            gid_next = load_gid(j + 2);
+            cur = pop();          // the next batch's gather is in flight during the walk
             GSA_TRACE_COUNT(n);
             unsigned long long contrib = 0ull;
             const bool live = any_cap ? walk_fwd<CH, F4, true, LISTS>(st, n, pyf, px, contrib)
                                       : walk_fwd<CH, F4, false, LISTS>(st, n, pyf, px, contrib);
             if (LISTS == 1) contrib = ~0ull;                   // every record the reach test kept
             contrib &= n >= 64 ? ~0ull : (1ull << n) - 1ull;   // the padding (null) entries "pass" with alpha 0
-            if (LISTS && contrib) {   // lane i < n <-> list entry i: append the blended ones, in list order
+            if (LISTS && contrib) {   // lane i < n <-> walk entry i: append the blended ones, in list order
                 const bool mine = (contrib >> lane) & 1ull;
                 const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(contrib >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)contrib, 0));
-                if (mine) my_list[listed + rank] = (uint32_t)__float_as_int(rec_at(st, st.list[lane])[2].z);
+                if (mine) my_list[listed + rank] = (uint32_t)__float_as_int(st.rec[F4 * lane + 2].z);
                 listed += __builtin_popcountll(contrib);
             }
             GSA_TRACE_MARK(4);
@@ -1360,14 +1501,35 @@ extern "C" int gsa_debug_set_trace(unsigned long long *buf) {
 }
 #endif
 
+extern "C" int gsa_quadrant_masks(uint32_t m_capacity, const uint32_t *m_dev, const uint16_t *sorted_bin,
+                                  const uint32_t *sorted_gid, const float *splat, int n, int width, int height, int bin_tile,
+                                  uint16_t *sorted_mask, gsa_stream_t stream) {
+    GSA_RETURN_IF(width <= 0 || height <= 0 || n < 0, GSA_ERR_INVALID_ARGUMENT);
+    const int bin_shift = bin_shift_of(bin_tile);
+    GSA_RETURN_IF(bin_shift < 0 || bin_shift > 1, GSA_ERR_INVALID_ARGUMENT);   // 16 masks 4 quadrants, 32 masks 16
+    if (m_capacity == 0 || n == 0) return GSA_OK;
+    GSA_RETURN_IF(!sorted_bin || !sorted_gid || !splat || !sorted_mask, GSA_ERR_INVALID_ARGUMENT);
+    const int bin_w = gsa_div_up(width, kTile << bin_shift);
+    const unsigned grid = (unsigned)gsa_div_up((long long)m_capacity, 256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (bin_shift == 0)
+        quadrant_mask_kernel<0><<<grid, 256, 0, s>>>(m_capacity, m_dev, sorted_bin, sorted_gid, splat, bin_w, n, sorted_mask);
+    else
+        quadrant_mask_kernel<1><<<grid, 256, 0, s>>>(m_capacity, m_dev, sorted_bin, sorted_gid, splat, bin_w, n, sorted_mask);
+    GSA_LAUNCH_CHECK();
+    return GSA_OK;
+}
+
 extern "C" int gsa_composite_fwd(int width, int height, int channels, const float *splat,
-                                 const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
+                                 const uint32_t *sorted_gid, const uint16_t *sorted_mask, const int32_t *tile_offsets,
+                                 const float *background,
                                  const int32_t *tile_order, float *render, float *alpha, float *final_T,
                                  int32_t *last_id, uint32_t *quad_list, int32_t *quad_count, float *v_splat_zero,
                                  long long n_zero_rows, int bin_tile, gsa_stream_t stream) {
     GSA_RETURN_IF(width <= 0 || height <= 0 || (channels != 3 && channels != 4), GSA_ERR_INVALID_ARGUMENT);
     const int bin_shift = bin_shift_of(bin_tile);
     GSA_RETURN_IF(bin_shift < 0, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(sorted_mask && bin_shift > 1, GSA_ERR_INVALID_ARGUMENT);   // (a 64 x 64 bin has 64 quadrants)
     GSA_RETURN_IF(!tile_offsets || !render || !alpha || !final_T || !last_id, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF((quad_list == nullptr) != (quad_count == nullptr), GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(n_zero_rows < 0 || (reinterpret_cast<uintptr_t>(v_splat_zero) & 15) != 0, GSA_ERR_INVALID_ARGUMENT);
@@ -1377,15 +1539,17 @@ extern "C" int gsa_composite_fwd(int width, int height, int channels, const floa
     const int n_tiles = tile_w * tile_h;
     const int grid = 32 * gsa_div_up(n_tiles, 8);   // one wave per (tile, quadrant)
     hipStream_t s = static_cast<hipStream_t>(stream);
-#define GSA_FWD_LAUNCH(C, L)                                                                                          \
-    composite_fwd_kernel<C, L><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid, tile_offsets, \
-                                                     background, tile_order, render, alpha, final_T, last_id,         \
-                                                     quad_list, quad_count, zero4, n_zero4)
+#define GSA_FWD_LAUNCH(C, L, M)                                                                                       \
+    composite_fwd_kernel<C, L, M><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid, \
+                                                        sorted_mask, tile_offsets, background, tile_order, render, alpha, \
+                                                        final_T, last_id, quad_list, quad_count, zero4, n_zero4)
+#define GSA_FWD_LAUNCH_CL(C, L) do { if (sorted_mask) GSA_FWD_LAUNCH(C, L, true); else GSA_FWD_LAUNCH(C, L, false); } while (0)
     if (quad_list) {
-        if (channels == 3) GSA_FWD_LAUNCH(3, GSA_LIST_MODE); else GSA_FWD_LAUNCH(4, GSA_LIST_MODE);
+        if (channels == 3) GSA_FWD_LAUNCH_CL(3, GSA_LIST_MODE); else GSA_FWD_LAUNCH_CL(4, GSA_LIST_MODE);
     } else {
-        if (channels == 3) GSA_FWD_LAUNCH(3, 0); else GSA_FWD_LAUNCH(4, 0);
+        if (channels == 3) GSA_FWD_LAUNCH_CL(3, 0); else GSA_FWD_LAUNCH_CL(4, 0);
     }
+#undef GSA_FWD_LAUNCH_CL
 #undef GSA_FWD_LAUNCH
     GSA_LAUNCH_CHECK();
     return GSA_OK;

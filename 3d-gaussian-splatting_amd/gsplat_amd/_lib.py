@@ -13,7 +13,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_u
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # GSPLAT_AMD_LIB: developer override to A/B another build of the SAME C ABI (still a HIP library; no fallback)
 LIB_PATH = os.environ.get("GSPLAT_AMD_LIB") or os.path.join(_PKG_ROOT, "lib", "libgsplat_amd.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 SPLAT_STRIDE = 16
 
 P = c_void_p  # every device pointer and the stream cross the boundary as void*
@@ -41,7 +41,8 @@ SIGNATURES = {
     "gsa_sort_pairs_u32_dev": (c_int, [c_int, P, P, P, P, P, P, P, c_int, c_int, P, c_size_t, P]),
     "gsa_tile_emit_dev": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_uint32, P, P, P, P]),
     "gsa_tile_offsets_dev": (c_int, [c_uint32, P, P, c_int, P, P]),
-    "gsa_composite_fwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, c_longlong, c_int, P]),
+    "gsa_composite_fwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, c_longlong, c_int, P]),
+    "gsa_quadrant_masks": (c_int, [c_uint32, P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "gsa_composite_bwd_prepare": (c_int, [c_longlong, P, c_int, P, P, P]),
     "gsa_composite_bwd_lists": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, c_int, P]),
     "gsa_tile_schedule": (c_int, [c_int, P, P, c_int, c_int, P]),

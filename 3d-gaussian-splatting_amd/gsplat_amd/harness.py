@@ -586,7 +586,7 @@ class ViewParallelTrainer:
                 done = torch.cuda.Event()
                 done.record(side)
                 if side is not main:   # the sweep reads these on the main stream: keep their memory until it has
-                    for t in (pose, splat, radii, bins.sorted_gid_buffer, bins.tile_offsets, order, aux):
+                    for t in (pose, splat, radii, bins.sorted_gid_buffer, bins.sorted_mask, bins.tile_offsets, order, aux):
                         if t is not None:
                             t.record_stream(main)
             return pose, splat, radii, bins, order, done, aux
@@ -605,7 +605,8 @@ class ViewParallelTrainer:
             W, H = view["width"], view["height"]
             bt = bins.bin_tile
             render, _, final_T, last_id, lists = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bgc, W,
-                                                                 H, 3, order, want_lists=True, bin_tile=bt)
+                                                                 H, 3, order, want_lists=True, bin_tile=bt,
+                                                                 sorted_mask=bins.sorted_mask)
             s3, v = S.view_loss(render, view["image"], c.lambda_dssim, grad_scale=scale / n_views)
             v_splat = S.composite_bwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bgc, final_T, last_id, v, None,
                                       W, H, 3, order, quad_lists=lists, bin_tile=bt)

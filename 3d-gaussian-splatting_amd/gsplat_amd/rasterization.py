@@ -49,13 +49,13 @@ class _RasterizeOneCamera(torch.autograd.Function):
                            bin_tile=bt)
         tile_order = S.tile_schedule(bins.tile_offsets, width, height, bt)   # longest record lists first (speed only)
         out = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg_c, width, height, channels,
-                              tile_order, want_lists=want_lists, bin_tile=bt)
+                              tile_order, want_lists=want_lists, bin_tile=bt, sorted_mask=bins.sorted_mask)
         if not bins.finalize()[1]:
             bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, exact=True,
                                tile_rects=rects, bin_tile=bt)
             tile_order = S.tile_schedule(bins.tile_offsets, width, height, bt)
             out = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg_c, width, height, channels,
-                                  tile_order, want_lists=want_lists, bin_tile=bt)
+                                  tile_order, want_lists=want_lists, bin_tile=bt, sorted_mask=bins.sorted_mask)
         render, alpha, final_T, last_id = out[:4]
         quad_list, quad_count = out[4] if want_lists else (None, None)
         ctx.zeroed_records = out[4].zeroed if want_lists else None   # cleared by the forward kernel; used once

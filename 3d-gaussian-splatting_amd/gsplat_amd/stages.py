@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes
 import math
 import os
+import threading
 import time
 from typing import Optional, Tuple
 
@@ -46,8 +47,9 @@ TIMER = StageTimer()
 
 def _call(name: str, fn, *args) -> None:
     """Launch one C-ABI stage on the current stream; raise on a non-zero return code."""
-    if _GUARD_DEVICE[0] is not None and torch.cuda.current_device() != _GUARD_DEVICE[0]:
-        raise RuntimeError(f"gsplat_amd: {name} was given tensors on cuda:{_GUARD_DEVICE[0]} while the current device is "
+    guard, _GUARD.device = getattr(_GUARD, "device", None), None   # (of THIS call's tensors: consumed, never sticky)
+    if guard is not None and torch.cuda.current_device() != guard:
+        raise RuntimeError(f"gsplat_amd: {name} was given tensors on cuda:{guard} while the current device is "
                            f"cuda:{torch.cuda.current_device()}; launches go to the current device's stream -- call "
                            "torch.cuda.set_device(tensor.device) (one process per GPU) or use torch.cuda.device(...)")
     if TIMER.enabled:
@@ -60,7 +62,8 @@ def _call(name: str, fn, *args) -> None:
         TIMER.records.append((name, start, end))
 
 
-_GUARD_DEVICE = [None]   # index of the device the tensors of the stage being launched live on (set by _ptr)
+_GUARD = threading.local()   # .device: index of the device the tensors of the stage being launched live on (set by _ptr
+                             # while the arguments of ONE _call are evaluated, consumed by that _call; per host thread)
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -69,7 +72,7 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     if t is None:
         return None
     if t.is_cuda:
-        _GUARD_DEVICE[0] = t.device.index
+        _GUARD.device = t.device.index
     return t.data_ptr()
 
 
@@ -133,6 +136,9 @@ def _next_token() -> int:
 
 
 WAIT_STATS = [0, 0.0]   # read-backs waited for, seconds spent waiting: the host's slack per view (bench.py reports it)
+# how often the speculation behind the asynchronous binning failed and a view was binned again with exact sizes:
+# the remembered record capacity was too small / the depth ordering's assumptions (key range, bucket capacity) did not hold
+REPAIR_STATS = {"views": 0, "capacity_misses": 0, "key_range_repairs": 0}
 
 
 def _wait_slot(slot) -> None:
@@ -158,10 +164,13 @@ def _wait_slot_impl(slot) -> None:
     spins, t0 = 0, time.monotonic()
     while ((int(words[3]) >> 8) & 0xFFFFFF) != token:
         spins += 1
+        if spins > 64:
+            time.sleep(0)   # yield the GIL: other host threads (data loader, collective watchdog) must not starve
         if spins > 200 and time.monotonic() - t0 > 10.0:   # (never seen: the kernel is queued ahead of whatever the
             torch.cuda.synchronize()                       # caller did since; a device fault would surface here)
             if ((int(words[3]) >> 8) & 0xFFFFFF) != token:
                 raise RuntimeError("gsplat_amd: the depth ordering never reported its control words")
+            return
 
 
 # GSPLAT_AMD_SH_AUX=0: project_fwd leaves no digest of the coefficient rows and project_bwd reads the 192-B rows again
@@ -217,8 +226,10 @@ class TileBins:
     ``finalize()`` which the caller runs after it has queued the work that consumes the bins."""
 
     def __init__(self, sorted_tile, sorted_gid, tile_offsets, capacity, m_known, key, slot=None, n=0, key_bits=32,
-                 keys_ok=True):
+                 keys_ok=True, sorted_mask=None):
         self._tile, self._gid, self.tile_offsets = sorted_tile, sorted_gid, tile_offsets
+        # per record: which 8 x 8 quadrants of its tile / bin it can reach (gsa_quadrant_masks; None on the 32-bit paths)
+        self.sorted_mask = sorted_mask
         self.capacity, self._m, self._key, self._slot, self._n = capacity, m_known, key, slot, n
         # what the depth ordering assumed about the visible keys -- bits an LSD sort covered, or (key_min, scale) of the
         # bucketed one; None: nothing to check -- and the result of the check
@@ -245,6 +256,11 @@ class TileBins:
             if self.key_bits is not None:   # (the unfused path sorts all 32 bits and leaves no range)
                 self._keys_ok = _note_keys(self._key, int(ctl_host[1]) & 0xFFFFFFFF, int(ctl_host[2]) & 0xFFFFFFFF,
                                            self.key_bits, int(ctl_host[3]) & 0xFF if isinstance(self.key_bits, tuple) else 0)
+            REPAIR_STATS["views"] += 1
+            if self._m > self.capacity:
+                REPAIR_STATS["capacity_misses"] += 1
+            elif not self._keys_ok:
+                REPAIR_STATS["key_range_repairs"] += 1
         return self._m, self._m <= self.capacity and self._keys_ok
 
     def __iter__(self):   # sorted_tile, sorted_gid, tile_offsets = bin_tiles(...)
@@ -266,6 +282,12 @@ def tile_ids(sorted_tile: torch.Tensor) -> torch.Tensor:
 
 
 _BIN_FUSED_DEFAULT = os.environ.get("GSPLAT_AMD_BIN_FUSED", "1") != "0"
+# GSPLAT_AMD_QUAD_MASKS=1: per-record quadrant masks (gsa_quadrant_masks) for the forward compositor, which then gathers only
+# the records that can reach its quadrant.  OFF by default: measured at C3 the masked forward sweep is 0.025 ms faster
+# (0.152 -> 0.127 ms, 99.5 M -> 82.7 M vector instructions) but the mask pass costs 0.070 ms -- one random 64-B row fetch
+# per binned record, 3.7 M of them, where the compositor's own gathers meet in L2 sixteen waves at a time and stop at
+# the quarter of a list where the pixels saturate (profiles/r03_fwd_masks.md).
+_QUAD_MASKS = os.environ.get("GSPLAT_AMD_QUAD_MASKS", "0") != "0"
 # (device, W, H, cull_mode) -> [records per gaussian the next call provisions for, consecutive low counts].
 # Keyed WITHOUT N: densify / prune changes N every 100 iterations (trainer.py:794-797) and a changed N predicts its
 # capacity from the remembered ratio instead of costing a blocking read-back.  Grows at once, shrinks only after many
@@ -365,7 +387,7 @@ def _note_count(key, n: int, m: int) -> None:
 
 def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, cull_mode: int = 0,
               exact: bool = False, fused: Optional[bool] = None, tile_rects=None, depth_msd: Optional[bool] = None,
-              bin_tile: int = TILE_SIZE) -> TileBins:
+              bin_tile: int = TILE_SIZE, quad_masks: Optional[bool] = None) -> TileBins:
     """Depth-order the gaussians, emit their tile records in that order, stable-sort the records by tile.
     -> TileBins(sorted_tile, sorted_gid, tile_offsets [n_tiles+1] i32).  ``sorted_tile`` holds 16-bit tile ids (an
     int16 tensor of uint16 bit patterns) on the fused path, int32 otherwise: read it through ``tile_ids``.
@@ -480,7 +502,13 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
               height, bin_tile, cap,
               _ptr(total), _ptr(k_tmp), _ptr(v_tmp), _ptr(sorted_tile), _ptr(sorted_gid), _ptr(tile_offsets), _ptr(ws2),
               ws2_bytes, st)
-        return TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key, slot, N, key_bits, keys_ok)
+        sorted_mask = None
+        # (optional: what a forward-compositor wave tests before it gathers a record; see _QUAD_MASKS)
+        if bin_tile <= 2 * TILE_SIZE and (_QUAD_MASKS if quad_masks is None else quad_masks):
+            sorted_mask = torch.empty(cap, dtype=torch.int16, device=dev)
+            _call("gsa_quadrant_masks", lib.gsa_quadrant_masks, cap, _ptr(total), _ptr(sorted_tile), _ptr(sorted_gid),
+                  _ptr(splat), N, width, height, bin_tile, _ptr(sorted_mask), st)
+        return TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key, slot, N, key_bits, keys_ok, sorted_mask)
     isect_tile = torch.empty(cap, dtype=torch.int32, device=dev)
     isect_gid = torch.empty(cap, dtype=torch.int32, device=dev)
     _call("gsa_tile_emit", lib.gsa_tile_emit_dev, N, _ptr(order), _ptr(offsets), _ptr(splat), _ptr(radii), width,
@@ -524,8 +552,9 @@ class QuadLists(tuple):
 
 
 def composite_fwd(splat, sorted_gid, tile_offsets, background, width: int, height: int, channels: int,
-                  tile_order=None, want_lists: bool = False, bin_tile: int = TILE_SIZE):
-    """-> render [H,W,channels], alpha [H,W,1], final_T [H,W], last_id [H,W] i32
+                  tile_order=None, want_lists: bool = False, bin_tile: int = TILE_SIZE, sorted_mask=None):
+    """``sorted_mask``: ``TileBins.sorted_mask`` of the same bins (optional; speed only).
+    -> render [H,W,channels], alpha [H,W,1], final_T [H,W], last_id [H,W] i32
     [, QuadLists(quad_list [4 * len(sorted_gid)] i32, quad_count [n_tiles,4] i32) with ``want_lists``: per 8x8 quadrant
     the records that were blended there -- what ``composite_bwd(..., quad_lists=...)`` sweeps]."""
     dev = splat.device
@@ -540,8 +569,10 @@ def composite_fwd(splat, sorted_gid, tile_offsets, background, width: int, heigh
         quad_list = torch.empty(slices * max(int(sorted_gid.numel()), 1), dtype=torch.int32, device=dev)
         quad_count = torch.empty(tile_w * tile_h, 4, dtype=torch.int32, device=dev)
         zeroed = torch.empty_like(splat)   # the backward sweep's gradient records: the forward kernel clears them
+    if sorted_mask is not None and (sorted_mask.numel() < sorted_gid.numel() or sorted_mask.dtype != torch.int16):
+        raise ValueError("composite_fwd: sorted_mask must be the int16 tensor of the same bins as sorted_gid")
     _call("gsa_composite_fwd", lib.gsa_composite_fwd, width, height, channels, _ptr(splat), _ptr(sorted_gid),
-          _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(render), _ptr(alpha), _ptr(final_T),
+          _ptr(sorted_mask), _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(render), _ptr(alpha), _ptr(final_T),
           _ptr(last_id), _ptr(quad_list), _ptr(quad_count), _ptr(zeroed), 0 if zeroed is None else zeroed.shape[0],
           bin_tile, _stream())
     if want_lists:

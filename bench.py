@@ -2,9 +2,12 @@
 """bench.py -- Mpix/s of rasterizer forward+backward on the synthetic 1M-gaussian / 1080p scene
 (BASELINE.json metric; SURVEY.md section 8d workload "C3"), 1..8 MI355X, one process per GPU.
 
-A step = one pass of the hot path over one view per rank: rasterization forward (project, bin, composite)
-+ the synthetic upstream gradient v_render + full backward to the five input gradients; with N > 1 ranks the
-view-parallel exchange (RCCL all-reduce of the 59*N-float gaussian gradients) is inside the step.
+A step = one pass of the hot path over one batch of views: every rank renders `--views-per-gpu` views (BASELINE
+config C3: B = 4 views per optimisation step) -- rasterization forward (project, bin, composite) + the synthetic
+upstream gradient v_render + full backward -- and the views' gradients are summed into ONE 59*N-float bucket; with
+N > 1 ranks the view-parallel exchange (RCCL over xGMI) is inside the step.  `value` = all views of all ranks x W x H /
+wall time.  The line also carries `single_view`: one view per step, one stream, a fixed camera -- the serial latency
+of a view, which is what the per-stage `stage_ms` / `roofline` figures are taken on.
 Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
@@ -32,6 +35,8 @@ for _p in (ROOT, os.path.join(ROOT, "3d-gaussian-splatting_amd")):
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+DEFAULT_VIEWS_PER_GPU = 4   # BASELINE config C3: B = 4 views per optimisation step
+DEFAULT_VIEW_STREAMS = 2
 WORKLOADS = {
     # name: (gaussians, width, height, sh_degree)
     "C3": (1_000_000, 1920, 1080, 3),
@@ -158,6 +163,9 @@ def self_launch(args) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
+    # The pool's host driver only supports dmabuf IPC: with the legacy IPC mode RCCL's buffer registration between the
+    # ranks of one node fails with `hipIpcGetMemHandle: invalid argument`.  The image exports this already; it is
+    # repeated here so that a shell which lost it still gets working collectives (never overrides a caller's value).
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     print(f"[bench] WORLD_SIZE unset: launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
     return subprocess.call(cmd, env=env)
@@ -170,16 +178,97 @@ def percentiles(xs):
             "p90": round(pick(0.9), 4)}
 
 
+class Exchange:
+    """The view-parallel exchange of one step: sums the 59 N-float gaussian gradient over the ranks.
+
+    ``factored``: every view leaves d loss / d rgb (3 N floats) instead of the 48 N-float
+    SH-coefficient gradient; the ranks all-GATHER that per view -- right behind the view's backward pass, so that with
+    several views per GPU the gather of view j travels while view j + 1 renders -- all-REDUCE the 11 N geometry floats
+    once per step, and rebuild sum_views basis (x) v_rgb locally (``expand``: stages.sh_grad_expand; summed in a fixed
+    view order, so the result is bit-identical on every rank).  Otherwise: one all-reduce of the whole bucket.
+
+    ``dist`` is torch.distributed or any object with its collectives (tests/test_bench_exchange.py drives this class with
+    a recording stand-in on the CPU, so that a shape or argument mistake in the RCCL branch does not wait for an 8-GPU
+    node to be found); ``dist = None``: one process, the factored form still saves the 48 N-float read-modify-write of
+    every view but the first."""
+
+    def __init__(self, dist, world: int, rank: int, n: int, views_per_gpu: int, factored: bool, device, expand=None):
+        self.dist, self.world, self.rank, self.n, self.B, self.factored = dist, world, rank, n, views_per_gpu, factored
+        self.expand = expand
+        self.backend = dist.get_backend() if dist is not None else None
+        # [view j of the step][rank][gaussian][rgb]: slot (j, rank) is what this rank's view j writes; gather j fills row j
+        self.v_rgb = torch.zeros(views_per_gpu, world, n, 3, device=device) if factored else None
+        self.pending = []
+        self.bytes_sent = 0   # by this rank, over all steps so far (ring / direct algorithms: (R - 1) / R of a buffer per phase)
+        self.steps = 0
+
+    def view_target(self, j: int):
+        """Where view j of this rank's step writes its rgb gradient (None: plain form)."""
+        return self.v_rgb[j, self.rank] if self.factored else None
+
+    def after_view(self, j: int) -> None:
+        """Queued right behind view j's backward pass, on its stream."""
+        if self.dist is None or not self.factored:
+            return
+        mine = self.v_rgb[j, self.rank]
+        if self.backend == "nccl":
+            work = self.dist.all_gather_into_tensor(self.v_rgb[j].view(self.world * self.n, 3), mine, async_op=True)
+        else:   # (gloo rehearsal: list form; the input must not alias an output)
+            work = self.dist.all_gather(list(self.v_rgb[j].unbind(0)), mine.clone(), async_op=True)
+        self.pending.append(work)
+        self.bytes_sent += mine.numel() * 4 * (self.world - 1)
+
+    def finish(self, flat_grad, means, deg: int, viewmats, Kmat, v_colors) -> None:
+        """After the last view's backward: the geometry all-reduce, the gathers' completion, the local rebuild.
+        viewmats: [B * world, 4, 4], entry j * world + r = the camera of rank r's view j."""
+        n = self.n
+        self.steps += 1
+        if self.factored:
+            summed = None
+            if self.dist is not None:
+                summed = self.dist.all_reduce(flat_grad[:11 * n], async_op=True)
+                self.bytes_sent += 2 * 11 * n * 4 * (self.world - 1) // self.world   # (ring / direct: 2 (R-1)/R of the buffer)
+            for work in self.pending:
+                work.wait()
+            self.pending = []
+            self.expand(means, deg, viewmats, Kmat, self.v_rgb.view(self.B * self.world, n, 3), v_colors)
+            if summed is not None:
+                summed.wait()
+        elif self.dist is not None:
+            self.dist.all_reduce(flat_grad)
+            self.bytes_sent += 2 * flat_grad.numel() * 4 * (self.world - 1) // self.world
+
+
+def rccl_version() -> str:
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception as exc:   # noqa: BLE001
+        return f"unknown ({type(exc).__name__})"
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)   # 0.14 s of device time: a 50-step window moved by +-1.5 %
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)   # x 4 views: 0.25 s of device time
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--cull-mode", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", default="factored", choices=("factored", "allreduce"),
-                    help="N > 1: how ranks sum the gaussian gradients (see DESIGN.md section 6)")
+                    help="how the gaussian gradients of the views are summed (see DESIGN.md section 6)")
+    ap.add_argument("--views-per-gpu", type=int, default=DEFAULT_VIEWS_PER_GPU,
+                    help="views every rank renders per step (BASELINE config C3: B = 4 views per step); the cameras of a "
+                         "step are `views-per-gpu x gpus` consecutive cameras of the ring")
+    ap.add_argument("--view-streams", type=int, default=DEFAULT_VIEW_STREAMS,
+                    help="HIP streams the views of a step alternate on (2: view j + 1's HBM- / latency-bound front end "
+                         "runs beside view j's VALU-bound sweeps; 1: strictly one view after the other)")
+    ap.add_argument("--views", type=int, default=8,
+                    help="ring size of the ROTATING-view pass (the reference samples random views every step, "
+                         "trainer.py:315-317): one view per step, cycling through this many cameras")
+    ap.add_argument("--profile-run", action="store_true",
+                    help="for rocprofv3: only `warmup` + `steps` single-view steps (one view per step, one stream, fixed "
+                         "camera), no settling, no extra passes; prints a minimal line")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -202,9 +291,12 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
+    import contextlib
+
     import gsplat_amd
     from gsplat_amd import scene, stages
 
+    B = max(1, args.views_per_gpu)
     n, width, height, deg = WORKLOADS[args.workload]
     sc = scene.make_scene(n, seed=0, sh_degree=deg, device="cpu")
     # the five rasterizer inputs (59 floats per gaussian) are views of one flat buffer and their gradients are
@@ -226,52 +318,77 @@ def main() -> None:
         off += cnt
     opac = leaves[3]
     K = scene.make_intrinsics(width, height).to(dev)[None]
-    # weak scaling: rank r renders view r of a ring of `world` cameras (view 0 = the single-GPU view)
-    vm = scene.make_camera(rank, world).to(dev)[None]
     v_render = scene.make_v_render(width, height, seed=2).to(dev)[None]
     bg = torch.zeros(1, 3, device=dev)
     info = {}
-    # N > 1, factored exchange: 48 of the 59 gradient floats per gaussian are the SH-coefficient gradient, which is
-    # the outer product basis(view direction) x (d loss / d rgb); every rank knows every rank's camera, so ranks
-    # all-reduce the 11 N geometry floats, all-gather 3 N rgb-gradient floats each and rebuild the coefficient
-    # gradient locally (summed in rank order: bit-identical on every rank).
-    factored = dist is not None and args.exchange == "factored"
-    if dist is not None:
-        vm_all = torch.stack([scene.make_camera(r, world) for r in range(world)]).to(dev)
-        vr_all = torch.zeros(world, n, 3, device=dev)
-        vr_mine = vr_all[rank]
+    rings = {}
 
-    def step(factored=factored):
-        for t in leaves:
-            t.grad = None
-        # the backward pass writes every gradient element straight into the bucket (no zero-fill, no copy)
-        # (opacities [N,1] -> [N] as the reference backend does it, gsplat_backend.py:157-158)
-        r, a, meta = gsplat_amd.rasterization(leaves[0], leaves[1], leaves[2], opac.squeeze(-1), leaves[4], vm, K, width,
-                                              height, sh_degree=deg, backgrounds=bg, cull_mode=args.cull_mode,
-                                              grad_out=grad_views, sh_grad_factored=vr_mine if factored else None)
-        r.backward(v_render)
-        if dist is not None and stages.TIMER.enabled:   # instrumented pass: time the whole exchange on the stream
-            x0 = torch.cuda.Event(enable_timing=True)
-            x0.record()
-        if factored:
-            # gather first, so the local rebuild of the SH gradient runs beside the geometry all-reduce
-            if dist.get_backend() == "nccl":
-                gathered = dist.all_gather_into_tensor(vr_all, vr_mine, async_op=True)
-            else:
-                gathered = dist.all_gather(list(vr_all.unbind(0)), vr_mine.clone(), async_op=True)
-            summed = dist.all_reduce(flat_grad[:11 * n], async_op=True)
-            gathered.wait()
-            stages.sh_grad_expand(leaves[0], deg, vm_all, K, vr_all, grad_views[4])
-            summed.wait()
-        elif dist is not None:  # one all-reduce of the whole 59 N-float bucket (RCCL over xGMI)
-            dist.all_reduce(flat_grad)
-        if dist is not None and stages.TIMER.enabled:
-            x1 = torch.cuda.Event(enable_timing=True)
-            x1.record()
-            stages.TIMER.records.append(("exchange", x0, x1))
-        if "M" not in info:   # (once: with 32 x 32 bins in the hot path the 16 x 16 record count is a reduction + read-back)
-            info["M"] = meta["n_isects"]
-            info["binned"] = meta["n_binned"]
+    def ring(v):   # the v cameras of a ring, on the device
+        if v not in rings:
+            rings[v] = torch.stack([scene.make_camera(i, v) for i in range(v)]).to(dev)
+        return rings[v]
+
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.view_streams))] if args.view_streams > 1 else []
+
+    def make_step(form: str, views: int, n_streams: int, ring_size: int):
+        """One step = `views` views on this rank (cameras j * world + rank of the step's window of the ring), forward +
+        backward each, their gradients summed into the bucket, then the exchange.  form: "factored" | "allreduce"."""
+        # one process, one view: nothing to sum, the backward writes the whole gradient itself
+        factored = form == "factored" and (world > 1 or views > 1)
+        ex = Exchange(dist, world, rank, n, views, factored, dev, expand=stages.sh_grad_expand)
+        use = streams[:n_streams] if n_streams > 1 else []
+        bwd_done = [torch.cuda.Event() for _ in range(views)]
+        step_done = torch.cuda.Event()
+        state = {"first": True}
+        cams, windows = ring(ring_size), {}
+
+        def step(i: int = 0):
+            for t in leaves:
+                t.grad = None
+            base = (i * views * world) % ring_size
+            main = torch.cuda.current_stream()
+            for j in range(views):
+                st = use[j % len(use)] if use else None
+                with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+                    vm = cams[(base + j * world + rank) % ring_size][None]
+                    # the backward pass writes every gradient element straight into the bucket (no zero-fill, no copy);
+                    # views after the first ADD to it.  (opacities [N,1] -> [N] as the reference backend does it,
+                    # gsplat_backend.py:157-158)
+                    r, a, meta = gsplat_amd.rasterization(leaves[0], leaves[1], leaves[2], opac.squeeze(-1), leaves[4], vm, K,
+                                                          width, height, sh_degree=deg, backgrounds=bg,
+                                                          cull_mode=args.cull_mode, grad_out=grad_views,
+                                                          grad_accumulate=j > 0, sh_grad_factored=ex.view_target(j))
+                    if st is not None:   # the bucket is summed into in view order; nothing else orders the streams
+                        if j > 0:
+                            st.wait_event(bwd_done[j - 1])
+                        elif not state["first"]:
+                            st.wait_event(step_done)
+                    r.backward(v_render)
+                    if st is not None:
+                        bwd_done[j].record(st)
+                    if dist is not None and stages.TIMER.enabled and j == views - 1:   # instrumented pass: the exchange's tail
+                        x0 = torch.cuda.Event(enable_timing=True)
+                        x0.record()
+                    ex.after_view(j)
+                if "M" not in info:   # (once: with 32 x 32 bins in the hot path the 16 x 16 record count is a reduction + read-back)
+                    info["M"] = meta["n_isects"]
+                    info["binned"] = meta["n_binned"]
+            for j in range(views if use else 0):
+                main.wait_event(bwd_done[j])
+            if factored or dist is not None:
+                if base not in windows:   # the cameras of the step's views, entry j * world + r = rank r's view j
+                    windows[base] = cams[(base + torch.arange(views * world, device=dev)) % ring_size].contiguous()
+                ex.finish(flat_grad, leaves[0], deg, windows[base], K, grad_views[4])
+            if dist is not None and stages.TIMER.enabled:
+                x1 = torch.cuda.Event(enable_timing=True)
+                x1.record()
+                stages.TIMER.records.append(("exchange_tail", x0, x1))
+            if use:
+                step_done.record(main)
+                state["first"] = False
+
+        step.exchange = ex
+        return step
 
     def fence():
         torch.cuda.synchronize()
@@ -279,119 +396,218 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed(form, warmup, per_step=False):
-        """`warmup` untimed steps, then exactly `steps` steps between two fences.  per_step: one event per step
-        boundary on the launch stream gives the per-step device times (median / p10 / p90) -- in a pass of its own:
-        an event record leaves a ~6 us bubble on the stream (rocprof kernel trace), 0.8 % of a step."""
-        for _ in range(warmup):
-            step(form)
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if per_step else None
+    def settle(step, limit=200, chunk=5, tol=0.02):
+        """Un-timed steps until three consecutive chunks of `chunk` steps take the same time within `tol` (bounded): the
+        first calls of a shape take the exact-size / LSD paths, the clocks ramp, and a short timed window right behind a
+        short warm-up measures that instead of the steady state.  -> steps run."""
+        times, done = [], 0
+        while done < limit:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for k in range(chunk):
+                step(done + k)
+            b.record()
+            b.synchronize()
+            done += chunk
+            times.append(a.elapsed_time(b))
+            if len(times) >= 3 and max(times[-3:]) <= (1.0 + tol) * min(times[-3:]):
+                break
+        if dist is not None:   # every rank must run the same number of steps (they contain collectives)
+            t = torch.tensor([done], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            for k in range(int(t.item()) - done):
+                step(done + k)
+            done = int(t.item())
+        return done
+
+    def timed(step, steps, warmup, per_step=False, converge=False):
+        """`warmup` untimed steps (+ `settle` with converge), then exactly `steps` steps between two fences.  per_step:
+        one event per step boundary on the launch stream gives the per-step device times (median / p10 / p90) -- in a
+        pass of its own: an event record leaves a ~6 us bubble on the stream (rocprof kernel trace)."""
+        for i in range(warmup):
+            step(i)
+        extra = settle(step) if converge else 0
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if per_step else None
         fence()
         stages.WAIT_STATS[:] = [0, 0.0]
         t0 = time.perf_counter()
         if per_step:
             marks[0].record()
-        for i in range(args.steps):
-            step(form)
+        for i in range(steps):
+            step(i)
             if per_step:
                 marks[i + 1].record()
-        if not per_step and form == factored:   # (the headline pass; before the closing fence)
-            info["host_wait_ms"] = stages.WAIT_STATS[1] / max(args.steps, 1) * 1e3
+        wait_ms = stages.WAIT_STATS[1] / max(steps, 1) * 1e3   # (before the closing fence)
         fence()
         dt = time.perf_counter() - t0
-        return dt, ([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)] if per_step else None)
+        if dist is not None:
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return {"s": dt, "warmup_effective": warmup + extra, "host_wait_ms": wait_ms,
+                "per_step_ms": [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)] if per_step else None}
 
-    # the timed region `value` comes from: the default exchange form of this run
-    elapsed, _ = timed(factored, args.warmup)
-    _, per_step_ms = timed(factored, 0, per_step=True)   # the same steps again, one event per step: the distribution
-    other_elapsed = None
+    p = width * height
+    n_streams = len(streams) if B > 1 else 1
+    if args.profile_run:
+        prof_step = make_step(args.exchange, 1, 1, world)
+        res = timed(prof_step, args.steps, args.warmup)
+        if rank == 0:
+            print(json.dumps({"profile_run": True, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_view": round(res["s"] / args.steps * 1e3, 4), "intersections_M": info["M"],
+                              "binned_records": info.get("binned")}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    # ---- the timed region `value` comes from: B views per rank and step, the default exchange form
+    head_step = make_step(args.exchange, B, n_streams, world * B)
+    head = timed(head_step, args.steps, args.warmup, converge=True)
+    dist_ms = timed(head_step, args.steps, 0, per_step=True)["per_step_ms"]   # the same steps, one event per step
+    other = None
     if dist is not None:   # the same steps with the other exchange form, for the comparison figure only
-        other_elapsed, _ = timed(not factored, args.warmup)
-        for _ in range(2):
-            step()
-    # a second, instrumented pass of the same steps gives the per-stage device times for the roofline object
-    # (HIP events around every C-ABI stage on the launch stream; the event records themselves cost a few percent,
-    # which is why this pass is not the one `value` is computed from)
+        other_form = "allreduce" if args.exchange == "factored" else "factored"
+        other = timed(make_step(other_form, B, n_streams, world * B), args.steps, 2, converge=True)
+    # ---- ONE view per step, one stream, a fixed camera: the serial latency of a view (rounds 1 and 2's headline), then
+    # the same steps with HIP events around every C-ABI stage for the roofline object (the event records cost a few
+    # percent, which is why the instrumented pass is not the timed one)
+    solo_step = make_step(args.exchange, 1, 1, world)
+    solo = timed(solo_step, args.steps, 2, converge=True)
     stages.TIMER.reset(enabled=True)
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        solo_step(i)
     fence()
     stage_ms = {k: (c, t) for k, (c, t) in stages.TIMER.summary().items()}
     stages.TIMER.reset(enabled=False)
-
-    if dist is not None:
-        tmax = torch.tensor([elapsed, other_elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed, other_elapsed = (float(x) for x in tmax.tolist())
-
-    grad_l1 = float(flat_grad.double().abs().sum())   # of the last step's exchanged gradient (same on every rank)
+    grad_l1 = float(flat_grad.double().abs().sum())   # of the last single-view step's exchanged gradient (same on every rank)
+    # ---- rotating views: one view per step cycling a ring of cameras -- how often the speculation behind the
+    # asynchronous binning (record capacity, depth-key range, bucket capacity) has to be repaired
+    rot = None
+    if world == 1 and args.views > 1:
+        rot_step = make_step(args.exchange, 1, 1, args.views)
+        for i in range(args.views):   # every camera once: the first call of a shape is exact by construction
+            rot_step(i)
+        for k in stages.REPAIR_STATS:
+            stages.REPAIR_STATS[k] = 0
+        rot = timed(rot_step, args.steps, 0)
+        rot["stats"] = dict(stages.REPAIR_STATS)
     copy_peak = measured_copy_peak(dev) if rank == 0 else 0.0   # after the timed regions
+
+    ex = head_step.exchange
+    if dist is not None:   # per rank, to stderr: what a sweep over NCCL_ALGO / NCCL_PROTO needs to be read without code changes
+        tail = stage_ms.get("exchange_tail", (0, 0.0))
+        print(f"[bench] rank {rank}/{dist.get_world_size()} backend={dist.get_backend()} rccl={rccl_version()} "
+              f"form={args.exchange} views_per_gpu={B} bytes_sent_per_step={ex.bytes_sent // max(1, ex.steps)} "
+              f"exchange_tail_ms(1 view/step)={tail[1] / max(tail[0], 1):.4f} "
+              f"NCCL_ALGO={os.environ.get('NCCL_ALGO', '(unset)')} NCCL_PROTO={os.environ.get('NCCL_PROTO', '(unset)')} "
+              f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '(unset)')}",
+              file=sys.stderr, flush=True)
     if rank == 0:
-        m, p = info["M"], width * height
-        ms_per_step = elapsed / args.steps * 1e3
-        value = world * p * args.steps / elapsed / 1e6
+        m = info["M"]
+        ms_per_step = head["s"] / args.steps * 1e3
+        value = world * B * p * args.steps / head["s"] / 1e6
+        ms_per_view = ms_per_step / B
         alg = algorithmic_bytes(n, m, p, deg)
-        # per C-ABI stage: average device time per step (binning = sorts + scan + emit + offsets)
-        per = {}
+        # per C-ABI stage: average device time per launch (binning = depth ordering + record generation + tile passes)
+        per, launches = {}, {}
         for name, (calls, total) in stage_ms.items():
-            other = {"gsa_sh_grad_expand": "sh_grad_rebuild", "gsa_composite_bwd_prepare": "bwd_prepare"}
-            key = name if name in alg or name == "exchange" else other.get(name, "binning")   # (exchange incl. rebuild)
+            renames = {"gsa_sh_grad_expand": "sh_grad_rebuild", "gsa_composite_bwd_prepare": "bwd_prepare",
+                       "exchange_tail": "exchange_tail"}
+            key = name if name in alg else renames.get(name, "binning")
             per[key] = per.get(key, 0.0) + total / args.steps
-        # the dominant KERNEL: "binning" is a stage of ~24 short launches (sorts, scan, emit, offsets), the other
-        # four stages are one kernel launch each
+            launches[key] = launches.get(key, 0) + calls / args.steps
+        # the dominant KERNEL: "binning" is a stage of several short launches, the other four stages are one launch each
         dominant = max((k for k in per if k in alg and k != "binning"), key=lambda k: per[k])
         ach = alg[dominant] / (per[dominant] * 1e-3) / 1e9
         total_bytes = sum(alg.values())
-        # measured per launch of the dominant kernel, from separate rocprofv3 --pmc passes of this command
-        # (profiles/*_traffic.json, tools/make_traffic_json.py): HBM bytes, VALU utilisation, float-atomic requests,
-        # and the bound the counters point at
-        traffic, counters = None, {}
-        for fname in ("r02_traffic.json", "r01_traffic.json"):
+        # measured per launch, from separate rocprofv3 --pmc passes of the single-view step (profiles/*_traffic.json,
+        # tools/make_traffic_json.py): HBM bytes of every kernel, VALU utilisation, float-atomic requests, and the
+        # bound the counters point at.  NOT measured in this run: `counters_from` names the file and the sources' revision.
+        traffic, counters, counters_from, measured_bytes = None, {}, None, None
+        for fname in ("r03_traffic.json", "r02_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fname)) as fh:
-                    if args.workload == "C3":
-                        counters = json.load(fh)["kernels"][dominant]
-                        traffic = counters["hbm_bytes_per_launch"]
-                        break
-            except (OSError, KeyError, ValueError):
+                    doc = json.load(fh)
+                if args.workload == "C3":
+                    counters = doc["kernels"][dominant]
+                    traffic = counters["hbm_bytes_per_launch"]
+                    measured_bytes = sum(k.get("hbm_bytes_per_launch", 0) * k.get("launches_per_step", 1)
+                                         for k in doc["kernels"].values())
+                    counters_from = f"profiles/{fname} @ {doc.get('csrc_rev', 'csrc of round ' + fname[1:3])}"
+                    break
+            except (OSError, KeyError, ValueError, TypeError):
                 continue
+        stage_gbs = {k: round(alg[k] / (per[k] * 1e-3) / 1e9, 1) for k in sorted(per) if k in alg}
+        solo_ms = solo["s"] / args.steps * 1e3
         line = {
             "metric": "Mpix/s fwd+bwd @1M gaussians/1080p", "value": round(value, 3), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {n} gaussians, {width}x{height}, SH degree {deg}, "
-                                   f"1 view per GPU per step, forward+backward"
-                                   + ((", RCCL all-reduce of 11N geometry grads + all-gather of 3N rgb grads per rank,"
-                                       " SH gradient rebuilt locally" if factored else
+                                   f"{B} view{'s' if B > 1 else ''} per GPU per step ({world * B} ring cameras per step), "
+                                   f"forward+backward into one 59N-float gradient bucket"
+                                   + ((", RCCL all-gather of 3N rgb grads per view + one all-reduce of 11N geometry grads per "
+                                       "step, SH gradient rebuilt locally" if args.exchange == "factored" else
                                        ", RCCL all-reduce of 59N-float grads") if world > 1 else ""),
+                       "views_per_gpu_per_step": B, "view_streams": n_streams, "ms_per_view": round(ms_per_view, 4),
                        "intersections_M": m, "bin_tile": stages.DEFAULT_BIN_TILE, "binned_records": info.get("binned"),
-                       "grad_l1": round(grad_l1, 3), "cull_mode": stages.DEFAULT_CULL_MODE if args.cull_mode is None else args.cull_mode},
+                       "grad_l1_single_view": round(grad_l1, 3),
+                       "cull_mode": stages.DEFAULT_CULL_MODE if args.cull_mode is None else args.cull_mode},
+            "warmup_effective": head["warmup_effective"],   # steps actually run before the timed window (see settle())
+            "step_ms": percentiles(dist_ms),
+            # how long per step the host sat waiting for the device's control words (it runs that far ahead)
+            "host_wait_ms_per_step": round(head["host_wait_ms"], 4),
+            # ONE view per step on one stream with a fixed camera -- the serial latency of a view, what rounds 1 and 2
+            # reported as `value`; every per-stage figure below is of THIS step
+            "single_view": {"ms": round(solo_ms, 4), "value": round(world * p / solo_ms / 1e3, 3),
+                            "warmup_effective": solo["warmup_effective"]},
             # `bound`: the roofline `achieved` / `peak` are priced against is HBM (no MFMA on this path);
             # `limiter`: what the PMC counters say the dominant kernel actually waits for
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "limiter": counters.get("limiter"), "valu_util": counters.get("valu_util"),
-                         "atomic_requests": counters.get("atomic_requests"),
+                         "atomic_requests": counters.get("atomic_requests"), "counters_from": counters_from,
                          "measured_copy_peak": round(copy_peak, 1),
                          "algorithmic_bytes_per_launch": alg[dominant], "avg_launch_ms": round(per[dominant], 4)},
-            "step_ms": percentiles(per_step_ms),
-            # how long per step the host sat waiting for the device's control words (it runs that far ahead)
-            "host_wait_ms_per_step": round(info.get("host_wait_ms", 0.0), 4),
-            "roofline_whole_step": {"algorithmic_bytes": total_bytes,
-                                    "achieved_GBs": round(total_bytes / (ms_per_step * 1e-3) / 1e9, 2),
-                                    "frac": round(total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            # SURVEY 8d's compulsory bytes of one view over the time of one view of the timed region
+            "roofline_whole_step": {"algorithmic_bytes_per_view": total_bytes,
+                                    "achieved_GBs": round(total_bytes / (ms_per_view * 1e-3) / 1e9, 2),
+                                    "frac": round(total_bytes / (ms_per_view * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                    "frac_single_view": round(total_bytes / (solo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
             "stage_ms": {k: round(v, 4) for k, v in sorted(per.items())},
-            "stage_algorithmic_GBs": {k: round(alg[k] / (per[k] * 1e-3) / 1e9, 1) for k in sorted(per) if k in alg},
+            "stage_launches": {k: round(v, 2) for k, v in sorted(launches.items())},
+            "stage_algorithmic_GBs": stage_gbs,
+            # a stage priced above the HBM peak is not moving SURVEY's bytes (it avoids them: digest instead of SH rows,
+            # bins instead of tiles, early-out) -- the contractual fraction then flatters; see roofline_measured
+            "over_peak": sorted(k for k, v in stage_gbs.items() if v > HBM_PEAK_GBS)
+                         + (["whole_step"] if total_bytes / (ms_per_view * 1e-3) / 1e9 > HBM_PEAK_GBS else []),
         }
+        if measured_bytes:
+            gbs = measured_bytes / (ms_per_view * 1e-3) / 1e9
+            line["roofline_measured"] = {"hbm_bytes_per_view": int(measured_bytes), "achieved_GBs": round(gbs, 1),
+                                         "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
+                                         "frac_of_copy_ceiling": round(gbs / max(copy_peak, 1.0), 4),
+                                         "counters_from": counters_from}
+        if rot is not None:
+            st = rot["stats"]
+            per100 = 100.0 / max(st["views"], 1)
+            line["rotating"] = {"views": args.views, "views_per_step": 1,
+                                "value_rotating": round(p * args.steps / rot["s"] / 1e6, 3),
+                                "ms_per_view": round(rot["s"] / args.steps * 1e3, 4),
+                                "capacity_misses_per_100": round(st["capacity_misses"] * per100, 2),
+                                "key_range_repairs_per_100": round(st["key_range_repairs"] * per100, 2)}
         if dist is not None:
-            other_value = world * p * args.steps / other_elapsed / 1e6
-            line["exchange"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
-                                "form": "factored" if factored else "allreduce",
-                                "exchange_ms": round(per.get("exchange", 0.0), 4),
-                                "value_factored": round(value if factored else other_value, 3),
-                                "value_allreduce": round(other_value if factored else value, 3)}
+            other_value = world * B * p * args.steps / other["s"] / 1e6
+            fact = args.exchange == "factored"
+            tail = stage_ms.get("exchange_tail", (0, 0.0))
+            line["exchange"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl": rccl_version(),
+                                "form": args.exchange,
+                                "exchange_tail_ms_single_view": round(tail[1] / max(tail[0], 1), 4),
+                                "value_factored": round(value if fact else other_value, 3),
+                                "value_allreduce": round(other_value if fact else value, 3),
+                                "NCCL_ALGO": os.environ.get("NCCL_ALGO"), "NCCL_PROTO": os.environ.get("NCCL_PROTO")}
         if world == 1 and not args.no_cpu_baseline and args.workload == "C3":
-            print(f"[bench] GPU leg done ({ms_per_step:.3f} ms/step); timing the CPU oracle on a bounded sample ...",
+            print(f"[bench] GPU leg done ({ms_per_view:.3f} ms/view); timing the CPU oracle on a bounded sample ...",
                   file=sys.stderr, flush=True)
             line["cpu_baseline"] = cpu_baseline(n, width, height, deg)
             line["cpu_baseline"]["cpu_model"] = cpu_model()

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSA_ABI_VERSION 6
+#define GSA_ABI_VERSION 7
 #define GSA_SPLAT_STRIDE 16
 
 #define GSA_OK 0
@@ -218,12 +218,28 @@ int gsa_tile_offsets(uint32_t m, const uint32_t *sorted_tile, int n_tiles, int32
  * tile_offsets[n_bins + 1] indexes the bins (row-major on ceil(width / 32) x ceil(height / 32)), the four tiles of a bin
  * walk its list, and quad_list holds 16 M uint32 (16 quadrant slices per bin, at 16 * offsets[bin] + (4 * sub-tile +
  * quadrant) * list length).
+ * sorted_mask (ABI 7; optional, NULL = every record is a candidate everywhere): per record of the sorted list the 8 x 8
+ * quadrants of its tile / bin that the record can reach (gsa_quadrant_masks).  A quadrant's wave then gathers and
+ * stages only the records whose mask has its bit; results do not depend on it (a record outside a quadrant's mask
+ * fails the alpha test at every pixel of the quadrant).  bin_tile 16 or 32 only.
  */
 int gsa_composite_fwd(int width, int height, int channels, const float *splat,
-                      const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
+                      const uint32_t *sorted_gid, const uint16_t *sorted_mask, const int32_t *tile_offsets,
+                      const float *background,
                       const int32_t *tile_order, float *render, float *alpha, float *final_T, int32_t *last_id,
                       uint32_t *quad_list, int32_t *quad_count, float *v_splat_zero, long long n_zero_rows,
                       int bin_tile, gsa_stream_t stream);
+
+/* ABI 7 -- quadrant masks for stage 3 (replaces the per-quadrant reach test gsplat's rasterize_to_pixels does not have
+ * either: it walks every record of a tile at every pixel; reference call site gsplat_backend.py:168-182).
+ * sorted_mask[i], i < min(m_capacity, *m_dev) (m_dev may be NULL: m_capacity is the count): bit s is set when the
+ * alpha >= 1/255 region of record i's gaussian can reach a pixel centre of quadrant slice s of the record's tile / bin
+ * (bin_tile 16: s = 2 qy + qx; bin_tile 32: s = 4 * sub-tile + 2 qy + qx, sub-tile = 2 (tile_y & 1) + (tile_x & 1) -- the
+ * slice numbering of quad_list).  A superset of the per-pixel rule (conservative margins).  sorted_bin: the 16-bit
+ * tile / bin ids of the sorted records (gsa_tile_bin16's sorted_tile); n: number of gaussians (ids are clamped to it). */
+int gsa_quadrant_masks(uint32_t m_capacity, const uint32_t *m_dev, const uint16_t *sorted_bin,
+                       const uint32_t *sorted_gid, const float *splat, int n, int width, int height, int bin_tile,
+                       uint16_t *sorted_mask, gsa_stream_t stream);
 
 /* Launch order for stages 3 and 4 (optional; speed only, never results): tile_order[8 * ceil(n_tiles / 8)] receives,
  * for each of the 8 tile bands, the band's tiles with the longest record lists first (-1 pads the last band). Pass it

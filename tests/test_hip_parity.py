@@ -677,7 +677,7 @@ def test_random_shapes_fused_paths_agree_with_plain_ones(gsa):
                                                          d["opacities"][:, 0].contiguous(), d["shs"], 3, vm, K, W, H, 0,
                                                          return_rects=True)
         a = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, fused=False)
-        b = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, fused=True, tile_rects=rects)
+        b = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, fused=True, tile_rects=rects, quad_masks=True)
         tag = (trial, W, H, N, s_max)
         assert a.finalize()[0] == b.finalize()[0] == int(tiles.sum()), tag
         assert torch.equal(b.sorted_gid, a.sorted_gid) and torch.equal(b.tile_offsets, a.tile_offsets), tag
@@ -687,6 +687,10 @@ def test_random_shapes_fused_paths_agree_with_plain_ones(gsa):
         r0, a0, T0, l0 = S.composite_fwd(splat, gid, offs, bg, W, H, 3)
         r1, a1, T1, l1, lists = S.composite_fwd(splat, gid, offs, bg, W, H, 3, S.tile_schedule(offs, W, H), want_lists=True)
         assert torch.equal(r0, r1) and torch.equal(T0, T1) and torch.equal(a0, a1), tag
+        # with the per-record quadrant masks of the fused binning a wave gathers only what can reach its quadrant: same image
+        assert b.sorted_mask is not None and a.sorted_mask is None, tag
+        rm, am, Tm, lm = S.composite_fwd(splat, gid, offs, bg, W, H, 3, sorted_mask=b.sorted_mask)
+        assert torch.equal(rm, r0) and torch.equal(Tm, T0) and torch.equal(am, a0), tag
         v_r = torch.from_numpy(rng.uniform(-1, 1, (H, W, 3)).astype(np.float32)).cuda()
         g0 = S.composite_bwd(splat, gid, offs, bg, T0, l0, v_r, None, W, H, 3)
         g1 = S.composite_bwd(splat, gid, offs, bg, T1, l1, v_r, None, W, H, 3, quad_lists=lists)
@@ -697,19 +701,74 @@ def test_random_shapes_fused_paths_agree_with_plain_ones(gsa):
         for bt in (32, 64):
             rects_b = S.project_fwd(d["means3D"], d["rotations"], d["scales"], d["opacities"][:, 0].contiguous(), d["shs"],
                                     3, vm, K, W, H, 0, return_rects=True, bin_tile=bt)[4]
-            bb = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, tile_rects=rects_b, bin_tile=bt)
+            bb = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, tile_rects=rects_b, bin_tile=bt, quad_masks=True)
             assert bb.bin_tile == bt and bb.finalize()[0] <= int(tiles.sum()), tag
             gb, ob = bb.sorted_gid_buffer, bb.tile_offsets
             rb, ab, Tb, lb, lists_b = S.composite_fwd(splat, gb, ob, bg, W, H, 3, S.tile_schedule(ob, W, H, bt),
                                                       want_lists=True, bin_tile=bt)
             assert torch.equal(rb, r0) and torch.equal(Tb, T0) and torch.equal(ab, a0), (tag, bt)
             sweeps = [S.composite_bwd(splat, gb, ob, bg, Tb, lb, v_r, None, W, H, 3, bin_tile=bt)]
+            if bt == 32:   # masked walk: the image bit for bit, and the lists it leaves drive the same sweep
+                rm, am, Tm, lm, lists_m = S.composite_fwd(splat, gb, ob, bg, W, H, 3, S.tile_schedule(ob, W, H, bt),
+                                                          want_lists=True, bin_tile=bt, sorted_mask=bb.sorted_mask)
+                assert torch.equal(rm, r0) and torch.equal(Tm, T0) and torch.equal(am, a0), (tag, bt)
+                sweeps.append(S.composite_bwd(splat, gb, ob, bg, Tm, lm, v_r, None, W, H, 3, quad_lists=lists_m, bin_tile=bt))
+            else:
+                assert bb.sorted_mask is None
             for mode in _bwd_modes():
                 with _bwd_mode(mode):
                     sweeps.append(S.composite_bwd(splat, gb, ob, bg, Tb, lb, v_r, None, W, H, 3, quad_lists=lists_b,
                                                   bin_tile=bt))
             for gsw in sweeps:
                 assert float(((g0 - gsw).abs().amax(0) / scale).max()) < 5e-5, (tag, bt)
+
+
+@pytest.mark.parametrize("bt", [16, 32])
+@pytest.mark.parametrize("N,s_min,s_max", [(6000, 0.004, 0.05), (1500, 0.01, 0.6), (4000, 0.0005, 0.3)])
+def test_quadrant_masks_cover_the_per_pixel_rule(gsa, bt, N, s_min, s_max):
+    """gsa_quadrant_masks: bit s of a record's mask must be set whenever ONE pixel centre of quadrant slice s of the record's
+    bin passes the per-pixel alpha test (sigma <= ln(255 o)) -- checked against a brute-force evaluation of sigma at every
+    pixel of every record's bin (fp64).  Also reports how tight the masks are (bits set / bits needed)."""
+    from gsplat_amd import scene, stages as S
+    W, H = 333, 190          # partial border bins
+    sc = _scene(N, seed=5, s_min=s_min, s_max=s_max)
+    if s_max > 0.5:          # needle-like splats: the closed form's fallback
+        sc["scales"][:, 0] *= 0.02
+    vm, K = scene.make_camera(1, 5).cuda(), scene.make_intrinsics(W, H).cuda()
+    d = {k: v.cuda().contiguous() for k, v in sc.items()}
+    splat, radii, tiles, keys, rects = S.project_fwd(d["means3D"], d["rotations"], d["scales"], d["opacities"][:, 0].contiguous(),
+                                                     d["shs"], 3, vm, K, W, H, 0, return_rects=True, bin_tile=bt)
+    bins = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, tile_rects=rects, bin_tile=bt, quad_masks=True)
+    m = bins.finalize()[0]
+    assert bins.sorted_mask is not None and m > 1000
+    gid = bins.sorted_gid.long()
+    bin_id = S.tile_ids(bins.sorted_tile)
+    mask = bins.sorted_mask[:m].long() & 0xFFFF
+    bw = (W + bt - 1) // bt
+    sp = splat.double()[gid]                                           # [m,16]
+    q = bt // 8                                                        # quadrants per bin side
+    ys, xs = torch.meshgrid(torch.arange(bt, device="cuda"), torch.arange(bt, device="cuda"), indexing="ij")
+    need = torch.zeros(m, dtype=torch.long, device="cuda")
+    for lo in range(0, m, 4096):
+        hi = min(m, lo + 4096)
+        r = sp[lo:hi]
+        X0 = (bin_id[lo:hi] % bw * bt).double()[:, None, None]
+        Y0 = (bin_id[lo:hi] // bw * bt).double()[:, None, None]
+        dx = r[:, 0, None, None] - (X0 + xs[None] + 0.5)
+        dy = r[:, 1, None, None] - (Y0 + ys[None] + 0.5)
+        sig = 0.5 * (r[:, 2, None, None] * dx * dx + r[:, 4, None, None] * dy * dy) + r[:, 3, None, None] * dx * dy
+        ok = (sig >= 0) & (sig <= r[:, 10, None, None])                 # alpha = o exp(-sigma) >= 1/255
+        okq = ok.view(-1, q, 8, q, 8).any(4).any(2)                     # [m', qy, qx]
+        for j in range(q):
+            for i in range(q):
+                bit = (j << 1) | i if q == 2 else (((((j >> 1) << 1) | (i >> 1)) << 2) | ((j & 1) << 1) | (i & 1))
+                need[lo:hi] |= okq[:, j, i].long() << bit
+    missing = need & ~mask
+    assert int((missing != 0).sum()) == 0, f"{int((missing != 0).sum())} records miss a quadrant they reach"
+    def pop(x):
+        return sum(int(((x >> b) & 1).sum()) for b in range(16))
+    print(f"mask tightness (bin {bt}): {pop(mask)} bits set for {pop(need)} needed, of {m * q * q} possible")
+    assert pop(mask) <= 1.6 * pop(need) + 0.02 * m * q * q or s_max > 0.5
 
 
 @pytest.mark.parametrize("W,H,N,cull_mode,channels", [(640, 360, 20_000, 0, 3), (250, 130, 3000, 1, 4),

@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() { # name, counters...
   n=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$n -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/$n.log 2>&1
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$n -- python3 $R/bench.py --steps 3 --warmup 2 --profile-run > $OUT/$n.log 2>&1
   rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/${n}_cal -- python3 $R/tools/pmc_calibrate.py > $OUT/${n}_cal.log 2>&1 || true
 }
 run fetch FETCH_SIZE

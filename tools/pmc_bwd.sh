@@ -7,7 +7,7 @@ for kv in "$@"; do export "$kv"; done
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() { n=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$n -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/$n.log 2>&1
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$n -- python3 $R/bench.py --steps 3 --warmup 2 --profile-run > $OUT/$n.log 2>&1
   python3 $R/tools/pmc_summary.py $(find $OUT/$n -name '*counter_collection.csv' | head -1) "composite" > $OUT/$n.txt
 }
 run insts SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY
