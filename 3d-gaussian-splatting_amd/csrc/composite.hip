@@ -1161,15 +1161,32 @@ __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_scan_kerne
 //   instructions of four whole 64-B gradient records each.
 // Same arithmetic per (pixel, record) as composite_bwd_list_kernel (the sums are taken in a different order).
 constexpr int kSub = 8;                 // records per sub-batch
-constexpr int kMatPitch = kSub + 1;     // float2 entries per pixel row of the LDS matrix
+#ifndef GSA_BWD_SWIZZLE
+#define GSA_BWD_SWIZZLE 0               // 1: XOR-swizzled [pixel][record] matrix and a 20-word tile pitch: no LDS bank conflicts, same time (see below)
+#endif
+// LDS layout of the [pixel][record] (u, fac) matrix.  Phase A stores one record of 16 consecutive pixels per quarter-wave
+// (ds_write_b64: banks mod 32), phase B loads 4 pixel columns x 8 records per half-wave (ds_read_b64: banks mod 64).
+// A row pitch of 9 entries makes the stores conflict-free but leaves the loads 2-way conflicted (the fourth column's 16
+// words wrap onto the first's); with 8 entries per row and the record slot XOR-ed with bits 1..3 of the pixel index both
+// are conflict-free -- for one v_xor per store (the address is no longer base + immediate).  Measured at C3
+// (profiles/r03_bwd_ablation.md): SQ_LDS_BANK_CONFLICT 17.2 M -> 0.02 M cycles, SQ_WAIT_INST_LDS 32.9 M -> 16.0 M, but
+// SQ_INSTS_VALU 119.6 M -> 125.0 M and the kernel's time unchanged (0.1993 / 0.2002 ms): the LDS pipe is not what the
+// sweep waits for.  Off by default (fewer instructions).
+constexpr int kMatPitch = GSA_BWD_SWIZZLE ? kSub : kSub + 1;     // float2 entries per pixel row of the LDS matrix
+constexpr int kTilePitch = GSA_BWD_SWIZZLE ? 20 : 16;            // words per record of the epilogue's [record][field] totals
+__device__ __forceinline__ int mat_slot(int pixel, int r) {
+    return GSA_BWD_SWIZZLE ? pixel * kMatPitch + (r ^ ((pixel >> 1) & 7)) : pixel * kMatPitch + r;
+}
 template <int CH>
 struct TwoPhase {
     float2 mat[kWave * kMatPitch];      // [pixel][record] (u, fac)
-    float tile[kSub * 16];              // epilogue: [record][field] totals
+    float tile[kSub * kTilePitch];      // epilogue: [record][field] totals
 };
 
+// (register budget: five waves per SIMD for the three-channel instance -- 96 registers, which it needs one more than
+// without the bound; the four-channel instance would spill there and keeps its 105)
 template <int CH>
-__global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_2p_kernel(
+__global__ __launch_bounds__(kWave, (CH == 3 ? 5 : GSA_BWD_WAVES)) void composite_bwd_2p_kernel(
     int width, int height, int tile_w, int n_tiles, int bin_shift, const float *__restrict__ splat,
     const uint32_t *__restrict__ sorted_gid, const int32_t *__restrict__ tile_offsets,
     const float *__restrict__ background, const int32_t *__restrict__ tile_order, const float *__restrict__ final_T,
@@ -1233,6 +1250,9 @@ __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_2p_kernel(
         for (int k = 0; k < CH; ++k) vcol[y][k] = in ? v_render[pp * CH + k] : 0.f;
     }
     const int f0 = 4 * ((lane >> 5) & 1) + 2 * ((lane >> 4) & 1) + ((lane >> 3) & 1);   // field this lane ends up with
+    const uint32_t mat_a0 = (uint32_t)(lane * 64) | (uint32_t)(((lane >> 1) & 7) << 3);   // phase A's swizzled store base (bytes)
+    uint32_t mat_b0 = (uint32_t)(col * 64) + (uint32_t)((rec ^ (col >> 1)) << 3), mat_b1 = mat_b0 ^ 32u;   // phase B's load bases
+    asm volatile("" : "+v"(mat_b0), "+v"(mat_b1));
 
     for (int done = 0, j = 0; done < count; done += kBatch, ++j) {
         bool any_cap;
@@ -1268,7 +1288,13 @@ __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_2p_kernel(
                         T = Tn;
                         u = CLAMP ? ((a == raw) ? -raw * v_a : 0.f) : -a * v_a;
                     }
-                    tp.mat[lane * kMatPitch + r] = make_float2(u, fac);
+                    if (GSA_BWD_SWIZZLE) {   // byte offset (lane * 64 | g << 3) ^ (r << 3): ONE v_xor per store, no table of
+                        uint32_t a0 = mat_a0;   // eight addresses in registers (the asm keeps the compiler from hoisting one)
+                        asm volatile("" : "+v"(a0));
+                        *reinterpret_cast<float2 *>(reinterpret_cast<char *>(tp.mat) + (a0 ^ (uint32_t)(r * 8))) = make_float2(u, fac);
+                    } else {
+                        tp.mat[mat_slot(lane, r)] = make_float2(u, fac);
+                    }
                 }
             };
             // the lists are walked from the deep end: once every pixel of the quadrant has reached its last position (the
@@ -1295,7 +1321,10 @@ __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_2p_kernel(
                 float su = 0.f, suy = 0.f, suyy = 0.f;
 #pragma unroll
                 for (int y = 0; y < 8; ++y) {
-                    const float2 uf = tp.mat[(8 * y + col) * kMatPitch + rec];
+                    // (swizzled: byte offset y * 512 + mat_b0 ^ 32 (y & 1) -- two base registers and an immediate)
+                    const float2 uf = GSA_BWD_SWIZZLE
+                        ? *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(tp.mat) + ((y & 1) ? mat_b1 : mat_b0) + y * 512)
+                        : tp.mat[mat_slot(8 * y + col, rec)];
                     const float yc = (float)y - 3.5f;
                     const float u = uf.x, fac = uf.y;
                     su += u;
@@ -1320,8 +1349,8 @@ __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_2p_kernel(
                         k3 = fold8(acc[6], acc[7]), k4 = fold8(acc[8], acc[9]);
             const float m0 = fold16(k0, k1), m1 = fold16(k2, k3), m2 = fold16(k4, k4);
             const float t0 = fold32(m0, m1), t1 = fold32(m2, m2);
-            tp.tile[16 * rec + f0] = t0;
-            tp.tile[16 * rec + 8 + f0] = t1;       // fields >= NF are never read back
+            tp.tile[kTilePitch * rec + f0] = t0;
+            tp.tile[kTilePitch * rec + 8 + f0] = t1;       // fields >= NF are never read back
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1330,7 +1359,7 @@ __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_2p_kernel(
             for (int t = 0; t < 2; ++t) {
                 const int r = 4 * t + (lane >> 4), f = lane & 15;
                 if (4 * t < nv) {
-                    const float total = tp.tile[64 * t + lane];
+                    const float total = tp.tile[kTilePitch * r + f];
                     if (f < NF && r < nv) {
                         const uint32_t g = __float_as_uint(st.rec[F4 * (s0 + r) + 2].w);
                         atomicAdd(v_splat + (size_t)g * GSA_SPLAT_STRIDE + f, total);

@@ -42,6 +42,7 @@ WORKLOADS = {
     "C3": (1_000_000, 1920, 1080, 3),
     "C2": (100_000, 1920, 1080, 3),
     "C5": (5_000_000, 3840, 2160, 3),
+    "T": (20_000, 320, 192, 3),   # (tests/test_scale.py rehearses the multi-rank / multi-view step on this one)
 }
 
 
@@ -266,6 +267,8 @@ def main() -> None:
     ap.add_argument("--views", type=int, default=8,
                     help="ring size of the ROTATING-view pass (the reference samples random views every step, "
                          "trainer.py:315-317): one view per step, cycling through this many cameras")
+    ap.add_argument("--dump-grad", default=None,
+                    help="(tests) rank 0 saves the gradient bucket of the last step of the timed region to this .pt file")
     ap.add_argument("--profile-run", action="store_true",
                     help="for rocprofv3: only `warmup` + `steps` single-view steps (one view per step, one stream, fixed "
                          "camera), no settling, no extra passes; prints a minimal line")
@@ -409,15 +412,14 @@ def main() -> None:
             b.record()
             b.synchronize()
             done += chunk
-            times.append(a.elapsed_time(b))
+            ms = a.elapsed_time(b)
+            if dist is not None:   # the steps contain collectives: every rank must take the same decision, on the same number
+                t = torch.tensor([ms], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                ms = float(t.item())
+            times.append(ms)
             if len(times) >= 3 and max(times[-3:]) <= (1.0 + tol) * min(times[-3:]):
                 break
-        if dist is not None:   # every rank must run the same number of steps (they contain collectives)
-            t = torch.tensor([done], device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            for k in range(int(t.item()) - done):
-                step(done + k)
-            done = int(t.item())
         return done
 
     def timed(step, steps, warmup, per_step=False, converge=False):
@@ -448,7 +450,7 @@ def main() -> None:
                 "per_step_ms": [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)] if per_step else None}
 
     p = width * height
-    n_streams = len(streams) if B > 1 else 1
+    n_streams = max(1, len(streams)) if B > 1 else 1
     if args.profile_run:
         prof_step = make_step(args.exchange, 1, 1, world)
         res = timed(prof_step, args.steps, args.warmup)
@@ -463,6 +465,9 @@ def main() -> None:
     # ---- the timed region `value` comes from: B views per rank and step, the default exchange form
     head_step = make_step(args.exchange, B, n_streams, world * B)
     head = timed(head_step, args.steps, args.warmup, converge=True)
+    grad_l1_head = float(flat_grad.double().abs().sum())   # of the last step's exchanged bucket (same on every rank)
+    if args.dump_grad and rank == 0:
+        torch.save(flat_grad.detach().cpu(), args.dump_grad)
     dist_ms = timed(head_step, args.steps, 0, per_step=True)["per_step_ms"]   # the same steps, one event per step
     other = None
     if dist is not None:   # the same steps with the other exchange form, for the comparison figure only
@@ -531,9 +536,9 @@ def main() -> None:
                 if args.workload == "C3":
                     counters = doc["kernels"][dominant]
                     traffic = counters["hbm_bytes_per_launch"]
-                    measured_bytes = sum(k.get("hbm_bytes_per_launch", 0) * k.get("launches_per_step", 1)
-                                         for k in doc["kernels"].values())
-                    counters_from = f"profiles/{fname} @ {doc.get('csrc_rev', 'csrc of round ' + fname[1:3])}"
+                    measured_bytes = sum(k.get("hbm_bytes_per_launch", 0) * k.get("launches_per_view", 1)
+                                         for grp in ("kernels", "binning_kernels") for k in doc.get(grp, {}).values())
+                    counters_from = f"profiles/{fname} @ csrc {doc.get('csrc_rev', 'of round ' + fname[1:3])}"
                     break
             except (OSError, KeyError, ValueError, TypeError):
                 continue
@@ -551,7 +556,7 @@ def main() -> None:
                                        ", RCCL all-reduce of 59N-float grads") if world > 1 else ""),
                        "views_per_gpu_per_step": B, "view_streams": n_streams, "ms_per_view": round(ms_per_view, 4),
                        "intersections_M": m, "bin_tile": stages.DEFAULT_BIN_TILE, "binned_records": info.get("binned"),
-                       "grad_l1_single_view": round(grad_l1, 3),
+                       "grad_l1": round(grad_l1_head, 3), "grad_l1_single_view": round(grad_l1, 3),
                        "cull_mode": stages.DEFAULT_CULL_MODE if args.cull_mode is None else args.cull_mode},
             "warmup_effective": head["warmup_effective"],   # steps actually run before the timed window (see settle())
             "step_ms": percentiles(dist_ms),
@@ -606,7 +611,7 @@ def main() -> None:
                                 "value_factored": round(value if fact else other_value, 3),
                                 "value_allreduce": round(other_value if fact else value, 3),
                                 "NCCL_ALGO": os.environ.get("NCCL_ALGO"), "NCCL_PROTO": os.environ.get("NCCL_PROTO")}
-        if world == 1 and not args.no_cpu_baseline and args.workload == "C3":
+        if world == 1 and not args.no_cpu_baseline and args.workload == "C3":   # (the oracle: bench.py's cpu_baseline leg only)
             print(f"[bench] GPU leg done ({ms_per_view:.3f} ms/view); timing the CPU oracle on a bounded sample ...",
                   file=sys.stderr, flush=True)
             line["cpu_baseline"] = cpu_baseline(n, width, height, deg)

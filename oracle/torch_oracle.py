@@ -243,7 +243,15 @@ def composite(
     The function is discontinuous at its three thresholds (alpha = 1/255, T(1-alpha) = 1e-4, and for the
     gradient o*exp(-sigma) = 0.999).  With ``ambiguity_tol`` a third value is returned: a bool [H,W] mask of
     the pixels where some comparison the pixel actually reaches sits within that RELATIVE distance of its
-    threshold -- there two correct fp32 implementations may legitimately decide differently."""
+    threshold -- there two correct fp32 implementations may legitimately decide differently -- and a fourth: a float
+    [H,W] BOUND on how far such an implementation's pixel may lie from this one's because of those decisions alone
+    (per colour channel; 0 where nothing is ambiguous).  One flipped SKIP decision at record e moves the pixel by
+    alpha_e T_e (c_e - colour behind e), at most alpha_e T_e (|c_e| + Cmax) with Cmax the largest colour in the tile's
+    list; a flipped STOP decision at e adds or removes alpha_e T_e c_e and whatever the transmittance T_e (1 - alpha_e)
+    that is left lets through, at most alpha_e T_e |c_e| + T_e (1 - alpha_e) Cmax.  The bound sums the first over the
+    pixel's near-threshold skip decisions and adds the largest of the second over the stop decisions inside a 2 %
+    window of 1e-4 (a flipped skip upstream scales T by 1 - 1/255, which can carry a stop across its threshold from
+    further away than ``ambiguity_tol``)."""
     dt = means2d.dtype
     N, D = feats.shape
     tw = (width + tile_size - 1) // tile_size
@@ -279,25 +287,36 @@ def composite(
             next_T = torch.cumprod(1.0 - a_v, dim=-1)
             contrib = valid & (next_T > K_.TRANSMITTANCE_EPS)
             amb = torch.zeros(ids.shape[0], px.shape[1], dtype=torch.bool)
+            bound = torch.zeros(ids.shape[0], px.shape[1], dtype=dt)
             if ambiguity_tol is not None:
                 tol = ambiguity_tol
                 raw = g_o[:, None, :] * torch.exp(-sigma)
-                live = torch.cat([torch.ones_like(contrib[..., :1]), next_T[..., :-1] > K_.TRANSMITTANCE_EPS], -1)
+                prev_T = torch.cat([torch.ones_like(next_T[..., :1]), next_T[..., :-1]], -1)
+                live = prev_T > K_.TRANSMITTANCE_EPS
+                live[..., 0] = True
                 near_a = (alpha * 255.0 - 1.0).abs() < tol
                 near_t = valid & ((next_T / K_.TRANSMITTANCE_EPS - 1.0).abs() < tol)
                 near_c = valid & ((raw / K_.MAX_ALPHA - 1.0).abs() < tol)
-                amb = ((near_a | near_t | near_c) & live & (sigma >= 0)).any(dim=-1)
+                reach = live & (sigma >= 0)
+                amb = ((near_a | near_t | near_c) & reach).any(dim=-1)
+                cnorm = g_f.abs().amax(-1)[:, None, :]                   # [nb, 1, L]
+                cmax = cnorm.amax(-1, keepdim=True)
+                wgt = alpha * prev_T
+                skip_term = torch.where(near_a & reach, wgt * (cnorm + cmax), torch.zeros_like(wgt)).sum(-1)
+                wide_t = valid & reach & ((next_T / K_.TRANSMITTANCE_EPS - 1.0).abs() < 0.02)
+                stop_term = torch.where(wide_t, wgt * cnorm + next_T * cmax, torch.zeros_like(wgt)).amax(-1)
+                bound = torch.where(amb, skip_term + stop_term, torch.zeros_like(skip_term))
         a_eff = torch.where(contrib, alpha, torch.zeros_like(alpha))
         T_incl = torch.cumprod(1.0 - a_eff, dim=-1)
         T_excl = torch.cat([torch.ones_like(T_incl[..., :1]), T_incl[..., :-1]], dim=-1)
         w = a_eff * T_excl
-        return torch.einsum("tpl,tld->tpd", w, g_f), T_incl[..., -1], amb
+        return torch.einsum("tpl,tld->tpd", w, g_f), T_incl[..., -1], amb, bound
 
     order = torch.argsort(counts, stable=True)
     order = order[counts[order] > 0]
     lens = counts[order].tolist()
     ar_max = torch.arange(max(lens) if lens else 0)
-    tile_idx_out, color_out, trans_out, amb_out = [], [], [], []
+    tile_idx_out, color_out, trans_out, amb_out, bound_out = [], [], [], [], []
     i, n_t = 0, len(lens)
     while i < n_t:
         # grow a batch of tiles of similar list length (ascending) under the element budget
@@ -314,24 +333,27 @@ def composite(
         px = ((tiles % tw) * tile_size).to(dt)[:, None] + px_in[None, :]   # [nb, npx]
         py = ((tiles // tw) * tile_size).to(dt)[:, None] + py_in[None, :]
         if checkpoint and torch.is_grad_enabled():
-            color, t_fin, amb = torch.utils.checkpoint.checkpoint(blend, ids, px, py, m2, cn, op, ft,
-                                                                  use_reentrant=False)
+            color, t_fin, amb, bnd = torch.utils.checkpoint.checkpoint(blend, ids, px, py, m2, cn, op, ft,
+                                                                       use_reentrant=False)
         else:
-            color, t_fin, amb = blend(ids, px, py, m2, cn, op, ft)
+            color, t_fin, amb, bnd = blend(ids, px, py, m2, cn, op, ft)
         tile_idx_out.append(tiles)
         color_out.append(color)
         trans_out.append(t_fin)
         amb_out.append(amb)
+        bound_out.append(bnd.detach())
 
     canvas_c = means2d.new_zeros(T_, npx, D)
     canvas_t = means2d.new_ones(T_, npx)
     canvas_a = torch.zeros(T_, npx, dtype=torch.bool)
+    canvas_b = means2d.new_zeros(T_, npx).detach()
     if tile_idx_out:
         tiles_all = torch.cat(tile_idx_out)
         canvas_c = canvas_c.index_copy(0, tiles_all, torch.cat(color_out))
         canvas_t = canvas_t.index_copy(0, tiles_all, torch.cat(trans_out))
         if ambiguity_tol is not None:
             canvas_a = canvas_a.index_copy(0, tiles_all, torch.cat(amb_out))
+            canvas_b = canvas_b.index_copy(0, tiles_all, torch.cat(bound_out))
     if background is not None:
         canvas_c = canvas_c + canvas_t[..., None] * background.to(dt)
 
@@ -341,7 +363,8 @@ def composite(
         return v.reshape(th * tile_size, tw * tile_size, k)[:height, :width]
 
     if ambiguity_tol is not None:
-        return untile(canvas_c), untile((1.0 - canvas_t)[..., None]), untile(canvas_a[..., None])[..., 0]
+        return (untile(canvas_c), untile((1.0 - canvas_t)[..., None]), untile(canvas_a[..., None])[..., 0],
+                untile(canvas_b[..., None])[..., 0])
     return untile(canvas_c), untile((1.0 - canvas_t)[..., None])
 
 
@@ -371,7 +394,8 @@ def rasterization(
     checkpoint: bool = False,
     **unsupported,
 ) -> Tuple[torch.Tensor, torch.Tensor, Dict]:
-    """``ambiguity_tol`` (oracle-only extension): adds ``meta['ambiguous']`` [C,H,W] bool, see ``composite``.
+    """``ambiguity_tol`` (oracle-only extension): adds ``meta['ambiguous']`` [C,H,W] bool and ``meta['flip_bound']``
+    [C,H,W] (how far a pixel may move through its ambiguous threshold decisions), see ``composite``.
 
     Same keyword surface and return contract as the call at
     /root/reference/src/backends/gsplat_backend.py:168-182:
@@ -399,7 +423,7 @@ def rasterization(
 
     out_r, out_a = [], []
     m_means2d, m_radii, m_depths, m_conics, m_tiles = [], [], [], [], []
-    keys_all, flat_all, m_amb = [], [], []
+    keys_all, flat_all, m_amb, m_bound = [], [], [], []
     for c in range(C):
         pr = project(means, quats, scales, opacities, viewmats[c], Ks[c], width, height,
                      near_plane, far_plane, radius_clip, eps2d)
@@ -439,6 +463,7 @@ def rasterization(
         img, alpha = comp[0], comp[1]
         if ambiguity_tol is not None:
             m_amb.append(comp[2])
+            m_bound.append(comp[3])
         if render_mode in ("ED", "RGB+ED"):
             img = torch.cat([img[..., :-1], img[..., -1:] / alpha.clamp(min=K_.DEPTH_ALPHA_EPS)], dim=-1)
         out_r.append(img)
@@ -467,6 +492,7 @@ def rasterization(
     }
     if ambiguity_tol is not None:
         meta["ambiguous"] = torch.stack(m_amb)
+        meta["flip_bound"] = torch.stack(m_bound)   # [C,H,W]: see composite()
     return torch.stack(out_r), torch.stack(out_a), meta
 
 

@@ -14,6 +14,8 @@ import sys
 
 import numpy as np
 import pytest
+import math
+
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -251,6 +253,107 @@ def test_c5_densify_and_prune_event_at_5m():
     model.check_bound()
     opt.step()                                            # the spliced optimizer still steps at the new size
     assert [name for name, _ in HF] == list(FIELDS)
+
+
+def _bench_bucket(tmp_path, tag, gpus, views_per_gpu, streams, exchange="factored"):
+    """Runs bench.py (the N > 1 ranks over gloo, sharing this box's GPU) on the tiny workload; -> the exchanged gradient
+    bucket of its last timed step and the printed line."""
+    import json
+    import subprocess
+    out = os.path.join(str(tmp_path), f"{tag}.pt")
+    env = dict(os.environ, GSPLAT_AMD_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", str(gpus), "--workload", "T", "--steps", "3",
+           "--warmup", "1", "--views-per-gpu", str(views_per_gpu), "--view-streams", str(streams), "--exchange", exchange,
+           "--no-cpu-baseline", "--views", "1", "--dump-grad", out]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    return torch.load(out), line
+
+
+def test_bench_multi_view_step_overlapped_equals_serial_and_one_process(tmp_path):
+    """bench.py's step with several views per GPU: (a) two ranks x two views with the views alternating on two HIP streams
+    (view j's all-gather under view j + 1's render) leave the bucket of the one-stream run up to the order of the float
+    atomics inside each view's sweep (two RUNS are compared: within a run the SH part -- rebuilt from the gathered rgb
+    gradients in a fixed view order -- is bit-identical on every rank, test_fused_view_parallel_two_ranks_match_reference_trainer);
+    (b) the same four ring cameras in ONE process (4 views per step) give the same sums; (c) the plain all-reduce form
+    agrees with the factored one."""
+    n = 20_000
+    serial, line_s = _bench_bucket(tmp_path, "serial", 2, 2, 1)
+    overlap, line_o = _bench_bucket(tmp_path, "overlap", 2, 2, 2)
+    assert line_o["config"]["view_streams"] == 2 and line_s["config"]["view_streams"] == 1
+    assert line_o["n_gpus"] == 2 and line_o["config"]["views_per_gpu_per_step"] == 2 and line_o["exchange"]["world_size"] == 2
+    scale = float(serial.abs().max())
+    assert scale > 0 and float((overlap[:11 * n] - serial[:11 * n]).abs().max()) <= 1e-5 * scale
+    sh_s, sh_o = serial[11 * n:], overlap[11 * n:]
+    assert float((sh_s - sh_o).abs().max()) <= 1e-5 * float(sh_s.abs().max())
+    one, line_1 = _bench_bucket(tmp_path, "one", 1, 4, 2)
+    assert line_1["n_gpus"] == 1 and float((one - serial).abs().max()) <= 2e-5 * scale
+    plain, _ = _bench_bucket(tmp_path, "plain", 2, 2, 2, exchange="allreduce")
+    assert float((plain - serial).abs().max()) <= 2e-5 * scale
+
+
+def test_c5_run_iteration_through_a_densify_event_then_renders_at_the_new_population():
+    """BASELINE config C5 as the loop runs it: ``ViewParallelTrainer.run`` at 5M gaussians / 3840x2160 / SH 3 (fused step) for two
+    iterations -- the first ends in a densify / prune event (clones, cut by the ``max_gaussians`` cap), the second
+    renders at the NEW population.  The record capacity of the second step is predicted from the remembered ratio (no
+    blocking read-back, no repair: the ``N > 1.4M`` rule keeps these sizes on the LSD depth ordering, whose key bits are
+    remembered too), the step produces finite metrics and the model, the optimizer and the bucket stay bound."""
+    import gsplat_amd
+    from gsplat_amd import scene, stages as S
+    from gsplat_amd.harness import LoopConfig, SplatModel, StepConfig, ViewParallelTrainer
+    N, W, H = 5_000_000, 3840, 2160
+    sc = scene.make_scene(N, seed=0, sh_degree=3)
+    model = SplatModel(N, "cuda")
+    model.load(xyz=sc["means3D"].cuda(), features_dc=sc["shs"][:, :1].cuda(), features_rest=sc["shs"][:, 1:].cuda(),
+               opacity=torch.logit(sc["opacities"].clamp(1e-4, 1 - 1e-4)).cuda(), scaling=torch.log(sc["scales"]).cuda(),
+               rotation=sc["rotations"].cuda())
+    K = scene.make_intrinsics(W, H).cuda()
+    tr = ViewParallelTrainer(model, gsplat_amd.HipBackend(K), StepConfig(), fused=True)
+    tr.iteration = 5100                                     # > densify_after and a multiple of densify_interval
+    g = torch.Generator(device="cuda").manual_seed(1)
+    target = torch.rand(H, W, 3, generator=g, device="cuda")
+    views = [{"image": target, "pose": scene.make_camera(v, 8).cuda(), "width": W, "height": H} for v in (0, 1)]
+
+    def loader():
+        i = 0
+        while True:
+            yield [views[i % 2]]
+            i += 1
+
+    calls, orig = [], S.bin_tiles
+
+    def spy(*a, **kw):
+        b = orig(*a, **kw)
+        calls.append((a[0].shape[0], bool(kw.get("exact", False)), b._m is None))
+        return b
+
+    S.bin_tiles = spy
+    trace = []
+    try:
+        # warm the shape's memory (capacity ratio, key bits) the way the iterations before 5100 would have
+        tr.training_step([views[1]])
+        tr.training_step([views[0]])
+        calls.clear()
+        for k in S.REPAIR_STATS:
+            S.REPAIR_STATS[k] = 0
+        loop = LoopConfig(iterations=5102, densify_grads_threshold=1e-12, max_gaussians=5_100_000)
+        tr.run(loader(), extent=1.0, loop=loop, on_step=lambda it, n0, met, st: trace.append((it, n0, met, st)))
+    finally:
+        S.bin_tiles = orig
+    (it0, n0, met0, st0), (it1, n1, met1, st1) = trace
+    assert (it0, n0, it1) == (5100, N, 5101) and st0 is not None and st1 is None
+    # (one step's gradient reaches the ~150 k gaussians in front -- the rest of the 5M is occluded; more than the cap admits)
+    assert st0["cloned"] + st0["split"] >= 50_000 and st0["capped"] and n1 == st0["n_after"] == model.n != N
+    assert all(math.isfinite(float(v)) for v in met1.values()) and 0.0 < met1["l1"] < 1.0
+    # iteration 5101 binned the new population ONCE, for a predicted capacity, without waiting for its record count
+    second = [c for c in calls if c[0] == n1]
+    assert second == [(n1, False, True)], calls
+    assert S.REPAIR_STATS["capacity_misses"] == 0 and S.REPAIR_STATS["key_range_repairs"] == 0, S.REPAIR_STATS
+    model.check_bound()
+    assert tr.optimizer.exp_avg.numel() == 59 * n1 and torch.isfinite(model.flat).all()
 
 
 def test_fused_adam_step_at_c3_size():

@@ -15,9 +15,11 @@ shutil.copy(f"{src}/traffic.json", f"{out}/{name}_traffic.json")
 profiled = open(f"{src}/bench_profiled.json").read().strip().splitlines()[-1]
 default = open(f"{src}/bench_default.json").read().strip().splitlines()[-1]
 pj = json.loads(profiled)
-traced = pj["warmup"] + 3 * pj["steps"]   # warm-up + headline pass + per-step-event pass + instrumented pass
 table = open(f"{src}/summary_table.md").read().rstrip()
 tr = json.load(open(f"{src}/traffic.json"))
+import subprocess
+tr["csrc_rev"] = subprocess.check_output(["git", "rev-parse", "--short=12", "HEAD:3d-gaussian-splatting_amd/csrc"], text=True).strip()
+json.dump(tr, open(f"{out}/{name}_traffic.json", "w"), indent=1)   # (the copy under profiles/ carries the sources' revision)
 
 
 def counters_row(label, k):
@@ -39,8 +41,9 @@ Produced by `tools/round_artifacts.sh {tag}` on one MI355X box (default bench, t
 behind `profiles/{name}_traffic.json`, in that order) and `tools/make_round_summary.py`.
 
 Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps {pj['steps']} --warmup {pj['warmup']} --no-cpu-baseline`
-({pj['warmup']} warm-up + {pj['steps']} timed + {pj['steps']} with one event per step + {pj['steps']} instrumented steps = {traced} steps traced;
-`profiles/{name}_kernel_stats.csv` is the raw stats file).
+(every pass of bench.py is traced: the {pj['config']['views_per_gpu_per_step']}-view steps of the timed region -- warm-up, settling, {pj['steps']} timed, {pj['steps']} with one event
+per step -- the single-view steps, the instrumented single-view steps, the rotating-view pass;
+`profiles/{name}_kernel_stats.csv` is the raw stats file, `profiles/{name}_traffic.json` was measured on csrc revision {tr['csrc_rev']}).
 
 bench.py line of the same (profiled) run:
 
@@ -54,9 +57,9 @@ Un-profiled default run (`python bench.py`, CPU baseline legs included) on the s
 {default}
 ```
 
-{table.replace('/ 45 steps', f'/ {traced} steps')}
+{table}
 
-(The `sum of kernel time` line divides by the {traced} traced steps.)  The dominant kernel's average duration under the
+The dominant kernel's average duration under the
 profiler (`composite_bwd_2p_kernel<3>`, table above) agrees with the HIP-event average bench.py reports in
 `roofline.avg_launch_ms` (un-profiled; the profiler adds a few percent).
 Binning is `radix_hist<unsigned int>` + `radix_scan_rows` + `radix_scatter<unsigned int>` (ONE global pass: depth

@@ -7,13 +7,13 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$tag
 mkdir -p $O
 cd $R
-python bench.py > $O/bench_default.json 2> $O/bench_default.err
+bash tools/hb.sh python bench.py > $O/bench_default.json 2> $O/bench_default.err
 echo "default bench done"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_profiled.json 2> $O/bench_profiled.err
 echo "rocprof stats done"
 cd $R
-python tools/prof_summary.py $O/stats/p_kernel_stats.csv 65 > $O/summary_table.md   # 5 warm-up + 3 x 20 steps traced
+python tools/prof_summary.py $O/stats/p_kernel_stats.csv > $O/summary_table.md
 echo "summary done"
 bash tools/collect_pmc.sh gpurun_out/$tag/pmc > $O/pmc.log 2>&1
 echo "pmc done"
