@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kBlock, GSA_PROJ_FWD_WAVES) void project_fwd_kernel
     const float *__restrict__ viewmat, const float *__restrict__ intrin, int width, int height, int tile_w,
     int tile_h, int cull_mode, float *__restrict__ splat, int32_t *__restrict__ radii,
     int32_t *__restrict__ tiles_touched, uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ tile_rects,
-    float *__restrict__ sh_aux, int bin_tile) {
+    float *__restrict__ sh_aux, int bin_tile, uint32_t *__restrict__ key_range) {
     __shared__ float4 sh_lds[STAGE ? (kBlock / 64) * kWaveLds : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Blocks walk the gaussians from the LAST to the first (GSA_PROJ_FWD_REVERSE): the kernel that ran before this one in
@@ -286,6 +286,22 @@ __global__ __launch_bounds__(kBlock, GSA_PROJ_FWD_WAVES) void project_fwd_kernel
         }
         float4 *out = reinterpret_cast<float4 *>(splat + i * GSA_SPLAT_STRIDE);
         out[0] = o0; out[1] = o1; out[2] = o2; out[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // key_range (optional): per WAVE the smallest / largest depth key of its visible gaussians (0xFFFFFFFF / 0 when it has
+    // none) and the keys of its lanes 0 and 32 (a sample of the view's keys), one plain 16-byte store -- the bucketed depth
+    // ordering builds THIS view's depth table from the ceil(n / 64) entries (gsa_depth_order_msd's key_range_dev).
+    // (Atomic min / max into a few shards were tried first: the waves of the kernel's first round all find the initial
+    // values and all add -- 31 k atomics on two cache lines tripled this kernel's time, 64 shards on lines of their own
+    // still cost 15 %.)
+    if (key_range) {
+        const uint32_t s0 = (uint32_t)__shfl((int)key, 0), s1 = (uint32_t)__shfl((int)key, 32);
+        uint32_t lo = key, hi = key == 0xFFFFFFFFu ? 0u : key;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            lo = min(lo, (uint32_t)__shfl_xor((int)lo, d));
+            hi = max(hi, (uint32_t)__shfl_xor((int)hi, d));
+        }
+        if (lane == 0) reinterpret_cast<uint4 *>(key_range)[blk * (kBlock / 64) + wave] = make_uint4(lo, hi, s0, s1);
     }
     if (!inside) return;
     *reinterpret_cast<int2 *>(radii + 2 * i) = make_int2(rx, ry);
@@ -612,19 +628,19 @@ int launch_fwd(bool stage, int n, const float *means, const float *quats, const 
                const float *opacities, const float *colors, int sh_coeffs, const float *viewmat,
                const float *intrin, int width, int height, int cull_mode, float *splat, int32_t *radii,
                int32_t *tiles_touched, uint32_t *depth_keys, uint32_t *tile_rects, float *sh_aux, int bin_tile,
-               hipStream_t s) {
+               uint32_t *key_range, hipStream_t s) {
     int tile_w = gsa_div_up(width, GSA_TILE_SIZE), tile_h = gsa_div_up(height, GSA_TILE_SIZE);
     dim3 grid(gsa_div_up(n, kBlock)), block(kBlock);
     if (stage)
         project_fwd_kernel<DEG, true><<<grid, block, 0, s>>>(n, means, quats, scales, opacities, colors, sh_coeffs,
                                                              viewmat, intrin, width, height, tile_w, tile_h, cull_mode,
                                                              splat, radii, tiles_touched, depth_keys, tile_rects, sh_aux,
-                                                             bin_tile);
+                                                             bin_tile, key_range);
     else
         project_fwd_kernel<DEG, false><<<grid, block, 0, s>>>(n, means, quats, scales, opacities, colors, sh_coeffs,
                                                               viewmat, intrin, width, height, tile_w, tile_h,
                                                               cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects,
-                                                              sh_aux, bin_tile);
+                                                              sh_aux, bin_tile, key_range);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }
@@ -673,7 +689,8 @@ extern "C" int gsa_project_fwd(int n, const float *means, const float *quats, co
                                const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
                                const float *viewmat, const float *intrin, int width, int height, int cull_mode,
                                float *splat, int32_t *radii, int32_t *tiles_touched, uint32_t *depth_keys,
-                               uint32_t *tile_rects, float *sh_aux, int bin_tile, gsa_stream_t stream) {
+                               uint32_t *tile_rects, float *sh_aux, int bin_tile, uint32_t *key_range,
+                               gsa_stream_t stream) {
     GSA_RETURN_IF(n < 0 || width <= 0 || height <= 0, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_degree < -1 || sh_degree > 3, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_degree >= 0 && sh_coeffs < (sh_degree + 1) * (sh_degree + 1), GSA_ERR_INVALID_ARGUMENT);
@@ -694,7 +711,7 @@ extern "C" int gsa_project_fwd(int n, const float *means, const float *quats, co
     bool stage = can_stage(colors, sh_degree, sh_coeffs) && sh_degree >= 1;
 #define GSA_FWD(D)                                                                                              \
     return launch_fwd<D>(stage, n, means, quats, scales, opacities, colors, sh_coeffs, viewmat, intrin, width, \
-                         height, cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects, sh_aux, bin_tile, s)
+                         height, cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects, sh_aux, bin_tile, key_range, s)
     switch (sh_degree) {
         case -1: GSA_FWD(-1);
         case 0: GSA_FWD(0);

@@ -58,9 +58,230 @@ __device__ __forceinline__ int resolve_count(int n_cap, const uint32_t *__restri
 struct RadixDigit {
     int shift;
     uint32_t sub;
-    int msd;
+    int msd;                 // 0: plain bits; 1: 255 equal MSD buckets from (sub, shift = scale); 2: a depth table on the device,
+                             // not yet resolved (resolve_table); 3: resolved -- bucket = lut[(key >> shift) - sub]
+    const uint32_t *table;   // msd >= 2: the view's depth table (kTabWords words, built by the histogram pass: build_depth_table)
+    const uint8_t *lut;      // msd == 3: its cell -> bucket map (global memory: 2 KB, served by L1)
+    uint32_t cells;          // msd == 3: cells in use
 };
+
+// ---- depth buckets that fit the view at hand (gsa_depth_order_msd with key_range_dev) --------------------------------
+// gsa_project_fwd leaves, per wave of 64 gaussians, (min, max) of the visible depth keys and two of the keys themselves.
+// The first launch of the ordering turns them into THIS view's DEPTH TABLE: the exact key range [lo, hi] is cut into at
+// most 4096 aligned CELLS of 2^shift keys (cell = (key >> shift) - g0), the ~2 N / 64 sample keys are counted per cell, and
+// consecutive cells are grouped into at most 255 buckets that hold about the same number of keys each -- and never more
+// cells than 16-bit key offsets cover (65536 >> shift).  A monotone map: buckets are still depth ranges and the order
+// produced is the same whatever the table; what the table decides is how full the fullest bucket is.  Depth is far from
+// uniformly distributed in key space (float bits are denser above every power of two; a frustum holds more gaussians far
+// away): 255 EQUAL buckets put 12.6 k of 1 M keys into one bucket for the diagonal cameras of the bench ring -- 3.5 x the
+// mean, beyond the 8192-key LDS capacity of the local sorts, so those views fell back to the LSD path -- and 6.7 k for the
+// axis-aligned ones.  ONE workgroup builds the table, in a launch of its own in front of the histogram pass 
+constexpr int kCellsMax = 4096;
+constexpr int kTabLut = 0;                   // 4096 bytes: cell -> bucket
+constexpr int kTabCs = 1024;                 // 257 words: bucket -> first cell (then the end)
+constexpr int kTabPlan = 1284;               // g0, shift, cells, flags
+constexpr int kTabWords = 1288;
+constexpr uint32_t kPlanWide = 1u;           // the key range is wider than 250 x 65536 keys: 16-bit local sorts cannot order it
+
+struct DepthPlan { uint32_t g0, shift, cells, flags; };
+
+// exclusive scan of one value per thread across the kTabThreads threads of the table kernel; total through `total`
+constexpr int kTabThreads = 1024;
+__device__ __forceinline__ uint32_t tab_excl_scan(uint32_t v, uint32_t *scratch, uint32_t &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < GSA_WAVE; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) scratch[wave] = inc;
+    __syncthreads();
+    uint32_t off = 0, sum = 0;
+#pragma unroll
+    for (int w = 0; w < kTabThreads / 64; ++w) {
+        const uint32_t c = scratch[w];
+        if (w < wave) off += c;
+        sum += c;
+    }
+    total = sum;
+    __syncthreads();
+    return off + inc - v;
+}
+
+// ONE workgroup, in front of the histogram pass: the view's depth table from what gsa_project_fwd left per wave.
+__global__ __launch_bounds__(kTabThreads) void depth_table_kernel(const uint4 *__restrict__ ranges, int n_waves,
+                                                                  uint32_t *__restrict__ table_out) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_lut[kCellsMax];
+    __shared__ uint32_t s_fine[kCellsMax], s_cs[260], scratch[8 * (kTabThreads / 64)];
+    const int t = threadIdx.x;
+    constexpr int NW = kTabThreads / 64;
+    // two totals over the block at once (one barrier; alternating scratch halves, so no second one)
+    int phase = 0;
+    auto block_sum2 = [&](uint32_t a, uint32_t b_, uint32_t &ta, uint32_t &tb) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { a += (uint32_t)__shfl_xor((int)a, d); b_ += (uint32_t)__shfl_xor((int)b_, d); }
+        uint32_t *sc = scratch + (phase & 1) * 2 * NW;
+        ++phase;
+        if ((t & 63) == 0) { sc[t >> 6] = a; sc[NW + (t >> 6)] = b_; }
+        __syncthreads();
+        ta = tb = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { ta += sc[w]; tb += sc[NW + w]; }
+    };
+    // ---- ONE pass over the per-wave entries: the exact key range now, the sample keys kept in registers for the cells
+    constexpr int kMaxTrips = 4;          // 4 x 8 x 1024 waves = 2 M gaussians (beyond that the sample is thinned: every k-th wave)
+    const int stride = (n_waves + kMaxTrips * 8 * kTabThreads - 1) / (kMaxTrips * 8 * kTabThreads);
+    const int n_eff = (n_waves + stride - 1) / stride;
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u, smp[kMaxTrips * 8][2];
+#pragma unroll
+    for (int trip = 0; trip < kMaxTrips; ++trip) {
+        uint4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = (trip * 8 + j) * kTabThreads + t;
+            v[j] = ranges[min((long)min(i, n_eff - 1) * stride, (long)n_waves - 1)];
+            if (i >= n_eff) v[j] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            lo = min(lo, v[j].x); hi = max(hi, v[j].y);
+            smp[trip * 8 + j][0] = v[j].z; smp[trip * 8 + j][1] = v[j].w;
+        }
+        if ((trip + 1) * 8 * kTabThreads >= n_eff) break;   // (uniform)
+    }
+    if (stride > 1) {   // the range must be exact: the waves the sample skips still count for it
+        for (int i = t; i < n_waves; i += kTabThreads) {
+            const uint2 r = *reinterpret_cast<const uint2 *>(&ranges[i]);
+            lo = min(lo, r.x); hi = max(hi, r.y);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, d));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, d));
+    }
+    if ((t & 63) == 0) { scratch[4 * NW + (t >> 6)] = lo; scratch[5 * NW + (t >> 6)] = hi; }
+    for (int c = t; c < kCellsMax; c += kTabThreads) s_fine[c] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { lo = min(lo, scratch[4 * NW + w]); hi = max(hi, scratch[5 * NW + w]); }
+    DepthPlan pl{0u, 0u, 1u, 0u};
+    if (lo <= hi) {
+        if ((unsigned long long)hi - lo + 1ull > 250ull * 65536ull) pl.flags = kPlanWide;   // (250: the cells' alignment and
+                                                                                              // rounding need the rest of the 254)
+        uint32_t sh = 0;
+        while ((hi >> sh) - (lo >> sh) + 1u > (uint32_t)kCellsMax) ++sh;   // (aligned cells of 2^sh keys; <= 21 trips)
+        pl.shift = sh;
+        pl.g0 = lo >> sh;
+        pl.cells = (hi >> sh) - pl.g0 + 1u;
+    }
+    const uint32_t G = pl.cells;
+    const uint32_t max_cells = pl.shift >= 16u ? 1u : (65536u >> pl.shift);   // cells whose keys fit 16-bit offsets (flagged if too few)
+    // ---- the sample, per cell
+    uint32_t n_smp = 0;
+#pragma unroll
+    for (int k = 0; k < kMaxTrips * 8; ++k) {
+        if ((k / 8) * 8 * kTabThreads >= n_eff && k >= 8) break;   // (uniform: trips that were not loaded)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (smp[k][h] != 0xFFFFFFFFu) { atomicAdd(&s_fine[(smp[k][h] >> pl.shift) - pl.g0], 1u); ++n_smp; }
+        }
+    }
+    uint32_t total, unused;
+    block_sum2(n_smp, 0u, total, unused);   // (the barrier in there also covers the counters)
+    // ---- cells -> buckets.  Thread t owns the cells [PER t, PER t + PER).  Every cell DEMANDS a fraction of a bucket (16.16 fixed
+    // point): its share of the keys at T sample keys per bucket, but never less than 1 / max_cells -- and cell c goes to bucket
+    // floor(demand of the cells in front of it).  Monotone; a bucket holds at most T keys + one cell's, and at most max_cells
+    // cells (each adds 1 / max_cells or more).  T: the smallest for which the demands add up to 254 buckets or fewer -- first the
+    // T that would do if every cell paid both terms (always feasible), then refined from what the cells really pay.
+    constexpr int PER = kCellsMax / kTabThreads;
+    uint32_t cnt[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) cnt[j] = (uint32_t)(PER * t + j) < G ? s_fine[PER * t + j] : 0u;
+    const uint32_t wq = (65536u + max_cells - 1u) / max_cells;                      // a cell's least demand
+    const float kBudget = 254.f * 65536.f;
+    const float width_all = (float)G * (float)wq;
+    // x = 65536 / T (T: sample keys per bucket): demand of a cell = max(cnt x, wq), in 1/65536 buckets
+    auto demand = [&](uint32_t c, float x) -> uint32_t { return max((uint32_t)fminf((float)c * x, kBudget), wq); };
+    // what the cells pay at x: the count term of the cells it governs (A), the width term of the others (B)
+    auto paid = [&](float x, uint32_t &A, uint32_t &B) {
+        uint32_t pay_cnt = 0, pay_wid = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if ((uint32_t)(PER * t + j) < G) {
+                const uint32_t q = (uint32_t)fminf((float)cnt[j] * x, kBudget);
+                if (q > wq) pay_cnt += q; else pay_wid += wq;
+            }
+        }
+        block_sum2(pay_cnt, pay_wid, A, B);
+    };
+    float x = 0.f;                                                                  // (width only: no sample, or no room)
+    if (total && width_all + 4.f * 65536.f < kBudget) x = (kBudget - width_all - 4.f * 65536.f) / (float)total * 0.9999f;
+    const float x_feasible = x;
+    if (x > 0.f) {
+        // The demand D(x) = sum of max(cnt x, w) is convex and increasing.  From the feasible x0: one Newton step (x1: exact if
+        // no cell changes sides, otherwise beyond the budget), then the chord between the two, whose root lies on the
+        // feasible side of a convex function.
+        uint32_t A0, B0, A1, B1;
+        paid(x, A0, B0);
+        const float D0 = (float)A0 + (float)B0;
+        if (A0 > 0u && D0 < kBudget) {
+            const float x1 = x * (1.f + (kBudget - D0) / (float)A0);
+            paid(x1, A1, B1);
+            const float D1 = (float)A1 + (float)B1;
+            if (D1 <= kBudget * 0.999f) x = x1;
+            else if (D1 > D0) x = fmaxf(x, (x + (x1 - x) * (kBudget - D0) / (D1 - D0)) * 0.995f);
+        }
+    }
+    uint32_t fin[PER];
+    for (int pass = 0; pass < 2; ++pass) {
+        uint32_t mine = 0, d[PER], all;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { d[j] = (uint32_t)(PER * t + j) < G ? demand(cnt[j], x) : 0u; mine += d[j]; }
+        uint32_t ex = tab_excl_scan(mine, scratch + 6 * NW, all);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { fin[j] = ex >> 16; ex += d[j]; }
+        if (all <= (254u << 16) || x == x_feasible) break;   // (block-uniform) -- else: rounding went the wrong way
+        x = x_feasible;
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) s_lut[PER * t + j] = (uint8_t)min(fin[j], 254u);
+    for (int v = t; v < 260; v += kTabThreads) s_cs[v] = G;
+    __syncthreads();
+    {
+        uint32_t prev_f = t > 0 ? (uint32_t)s_lut[PER * t - 1] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const uint32_t c = (uint32_t)(PER * t + j), fc = min(fin[j], 254u);
+            if (c < G && fc != prev_f) {
+                for (uint32_t v = prev_f == 0xFFFFFFFFu ? 0u : prev_f + 1u; v <= fc; ++v) s_cs[v] = c;
+            }
+            prev_f = fc;
+        }
+    }
+    __syncthreads();
+    const uint32_t *lw = reinterpret_cast<const uint32_t *>(s_lut);
+    for (int w = t; w < kCellsMax / 4; w += kTabThreads) table_out[kTabLut + w] = lw[w];
+    for (int v = t; v < 257; v += kTabThreads) table_out[kTabCs + v] = s_cs[v];
+    if (t == 0) {
+        table_out[kTabPlan] = pl.g0; table_out[kTabPlan + 1] = pl.shift;
+        table_out[kTabPlan + 2] = pl.cells; table_out[kTabPlan + 3] = pl.flags;
+    }
+}
+
+// msd == 2 -> 3: the plan and the table of THIS view, as the histogram pass left them
+__device__ __forceinline__ void resolve_table(RadixDigit &dg) {
+    if (dg.msd != 2) return;
+    dg.sub = dg.table[kTabPlan];
+    dg.shift = (int)dg.table[kTabPlan + 1];
+    dg.cells = dg.table[kTabPlan + 2];
+    dg.lut = reinterpret_cast<const uint8_t *>(dg.table + kTabLut);
+    dg.msd = 3;
+}
+
 __device__ __forceinline__ uint32_t digit_of(uint32_t key, const RadixDigit &dg) {
+    if (dg.msd == 3) return key == 0xFFFFFFFFu ? 255u : (uint32_t)dg.lut[min((key >> dg.shift) - dg.sub, dg.cells - 1u)];
     if (dg.msd) return key == 0xFFFFFFFFu ? 255u : min(__umulhi(key - dg.sub, (uint32_t)dg.shift), 254u);
     return (key >> dg.shift) & (kRadix - 1);
 }
@@ -86,6 +307,22 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(int n_cap, con
                                                                   RadixDigit dg, int nblocks,
                                                                   uint32_t *__restrict__ hist,
                                                                   uint32_t *__restrict__ block_range) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_lut[sizeof(KeyT) == 4 ? kCellsMax : 4];
+    DepthPlan pl{0u, 0u, 1u, 0u};
+    bool tabled = false;
+    if constexpr (sizeof(KeyT) == 4) {
+        if (dg.msd == 2) {   // this view's depth table (depth_table_kernel): the cell -> bucket map into LDS
+            pl.g0 = dg.table[kTabPlan]; pl.shift = dg.table[kTabPlan + 1]; pl.cells = dg.table[kTabPlan + 2];
+            uint32_t *lw = reinterpret_cast<uint32_t *>(s_lut);
+            for (int w = threadIdx.x; w < kCellsMax / 4; w += kSortThreads) lw[w] = dg.table[kTabLut + w];
+            tabled = true;   // (the barrier in front of the counting loop covers these stores)
+        }
+    }
+    // (with a table the digit comes out of the LDS copy; digit_of's msd == 3 form reads the stored one)
+    auto digit = [&](uint32_t key) -> uint32_t {
+        if (tabled) return key == 0xFFFFFFFFu ? 255u : (uint32_t)s_lut[min((key >> pl.shift) - pl.g0, pl.cells - 1u)];
+        return digit_of(key, dg);
+    };
     const int shift = dg.shift;
     __shared__ uint32_t h[kRadix];
     __shared__ uint32_t s_lo, s_hi;
@@ -133,7 +370,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(int n_cap, con
         for (int r = 0; r < kSortItems; ++r) kk[r] = (uint32_t)keys[base + r * kSortThreads + threadIdx.x];
 #pragma unroll
         for (int r = 0; r < kSortItems; ++r) {
-            atomicAdd(&h[digit_of(kk[r], dg)], 1u);
+            atomicAdd(&h[digit(kk[r])], 1u);
             if (kk[r] != 0xFFFFFFFFu) { lo = min(lo, kk[r]); hi = max(hi, kk[r]); }
         }
     } else {
@@ -142,7 +379,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(int n_cap, con
             long i = base + r * kSortThreads + threadIdx.x;
             if (i < n) {
                 const uint32_t kk = (uint32_t)keys[i];
-                atomicAdd(&h[digit_of(kk, dg)], 1u);
+                atomicAdd(&h[digit(kk)], 1u);
                 if (kk != 0xFFFFFFFFu) { lo = min(lo, kk); hi = max(hi, kk); }
             }
         }
@@ -294,6 +531,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     const int n = resolve_count(n_cap, n_dev);
     if ((long)sort_block_id() * kSortChunk >= n) return;   // whole block beyond the live items (capacity launch)
     SORT_TRACE_BEGIN();
+    resolve_table(dg);
 
     // (keys and values first: their latency hides behind the histogram columns and the two block scans)
     const long base = (long)sort_block_id() * kSortChunk + wave * (kSortChunk / 4);
@@ -895,11 +1133,11 @@ static int sort_pairs_impl(int n, const uint32_t *n_dev, const uint32_t *keys_in
         uint32_t *kout = to_out ? keys_out : keys_tmp;
         uint32_t *vout = to_out ? vals_out : vals_tmp;
         int shift = begin_bit + 8 * p;
-        radix_hist_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(n, n_dev, kin, RadixDigit{shift, 0u, 0}, nblocks, hist, nullptr);
+        radix_hist_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(n, n_dev, kin, RadixDigit{shift, 0u, 0, nullptr, nullptr, 0u}, nblocks, hist, nullptr);
         GSA_LAUNCH_CHECK();
         radix_scan_rows_kernel<<<kRadix, kSortThreads, 0, s>>>(nblocks, hist, digit_total);
         GSA_LAUNCH_CHECK();
-        radix_scatter_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(n, n_dev, kin, vin, kout, vout, RadixDigit{shift, 0u, 0},
+        radix_scatter_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(n, n_dev, kin, vin, kout, vout, RadixDigit{shift, 0u, 0, nullptr, nullptr, 0u},
                                                                         nblocks, hist, digit_total);
         GSA_LAUNCH_CHECK();
         kin = kout;
@@ -1004,14 +1242,14 @@ extern "C" int gsa_depth_order(int n, const uint32_t *depth_keys, const uint32_t
         const bool last = p == passes - 1;
         uint32_t *kout = last ? nullptr : kbuf[p & 1];
         uint32_t *vout = last ? order : vbuf[p & 1];
-        radix_hist_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(n, nullptr, kin, RadixDigit{8 * p, 0u, 0}, nblocks, hist,
+        radix_hist_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(n, nullptr, kin, RadixDigit{8 * p, 0u, 0, nullptr, nullptr, 0u}, nblocks, hist,
                                                                      p == 0 ? block_range : nullptr);
         GSA_LAUNCH_CHECK();
         radix_scan_rows_kernel<<<kRadix, kSortThreads, 0, s>>>(nblocks, hist, digit_total, p == 0 ? block_range : nullptr,
                                                                p == 0 ? key_range : nullptr);
         GSA_LAUNCH_CHECK();
         radix_scatter_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(
-            n, nullptr, kin, vin, kout, vout, RadixDigit{8 * p, 0u, 0}, nblocks, hist, digit_total,
+            n, nullptr, kin, vin, kout, vout, RadixDigit{8 * p, 0u, 0, nullptr, nullptr, 0u}, nblocks, hist, digit_total,
             last ? reinterpret_cast<const uint2 *>(tile_rects) : nullptr, last ? rects : nullptr, last ? counts : nullptr);
         GSA_LAUNCH_CHECK();
         kin = kout;
@@ -1034,7 +1272,7 @@ extern "C" int gsa_depth_order(int n, const uint32_t *depth_keys, const uint32_t
 // ctl[1..2]); the caller then repeats with the LSD path.
 constexpr int kLocalThreads = 1024, kLocalWaves = kLocalThreads / 64, kLocalCap = 8192;
 constexpr unsigned long long kGranuleReady = 1ull << 63;
-constexpr uint32_t kStatusOverflow = 1u, kStatusTimeout = 2u;
+constexpr uint32_t kStatusOverflow = 1u, kStatusTimeout = 2u, kStatusWide = 4u;
 
 struct BucketLds {
     uint32_t val[2][kLocalCap];           // gaussian ids, ping-pong; after the sort the idle half holds the record counts
@@ -1127,7 +1365,7 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
     uint32_t key_min, uint32_t scale, const uint2 *__restrict__ tile_rects, uint32_t *__restrict__ order,
     uint32_t *__restrict__ rects, uint32_t *__restrict__ offsets, int32_t *__restrict__ block_owner, int n_owner_blocks,
     unsigned long long *granule, uint32_t *ticket, uint32_t *__restrict__ ctl, uint32_t *__restrict__ ctl_host,
-    uint32_t token) {
+    uint32_t token, const uint32_t *__restrict__ table) {
     __shared__ BucketLds L;
     __shared__ uint32_t s_bucket;
     const int t = threadIdx.x;
@@ -1154,9 +1392,18 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
     // bucket d holds the keys x = key - key_min with (x * scale) >> 32 == d: x in [lo_d, lo_(d+1)), lo_d = ceil(d 2^32 /
     // scale); the local sorts run on x - lo_d (< 2^16 by the caller's choice of scale; the last bucket is clamped, a key
     // beyond the assumed range wraps there and the caller, who checks the measured range, repeats)
-    const uint32_t lo_d = (uint32_t)((((unsigned long long)d << 32) + scale - 1u) / scale);
-    const uint32_t width = (uint32_t)((((unsigned long long)(d + 1) << 32) + scale - 1u) / scale) - lo_d;
-    const uint32_t sub = key_min + lo_d, mask = 0xFFFFu;
+    // (with a depth table: bucket d = the cells [cs[d], cs[d + 1]) of 2^shift keys each, counted from cell g0)
+    uint32_t sub, width;
+    if (table) {
+        const uint32_t c0 = table[kTabCs + min(d, 255)], c1 = table[kTabCs + min(d + 1, 256)], sh = table[kTabPlan + 1];
+        sub = (table[kTabPlan] + c0) << sh;
+        width = (c1 - c0) << sh;
+    } else {
+        const uint32_t lo_d = (uint32_t)((((unsigned long long)d << 32) + scale - 1u) / scale);
+        width = (uint32_t)((((unsigned long long)(d + 1) << 32) + scale - 1u) / scale) - lo_d;
+        sub = key_min + lo_d;
+    }
+    const uint32_t mask = 0xFFFFu;
     // (loads in groups of four strides with CLAMPED indices, all of a group in flight at once: a plain strided loop
     // waits for every load before it issues the next -- one memory round trip per 1024 items)
     constexpr int kStrides = kLocalCap / kLocalThreads;
@@ -1254,6 +1501,7 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
             // count and key range first, then -- released at system scope -- the status tagged with the caller's token,
             // which the host polls for.  (A block can only time out on a granule this block waits for as well, so the
             // status read here is final.)
+            if (table && (table[kTabPlan + 3] & kPlanWide)) atomicOr(&ctl[3], kStatusWide);   // the range was too wide for 16-bit local sorts
             if (ctl_host) {
                 __threadfence();
                 const uint32_t st = __hip_atomic_load(&ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1297,19 +1545,33 @@ extern "C" size_t gsa_depth_order_msd_workspace_bytes(int n) {
     if (n < 0) n = 0;
     // first-pass output (keys, values), per-block key ranges, histograms, granules + ticket
     return (size_t)2 * n * sizeof(uint32_t) + (size_t)2 * ((size_t)sort_blocks(n) + 1) * sizeof(uint32_t) +
-           gsa_sort_workspace_bytes(n) + (size_t)(2 * kRadix + 16) * sizeof(uint32_t) + 16;
+           gsa_sort_workspace_bytes(n) + (size_t)(2 * kRadix + 16 + kTabWords) * sizeof(uint32_t) + 16;
 }
 
 extern "C" int gsa_depth_order_msd_max_width(void) { return 65536; }
 
+// where gsa_depth_order_msd(key_range_dev) leaves the view's depth table inside its workspace (diagnostics and tests):
+// byte offset from a 16-byte-aligned workspace base; gsa_depth_order_msd_table_words() uint32 -- bytes [0, 4096): bucket of
+// every cell; words [1024, 1281): first cell of every bucket, then the end; words 1284..1287: g0, shift, cells, flags
+extern "C" size_t gsa_depth_order_msd_table_offset(int n) {
+    if (n < 0) n = 0;
+    const size_t nblocks = (size_t)sort_blocks(n);
+    size_t words = (size_t)2 * n + 2 * (nblocks + 1) + (size_t)kRadix * nblocks + kRadix;
+    size_t bytes = (words * sizeof(uint32_t) + 15) & ~(size_t)15;
+    return bytes + (size_t)kRadix * sizeof(unsigned long long) + 16 * sizeof(uint32_t);
+}
+extern "C" int gsa_depth_order_msd_table_words(void) { return kTabWords; }
+
 extern "C" int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint32_t *tile_rects, uint32_t key_min,
-                                   uint32_t scale, uint32_t *order, uint32_t *rects, uint32_t *offsets, int32_t *block_owner,
+                                   uint32_t scale, const uint32_t *key_range_dev, uint32_t *order, uint32_t *rects,
+                                   uint32_t *offsets, int32_t *block_owner,
                                    int n_blocks, uint32_t *ctl, uint32_t *ctl_host, uint32_t token, void *workspace,
                                    size_t workspace_bytes, gsa_stream_t stream) {
     // (scale >= 2^16: a bucket is at most 2^32 / scale + 1 <= 65537 keys wide -- 16-bit local sorts; exactly 2^16 is the
     // power-of-two case shift = 16)
-    GSA_RETURN_IF(n < 0 || scale < 65536u || !ctl || n_blocks < 0 || (n_blocks > 0 && !block_owner),
+    GSA_RETURN_IF(n < 0 || (!key_range_dev && scale < 65536u) || !ctl || n_blocks < 0 || (n_blocks > 0 && !block_owner),
                   GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF((reinterpret_cast<uintptr_t>(key_range_dev) & 15) != 0, GSA_ERR_INVALID_ARGUMENT);
     hipStream_t s = static_cast<hipStream_t>(stream);
     GSA_RETURN_IF(token > 0xFFFFFFu, GSA_ERR_INVALID_ARGUMENT);
     if (n == 0) {
@@ -1334,7 +1596,14 @@ extern "C" int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint
     g = (g + 15) & ~(uintptr_t)15;
     unsigned long long *granule = reinterpret_cast<unsigned long long *>(g);
     uint32_t *ticket = reinterpret_cast<uint32_t *>(granule + kRadix);
-    const RadixDigit dg{(int)scale, key_min, 1};
+    // key_range_dev: what gsa_project_fwd left per wave -> one workgroup builds this view's depth table behind the ticket
+    // for the launches that follow (the row scan zeroes only granules, ticket and ctl[3])
+    uint32_t *table = key_range_dev ? ticket + 16 : nullptr;
+    const RadixDigit dg{(int)scale, key_min, table ? 2 : 1, table, nullptr, 0u};
+    if (table) {
+        depth_table_kernel<<<1, kTabThreads, 0, s>>>(reinterpret_cast<const uint4 *>(key_range_dev), gsa_div_up(n, 64), table);
+        GSA_LAUNCH_CHECK();
+    }
     radix_hist_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(n, nullptr, depth_keys, dg, nblocks, hist, block_range);
     GSA_LAUNCH_CHECK();
     // (block 0 also reduces the key range into ctl[1..2]; block 1 zeroes the granules, the ticket and ctl[3])
@@ -1347,7 +1616,7 @@ extern "C" int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint
     depth_bucket_sort_kernel<<<kRadix, kLocalThreads, 0, s>>>(kbuf, vbuf, digit_total, key_min, scale,
                                                               reinterpret_cast<const uint2 *>(tile_rects), order, rects,
                                                               offsets, n_blocks > 0 ? block_owner : nullptr, n_blocks,
-                                                              granule, ticket, ctl, ctl_host, token);
+                                                              granule, ticket, ctl, ctl_host, token, table);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }
@@ -1471,12 +1740,12 @@ extern "C" int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offs
                                                          nblocks, hist, digit_total, low_mask);
     GSA_LAUNCH_CHECK();
     if (two) {
-        radix_hist_kernel<uint16_t><<<nblocks, kSortThreads, 0, s>>>((int)m_capacity, m_dev, tile_tmp, RadixDigit{low_bits, 0u, 0}, nblocks, hist, nullptr);
+        radix_hist_kernel<uint16_t><<<nblocks, kSortThreads, 0, s>>>((int)m_capacity, m_dev, tile_tmp, RadixDigit{low_bits, 0u, 0, nullptr, nullptr, 0u}, nblocks, hist, nullptr);
         GSA_LAUNCH_CHECK();
         radix_scan_rows_kernel<<<kRadix, kSortThreads, 0, s>>>(nblocks, hist, digit_total);
         GSA_LAUNCH_CHECK();
         radix_scatter_kernel<uint16_t><<<nblocks, kSortThreads, 0, s>>>((int)m_capacity, m_dev, tile_tmp, gid_tmp, sorted_tile,
-                                                                        sorted_gid, RadixDigit{low_bits, 0u, 0}, nblocks, hist,
+                                                                        sorted_gid, RadixDigit{low_bits, 0u, 0, nullptr, nullptr, 0u}, nblocks, hist,
                                                                         digit_total);
         GSA_LAUNCH_CHECK();
     }

@@ -39,14 +39,15 @@ class _RasterizeOneCamera(torch.autograd.Function):
         # the records are binned into 32 x 32 BINS where the fused binning applies (S.bin_tile_for): the four 16 x 16
         # tiles of a bin walk the bin's list -- a compositor wave re-tests every record against its 8 x 8 quadrant anyway
         bt = S.bin_tile_for(width, height, cull_mode)
+        kr = S.key_range_buffer(means_c.shape[0], means_c.device)   # this view's depth-key range, for the depth ordering's bucket plan
         proj = S.project_fwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
-                             cull_mode, return_rects=True, return_aux=want_lists, bin_tile=bt)
+                             cull_mode, return_rects=True, return_aux=want_lists, bin_tile=bt, key_range=kr)
         splat, radii, tiles_touched, depth_keys, rects = proj[:5]
         sh_aux = proj[5] if want_lists else None
         # the host does not wait for the record count: bins are sized for a remembered capacity, the compositor is
         # queued, and only then is the count (long since copied back) checked -- a miss repeats with exact sizes
         bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, tile_rects=rects,
-                           bin_tile=bt)
+                           bin_tile=bt, key_range=kr)
         tile_order = S.tile_schedule(bins.tile_offsets, width, height, bt)   # longest record lists first (speed only)
         out = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg_c, width, height, channels,
                               tile_order, want_lists=want_lists, bin_tile=bt, sorted_mask=bins.sorted_mask)

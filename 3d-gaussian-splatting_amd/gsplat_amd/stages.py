@@ -125,6 +125,13 @@ def _pinned_scalar(dev):
     return words[nxt], events[nxt], (gens, nxt, gens[nxt])   # another view's count
 
 
+def key_range_buffer(n: int, dev) -> torch.Tensor:
+    """[ceil(n / 64), 4] int32 for the depth keys of ONE view: ``project_fwd(key_range=...)`` writes, per wave of 64 gaussians,
+    the (min, max) of the visible keys and two of the keys (a sample); ``bin_tiles(key_range=...)`` hands it to the bucketed
+    depth ordering, which builds the depth table of the view at hand from it on the device."""
+    return torch.empty((n + 63) // 64, 4, dtype=torch.int32, device=dev)
+
+
 _TOKEN = [0]
 
 
@@ -182,12 +189,14 @@ _SH_AUX = os.environ.get("GSPLAT_AMD_SH_AUX", "1") != "0"
 
 
 def project_fwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat, Kmat, width: int, height: int,
-                cull_mode: int = 0, return_rects: bool = False, return_aux: bool = False, bin_tile: int = TILE_SIZE):
+                cull_mode: int = 0, return_rects: bool = False, return_aux: bool = False, bin_tile: int = TILE_SIZE,
+                key_range: Optional[torch.Tensor] = None):
     """-> splat [N,16], radii [N,2] i32, tiles_touched [N] i32, depth_keys [N] (uint32 bits in int32 storage)
     [, tile_rects [N,2] i32: (packed tile rectangle, record count) pairs the fused binning reads, with
     ``return_rects`` -- in tiles of ``bin_tile`` pixels: 16, or 32 for ``bin_tiles(..., bin_tile=32)``]
     [, sh_aux [N,12] f32 or None (sh_degree < 1): the 48-B digest of each coefficient row that lets
-    ``project_bwd`` skip the rows, with ``return_aux``]."""
+    ``project_bwd`` skip the rows, with ``return_aux``].
+    ``key_range``: a ``key_range_buffer`` that receives the view's depth-key range (for ``bin_tiles(key_range=...)``)."""
     dev, N = means.device, means.shape[0]
     sh_coeffs = colors.shape[1] if sh_degree >= 0 else 0
     splat = torch.empty(N, SPLAT_STRIDE, dtype=torch.float32, device=dev)
@@ -198,7 +207,8 @@ def project_fwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat
     sh_aux = torch.empty(N, 12, dtype=torch.float32, device=dev) if (return_aux and sh_degree >= 1 and _SH_AUX) else None
     _call("gsa_project_fwd", lib.gsa_project_fwd, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
           _ptr(colors), sh_degree, sh_coeffs, _ptr(viewmat), _ptr(Kmat), width, height, cull_mode, _ptr(splat),
-          _ptr(radii), _ptr(tiles_touched), _ptr(depth_keys), _ptr(tile_rects), _ptr(sh_aux), bin_tile, _stream())
+          _ptr(radii), _ptr(tiles_touched), _ptr(depth_keys), _ptr(tile_rects), _ptr(sh_aux), bin_tile, _ptr(key_range),
+          _stream())
     out = (splat, radii, tiles_touched, depth_keys)
     if return_rects:
         out += (tile_rects,)
@@ -303,9 +313,20 @@ _SHRINK_AFTER = 32
 _KEY_RANGE = {}
 _MSD_MAX_WIDTH = int(lib.gsa_depth_order_msd_max_width())
 _DEPTH_MSD_DEFAULT = os.environ.get("GSPLAT_AMD_DEPTH_MSD", "1") != "0"
+# How the bucketed depth ordering gets its buckets.  "host": 255 EQUAL buckets over the union of the key ranges of the views of
+# this scene shape seen so far (planned here; 4 launches) -- the fastest when it fits, but one wide view empties the buckets
+# of all the others and unevenly distributed depths (the diagonal cameras of the bench ring: 3.5 x the mean in one bucket)
+# overflow a bucket.  "device": the view's own DEPTH TABLE, built on the device from what project_fwd leaves per wave (one
+# more, single-workgroup launch: +0.012 ms at 1 M gaussians) -- level buckets for any view.  GSPLAT_AMD_DEPTH_TABLE=auto (default):
+# a scene shape starts on "host" and moves to "device" for the next _TABLE_VIEWS views when a host-planned ordering has to
+# be repaired; =1 / =0: always / never.
+_DEPTH_TABLE = os.environ.get("GSPLAT_AMD_DEPTH_TABLE", "auto")
+_TABLE_VIEWS = 4096
+_TABLE_MODE = {}          # scene shape -> views left on the device-built table
 _MSD_MIN_N = 32768        # below this the 256 x 1024-thread bucket launch costs more than the LSD passes it replaces
 _MSD_MAX_N = 1_400_000    # above this an average bucket (N / 255, x1.5 for skew) no longer fits the 8192-key LDS capacity
 _MSD_BACKOFF = {}         # scene shape -> calls left before the bucketed ordering is tried again after an overflow
+_MSD_STREAK = {}          # scene shape -> overflows of the device-planned ordering in a row (escalates the back-off)
 
 
 def _key_bits_needed(lo: int, hi: int) -> int:
@@ -353,9 +374,24 @@ def _note_keys(key, lo: int, hi: int, assumed, status: int = 0) -> bool:
             else:
                 ent[2] = 0
     if isinstance(assumed, tuple):
+        if len(assumed) == 3:   # planned on the device from the view's own range: only the status can say no
+            if status & 4:      # the range is beyond 16-bit local sorts: no table helps
+                _MSD_BACKOFF[key] = 64
+            elif status & 1:    # a bucket overflowed although its table was built from the view's own keys (a cluster of equal
+                streak = _MSD_STREAK.get(key, 0)          # depths, or an unlucky sample): back off, longer when it repeats
+                _MSD_BACKOFF[key] = min(64, 4 << streak)
+                _MSD_STREAK[key] = min(streak + 1, 4)
+            elif status == 0:
+                _MSD_STREAK.pop(key, None)
+            return status == 0
         kmin, scale = assumed
-        if status & 1:     # a depth cluster overflowed a bucket's LDS: every such call costs a repair, so back off
-            _MSD_BACKOFF[key] = 64
+        ok = status == 0 and (lo > hi or (lo >= kmin and _msd_bucket(hi - kmin, scale) <= 254))
+        if not ok and _DEPTH_TABLE == "auto" and not (status & 4):
+            _TABLE_MODE[key] = _TABLE_VIEWS   # equal buckets over a remembered range do not fit these views: level tables
+            return False                      # from here on (no back-off: the next attempt runs on the device's plan)
+        if status & 5:     # a depth cluster overflowed a bucket's LDS / the view's range is beyond 16-bit local sorts: every
+            _MSD_BACKOFF[key] = 64   # such call costs a repair, so back off
+        kmin, scale = assumed
         return status == 0 and (lo > hi or (lo >= kmin and _msd_bucket(hi - kmin, scale) <= 254))
     return _key_bits_needed(lo, hi) <= assumed
 
@@ -387,10 +423,12 @@ def _note_count(key, n: int, m: int) -> None:
 
 def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, cull_mode: int = 0,
               exact: bool = False, fused: Optional[bool] = None, tile_rects=None, depth_msd: Optional[bool] = None,
-              bin_tile: int = TILE_SIZE, quad_masks: Optional[bool] = None) -> TileBins:
+              bin_tile: int = TILE_SIZE, quad_masks: Optional[bool] = None, key_range: Optional[torch.Tensor] = None) -> TileBins:
     """Depth-order the gaussians, emit their tile records in that order, stable-sort the records by tile.
     -> TileBins(sorted_tile, sorted_gid, tile_offsets [n_tiles+1] i32).  ``sorted_tile`` holds 16-bit tile ids (an
     int16 tensor of uint16 bit patterns) on the fused path, int32 otherwise: read it through ``tile_ids``.
+    ``key_range``: the buffer ``project_fwd(key_range=...)`` filled for THIS view: the bucketed depth ordering then plans
+    its buckets from the view's own key range on the device (no remembered range, no repair when the views differ).
     ``bin_tile`` = 32 (fused path only, ``tile_rects`` from ``project_fwd(bin_tile=32)``): the records are binned into
     32 x 32 bins instead -- tile ids, ``tile_offsets`` and the record count are then those of the bin grid, and the
     compositor stages must be told (their ``bin_tile``).
@@ -436,7 +474,18 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
         if backoff:
             _MSD_BACKOFF[key] = backoff - 1
         use_msd = depth_msd if depth_msd is not None else (_DEPTH_MSD_DEFAULT and _MSD_MIN_N <= N <= _MSD_MAX_N and backoff == 0)
-        plan = _msd_plan(rng[0], rng[1]) if (rng is not None and cap is not None and use_msd) else None
+        plan = None
+        if cap is not None and use_msd:
+            left = _TABLE_MODE.get(key, 0)
+            if left > 0:
+                _TABLE_MODE[key] = left - 1
+            want_table = _DEPTH_TABLE == "1" or (_DEPTH_TABLE == "auto" and left > 0)
+            if want_table and key_range is not None:
+                plan = (0, 0, "device")     # the view's own depth table, built on the device
+            elif want_table and _DEPTH_TABLE == "auto":
+                plan = None                 # (equal buckets are known not to fit and the caller brought no key range: LSD)
+            elif rng is not None:
+                plan = _msd_plan(rng[0], rng[1])
         if plan is not None:
             key_bits = plan
             n_blocks = (cap + BIN_BLOCK - 1) // BIN_BLOCK
@@ -449,6 +498,7 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
             m_host[3] = 0
             slot = (m_host, m_event, token, guard)
             _call("gsa_depth_order", lib.gsa_depth_order_msd, N, _ptr(depth_keys), _ptr(tile_rects), plan[0], plan[1],
+                  _ptr(key_range) if len(plan) == 3 else None,
                   _ptr(order), _ptr(rects), _ptr(offsets), _ptr(block_owner), n_blocks, _ptr(ctl),
                   ctypes.c_void_p(m_host.data_ptr()), token, _ptr(dws), dws_bytes, st)
         else:

@@ -84,12 +84,16 @@ const char *gsa_error_string(int code);
  *          sort, for a compositor that is told so (bin_tile of gsa_tile_bin16 / gsa_tile_schedule / gsa_composite_*:
  *          the four tiles of a bin walk the bin's list; a wave re-tests every record against its 8 x 8 quadrant anyway).
  *          splat word 11, radii and tiles_touched always describe the 16 x 16 tiles.
+ *  key_range (ABI 7; optional, may be NULL; 16-byte aligned): 4 * ceil(n / 64) uint32 -- per wave of 64 consecutive
+ *          gaussians the (min, max) of the depth keys of its VISIBLE members ((0xFFFFFFFF, 0) when it has none) and the
+ *          keys of its members 0 and 32 (a sample; 0xFFFFFFFF if culled or beyond n); every entry is written.
+ *          gsa_depth_order_msd(key_range_dev) builds the view's depth table from them on the device.
  */
 int gsa_project_fwd(int n, const float *means, const float *quats, const float *scales,
                     const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
                     const float *viewmat, const float *intrin, int width, int height, int cull_mode,
                     float *splat, int32_t *radii, int32_t *tiles_touched, uint32_t *depth_keys,
-                    uint32_t *tile_rects, float *sh_aux, int bin_tile, gsa_stream_t stream);
+                    uint32_t *tile_rects, float *sh_aux, int bin_tile, uint32_t *key_range, gsa_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stage 2 (row a3.3): tile binning.  Replaces gsplat's isect_tiles + 64-bit radix sort +
@@ -159,13 +163,26 @@ int gsa_depth_order(int n, const uint32_t *depth_keys, const uint32_t *tile_rect
  * ctl_host (optional): four words of PINNED, device-mapped HOST memory (hipHostMalloc).  The last workgroup stores
  * ctl[0..2] there and then, released at system scope, word 3 = status | token << 8 (token < 2^24, chosen by the caller,
  * different from what the word holds): the caller polls word 3 for its token instead of queueing a 16-byte copy and an
- * event behind the kernel (on the bench step those cost a 4-us copy kernel and a 6-us bubble on the stream). */
+ * event behind the kernel (on the bench step those cost a 4-us copy kernel and a 6-us bubble on the stream).
+ * key_range_dev (ABI 7; optional, may be NULL; 16-byte aligned): the 4 * ceil(n / 64) words gsa_project_fwd left for THIS
+ * view.  key_min / scale are then ignored: the first launch builds the view's own DEPTH TABLE on the device -- the exact
+ * key range cut into <= 4096 aligned cells, the sample keys counted per cell, consecutive cells grouped into <= 255
+ * buckets of about equal key count and at most 65536 keys of width -- so the buckets fit the view at hand whatever views
+ * came before, and however unevenly depth is distributed (with 255 EQUAL buckets the diagonal cameras of the bench ring
+ * put 3.5 x the mean into one bucket, beyond the local sorts' capacity).  The order produced does not depend on the
+ * table (any monotone table gives the same order).  ctl[3] bit 2: the view's key range is wider than 250 x 65536 keys
+ * (about two octaves of depth); the caller repeats with gsa_depth_order. */
 size_t gsa_depth_order_msd_workspace_bytes(int n);
 int gsa_depth_order_msd_max_width(void);
+/* (diagnostics) where gsa_depth_order_msd(key_range_dev) leaves the view's depth table inside its workspace: byte offset from
+ * a 16-byte-aligned workspace base, and its size in uint32 -- bytes [0, 4096): bucket of every cell; words [1024, 1281):
+ * first cell of every bucket, then the end; words 1284..1287: first cell's index (key >> shift), shift, cells, flags. */
+size_t gsa_depth_order_msd_table_offset(int n);
+int gsa_depth_order_msd_table_words(void);
 int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint32_t *tile_rects, uint32_t key_min, uint32_t scale,
-                        uint32_t *order, uint32_t *rects, uint32_t *offsets, int32_t *block_owner, int n_blocks,
-                        uint32_t *ctl, uint32_t *ctl_host, uint32_t token, void *workspace, size_t workspace_bytes,
-                        gsa_stream_t stream);
+                        const uint32_t *key_range_dev, uint32_t *order, uint32_t *rects, uint32_t *offsets, int32_t *block_owner,
+                        int n_blocks, uint32_t *ctl, uint32_t *ctl_host, uint32_t token, void *workspace,
+                        size_t workspace_bytes, gsa_stream_t stream);
 int gsa_scan_tiles_sorted(int n, uint32_t *counts_offsets, int32_t *block_owner, int n_blocks, uint32_t *total,
                           void *workspace, size_t workspace_bytes, gsa_stream_t stream);
 int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offsets, const uint32_t *rects,

@@ -412,6 +412,31 @@ def test_camera_inside_cloud_gradients(gsa):
              bg=torch.tensor([0.0, 0.0, 0.0]))
 
 
+def test_project_fwd_leaves_the_views_depth_key_range(gsa):
+    """``project_fwd(key_range=...)``: per wave of 64 gaussians the extreme depth keys of its VISIBLE members (culled ones
+    carry 0xFFFFFFFF and do not count) and the keys of its members 0 and 32 (the sample the depth table is built from)."""
+    from gsplat_amd import scene, stages as S
+    W, H, N = 320, 200, 50_037
+    sc = _scene(N, seed=21)
+    d = {k: v.cuda().contiguous() for k, v in sc.items()}
+    d["means3D"][:500, 2] = -30.0                     # behind the camera: culled (the first seven waves entirely)
+    vm, K = scene.make_camera(0, 1).cuda(), scene.make_intrinsics(W, H).cuda()
+    kr = S.key_range_buffer(N, d["means3D"].device)
+    kr.fill_(7)                                       # (every pair is written)
+    splat, radii, tiles, keys = S.project_fwd(d["means3D"], d["rotations"], d["scales"], d["opacities"][:, 0].contiguous(),
+                                              d["shs"], 3, vm, K, W, H, 0, key_range=kr)
+    k = keys.long() & 0xFFFFFFFF
+    pad = torch.full((kr.shape[0] * 64 - N,), 0xFFFFFFFF, dtype=torch.long, device="cuda")
+    kw = torch.cat([k, pad]).view(-1, 64)
+    vis = kw != 0xFFFFFFFF
+    want_lo = torch.where(vis, kw, torch.full_like(kw, 0xFFFFFFFF)).amin(1)
+    want_hi = torch.where(vis, kw, torch.zeros_like(kw)).amax(1)
+    got = kr.long() & 0xFFFFFFFF
+    assert 0 < int(vis.sum()) < N and int((~vis.any(1)).sum()) >= 7
+    assert torch.equal(got[:, 0], want_lo) and torch.equal(got[:, 1], want_hi)
+    assert torch.equal(got[:, 2], kw[:, 0]) and torch.equal(got[:, 3], kw[:, 32])      # the sample: lanes 0 and 32
+
+
 def test_cull_modes_give_identical_images(gsa):
     """Exact ellipse culling only removes (tile, splat) pairs whose every pixel fails alpha >= 1/255."""
     from gsplat_amd import scene
@@ -1094,7 +1119,7 @@ def test_bucketed_depth_order_equals_lsd_sort(gsa, n, dist):
     # (the control words also go to a pinned host slot, written by the kernel itself and tagged with the caller's token)
     host = torch.zeros(4, dtype=torch.int32, pin_memory=True)
     token = 0xABCDE
-    check(lib.gsa_depth_order_msd(n, k32.data_ptr(), pairs.data_ptr(), plan[0], plan[1], o1.data_ptr(), r1.data_ptr(),
+    check(lib.gsa_depth_order_msd(n, k32.data_ptr(), pairs.data_ptr(), plan[0], plan[1], None, o1.data_ptr(), r1.data_ptr(),
                                   f1.data_ptr(), b1.data_ptr(), n_blocks, c1.data_ptr(), host.data_ptr(), token, ws.data_ptr(),
                                   ws.numel(), st),
           "gsa_depth_order_msd")
@@ -1107,6 +1132,83 @@ def test_bucketed_depth_order_equals_lsd_sort(gsa, n, dist):
     assert torch.equal(b1[:live_blocks], b0[:live_blocks])
     if m_true:
         assert int(b1[n_blocks]) == int(b0[n_blocks])
+    # the same through the view's own DEPTH TABLE, built on the device from what gsa_project_fwd leaves per wave of 64
+    # gaussians -- (min, max) of the visible keys and two of the keys (a sample): the order must not depend on the table
+    def per_wave(kk):
+        pad = torch.full(((-n) % 64,), 0xFFFFFFFF, dtype=torch.long)
+        kw = torch.cat([kk, pad]).view(-1, 64)
+        vis_w = kw != 0xFFFFFFFF
+        wlo = torch.where(vis_w, kw, torch.full_like(kw, 0xFFFFFFFF)).amin(1)
+        whi = torch.where(vis_w, kw, torch.zeros_like(kw)).amax(1)
+        out = torch.stack([wlo, whi, kw[:, 0], kw[:, 32]], dim=1)
+        return torch.where(out >= 2 ** 31, out - 2 ** 32, out).to(torch.int32).contiguous().cuda()
+
+    kr = per_wave(keys)
+    o2, r2, f2, b2, c2 = buffers()
+    check(lib.gsa_depth_order_msd(n, k32.data_ptr(), pairs.data_ptr(), 0, 0, kr.data_ptr(), o2.data_ptr(), r2.data_ptr(),
+                                  f2.data_ptr(), b2.data_ptr(), n_blocks, c2.data_ptr(), None, 0, ws.data_ptr(), ws.numel(), st),
+          "gsa_depth_order_msd(key_range_dev)")
+    torch.cuda.synchronize()
+    assert [int(x) & 0xFFFFFFFF for x in c2] == [m_true, lo, hi, 0]
+    assert torch.equal(o2[:n_vis], o0[:n_vis]) and torch.equal(r2[:n_vis], r0[:n_vis]) and torch.equal(f2[:n_vis], f0[:n_vis])
+    assert torch.equal(b2[:live_blocks], b0[:live_blocks])
+    if m_true:
+        assert int(b2[n_blocks]) == int(b0[n_blocks])
+
+
+def test_depth_table_levels_the_buckets(gsa):
+    """The table the bucketed ordering builds for a view (cells -> buckets, from the per-wave sample of keys): valid --
+    monotone, every bucket at most 65536 keys wide -- and LEVEL: on keys as unevenly distributed as the diagonal cameras of
+    the bench ring see them (3.5 x the mean in the fullest of 255 equal buckets, more than the local sorts hold) the fullest
+    bucket stays well inside the 8192-key capacity, and the ordering reports no overflow."""
+    from gsplat_amd import scene, stages as S
+    from gsplat_amd._lib import check, lib
+    N, W, H = 1_000_000, 1920, 1080
+    sc = scene.make_scene(N, seed=0, sh_degree=3)
+    d = {k: v.cuda().contiguous() for k, v in sc.items()}
+    K = scene.make_intrinsics(W, H).cuda()
+    for view in (1, 0):        # 45 degrees: the cube seen along a diagonal; 0: along an axis
+        vm = scene.make_camera(view, 8).cuda()
+        kr = S.key_range_buffer(N, d["means3D"].device)
+        splat, radii, tiles, keys, rects = S.project_fwd(d["means3D"], d["rotations"], d["scales"], d["opacities"][:, 0].contiguous(),
+                                                         d["shs"], 3, vm, K, W, H, 0, return_rects=True, bin_tile=32, key_range=kr)
+        st = S._stream()
+        bufs = [torch.empty(N, dtype=torch.int32, device="cuda") for _ in range(3)]
+        owner = torch.empty(2000, dtype=torch.int32, device="cuda")
+        ctl = torch.empty(4, dtype=torch.int32, device="cuda")
+        ws = torch.zeros(lib.gsa_depth_order_msd_workspace_bytes(N), dtype=torch.uint8, device="cuda")
+        check(lib.gsa_depth_order_msd(N, keys.data_ptr(), rects.data_ptr(), 0, 0, kr.data_ptr(), bufs[0].data_ptr(), bufs[1].data_ptr(),
+                                      bufs[2].data_ptr(), owner.data_ptr(), 1999, ctl.data_ptr(), None, 0, ws.data_ptr(), ws.numel(), st),
+              "gsa_depth_order_msd")
+        torch.cuda.synchronize()
+        assert int(ctl[3]) == 0, f"view {view}: status {int(ctl[3])}"
+        k = keys.long() & 0xFFFFFFFF
+        k = k[k != 0xFFFFFFFF]
+        lo, hi = int(k.min()), int(k.max())
+        assert (int(ctl[1]) & 0xFFFFFFFF, int(ctl[2]) & 0xFFFFFFFF) == (lo, hi)
+        # the order is the stable order by key
+        n_vis = k.numel()
+        ref = torch.sort(keys.long() & 0xFFFFFFFF, stable=True).indices
+        assert torch.equal(bufs[0][:n_vis].long(), ref[:n_vis])
+        # equal buckets for comparison (the host-side plan of r02)
+        a, scale = S._msd_plan(lo, hi)
+        fullest_equal = int(torch.bincount((((k - a) * scale) >> 32).clamp(max=254), minlength=255).max())
+        # the table the first launch built and stored inside the workspace
+        off = lib.gsa_depth_order_msd_table_offset(N)
+        tab = ws[off:off + 4 * lib.gsa_depth_order_msd_table_words()].view(torch.int32).cpu()
+        cells, shift, g0 = int(tab[1286]), int(tab[1285]), int(tab[1284]) & 0xFFFFFFFF
+        lut = tab[:1024].contiguous().view(torch.uint8)[:cells].long()
+        k = k.cpu()
+        cs = tab[1024:1024 + 257].long()
+        assert 0 < cells <= 4096 and (hi >> shift) - g0 + 1 == cells and lo >> shift == g0
+        assert int(lut[0]) == 0 and bool((lut[1:] >= lut[:-1]).all()) and int(lut.max()) <= 254
+        for v in range(int(lut.max()) + 1):
+            assert bool((lut[int(cs[v]):int(cs[v + 1])] == v).all()) and (int(cs[v + 1]) - int(cs[v])) << shift <= 65536, v
+        assert int(cs[int(lut.max()) + 1]) == cells
+        fullest = int(torch.bincount(lut[(k >> shift) - g0], minlength=255).max())
+        print(f"view {view}: {n_vis} visible keys, {cells} cells of 2^{shift} keys, {int(lut.max()) + 1} buckets; fullest bucket "
+              f"{fullest} (255 equal buckets: {fullest_equal}), mean {n_vis / 254:.0f}")
+        assert fullest < 0.8 * 8192 and fullest < 0.85 * fullest_equal
 
 
 def test_bucketed_depth_order_reports_what_it_cannot_do(gsa):
@@ -1126,17 +1228,58 @@ def test_bucketed_depth_order_reports_what_it_cannot_do(gsa):
     ctl = torch.empty(4, dtype=torch.int32, device="cuda")
     ws = torch.empty(lib.gsa_depth_order_msd_workspace_bytes(n), dtype=torch.uint8, device="cuda")
     plan = S._msd_plan(int(keys.min()), int(keys.max()))
-    check(lib.gsa_depth_order_msd(n, k32.data_ptr(), pairs.data_ptr(), plan[0], plan[1], out[0].data_ptr(), out[1].data_ptr(),
+    check(lib.gsa_depth_order_msd(n, k32.data_ptr(), pairs.data_ptr(), plan[0], plan[1], None, out[0].data_ptr(), out[1].data_ptr(),
                                   out[2].data_ptr(), owner.data_ptr(), 63, ctl.data_ptr(), None, 0, ws.data_ptr(), ws.numel(), st), "msd")
     assert int(ctl[3]) & 1, "bucket overflow must be reported"
     assert not S._note_keys(("t", 0), int(ctl[1]), int(ctl[2]), plan, int(ctl[3]))
     # keys below the assumed minimum: the measured range tells
     narrow = (0x40400000, 1 << 24)   # (buckets 256 keys wide from there)
-    check(lib.gsa_depth_order_msd(n, k32.data_ptr(), pairs.data_ptr(), narrow[0], narrow[1], out[0].data_ptr(), out[1].data_ptr(),
+    check(lib.gsa_depth_order_msd(n, k32.data_ptr(), pairs.data_ptr(), narrow[0], narrow[1], None, out[0].data_ptr(), out[1].data_ptr(),
                                   out[2].data_ptr(), owner.data_ptr(), 63, ctl.data_ptr(), None, 0, ws.data_ptr(), ws.numel(), st), "msd")
     assert not S._note_keys(("t", 1), int(ctl[1]), int(ctl[2]), narrow, int(ctl[3]))
+    # a device-planned ordering over a range beyond two octaves of depth says so (status bit 2) instead of mis-sorting silently
+    wide = torch.full(((n + 63) // 64, 4), -1, dtype=torch.int32)
+    wide[:, 1] = 0
+    wide[0, 0], wide[0, 1] = 0x3F000000, 0x42000000
+    wide = wide.cuda()
+    check(lib.gsa_depth_order_msd(n, k32.data_ptr(), pairs.data_ptr(), 0, 0, wide.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
+                                  out[2].data_ptr(), owner.data_ptr(), 63, ctl.data_ptr(), None, 0, ws.data_ptr(), ws.numel(), st), "msd")
+    assert int(ctl[3]) & 4 and not S._note_keys(("t", 2), int(ctl[1]), int(ctl[2]), (0, 0, "device"), int(ctl[3]))
+    S._MSD_BACKOFF.pop(("t", 2), None)
+    S._KEY_RANGE.pop(("t", 2), None)
     S._KEY_RANGE.pop(("t", 0), None)
     S._KEY_RANGE.pop(("t", 1), None)
+
+
+def test_views_equal_buckets_do_not_fit_move_the_shape_to_depth_tables(gsa):
+    """The bench ring at 1 M gaussians: the axis-aligned cameras fit 255 equal depth buckets (planned on the host from the
+    remembered key range: the fast path), the diagonal ones put 12.6 k keys into one bucket.  The first such view is
+    repaired once; from then on the shape's views run on their own device-built depth tables -- no repair, no LSD
+    fallback -- and the images are those of the exact (LSD) path."""
+    from gsplat_amd import scene, stages as S
+    N, W, H = 1_000_000, 1920, 1080
+    sc = scene.make_scene(N, seed=0, sh_degree=3)
+    d = {k: v.cuda().contiguous() for k, v in sc.items()}
+    K = scene.make_intrinsics(W, H).cuda()[None]
+    key = ("cuda", torch.cuda.current_device(), W, H, 0, S.bin_tile_for(W, H, 0))
+    for t in (S._CAPACITY, S._KEY_RANGE, S._MSD_BACKOFF, S._TABLE_MODE, S._MSD_STREAK):
+        t.pop(key, None)
+    for k in S.REPAIR_STATS:
+        S.REPAIR_STATS[k] = 0
+
+    def render(v):
+        with torch.no_grad():
+            r, a, meta = gsa.rasterization(d["means3D"], d["rotations"], d["scales"], d["opacities"][:, 0].contiguous(), d["shs"],
+                                           scene.make_camera(v, 8).cuda()[None], K, W, H, sh_degree=3)
+        return r
+
+    first = [render(v) for v in (0, 0, 2, 1)]        # first call (exact), host-planned, host-planned, the diagonal view: repaired
+    assert S.REPAIR_STATS["key_range_repairs"] == 1 and S._TABLE_MODE.get(key, 0) > 0, (S.REPAIR_STATS, S._TABLE_MODE)
+    again = [render(v) for v in (1, 0, 3, 2, 5, 4, 7, 6)]
+    assert S.REPAIR_STATS["key_range_repairs"] == 1 and S.REPAIR_STATS["capacity_misses"] <= 1, S.REPAIR_STATS
+    assert torch.equal(again[0], first[3]) and torch.equal(again[1], first[0]) and torch.equal(again[3], first[2])
+    for t in (S._CAPACITY, S._KEY_RANGE, S._MSD_BACKOFF, S._TABLE_MODE, S._MSD_STREAK):
+        t.pop(key, None)
 
 
 def test_depth_cluster_falls_back_to_the_lsd_path(gsa):
@@ -1158,7 +1301,7 @@ def test_depth_cluster_falls_back_to_the_lsd_path(gsa):
     radii = torch.ones(N, 2, dtype=torch.int32, device="cuda")
     k32 = keys.to(torch.int32).cuda()
     key = ("cuda", torch.cuda.current_device(), W, H, 0, 16)
-    for d in (S._CAPACITY, S._KEY_RANGE, S._MSD_BACKOFF):
+    for d in (S._CAPACITY, S._KEY_RANGE, S._MSD_BACKOFF, S._TABLE_MODE, S._MSD_STREAK):
         d.pop(key, None)
 
     def bins(**kw):
@@ -1190,5 +1333,5 @@ def test_depth_cluster_falls_back_to_the_lsd_path(gsa):
     third = bins()                                     # backed off: LSD on the bits the keys differ in
     assert not isinstance(third.key_bits, tuple) and third.finalize() == (m, True)
     assert torch.equal(third.sorted_gid, ref_gid) and torch.equal(third.tile_offsets, ref_off)
-    for d in (S._CAPACITY, S._KEY_RANGE, S._MSD_BACKOFF):
+    for d in (S._CAPACITY, S._KEY_RANGE, S._MSD_BACKOFF, S._TABLE_MODE, S._MSD_STREAK):
         d.pop(key, None)

@@ -32,7 +32,7 @@ st = S._stream()
 
 
 def msd():
-    check(lib.gsa_depth_order_msd(n, k32.data_ptr(), pairs.data_ptr(), plan[0], plan[1], bufs[0].data_ptr(), bufs[1].data_ptr(),
+    check(lib.gsa_depth_order_msd(n, k32.data_ptr(), pairs.data_ptr(), plan[0], plan[1], None, bufs[0].data_ptr(), bufs[1].data_ptr(),
                                   bufs[2].data_ptr(), owner.data_ptr(), n_blocks, ctl.data_ptr(), None, 0, ws_m.data_ptr(), ws_m.numel(), st), "msd")
 
 

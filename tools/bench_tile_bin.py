@@ -35,7 +35,7 @@ st = S._stream()
 vis = keys[~culled]
 plan = S._msd_plan(int(vis.min()), int(vis.max()))
 ws = torch.empty(lib.gsa_depth_order_msd_workspace_bytes(n), dtype=torch.uint8, device="cuda")
-check(lib.gsa_depth_order_msd(n, k32.data_ptr(), pairs.data_ptr(), plan[0], plan[1], order.data_ptr(), rects.data_ptr(),
+check(lib.gsa_depth_order_msd(n, k32.data_ptr(), pairs.data_ptr(), plan[0], plan[1], None, order.data_ptr(), rects.data_ptr(),
                               offsets.data_ptr(), owner.data_ptr(), n_blocks, ctl.data_ptr(), None, 0, ws.data_ptr(), ws.numel(), st), "msd")
 torch.cuda.synchronize()
 assert (int(ctl[0]), int(ctl[3])) == (m, 0)

@@ -14,3 +14,13 @@ python bench.py --workload C5 --no-cpu-baseline --steps 20 --warmup 3 --views 1 
 python tools/prof_summary.py $O/c5_prof/p_kernel_stats.csv > $O/c5_table.md
 kill $HB 2>/dev/null
 ls $O
+# sweep of views per step x streams (same box)
+for b in 1 2 4 8; do for s in 1 2 3; do
+  [ $b == 1 ] && [ $s != 1 ] && continue
+  python bench.py --no-cpu-baseline --views 1 --steps 50 --views-per-gpu $b --view-streams $s > $O/sweep_${b}_${s}.json 2>/dev/null
+  python - "$O/sweep_${b}_${s}.json" <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print(sys.argv[1].split('/')[-1], "ms/view", d["config"]["ms_per_view"], "single", d["single_view"]["ms"])
+PY
+done; done
