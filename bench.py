@@ -580,7 +580,7 @@ def main() -> None:
                                     "frac": round(total_bytes / (ms_per_view * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                                     "frac_single_view": round(total_bytes / (solo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
             "stage_ms": {k: round(v, 4) for k, v in sorted(per.items())},
-            "stage_launches": {k: round(v, 2) for k, v in sorted(launches.items())},
+            "stage_abi_calls": {k: round(v, 2) for k, v in sorted(launches.items())},   # (C-ABI calls per view; binning: 3 calls, 12 kernels)
             "stage_algorithmic_GBs": stage_gbs,
             # a stage priced above the HBM peak is not moving SURVEY's bytes (it avoids them: digest instead of SH rows,
             # bins instead of tiles, early-out) -- the contractual fraction then flatters; see roofline_measured

@@ -12,5 +12,5 @@ python - <<PY
 import json
 d=json.loads(open("$O/bench.json").read().strip().splitlines()[-1])
 print(d["value"], d["config"]["ms_per_view"], d["single_view"], d.get("rotating"))
-print(d["stage_ms"], d["stage_launches"])
+print(d["stage_ms"])
 PY
