@@ -387,6 +387,8 @@ def _note_keys(key, lo: int, hi: int, assumed, status: int = 0) -> bool:
         kmin, scale = assumed
         ok = status == 0 and (lo > hi or (lo >= kmin and _msd_bucket(hi - kmin, scale) <= 254))
         if not ok and _DEPTH_TABLE == "auto" and not (status & 4):
+            while len(_TABLE_MODE) >= _CAPACITY_MAX_KEYS and key not in _TABLE_MODE:
+                _TABLE_MODE.pop(next(iter(_TABLE_MODE)))
             _TABLE_MODE[key] = _TABLE_VIEWS   # equal buckets over a remembered range do not fit these views: level tables
             return False                      # from here on (no back-off: the next attempt runs on the device's plan)
         if status & 5:     # a depth cluster overflowed a bucket's LDS / the view's range is beyond 16-bit local sorts: every
