@@ -296,6 +296,14 @@ __device__ __forceinline__ unsigned sort_block_id() {
     return x * q + min(x, r) + (p >> 3);
 }
 
+// The same for a CAPACITY launch of which only the first `live` chunks hold items: XCD x owns the consecutive live chunks
+// [x q + min(x, r), ...) (live = 8 q + r), its surplus workgroups get none (0xFFFFFFFF) -- with sort_block_id over the
+// whole grid the live chunks of a launch 25 % above its count filled six XCDs beyond their wave slots and left two idle.
+__device__ __forceinline__ unsigned live_block_id(unsigned live) {
+    const unsigned p = blockIdx.x, q = live >> 3, r = live & 7u, x = p & 7u, i = p >> 3;
+    return i < q + (x < r ? 1u : 0u) ? x * q + min(x, r) + i : 0xFFFFFFFFu;
+}
+
 // ---- pass 1: per-block digit histogram, written digit-major: hist[d * nblocks + block] -------------
 // Plain per-lane LDS atomics: measured faster than aggregating same-digit lanes with ballots first (the LDS
 // resolves same-address adds of one instruction cheaply; the 8 ballots per key cost more than they save).
@@ -863,6 +871,20 @@ __device__ __forceinline__ uint4 emit_entry(uint32_t off, uint32_t rect, uint32_
     return make_uint4(off, rect, gid, __float_as_uint(__builtin_amdgcn_rcpf((float)wl)));
 }
 
+// (the histogram kernel of the direct path needs neither the gaussian index nor the stored reciprocal: 8-B entries leave
+// room for its per-bin counters at four workgroups per CU)
+__device__ __forceinline__ uint2 emit_entry_small(uint32_t off, uint32_t rect) { return make_uint2(off, rect); }
+__device__ __forceinline__ uint4 emit_widen(uint4 e) { return e; }
+__device__ __forceinline__ uint4 emit_widen(uint2 e) {
+    return make_uint4(e.x, e.y, 0u, __float_as_uint(__builtin_amdgcn_rcpf((float)max((int)(e.y >> 20), 1))));
+}
+__device__ __forceinline__ void emit_store_entry(uint4 *s_g, uint32_t i, uint32_t off, uint32_t rect, uint32_t gid) {
+    s_g[i] = emit_entry(off, rect, gid);
+}
+__device__ __forceinline__ void emit_store_entry(uint2 *s_g, uint32_t i, uint32_t off, uint32_t rect, uint32_t) {
+    s_g[i] = emit_entry_small(off, rect);
+}
+
 // The block's gaussians [k_lo, k_hi] (owner of its first slot .. last one that can start inside it) and the global loads
 // of the first kEmitStage of them (three per thread), ISSUED here and consumed in emit_owners: the caller puts its own
 // prologue (histogram columns, block scans) between the two, under the loads' latency.
@@ -896,9 +918,10 @@ __device__ __forceinline__ EmitLoads emit_owner_loads(const uint32_t *__restrict
 // s_g [kEmitStage]: the packed entries of the first kEmitStage gaussians of the block, read once (coalesced)
 // while their starts are marked; owners beyond (a block of gaussians with fewer than four records each) are looked
 // up in global memory.  want_gid: the histogram does not need the gaussian indices.
+template <typename ENTRY>
 __device__ __forceinline__ EmitBlock emit_owners(const EmitLoads &el, const uint32_t *__restrict__ offsets,
                                                   uint32_t m_total, uint32_t *__restrict__ s_own,
-                                                  uint4 *__restrict__ s_g, uint32_t *__restrict__ scratch, unsigned bid) {
+                                                  ENTRY *__restrict__ s_g, uint32_t *__restrict__ scratch, unsigned bid) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     EmitBlock eb;
     eb.slot0 = bid * (uint32_t)kSortChunk;
@@ -914,7 +937,7 @@ __device__ __forceinline__ EmitBlock emit_owners(const EmitLoads &el, const uint
         const int k = eb.k_lo + j * kSortThreads + t;
         if (k <= k_hi) {
             const uint32_t i = (uint32_t)(k - eb.k_lo);
-            s_g[i] = emit_entry(el.off[j], el.rect[j], el.gid[j]);
+            emit_store_entry(s_g, i, el.off[j], el.rect[j], el.gid[j]);
             const uint32_t o = el.off[j] - eb.slot0;   // (gaussians without records at the block's end start at slot_end)
             if (i > 0u && o < eb.live) atomicMax(&s_own[o], i);
         }
@@ -951,15 +974,15 @@ __device__ __forceinline__ EmitBlock emit_owners(const EmitLoads &el, const uint
 }
 
 // the record of block slot `slot` (< eb.live): tile id and gaussian index
-template <bool WANT_GID>
+template <bool WANT_GID, typename ENTRY>
 __device__ __forceinline__ void emit_record(const EmitBlock &eb, uint32_t slot, const uint32_t *__restrict__ s_own,
-                                            const uint4 *__restrict__ s_g, const uint32_t *__restrict__ offsets,
+                                            const ENTRY *__restrict__ s_g, const uint32_t *__restrict__ offsets,
                                             const uint32_t *__restrict__ rects, const uint32_t *__restrict__ order,
                                             int tile_w, uint32_t &tile, uint32_t &gid) {
     const uint32_t i = s_own[slot];
     uint4 e;
     if (i < (uint32_t)kEmitStage) {
-        e = s_g[i];
+        e = emit_widen(s_g[i]);
     } else {   // (a block of gaussians with fewer than ~5 records each: the tail is looked up in global memory)
         const int k = eb.k_lo + (int)i;
         e = emit_entry(offsets[k], rects[k], WANT_GID ? order[k] : 0u);
@@ -1099,6 +1122,247 @@ __global__ __launch_bounds__(kSortThreads) void emit_scatter_kernel(
         }
     }
     SORT_TRACE_MARK(5);   // output stores (issue)
+    SORT_TRACE_END(2);
+}
+
+// ---- direct binning: ONE generation pass places every record in its bin's list ---------------------------------------
+// Bin grids of at most kBinsDirect bins (the 60 x 34 bins of 32 x 32 pixels at 1920 x 1080).  The two-pass tile sort
+// above moves every record three times (generated into digit runs, read back for the second histogram, read and
+// scattered again) and then searches the sorted ids for the list boundaries.  Here the per-block histogram is over the
+// BIN ITSELF: emit_binhist leaves one dense row of counts per 4096-slot block (coalesced 8-KB rows), bin_colscan turns
+// the columns into exclusive prefixes in place and -- its last workgroup -- the column totals into tile_offsets, and
+// emit_place generates the records once more and stores each gaussian id straight at
+//   tile_offsets[bin] + (records of that bin in the blocks in front) + (rank among the block's records of the bin).
+// The stores are single words, but a bin's region is filled front to back by consecutive blocks, and consecutive
+// blocks run on ONE XCD (sort_block_id): the words of a line meet in that XCD's L2 and leave it as whole lines.
+constexpr int kBinsDirect = 2048;
+constexpr int kColSegs = 64, kColBins = 16, kColThreads = kColSegs * kColBins;
+#ifndef GSA_PLACE_XCD
+#define GSA_PLACE_XCD 1   // emit_binhist / emit_place: a workgroup's record block by sort_block_id (1) or by its index (0)
+#endif
+
+__global__ __launch_bounds__(kSortThreads) void emit_binhist_kernel(int n, const uint32_t *__restrict__ order,
+                                                                    const uint32_t *__restrict__ offsets,
+                                                                    const uint32_t *__restrict__ rects,
+                                                                    const int32_t *__restrict__ block_owner, int tile_w,
+                                                                    uint32_t m_cap, const uint32_t *__restrict__ m_dev,
+                                                                    int nblocks, int nb, int n_tiles,
+                                                                    uint32_t *__restrict__ mat,
+                                                                    uint32_t *__restrict__ done_counter) {
+    __shared__ uint32_t scratch[4];
+    __shared__ uint32_t h[kBinsDirect];
+    __shared__ __attribute__((aligned(16))) uint32_t s_own[kSortChunk];
+    __shared__ uint2 s_g[kEmitStage];
+    const uint32_t m_total = m_dev ? min(m_cap, *m_dev) : m_cap;
+    const unsigned live = (unsigned)(((uint64_t)m_total + kSortChunk - 1) / kSortChunk);
+    const unsigned bid = GSA_PLACE_XCD ? live_block_id(live) : blockIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *done_counter = 0u;   // (bin_colscan's arrival counter; it runs behind this kernel)
+    if (bid >= live) return;                                // (rows of blocks beyond the count are never read)
+#pragma unroll
+    for (int j = 0; j < kBinsDirect / kSortThreads; ++j) h[j * kSortThreads + threadIdx.x] = 0u;
+    const EmitLoads el = emit_owner_loads(offsets, rects, order, block_owner, nblocks, m_total, false, bid, n);
+    const EmitBlock eb = emit_owners(el, offsets, m_total, s_own, s_g, scratch, bid);   // (its barriers cover the zeroing)
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const uint32_t slot = r * kSortThreads + threadIdx.x;
+        if (slot < eb.live) {
+            uint32_t tile, gid = 0;
+            emit_record<false>(eb, slot, s_own, s_g, offsets, rects, order, tile_w, tile, gid);
+            atomicAdd(&h[min(tile, (uint32_t)n_tiles - 1u)], 1u);   // (clamped: after a reported ordering failure
+                                                                     // the rectangles may hold anything)
+        }
+    }
+    __syncthreads();
+    uint32_t *row = mat + (size_t)bid * nb;
+    for (int i = threadIdx.x; i < nb; i += kSortThreads) row[i] = h[i];
+}
+
+// columns of the [live blocks][nb] count matrix -> exclusive prefixes over the blocks, in place; bin totals; the
+// workgroup that arrives last scans the totals into tile_offsets[0 .. n_tiles].  Thread (segment s, bin j): the blocks
+// are cut into 64 segments, the 16 bins of a workgroup are 64 contiguous bytes of every row.
+// (The totals travel as agent-scope stores, the arrival is ONE relaxed agent-scope add per workgroup behind the storing
+// lane's s_waitcnt, and the last workgroup reads them with agent-scope loads: no __threadfence -- an agent-scope release
+// writes back the XCD's whole L2, and 128 of them made this kernel 79 us long.)
+__global__ __launch_bounds__(kColThreads) void bin_colscan_kernel(uint32_t m_cap, const uint32_t *__restrict__ m_dev, int nb,
+                                                                  int n_tiles, uint32_t *__restrict__ mat,
+                                                                  uint32_t *__restrict__ totals,
+                                                                  int32_t *__restrict__ tile_offsets,
+                                                                  uint32_t *__restrict__ done_counter) {
+    __shared__ uint32_t seg[kColSegs][kColBins];
+    __shared__ uint32_t scratch[kColThreads / 64 + 2];
+    __shared__ uint32_t s_last;
+    const int t = threadIdx.x, s = t / kColBins, j = t % kColBins;
+    const uint32_t m_total = m_dev ? min(m_cap, *m_dev) : m_cap;
+    const int live = (int)(((uint64_t)m_total + kSortChunk - 1) / kSortChunk);
+    const int seg_len = (live + kColSegs - 1) / kColSegs;
+    const int r0 = min(s * seg_len, live), r1 = min(r0 + seg_len, live);
+    const int bin = blockIdx.x * kColBins + j;                 // (< nb: the grid is nb / kColBins workgroups)
+    uint32_t *col = mat + bin;
+    constexpr int kKeep = 16;                                  // rows kept in registers between the two sweeps
+    uint32_t v[kKeep], sum = 0;
+#pragma unroll
+    for (int q = 0; q < kKeep; ++q) v[q] = r0 < r1 ? col[(size_t)min(r0 + q, r1 - 1) * nb] : 0u;   // (clamped: all in flight)
+#pragma unroll
+    for (int q = 0; q < kKeep; ++q) { v[q] = r0 + q < r1 ? v[q] : 0u; sum += v[q]; }
+    for (int r = r0 + kKeep; r < r1; ++r) sum += col[(size_t)r * nb];
+    seg[s][j] = sum;
+    __syncthreads();
+    uint32_t run = 0, all = 0;
+#pragma unroll 8
+    for (int q = 0; q < kColSegs; ++q) {
+        const uint32_t c = seg[q][j];
+        if (q < s) run += c;
+        all += c;
+    }
+#pragma unroll
+    for (int q = 0; q < kKeep; ++q) {
+        if (r0 + q < r1) col[(size_t)(r0 + q) * nb] = run;
+        run += v[q];
+    }
+    for (int r = r0 + kKeep; r < r1; ++r) {
+        const uint32_t c = col[(size_t)r * nb];
+        col[(size_t)r * nb] = run;
+        run += c;
+    }
+    if (t < kColBins) {   // (s == 0: the first 16 lanes of wave 0)
+        __hip_atomic_store(&totals[bin], all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t == 0)
+            s_last = __hip_atomic_fetch_add(done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // the last workgroup: exclusive scan of the nb (<= 2048) totals, two per thread
+    uint32_t a[2], mine = 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = 2 * t + q;
+        a[q] = i < nb ? __hip_atomic_load(&totals[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        mine += a[q];
+    }
+    const int lane = t & 63, wave = t >> 6;
+    const uint32_t inc = wave_incl_scan(mine, lane);
+    if (lane == 63) scratch[wave] = inc;
+    __syncthreads();
+    uint32_t off = 0;
+    for (int w = 0; w < wave; ++w) off += scratch[w];
+    uint32_t ex = off + inc - mine;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = 2 * t + q;
+        if (i <= n_tiles) tile_offsets[i] = (int32_t)ex;   // (bins at and beyond n_tiles hold no records: entry n_tiles is the count)
+        ex += a[q];
+    }
+    if (t == 0) *done_counter = 0u;
+}
+
+// rank of this lane's record among the wave's records of the same bin so far (wave_rank_round for 11-bit ids): the lanes
+// of a bin find one another through the peer word of the id's low 8 bits and three ballots over its high bits; the
+// counters are 16-bit (a wave ranks 1024 records per block)
+__device__ __forceinline__ uint32_t wave_rank_round_bins(unsigned long long *mask, uint16_t *cnt, uint32_t bin, bool valid,
+                                                         int lane) {
+    const unsigned long long bit = 1ull << lane;
+    const uint32_t d = bin & (kRadix - 1);
+    if (valid) atomicOr(&mask[d], bit);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const unsigned long long raw = valid ? mask[d] : 0ull;
+    unsigned long long peers = raw;
+#pragma unroll
+    for (int b = 8; b < 11; ++b) {
+        const bool set = (bin >> b) & 1u;
+        const unsigned long long bal = __ballot(valid && set);
+        peers &= set ? bal : ~bal;
+    }
+    const uint32_t below = __popcll(peers & (bit - 1ull));
+    const uint32_t seen = cnt[bin];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (valid && below == 0) cnt[bin] = (uint16_t)(seen + (uint32_t)__popcll(peers));
+    if (valid && (raw & (bit - 1ull)) == 0ull) mask[d] = 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return seen + below;
+}
+
+__global__ __launch_bounds__(kSortThreads) void emit_place_kernel(
+    int n, const uint32_t *__restrict__ order, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ rects,
+    const int32_t *__restrict__ block_owner, int tile_w, uint32_t m_cap, const uint32_t *__restrict__ m_dev,
+    uint16_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int nblocks, int nb, int n_tiles,
+    const uint32_t *__restrict__ mat, const int32_t *__restrict__ tile_offsets) {
+    __shared__ uint32_t scratch[4];
+    // two regions, each with two lives: the generation's (slot owners | staged gaussians) and the placement's (peer
+    // words + the bins' first slots | wave-private 16-bit bin counters)
+    __shared__ __attribute__((aligned(16))) uint32_t s_val[kSortChunk];
+    constexpr int kPoolWords = 4 * kEmitStage > 2 * kBinsDirect ? 4 * kEmitStage : 2 * kBinsDirect;
+    __shared__ __attribute__((aligned(16))) uint32_t s_pool[kPoolWords];
+    static_assert(kSortChunk >= 2 * 4 * kRadix + kBinsDirect, "peer words and bin bases share the owners' region");
+    uint4 *s_g = reinterpret_cast<uint4 *>(s_pool);
+    uint16_t(*wave_cnt)[kBinsDirect] = reinterpret_cast<uint16_t(*)[kBinsDirect]>(s_pool);
+    uint32_t *s_base = s_val + 2 * 4 * kRadix;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t m_total = m_dev ? min(m_cap, *m_dev) : m_cap;
+    const unsigned live = (unsigned)(((uint64_t)m_total + kSortChunk - 1) / kSortChunk);
+    const unsigned bid = GSA_PLACE_XCD ? live_block_id(live) : blockIdx.x;
+    if (bid >= live) return;
+    SORT_TRACE_BEGIN();
+    const EmitLoads el = emit_owner_loads(offsets, rects, order, block_owner, nblocks, m_total, true, bid, n);
+    // (first slot of every bin for this block: in flight under the generation)
+    uint32_t base_r[kBinsDirect / kSortThreads];
+    const uint32_t *row = mat + (size_t)bid * nb;
+#pragma unroll
+    for (int j = 0; j < kBinsDirect / kSortThreads; ++j) {
+        const int i = min(j * kSortThreads + t, nb - 1);
+        base_r[j] = row[i] + (uint32_t)tile_offsets[min(i, n_tiles)];
+    }
+    const EmitBlock eb = emit_owners(el, offsets, m_total, s_val, s_g, scratch, bid);
+    SORT_TRACE_MARK(0);   // loads + slot owners
+    const uint32_t wbase = wave * (kSortChunk / 4);
+    uint32_t k[kSortItems], v[kSortItems], rk[kSortItems];
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const uint32_t slot = wbase + r * 64 + lane;
+        k[r] = 0u; v[r] = 0u;
+        if (slot < eb.live) {
+            emit_record<true>(eb, slot, s_val, s_g, offsets, rects, order, tile_w, k[r], v[r]);
+            k[r] = min(k[r], (uint32_t)n_tiles - 1u);
+            v[r] = min(v[r], (uint32_t)n - 1u);   // (the compositor gathers splat rows by this id, unchecked)
+        }
+    }
+    __syncthreads();   // owners and staged data consumed: the regions start their second life
+    SORT_TRACE_MARK(1);   // record generation
+#pragma unroll
+    for (int w = 0; w < 4; ++w) reinterpret_cast<unsigned long long *>(s_val)[w * kRadix + t] = 0ull;
+#pragma unroll
+    for (int j = 0; j < kBinsDirect / kSortThreads; ++j) {
+        s_base[j * kSortThreads + t] = base_r[j];
+        reinterpret_cast<uint2 *>(s_pool)[j * kSortThreads + t] = make_uint2(0u, 0u);     // 4 x 2048 16-bit counters
+    }
+    __syncthreads();
+    uint16_t *cnt = wave_cnt[wave];
+    unsigned long long *mask = reinterpret_cast<unsigned long long *>(s_val) + wave * kRadix;
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) rk[r] = wave_rank_round_bins(mask, cnt, k[r], wbase + r * 64 + lane < eb.live, lane);
+    __syncthreads();
+    SORT_TRACE_MARK(2);   // bases to LDS + ranking
+#pragma unroll
+    for (int j = 0; j < kBinsDirect / kSortThreads; ++j) {   // per bin: first rank of each wave's records in the block
+        const int b = j * kSortThreads + t;
+        const uint32_t c0 = wave_cnt[0][b], c1 = wave_cnt[1][b], c2 = wave_cnt[2][b];
+        wave_cnt[0][b] = 0; wave_cnt[1][b] = (uint16_t)c0; wave_cnt[2][b] = (uint16_t)(c0 + c1);
+        wave_cnt[3][b] = (uint16_t)(c0 + c1 + c2);
+    }
+    __syncthreads();
+    SORT_TRACE_MARK(3);   // the waves' first ranks
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        if (wbase + r * 64 + lane < eb.live) {
+            const uint32_t pos = s_base[k[r]] + (uint32_t)cnt[k[r]] + rk[r];
+            if (pos < m_total) {   // (always, unless the depth ordering in front failed and reported it)
+                vals_out[pos] = v[r];
+                if (keys_out) keys_out[pos] = (uint16_t)k[r];
+            }
+        }
+    }
+    SORT_TRACE_MARK(4);   // stores (issue)
     SORT_TRACE_END(2);
 }
 
@@ -1695,6 +1959,29 @@ extern "C" int gsa_tile_bins_supported(int width, int height, int bin_tile) {
 
 extern "C" int gsa_tile_bin16_supported(int width, int height) { return gsa_tile_bins_supported(width, height, GSA_TILE_SIZE); }
 
+static int bin_columns(int n_tiles) { return ((n_tiles + 1 + 63) / 64) * 64; }   // columns of the direct path's count matrix
+
+// 1: gsa_tile_bin16 called without tile_tmp / gid_tmp takes the direct path for this grid (per-bin histograms)
+extern "C" int gsa_tile_bin16_direct(int width, int height, int bin_tile) {
+    if (!gsa_tile_bins_supported(width, height, bin_tile)) return 0;
+    if (bin_tile == 0) bin_tile = GSA_TILE_SIZE;
+    const int n_tiles = gsa_div_up(width, bin_tile) * gsa_div_up(height, bin_tile);
+    return n_tiles > kRadix && n_tiles + 1 <= kBinsDirect ? 1 : 0;
+}
+
+// workspace of gsa_tile_bin16 for either of its paths
+extern "C" size_t gsa_tile_bin16_workspace_bytes(int width, int height, int bin_tile, uint32_t m_capacity) {
+    size_t bytes = gsa_sort_workspace_bytes((int)min(m_capacity, 0x7FFFFFFFu));
+    if (gsa_tile_bin16_direct(width, height, bin_tile)) {
+        if (bin_tile == 0) bin_tile = GSA_TILE_SIZE;
+        const int n_tiles = gsa_div_up(width, bin_tile) * gsa_div_up(height, bin_tile);
+        const size_t nb = (size_t)bin_columns(n_tiles);
+        const size_t direct = ((size_t)sort_blocks((int)min(m_capacity, 0x7FFFFFFFu)) * nb + nb + 16) * sizeof(uint32_t);
+        if (direct > bytes) bytes = direct;
+    }
+    return bytes;
+}
+
 extern "C" int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offsets, const uint32_t *rects,
                               const int32_t *block_owner, int width, int height, int bin_tile, uint32_t m_capacity,
                               const uint32_t *m_dev, uint16_t *tile_tmp,
@@ -1714,10 +2001,30 @@ extern "C" int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offs
     if (n == 0 || m_capacity == 0) {   // no records: every tile's list is empty
         return (int)hipMemsetAsync(tile_offsets, 0, sizeof(int32_t) * ((size_t)n_tiles + 1), s);
     }
-    GSA_RETURN_IF(!order || !offsets || !rects || !block_owner || !sorted_tile || !sorted_gid || !workspace,
-                  GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(!order || !offsets || !rects || !block_owner || !sorted_gid || !workspace, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(workspace_bytes < gsa_sort_workspace_bytes((int)m_capacity), GSA_ERR_WORKSPACE_TOO_SMALL);
     const bool two = n_tiles > kRadix;   // tile ids above 8 bits: a second (high-digit) pass
+    // ... unless the caller brought no buffers for one (tile_tmp == gid_tmp == NULL) and the grid is small enough for a
+    // per-bin histogram in LDS: the direct path above (sorted_tile optional there: the lists are tile_offsets' alone)
+    if (two && !tile_tmp && !gid_tmp && n_tiles + 1 <= kBinsDirect) {
+        GSA_RETURN_IF(workspace_bytes < gsa_tile_bin16_workspace_bytes(width, height, bin_tile, m_capacity),
+                      GSA_ERR_WORKSPACE_TOO_SMALL);
+        const int nblocks = sort_blocks((int)m_capacity), nb = bin_columns(n_tiles);
+        uint32_t *mat = static_cast<uint32_t *>(workspace);
+        uint32_t *totals = mat + (size_t)nblocks * nb;
+        uint32_t *done_counter = totals + nb;
+        emit_binhist_kernel<<<nblocks, kSortThreads, 0, s>>>(n, order, offsets, rects, block_owner, tile_w, m_capacity, m_dev,
+                                                             nblocks, nb, n_tiles, mat, done_counter);
+        GSA_LAUNCH_CHECK();
+        bin_colscan_kernel<<<nb / kColBins, kColThreads, 0, s>>>(m_capacity, m_dev, nb, n_tiles, mat, totals, tile_offsets,
+                                                                  done_counter);
+        GSA_LAUNCH_CHECK();
+        emit_place_kernel<<<nblocks, kSortThreads, 0, s>>>(n, order, offsets, rects, block_owner, tile_w, m_capacity, m_dev,
+                                                           sorted_tile, sorted_gid, nblocks, nb, n_tiles, mat, tile_offsets);
+        GSA_LAUNCH_CHECK();
+        return GSA_OK;
+    }
+    GSA_RETURN_IF(!sorted_tile, GSA_ERR_INVALID_ARGUMENT);
     // Two passes split the id bits EVENLY (13 bits: 7 + 6, not 8 + 5): a block's 4096 records then leave the first
     // pass in 128 runs of ~32 (full 128-B lines of values) instead of 256 runs of ~16, and the second pass still writes
     // runs of 64+.

@@ -60,7 +60,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
         render, alpha, final_T, last_id = out[:4]
         quad_list, quad_count = out[4] if want_lists else (None, None)
         ctx.zeroed_records = out[4].zeroed if want_lists else None   # cleared by the forward kernel; used once
-        sorted_tile, sorted_gid, tile_offsets = bins.sorted_tile, bins.sorted_gid, bins.tile_offsets
+        sorted_tile, sorted_gid, tile_offsets = bins.sorted_tile_stored, bins.sorted_gid, bins.tile_offsets
 
         ctx.save_for_backward(means_c, quats_c, scales_c, opac_c, colors_c, view_c, K_c, bg_c, splat, radii,
                               sorted_gid, tile_offsets, final_T, last_id, tile_order, quad_list, quad_count, sh_aux)
@@ -264,7 +264,9 @@ def _isect_ids(per_cam, n_tiles: int) -> torch.Tensor:
     for c, pc in enumerate(per_cam):
         depth_bits = pc[0][:, 9].contiguous().view(torch.int32).long() & 0xFFFFFFFF
         gid = pc[4].long()
-        parts.append((c << (32 + tile_bits)) | (S.tile_ids(pc[3]) << 32) | depth_bits[gid])
+        # (the one-pass binning stores no tile ids: the lists' offsets say which records are whose)
+        tiles = S.tile_ids(pc[3]) if pc[3].numel() == gid.numel() else S.tile_ids_from_offsets(pc[5]).long()
+        parts.append((c << (32 + tile_bits)) | (tiles << 32) | depth_bits[gid])
     return torch.cat(parts)
 
 

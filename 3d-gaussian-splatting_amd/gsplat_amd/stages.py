@@ -278,11 +278,27 @@ class TileBins:
 
     @property
     def sorted_tile(self):
+        m = self.finalize()[0]
+        if self._tile is None:   # direct binning writes no ids: a list's records are those between its offsets
+            self._tile = tile_ids_from_offsets(self.tile_offsets)[:self.capacity]
+        return self._tile[:m]
+
+    @property
+    def sorted_tile_stored(self):
+        """The ids if the binning path wrote them, else an EMPTY tensor (no work: ``tile_ids_from_offsets`` rebuilds them)."""
+        if self._tile is None:
+            return torch.empty(0, dtype=torch.int16, device=self._gid.device)
         return self._tile[:self.finalize()[0]]
 
     @property
     def sorted_gid(self):
         return self._gid[:self.finalize()[0]]
+
+
+def tile_ids_from_offsets(tile_offsets: torch.Tensor) -> torch.Tensor:
+    """int32 tile id of every record of lists given by their offsets (``TileBins.sorted_tile`` of the direct binning)."""
+    counts = (tile_offsets[1:] - tile_offsets[:-1]).long()
+    return torch.repeat_interleave(torch.arange(counts.numel(), device=counts.device, dtype=torch.int32), counts)
 
 
 def tile_ids(sorted_tile: torch.Tensor) -> torch.Tensor:
@@ -292,6 +308,8 @@ def tile_ids(sorted_tile: torch.Tensor) -> torch.Tensor:
 
 
 _BIN_FUSED_DEFAULT = os.environ.get("GSPLAT_AMD_BIN_FUSED", "1") != "0"
+# GSPLAT_AMD_BIN_DIRECT=0: the two-pass tile sort where gsa_tile_bin16_direct offers the one-pass placement (A/B timing)
+_BIN_DIRECT = os.environ.get("GSPLAT_AMD_BIN_DIRECT", "1") != "0"
 # GSPLAT_AMD_QUAD_MASKS=1: per-record quadrant masks (gsa_quadrant_masks) for the forward compositor, which then gathers only
 # the records that can reach its quadrant.  OFF by default: measured at C3 the masked forward sweep is 0.025 ms faster
 # (0.152 -> 0.127 ms, 99.5 M -> 82.7 M vector instructions) but the mask pass costs 0.070 ms -- one random 64-B row fetch
@@ -543,12 +561,15 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
             block_owner = scan(cap)
     tile_offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
     if fused:
-        sorted_tile = torch.empty(cap, dtype=torch.int16, device=dev)       # uint16 tile ids (see tile_ids)
+        want_masks = bin_tile <= 2 * TILE_SIZE and (_QUAD_MASKS if quad_masks is None else quad_masks)
+        direct = _BIN_DIRECT and bool(lib.gsa_tile_bin16_direct(width, height, bin_tile))
+        # (direct placement: no 16-bit ids unless the mask pass wants them, no second-pass buffers)
+        sorted_tile = None if direct and not want_masks else torch.empty(cap, dtype=torch.int16, device=dev)   # uint16 tile ids (see tile_ids)
         sorted_gid = torch.empty(cap, dtype=torch.int32, device=dev)
-        two = n_tiles > 256   # (n_tiles: of the bin grid)
-        k_tmp = torch.empty(cap if two else 0, dtype=torch.int16, device=dev)
-        v_tmp = torch.empty(cap if two else 0, dtype=torch.int32, device=dev)
-        ws2_bytes = lib.gsa_sort_workspace_bytes(cap)
+        two = n_tiles > 256 and not direct   # (n_tiles: of the bin grid)
+        k_tmp = torch.empty(cap, dtype=torch.int16, device=dev) if two else None
+        v_tmp = torch.empty(cap, dtype=torch.int32, device=dev) if two else None
+        ws2_bytes = lib.gsa_tile_bin16_workspace_bytes(width, height, bin_tile, cap) if direct else lib.gsa_sort_workspace_bytes(cap)
         ws2 = torch.empty(ws2_bytes, dtype=torch.uint8, device=dev)
         _call("gsa_tile_bin16", lib.gsa_tile_bin16, N, _ptr(order), _ptr(offsets), _ptr(rects), _ptr(block_owner), width,
               height, bin_tile, cap,
@@ -556,7 +577,7 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
               ws2_bytes, st)
         sorted_mask = None
         # (optional: what a forward-compositor wave tests before it gathers a record; see _QUAD_MASKS)
-        if bin_tile <= 2 * TILE_SIZE and (_QUAD_MASKS if quad_masks is None else quad_masks):
+        if want_masks:
             sorted_mask = torch.empty(cap, dtype=torch.int16, device=dev)
             _call("gsa_quadrant_masks", lib.gsa_quadrant_masks, cap, _ptr(total), _ptr(sorted_tile), _ptr(sorted_gid),
                   _ptr(splat), N, width, height, bin_tile, _ptr(sorted_mask), st)

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSA_ABI_VERSION 7
+#define GSA_ABI_VERSION 8
 #define GSA_SPLAT_STRIDE 16
 
 #define GSA_OK 0
@@ -124,9 +124,17 @@ int gsa_scan_tiles(int n, const int32_t *tiles_touched, const uint32_t *order, u
  * (as uint16), sorted_gid, tile_offsets[n_tiles + 1] -- without ever writing the records in emission order: the
  * first pass of the tile sort generates them from the rectangles.  m_dev: live record count on the device (NULL:
  * m_capacity is the count); block_owner: from a scan with n_blocks == ceil(m_capacity / GSA_BIN_BLOCK); tile_tmp / gid_tmp:
- * m_capacity elements each (unused for at most 256 tiles); workspace: gsa_sort_workspace_bytes(m_capacity). */
+ * m_capacity elements each (unused for at most 256 tiles); workspace: gsa_sort_workspace_bytes(m_capacity).
+ * ABI 8 -- the direct path.  For grids of 257 .. 2047 tiles / bins (gsa_tile_bin16_direct: the 60 x 34 bins of 32 x 32
+ * pixels at 1920 x 1080) a caller that passes tile_tmp == gid_tmp == NULL and a workspace of
+ * gsa_tile_bin16_workspace_bytes gets the lists from ONE placement pass: a per-block histogram over the bins
+ * themselves, a column scan that also writes tile_offsets, and every gaussian id stored straight at its place in its
+ * bin's list (no digit passes, no search for the list boundaries).  sorted_tile may then be NULL (not written): the
+ * lists are sorted_gid + tile_offsets.  Same output, bit for bit, as the two-pass path. */
 #define GSA_BIN_BLOCK 4096
 int gsa_tile_bin16_supported(int width, int height);
+int gsa_tile_bin16_direct(int width, int height, int bin_tile);
+size_t gsa_tile_bin16_workspace_bytes(int width, int height, int bin_tile, uint32_t m_capacity);
 /* ... for bins of bin_tile pixels (16 / 32 / 64): an 8K image has too many 16 x 16 tiles for 16-bit ids, but not 32 x 32 bins */
 int gsa_tile_bins_supported(int width, int height, int bin_tile);
 int gsa_scan_tiles_rect(int n, const uint32_t *order, const uint32_t *tile_rects, uint32_t *offsets,

@@ -926,11 +926,13 @@ def test_backward_sweep_over_blended_record_lists(gsa, W, H, N, cull_mode, chann
 
 
 @pytest.mark.parametrize("W,H,N,s_max,giants", [(640, 360, 30_000, 0.05, 0), (160, 96, 4000, 0.3, 0),
-                                                 (1920, 1080, 50_000, 0.02, 5), (40, 24, 500, 0.5, 0)])
+                                                 (1920, 1080, 50_000, 0.02, 5), (40, 24, 500, 0.5, 0),
+                                                 (800, 592, 60_000, 0.03, 4)])
 def test_fused_binning_equals_emit_and_sort(gsa, W, H, N, s_max, giants):
     """gsa_scan_tiles_rect + gsa_tile_bin16 (records generated inside the first tile-sort pass, 16-bit tile ids) ==
     gsa_tile_emit + gsa_sort_pairs_u32 + gsa_tile_offsets, bit for bit: tile ids, gaussian ids, tile offsets.
-    Covers one- and two-digit tile grids, gaussians without records between ones that have some (the off-screen
+    Covers one- and two-digit tile grids and the grids in between that take the ONE-PASS placement (gsa_tile_bin16_direct:
+    920 and 1850 tiles here), gaussians without records between ones that have some (the off-screen
     5 %), and a remembered capacity smaller than the record count (reported by finalize(); the caller re-runs)."""
     from gsplat_amd import scene, stages as S
     sc = _scene(N, seed=21, s_min=0.002, s_max=s_max)
@@ -942,11 +944,15 @@ def test_fused_binning_equals_emit_and_sort(gsa, W, H, N, s_max, giants):
     splat, radii, tiles, keys = S.project_fwd(d["means3D"], d["rotations"], d["scales"], d["opacities"][:, 0].contiguous(),
                                               d["shs"], 3, vm, K, W, H, 0)
     assert int((tiles == 0).sum()) > 0 and int((tiles > 0).sum()) > 0
+    grid = S.tile_grid(W, H)[0] * S.tile_grid(W, H)[1]
+    direct = bool(gsa.lib.gsa_tile_bin16_direct(W, H, 16))
+    assert direct == (256 < grid < 2048)
     if giants:
-        assert int(tiles.max()) == S.tile_grid(W, H)[0] * S.tile_grid(W, H)[1] > S.BIN_BLOCK   # the whole grid
+        assert int(tiles.max()) == grid and (direct or grid > S.BIN_BLOCK)   # the whole grid
     a = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, fused=False)
     b = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, fused=True)
-    assert b.sorted_tile.dtype == torch.int16 and a.sorted_tile.dtype == torch.int32
+    assert (b._tile is None) == direct                 # (the one-pass placement stores no ids: the offsets imply them)
+    assert b.sorted_tile.dtype == (torch.int32 if direct else torch.int16) and a.sorted_tile.dtype == torch.int32
     m = a.finalize()[0]
     assert m == b.finalize()[0] == int(tiles.sum()) and m > 0
     assert torch.equal(S.tile_ids(b.sorted_tile), S.tile_ids(a.sorted_tile))
@@ -965,6 +971,44 @@ def test_fused_binning_equals_emit_and_sort(gsa, W, H, N, s_max, giants):
     assert t.finalize() == (m, False) and int(t.tile_offsets.max()) <= t.capacity
     e = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, fused=True)
     assert torch.equal(e.sorted_gid, a.sorted_gid) and torch.equal(e.tile_offsets, a.tile_offsets)
+
+
+@pytest.mark.parametrize("N,W,H,bt", [(200_000, 1920, 1080, 32), (1_250_000, 1920, 1080, 32), (30_000, 640, 480, 16)])
+def test_one_pass_placement_equals_the_two_pass_tile_sort(gsa, N, W, H, bt):
+    """gsa_tile_bin16 without second-pass buffers (per-bin histogram rows, column scan, every id stored at its final
+    place) == the two-pass tile sort + boundary search: sorted_gid and tile_offsets bit for bit, at the bench's bin grid
+    (2040 bins; 170 and ~1100 record blocks: one and several rows per column-scan segment, beyond the rows a thread keeps
+    in registers) and on 16 x 16 tiles; with ids on request (what gsa_quadrant_masks reads) and with a remembered
+    capacity above the count."""
+    from gsplat_amd import scene, stages as S
+    sc = scene.make_scene(N, seed=5, sh_degree=0)
+    vm, K = scene.make_camera(1, 4).cuda(), scene.make_intrinsics(W, H).cuda()
+    d = {k: v.cuda().contiguous() for k, v in sc.items()}
+    out = S.project_fwd(d["means3D"], d["rotations"], d["scales"], d["opacities"][:, 0].contiguous(), d["shs"], 0, vm, K,
+                        W, H, 0, return_rects=True, bin_tile=bt)
+    splat, radii, tiles, keys, rects = out[:5]
+    assert gsa.lib.gsa_tile_bin16_direct(W, H, bt) == 1
+    res = {}
+    for direct in (False, True):
+        real = S._BIN_DIRECT
+        S._BIN_DIRECT = direct
+        try:
+            # (depth_msd=False: the LSD ordering -- 1.25 M gaussians overflow the bucketed one's LDS, which is another test's subject)
+            res[direct] = [S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=e, fused=True, tile_rects=rects, bin_tile=bt,
+                                       quad_masks=q, depth_msd=False)
+                           for e, q in ((True, False), (False, False), (False, bt == 32))]
+        finally:
+            S._BIN_DIRECT = real
+    m = res[False][0].finalize()[0]
+    assert m > (4_300_000 if N > 1_000_000 else 50_000)
+    assert res[True][0]._tile is None and (res[True][2]._tile is not None) == (bt == 32)   # ids only on request
+    for a, b in zip(res[False], res[True]):
+        assert b.finalize() == (m, True) == a.finalize()
+        assert torch.equal(b.tile_offsets, a.tile_offsets) and int(b.tile_offsets[-1]) == m
+        assert torch.equal(b.sorted_gid, a.sorted_gid)
+        assert torch.equal(S.tile_ids(b.sorted_tile), S.tile_ids(a.sorted_tile))
+    if bt == 32:
+        assert torch.equal(res[True][2].sorted_mask[:m], res[False][2].sorted_mask[:m])
 
 
 @pytest.mark.parametrize("deg", [3, 1])

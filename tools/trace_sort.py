@@ -26,7 +26,9 @@ torch.cuda.synchronize(); step(); torch.cuda.synchronize()
 tr = buf.cpu().numpy().reshape(NK, 32768, 16)
 names = {0: ("radix_scatter<u32> (last call)", ["prologue", "ranking", "reorder", "stores"]),
          1: ("radix_scatter<u16>", ["prologue", "ranking", "reorder", "stores"]),
-         2: ("emit_scatter", ["hist columns", "owners", "generation", "ranking", "reorder", "stores"]),
+         2: (("emit_place", ["loads + owners", "generation", "bases + ranking", "wave ranks", "stores"])
+             if os.environ.get("GSPLAT_AMD_BIN_DIRECT", "1") != "0" else
+             ("emit_scatter", ["hist columns", "owners", "generation", "ranking", "reorder", "stores"])),
          3: ("depth_bucket_sort", ["bounds + loads", "local passes", "gathers", "count scan", "wait in front", "offsets"])}
 for k, (name, phases) in names.items():
     d = tr[k]; d = d[d[:, 1] > 0]
@@ -37,5 +39,9 @@ for k, (name, phases) in names.items():
     acc = d[:, 2:2 + len(phases)] / 100.0
     print(f"== {name}: {len(d)} workgroups, span {span:.1f} us, mean WG time {dur.mean():.2f} us (p90 {np.percentile(dur, 90):.2f}), "
           f"avg concurrent {dur.sum() / span:.0f}")
+    st = (t0 - t0.min()) / 100.0
+    print(f"   WG start after the first, us: p10 {np.percentile(st, 10):.1f} p50 {np.percentile(st, 50):.1f} p90 {np.percentile(st, 90):.1f} "
+          f"max {st.max():.1f}; duration of the earliest / latest tenth: {dur[st <= np.percentile(st, 10)].mean():.1f} / "
+          f"{dur[st >= np.percentile(st, 90)].mean():.1f}")
     print("   phases, us per WG: " + ", ".join(f"{p} {acc[:, i].mean():.2f}" for i, p in enumerate(phases))
           + f"; tail (stores drain) {(dur - acc.sum(1)).mean():.2f}")
