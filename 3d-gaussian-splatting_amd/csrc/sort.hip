@@ -1136,7 +1136,10 @@ __global__ __launch_bounds__(kSortThreads) void emit_scatter_kernel(
 // The stores are single words, but a bin's region is filled front to back by consecutive blocks, and consecutive
 // blocks run on ONE XCD (sort_block_id): the words of a line meet in that XCD's L2 and leave it as whole lines.
 constexpr int kBinsDirect = 2048;
-constexpr int kColSegs = 64, kColBins = 16, kColThreads = kColSegs * kColBins;
+#ifndef GSA_COL_BINS
+#define GSA_COL_BINS 32   // bins (128 contiguous bytes of every row) per workgroup of bin_colscan: 8 -> 15.8 us, 16 -> 10.5, 32 -> 8.8, 64 -> 30.5 (32 workgroups)
+#endif
+constexpr int kColBins = GSA_COL_BINS, kColSegs = 1024 / kColBins, kColThreads = kColSegs * kColBins;
 #ifndef GSA_PLACE_XCD
 #define GSA_PLACE_XCD 1   // emit_binhist / emit_place: a workgroup's record block by sort_block_id (1) or by its index (0)
 #endif
@@ -1179,7 +1182,7 @@ __global__ __launch_bounds__(kSortThreads) void emit_binhist_kernel(int n, const
 
 // columns of the [live blocks][nb] count matrix -> exclusive prefixes over the blocks, in place; bin totals; the
 // workgroup that arrives last scans the totals into tile_offsets[0 .. n_tiles].  Thread (segment s, bin j): the blocks
-// are cut into 64 segments, the 16 bins of a workgroup are 64 contiguous bytes of every row.
+// are cut into kColSegs segments, the kColBins bins of a workgroup are contiguous bytes of every row.
 // (The totals travel as agent-scope stores, the arrival is ONE relaxed agent-scope add per workgroup behind the storing
 // lane's s_waitcnt, and the last workgroup reads them with agent-scope loads: no __threadfence -- an agent-scope release
 // writes back the XCD's whole L2, and 128 of them made this kernel 79 us long.)
@@ -1198,7 +1201,7 @@ __global__ __launch_bounds__(kColThreads) void bin_colscan_kernel(uint32_t m_cap
     const int r0 = min(s * seg_len, live), r1 = min(r0 + seg_len, live);
     const int bin = blockIdx.x * kColBins + j;                 // (< nb: the grid is nb / kColBins workgroups)
     uint32_t *col = mat + bin;
-    constexpr int kKeep = 16;                                  // rows kept in registers between the two sweeps
+    constexpr int kKeep = kColBins;                            // rows kept in registers between the two sweeps (all of them at the bench: 883 blocks)
     uint32_t v[kKeep], sum = 0;
 #pragma unroll
     for (int q = 0; q < kKeep; ++q) v[q] = r0 < r1 ? col[(size_t)min(r0 + q, r1 - 1) * nb] : 0u;   // (clamped: all in flight)
@@ -1224,7 +1227,7 @@ __global__ __launch_bounds__(kColThreads) void bin_colscan_kernel(uint32_t m_cap
         col[(size_t)r * nb] = run;
         run += c;
     }
-    if (t < kColBins) {   // (s == 0: the first 16 lanes of wave 0)
+    if (t < kColBins) {   // (s == 0: lanes of wave 0)
         __hip_atomic_store(&totals[bin], all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (t == 0)
@@ -1634,12 +1637,12 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
     __shared__ uint32_t s_bucket;
     const int t = threadIdx.x;
     SORT_TRACE_BEGIN();
+    const uint32_t dt = t < kRadix ? digit_total[t] : 0u;   // (in flight beside the ticket, not behind its barrier)
     if (t == 0) s_bucket = atomicAdd(ticket, 1u);
     __syncthreads();
     const int d = (int)s_bucket;                       // this block's bucket, in order of arrival
     // bucket d = items [lo, lo + m) of the first pass's output
     uint32_t all;
-    const uint32_t dt = t < kRadix ? digit_total[t] : 0u;
     const uint32_t lo_t = block1024_excl_scan(dt, L.scratch, all);   // (thread t: start of bucket t)
     if (t == d) { L.dbase[0] = lo_t; L.dbase[1] = dt; }
     __syncthreads();

@@ -1009,6 +1009,12 @@ def test_one_pass_placement_equals_the_two_pass_tile_sort(gsa, N, W, H, bt):
         assert torch.equal(S.tile_ids(b.sorted_tile), S.tile_ids(a.sorted_tile))
     if bt == 32:
         assert torch.equal(res[True][2].sorted_mask[:m], res[False][2].sorted_mask[:m])
+    # a view without a single record, queued for the remembered capacity: every list is empty
+    none = rects.clone()
+    none[:, 1] = 0
+    e = S.bin_tiles(splat, radii, torch.zeros_like(tiles), keys, W, H, 0, fused=True, tile_rects=none, bin_tile=bt,
+                    depth_msd=False)
+    assert e.capacity >= m and e.finalize() == (0, True) and int(e.tile_offsets.abs().max()) == 0
 
 
 @pytest.mark.parametrize("deg", [3, 1])
