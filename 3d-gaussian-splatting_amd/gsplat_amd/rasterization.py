@@ -8,6 +8,7 @@ One ``torch.autograd.Function`` per camera chains the C-ABI stages (``stages.py`
 
 from __future__ import annotations
 
+import contextlib
 import math
 from typing import Dict, Optional, Tuple
 
@@ -27,7 +28,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, colors, viewmat, Kmat, background,
                 width: int, height: int, sh_degree: int, channels: int, cull_mode: int, grad_out, grad_accumulate,
-                sh_grad_factored):
+                sh_grad_factored, front_stream=None, deferred=None):
         means_c, quats_c, scales_c = S.f32c(means, "means"), S.f32c(quats, "quats"), S.f32c(scales, "scales")
         opac_c, colors_c = S.f32c(opacities, "opacities"), S.f32c(colors, "colors")
         view_c, K_c = S.f32c(viewmat, "viewmats"), S.f32c(Kmat, "Ks")
@@ -39,19 +40,38 @@ class _RasterizeOneCamera(torch.autograd.Function):
         # the records are binned into 32 x 32 BINS where the fused binning applies (S.bin_tile_for): the four 16 x 16
         # tiles of a bin walk the bin's list -- a compositor wave re-tests every record against its 8 x 8 quadrant anyway
         bt = S.bin_tile_for(width, height, cull_mode)
-        kr = S.key_range_buffer(means_c.shape[0], means_c.device)   # this view's depth-key range, for the depth ordering's bucket plan
-        proj = S.project_fwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
-                             cull_mode, return_rects=True, return_aux=want_lists, bin_tile=bt, key_range=kr)
-        splat, radii, tiles_touched, depth_keys, rects = proj[:5]
-        sh_aux = proj[5] if want_lists else None
-        # the host does not wait for the record count: bins are sized for a remembered capacity, the compositor is
-        # queued, and only then is the count (long since copied back) checked -- a miss repeats with exact sizes
-        bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, tile_rects=rects,
-                           bin_tile=bt, key_range=kr)
-        tile_order = S.tile_schedule(bins.tile_offsets, width, height, bt)   # longest record lists first (speed only)
+        # The FRONT END (projection, depth ordering, binning: HBM- and latency-bound) may be queued on a stream of its own,
+        # where it runs beside the sweeps of the view in front (vector-issue-bound) instead of behind them; the sweeps stay
+        # on the current stream and wait for it.  Its buffers are allocated under that stream and handed over by
+        # record_stream.
+        main = torch.cuda.current_stream() if front_stream is not None else None
+        with (torch.cuda.stream(front_stream) if front_stream is not None else contextlib.nullcontext()):
+            kr = S.key_range_buffer(means_c.shape[0], means_c.device)   # this view's depth-key range, for the depth ordering's bucket plan
+            proj = S.project_fwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
+                                 cull_mode, return_rects=True, return_aux=want_lists, bin_tile=bt, key_range=kr)
+            splat, radii, tiles_touched, depth_keys, rects = proj[:5]
+            sh_aux = proj[5] if want_lists else None
+            # the host does not wait for the record count: bins are sized for a remembered capacity, the compositor is
+            # queued, and only then is the count (long since copied back) checked -- a miss repeats with exact sizes
+            bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, tile_rects=rects,
+                               bin_tile=bt, key_range=kr)
+            tile_order = S.tile_schedule(bins.tile_offsets, width, height, bt)   # longest record lists first (speed only)
+            if front_stream is not None:
+                handed = torch.cuda.Event()
+                handed.record(front_stream)
+        if front_stream is not None:
+            main.wait_event(handed)
+            for t in (splat, radii, tiles_touched, depth_keys, rects, sh_aux, bins.sorted_gid_buffer, bins.tile_offsets,
+                      bins.sorted_mask, bins._tile, tile_order):
+                if t is not None:
+                    t.record_stream(main)
         out = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg_c, width, height, channels,
                               tile_order, want_lists=want_lists, bin_tile=bt, sorted_mask=bins.sorted_mask)
-        if not bins.finalize()[1]:
+        if deferred is not None:
+            # the caller checks the speculation (record capacity, depth-key range) later, for several views at once
+            # (meta['speculation_ok']): the host does not wait here for this view's control words and runs ahead
+            deferred.append(bins)
+        elif not bins.finalize()[1]:
             bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, exact=True,
                                tile_rects=rects, bin_tile=bt)
             tile_order = S.tile_schedule(bins.tile_offsets, width, height, bt)
@@ -60,7 +80,11 @@ class _RasterizeOneCamera(torch.autograd.Function):
         render, alpha, final_T, last_id = out[:4]
         quad_list, quad_count = out[4] if want_lists else (None, None)
         ctx.zeroed_records = out[4].zeroed if want_lists else None   # cleared by the forward kernel; used once
-        sorted_tile, sorted_gid, tile_offsets = bins.sorted_tile_stored, bins.sorted_gid, bins.tile_offsets
+        if deferred is not None:   # (capacity-sized: rasterization() cuts them to the record count when somebody looks)
+            sorted_tile = bins._tile if bins._tile is not None else torch.empty(0, dtype=torch.int16, device=splat.device)
+            sorted_gid, tile_offsets = bins.sorted_gid_buffer, bins.tile_offsets
+        else:
+            sorted_tile, sorted_gid, tile_offsets = bins.sorted_tile_stored, bins.sorted_gid, bins.tile_offsets
 
         ctx.save_for_backward(means_c, quats_c, scales_c, opac_c, colors_c, view_c, K_c, bg_c, splat, radii,
                               sorted_gid, tile_offsets, final_T, last_id, tile_order, quad_list, quad_count, sh_aux)
@@ -95,10 +119,10 @@ class _RasterizeOneCamera(torch.autograd.Function):
                               splat, radii, v_splat, out=ctx.grad_out, accumulate=ctx.grad_accumulate,
                               v_rgb_out=ctx.sh_grad_factored, sh_aux=sh_aux)
         if ctx.grad_accumulate:   # the sums live in the caller's buffers; autograd gets nothing to accumulate
-            return (None,) * 16
+            return (None,) * 18
         need = ctx.needs_input_grad
         grads = tuple(g.view(shp) if (nd and g is not None) else None for g, shp, nd in zip(grads, ctx.in_shapes, need[:5]))
-        return grads + (None,) * 11
+        return grads + (None,) * 13
 
 
 def rasterization(
@@ -124,6 +148,8 @@ def rasterization(
     grad_out=None,
     grad_accumulate: bool = False,
     sh_grad_factored: Optional[torch.Tensor] = None,
+    front_stream: Optional[torch.cuda.Stream] = None,
+    defer_check: bool = False,
     **unsupported,
 ) -> Tuple[torch.Tensor, torch.Tensor, Dict]:
     """Returns ``(renders [C,H,W,D], alphas [C,H,W,1], meta)``; ``meta['means2d']`` [C,N,2] and
@@ -140,6 +166,18 @@ def rasterization(
     gaussian instead of the [N,K,3] SH-coefficient gradient (``colors`` then gets no gradient; ``grad_out[4]`` is not
     written).  The coefficient gradient is the outer product of the view's SH basis with it
     (``stages.sh_grad_expand``): the form in which view-parallel ranks exchange it -- 3 floats instead of 48.
+    ``front_stream`` (extension): a HIP stream for the view's FRONT END -- projection, depth ordering, binning; HBM- and
+    latency-bound -- while the sweeps (and the backward pass) stay on the current stream and wait for it.  Queued on a
+    stream of its own it runs beside the sweeps of the view in front, which are vector-issue-bound, instead of behind
+    them.  The caller orders that stream after whatever last wrote the inputs (``front_stream.wait_event(...)`` after an
+    optimizer step; nothing for further views of the same parameters) -- the call itself only makes the current
+    stream wait for the front end.
+    ``defer_check`` (extension): the bins are sized for a remembered record capacity and the depth ordering assumes a
+    remembered key range; by default the call waits (host side) for the view's control words once its sweep is queued and
+    repeats the binning if either was too small, so what it returns is always right.  With ``defer_check=True`` it does
+    not wait: the host queues view after view, far ahead of the device, and the CALLER asks ``meta['speculation_ok']``
+    -- a bool, waiting for the control words only then -- before it trusts the view (image, gradients), and renders it
+    again (without ``defer_check``) if it is False.  A training loop asks once per step, in front of the optimizer.
     """
     for k, v in unsupported.items():
         ok = (k in ("sparse_grad", "absgrad", "distributed") and not v) or \
@@ -185,6 +223,7 @@ def rasterization(
     channels = 4 if want_depth else 3
 
     renders, alphas, per_cam = [], [], []
+    pending = [] if defer_check else None   # TileBins per camera whose control words nobody has waited for yet
     for c in range(C):
         bg = None
         if backgrounds is not None:
@@ -192,7 +231,8 @@ def rasterization(
             if want_depth:
                 bg = torch.cat([bg, bg.new_zeros(1)])
         out = _RasterizeOneCamera.apply(means, quats, scales, opacities, colors, viewmats[c], Ks[c], bg,
-                                        width, height, deg, channels, cull, grad_out, grad_accumulate, sh_grad_factored)
+                                        width, height, deg, channels, cull, grad_out, grad_accumulate, sh_grad_factored,
+                                        front_stream, pending)
         render, alpha = out[0], out[1]
         if render_mode in ("ED", "RGB+ED"):
             render = torch.cat([render[..., :3], render[..., 3:] / alpha.clamp(min=1e-10)], dim=-1)
@@ -201,6 +241,19 @@ def rasterization(
         renders.append(render)
         alphas.append(alpha)
         per_cam.append(out[2:])  # splat, radii, tiles_touched, sorted_tile, sorted_gid, tile_offsets, last_id
+
+    def settled():
+        """per_cam with the record buffers cut to the record counts (deferred check: waits for the control words now)."""
+        if pending:
+            for c, b in enumerate(pending):
+                m = b.finalize()[0]
+                pc = list(per_cam[c])
+                pc[3], pc[4] = (pc[3][:m] if pc[3].numel() else pc[3]), pc[4][:m]
+                per_cam[c] = tuple(pc)
+            pending.clear()
+        return per_cam
+
+    checked = list(pending) if pending else []
 
     def gather(i):  # [C, ...] without a copy for the single-camera call the reference makes
         return per_cam[0][i][None] if C == 1 else torch.stack([pc[i] for pc in per_cam])
@@ -220,7 +273,7 @@ def rasterization(
         reads them: the reference looks at means2d and radii, gsplat_backend.py:204-208)."""
         if "v" not in tiled:
             if bt == TILE_SIZE:
-                tiled["v"] = per_cam
+                tiled["v"] = settled()
             else:
                 out16 = []
                 for pc in per_cam:
@@ -236,9 +289,11 @@ def rasterization(
     meta._lazy = {
         "means2d": lambda: gather(0)[..., 0:2], "conics": lambda: gather(0)[..., 2:5],
         "depths": lambda: gather(0)[..., 9], "radii": lambda: gather(1), "tiles_per_gauss": lambda: gather(2),
-        "n_isects": lambda: (sum(int(pc[4].numel()) for pc in per_cam) if bt == TILE_SIZE
+        "n_isects": lambda: (sum(int(pc[4].numel()) for pc in settled()) if bt == TILE_SIZE
                              else sum(int(pc[2].sum()) for pc in per_cam)),
-        "n_binned": lambda: sum(int(pc[4].numel()) for pc in per_cam),   # records the hot path sorted (its bins)
+        "n_binned": lambda: sum(int(pc[4].numel()) for pc in settled()),   # records the hot path sorted (its bins)
+        # (defer_check: did the remembered capacity / key range hold for every camera of this call?  Waits for the control words.)
+        "speculation_ok": lambda: all(b.finalize()[1] for b in checked),
         "flatten_ids": lambda: torch.cat([pc[4] + c * N for c, pc in enumerate(tile_lists())]),
         "isect_offsets": lambda: _isect_offsets(tile_lists(), tile_h, tile_w),
         "isect_ids": lambda: _isect_ids(tile_lists(), tile_w * tile_h),

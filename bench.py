@@ -264,6 +264,15 @@ def main() -> None:
     ap.add_argument("--view-streams", type=int, default=DEFAULT_VIEW_STREAMS,
                     help="HIP streams the views of a step alternate on (2: view j + 1's HBM- / latency-bound front end "
                          "runs beside view j's VALU-bound sweeps; 1: strictly one view after the other)")
+    ap.add_argument("--overlap", default="alternate", choices=("front", "alternate"),
+                    help="with --view-streams >= 2: 'alternate' -- whole views on alternating streams, the backward passes "
+                         "ordered by events (the bucket is summed into in view order); 'front' -- every view's projection / "
+                         "depth ordering / binning on a side stream (rasterization(front_stream=...)), all sweeps in view "
+                         "order on the main stream (measured slower: the binning kernels want 35-128 KB of LDS per "
+                         "workgroup, which a running sweep never leaves free, so they sit out the sweep beside them)")
+    ap.add_argument("--no-defer-check", action="store_true",
+                    help="multi-view steps: wait for every view's control words inside its rasterization() call (the r03 "
+                         "behaviour) instead of checking the step's views once, behind the last one (defer_check=True)")
     ap.add_argument("--views", type=int, default=8,
                     help="ring size of the ROTATING-view pass (the reference samples random views every step, "
                          "trainer.py:315-317): one view per step, cycling through this many cameras")
@@ -331,7 +340,11 @@ def main() -> None:
             rings[v] = torch.stack([scene.make_camera(i, v) for i in range(v)]).to(dev)
         return rings[v]
 
-    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.view_streams))] if args.view_streams > 1 else []
+    # (front mode: the side stream is a HIGH-PRIORITY one -- the dispatcher serves the oldest kernel first, so the small
+    # kernels of a front end that becomes ready while a sweep fills the chip would otherwise wait for the sweep's tail)
+    prio = int(os.environ.get("GSPLAT_AMD_BENCH_FRONT_PRIORITY", "-1")) if args.overlap == "front" else 0
+    streams = [torch.cuda.Stream(device=dev, priority=prio if i == 0 else 0)
+               for i in range(max(1, args.view_streams))] if args.view_streams > 1 else []
 
     def make_step(form: str, views: int, n_streams: int, ring_size: int):
         """One step = `views` views on this rank (cameras j * world + rank of the step's window of the ring), forward +
@@ -339,17 +352,25 @@ def main() -> None:
         # one process, one view: nothing to sum, the backward writes the whole gradient itself
         factored = form == "factored" and (world > 1 or views > 1)
         ex = Exchange(dist, world, rank, n, views, factored, dev, expand=stages.sh_grad_expand)
-        use = streams[:n_streams] if n_streams > 1 else []
+        front = streams[0] if n_streams > 1 and args.overlap == "front" else None
+        use = streams[:n_streams] if n_streams > 1 and front is None else []
+        inputs_ready = torch.cuda.Event()
         bwd_done = [torch.cuda.Event() for _ in range(views)]
         step_done = torch.cuda.Event()
         state = {"first": True}
         cams, windows = ring(ring_size), {}
 
-        def step(i: int = 0):
+        defer = views > 1 and not args.no_defer_check   # the views' speculation is checked once per step, behind the last view
+
+        def step(i: int = 0, deferred: bool = defer):
             for t in leaves:
                 t.grad = None
+            metas = []
             base = (i * views * world) % ring_size
             main = torch.cuda.current_stream()
+            if front is not None:   # the front ends of this step's views read the parameters as the step in front left them
+                inputs_ready.record(main)
+                front.wait_event(inputs_ready)
             for j in range(views):
                 st = use[j % len(use)] if use else None
                 with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
@@ -360,7 +381,9 @@ def main() -> None:
                     r, a, meta = gsplat_amd.rasterization(leaves[0], leaves[1], leaves[2], opac.squeeze(-1), leaves[4], vm, K,
                                                           width, height, sh_degree=deg, backgrounds=bg,
                                                           cull_mode=args.cull_mode, grad_out=grad_views,
-                                                          grad_accumulate=j > 0, sh_grad_factored=ex.view_target(j))
+                                                          grad_accumulate=j > 0, sh_grad_factored=ex.view_target(j),
+                                                          front_stream=front, defer_check=deferred)
+                    metas.append(meta)
                     if st is not None:   # the bucket is summed into in view order; nothing else orders the streams
                         if j > 0:
                             st.wait_event(bwd_done[j - 1])
@@ -389,6 +412,12 @@ def main() -> None:
             if use:
                 step_done.record(main)
                 state["first"] = False
+            # the step's views were queued without waiting for their control words; what a trainer does in front of its
+            # optimizer: ask now (the device is a view or more behind), and render the step again if a view's remembered
+            # capacity or key range did not hold
+            if deferred and not all(m["speculation_ok"] for m in metas):
+                info["deferred_repairs"] = info.get("deferred_repairs", 0) + 1
+                step(i, deferred=False)
 
         step.exchange = ex
         return step
@@ -554,7 +583,10 @@ def main() -> None:
                                    + ((", RCCL all-gather of 3N rgb grads per view + one all-reduce of 11N geometry grads per "
                                        "step, SH gradient rebuilt locally" if args.exchange == "factored" else
                                        ", RCCL all-reduce of 59N-float grads") if world > 1 else ""),
-                       "views_per_gpu_per_step": B, "view_streams": n_streams, "ms_per_view": round(ms_per_view, 4),
+                       "views_per_gpu_per_step": B, "view_streams": n_streams,
+                       "overlap": (args.overlap if n_streams > 1 else "none"),
+                       "speculation_check": ("per step, repairs: %d" % info.get("deferred_repairs", 0)) if B > 1 and not args.no_defer_check else "per view",
+                       "ms_per_view": round(ms_per_view, 4),
                        "intersections_M": m, "bin_tile": stages.DEFAULT_BIN_TILE, "binned_records": info.get("binned"),
                        "grad_l1": round(grad_l1_head, 3), "grad_l1_single_view": round(grad_l1, 3),
                        "cull_mode": stages.DEFAULT_CULL_MODE if args.cull_mode is None else args.cull_mode},

@@ -473,6 +473,45 @@ def test_record_capacity_miss_is_repaired(gsa):
     assert S._capacity_for(key, N) >= m0["n_binned"]                       # the miss re-learned the capacity
 
 
+def test_deferred_check_reports_a_miss_and_the_next_call_is_right(gsa):
+    """``defer_check=True``: the call does not wait for the view's control words (the host queues views far ahead of the
+    device); ``meta['speculation_ok']`` says afterwards whether the remembered capacity / key range held.  In steady state
+    it is True and image, gradients and meta entries equal the checked call's; after a simulated threefold growth it is
+    False, and rendering the view again gives the checked call's result.  Also with the front end on a stream of its own."""
+    from gsplat_amd import scene, stages as S
+    W, H, N = 320, 200, 20_000
+    sc = _scene(N, seed=3, s_min=0.005, s_max=0.08)
+    base = [sc["means3D"], sc["rotations"], sc["scales"], sc["opacities"][:, 0], sc["shs"]]
+    cam = [scene.make_camera(1, 5)[None].cuda(), scene.make_intrinsics(W, H)[None].cuda()]
+    w = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(9)).cuda()
+    side = torch.cuda.Stream()
+
+    def run(**kw):
+        leaves = [t.cuda().clone().requires_grad_(True) for t in base]
+        r, a, m = gsa.rasterization(*leaves, *cam, W, H, sh_degree=3, **kw)
+        (r * w).sum().backward()
+        torch.cuda.synchronize()
+        return r.detach(), a.detach(), m, [t.grad for t in leaves]
+
+    run()                                                                   # first call of the shape: exact sizes
+    r0, a0, m0, g0 = run()
+    key = ("cuda", torch.cuda.current_device(), W, H, S.DEFAULT_CULL_MODE, S.bin_tile_for(W, H, S.DEFAULT_CULL_MODE))
+    for kw in ({"defer_check": True}, {"defer_check": True, "front_stream": side}, {"front_stream": side}):
+        r1, a1, m1, g1 = run(**kw)
+        assert m1["speculation_ok"] is True
+        assert torch.equal(r1, r0) and torch.equal(a1, a0)
+        assert all(_rel(x.reshape(-1).cpu(), y.reshape(-1).cpu()) < 1e-5 for x, y in zip(g1, g0)), kw   # (float atomics: not bit-equal run to run)
+        assert m1["n_binned"] == m0["n_binned"] and m1["n_isects"] == m0["n_isects"]
+        assert torch.equal(m1["flatten_ids"], m0["flatten_ids"]) and torch.equal(m1["isect_ids"], m0["isect_ids"])
+    S._CAPACITY[key][0] = m0["n_binned"] / N / 3                            # pretend the scene grew threefold
+    r2, a2, m2, g2 = run(defer_check=True)
+    assert m2["speculation_ok"] is False                                    # ... reported, not repaired
+    assert m2["n_binned"] < m0["n_binned"] <= S._capacity_for(key, N)       # (clamped to the capacity it ran with; the miss re-learned it)
+    r3, a3, m3, g3 = run(defer_check=True)
+    assert m3["speculation_ok"] is True and torch.equal(r3, r0)
+    assert all(_rel(x.reshape(-1).cpu(), y.reshape(-1).cpu()) < 1e-5 for x, y in zip(g3, g0))
+
+
 def test_population_change_keeps_the_pipeline_asynchronous(gsa):
     """Densify / prune changes N every 100 iterations (/root/reference/src/training/trainer.py:794-797): the record
     capacity is remembered per scene SHAPE as records per gaussian, so a population 5 % larger or smaller is binned

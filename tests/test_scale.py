@@ -255,7 +255,7 @@ def test_c5_densify_and_prune_event_at_5m():
     assert [name for name, _ in HF] == list(FIELDS)
 
 
-def _bench_bucket(tmp_path, tag, gpus, views_per_gpu, streams, exchange="factored"):
+def _bench_bucket(tmp_path, tag, gpus, views_per_gpu, streams, exchange="factored", extra=()):
     """Runs bench.py (the N > 1 ranks over gloo, sharing this box's GPU) on the tiny workload; -> the exchanged gradient
     bucket of its last timed step and the printed line."""
     import json
@@ -266,7 +266,7 @@ def _bench_bucket(tmp_path, tag, gpus, views_per_gpu, streams, exchange="factore
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", str(gpus), "--workload", "T", "--steps", "3",
            "--warmup", "1", "--views-per-gpu", str(views_per_gpu), "--view-streams", str(streams), "--exchange", exchange,
-           "--no-cpu-baseline", "--views", "1", "--dump-grad", out]
+           "--no-cpu-baseline", "--views", "1", "--dump-grad", out, *extra]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
@@ -293,6 +293,14 @@ def test_bench_multi_view_step_overlapped_equals_serial_and_one_process(tmp_path
     assert line_1["n_gpus"] == 1 and float((one - serial).abs().max()) <= 2e-5 * scale
     plain, _ = _bench_bucket(tmp_path, "plain", 2, 2, 2, exchange="allreduce")
     assert float((plain - serial).abs().max()) <= 2e-5 * scale
+    # (d) the views' speculation checked once per step (the default with several views) or inside every call, and the
+    # front ends on a side stream instead of whole views on alternating streams: the same sums
+    assert line_1["config"]["speculation_check"].startswith("per step") and line_1["config"]["overlap"] == "alternate"
+    for tag, extra in (("percall", ("--no-defer-check",)), ("front", ("--overlap", "front"))):
+        other, line = _bench_bucket(tmp_path, tag, 1, 4, 2, extra=extra)
+        assert float((other - serial).abs().max()) <= 2e-5 * scale, tag
+        assert line["config"]["speculation_check"] == ("per view" if tag == "percall" else "per step, repairs: 0")
+        assert line["config"]["overlap"] == ("front" if tag == "front" else "alternate")
 
 
 def test_c5_run_iteration_through_a_densify_event_then_renders_at_the_new_population():
