@@ -302,6 +302,16 @@ def main() -> None:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+    # the ranks agree on "did every view's speculation hold" through a HOST-side group: a collective on the device would
+    # sit behind the step's kernels in stream order, and the host is a step ahead of those
+    flag_group = dist.new_group(backend="gloo") if dist is not None else None
+
+    def agree(ok: bool) -> bool:
+        if dist is None:
+            return ok
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=flag_group)
+        return bool(t.item())
 
     import contextlib
 
@@ -415,7 +425,8 @@ def main() -> None:
             # the step's views were queued without waiting for their control words; what a trainer does in front of its
             # optimizer: ask now (the device is a view or more behind), and render the step again if a view's remembered
             # capacity or key range did not hold
-            if deferred and not all(m["speculation_ok"] for m in metas):
+            # (every rank takes the same decision: the repeated step repeats its collectives)
+            if deferred and not agree(all(m["speculation_ok"] for m in metas)):
                 info["deferred_repairs"] = info.get("deferred_repairs", 0) + 1
                 step(i, deferred=False)
 
