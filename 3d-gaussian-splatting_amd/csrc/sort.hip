@@ -1201,13 +1201,17 @@ __global__ __launch_bounds__(kColThreads) void bin_colscan_kernel(uint32_t m_cap
     const int r0 = min(s * seg_len, live), r1 = min(r0 + seg_len, live);
     const int bin = blockIdx.x * kColBins + j;                 // (< nb: the grid is nb / kColBins workgroups)
     uint32_t *col = mat + bin;
-    constexpr int kKeep = kColBins;                            // rows kept in registers between the two sweeps (all of them at the bench: 883 blocks)
+    // rows in chunks of kKeep, a chunk's loads all in flight (clamped, not predicated); a segment of one chunk -- the bench's
+    // 883 blocks: 28 rows -- keeps it in registers between the two sweeps, longer ones are read again (out of L2)
+    constexpr int kKeep = kColBins;
+    const bool one_chunk = seg_len <= kKeep;   // (uniform)
     uint32_t v[kKeep], sum = 0;
+    for (int b = r0; b < r1; b += kKeep) {
 #pragma unroll
-    for (int q = 0; q < kKeep; ++q) v[q] = r0 < r1 ? col[(size_t)min(r0 + q, r1 - 1) * nb] : 0u;   // (clamped: all in flight)
+        for (int q = 0; q < kKeep; ++q) v[q] = col[(size_t)min(b + q, r1 - 1) * nb];
 #pragma unroll
-    for (int q = 0; q < kKeep; ++q) { v[q] = r0 + q < r1 ? v[q] : 0u; sum += v[q]; }
-    for (int r = r0 + kKeep; r < r1; ++r) sum += col[(size_t)r * nb];
+        for (int q = 0; q < kKeep; ++q) { v[q] = b + q < r1 ? v[q] : 0u; sum += v[q]; }
+    }
     seg[s][j] = sum;
     __syncthreads();
     uint32_t run = 0, all = 0;
@@ -1217,15 +1221,16 @@ __global__ __launch_bounds__(kColThreads) void bin_colscan_kernel(uint32_t m_cap
         if (q < s) run += c;
         all += c;
     }
+    for (int b = r0; b < r1; b += kKeep) {
+        if (!one_chunk) {
 #pragma unroll
-    for (int q = 0; q < kKeep; ++q) {
-        if (r0 + q < r1) col[(size_t)(r0 + q) * nb] = run;
-        run += v[q];
-    }
-    for (int r = r0 + kKeep; r < r1; ++r) {
-        const uint32_t c = col[(size_t)r * nb];
-        col[(size_t)r * nb] = run;
-        run += c;
+            for (int q = 0; q < kKeep; ++q) v[q] = col[(size_t)min(b + q, r1 - 1) * nb];
+        }
+#pragma unroll
+        for (int q = 0; q < kKeep; ++q) {
+            if (b + q < r1) col[(size_t)(b + q) * nb] = run;
+            run += b + q < r1 ? v[q] : 0u;
+        }
     }
     if (t < kColBins) {   // (s == 0: lanes of wave 0)
         __hip_atomic_store(&totals[bin], all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
