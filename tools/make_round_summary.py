@@ -16,6 +16,10 @@ profiled = open(f"{src}/bench_profiled.json").read().strip().splitlines()[-1]
 default = open(f"{src}/bench_default.json").read().strip().splitlines()[-1]
 pj = json.loads(profiled)
 table = open(f"{src}/summary_table.md").read().rstrip()
+solo = open(f"{src}/summary_table_solo.md").read().rstrip() if os.path.exists(f"{src}/summary_table_solo.md") else ""
+if solo:
+    shutil.copy(f"{src}/stats_solo/p_kernel_stats.csv", f"{out}/{name}_kernel_stats_solo.csv")
+solo = "\n".join(ln for ln in solo.splitlines() if not ln.startswith("| at::") and "rocclr" not in ln)
 tr = json.load(open(f"{src}/traffic.json"))
 import subprocess
 tr["csrc_rev"] = subprocess.check_output(["git", "rev-parse", "--short=12", "HEAD:3d-gaussian-splatting_amd/csrc"], text=True).strip()
@@ -57,18 +61,31 @@ Un-profiled default run (`python bench.py`, CPU baseline legs included) on the s
 {default}
 ```
 
+The kernels ALONE -- `rocprofv3 --kernel-trace --stats -- python3 bench.py --profile-run --steps 30 --warmup 5`: single-view
+steps on one stream, the protocol `roofline` and `stage_ms` are quoted on (`profiles/{name}_kernel_stats_solo.csv`):
+
+{solo}
+
+The dominant kernel's average duration under the profiler (`composite_bwd_2p_kernel<3>`, this table) agrees with the
+HIP-event average bench.py reports in `roofline.avg_launch_ms` (un-profiled; the profiler adds a few percent).
+
+The same kernels in the whole bench (the command at the top: mostly {pj['config']['views_per_gpu_per_step']}-view steps on two streams).  Here a
+kernel's duration INCLUDES the time it waits beside another stream's sweep -- the LDS-hungry binning kernels
+(`radix_scatter`, `depth_bucket_sort`, `emit_binhist`, `emit_place`, `bin_colscan`) sit out a sweep that leaves a CU no
+LDS, `project_fwd` runs beside one at half speed (`profiles/r03_host_pipeline.md`) -- so the averages are longer than
+above although the views are shorter:
+
 {table}
 
-The dominant kernel's average duration under the
-profiler (`composite_bwd_2p_kernel<3>`, table above) agrees with the HIP-event average bench.py reports in
-`roofline.avg_launch_ms` (un-profiled; the profiler adds a few percent).
 Binning is `radix_hist<unsigned int>` + `radix_scan_rows` + `radix_scatter<unsigned int>` (ONE global pass: depth
 buckets) + `depth_bucket_sort_kernel` (local sorts fused with the scan and the block-owner table; it also leaves the
-control words in the caller's pinned slot -- no copy kernel), then `emit_hist` + `radix_scan_rows` + `emit_scatter`
-(records generated from the depth-ordered rectangles -- of the 32 x 32 bins: {pj['config'].get('binned_records')} records where the 16 x 16
-rule has {pj['config']['intersections_M']}; low half of the bin id's bits) + one 16-bit hist / scan / scatter pass (high half) + `tile_offsets_bsearch` + `tile_schedule`: 12 launches, 17 per forward + backward view.  The `scan_*`
-kernels, `tile_offsets_kernel` and the second / third `radix_*<unsigned int>` calls belong to the first call of the scene
-shape (LSD path, which learns the key range); `__amd_rocclr_copyBuffer` is the scene upload and that first call's read-back.
+control words in the caller's pinned slot -- no copy kernel), then `emit_binhist` + `bin_colscan` + `emit_place` (records
+generated from the depth-ordered rectangles -- of the 32 x 32 bins: {pj['config'].get('binned_records')} records where the 16 x 16 rule has
+{pj['config']['intersections_M']} -- counted per bin and block, the counts scanned into the lists' offsets, every id stored
+at its final place: `profiles/r03_binning_direct.md`) + `tile_schedule`: 8 launches, 13 per forward + backward view.
+The `scan_*` kernels, `tile_offsets_kernel` and the second / third `radix_*<unsigned int>` calls belong to the first call
+of the scene shape (LSD path, which learns the key range); `__amd_rocclr_copyBuffer` is the scene upload and that first
+call's read-back.
 
 Counters of the compositor kernels (`profiles/{name}_traffic.json`, separate `--pmc` passes of the same command):
 

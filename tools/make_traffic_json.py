@@ -65,8 +65,8 @@ for k in sorted(set(fetch) | set(write)):
     a = write.get(k, {}).get("TCC_EA0_ATOMIC_sum", 0.0)
     row = {"kernel": k, "fetch_size_bytes_raw": f, "fetch_bytes_corrected": 2 * f, "write_bytes": w, "atomic_requests": a,
            "hbm_bytes_per_launch": 2 * f + w,
-           # launches per fwd+bwd view on the steady-state path (the three row scans: depth buckets, two tile passes)
-           "launches_per_view": 3 if base == "radix_scan_rows_kernel" else 1}
+           # launches per fwd+bwd view on the steady-state path (one-pass binning: every kernel runs once a view)
+           "launches_per_view": 1}
     if base in STAGE:
         i, ac = insts.get(k, {}), active.get(k, {})
         if i and ac:
