@@ -1201,16 +1201,21 @@ __global__ __launch_bounds__(kColThreads) void bin_colscan_kernel(uint32_t m_cap
     const int r0 = min(s * seg_len, live), r1 = min(r0 + seg_len, live);
     const int bin = blockIdx.x * kColBins + j;                 // (< nb: the grid is nb / kColBins workgroups)
     uint32_t *col = mat + bin;
-    // rows in chunks of kKeep, a chunk's loads all in flight (clamped, not predicated); a segment of one chunk -- the bench's
-    // 883 blocks: 28 rows -- keeps it in registers between the two sweeps, longer ones are read again (out of L2)
-    constexpr int kKeep = kColBins;
-    const bool one_chunk = seg_len <= kKeep;   // (uniform)
+    // the first kKeep rows of the segment stay in registers between the two sweeps (all of them at the bench: 883 blocks, 28
+    // rows a segment); what a longer segment has beyond them is read in chunks of eight, a chunk's loads in flight together,
+    // and read again (out of L2) in the second sweep.  (All rows in chunks of 32 spilled: 8.8 -> 14.8 us.)
+    constexpr int kKeep = kColBins, kMore = 8;
     uint32_t v[kKeep], sum = 0;
-    for (int b = r0; b < r1; b += kKeep) {
 #pragma unroll
-        for (int q = 0; q < kKeep; ++q) v[q] = col[(size_t)min(b + q, r1 - 1) * nb];
+    for (int q = 0; q < kKeep; ++q) v[q] = r0 < r1 ? col[(size_t)min(r0 + q, r1 - 1) * nb] : 0u;   // (clamped: all in flight)
 #pragma unroll
-        for (int q = 0; q < kKeep; ++q) { v[q] = b + q < r1 ? v[q] : 0u; sum += v[q]; }
+    for (int q = 0; q < kKeep; ++q) { v[q] = r0 + q < r1 ? v[q] : 0u; sum += v[q]; }
+    for (int b = r0 + kKeep; b < r1; b += kMore) {
+        uint32_t w[kMore];
+#pragma unroll
+        for (int q = 0; q < kMore; ++q) w[q] = col[(size_t)min(b + q, r1 - 1) * nb];
+#pragma unroll
+        for (int q = 0; q < kMore; ++q) sum += b + q < r1 ? w[q] : 0u;
     }
     seg[s][j] = sum;
     __syncthreads();
@@ -1221,15 +1226,19 @@ __global__ __launch_bounds__(kColThreads) void bin_colscan_kernel(uint32_t m_cap
         if (q < s) run += c;
         all += c;
     }
-    for (int b = r0; b < r1; b += kKeep) {
-        if (!one_chunk) {
 #pragma unroll
-            for (int q = 0; q < kKeep; ++q) v[q] = col[(size_t)min(b + q, r1 - 1) * nb];
-        }
+    for (int q = 0; q < kKeep; ++q) {
+        if (r0 + q < r1) col[(size_t)(r0 + q) * nb] = run;
+        run += v[q];
+    }
+    for (int b = r0 + kKeep; b < r1; b += kMore) {
+        uint32_t w[kMore];
 #pragma unroll
-        for (int q = 0; q < kKeep; ++q) {
+        for (int q = 0; q < kMore; ++q) w[q] = col[(size_t)min(b + q, r1 - 1) * nb];
+#pragma unroll
+        for (int q = 0; q < kMore; ++q) {
             if (b + q < r1) col[(size_t)(b + q) * nb] = run;
-            run += b + q < r1 ? v[q] : 0u;
+            run += b + q < r1 ? w[q] : 0u;
         }
     }
     if (t < kColBins) {   // (s == 0: lanes of wave 0)
