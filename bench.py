@@ -304,7 +304,14 @@ def main() -> None:
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     # the ranks agree on "did every view's speculation hold" through a HOST-side group: a collective on the device would
     # sit behind the step's kernels in stream order, and the host is a step ahead of those
-    flag_group = dist.new_group(backend="gloo") if dist is not None else None
+    flag_group, flag_error = None, None
+    if dist is not None:
+        try:
+            flag_group = dist.new_group(backend="gloo")
+        except Exception as exc:   # noqa: BLE001  (no usable host interface for gloo: every view is checked inside its own call)
+            flag_error = f"{type(exc).__name__}: {exc}"
+            args.no_defer_check = True
+            print(f"[bench] rank {rank}: no host-side group for the per-step check ({flag_error}); checking per view", file=sys.stderr)
 
     def agree(ok: bool) -> bool:
         if dist is None:
