@@ -605,7 +605,7 @@ def main() -> None:
                        "overlap": (args.overlap if n_streams > 1 else "none"),
                        "speculation_check": ("per step, repairs: %d" % info.get("deferred_repairs", 0)) if B > 1 and not args.no_defer_check else "per view",
                        "ms_per_view": round(ms_per_view, 4),
-                       "intersections_M": m, "bin_tile": stages.DEFAULT_BIN_TILE, "binned_records": info.get("binned"),
+                       "intersections_M": m, "bin_tile": stages.bin_tile_for(width, height, stages.DEFAULT_CULL_MODE if args.cull_mode is None else args.cull_mode), "binned_records": info.get("binned"),
                        "grad_l1": round(grad_l1_head, 3), "grad_l1_single_view": round(grad_l1, 3),
                        "cull_mode": stages.DEFAULT_CULL_MODE if args.cull_mode is None else args.cull_mode},
             "warmup_effective": head["warmup_effective"],   # steps actually run before the timed window (see settle())

@@ -255,6 +255,43 @@ def test_c5_densify_and_prune_event_at_5m():
     assert [name for name, _ in HF] == list(FIELDS)
 
 
+def test_4k_frame_takes_64_pixel_bins_and_the_one_pass_placement():
+    """3840x2160: the 8160 bins of 32 x 32 are beyond the one-pass placement (2047), the 2040 bins of 64 x 64 are not, and
+    ``bin_tile_for`` picks those (C5: binning 0.79 -> 0.54 ms) -- the same image, alpha and record count as with 32 x 32 bins,
+    gradients up to the order of the float atomics."""
+    import gsplat_amd as gsa
+    from gsplat_amd import scene, stages as S
+    assert [S.bin_tile_for(w, h, 0) for w, h in ((1920, 1080), (2560, 1440), (3840, 2160), (7680, 4320), (640, 480))] == \
+        [32, 64, 64, 32, 32]
+    assert S.bin_tile_for(3840, 2160, 1) == 16                       # (exact culling: the unfused path)
+    N, W, H = 60_000, 3840, 2160
+    assert gsa.lib.gsa_tile_bin16_direct(W, H, 64) == 1 and gsa.lib.gsa_tile_bin16_direct(W, H, 32) == 0
+    sc = scene.make_scene(N, seed=6, sh_degree=3)
+    vm, K = scene.make_camera(1, 3)[None].cuda(), scene.make_intrinsics(W, H)[None].cuda()
+    base = [sc["means3D"].cuda(), sc["rotations"].cuda(), (sc["scales"] * 2.0).cuda(), sc["opacities"][:, 0].cuda(),
+            sc["shs"].cuda()]
+    v = scene.make_v_render(W, H, seed=2).cuda()[None]
+
+    def run(force):
+        was = S._BIN_TILE_ENV
+        S._BIN_TILE_ENV = force            # (None: the automatic choice; "32": as if GSPLAT_AMD_BIN_TILE=32 were set)
+        try:
+            leaves = [t.clone().requires_grad_(True) for t in base]
+            r, a, meta = gsa.rasterization(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], vm, K, W, H, sh_degree=3)
+            r.backward(v)
+            return r.detach(), a.detach(), [t.grad for t in leaves], meta
+        finally:
+            S._BIN_TILE_ENV = was
+
+    r64, a64, g64, m64 = run(None)
+    r32, a32, g32, m32 = run("32")
+    assert m64["bin_tile"] == 64 and m32["bin_tile"] == 32 and m64["n_isects"] == m32["n_isects"] > 0
+    assert m64["n_binned"] < m32["n_binned"]
+    assert torch.equal(r64, r32) and torch.equal(a64, a32)
+    for x, y in zip(g64, g32):
+        assert float((x - y).abs().max()) <= 2e-5 * max(float(y.abs().max()), 1e-30)
+
+
 def _bench_bucket(tmp_path, tag, gpus, views_per_gpu, streams, exchange="factored", extra=()):
     """Runs bench.py (the N > 1 ranks over gloo, sharing this box's GPU) on the tiny workload; -> the exchanged gradient
     bucket of its last timed step and the printed line."""
