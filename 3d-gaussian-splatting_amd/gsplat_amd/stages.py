@@ -111,15 +111,15 @@ if DEFAULT_BIN_TILE not in (TILE_SIZE, 2 * TILE_SIZE, 4 * TILE_SIZE):
 
 def bin_tile_for(width: int, height: int, cull_mode: int) -> int:
     """The bin side rasterization() uses for this view: DEFAULT_BIN_TILE where the fused binning applies, else 16.
-    Unless GSPLAT_AMD_BIN_TILE says otherwise, a frame whose 32 x 32 bins are too many for the one-pass placement
-    (gsa_tile_bin16_direct: 2047) but whose 64 x 64 bins are not -- 2560 x 1440, 3840 x 2160 -- is binned at 64: measured at C5
-    (5 M gaussians, 4K) binning 0.79 -> 0.54 ms with 17.7 M instead of 40.1 M records, the forward sweep +0.04, the view 2.31 ->
-    2.07 ms in the 4-view step."""
+    Unless GSPLAT_AMD_BIN_TILE says otherwise, a LARGE frame (more than 4096 bins of 32 x 32) whose 64 x 64 bins fit the
+    one-pass placement (gsa_tile_bin16_direct: 2047) -- 3840 x 2160 -- is binned at 64: measured at C5 (5 M gaussians, 4K)
+    binning 0.79 -> 0.54 ms with 17.7 M instead of 40.1 M records, the forward sweep +0.04, the view 2.31 -> 2.07 ms in the
+    4-view step.  (2560 x 1440 with 1 M gaussians: 0.900 ms per view at 32, 0.913 at 64 -- stays at 32, as 1920 x 1080 does.)"""
     if not (cull_mode == 0 and _BIN_FUSED_DEFAULT):
         return TILE_SIZE
     bt = DEFAULT_BIN_TILE
-    if _BIN_TILE_ENV is None and bt == 2 * TILE_SIZE and _BIN_DIRECT and not lib.gsa_tile_bin16_direct(width, height, bt) \
-            and lib.gsa_tile_bin16_direct(width, height, 2 * bt):
+    if _BIN_TILE_ENV is None and bt == 2 * TILE_SIZE and _BIN_DIRECT and tile_grid(width, height, bt)[0] * \
+            tile_grid(width, height, bt)[1] > 4096 and lib.gsa_tile_bin16_direct(width, height, 2 * bt):
         bt = 2 * bt
     return bt if bool(lib.gsa_tile_bins_supported(width, height, bt)) else TILE_SIZE
 
