@@ -1417,40 +1417,43 @@ __global__ __launch_bounds__(kSchedThreads) void tile_schedule_kernel(int n_tile
     // CONSECUTIVE places -- their waves then run together and gather the bin's records out of the same L2 at the same
     // time -- and the member with the smallest index inside this band speaks for its bin.
     const int tile_h = n_tiles / max(tile_w, 1), bin_w = (tile_w + SIDE - 1) >> SHIFT;
-    auto plan = [&](int t, int (&m)[MEMBERS], int &bkt) {   // -> number of places t reserves (0: another tile speaks for it)
+    // member j of t's bin, if it is a tile of the image inside this band (else -1)
+    auto member = [&](int tx0, int ty0, int j) -> int {
+        const int x = tx0 + (j & (SIDE - 1)), y = ty0 + (j >> SHIFT), u = y * tile_w + x;
+        return x < tile_w && y < tile_h && u >= lo && u < hi ? u : -1;
+    };
+    auto plan = [&](int t, int &tx0, int &ty0, int &bkt) {   // -> number of places t reserves (0: another tile speaks for it)
         const int ty = t / max(tile_w, 1), tx = t - ty * tile_w;
         const int idx = SHIFT ? (ty >> SHIFT) * bin_w + (tx >> SHIFT) : t;
         const int len = tile_offsets[idx + 1] - tile_offsets[idx];
         bkt = kSchedBuckets - 1 - min(kSchedBuckets - 1, len >> 6);   // bucket 0 = longest lists
-        const int tx0 = (tx >> SHIFT) << SHIFT, ty0 = (ty >> SHIFT) << SHIFT;
-        int k = 0;
+        tx0 = (tx >> SHIFT) << SHIFT; ty0 = (ty >> SHIFT) << SHIFT;
+        int k = 0, head = -1;
 #pragma unroll
         for (int j = 0; j < MEMBERS; ++j) {
-            const int x = tx0 + (j & (SIDE - 1)), y = ty0 + (j >> SHIFT), u = y * tile_w + x;
-            const bool in = x < tile_w && y < tile_h && u >= lo && u < hi;
-#pragma unroll
-            for (int q = 0; q < MEMBERS; ++q)
-                if (q == k && in) m[q] = u;   // (compile-time indices: m stays in registers)
-            k += in ? 1 : 0;
+            const int u = member(tx0, ty0, j);
+            if (u >= 0) { if (head < 0) head = u; ++k; }
         }
-        return m[0] == t ? k : 0;
+        return head == t ? k : 0;
     };
     for (int t = lo + threadIdx.x; t < hi; t += kSchedThreads) {
-        int m[MEMBERS], bkt;
-        const int k = plan(t, m, bkt);
+        int tx0, ty0, bkt;
+        const int k = plan(t, tx0, ty0, bkt);
         if (k) atomicAdd(&cnt[bkt], k);
     }
     __syncthreads();
     bucket_starts<kSchedBuckets>(cnt, first);
     __syncthreads();
     for (int t = lo + threadIdx.x; t < hi; t += kSchedThreads) {
-        int m[MEMBERS], bkt;
-        const int k = plan(t, m, bkt);
+        int tx0, ty0, bkt;
+        const int k = plan(t, tx0, ty0, bkt);
         if (k) {
-            const int at = lo + atomicAdd(&first[bkt], k);
+            int at = lo + atomicAdd(&first[bkt], k);
 #pragma unroll
-            for (int j = 0; j < MEMBERS; ++j)
-                if (j < k) tile_order[at + j] = m[j];
+            for (int j = 0; j < MEMBERS; ++j) {
+                const int u = member(tx0, ty0, j);
+                if (u >= 0) tile_order[at++] = u;
+            }
         }
     }
     for (int t = max(hi, lo) + threadIdx.x; t < lo + chunk; t += kSchedThreads) tile_order[t] = -1;   // padding
