@@ -48,9 +48,10 @@ prices 112 M records of the 16 x 16 rule where 40 M bin records are sorted, and 
 reads the 48-B digest -- the contractual fraction flatters at this size (`roofline_whole_step.frac` > 1); what the kernels
 do is in the table below.  5 M gaussians are beyond the bucketed depth ordering (an average bucket of N / 255 keys no longer
 fits the 8192-key LDS capacity of the local sorts, and the 8-bit radix machinery has no more buckets to give): the LSD path
-(three `radix_scatter<unsigned int>` passes per view below) orders the depths; and the 8160 bins of a 4K frame are beyond
-the one-pass placement (2047 bins: its per-bin counters live in LDS), so the records take the two-pass tile sort:
-{c5['stage_ms']['binning']} ms of binning in all.
+(three `radix_scatter<unsigned int>` passes per view below) orders the depths.  The 8160 bins of 32 x 32 of a 4K frame are
+beyond the one-pass placement (2047 bins: its per-bin counters live in LDS), so frames that large are binned at 64 x 64
+(`config.bin_tile` = {c5['config'].get('bin_tile')}: 2040 bins, {c5['config'].get('binned_records')} records where 32 x 32 bins have 40.1 M): {c5['stage_ms']['binning']} ms of
+binning in all (0.79 with 32 x 32 bins and the two-pass tile sort, the view 2.31 ms).
 
 `rocprofv3 --kernel-trace --stats -- python3 bench.py --workload C5 --profile-run --steps 10 --warmup 3` (single-view steps):
 
