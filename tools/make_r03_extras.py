@@ -44,7 +44,7 @@ speculation checked once per step; the `single_view` object is one view per step
 
 {c5['config']['ms_per_view']} ms per 4K view in the 4-view step ({c5['value']} Mpix/s), {c5['single_view']['ms']} ms for a view alone (r02: 2.58; r01: 3.9).
 `over_peak` lists the stages (and the whole step) whose SURVEY-8d "algorithmic" rate exceeds the 8 TB/s peak: the formula
-prices 112 M records of the 16 x 16 rule where 40 M bin records are sorted, and the whole 192-B SH rows where the backward
+prices 112 M records of the 16 x 16 rule where {c5['config'].get('binned_records')} bin records are placed, and the whole 192-B SH rows where the backward
 reads the 48-B digest -- the contractual fraction flatters at this size (`roofline_whole_step.frac` > 1); what the kernels
 do is in the table below.  5 M gaussians are beyond the bucketed depth ordering (an average bucket of N / 255 keys no longer
 fits the 8192-key LDS capacity of the local sorts, and the 8-bit radix machinery has no more buckets to give): the LSD path
