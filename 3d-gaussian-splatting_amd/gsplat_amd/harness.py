@@ -371,13 +371,17 @@ class ViewParallelTrainer:
 
     def __init__(self, model: SplatModel, backend, config: Optional[StepConfig] = None,
                  process_group=None, rank: int = 0, world_size: int = 1, fused: bool = False,
-                 factored_exchange: Optional[bool] = None, overlap_views: bool = True):
+                 factored_exchange: Optional[bool] = None, overlap_views=True):
         self.model, self.backend = model, backend
         self.cfg = config or StepConfig()
         self.group, self.rank, self.world = process_group, rank, world_size
         self.iteration = 0
         self.fused = bool(fused)
-        self.overlap_views = bool(overlap_views)   # fused step: next view's front end on a side stream
+        # fused step: True / "front" (default) -- the next view's front end on a side stream; "alternate" -- whole views on two
+        # alternating streams, their speculation checked once in front of the optimizer (bench.py's scheme; measured equal
+        # here, 3.32 against 3.29 ms per 4-view step at C3: a step of four views that ends in a host read-back has little
+        # for the host to run ahead into); False -- one stream (3.41 ms)
+        self.overlap_views = overlap_views if overlap_views in ("alternate", "front") else ("front" if overlap_views else False)
         if self.fused and not model.flat.is_cuda:
             raise RuntimeError("ViewParallelTrainer(fused=True) needs the model on a HIP device (no CPU path)")
         # fused: the SH-coefficient gradient is kept (and, for world > 1, exchanged) in factored form
@@ -520,7 +524,7 @@ class ViewParallelTrainer:
         return {"loss": float(report[3]), "l1": float(report[0]) / n_views, "ssim": float(report[1]) / n_views,
                 "psnr": float(report[2]) / n_views, "scale_reg": float(reg.detach())}
 
-    def _training_step_fused(self, batch: Sequence[Dict]) -> Dict[str, float]:
+    def _training_step_fused(self, batch: Sequence[Dict], exact: bool = False) -> Dict[str, float]:
         """Same step on the HIP kernels end to end.  Besides the loss and Adam kernels, the gradients never pass
         through autograd's accumulation: the activations (trainer.py:399-406) are evaluated once without a graph,
         every view's backward ADDS its activated-parameter gradients into one bucket (``grad_accumulate``), and the
@@ -566,13 +570,14 @@ class ViewParallelTrainer:
         main = torch.cuda.current_stream()
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=dev)
-        side = self._side if self.overlap_views else main
+        alternate = self.overlap_views == "alternate" and not exact
+        side = self._side if self.overlap_views == "front" else main
         cull = S.DEFAULT_CULL_MODE
         Kc, bgc = K[0].contiguous(), bg[0].contiguous()
         params_ready = torch.cuda.Event()
         params_ready.record(main)
 
-        def front(view, exact=False):
+        def front(view, exact=exact, side=side):
             with torch.cuda.stream(side):
                 side.wait_event(params_ready)
                 pose = view["pose"].to(torch.float32).contiguous()
@@ -597,14 +602,9 @@ class ViewParallelTrainer:
         mine = list(batch[self.rank::self.world])
         scale = self.loss_scale if self.amp else 1.0   # loss scale: the backward passes see v_render times it
         sums, first = [], True
-        ahead = front(mine[0]) if mine else None
-        for j, view in enumerate(mine):
-            pose, splat, radii, bins, order, done, aux = ahead
-            if not bins.finalize()[1]:       # record capacity missed (the scene grew): bin again with exact sizes
-                pose, splat, radii, bins, order, done, aux = front(view, exact=True)
-                bins.finalize()
-            ahead = front(mine[j + 1]) if j + 1 < len(mine) else None
-            main.wait_event(done)
+
+        def sweep(j, view, pose, splat, radii, bins, order, aux, before_bucket=None):
+            """compositor forward, loss, compositor backward, projection backward of view j on the current stream"""
             W, H = view["width"], view["height"]
             bt = bins.bin_tile
             render, _, final_T, last_id, lists = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bgc, W,
@@ -613,11 +613,43 @@ class ViewParallelTrainer:
             s3, v = S.view_loss(render, view["image"], c.lambda_dssim, grad_scale=scale / n_views)
             v_splat = S.composite_bwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bgc, final_T, last_id, v, None,
                                       W, H, 3, order, quad_lists=lists, bin_tile=bt)
+            if before_bucket is not None:   # (the bucket is summed into in view order)
+                torch.cuda.current_stream().wait_event(before_bucket)
             S.project_bwd(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], degree, pose, Kc, W, H, splat, radii,
-                          v_splat, out=grad_out, accumulate=not first,
+                          v_splat, out=grad_out, accumulate=j > 0,
                           v_rgb_out=vr_all[self.rank, j] if factored else None, sh_aux=aux)
-            sums.append(s3 / float(v.numel()))            # -> l1, ssim, mse of this view
-            first = False
+            return s3 / float(v.numel())            # -> l1, ssim, mse of this view
+
+        if alternate:
+            # whole views on two alternating streams; nobody waits for a view's control words until all are queued
+            streams, pending, bucket_done = (main, self._side), [], None
+            for j, view in enumerate(mine):
+                st = streams[j % 2]
+                pose, splat, radii, bins, order, done, aux = front(view, side=st)
+                with torch.cuda.stream(st):
+                    res = sweep(j, view, pose, splat, radii, bins, order, aux, before_bucket=bucket_done)
+                    bucket_done = torch.cuda.Event()
+                    bucket_done.record(st)
+                    if st is not main:
+                        res.record_stream(main)
+                sums.append(res)
+                pending.append(bins)
+                first = False
+            if bucket_done is not None:
+                main.wait_event(bucket_done)
+            if not all(b.finalize()[1] for b in pending):   # a remembered capacity / key range did not hold: the step again,
+                return self._training_step_fused(batch, exact=True)   # one stream, exact sizes (nothing was applied yet)
+        else:
+            ahead = front(mine[0]) if mine else None
+            for j, view in enumerate(mine):
+                pose, splat, radii, bins, order, done, aux = ahead
+                if not bins.finalize()[1]:       # record capacity missed (the scene grew): bin again with exact sizes
+                    pose, splat, radii, bins, order, done, aux = front(view, exact=True)
+                    bins.finalize()
+                ahead = front(mine[j + 1]) if j + 1 < len(mine) else None
+                main.wait_event(done)
+                sums.append(sweep(j, view, pose, splat, radii, bins, order, aux))
+                first = False
         if first:                                          # this rank rendered nothing
             m.flat_grad.zero_()
             for g in (g_quats, g_scales, g_opac):

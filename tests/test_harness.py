@@ -169,12 +169,13 @@ def test_training_step_on_hip_backend_matches_reference_trainer(gold):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("overlap,factored", [(True, True), (False, True), (True, False)])
+@pytest.mark.parametrize("overlap,factored", [("alternate", True), (True, True), (False, True), (True, False), ("alternate", False)])
 def test_fused_training_step_matches_reference_trainer(gold, overlap, factored):
     """The same two steps on HIP kernels end to end -- rasterizer stages called directly, activations
     (gsa_activate_fwd / _bwd), loss (gsa_view_loss), SH-gradient rebuild (gsa_sh_grad_expand_split) and Adam
-    (gsa_adam_step): still the reference trainer's metrics, gradients, parameters and Adam moments.  With and without
-    the next view's front end on a side stream, and with the plain 48-float SH-gradient accumulation."""
+    (gsa_adam_step): still the reference trainer's metrics, gradients, parameters and Adam moments.  With whole views on
+    two alternating streams (the default), with only the next view's front end on a side stream, on one stream, and with
+    the plain 48-float SH-gradient accumulation."""
     import gsplat_amd
     from gsplat_amd.harness import ViewParallelTrainer
     model, batch = _model_and_batch(gold, "cuda")

@@ -22,7 +22,7 @@ for fused in ((True,) if os.environ.get("FUSED_ONLY") else (False, True)):
                                     opacity=torch.logit(sc["opacities"].clamp(1e-4, 1 - 1e-4)).to(dev),
                                     scaling=torch.log(sc["scales"]).to(dev), rotation=sc["rotations"].to(dev))
     tr = ViewParallelTrainer(model, gsplat_amd.HipBackend(K), fused=fused,
-                             overlap_views=os.environ.get("OVERLAP", "1") != "0")
+                             overlap_views={"0": False, "alternate": "alternate"}.get(os.environ.get("OVERLAP", "front"), "front"))
     if os.environ.get("SIDE_PRIORITY"):
         tr._side = torch.cuda.Stream(device=dev, priority=int(os.environ["SIDE_PRIORITY"]))
     tr.iteration = 5000   # SH degree 3
