@@ -340,6 +340,9 @@ _QUAD_MASKS = os.environ.get("GSPLAT_AMD_QUAD_MASKS", "0") != "0"
 _CAPACITY = {}
 _CAPACITY_MAX_KEYS = 64
 _SHRINK_AFTER = 32
+# views of ONE camera after which what is remembered about a scene shape (record capacity, depth-key range) has settled on
+# that camera: a benchmark that goes from several cameras to one warms up this long before it times
+SPECULATION_SETTLE_VIEWS = _SHRINK_AFTER + 8
 
 
 # scene shape -> [lo, hi, consecutive much-narrower views]: the union of the visible depth-key ranges seen so far
