@@ -559,14 +559,23 @@ def test_two_cameras_in_one_call_equal_two_calls(gsa):
     Ks = torch.stack([scene.make_intrinsics(W, H)] * 2).cuda()
     v = torch.from_numpy(np.random.default_rng(3).uniform(-1, 1, (2, H, W, 3)).astype(np.float32)).cuda()
 
-    def run(cams):
+    def run(cams, **kw):
         leaves = [sc[k].cuda().clone().requires_grad_(True) for k in NAMES]
         r, a, meta = gsa.rasterization(leaves[0], leaves[1], leaves[2], leaves[3][:, 0], leaves[4], vms[cams], Ks[cams], W, H,
-                                       sh_degree=3, backgrounds=torch.zeros(len(cams), 3, device="cuda"))
+                                       sh_degree=3, backgrounds=torch.zeros(len(cams), 3, device="cuda"), **kw)
         (r * v[cams]).sum().backward()
         return r.detach(), a.detach(), meta, [t.grad for t in leaves]
 
+    run([0, 1])                                        # (first call of the shape: exact sizes)
     r2, a2, m2, g2 = run([0, 1])
+    # the same call without waiting for either camera's control words, front ends on a side stream: same results, and the
+    # meta entries that depend on the record counts wait for them on access
+    rd, ad, md, gd = run([0, 1], defer_check=True, front_stream=torch.cuda.Stream())
+    assert md["speculation_ok"] is True and torch.equal(rd, r2) and torch.equal(ad, a2)
+    assert md["n_isects"] == m2["n_isects"] and torch.equal(md["flatten_ids"], m2["flatten_ids"])
+    assert torch.equal(md["isect_ids"], m2["isect_ids"]) and torch.equal(md["isect_offsets"], m2["isect_offsets"])
+    for name, x, y in zip(NAMES, gd, g2):
+        assert _rel(x, y) < 1e-5, name
     singles = [run([k]) for k in (0, 1)]
     assert r2.shape == (2, H, W, 3) and m2["n_cameras"] == 2
     for k, (r1, a1, m1, _) in enumerate(singles):
