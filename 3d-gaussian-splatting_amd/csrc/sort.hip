@@ -1134,14 +1134,17 @@ __global__ __launch_bounds__(kSortThreads) void emit_scatter_kernel(
 // emit_place generates the records once more and stores each gaussian id straight at
 //   tile_offsets[bin] + (records of that bin in the blocks in front) + (rank among the block's records of the bin).
 // The stores are single words, but a bin's region is filled front to back by consecutive blocks, and consecutive
-// blocks run on ONE XCD (sort_block_id): the words of a line meet in that XCD's L2 and leave it as whole lines.
+// blocks run on ONE XCD (live_block_id): the words of a line meet in that XCD's L2 and leave it as whole lines.
+// (Measured and dropped: generating the records once -- a ranking kernel that leaves (bin, rank, id) per slot, then a
+// placement without LDS that could run beside another stream's sweep: that placement pays two scattered loads per record
+// for its bases, 28.9 us, and comes behind the stream's LDS-hungry kernels anyway)
 constexpr int kBinsDirect = 2048;
 #ifndef GSA_COL_BINS
 #define GSA_COL_BINS 32   // bins (128 contiguous bytes of every row) per workgroup of bin_colscan: 8 -> 15.8 us, 16 -> 10.5, 32 -> 8.8, 64 -> 30.5 (32 workgroups)
 #endif
 constexpr int kColBins = GSA_COL_BINS, kColSegs = 1024 / kColBins, kColThreads = kColSegs * kColBins;
 #ifndef GSA_PLACE_XCD
-#define GSA_PLACE_XCD 1   // emit_binhist / emit_place: a workgroup's record block by sort_block_id (1) or by its index (0)
+#define GSA_PLACE_XCD 1   // emit_binhist / emit_place: a workgroup's record block by live_block_id (1) or by its index (0: binning +22 us)
 #endif
 
 __global__ __launch_bounds__(kSortThreads) void emit_binhist_kernel(int n, const uint32_t *__restrict__ order,
