@@ -1173,7 +1173,11 @@ constexpr int kSub = 8;                 // records per sub-batch
 // SQ_INSTS_VALU 119.6 M -> 125.0 M and the kernel's time unchanged (0.1993 / 0.2002 ms): the LDS pipe is not what the
 // sweep waits for.  Off by default (fewer instructions).
 constexpr int kMatPitch = GSA_BWD_SWIZZLE ? kSub : kSub + 1;     // float2 entries per pixel row of the LDS matrix
-constexpr int kTilePitch = GSA_BWD_SWIZZLE ? 20 : 16;            // words per record of the epilogue's [record][field] totals
+#ifndef GSA_BWD_TILE_PITCH
+#define GSA_BWD_TILE_PITCH 10   // (16 = a whole 64-B record: 192 B more per wave, 8384 B, and 19 instead of 20 waves per CU)
+#endif
+constexpr int kTilePitch = GSA_BWD_SWIZZLE ? 20 : GSA_BWD_TILE_PITCH;   // words per record of the epilogue's [record][field] totals
+static_assert(kTilePitch >= 10, "a record's 6 + CH fields");
 __device__ __forceinline__ int mat_slot(int pixel, int r) {
     return GSA_BWD_SWIZZLE ? pixel * kMatPitch + (r ^ ((pixel >> 1) & 7)) : pixel * kMatPitch + r;
 }
@@ -1350,7 +1354,7 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 5 : GSA_BWD_WAVES)) void composit
             const float m0 = fold16(k0, k1), m1 = fold16(k2, k3), m2 = fold16(k4, k4);
             const float t0 = fold32(m0, m1), t1 = fold32(m2, m2);
             tp.tile[kTilePitch * rec + f0] = t0;
-            tp.tile[kTilePitch * rec + 8 + f0] = t1;       // fields >= NF are never read back
+            if (kTilePitch >= 16 || 8 + f0 < NF) tp.tile[kTilePitch * rec + 8 + f0] = t1;       // fields >= NF are never read back
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1359,7 +1363,7 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 5 : GSA_BWD_WAVES)) void composit
             for (int t = 0; t < 2; ++t) {
                 const int r = 4 * t + (lane >> 4), f = lane & 15;
                 if (4 * t < nv) {
-                    const float total = tp.tile[kTilePitch * r + f];
+                    const float total = tp.tile[kTilePitch * r + (kTilePitch >= 16 ? f : min(f, NF - 1))];
                     if (f < NF && r < nv) {
                         const uint32_t g = __float_as_uint(st.rec[F4 * (s0 + r) + 2].w);
                         atomicAdd(v_splat + (size_t)g * GSA_SPLAT_STRIDE + f, total);
