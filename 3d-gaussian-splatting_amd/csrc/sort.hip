@@ -111,7 +111,7 @@ __device__ __forceinline__ uint32_t tab_excl_scan(uint32_t v, uint32_t *scratch,
 
 // ONE workgroup, in front of the histogram pass: the view's depth table from what gsa_project_fwd left per wave.
 __global__ __launch_bounds__(kTabThreads) void depth_table_kernel(const uint4 *__restrict__ ranges, int n_waves,
-                                                                  uint32_t *__restrict__ table_out) {
+                                                                  uint32_t *__restrict__ table_out, int margin) {
     __shared__ __attribute__((aligned(16))) uint8_t s_lut[kCellsMax];
     __shared__ uint32_t s_fine[kCellsMax], s_cs[260], scratch[8 * (kTabThreads / 64)];
     const int t = threadIdx.x;
@@ -167,6 +167,11 @@ __global__ __launch_bounds__(kTabThreads) void depth_table_kernel(const uint4 *_
 #pragma unroll
     for (int w = 0; w < NW; ++w) { lo = min(lo, scratch[4 * NW + w]); hi = max(hi, scratch[5 * NW + w]); }
     DepthPlan pl{0u, 0u, 1u, 0u};
+    if (margin && lo <= hi) {   // a table that is to serve LATER views of the shape as well: 1/16 of the range more at either end
+        const uint32_t m = ((hi - lo) >> 4) + 1u;
+        lo = lo > m ? lo - m : 0u;
+        hi = hi < 0xFFFFFFFEu - m ? hi + m : 0xFFFFFFFEu;
+    }
     if (lo <= hi) {
         if ((unsigned long long)hi - lo + 1ull > 250ull * 65536ull) pl.flags = kPlanWide;   // (250: the cells' alignment and
                                                                                               // rounding need the rest of the 254)
@@ -1556,7 +1561,7 @@ extern "C" int gsa_depth_order(int n, const uint32_t *depth_keys, const uint32_t
 // ctl[1..2]); the caller then repeats with the LSD path.
 constexpr int kLocalThreads = 1024, kLocalWaves = kLocalThreads / 64, kLocalCap = 8192;
 constexpr unsigned long long kGranuleReady = 1ull << 63;
-constexpr uint32_t kStatusOverflow = 1u, kStatusTimeout = 2u, kStatusWide = 4u;
+constexpr uint32_t kStatusOverflow = 1u, kStatusTimeout = 2u, kStatusWide = 4u, kStatusRange = 8u;
 
 struct BucketLds {
     uint32_t val[2][kLocalCap];           // gaussian ids, ping-pong; after the sort the idle half holds the record counts
@@ -1786,6 +1791,10 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
             // which the host polls for.  (A block can only time out on a granule this block waits for as well, so the
             // status read here is final.)
             if (table && (table[kTabPlan + 3] & kPlanWide)) atomicOr(&ctl[3], kStatusWide);   // the range was too wide for 16-bit local sorts
+            if (table && ctl[1] <= ctl[2]) {   // a table built for ANOTHER view: do this view's visible keys lie inside its cells?
+                const uint32_t sh = table[kTabPlan + 1], g0 = table[kTabPlan], cells = table[kTabPlan + 2];
+                if ((ctl[1] >> sh) < g0 || (ctl[2] >> sh) - g0 >= cells) atomicOr(&ctl[3], kStatusRange);
+            }
             if (ctl_host) {
                 __threadfence();
                 const uint32_t st = __hip_atomic_load(&ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1846,15 +1855,15 @@ extern "C" size_t gsa_depth_order_msd_table_offset(int n) {
 }
 extern "C" int gsa_depth_order_msd_table_words(void) { return kTabWords; }
 
-extern "C" int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint32_t *tile_rects, uint32_t key_min,
-                                   uint32_t scale, const uint32_t *key_range_dev, uint32_t *order, uint32_t *rects,
-                                   uint32_t *offsets, int32_t *block_owner,
-                                   int n_blocks, uint32_t *ctl, uint32_t *ctl_host, uint32_t token, void *workspace,
-                                   size_t workspace_bytes, gsa_stream_t stream) {
+static int depth_order_msd_impl(int n, const uint32_t *depth_keys, const uint32_t *tile_rects, uint32_t key_min,
+                                uint32_t scale, const uint32_t *key_range_dev, uint32_t *table_ext, uint32_t *order,
+                                uint32_t *rects, uint32_t *offsets, int32_t *block_owner,
+                                int n_blocks, uint32_t *ctl, uint32_t *ctl_host, uint32_t token, void *workspace,
+                                size_t workspace_bytes, gsa_stream_t stream) {
     // (scale >= 2^16: a bucket is at most 2^32 / scale + 1 <= 65537 keys wide -- 16-bit local sorts; exactly 2^16 is the
     // power-of-two case shift = 16)
-    GSA_RETURN_IF(n < 0 || (!key_range_dev && scale < 65536u) || !ctl || n_blocks < 0 || (n_blocks > 0 && !block_owner),
-                  GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(n < 0 || (!key_range_dev && !table_ext && scale < 65536u) || !ctl || n_blocks < 0 ||
+                  (n_blocks > 0 && !block_owner), GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF((reinterpret_cast<uintptr_t>(key_range_dev) & 15) != 0, GSA_ERR_INVALID_ARGUMENT);
     hipStream_t s = static_cast<hipStream_t>(stream);
     GSA_RETURN_IF(token > 0xFFFFFFu, GSA_ERR_INVALID_ARGUMENT);
@@ -1882,10 +1891,12 @@ extern "C" int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint
     uint32_t *ticket = reinterpret_cast<uint32_t *>(granule + kRadix);
     // key_range_dev: what gsa_project_fwd left per wave -> one workgroup builds this view's depth table behind the ticket
     // for the launches that follow (the row scan zeroes only granules, ticket and ctl[3])
-    uint32_t *table = key_range_dev ? ticket + 16 : nullptr;
+    // table_ext: the caller's table -- built here, with a margin, if key_range_dev is given; used as it is otherwise
+    uint32_t *table = table_ext ? table_ext : (key_range_dev ? ticket + 16 : nullptr);
     const RadixDigit dg{(int)scale, key_min, table ? 2 : 1, table, nullptr, 0u};
-    if (table) {
-        depth_table_kernel<<<1, kTabThreads, 0, s>>>(reinterpret_cast<const uint4 *>(key_range_dev), gsa_div_up(n, 64), table);
+    if (key_range_dev) {
+        depth_table_kernel<<<1, kTabThreads, 0, s>>>(reinterpret_cast<const uint4 *>(key_range_dev), gsa_div_up(n, 64), table,
+                                                     table_ext ? 1 : 0);
         GSA_LAUNCH_CHECK();
     }
     radix_hist_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(n, nullptr, depth_keys, dg, nblocks, hist, block_range);
@@ -1903,6 +1914,29 @@ extern "C" int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint
                                                               granule, ticket, ctl, ctl_host, token, table);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
+}
+
+extern "C" int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint32_t *tile_rects, uint32_t key_min,
+                                   uint32_t scale, const uint32_t *key_range_dev, uint32_t *order, uint32_t *rects,
+                                   uint32_t *offsets, int32_t *block_owner,
+                                   int n_blocks, uint32_t *ctl, uint32_t *ctl_host, uint32_t token, void *workspace,
+                                   size_t workspace_bytes, gsa_stream_t stream) {
+    return depth_order_msd_impl(n, depth_keys, tile_rects, key_min, scale, key_range_dev, nullptr, order, rects, offsets,
+                                block_owner, n_blocks, ctl, ctl_host, token, workspace, workspace_bytes, stream);
+}
+
+// ... with the depth table in the CALLER's memory (gsa_depth_order_msd_table_words() uint32): built from key_range_dev with a
+// margin of 1/16 of the key range at either end when that is given, used as it is when it is NULL -- a table one view built
+// then orders the later views of the same scene shape without a table launch of their own.  The ordering never depends
+// on the table; a view whose visible keys leave the table's cells is REPORTED (ctl[3] bit 3), like a bucket overflow.
+extern "C" int gsa_depth_order_msd_table(int n, const uint32_t *depth_keys, const uint32_t *tile_rects,
+                                         const uint32_t *key_range_dev, uint32_t *table, uint32_t *order, uint32_t *rects,
+                                         uint32_t *offsets, int32_t *block_owner, int n_blocks, uint32_t *ctl,
+                                         uint32_t *ctl_host, uint32_t token, void *workspace, size_t workspace_bytes,
+                                         gsa_stream_t stream) {
+    GSA_RETURN_IF(!table || (reinterpret_cast<uintptr_t>(table) & 15) != 0, GSA_ERR_INVALID_ARGUMENT);
+    return depth_order_msd_impl(n, depth_keys, tile_rects, 0u, 0u, key_range_dev, table, order, rects, offsets, block_owner,
+                                n_blocks, ctl, ctl_host, token, workspace, workspace_bytes, stream);
 }
 
 static int tile_emit_impl(int n, const uint32_t *order, const uint32_t *offsets, const float *splat,

@@ -13,7 +13,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_u
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # GSPLAT_AMD_LIB: developer override to A/B another build of the SAME C ABI (still a HIP library; no fallback)
 LIB_PATH = os.environ.get("GSPLAT_AMD_LIB") or os.path.join(_PKG_ROOT, "lib", "libgsplat_amd.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 SPLAT_STRIDE = 16
 
 P = c_void_p  # every device pointer and the stream cross the boundary as void*
@@ -38,6 +38,7 @@ SIGNATURES = {
     "gsa_depth_order_msd_table_offset": (c_size_t, [c_int]),
     "gsa_depth_order_msd_table_words": (c_int, []),
     "gsa_depth_order_msd": (c_int, [c_int, P, P, c_uint32, c_uint32, P, P, P, P, P, c_int, P, P, c_uint32, P, c_size_t, P]),
+    "gsa_depth_order_msd_table": (c_int, [c_int, P, P, P, P, P, P, P, P, c_int, P, P, c_uint32, P, c_size_t, P]),
     "gsa_scan_tiles_sorted": (c_int, [c_int, P, P, c_int, P, P, c_size_t, P]),
     "gsa_tile_bin16": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_uint32, P, P, P, P, P, P, P, c_size_t, P]),
     "gsa_tile_emit": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_uint32, P, P, P]),

@@ -365,6 +365,15 @@ _MSD_MIN_N = 32768        # below this the 256 x 1024-thread bucket launch costs
 _MSD_MAX_N = 1_400_000    # above this an average bucket (N / 255, x1.5 for skew) no longer fits the 8192-key LDS capacity
 _MSD_BACKOFF = {}         # scene shape -> calls left before the bucketed ordering is tried again after an overflow
 _MSD_STREAK = {}          # scene shape -> overflows of the device-planned ordering in a row (escalates the back-off)
+# GSPLAT_AMD_TABLE_REUSE=1: a depth table built (with a margin) for one view of a scene shape orders the later views of the
+# shape as well -- no table launch of their own, buckets levelled as far as the views resemble one another -- until a view
+# does not fit it (reported, repaired, the shape back on the other plans for _REUSE_BACKOFF_VIEWS views)
+_TABLE_REUSE = os.environ.get("GSPLAT_AMD_TABLE_REUSE", "0") != "0"
+_REUSE_BACKOFF_VIEWS, _REUSE_AFTER_GOOD = 256, 8
+_SHAPE_TABLE = {}         # scene shape -> the table (device tensor) its views are ordered with
+_SHAPE_GOOD = {}          # scene shape -> host-planned views in a row that held
+_REUSE_BACKOFF = {}       # scene shape -> views left before a table is built for reuse again
+_TABLE_GRAVEYARD = []     # tables dropped while kernels of another stream may still read them (kept a while)
 
 
 def _key_bits_needed(lo: int, hi: int) -> int:
@@ -412,7 +421,22 @@ def _note_keys(key, lo: int, hi: int, assumed, status: int = 0) -> bool:
             else:
                 ent[2] = 0
     if isinstance(assumed, tuple):
-        if len(assumed) == 3:   # planned on the device from the view's own range: only the status can say no
+        if len(assumed) >= 3:   # planned on the device (the view's own table, or the shape's: assumed[3], [4]): only the status can say no
+            if len(assumed) == 5:
+                mode, tab = assumed[3], assumed[4]
+                if status == 0 and mode == "build":
+                    while len(_SHAPE_TABLE) >= _CAPACITY_MAX_KEYS and key not in _SHAPE_TABLE:
+                        _TABLE_GRAVEYARD.append(_SHAPE_TABLE.pop(next(iter(_SHAPE_TABLE))))
+                    _SHAPE_TABLE[key] = tab
+                elif status != 0:   # the shape's table does not fit this view (bit 3) or overflowed a bucket with it (bit 0)
+                    old = _SHAPE_TABLE.pop(key, None)
+                    if old is not None:
+                        _TABLE_GRAVEYARD.append(old)
+                    del _TABLE_GRAVEYARD[:-8]
+                    _REUSE_BACKOFF[key] = _REUSE_BACKOFF_VIEWS
+                    _SHAPE_GOOD.pop(key, None)
+                    if mode == "reuse" and not (status & 6):   # (a table of ANOTHER view did not fit this one -- range, or a
+                        return False                            # bucket it did not level: the other plans take the next view at once)
             if status & 4:      # the range is beyond 16-bit local sorts: no table helps
                 _MSD_BACKOFF[key] = 64
             elif status & 1:    # a bucket overflowed although its table was built from the view's own keys (a cluster of equal
@@ -432,7 +456,9 @@ def _note_keys(key, lo: int, hi: int, assumed, status: int = 0) -> bool:
         if status & 5:     # a depth cluster overflowed a bucket's LDS / the view's range is beyond 16-bit local sorts: every
             _MSD_BACKOFF[key] = 64   # such call costs a repair, so back off
         kmin, scale = assumed
-        return status == 0 and (lo > hi or (lo >= kmin and _msd_bucket(hi - kmin, scale) <= 254))
+        held = status == 0 and (lo > hi or (lo >= kmin and _msd_bucket(hi - kmin, scale) <= 254))
+        _SHAPE_GOOD[key] = _SHAPE_GOOD.get(key, 0) + 1 if held else 0
+        return held
     return _key_bits_needed(lo, hi) <= assumed
 
 
@@ -515,7 +541,15 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
             _MSD_BACKOFF[key] = backoff - 1
         use_msd = depth_msd if depth_msd is not None else (_DEPTH_MSD_DEFAULT and _MSD_MIN_N <= N <= _MSD_MAX_N and backoff == 0)
         plan = None
-        if cap is not None and use_msd:
+        if cap is not None and use_msd and _TABLE_REUSE and key_range is not None and _DEPTH_TABLE == "auto":
+            wait = _REUSE_BACKOFF.get(key, 0)
+            if wait:
+                _REUSE_BACKOFF[key] = wait - 1
+            elif key in _SHAPE_TABLE:
+                plan = (0, 0, "device", "reuse", _SHAPE_TABLE[key])
+            elif _SHAPE_GOOD.get(key, 0) >= _REUSE_AFTER_GOOD:   # (views alike enough for ONE equal-bucket plan: try one table)
+                plan = (0, 0, "device", "build", torch.empty(lib.gsa_depth_order_msd_table_words(), dtype=torch.int32, device=dev))
+        if plan is None and cap is not None and use_msd:
             left = _TABLE_MODE.get(key, 0)
             if left > 0:
                 _TABLE_MODE[key] = left - 1
@@ -537,10 +571,17 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
             token = _next_token()
             m_host[3] = 0
             slot = (m_host, m_event, token, guard)
-            _call("gsa_depth_order", lib.gsa_depth_order_msd, N, _ptr(depth_keys), _ptr(tile_rects), plan[0], plan[1],
-                  _ptr(key_range) if len(plan) == 3 else None,
-                  _ptr(order), _ptr(rects), _ptr(offsets), _ptr(block_owner), n_blocks, _ptr(ctl),
-                  ctypes.c_void_p(m_host.data_ptr()), token, _ptr(dws), dws_bytes, st)
+            if len(plan) == 5:   # the shape's own table: built by this call (with a margin) or by an earlier one
+                plan[4].record_stream(torch.cuda.current_stream())
+                _call("gsa_depth_order", lib.gsa_depth_order_msd_table, N, _ptr(depth_keys), _ptr(tile_rects),
+                      _ptr(key_range) if plan[3] == "build" else None, _ptr(plan[4]),
+                      _ptr(order), _ptr(rects), _ptr(offsets), _ptr(block_owner), n_blocks, _ptr(ctl),
+                      ctypes.c_void_p(m_host.data_ptr()), token, _ptr(dws), dws_bytes, st)
+            else:
+                _call("gsa_depth_order", lib.gsa_depth_order_msd, N, _ptr(depth_keys), _ptr(tile_rects), plan[0], plan[1],
+                      _ptr(key_range) if len(plan) == 3 else None,
+                      _ptr(order), _ptr(rects), _ptr(offsets), _ptr(block_owner), n_blocks, _ptr(ctl),
+                      ctypes.c_void_p(m_host.data_ptr()), token, _ptr(dws), dws_bytes, st)
         else:
             if rng is not None:
                 key_bits = _key_bits_needed(rng[0], rng[1])

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSA_ABI_VERSION 8
+#define GSA_ABI_VERSION 9
 #define GSA_SPLAT_STRIDE 16
 
 #define GSA_OK 0
@@ -191,6 +191,15 @@ int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint32_t *tile_
                         const uint32_t *key_range_dev, uint32_t *order, uint32_t *rects, uint32_t *offsets, int32_t *block_owner,
                         int n_blocks, uint32_t *ctl, uint32_t *ctl_host, uint32_t token, void *workspace,
                         size_t workspace_bytes, gsa_stream_t stream);
+/* ABI 9 -- the same with the depth table in the CALLER's memory (gsa_depth_order_msd_table_words() uint32, 16-byte aligned):
+ * built from key_range_dev, with 1/16 of the key range as margin at either end, when that is given; used as it is when
+ * key_range_dev is NULL -- the table of one view orders the later views of the same scene shape without a table launch of
+ * their own.  A view whose visible keys leave the table's cells is reported (ctl[3] bit 3, like a bucket overflow: bit 0);
+ * the ordering itself never depends on the table. */
+int gsa_depth_order_msd_table(int n, const uint32_t *depth_keys, const uint32_t *tile_rects, const uint32_t *key_range_dev,
+                              uint32_t *table, uint32_t *order, uint32_t *rects, uint32_t *offsets, int32_t *block_owner,
+                              int n_blocks, uint32_t *ctl, uint32_t *ctl_host, uint32_t token, void *workspace,
+                              size_t workspace_bytes, gsa_stream_t stream);
 int gsa_scan_tiles_sorted(int n, uint32_t *counts_offsets, int32_t *block_owner, int n_blocks, uint32_t *total,
                           void *workspace, size_t workspace_bytes, gsa_stream_t stream);
 int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offsets, const uint32_t *rects,

@@ -1380,6 +1380,55 @@ def test_views_equal_buckets_do_not_fit_move_the_shape_to_depth_tables(gsa):
         t.pop(key, None)
 
 
+def test_a_shapes_depth_table_is_reused_until_a_view_does_not_fit_it(gsa):
+    """GSPLAT_AMD_TABLE_REUSE: after eight host-planned views that held, ONE view builds the shape's depth table (with a margin)
+    and the views after it are ordered with that table -- no table launch, the same images as the exact path -- until a
+    view's keys leave its cells (the camera backs off to twice the distance): reported, repaired, and the shape is back on
+    the other plans."""
+    from gsplat_amd import scene, stages as S
+    N, W, H = 200_000, 640, 480
+    sc = scene.make_scene(N, seed=1, sh_degree=1)
+    d = {k: v.cuda().contiguous() for k, v in sc.items()}
+    K = scene.make_intrinsics(W, H).cuda()[None]
+    key = ("cuda", torch.cuda.current_device(), W, H, 0, S.bin_tile_for(W, H, 0))
+    tables = (S._CAPACITY, S._KEY_RANGE, S._MSD_BACKOFF, S._TABLE_MODE, S._MSD_STREAK, S._SHAPE_TABLE, S._SHAPE_GOOD, S._REUSE_BACKOFF)
+    for t in tables:
+        t.pop(key, None)
+    for k in S.REPAIR_STATS:
+        S.REPAIR_STATS[k] = 0
+    was, was_min = S._TABLE_REUSE, S._MSD_MIN_N
+    S._TABLE_REUSE, S._MSD_MIN_N = True, 0
+
+    def render(v, far=1.0):
+        vm = scene.make_camera(v, 4).cuda()      # (a quarter turn apart: the box looks alike from both)
+        vm = vm.clone()
+        vm[:3, 3] *= far
+        with torch.no_grad():
+            r, a, meta = gsa.rasterization(d["means3D"], d["rotations"], d["scales"], d["opacities"][:, 0].contiguous(), d["shs"],
+                                           vm[None], K, W, H, sh_degree=1)
+        return r
+
+    try:
+        exact = {v: render(v) for v in (0, 1)}                      # (first calls of the shape: exact sizes, LSD ordering)
+        calls = 0
+        while key not in S._SHAPE_TABLE and calls < 16:                            # host-planned views, then the one that builds the table
+            assert torch.equal(render(calls % 2), exact[calls % 2])
+            calls += 1
+        assert key in S._SHAPE_TABLE and calls >= S._REUSE_AFTER_GOOD and S._SHAPE_GOOD.get(key, 0) >= S._REUSE_AFTER_GOOD
+        tab = S._SHAPE_TABLE[key]
+        for i in range(6):
+            assert torch.equal(render(i % 2), exact[i % 2])                        # ... and these are ordered with it
+        assert S._SHAPE_TABLE.get(key) is tab and S.REPAIR_STATS["key_range_repairs"] == 0
+        far_exact = render(0, far=2.0)                                             # keys beyond the table's cells: reported + repaired
+        assert S.REPAIR_STATS["key_range_repairs"] == 1 and key not in S._SHAPE_TABLE and S._REUSE_BACKOFF.get(key, 0) > 0
+        assert torch.equal(render(0, far=2.0), far_exact) and torch.equal(render(1), exact[1])
+        assert S.REPAIR_STATS["key_range_repairs"] <= 2
+    finally:
+        S._TABLE_REUSE, S._MSD_MIN_N = was, was_min
+        for t in tables:
+            t.pop(key, None)
+
+
 def test_depth_cluster_falls_back_to_the_lsd_path(gsa):
     """``stages.bin_tiles`` end to end on a population with a depth cluster (20 k of 100 k keys in one bucket): the
     bucketed ordering reports the overflow, ``finalize()`` says so, the exact repeat gives the first call's bins, and
