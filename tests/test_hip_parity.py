@@ -1021,12 +1021,13 @@ def test_fused_binning_equals_emit_and_sort(gsa, W, H, N, s_max, giants):
     assert torch.equal(e.sorted_gid, a.sorted_gid) and torch.equal(e.tile_offsets, a.tile_offsets)
 
 
-@pytest.mark.parametrize("N,W,H,bt", [(200_000, 1920, 1080, 32), (1_250_000, 1920, 1080, 32), (30_000, 640, 480, 16)])
+@pytest.mark.parametrize("N,W,H,bt", [(200_000, 1920, 1080, 32), (1_250_000, 1920, 1080, 32), (30_000, 640, 480, 16),
+                                      (60_000, 1000, 700, 32), (20_000, 500, 300, 16)])
 def test_one_pass_placement_equals_the_two_pass_tile_sort(gsa, N, W, H, bt):
     """gsa_tile_bin16 without second-pass buffers (per-bin histogram rows, column scan, every id stored at its final
     place) == the two-pass tile sort + boundary search: sorted_gid and tile_offsets bit for bit, at the bench's bin grid
     (2040 bins; 170 and ~1100 record blocks: one and several rows per column-scan segment, beyond the rows a thread keeps
-    in registers) and on 16 x 16 tiles; with ids on request (what gsa_quadrant_masks reads) and with a remembered
+    in registers), on 16 x 16 tiles, and on frames that are no multiple of the bin (704 and 608 bins); with ids on request (what gsa_quadrant_masks reads) and with a remembered
     capacity above the count."""
     from gsplat_amd import scene, stages as S
     sc = scene.make_scene(N, seed=5, sh_degree=0)
@@ -1048,7 +1049,7 @@ def test_one_pass_placement_equals_the_two_pass_tile_sort(gsa, N, W, H, bt):
         finally:
             S._BIN_DIRECT = real
     m = res[False][0].finalize()[0]
-    assert m > (4_300_000 if N > 1_000_000 else 50_000)
+    assert m > (4_300_000 if N > 1_000_000 else 30_000)
     assert res[True][0]._tile is None and (res[True][2]._tile is not None) == (bt == 32)   # ids only on request
     for a, b in zip(res[False], res[True]):
         assert b.finalize() == (m, True) == a.finalize()
