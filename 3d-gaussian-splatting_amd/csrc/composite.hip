@@ -174,46 +174,6 @@ __device__ __forceinline__ bool quadrant_reach(float mx, float my, float a, floa
     return best <= thr;
 }
 
-// Which 8 x 8 quadrants of a block of Q x Q quadrants (origin (X0, Y0): pixel coordinates of its first pixel) can the
-// alpha >= 1/255 region of a splat reach?  Bit order = the compositor's quadrant slices (tile_list): Q = 2: (qy << 1) | qx;
-// Q = 4 (a 32 x 32 bin): (((j >> 1) << 1 | (i >> 1)) << 2) | ((j & 1) << 1) | (i & 1) for quadrant column i, row j.
-// Per row of quadrants (a band of 8 pixel-centre rows) the reachable region is an INTERVAL in x -- the projection of
-// (ellipse intersected with the band), a convex set -- whose ends are the ellipse's right- / leftmost points when those lie
-// inside the band and lie on the band's nearer edge otherwise: two square roots per band instead of a min-sigma search
-// per quadrant.  A SUPERSET of the per-pixel rule is all the compositor needs (it re-tests what it stages, and a record
-// that passes no pixel's alpha test blends nothing): the threshold carries quadrant_reach's margin, the interval another
-// 1e-3 px, and a conic too ill-conditioned for the closed form (needle-like splats) gets every bit.
-template <int Q>
-__device__ __forceinline__ uint32_t reach_mask(float mx, float my, float a, float b, float c, float sig_max, float X0,
-                                               float Y0) {
-    constexpr uint32_t kAll = Q == 2 ? 0xFu : 0xFFFFu;
-    const float t2 = 2.f * (sig_max * 1.0001f + 1e-4f);
-    const float D = a * c - b * b;
-    if (!(D > 1e-3f * a * c) || !(t2 > 0.f)) return kAll;
-    const float ra = __builtin_amdgcn_rcpf(a), rD = __builtin_amdgcn_rcpf(D);
-    const float vmax = __builtin_sqrtf(t2 * a * rD) + 1e-3f;                  // the ellipse's extent in y
-    const float vR = -b * __builtin_sqrtf(t2 * c * rD) * __builtin_amdgcn_rcpf(c);   // y offset of its rightmost point
-    const float k = -b * ra;                                                    // centre line: u = k v
-    const float eps = 1e-3f;
-    uint32_t m = 0;
-#pragma unroll
-    for (int j = 0; j < Q; ++j) {
-        const float v0 = (Y0 + 8.f * j + 0.5f) - my, v1 = v0 + 7.f;            // pixel centre - mean
-        const float w0 = fmaxf(v0, -vmax), w1 = fminf(v1, vmax);
-        const bool band = w0 <= w1;
-        const float vr = fminf(fmaxf(vR, w0), w1), vl = fminf(fmaxf(-vR, w0), w1);
-        const float R = k * vr + __builtin_sqrtf(fmaxf(0.f, t2 * a - D * vr * vr)) * ra + eps;
-        const float L = k * vl - __builtin_sqrtf(fmaxf(0.f, t2 * a - D * vl * vl)) * ra - eps;
-#pragma unroll
-        for (int i = 0; i < Q; ++i) {
-            const float u0 = (X0 + 8.f * i + 0.5f) - mx, u1 = u0 + 7.f;
-            const int bit = Q == 2 ? ((j << 1) | i) : (((((j >> 1) << 1) | (i >> 1)) << 2) | ((j & 1) << 1) | (i & 1));
-            m |= (band && L <= u1 && R >= u0) ? (1u << bit) : 0u;
-        }
-    }
-    return m;
-}
-
 // One thread per binned record: the quadrant mask of (bin, gaussian).  The forward compositor's waves test ONE bit of it
 // per list entry before they gather anything: of the records of a 32 x 32 bin only a fifth reach a given 8 x 8 quadrant.
 template <int SHIFT>
@@ -231,7 +191,7 @@ __global__ __launch_bounds__(256) void quadrant_mask_kernel(uint32_t m_cap, cons
     const float4 r0 = row[0], r1 = row[1], r2 = row[2];
     const int by = (int)bin / bin_w, bx = (int)bin - by * bin_w;
     constexpr int Q = 2 << SHIFT;
-    mask_out[p] = (uint16_t)reach_mask<Q>(r0.x, r0.y, r0.z, r0.w, r1.x, r2.z, (float)(bx * (kTile << SHIFT)),
+    mask_out[p] = (uint16_t)gsa_reach_mask<Q>(r0.x, r0.y, r0.z, r0.w, r1.x, r2.z, (float)(bx * (kTile << SHIFT)),
                                           (float)(by * (kTile << SHIFT)));
 }
 

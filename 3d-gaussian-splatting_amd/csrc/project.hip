@@ -301,7 +301,9 @@ __global__ __launch_bounds__(kBlock, GSA_PROJ_FWD_WAVES) void project_fwd_kernel
             lo = min(lo, (uint32_t)__shfl_xor((int)lo, d));
             hi = max(hi, (uint32_t)__shfl_xor((int)hi, d));
         }
-        if (lane == 0) reinterpret_cast<uint4 *>(key_range)[blk * (kBlock / 64) + wave] = make_uint4(lo, hi, s0, s1);
+        // (the buffer holds ceil(n / 64) entries: the waves of the last block that lie wholly beyond n have none)
+        if (lane == 0 && blk * kBlock + wave * 64 < (long)n)
+            reinterpret_cast<uint4 *>(key_range)[blk * (kBlock / 64) + wave] = make_uint4(lo, hi, s0, s1);
     }
     if (!inside) return;
     *reinterpret_cast<int2 *>(radii + 2 * i) = make_int2(rx, ry);

@@ -983,7 +983,8 @@ template <bool WANT_GID, typename ENTRY>
 __device__ __forceinline__ void emit_record(const EmitBlock &eb, uint32_t slot, const uint32_t *__restrict__ s_own,
                                             const ENTRY *__restrict__ s_g, const uint32_t *__restrict__ offsets,
                                             const uint32_t *__restrict__ rects, const uint32_t *__restrict__ order,
-                                            int tile_w, uint32_t &tile, uint32_t &gid) {
+                                            int tile_w, uint32_t &tile, uint32_t &gid, int *bin_x = nullptr,
+                                            int *bin_y = nullptr) {
     const uint32_t i = s_own[slot];
     uint4 e;
     if (i < (uint32_t)kEmitStage) {
@@ -1000,6 +1001,7 @@ __device__ __forceinline__ void emit_record(const EmitBlock &eb, uint32_t slot, 
     const int row = (int)(((float)j + 0.5f) * __uint_as_float(e.w));
     const int col = (int)j - row * wl;
     tile = (uint32_t)((y0 + row) * tile_w + x0 + col);
+    if (bin_x) { *bin_x = x0 + col; *bin_y = y0 + row; }
 }
 
 __global__ __launch_bounds__(kSortThreads) void emit_hist_kernel(int n, const uint32_t *__restrict__ order,
@@ -1148,6 +1150,9 @@ constexpr int kBinsDirect = 2048;
 #define GSA_COL_BINS 32   // bins (128 contiguous bytes of every row) per workgroup of bin_colscan: 8 -> 15.8 us, 16 -> 10.5, 32 -> 8.8, 64 -> 30.5 (32 workgroups)
 #endif
 constexpr int kColBins = GSA_COL_BINS, kColSegs = 1024 / kColBins, kColThreads = kColSegs * kColBins;
+#ifndef GSA_MASK_GROUP
+#define GSA_MASK_GROUP 2   // records whose splat-row words emit_place keeps in flight while it computes quadrant masks
+#endif
 #ifndef GSA_PLACE_XCD
 #define GSA_PLACE_XCD 1   // emit_binhist / emit_place: a workgroup's record block by live_block_id (1) or by its index (0: binning +22 us)
 #endif
@@ -1308,11 +1313,20 @@ __device__ __forceinline__ uint32_t wave_rank_round_bins(unsigned long long *mas
     return seen + below;
 }
 
-__global__ __launch_bounds__(kSortThreads) void emit_place_kernel(
+// MASK_Q (0: none; 2 / 4: a bin is MASK_Q x MASK_Q quadrants of 8 x 8 pixels -- 16 x 16 tiles / 32 x 32 bins): the record's
+// QUADRANT MASK is computed where the record is generated and stored beside its gaussian id (masks_out): which 8 x 8
+// quadrants of its bin the alpha >= 1/255 ellipse of the gaussian can reach (gsa_reach_mask) -- what a forward-compositor
+// wave tests, one bit per list entry, before it gathers anything.  The gaussian's mean / conic / ln(255 o) come out of its
+// 64-B splat row: the records of one gaussian are CONSECUTIVE slots here (3.9 of them at the bench scene), so neighbouring
+// lanes read the same line -- ~1.3 M distinct row fetches for 3.6 M records, under the LDS-bound ranking -- where a pass
+// over the PLACED records (gsa_quadrant_masks, round 3) paid one random row per record: 0.070 ms for 0.024 ms saved.
+template <int MASK_Q>
+__global__ __launch_bounds__(kSortThreads, 4) void emit_place_kernel(
     int n, const uint32_t *__restrict__ order, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ rects,
     const int32_t *__restrict__ block_owner, int tile_w, uint32_t m_cap, const uint32_t *__restrict__ m_dev,
     uint16_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int nblocks, int nb, int n_tiles,
-    const uint32_t *__restrict__ mat, const int32_t *__restrict__ tile_offsets) {
+    const uint32_t *__restrict__ mat, const int32_t *__restrict__ tile_offsets, const float *__restrict__ splat,
+    uint16_t *__restrict__ masks_out) {
     __shared__ uint32_t scratch[4];
     // two regions, each with two lives: the generation's (slot owners | staged gaussians) and the placement's (peer
     // words + the bins' first slots | wave-private 16-bit bin counters)
@@ -1330,14 +1344,18 @@ __global__ __launch_bounds__(kSortThreads) void emit_place_kernel(
     if (bid >= live) return;
     SORT_TRACE_BEGIN();
     const EmitLoads el = emit_owner_loads(offsets, rects, order, block_owner, nblocks, m_total, true, bid, n);
-    // (first slot of every bin for this block: in flight under the generation)
+    // (first slot of every bin for this block: in flight under the generation -- with masks, whose arithmetic needs the
+    // registers, under the mask computation instead)
     uint32_t base_r[kBinsDirect / kSortThreads];
     const uint32_t *row = mat + (size_t)bid * nb;
+    auto load_bases = [&]() {
 #pragma unroll
-    for (int j = 0; j < kBinsDirect / kSortThreads; ++j) {
-        const int i = min(j * kSortThreads + t, nb - 1);
-        base_r[j] = row[i] + (uint32_t)tile_offsets[min(i, n_tiles)];
-    }
+        for (int j = 0; j < kBinsDirect / kSortThreads; ++j) {
+            const int i = min(j * kSortThreads + t, nb - 1);
+            base_r[j] = row[i] + (uint32_t)tile_offsets[min(i, n_tiles)];
+        }
+    };
+    if constexpr (MASK_Q == 0) load_bases();
     const EmitBlock eb = emit_owners(el, offsets, m_total, s_val, s_g, scratch, bid);
     SORT_TRACE_MARK(0);   // loads + slot owners
     const uint32_t wbase = wave * (kSortChunk / 4);
@@ -1350,6 +1368,33 @@ __global__ __launch_bounds__(kSortThreads) void emit_place_kernel(
             emit_record<true>(eb, slot, s_val, s_g, offsets, rects, order, tile_w, k[r], v[r]);
             k[r] = min(k[r], (uint32_t)n_tiles - 1u);
             v[r] = min(v[r], (uint32_t)n - 1u);   // (the compositor gathers splat rows by this id, unchecked)
+        }
+    }
+    if constexpr (MASK_Q != 0) {
+        load_bases();
+        // kMaskGroup records' row words in flight at a time (all sixteen at once: 268 registers); the mask rides in the
+        // upper half of the bin id through the ranking, so it costs no register of its own.  (bin -> (x, y) by a reciprocal:
+        // (bin + 0.5) / tile_w is at least 0.5 / tile_w away from an integer, ids and widths are below 2^11 -- exact.)
+        constexpr int kMaskGroup = GSA_MASK_GROUP;
+        const float inv_tw = __builtin_amdgcn_rcpf((float)tile_w);
+#pragma unroll
+        for (int r0 = 0; r0 < kSortItems; r0 += kMaskGroup) {
+            float4 g4[kMaskGroup];
+            float cc[kMaskGroup], smax[kMaskGroup];
+#pragma unroll
+            for (int j = 0; j < kMaskGroup; ++j) {   // (slots beyond the block's records hold id 0: a valid row, an unused mask)
+                const float *row = splat + (size_t)v[r0 + j] * GSA_SPLAT_STRIDE;
+                g4[j] = *reinterpret_cast<const float4 *>(row);
+                cc[j] = row[4];
+                smax[j] = row[10];
+            }
+#pragma unroll
+            for (int j = 0; j < kMaskGroup; ++j) {
+                const int by = (int)(((float)k[r0 + j] + 0.5f) * inv_tw), bx = (int)k[r0 + j] - by * tile_w;
+                k[r0 + j] |= gsa_reach_mask<MASK_Q>(g4[j].x, g4[j].y, g4[j].z, g4[j].w, cc[j], smax[j],
+                                                    (float)(bx * (8 * MASK_Q)), (float)(by * (8 * MASK_Q))) << 16;
+            }
+            asm volatile("" ::: "memory");   // (keeps the next group's loads behind this group's arithmetic)
         }
     }
     __syncthreads();   // owners and staged data consumed: the regions start their second life
@@ -1365,7 +1410,8 @@ __global__ __launch_bounds__(kSortThreads) void emit_place_kernel(
     uint16_t *cnt = wave_cnt[wave];
     unsigned long long *mask = reinterpret_cast<unsigned long long *>(s_val) + wave * kRadix;
 #pragma unroll
-    for (int r = 0; r < kSortItems; ++r) rk[r] = wave_rank_round_bins(mask, cnt, k[r], wbase + r * 64 + lane < eb.live, lane);
+    for (int r = 0; r < kSortItems; ++r)
+        rk[r] = wave_rank_round_bins(mask, cnt, k[r] & 0xFFFFu, wbase + r * 64 + lane < eb.live, lane);
     __syncthreads();
     SORT_TRACE_MARK(2);   // bases to LDS + ranking
 #pragma unroll
@@ -1380,10 +1426,12 @@ __global__ __launch_bounds__(kSortThreads) void emit_place_kernel(
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         if (wbase + r * 64 + lane < eb.live) {
-            const uint32_t pos = s_base[k[r]] + (uint32_t)cnt[k[r]] + rk[r];
+            const uint32_t bin = k[r] & 0xFFFFu;
+            const uint32_t pos = s_base[bin] + (uint32_t)cnt[bin] + rk[r];
             if (pos < m_total) {   // (always, unless the depth ordering in front failed and reported it)
                 vals_out[pos] = v[r];
-                if (keys_out) keys_out[pos] = (uint16_t)k[r];
+                if (keys_out) keys_out[pos] = (uint16_t)bin;
+                if constexpr (MASK_Q != 0) masks_out[pos] = (uint16_t)(k[r] >> 16);
             }
         }
     }
@@ -2023,6 +2071,13 @@ extern "C" int gsa_tile_bin16_direct(int width, int height, int bin_tile) {
     return n_tiles > kRadix && n_tiles + 1 <= kBinsDirect ? 1 : 0;
 }
 
+// 1: gsa_tile_bin16 can leave per-record quadrant masks for this grid (sorted_mask): the one-pass placement, bins of at
+// most 4 x 4 quadrants (16 x 16 tiles or 32 x 32 bins)
+extern "C" int gsa_tile_bin16_masks(int width, int height, int bin_tile) {
+    if (bin_tile == 0) bin_tile = GSA_TILE_SIZE;
+    return gsa_tile_bin16_direct(width, height, bin_tile) && bin_tile <= 2 * GSA_TILE_SIZE ? 1 : 0;
+}
+
 // workspace of gsa_tile_bin16 for either of its paths
 extern "C" size_t gsa_tile_bin16_workspace_bytes(int width, int height, int bin_tile, uint32_t m_capacity) {
     size_t bytes = gsa_sort_workspace_bytes((int)min(m_capacity, 0x7FFFFFFFu));
@@ -2040,8 +2095,12 @@ extern "C" int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offs
                               const int32_t *block_owner, int width, int height, int bin_tile, uint32_t m_capacity,
                               const uint32_t *m_dev, uint16_t *tile_tmp,
                               uint32_t *gid_tmp, uint16_t *sorted_tile, uint32_t *sorted_gid, int32_t *tile_offsets,
+                              const float *splat, uint16_t *sorted_mask,
                               void *workspace, size_t workspace_bytes, gsa_stream_t stream) {
     GSA_RETURN_IF(n < 0 || !tile_offsets, GSA_ERR_INVALID_ARGUMENT);
+    // (masks: only where the records are placed in one pass and a bin has at most 16 quadrants -- gsa_tile_bin16_masks)
+    GSA_RETURN_IF(sorted_mask && (!splat || !gsa_tile_bin16_masks(width, height, bin_tile) || tile_tmp || gid_tmp),
+                  GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(!gsa_tile_bins_supported(width, height, bin_tile), GSA_ERR_UNSUPPORTED);
     GSA_RETURN_IF(m_capacity >= 0x7FFFFFFFu - (uint32_t)kSortChunk, GSA_ERR_UNSUPPORTED);
     // bin_tile: the side of the tiles the records are binned into -- GSA_TILE_SIZE (0 = the same), or twice that for
@@ -2073,8 +2132,14 @@ extern "C" int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offs
         bin_colscan_kernel<<<nb / kColBins, kColThreads, 0, s>>>(m_capacity, m_dev, nb, n_tiles, mat, totals, tile_offsets,
                                                                   done_counter);
         GSA_LAUNCH_CHECK();
-        emit_place_kernel<<<nblocks, kSortThreads, 0, s>>>(n, order, offsets, rects, block_owner, tile_w, m_capacity, m_dev,
-                                                           sorted_tile, sorted_gid, nblocks, nb, n_tiles, mat, tile_offsets);
+#define GSA_PLACE(Q)                                                                                                     \
+    emit_place_kernel<Q><<<nblocks, kSortThreads, 0, s>>>(n, order, offsets, rects, block_owner, tile_w, m_capacity, m_dev, \
+                                                          sorted_tile, sorted_gid, nblocks, nb, n_tiles, mat, tile_offsets, \
+                                                          splat, sorted_mask)
+        if (!sorted_mask) GSA_PLACE(0);
+        else if (bin_tile == GSA_TILE_SIZE) GSA_PLACE(2);
+        else GSA_PLACE(4);
+#undef GSA_PLACE
         GSA_LAUNCH_CHECK();
         return GSA_OK;
     }

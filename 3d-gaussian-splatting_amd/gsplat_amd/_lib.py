@@ -13,7 +13,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_u
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # GSPLAT_AMD_LIB: developer override to A/B another build of the SAME C ABI (still a HIP library; no fallback)
 LIB_PATH = os.environ.get("GSPLAT_AMD_LIB") or os.path.join(_PKG_ROOT, "lib", "libgsplat_amd.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 SPLAT_STRIDE = 16
 
 P = c_void_p  # every device pointer and the stream cross the boundary as void*
@@ -28,6 +28,7 @@ SIGNATURES = {
     "gsa_scan_tiles": (c_int, [c_int, P, P, P, P, P, c_size_t, P]),
     "gsa_tile_bin16_supported": (c_int, [c_int, c_int]),
     "gsa_tile_bin16_direct": (c_int, [c_int, c_int, c_int]),
+    "gsa_tile_bin16_masks": (c_int, [c_int, c_int, c_int]),
     "gsa_tile_bin16_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_uint32]),
     "gsa_tile_bins_supported": (c_int, [c_int, c_int, c_int]),
     "gsa_scan_tiles_rect": (c_int, [c_int, P, P, P, P, P, c_int, P, P, c_size_t, P]),
@@ -40,7 +41,7 @@ SIGNATURES = {
     "gsa_depth_order_msd": (c_int, [c_int, P, P, c_uint32, c_uint32, P, P, P, P, P, c_int, P, P, c_uint32, P, c_size_t, P]),
     "gsa_depth_order_msd_table": (c_int, [c_int, P, P, P, P, P, P, P, P, c_int, P, P, c_uint32, P, c_size_t, P]),
     "gsa_scan_tiles_sorted": (c_int, [c_int, P, P, c_int, P, P, c_size_t, P]),
-    "gsa_tile_bin16": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_uint32, P, P, P, P, P, P, P, c_size_t, P]),
+    "gsa_tile_bin16": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_uint32, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "gsa_tile_emit": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_uint32, P, P, P]),
     "gsa_tile_offsets": (c_int, [c_uint32, P, c_int, P, P]),
     "gsa_sort_pairs_u32_dev": (c_int, [c_int, P, P, P, P, P, P, P, c_int, c_int, P, c_size_t, P]),

@@ -327,12 +327,13 @@ def tile_ids(sorted_tile: torch.Tensor) -> torch.Tensor:
 _BIN_FUSED_DEFAULT = os.environ.get("GSPLAT_AMD_BIN_FUSED", "1") != "0"
 # GSPLAT_AMD_BIN_DIRECT=0: the two-pass tile sort where gsa_tile_bin16_direct offers the one-pass placement (A/B timing)
 _BIN_DIRECT = os.environ.get("GSPLAT_AMD_BIN_DIRECT", "1") != "0"
-# GSPLAT_AMD_QUAD_MASKS=1: per-record quadrant masks (gsa_quadrant_masks) for the forward compositor, which then gathers only
-# the records that can reach its quadrant.  OFF by default: measured at C3 the masked forward sweep is 0.025 ms faster
-# (0.152 -> 0.127 ms, 99.5 M -> 82.7 M vector instructions) but the mask pass costs 0.070 ms -- one random 64-B row fetch
-# per binned record, 3.7 M of them, where the compositor's own gathers meet in L2 sixteen waves at a time and stop at
-# the quarter of a list where the pixels saturate (profiles/r03_fwd_masks.md).
-_QUAD_MASKS = os.environ.get("GSPLAT_AMD_QUAD_MASKS", "0") != "0"
+# Per-record quadrant masks for the forward compositor (which then gathers only the records that can reach its quadrant:
+# 0.152 -> 0.128 ms at C3).  Where the records are placed in one pass (gsa_tile_bin16_masks) the placement kernel computes
+# them as it generates the records -- the records of one gaussian are consecutive there, so its splat row is fetched about
+# once; round 3's separate pass over the PLACED records (gsa_quadrant_masks: one random 64-B row per record, 0.070 ms) made
+# them a net loss and is now only what the other binning paths fall back to when masks are asked for explicitly
+# (``bin_tiles(quad_masks=True)``).  GSPLAT_AMD_QUAD_MASKS=0 switches the masks off (A/B).
+_QUAD_MASKS = os.environ.get("GSPLAT_AMD_QUAD_MASKS", "1") != "0"
 # (device, W, H, cull_mode) -> [records per gaussian the next call provisions for, consecutive low counts].
 # Keyed WITHOUT N: densify / prune changes N every 100 iterations (trainer.py:794-797) and a changed N predicts its
 # capacity from the remembered ratio instead of costing a blocking read-back.  Grows at once, shrinks only after many
@@ -622,11 +623,16 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
             block_owner = scan(cap)
     tile_offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
     if fused:
-        want_masks = bin_tile <= 2 * TILE_SIZE and (_QUAD_MASKS if quad_masks is None else quad_masks)
         direct = _BIN_DIRECT and bool(lib.gsa_tile_bin16_direct(width, height, bin_tile))
+        # quadrant masks: from the placement pass itself where there is one (default on); from a pass of their own over the
+        # placed records only on explicit request (quad_masks=True on a grid the one-pass placement does not take)
+        masks_inline = direct and bool(lib.gsa_tile_bin16_masks(width, height, bin_tile)) and \
+            (_QUAD_MASKS if quad_masks is None else quad_masks)
+        masks_pass = bool(quad_masks) and not masks_inline and bin_tile <= 2 * TILE_SIZE
         # (direct placement: no 16-bit ids unless the mask pass wants them, no second-pass buffers)
-        sorted_tile = None if direct and not want_masks else torch.empty(cap, dtype=torch.int16, device=dev)   # uint16 tile ids (see tile_ids)
+        sorted_tile = None if direct and not masks_pass else torch.empty(cap, dtype=torch.int16, device=dev)   # uint16 tile ids (see tile_ids)
         sorted_gid = torch.empty(cap, dtype=torch.int32, device=dev)
+        sorted_mask = torch.empty(cap, dtype=torch.int16, device=dev) if (masks_inline or masks_pass) else None
         two = n_tiles > 256 and not direct   # (n_tiles: of the bin grid)
         k_tmp = torch.empty(cap, dtype=torch.int16, device=dev) if two else None
         v_tmp = torch.empty(cap, dtype=torch.int32, device=dev) if two else None
@@ -634,12 +640,9 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
         ws2 = torch.empty(ws2_bytes, dtype=torch.uint8, device=dev)
         _call("gsa_tile_bin16", lib.gsa_tile_bin16, N, _ptr(order), _ptr(offsets), _ptr(rects), _ptr(block_owner), width,
               height, bin_tile, cap,
-              _ptr(total), _ptr(k_tmp), _ptr(v_tmp), _ptr(sorted_tile), _ptr(sorted_gid), _ptr(tile_offsets), _ptr(ws2),
-              ws2_bytes, st)
-        sorted_mask = None
-        # (optional: what a forward-compositor wave tests before it gathers a record; see _QUAD_MASKS)
-        if want_masks:
-            sorted_mask = torch.empty(cap, dtype=torch.int16, device=dev)
+              _ptr(total), _ptr(k_tmp), _ptr(v_tmp), _ptr(sorted_tile), _ptr(sorted_gid), _ptr(tile_offsets),
+              _ptr(splat) if masks_inline else None, _ptr(sorted_mask) if masks_inline else None, _ptr(ws2), ws2_bytes, st)
+        if masks_pass:
             _call("gsa_quadrant_masks", lib.gsa_quadrant_masks, cap, _ptr(total), _ptr(sorted_tile), _ptr(sorted_gid),
                   _ptr(splat), N, width, height, bin_tile, _ptr(sorted_mask), st)
         return TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key, slot, N, key_bits, keys_ok, sorted_mask)

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSA_ABI_VERSION 9
+#define GSA_ABI_VERSION 10
 #define GSA_SPLAT_STRIDE 16
 
 #define GSA_OK 0
@@ -130,10 +130,17 @@ int gsa_scan_tiles(int n, const int32_t *tiles_touched, const uint32_t *order, u
  * gsa_tile_bin16_workspace_bytes gets the lists from ONE placement pass: a per-block histogram over the bins
  * themselves, a column scan that also writes tile_offsets, and every gaussian id stored straight at its place in its
  * bin's list (no digit passes, no search for the list boundaries).  sorted_tile may then be NULL (not written): the
- * lists are sorted_gid + tile_offsets.  Same output, bit for bit, as the two-pass path. */
+ * lists are sorted_gid + tile_offsets.  Same output, bit for bit, as the two-pass path.
+ * ABI 10 -- quadrant masks from the placement pass.  Where gsa_tile_bin16_masks says 1 (the direct path, bins of 16 or 32
+ * pixels) a caller may pass splat (gsa_project_fwd's records) and sorted_mask[m_capacity] (uint16): the placement then
+ * also stores, beside every gaussian id, which 8 x 8 quadrants of the record's bin the alpha >= 1/255 ellipse of the
+ * gaussian can reach -- bit order as gsa_quadrant_masks; a superset of the per-pixel rule -- computed where the record
+ * is generated (the records of a gaussian are consecutive there: no per-record gather).  gsa_composite_fwd's
+ * sorted_mask.  Both NULL: no masks (the other paths of gsa_tile_bin16 never write any). */
 #define GSA_BIN_BLOCK 4096
 int gsa_tile_bin16_supported(int width, int height);
 int gsa_tile_bin16_direct(int width, int height, int bin_tile);
+int gsa_tile_bin16_masks(int width, int height, int bin_tile);
 size_t gsa_tile_bin16_workspace_bytes(int width, int height, int bin_tile, uint32_t m_capacity);
 /* ... for bins of bin_tile pixels (16 / 32 / 64): an 8K image has too many 16 x 16 tiles for 16-bit ids, but not 32 x 32 bins */
 int gsa_tile_bins_supported(int width, int height, int bin_tile);
@@ -206,6 +213,7 @@ int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offsets, const 
                    const int32_t *block_owner, int width, int height, int bin_tile, uint32_t m_capacity,
                    const uint32_t *m_dev, uint16_t *tile_tmp,
                    uint32_t *gid_tmp, uint16_t *sorted_tile, uint32_t *sorted_gid, int32_t *tile_offsets,
+                   const float *splat, uint16_t *sorted_mask,
                    void *workspace, size_t workspace_bytes, gsa_stream_t stream);
 
 /* For k in depth order, g = order[k]: write that gaussian's tile ids and its index g at
