@@ -231,29 +231,59 @@ __device__ __forceinline__ int stage_batch(Staged<F4> &st, int lane, const Row &
     return n;
 }
 
-// log2(e) * sigma at one pixel.  ONE expression with explicit fused steps for both kernels: the backward sweep
-// must reproduce the forward's alpha bit for bit, or a pixel's threshold decisions could differ between them.
-__device__ __forceinline__ float scaled_sigma(const float4 &q0, const float4 &q1, float dx, float dy) {
+// THE ALPHA EXPONENT of a record at the pixels of one 8 x 8 quadrant, as a POLYNOMIAL in quadrant-local coordinates (r04).
+// alpha = o exp(-sigma) = exp2(-s) with s = log2e sigma - log2 o.  With (cx, cy) the quadrant's centre, u = mean - (cx, cy)
+// and a pixel centre at (cx + x, cy + y), x, y in {-3.5 .. 3.5}:
+//   s(x, y) = A (ux - x)^2 + B (ux - x)(uy - y) + C (uy - y)^2 - log2 o = s0 + x (gx + A x + B y) + y (gy + C y)
+//   s0 = A ux^2 + B ux uy + C uy^2 - log2 o,  gx = -(2 A ux + B uy),  gy = -(B ux + 2 C uy)   (A = log2e a / 2, B = log2e b, C = log2e c / 2)
+// (s0, gx, gy) are computed ONCE per staged record by the lane that stages it (sigma_form); a pixel then pays five fused
+// multiply-adds and the exponential -- where "d = mean - pixel, d^T Q d, o * exp" cost two subtractions, five multiply-adds,
+// the exponential and a multiplication: 3 of the ~18 vector instructions of a (quadrant, record) visit, in both sweeps, and
+// the record needs neither its opacity nor its threshold in LDS: the skip rule "alpha < 1/255" is s > log2 255 for every
+// record.  Every step is an explicit fma and the form is a function of the stored record and the quadrant alone, so the
+// forward and the backward sweep evaluate bit-identical exponents: a pixel's threshold decisions never differ between
+// them.  Rounding: the terms are of the size of s0 (the exponent at the quadrant's centre, <~ 100 for a record that reaches
+// the quadrant at all), so s carries ~1e-5 absolute where the direct form carried 1e-6 -- d alpha / alpha <~ 1e-5, an order
+// below the parity bound.  What that would break is the rule "sigma < 0: skip" where a pixel centre coincides with the
+// mean of an opaque splat (true s = 0, computed -1e-6): the test therefore compares |s| (a free operand modifier).  A
+// positive-definite conic -- every conic the projection emits -- and an opacity <= 1 give no other negative.
+constexpr float kLog2Of255 = 7.994353436858858f;
+struct SigmaForm { float s0, gx, gy; };
+__device__ __forceinline__ SigmaForm sigma_form(float mx, float my, float A, float B, float C, float opacity, float cx,
+                                                float cy) {
 #pragma clang fp contract(off)
-    return __builtin_fmaf(dx, __builtin_fmaf(q0.z, dx, q0.w * dy), (q1.x * dy) * dy);
+    const float ux = mx - cx, uy = my - cy;   // (exact: |mean - centre| is small against the operands whenever the record reaches the quadrant)
+    const float Aux = A * ux, Cuy = C * uy;
+    SigmaForm f;
+    f.gx = -__builtin_fmaf(B, uy, Aux + Aux);
+    f.gy = -__builtin_fmaf(B, ux, Cuy + Cuy);
+    // (opacity 0 -- a culled or padding record -- gives s0 = +inf: alpha 0 everywhere)
+    f.s0 = __builtin_fmaf(ux, __builtin_fmaf(B, uy, Aux), Cuy * uy) - __builtin_amdgcn_logf(opacity);
+    return f;
+}
+// (x: NaN for a finished pixel -- s is then NaN and fails the alpha test)
+__device__ __forceinline__ float alpha_exponent(float s0, float gx, float gy, float A, float B, float C, float x, float y) {
+#pragma clang fp contract(off)
+    const float t1 = __builtin_fmaf(B, y, __builtin_fmaf(A, x, gx));
+    const float t2 = __builtin_fmaf(C, y, gy);
+    return __builtin_fmaf(y, t2, __builtin_fmaf(x, t1, s0));
 }
 
-// alpha of one record at one pixel, 0 if the record is skipped there.  The skip rule "sigma < 0 or
-// o exp(-sigma) < 1/255" is evaluated as ONE unsigned compare of the float bits, 0 <= s <= smax (a negative or
-// NaN s has a larger bit pattern than any smax >= 0); `off_bit` (0 or the sign bit) switches a lane off.
-// The 0.999 cap is only compiled in for batches that hold an opacity above it (exp2(-s) <= 1 otherwise keeps
+// alpha of one record at one pixel, 0 if the record is skipped there.  The skip rule "o exp(-sigma) < 1/255" is ONE
+// compare, |s| <= log2 255 (a NaN s fails it); `off` (all ones or zero) switches a lane off by turning s into a NaN
+// first.  The 0.999 cap is only compiled in for batches that hold an opacity above it (s >= -log2 o otherwise keeps
 // alpha <= o).
 template <bool CLAMP>
-__device__ __forceinline__ float record_alpha(float s, float smax, float opacity, uint32_t off_bit, float &raw, bool &hit) {
-    raw = opacity * __builtin_amdgcn_exp2f(-s);
+__device__ __forceinline__ float record_alpha(float s, uint32_t off, float &raw, bool &hit) {
+    raw = __builtin_amdgcn_exp2f(-s);
     const float al = CLAMP ? fminf(GSA_MAX_ALPHA, raw) : raw;
-    hit = (__float_as_uint(s) | off_bit) <= __float_as_uint(smax);
+    hit = __builtin_fabsf(__uint_as_float(__float_as_uint(s) | off)) <= kLog2Of255;
     return hit ? al : 0.f;
 }
 template <bool CLAMP>
-__device__ __forceinline__ float record_alpha(float s, float smax, float opacity, uint32_t off_bit, float &raw) {
+__device__ __forceinline__ float record_alpha(float s, uint32_t off, float &raw) {
     bool hit;
-    return record_alpha<CLAMP>(s, smax, opacity, off_bit, raw, hit);
+    return record_alpha<CLAMP>(s, off, raw, hit);
 }
 
 template <int F4>
@@ -270,8 +300,8 @@ __device__ __forceinline__ const float4 *rec_at(const Staged<F4> &st, uint32_t b
 template <int CH>
 struct FwdPixel {
     float T, Tend, acc[CH];
-    float x;          // the pixel centre's x -- NaN once the pixel is finished: sigma is then NaN, whose bit pattern fails the
-                      // one unsigned compare of the alpha test, so the walk needs no per-record "is this lane off" operand
+    float x;          // the pixel centre's x relative to the quadrant's centre (-3.5 .. 3.5) -- NaN once the pixel is finished: sigma
+                      // is then NaN and fails the one compare of the alpha test, so the walk needs no per-record "is this lane off" operand
     uint32_t dead;
     int last;
 };
@@ -292,7 +322,7 @@ struct FwdPixel {
 // One group of G list entries starting at entry i: per-record alpha (0 where skipped / pixel finished), colours,
 // list positions.
 template <int CH, int F4, bool CLAMP, int G, typename ST>
-__device__ __forceinline__ void eval_group(const ST &st, int i, float pxf, float pyf,
+__device__ __forceinline__ void eval_group(const ST &st, int i, float xrel, float yrel,
                                            float (&a)[G], float (&col)[G][CH], int (&idx)[G],
                                            unsigned long long (&passed)[G]) {
     uint32_t off[G];
@@ -310,14 +340,14 @@ __device__ __forceinline__ void eval_group(const ST &st, int i, float pxf, float
     for (int e = 0; e < G; ++e) {
         const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(st.rec) + off[e]);
         const float4 q0 = p[0], q1 = p[1], q2 = p[2];
-        const float dx = q0.x - pxf, dy = q0.y - pyf;
         float raw;
         bool hit;
-        a[e] = record_alpha<CLAMP>(scaled_sigma(q0, q1, dx, dy), q2.y, q1.y, 0u, raw, hit);   // (pxf is NaN for a finished pixel)
+        // (xrel is NaN for a finished pixel)
+        a[e] = record_alpha<CLAMP>(alpha_exponent(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, xrel, yrel), 0u, raw, hit);
         passed[e] = __ballot(hit);   // the compare's own lane mask: which pixels take this record (no extra VALU)
         col[e][0] = q1.z; col[e][1] = q1.w; col[e][2] = q2.x;
-        if (CH == 4) col[e][CH - 1] = p[F4 - 1].x;
-        idx[e] = __float_as_int(q2.z);
+        if (CH == 4) col[e][CH - 1] = q2.z;
+        idx[e] = __float_as_int(q2.y);
     }
 }
 
@@ -338,7 +368,7 @@ __device__ __forceinline__ void note_taken(unsigned long long &contrib, unsigned
 // LISTS: `contrib` receives one bit per list entry that was BLENDED at one pixel of the quadrant at least (alpha test
 // passed, pixel live and not stopping there) -- the records the backward sweep has to visit here.
 template <int CH, int F4, bool CLAMP, int LISTS, typename ST>
-__device__ __forceinline__ bool walk_fwd(const ST &st, int n, float pyf, FwdPixel<CH> &px,
+__device__ __forceinline__ bool walk_fwd(const ST &st, int n, float yrel, FwdPixel<CH> &px,
                                          unsigned long long &contrib) {
     constexpr int G = GSA_FWD_GROUP;
     int i = 0;
@@ -349,7 +379,7 @@ __device__ __forceinline__ bool walk_fwd(const ST &st, int n, float pyf, FwdPixe
             float a[G], col[G][CH], t[G + 1];
             int idx[G];
             unsigned long long passed[G];
-            eval_group<CH, F4, CLAMP, G>(st, i, px.x, pyf, a, col, idx, passed);
+            eval_group<CH, F4, CLAMP, G>(st, i, px.x, yrel, a, col, idx, passed);
             t[0] = px.T;
             // T (1 - alpha) as ONE fused step, here and on the careful path: the rounding must not depend on the path
 #pragma unroll
@@ -375,7 +405,7 @@ __device__ __forceinline__ bool walk_fwd(const ST &st, int n, float pyf, FwdPixe
             float a[G], col[G][CH];
             int idx[G];
             unsigned long long passed[G];
-            eval_group<CH, F4, CLAMP, G>(st, i, px.x, pyf, a, col, idx, passed);
+            eval_group<CH, F4, CLAMP, G>(st, i, px.x, yrel, a, col, idx, passed);
 #pragma unroll
             for (int e = 0; e < G; ++e) {
                 const float ae = px.dead ? 0.f : a[e];      // a pixel that stopped earlier in this group
@@ -408,6 +438,10 @@ __device__ __forceinline__ bool walk_fwd(const ST &st, int n, float pyf, FwdPixe
 //          survivors written to CONSECUTIVE slots of the wave's LDS image -- so that
 //   WALK   needs no offset list: slot i of the image is entry i of the walk (walk_fwd with a dense image).
 // Without masks (sorted_mask == NULL: the 32-bit binning paths) every entry is a candidate and STAGE's test is the filter.
+// The wave's LDS image, three float4 per staged record:
+//   [0] s0  gx  gy  A          (the record's alpha exponent for THIS quadrant: sigma_form / alpha_exponent)
+//   [1] B  C  r  g
+//   [2] b  (int) position in the sorted list  depth  -
 constexpr int kQueue = 256;        // candidates: < 64 left over + 128 from one scan step
 constexpr int kScanWin = 2;        // windows of 64 entries per scan step
 template <int F4>
@@ -420,15 +454,17 @@ struct Dense {
 // LISTS: additionally writes, per quadrant, the list positions of the records that were blended there
 // (quad_list[4 * start + q * (end - start) ...], ascending) and their number (quad_count[4 * tile + q]): the backward
 // sweep then visits exactly those, without a reach test and in full batches.
+// (register budget: seven waves per SIMD for the three-channel instances -- 72 registers; a handful of values of the
+// prologue and the staging step then live in scratch, none of the walk's; the four-channel instances keep what they need)
 template <int CH, int LISTS, bool HAS_MASK>
-__global__ __launch_bounds__(kWave, GSA_FWD_WAVES) void composite_fwd_kernel(
+__global__ __launch_bounds__(kWave, (CH == 3 ? 7 : GSA_FWD_WAVES)) void composite_fwd_kernel(
     int width, int height, int tile_w, int n_tiles, int bin_shift, const float *__restrict__ splat,
     const uint32_t *__restrict__ sorted_gid, const uint16_t *__restrict__ sorted_mask,
     const int32_t *__restrict__ tile_offsets,
     const float *__restrict__ background, const int32_t *__restrict__ tile_order, float *__restrict__ render,
     float *__restrict__ alpha_out, float *__restrict__ final_T, int32_t *__restrict__ last_id,
     uint32_t *__restrict__ quad_list, int32_t *__restrict__ quad_count, float4 *__restrict__ zero4, long n_zero4) {
-    constexpr int F4 = CH == 4 ? 4 : 3;
+    constexpr int F4 = 3;   // (the depth channel's value rides in the third quad)
     __shared__ Dense<F4> st;
 
     // zero4 (optional): the gradient records the backward sweep will accumulate into.  Every wave clears its share on
@@ -449,14 +485,15 @@ __global__ __launch_bounds__(kWave, GSA_FWD_WAVES) void composite_fwd_kernel(
     const int qx = tx * kTile + (q & 1) * 8, qy = ty * kTile + (q >> 1) * 8;
     const int px_ = qx + (lane & 7), py_ = qy + (lane >> 3);
     const bool inside = px_ < width && py_ < height;
-    const float pxf = px_ + 0.5f, pyf = py_ + 0.5f, qx0 = qx + 0.5f, qy0 = qy + 0.5f;
+    const float qx0 = qx + 0.5f, qy0 = qy + 0.5f, qcx = qx + 4.f, qcy = qy + 4.f;   // first pixel centre; the quadrant's centre
+    const float xrel = (float)(lane & 7) - 3.5f, yrel = (float)(lane >> 3) - 3.5f;    // this lane's pixel centre relative to it
     int start, end, slice;   // this tile's record list (its bin's), and which of the bin's quadrant slices is this wave's
     tile_list(tile_offsets, tile, tile_w, bin_shift, q, start, end, slice);
     const uint32_t my_bit = HAS_MASK ? 1u << slice : 1u;   // (no masks: every entry carries 0xFFFF)
 
     FwdPixel<CH> px;
     px.T = 1.f; px.Tend = 1.f; px.dead = inside ? 0u : kSign; px.last = -1;
-    px.x = inside ? pxf : __builtin_nanf("");
+    px.x = inside ? xrel : __builtin_nanf("");
 #pragma unroll
     for (int k = 0; k < CH; ++k) px.acc[k] = 0.f;
     int listed = 0;   // LISTS: entries written to this quadrant's list so far (wave-uniform)
@@ -527,17 +564,19 @@ __global__ __launch_bounds__(kWave, GSA_FWD_WAVES) void composite_fwd_kernel(
             const int n = __builtin_popcountll(hb);
             const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0));
             if (hit) {
-                st.rec[F4 * slot + 0] = make_float4(r0.x, r0.y, 0.5f * kLog2e * r0.z, kLog2e * r0.w);
-                st.rec[F4 * slot + 1] = make_float4(0.5f * kLog2e * r1.x, r1.y, r1.z, r1.w);
-                st.rec[F4 * slot + 2] = make_float4(r2.x, fmaxf(0.f, kLog2e * r2.z), __int_as_float(cur.pos), __uint_as_float(cur.row.gid));
-                if (F4 == 4) st.rec[F4 * slot + 3] = make_float4(r2.y, 0.f, 0.f, 0.f);
+                const float A = 0.5f * kLog2e * r0.z, B = kLog2e * r0.w, C = 0.5f * kLog2e * r1.x;
+                const SigmaForm f = sigma_form(r0.x, r0.y, A, B, C, r1.y, qcx, qcy);
+                st.rec[F4 * slot + 0] = make_float4(f.s0, f.gx, f.gy, A);
+                st.rec[F4 * slot + 1] = make_float4(B, C, r1.z, r1.w);
+                st.rec[F4 * slot + 2] = make_float4(r2.x, __int_as_float(cur.pos), r2.y, 0.f);
             }
-            // NULL records (opacity 0: blend nothing) pad the walk to whole groups; they carry the list position of the
+            // NULL records (exponent +inf: alpha 0) pad the walk to whole groups; they carry the list position of the
             // last real entry (a pixel that is live behind the group has "seen" exactly that far)
             const int last_pos = __builtin_amdgcn_readlane(cur.pos, hb ? 63 - __builtin_clzll(hb) : 0);
             if (lane < (GSA_FWD_GROUP - 1) * F4) {
                 float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (lane % F4 == 2) z.z = __int_as_float(last_pos);
+                if (lane % F4 == 0) z.x = __builtin_inff();
+                if (lane % F4 == 2) z.y = __int_as_float(last_pos);
                 st.rec[F4 * n + lane] = z;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -547,14 +586,14 @@ __global__ __launch_bounds__(kWave, GSA_FWD_WAVES) void composite_fwd_kernel(
             cur = pop();          // the next batch's gather is in flight during the walk
             GSA_TRACE_COUNT(n);
             unsigned long long contrib = 0ull;
-            const bool live = any_cap ? walk_fwd<CH, F4, true, LISTS>(st, n, pyf, px, contrib)
-                                      : walk_fwd<CH, F4, false, LISTS>(st, n, pyf, px, contrib);
+            const bool live = any_cap ? walk_fwd<CH, F4, true, LISTS>(st, n, yrel, px, contrib)
+                                      : walk_fwd<CH, F4, false, LISTS>(st, n, yrel, px, contrib);
             if (LISTS == 1) contrib = ~0ull;                   // every record the reach test kept
             contrib &= n >= 64 ? ~0ull : (1ull << n) - 1ull;   // the padding (null) entries "pass" with alpha 0
             if (LISTS && contrib) {   // lane i < n <-> walk entry i: append the blended ones, in list order
                 const bool mine = (contrib >> lane) & 1ull;
                 const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(contrib >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)contrib, 0));
-                if (mine) my_list[listed + rank] = (uint32_t)__float_as_int(st.rec[F4 * lane + 2].z);
+                if (mine) my_list[listed + rank] = (uint32_t)__float_as_int(st.rec[F4 * lane + 2].y);
                 listed += __builtin_popcountll(contrib);
             }
             GSA_TRACE_MARK(4);
@@ -648,8 +687,8 @@ __device__ __forceinline__ float reduce_quad(const float *v, int lane) {
 
 // Walks n list entries (records in REVERSE list order), four per trip.
 template <int CH, int F4, bool CLAMP>
-__device__ __forceinline__ void walk_bwd(const Staged<F4> &st, int n, int lane, float pxf, float pyf, int binf,
-                                         const float (&vout)[CH], float &T, float &Wd, int my_field, bool my_add,
+__device__ __forceinline__ void walk_bwd(const Staged<F4> &st, int n, int lane, float pxf, float pyf, float qcx, float qcy,
+                                         int binf, const float (&vout)[CH], float &T, float &Wd, int my_field, bool my_add,
                                          float *__restrict__ v_splat) {
     constexpr int NF = 6 + CH;
     for (int i = 0; i < n; i += 4) {
@@ -662,10 +701,14 @@ __device__ __forceinline__ void walk_bwd(const Staged<F4> &st, int n, int lane, 
             const float4 q0 = p[0], q1 = p[1], q2 = p[2];
             const float dx = q0.x - pxf, dy = q0.y - pyf;
             // the pixel stopped in front of this record (its list position is beyond the pixel's last one):
-            // binf - position is negative, its sign bit switches the lane off
-            const uint32_t off_bit = (uint32_t)(binf - __float_as_int(q2.z)) & kSign;
+            // binf - position is negative, its sign switches the lane off
+            const uint32_t off = (uint32_t)((binf - __float_as_int(q2.z)) >> 31);
+            // (this sweep is not the hot one: it recomputes the record's sigma form -- the SAME arithmetic on the same
+            // stored record as the forward's staging lane, so the same bits -- instead of staging it)
+            const SigmaForm f = sigma_form(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, qcx, qcy);
             float raw;
-            const float a = record_alpha<CLAMP>(scaled_sigma(q0, q1, dx, dy), q2.y, q1.y, off_bit, raw);
+            const float a = record_alpha<CLAMP>(alpha_exponent(f.s0, f.gx, f.gy, q0.z, q0.w, q1.x, pxf - qcx, pyf - qcy),
+                                                off, raw);
             // a == 0: ra = 1, fac = 0 -- T, Wd and the sums pass through unchanged, no selects needed
             const float ra = __builtin_amdgcn_rcpf(1.f - a);
             const float Tn = T * ra;             // transmittance in front of this splat
@@ -738,7 +781,7 @@ __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_kernel(
     const int qx = tx * kTile + (q & 1) * 8, qy = ty * kTile + (q >> 1) * 8;
     const int px = qx + (lane & 7), py = qy + (lane >> 3);
     const bool inside = px < width && py < height;
-    const float pxf = px + 0.5f, pyf = py + 0.5f, qx0 = qx + 0.5f, qy0 = qy + 0.5f;
+    const float pxf = px + 0.5f, pyf = py + 0.5f, qx0 = qx + 0.5f, qy0 = qy + 0.5f, qcx = qx + 4.f, qcy = qy + 4.f;
 
     // per pixel: T = transmittance behind the current record; Wd = T_final (v_alpha - bg.v_out) - sum of
     // (colour . v_out) * weight over the splats behind -- what d(out)/d(alpha_i) multiplies by 1/(1-alpha_i)
@@ -783,372 +826,74 @@ __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_kernel(
         gid_next = load_gid(j + 2);
         GSA_TRACE_COUNT(n);
         if (any_cap)
-            walk_bwd<CH, F4, true>(st, n, lane, pxf, pyf, binf, vout, T, Wd, my_field, my_add, v_splat);
+            walk_bwd<CH, F4, true>(st, n, lane, pxf, pyf, qcx, qcy, binf, vout, T, Wd, my_field, my_add, v_splat);
         else
-            walk_bwd<CH, F4, false>(st, n, lane, pxf, pyf, binf, vout, T, Wd, my_field, my_add, v_splat);
+            walk_bwd<CH, F4, false>(st, n, lane, pxf, pyf, qcx, qcy, binf, vout, T, Wd, my_field, my_add, v_splat);
         GSA_TRACE_MARK(4);
     }
     GSA_TRACE_END(1, tile * 4 + q, qmax + 1 - start);
 }
 
-// The same sweep over the forward pass's per-quadrant lists of BLENDED records (composite_fwd_kernel<CH, true>): no
-// reach test, no compaction, every staged record is walked -- full batches of 64, and none of the ~10 % of reach-test
-// survivors that blend nowhere.  Lane l of batch j holds list entry count - 1 - 64 j - l (walk order = reverse).
-template <int F4>
-__device__ __forceinline__ int stage_listed(Staged<F4> &st, int lane, const Row &row, bool valid, int idx, bool &any_cap) {
-    const float4 r0 = row.r0, r1 = row.r1, r2 = row.r2;
-    st.rec[F4 * lane + 0] = make_float4(r0.x, r0.y, 0.5f * kLog2e * r0.z, kLog2e * r0.w);
-    st.rec[F4 * lane + 1] = make_float4(0.5f * kLog2e * r1.x, r1.y, r1.z, r1.w);
-    st.rec[F4 * lane + 2] = make_float4(r2.x, fmaxf(0.f, kLog2e * r2.z), __int_as_float(idx), __uint_as_float(row.gid));
-    if (F4 == 4) st.rec[F4 * lane + 3] = make_float4(r2.y, 0.f, 0.f, 0.f);
-    const unsigned long long b = __ballot(valid);          // valid lanes are a prefix: lane < n
-    any_cap = __ballot(valid && r1.y > GSA_MAX_ALPHA) != 0ull;
-    const int n = __builtin_popcountll(b);
-    st.list[lane] = (uint16_t)(lane * Staged<F4>::kRecBytes);
-    if (lane < 3) st.list[n + lane] = (uint16_t)(kBatch * Staged<F4>::kRecBytes);
-    const int last_idx = __builtin_amdgcn_readlane(idx, n ? n - 1 : 0);
-    if (lane < F4) {
-        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lane == 2) z.z = __int_as_float(last_idx);
-        st.rec[kBatch * F4 + lane] = z;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    return n;
-}
-
-#ifdef GSA_DEV_KERNELS   // superseded sweeps over the lists, kept for A/B in developer builds (gsa_debug_set_bwd_mode)
-template <int CH>
-__global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_list_kernel(
-    int width, int height, int tile_w, int n_tiles, int bin_shift, const float *__restrict__ splat,
-    const uint32_t *__restrict__ sorted_gid, const int32_t *__restrict__ tile_offsets,
-    const float *__restrict__ background, const int32_t *__restrict__ tile_order, const float *__restrict__ final_T,
-    const int32_t *__restrict__ last_id, const float *__restrict__ v_render, const float *__restrict__ v_alpha,
-    const uint32_t *__restrict__ quad_list, const int32_t *__restrict__ quad_count, float *__restrict__ v_splat) {
-    constexpr int F4 = CH == 4 ? 4 : 3;
-    constexpr int NF = 6 + CH;
-    __shared__ Staged<F4> st;
-
-    int tile, q;
-    wave_unit(blockIdx.x, n_tiles, tile_order, tile, q);
-    if (tile >= n_tiles) return;
-    const int lane = threadIdx.x;
-    const int count = __builtin_amdgcn_readfirstlane(quad_count[4 * tile + q]);
-    if (count <= 0) return;
-    int start, end, slice;   // this tile's record list (its bin's), and which of the bin's quadrant slices is this wave's
-    tile_list(tile_offsets, tile, tile_w, bin_shift, q, start, end, slice);
-    const uint32_t *my_list = quad_list + (((size_t)start << 2) << (2 * bin_shift)) + (size_t)slice * (size_t)(end - start);
-    GSA_TRACE_BEGIN();
-    const int tx = tile % tile_w, ty = tile / tile_w;
-    const int qx = tx * kTile + (q & 1) * 8, qy = ty * kTile + (q >> 1) * 8;
-    const int px = qx + (lane & 7), py = qy + (lane >> 3);
-    const bool inside = px < width && py < height;
-    const float pxf = px + 0.5f, pyf = py + 0.5f;
-
-    const size_t pix = inside ? (size_t)py * width + px : 0;
-    const int binf = inside ? last_id[pix] : -1;   // last list position the pixel saw while live
-
-    // software pipeline three deep: list entries of batch j+2, ids of batch j+1, records of batch j
-    auto load_pos = [&](int j) -> int {
-        const int e = count - 1 - j * kBatch - lane;
-        return e >= 0 ? (int)my_list[e] : -1;
-    };
-    auto load_gid = [&](int pos) -> uint32_t { return pos >= 0 ? sorted_gid[pos] : 0u; };
-    int pos_cur = load_pos(0);
-    int pos_next = load_pos(1);
-    uint32_t gid_cur = load_gid(pos_cur);
-    const float Tf = inside ? final_T[pix] : 1.f;
-    float T = Tf;
-    float vout[CH], bgdot = 0.f;
-#pragma unroll
-    for (int k = 0; k < CH; ++k) {
-        vout[k] = inside ? v_render[pix * CH + k] : 0.f;
-        if (background) bgdot += background[k] * vout[k];
-    }
-    float Wd = Tf * (((inside && v_alpha) ? v_alpha[pix] : 0.f) - bgdot);
-    Row row = load_row(splat, gid_cur, pos_cur >= 0);
-    uint32_t gid_next = load_gid(pos_next);
-    int pos_next2 = load_pos(2);
-
-    const int my_r = (lane & 1) ? 2 : ((lane >> 1) & 1);
-    const int my_field = 2 * (2 * my_r + ((lane >> 4) & 1)) + ((lane >> 5) & 1);
-    const bool my_add = my_field < NF && (!(lane & 1) || !(lane & (2 | 16)));
-
-    GSA_TRACE_MARK(0);
-    for (int done = 0, j = 0; done < count; done += kBatch, ++j) {
-        bool any_cap;
-        const int n = stage_listed(st, lane, row, pos_cur >= 0, pos_cur, any_cap);
-        GSA_TRACE_MARK(1);
-        row = load_row(splat, gid_next, pos_next >= 0);
-        pos_cur = pos_next;
-        gid_next = load_gid(pos_next2);
-        pos_next = pos_next2;
-        pos_next2 = load_pos(j + 3);
-        GSA_TRACE_COUNT(n);
-        if (any_cap)
-            walk_bwd<CH, F4, true>(st, n, lane, pxf, pyf, binf, vout, T, Wd, my_field, my_add, v_splat);
-        else
-            walk_bwd<CH, F4, false>(st, n, lane, pxf, pyf, binf, vout, T, Wd, my_field, my_add, v_splat);
-        GSA_TRACE_MARK(4);
-    }
-    GSA_TRACE_END(1, tile * 4 + q, count);
-}
-
-// ------------------------------------------------------------------------------------------------
-// backward, record-parallel: lanes = (4 pixels) x (16 records), transmittance by a prefix scan over the records
-// ------------------------------------------------------------------------------------------------
-// The pixel-parallel sweep above sums 9 (10) moment contributions per record over the 64 pixel lanes: ~20 cross-lane
-// instructions per record -- 29 % of that kernel (profiles/r02_bwd_ablation.md).  Here a row of 16 lanes holds 16
-// consecutive records of the quadrant's list (walk order) and the four rows work on four different pixels.  What a
-// pixel needs from the records in front of it is a PREFIX: the transmittance in front of record m is
-// T_carry * prod_{m' <= m} 1 / (1 - alpha_m'), and the colour still to come behind it is Wd_carry - sum_{m' < m}
-// fac_m' (c_m' . v_out): two inclusive scans over the 16 lanes of a row (4 row_shr DPP steps each), the carries kept
-// per pixel in LDS.  Every lane then ACCUMULATES its record's moments over the pixels it visits in registers (plain
-// fused multiply-adds, no cross-lane traffic); per 16 records one short fold over the four rows (2 levels) and one
-// transposition through LDS turn them into four atomic instructions of four whole 64-B gradient records each.
-// The pixel loop only visits the pixels that can still be behind a record of the sub-batch (last list position the
-// pixel saw >= smallest position in the sub-batch): the sweep starts at the deep end of the lists, where few pixels
-// are left.  alpha is recomputed with the forward's expression (scaled_sigma / record_alpha), so both passes take
-// identical decisions.
-template <int CH>
-struct PixState {              // per-wave pixel table; entry kWave is a NULL pixel (sees no record) padding the lists
-    float4 a[kWave + 1];       // v_out r, g, b; bits of the last list position the pixel saw while live
-    float4 b[kWave + 1];       // T behind the current record, Wd (see composite_bwd_kernel), pixel centre x, y
-    float d[kWave + 1];        // v_out of the depth channel (CH == 4)
-    float tile[16 * 16];       // epilogue: [record][field] totals of one sub-batch
-    uint8_t plist[kWave + 8];  // the sub-batch's live pixels, compacted
-};
-
-// inclusive scans over the 16 lanes of a DPP row; a lane without a source keeps its own value (no bound_ctrl: the
-// instruction is disabled there), which is the scan's identity step.  s_nop 1: see fold8.
-__device__ __forceinline__ float row_scan_mul(float x) {
-    asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf"
-                 : "+v"(x));
-    return x;
-}
-__device__ __forceinline__ float row_scan_add(float x) {
-    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf"
-                 : "+v"(x));
-    return x;
-}
-
-// One sub-batch: the 16 records st.rec[s0 .. s0 + nv) against the `iters` groups of four live pixels in ps.plist.
-// acc[f]: this lane's share (its row's pixels) of field f of ITS record (lane & 15).
-template <int CH, int F4, bool CLAMP>
-__device__ __forceinline__ void sweep16(const Staged<F4> &st, PixState<CH> &ps, int lane, int s0, int nv, int iters,
-                                        float (&acc)[6 + CH]) {
-    const int m = lane & 15, rowi = lane >> 4;
-    // invalid lanes of a short sub-batch hold the null record (opacity 0: alpha 0 everywhere)
-    const float4 *p = &st.rec[F4 * (m < nv ? s0 + m : kBatch)];
-    const float4 q0 = p[0], q1 = p[1], q2 = p[2];
-    const float depth = CH == 4 ? p[F4 - 1].x : 0.f;
-    const int pos = __float_as_int(q2.z);
-    for (int i = 0; i < iters; ++i) {
-        const int pi = ps.plist[4 * i + rowi];
-        const float4 A = ps.a[pi], B = ps.b[pi];
-        const float dx = q0.x - B.z, dy = q0.y - B.w;
-        const uint32_t off_bit = (uint32_t)(__float_as_int(A.w) - pos) & kSign;   // the pixel stopped in front of it
-        float raw;
-        const float a = record_alpha<CLAMP>(scaled_sigma(q0, q1, dx, dy), q2.y, q1.y, off_bit, raw);
-        const float ra = __builtin_amdgcn_rcpf(1.f - a);      // a == 0: 1
-        const float Tn = B.x * row_scan_mul(ra);              // transmittance in front of this record
-        const float fac = a * Tn;
-        float cv = q1.z * A.x + q1.w * A.y + q2.x * A.z;
-        if (CH == 4) cv += depth * ps.d[pi];
-        const float fc = fac * cv;
-        const float S = row_scan_add(fc);                     // inclusive: fac (c . v_out) of the records up to this one
-        const float v_a = Tn * cv + ra * (B.y - (S - fc));
-        const float u = CLAMP ? ((a == raw) ? -raw * v_a : 0.f) : -a * v_a;
-        const float udx = u * dx, udy = u * dy;
-        acc[0] = __builtin_fmaf(u, dx, acc[0]);
-        acc[1] = __builtin_fmaf(u, dy, acc[1]);
-        acc[2] = __builtin_fmaf(udx, dx, acc[2]);
-        acc[3] = __builtin_fmaf(udx, dy, acc[3]);
-        acc[4] = __builtin_fmaf(udy, dy, acc[4]);
-        acc[5] += u;
-        acc[6] = __builtin_fmaf(fac, A.x, acc[6]);
-        acc[7] = __builtin_fmaf(fac, A.y, acc[7]);
-        acc[8] = __builtin_fmaf(fac, A.z, acc[8]);
-        if (CH == 4) acc[6 + CH - 1] = __builtin_fmaf(fac, ps.d[pi], acc[6 + CH - 1]);
-        if (m == 15) {   // the row's last lane holds the pixel's state behind the whole sub-batch
-            float2 *carry = reinterpret_cast<float2 *>(&ps.b[pi]);
-            *carry = make_float2(Tn, B.y - S);
-        }
-    }
-}
-
-template <int CH>
-__global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_scan_kernel(
-    int width, int height, int tile_w, int n_tiles, int bin_shift, const float *__restrict__ splat,
-    const uint32_t *__restrict__ sorted_gid, const int32_t *__restrict__ tile_offsets,
-    const float *__restrict__ background, const int32_t *__restrict__ tile_order, const float *__restrict__ final_T,
-    const int32_t *__restrict__ last_id, const float *__restrict__ v_render, const float *__restrict__ v_alpha,
-    const uint32_t *__restrict__ quad_list, const int32_t *__restrict__ quad_count, float *__restrict__ v_splat) {
-    constexpr int F4 = CH == 4 ? 4 : 3;
-    constexpr int NF = 6 + CH;
-    __shared__ Staged<F4> st;
-    __shared__ PixState<CH> ps;
-
-    int tile, q;
-    wave_unit(blockIdx.x, n_tiles, tile_order, tile, q);
-    if (tile >= n_tiles) return;
-    const int lane = threadIdx.x;
-    const int count = __builtin_amdgcn_readfirstlane(quad_count[4 * tile + q]);
-    if (count <= 0) return;
-    int start, end, slice;   // this tile's record list (its bin's), and which of the bin's quadrant slices is this wave's
-    tile_list(tile_offsets, tile, tile_w, bin_shift, q, start, end, slice);
-    const uint32_t *my_list = quad_list + (((size_t)start << 2) << (2 * bin_shift)) + (size_t)slice * (size_t)(end - start);
-    const int tx = tile % tile_w, ty = tile / tile_w;
-    const int qx = tx * kTile + (q & 1) * 8, qy = ty * kTile + (q >> 1) * 8;
-    const int px = qx + (lane & 7), py = qy + (lane >> 3);
-    const bool inside = px < width && py < height;
-
-    // software pipeline three deep, as in composite_bwd_list_kernel
-    auto load_pos = [&](int j) -> int {
-        const int e = count - 1 - j * kBatch - lane;
-        return e >= 0 ? (int)my_list[e] : -1;
-    };
-    auto load_gid = [&](int pos) -> uint32_t { return pos >= 0 ? sorted_gid[pos] : 0u; };
-    int pos_cur = load_pos(0);
-    int pos_next = load_pos(1);
-    uint32_t gid_cur = load_gid(pos_cur);
-
-    // pixel table (lane p = pixel p of the quadrant)
-    const size_t pix = inside ? (size_t)py * width + px : 0;
-    const int binf = inside ? last_id[pix] : -1;   // last list position the pixel saw while live
-    {
-        const float Tf = inside ? final_T[pix] : 1.f;
-        float vout[CH], bgdot = 0.f;
-#pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            vout[k] = inside ? v_render[pix * CH + k] : 0.f;
-            if (background) bgdot += background[k] * vout[k];
-        }
-        const float Wd = Tf * (((inside && v_alpha) ? v_alpha[pix] : 0.f) - bgdot);
-        ps.a[lane] = make_float4(vout[0], vout[1], vout[2], __int_as_float(binf));
-        ps.b[lane] = make_float4(Tf, Wd, px + 0.5f, py + 0.5f);
-        if (CH == 4) ps.d[lane] = vout[CH - 1];
-        if (lane == 0) {
-            ps.a[kWave] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-            ps.b[kWave] = make_float4(1.f, 0.f, 0.f, 0.f);
-            if (CH == 4) ps.d[kWave] = 0.f;
-        }
-    }
-    Row row = load_row(splat, gid_cur, pos_cur >= 0);
-    uint32_t gid_next = load_gid(pos_next);
-    int pos_next2 = load_pos(2);
-    const int m = lane & 15, rowi = lane >> 4;
-    const int fb = 2 * (rowi & 1) + (rowi >> 1);   // after the row fold this lane holds fields fb, fb + 4, fb + 8
-
-    for (int done = 0, j = 0; done < count; done += kBatch, ++j) {
-        bool any_cap;
-        const int n = stage_listed(st, lane, row, pos_cur >= 0, pos_cur, any_cap);
-        row = load_row(splat, gid_next, pos_next >= 0);
-        pos_cur = pos_next;
-        gid_next = load_gid(pos_next2);
-        pos_next = pos_next2;
-        pos_next2 = load_pos(j + 3);
-        for (int s0 = 0; s0 < n; s0 += 16) {
-            const int nv = min(16, n - s0);
-            // live pixels of this sub-batch: those whose last seen position is not in front of all its records
-            const int pos_lo = __builtin_amdgcn_readfirstlane(__float_as_int(st.rec[F4 * (s0 + nv - 1) + 2].z));
-            const unsigned long long lv = __ballot(binf >= pos_lo);
-            if (lv == 0ull) continue;
-            const int np = __builtin_popcountll(lv);
-            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(lv >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lv, 0));
-            if ((lv >> lane) & 1ull) ps.plist[rank] = (uint8_t)lane;
-            if (lane < 3) ps.plist[np + lane] = (uint8_t)kWave;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            float acc[NF];
-#pragma unroll
-            for (int f = 0; f < NF; ++f) acc[f] = 0.f;
-            const int iters = (np + 3) >> 2;
-            if (any_cap) sweep16<CH, F4, true>(st, ps, lane, s0, nv, iters, acc);
-            else sweep16<CH, F4, false>(st, ps, lane, s0, nv, iters, acc);
-            // sum over the four rows (lanes with equal record): fold32 leaves sum(field 2 i + half) in each half,
-            // fold16 sum(field 4 k + 2 (row & 1) + half) in each row
-            const float a9 = NF == 10 ? acc[NF - 1] : 0.f;
-            const float n0 = fold32(acc[0], acc[1]), n1 = fold32(acc[2], acc[3]), n2 = fold32(acc[4], acc[5]),
-                        n3 = fold32(acc[6], acc[7]), n4 = fold32(acc[8], a9);
-            const float r0 = fold16(n0, n1), r1 = fold16(n2, n3), r2 = fold16(n4, n4);
-            ps.tile[16 * m + fb] = r0;
-            ps.tile[16 * m + fb + 4] = r1;
-            ps.tile[16 * m + fb + 8] = r2;       // fields 8 .. 11: those >= NF are never read back
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // one atomic instruction per four records: lanes (record 4 t + row, field m) cover four 64-B records
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int r = 4 * t + rowi;
-                if (4 * t < nv) {
-                    const float total = ps.tile[64 * t + lane];
-                    if (m < NF && r < nv) {
-                        const uint32_t g = __float_as_uint(st.rec[F4 * (s0 + r) + 2].w);
-                        atomicAdd(v_splat + (size_t)g * GSA_SPLAT_STRIDE + m, total);
-                    }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-    }
-}
-#endif  // GSA_DEV_KERNELS
-
 // ------------------------------------------------------------------------------------------------
 // backward, two phases per 8 records: pixel-parallel recurrence, record-parallel moment sums
 // ------------------------------------------------------------------------------------------------
-// What the pixel-parallel sweep spends on the cross-lane sums of the moments (~20 of its ~58 vector instructions per
+// The sweep over the forward pass's per-quadrant lists of BLENDED records (composite_fwd_kernel<CH, 2>): no reach test, no
+// compaction, every staged record is walked -- full batches of 64, and none of the ~10 % of reach-test survivors that blend
+// nowhere.  Lane l of batch j stages list entry count - 1 - 64 j - l (walk order = reverse).
+// What a pixel-parallel sweep spends on the cross-lane sums of the moments (~20 of its ~58 vector instructions per
 // record, profiles/r02_bwd_ablation.md) is avoided by changing the lane mapping between the two halves of the work:
 //   phase A, lane = pixel: the sequential part -- alpha, T, Wd -- for 8 records; per (pixel, record) only the two
 //            scalars the moments are linear in, u = d loss / d sigma and fac = alpha T, go to an LDS matrix
-//            [pixel][record] (rows padded to 9 entries: conflict-free 8-B stores and loads);
+//            [pixel][record] (rows padded to 9 entries: conflict-free 8-B stores);
 //   phase B, lane = (pixel column x = lane >> 3, record = lane & 7), 8 steps over the pixel rows y: every lane reads its
 //            record's (u, fac) at pixel (x, y) and ACCUMULATES the nine moments in registers with plain FMAs
 //            (d = mean - pixel is a per-lane constant in x and a per-step constant in y);
 //   then one short fold over the 8 lanes of a record (3 levels) and a transposition through LDS give two atomic
 //   instructions of four whole 64-B gradient records each.
-// Same arithmetic per (pixel, record) as composite_bwd_list_kernel (the sums are taken in a different order).
+// (An XOR-swizzled matrix removes phase B's 2-way bank conflicts -- SQ_LDS_BANK_CONFLICT 17.2 M -> 0.02 M cycles -- for one
+// v_xor per store and the same kernel time, profiles/r03_bwd_ablation.md: not kept.)
+//
+// LDS per wave (r04: 7936 B, 8192 before):
+//   rec   64 x 3 float4    [0] s0 gx gy A  [1] B C r g  [2] b (int) list position  depth  -
+//                          (the forward's image: the record's alpha exponent for THIS quadrant, sigma_form / alpha_exponent)
+//   mat   64 x 9 float2    [pixel][record] (u, fac) of the current sub-batch; the ninth entry of row l -- the padding that keeps
+//                          phase A's stores conflict-free -- holds mean2d of staged record l (phase B's d = mean - pixel);
+//                          words 18 r + f (r < 8, f < 6 + CH) of the same rows double as the epilogue's [record][field]
+//                          totals once phase B has read the matrix
+//   gid   64 uint32        gaussian index of staged record l (the epilogue's atomics)
 constexpr int kSub = 8;                 // records per sub-batch
-#ifndef GSA_BWD_SWIZZLE
-#define GSA_BWD_SWIZZLE 0               // 1: XOR-swizzled [pixel][record] matrix and a 20-word tile pitch: no LDS bank conflicts, same time (see below)
-#endif
-// LDS layout of the [pixel][record] (u, fac) matrix.  Phase A stores one record of 16 consecutive pixels per quarter-wave
-// (ds_write_b64: banks mod 32), phase B loads 4 pixel columns x 8 records per half-wave (ds_read_b64: banks mod 64).
-// A row pitch of 9 entries makes the stores conflict-free but leaves the loads 2-way conflicted (the fourth column's 16
-// words wrap onto the first's); with 8 entries per row and the record slot XOR-ed with bits 1..3 of the pixel index both
-// are conflict-free -- for one v_xor per store (the address is no longer base + immediate).  Measured at C3
-// (profiles/r03_bwd_ablation.md): SQ_LDS_BANK_CONFLICT 17.2 M -> 0.02 M cycles, SQ_WAIT_INST_LDS 32.9 M -> 16.0 M, but
-// SQ_INSTS_VALU 119.6 M -> 125.0 M and the kernel's time unchanged (0.1993 / 0.2002 ms): the LDS pipe is not what the
-// sweep waits for.  Off by default (fewer instructions).
-constexpr int kMatPitch = GSA_BWD_SWIZZLE ? kSub : kSub + 1;     // float2 entries per pixel row of the LDS matrix
-#ifndef GSA_BWD_TILE_PITCH
-#define GSA_BWD_TILE_PITCH 10   // (16 = a whole 64-B record: 192 B more per wave, 8384 B, and 19 instead of 20 waves per CU)
-#endif
-constexpr int kTilePitch = GSA_BWD_SWIZZLE ? 20 : GSA_BWD_TILE_PITCH;   // words per record of the epilogue's [record][field] totals
-static_assert(kTilePitch >= 10, "a record's 6 + CH fields");
-__device__ __forceinline__ int mat_slot(int pixel, int r) {
-    return GSA_BWD_SWIZZLE ? pixel * kMatPitch + (r ^ ((pixel >> 1) & 7)) : pixel * kMatPitch + r;
-}
-template <int CH>
+constexpr int kMatPitch = kSub + 1;     // float2 entries per pixel row of the LDS matrix
+constexpr int kTilePitch = 2 * kMatPitch;   // words between the epilogue's record rows (= a matrix row)
+template <int F4>
 struct TwoPhase {
-    float2 mat[kWave * kMatPitch];      // [pixel][record] (u, fac)
-    float tile[kSub * kTilePitch];      // epilogue: [record][field] totals
+    float4 rec[kBatch * F4];
+    float2 mat[kWave * kMatPitch];
+    uint32_t gid[kBatch];
 };
 
-// (register budget: five waves per SIMD for the three-channel instance -- 96 registers, which it needs one more than
-// without the bound; the four-channel instance would spill there and keeps its 105)
+// Lane l stages ITS record of the batch (list position idx; !valid: a record that blends nothing).  Returns the number of
+// valid records (a prefix of the lanes); any_cap: does one of them exceed the 0.999 alpha cap.
+template <int F4>
+__device__ __forceinline__ int stage_listed(TwoPhase<F4> &tp, int lane, const Row &row, bool valid, int idx, float qcx,
+                                            float qcy, bool &any_cap) {
+    const float4 r0 = row.r0, r1 = row.r1, r2 = row.r2;
+    const float A = 0.5f * kLog2e * r0.z, B = kLog2e * r0.w, C = 0.5f * kLog2e * r1.x;
+    const SigmaForm f = sigma_form(r0.x, r0.y, A, B, C, r1.y, qcx, qcy);
+    tp.rec[F4 * lane + 0] = make_float4(f.s0, f.gx, f.gy, A);
+    tp.rec[F4 * lane + 1] = make_float4(B, C, r1.z, r1.w);
+    tp.rec[F4 * lane + 2] = make_float4(r2.x, __int_as_float(idx), r2.y, 0.f);
+    tp.mat[lane * kMatPitch + kSub] = make_float2(r0.x, r0.y);
+    tp.gid[lane] = row.gid;
+    const unsigned long long b = __ballot(valid);          // valid lanes are a prefix: lane < n
+    any_cap = __ballot(valid && r1.y > GSA_MAX_ALPHA) != 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return __builtin_popcountll(b);
+}
+
+// (register budget: five waves per SIMD for the three-channel instance -- 96 registers; the four-channel instance would
+// spill there and keeps what it needs)
 template <int CH>
 __global__ __launch_bounds__(kWave, (CH == 3 ? 5 : GSA_BWD_WAVES)) void composite_bwd_2p_kernel(
     int width, int height, int tile_w, int n_tiles, int bin_shift, const float *__restrict__ splat,
@@ -1156,27 +901,28 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 5 : GSA_BWD_WAVES)) void composit
     const float *__restrict__ background, const int32_t *__restrict__ tile_order, const float *__restrict__ final_T,
     const int32_t *__restrict__ last_id, const float *__restrict__ v_render, const float *__restrict__ v_alpha,
     const uint32_t *__restrict__ quad_list, const int32_t *__restrict__ quad_count, float *__restrict__ v_splat) {
-    constexpr int F4 = CH == 4 ? 4 : 3;
+    constexpr int F4 = 3;
     constexpr int NF = 6 + CH;
-    __shared__ Staged<F4> st;
-    __shared__ TwoPhase<CH> tp;
+    static_assert(NF <= 2 * kSub, "the epilogue's totals of a record fit the non-padding words of a matrix row");
+    __shared__ TwoPhase<F4> tp;
+    float *tile = reinterpret_cast<float *>(tp.mat);   // [record][field] totals at words kTilePitch * r + f
 
-    int tile, q;
-    wave_unit(blockIdx.x, n_tiles, tile_order, tile, q);
-    if (tile >= n_tiles) return;
+    int tile_id, q;
+    wave_unit(blockIdx.x, n_tiles, tile_order, tile_id, q);
+    if (tile_id >= n_tiles) return;
     const int lane = threadIdx.x;
-    const int count = __builtin_amdgcn_readfirstlane(quad_count[4 * tile + q]);
+    const int count = __builtin_amdgcn_readfirstlane(quad_count[4 * tile_id + q]);
     if (count <= 0) return;
     int start, end, slice;   // this tile's record list (its bin's), and which of the bin's quadrant slices is this wave's
-    tile_list(tile_offsets, tile, tile_w, bin_shift, q, start, end, slice);
+    tile_list(tile_offsets, tile_id, tile_w, bin_shift, q, start, end, slice);
     const uint32_t *my_list = quad_list + (((size_t)start << 2) << (2 * bin_shift)) + (size_t)slice * (size_t)(end - start);
-    const int tx = tile % tile_w, ty = tile / tile_w;
+    const int tx = tile_id % tile_w, ty = tile_id / tile_w;
     const int qx = tx * kTile + (q & 1) * 8, qy = ty * kTile + (q >> 1) * 8;
     const int px = qx + (lane & 7), py = qy + (lane >> 3);
     const bool inside = px < width && py < height;
-    const float pxf = px + 0.5f, pyf = py + 0.5f;
+    const float xrel = (float)(lane & 7) - 3.5f, yrel = (float)(lane >> 3) - 3.5f;    // this lane's pixel centre relative to the quadrant's centre
 
-    // software pipeline three deep, as in composite_bwd_list_kernel
+    // software pipeline three deep: list entries of batch j + 2, gaussian ids of batch j + 1, records of batch j
     auto load_pos = [&](int j) -> int {
         const int e = count - 1 - j * kBatch - lane;
         return e >= 0 ? (int)my_list[e] : -1;
@@ -1186,9 +932,10 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 5 : GSA_BWD_WAVES)) void composit
     int pos_next = load_pos(1);
     uint32_t gid_cur = load_gid(pos_cur);
 
-    // phase A state (lane = pixel): as in composite_bwd_kernel
+    // phase A state (lane = pixel): T = transmittance behind the current record; Wd = T_final (v_alpha - bg.v_out) - sum of
+    // (colour . v_out) * weight over the splats behind -- what d(out)/d(alpha_i) multiplies by 1/(1-alpha_i)
     const size_t pix = inside ? (size_t)py * width + px : 0;
-    const int binf = inside ? last_id[pix] : -1;
+    const int binf = inside ? last_id[pix] : -1;   // last list position the pixel saw while live
     const float Tf = inside ? final_T[pix] : 1.f;
     float T = Tf;
     float vout[CH], bgdot = 0.f;
@@ -1214,13 +961,14 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 5 : GSA_BWD_WAVES)) void composit
         for (int k = 0; k < CH; ++k) vcol[y][k] = in ? v_render[pp * CH + k] : 0.f;
     }
     const int f0 = 4 * ((lane >> 5) & 1) + 2 * ((lane >> 4) & 1) + ((lane >> 3) & 1);   // field this lane ends up with
-    const uint32_t mat_a0 = (uint32_t)(lane * 64) | (uint32_t)(((lane >> 1) & 7) << 3);   // phase A's swizzled store base (bytes)
-    uint32_t mat_b0 = (uint32_t)(col * 64) + (uint32_t)((rec ^ (col >> 1)) << 3), mat_b1 = mat_b0 ^ 32u;   // phase B's load bases
-    asm volatile("" : "+v"(mat_b0), "+v"(mat_b1));
 
     for (int done = 0, j = 0; done < count; done += kBatch, ++j) {
         bool any_cap;
-        const int n = stage_listed(st, lane, row, pos_cur >= 0, pos_cur, any_cap);
+        // (the quadrant's centre, rebuilt from scalars per batch: two conversions instead of two registers held through the
+        // sweep, which runs at its 96-register budget)
+        int cxi = qx + 4, cyi = qy + 4;
+        asm volatile("" : "+s"(cxi), "+s"(cyi));
+        const int n = stage_listed(tp, lane, row, pos_cur >= 0, pos_cur, (float)cxi, (float)cyi, any_cap);
         row = load_row(splat, gid_next, pos_next >= 0);
         pos_cur = pos_next;
         gid_next = load_gid(pos_next2);
@@ -1236,34 +984,29 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 5 : GSA_BWD_WAVES)) void composit
                 for (int r = 0; r < kSub; ++r) {
                     float u = 0.f, fac = 0.f;
                     if (r < nv) {   // (uniform)
-                        const float4 *p = &st.rec[F4 * (s0 + r)];
+                        const float4 *p = &tp.rec[F4 * (s0 + r)];
                         const float4 q0 = p[0], q1 = p[1], q2 = p[2];
-                        const float dx = q0.x - pxf, dy = q0.y - pyf;
-                        const uint32_t off_bit = ALL_ON ? 0u : (uint32_t)(binf - __float_as_int(q2.z)) & kSign;
+                        // the pixel stopped in front of this record (its list position is beyond the pixel's last one)
+                        const uint32_t off = ALL_ON ? 0u : (uint32_t)((binf - __float_as_int(q2.y)) >> 31);
                         float raw;
-                        const float a = record_alpha<CLAMP>(scaled_sigma(q0, q1, dx, dy), q2.y, q1.y, off_bit, raw);
+                        const float a = record_alpha<CLAMP>(alpha_exponent(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, xrel, yrel),
+                                                            off, raw);
                         const float ra = __builtin_amdgcn_rcpf(1.f - a);   // a == 0: ra = 1, fac = 0, u = 0
                         const float Tn = T * ra;
                         fac = a * Tn;
                         float cv = q1.z * vout[0] + q1.w * vout[1] + q2.x * vout[2];
-                        if (CH == 4) cv += p[F4 - 1].x * vout[CH - 1];
+                        if (CH == 4) cv += q2.z * vout[CH - 1];
                         const float v_a = Tn * cv + ra * Wd;
                         Wd -= fac * cv;
                         T = Tn;
                         u = CLAMP ? ((a == raw) ? -raw * v_a : 0.f) : -a * v_a;
                     }
-                    if (GSA_BWD_SWIZZLE) {   // byte offset (lane * 64 | g << 3) ^ (r << 3): ONE v_xor per store, no table of
-                        uint32_t a0 = mat_a0;   // eight addresses in registers (the asm keeps the compiler from hoisting one)
-                        asm volatile("" : "+v"(a0));
-                        *reinterpret_cast<float2 *>(reinterpret_cast<char *>(tp.mat) + (a0 ^ (uint32_t)(r * 8))) = make_float2(u, fac);
-                    } else {
-                        tp.mat[mat_slot(lane, r)] = make_float2(u, fac);
-                    }
+                    tp.mat[lane * kMatPitch + r] = make_float2(u, fac);
                 }
             };
             // the lists are walked from the deep end: once every pixel of the quadrant has reached its last position (the
             // sub-batch's first record is its deepest) the "pixel stopped in front of this record" test is dead code
-            const int pos_hi = __builtin_amdgcn_readfirstlane(__float_as_int(st.rec[F4 * s0 + 2].z));
+            const int pos_hi = __builtin_amdgcn_readfirstlane(__float_as_int(tp.rec[F4 * s0 + 2].y));
             const bool all_on = __ballot(binf >= pos_hi) == ~0ull;
             if (any_cap) {
                 if (all_on) phase_a(std::true_type{}, std::true_type{}); else phase_a(std::true_type{}, std::false_type{});
@@ -1280,15 +1023,13 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 5 : GSA_BWD_WAVES)) void composit
             {
                 // d = mean - pixel is constant in x for this lane and, per step, a compile-time offset in y: the lane sums
                 // u, u y', u y'^2 (y' = y - 3.5: three FMAs per step) and expands the five moments of u once per sub-batch
-                const float2 mean = *reinterpret_cast<const float2 *>(&st.rec[F4 * (rec < nv ? s0 + rec : kBatch)]);
+                // (records beyond nv: whatever batch slot s0 + rec holds -- finite, and their u and fac are zeros)
+                const float2 mean = tp.mat[(s0 + rec) * kMatPitch + kSub];
                 const float dx = mean.x - colx, dyc = mean.y - (rowy0 + 3.5f);   // dy = dyc - y'
                 float su = 0.f, suy = 0.f, suyy = 0.f;
 #pragma unroll
                 for (int y = 0; y < 8; ++y) {
-                    // (swizzled: byte offset y * 512 + mat_b0 ^ 32 (y & 1) -- two base registers and an immediate)
-                    const float2 uf = GSA_BWD_SWIZZLE
-                        ? *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(tp.mat) + ((y & 1) ? mat_b1 : mat_b0) + y * 512)
-                        : tp.mat[mat_slot(8 * y + col, rec)];
+                    const float2 uf = tp.mat[(8 * y + col) * kMatPitch + rec];
                     const float yc = (float)y - 3.5f;
                     const float u = uf.x, fac = uf.y;
                     su += u;
@@ -1313,8 +1054,10 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 5 : GSA_BWD_WAVES)) void composit
                         k3 = fold8(acc[6], acc[7]), k4 = fold8(acc[8], acc[9]);
             const float m0 = fold16(k0, k1), m1 = fold16(k2, k3), m2 = fold16(k4, k4);
             const float t0 = fold32(m0, m1), t1 = fold32(m2, m2);
-            tp.tile[kTilePitch * rec + f0] = t0;
-            if (kTilePitch >= 16 || 8 + f0 < NF) tp.tile[kTilePitch * rec + 8 + f0] = t1;       // fields >= NF are never read back
+            // (the totals go where phase B has just read the matrix: same wave, LDS operations complete in order, and the
+            // stored values depend on every load)
+            tile[kTilePitch * rec + f0] = t0;
+            if (8 + f0 < NF) tile[kTilePitch * rec + 8 + f0] = t1;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1323,9 +1066,9 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 5 : GSA_BWD_WAVES)) void composit
             for (int t = 0; t < 2; ++t) {
                 const int r = 4 * t + (lane >> 4), f = lane & 15;
                 if (4 * t < nv) {
-                    const float total = tp.tile[kTilePitch * r + (kTilePitch >= 16 ? f : min(f, NF - 1))];
+                    const float total = tile[kTilePitch * r + min(f, NF - 1)];
                     if (f < NF && r < nv) {
-                        const uint32_t g = __float_as_uint(st.rec[F4 * (s0 + r) + 2].w);
+                        const uint32_t g = tp.gid[s0 + r];
                         atomicAdd(v_splat + (size_t)g * GSA_SPLAT_STRIDE + f, total);
                     }
                 }
@@ -1574,10 +1317,6 @@ extern "C" int gsa_composite_bwd(int width, int height, int channels, const floa
     return GSA_OK;
 }
 
-#ifdef GSA_DEV_KERNELS
-static int g_dev_bwd_mode = 2;
-extern "C" int gsa_debug_set_bwd_mode(int mode) { g_dev_bwd_mode = mode; return GSA_OK; }
-#endif
 
 extern "C" int gsa_composite_bwd_lists(int width, int height, int channels, const float *splat,
                                        const uint32_t *sorted_gid, const int32_t *tile_offsets,
@@ -1594,34 +1333,6 @@ extern "C" int gsa_composite_bwd_lists(int width, int height, int channels, cons
     const int n_tiles = tile_w * tile_h;
     const int grid = 32 * gsa_div_up(n_tiles, 8);
     hipStream_t s = static_cast<hipStream_t>(stream);
-#ifdef GSA_DEV_KERNELS   // developer builds: 1 = record-parallel sweep with prefix scans, 0 = pixel-parallel sweep with the
-                         // transpose-reduce (same results up to summation order); the product library has the two-phase sweep only
-    const int mode = g_dev_bwd_mode;
-    if (mode == 1) {
-        if (channels == 3)
-            composite_bwd_scan_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid,
-                                                               tile_offsets, background, tile_order, final_T, last_id,
-                                                               v_render, v_alpha, quad_list, quad_count, v_splat);
-        else
-            composite_bwd_scan_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid,
-                                                               tile_offsets, background, tile_order, final_T, last_id,
-                                                               v_render, v_alpha, quad_list, quad_count, v_splat);
-        GSA_LAUNCH_CHECK();
-        return GSA_OK;
-    }
-    if (mode == 0) {
-        if (channels == 3)
-            composite_bwd_list_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid, tile_offsets,
-                                                               background, tile_order, final_T, last_id, v_render, v_alpha,
-                                                               quad_list, quad_count, v_splat);
-        else
-            composite_bwd_list_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid, tile_offsets,
-                                                               background, tile_order, final_T, last_id, v_render, v_alpha,
-                                                               quad_list, quad_count, v_splat);
-        GSA_LAUNCH_CHECK();
-        return GSA_OK;
-    }
-#endif
     if (channels == 3)
         composite_bwd_2p_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid,
                                                          tile_offsets, background, tile_order, final_T, last_id,

@@ -1326,7 +1326,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void emit_place_kernel(
     const int32_t *__restrict__ block_owner, int tile_w, uint32_t m_cap, const uint32_t *__restrict__ m_dev,
     uint16_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int nblocks, int nb, int n_tiles,
     const uint32_t *__restrict__ mat, const int32_t *__restrict__ tile_offsets, const float *__restrict__ splat,
-    uint16_t *__restrict__ masks_out) {
+    uint16_t *__restrict__ masks_out, uint32_t mask_q8) {
     __shared__ uint32_t scratch[4];
     // two regions, each with two lives: the generation's (slot owners | staged gaussians) and the placement's (peer
     // words + the bins' first slots | wave-private 16-bit bin counters)
@@ -1370,7 +1370,19 @@ __global__ __launch_bounds__(kSortThreads, 4) void emit_place_kernel(
             v[r] = min(v[r], (uint32_t)n - 1u);   // (the compositor gathers splat rows by this id, unchecked)
         }
     }
+    // mask_q8 / 256: the fraction of the records, in DEPTH order, that get a computed mask; the blocks behind it store
+    // all-ones (the compositor then falls back to its own reach test for those entries).  A record block holds records of
+    // one depth range, i.e. the same relative position in every bin's list -- and where the scene is dense enough for the
+    // masks to matter, a quadrant's pixels saturate within the first third of its list: the deep half is never scanned.
+    const bool compute_masks = MASK_Q != 0 && (uint64_t)bid * 256u < (uint64_t)live * mask_q8;
     if constexpr (MASK_Q != 0) {
+        if (!compute_masks) {
+            load_bases();
+#pragma unroll
+            for (int r = 0; r < kSortItems; ++r) k[r] |= 0xFFFF0000u;
+        }
+    }
+    if (compute_masks) {
         load_bases();
         // kMaskGroup records' row words in flight at a time (all sixteen at once: 268 registers); the mask rides in the
         // upper half of the bin id through the ranking, so it costs no register of its own.  (bin -> (x, y) by a reciprocal:
@@ -2095,9 +2107,10 @@ extern "C" int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offs
                               const int32_t *block_owner, int width, int height, int bin_tile, uint32_t m_capacity,
                               const uint32_t *m_dev, uint16_t *tile_tmp,
                               uint32_t *gid_tmp, uint16_t *sorted_tile, uint32_t *sorted_gid, int32_t *tile_offsets,
-                              const float *splat, uint16_t *sorted_mask,
+                              const float *splat, uint16_t *sorted_mask, int mask_depth_q8,
                               void *workspace, size_t workspace_bytes, gsa_stream_t stream) {
     GSA_RETURN_IF(n < 0 || !tile_offsets, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(sorted_mask && (mask_depth_q8 < 1 || mask_depth_q8 > 256), GSA_ERR_INVALID_ARGUMENT);
     // (masks: only where the records are placed in one pass and a bin has at most 16 quadrants -- gsa_tile_bin16_masks)
     GSA_RETURN_IF(sorted_mask && (!splat || !gsa_tile_bin16_masks(width, height, bin_tile) || tile_tmp || gid_tmp),
                   GSA_ERR_INVALID_ARGUMENT);
@@ -2135,7 +2148,7 @@ extern "C" int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offs
 #define GSA_PLACE(Q)                                                                                                     \
     emit_place_kernel<Q><<<nblocks, kSortThreads, 0, s>>>(n, order, offsets, rects, block_owner, tile_w, m_capacity, m_dev, \
                                                           sorted_tile, sorted_gid, nblocks, nb, n_tiles, mat, tile_offsets, \
-                                                          splat, sorted_mask)
+                                                          splat, sorted_mask, (uint32_t)mask_depth_q8)
         if (!sorted_mask) GSA_PLACE(0);
         else if (bin_tile == GSA_TILE_SIZE) GSA_PLACE(2);
         else GSA_PLACE(4);

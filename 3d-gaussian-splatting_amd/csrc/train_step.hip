@@ -4,7 +4,8 @@
 //                   streaming pass:  loss = (1 - lambda) L1 + lambda (1 - SSIM_3x3)  on the straight-through-clamped
 //                   render (/root/reference/src/training/trainer.py:485-492 with _stclamp :102-107 and _compute_ssim
 //                   :354-371; PSNR's mse :70-75 comes out of the same pass).  The torch formulation makes ~10
-//                   full-image passes forward and as many backward; here render and target are read once.
+//                   full-image passes forward and as many backward; here render and target are read once (1.2 times,
+//                   counting the strips' halos) and nothing passes through LDS.
 //   gsa_adam_step   one fused Adam update over the flat 59 N parameter bucket with per-segment learning rates
 //                   (torch.optim.Adam as configured at trainer.py:331-340: betas 0.9 / 0.999, eps 1e-15, no weight
 //                   decay, no amsgrad): 4 arrays read, 3 written, once.
@@ -22,8 +23,8 @@ constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 
 __device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
 
-// block sum of three doubles -> block_sums[3 * blockIdx.x ..].  (One atomicAdd per block on the three result words was
-// the whole cost of the kernel: 8100 blocks hammering three addresses serialise at the memory side at ~90 adds/us.)
+// block sum of three doubles -> block_sums[3 * blockIdx.x ..]  (gsa_activate_bwd's regulariser value; one atomicAdd per
+// block on a few result words serialises at the memory side at ~90 adds/us)
 __device__ __forceinline__ void block_add3(double a, double b, double c, double *__restrict__ block_sums) {
     __shared__ double red[3][kThreads / GSA_WAVE];
 #pragma unroll
@@ -39,6 +40,7 @@ __device__ __forceinline__ void block_add3(double a, double b, double c, double 
         block_sums[3 * (long)blockIdx.x + threadIdx.x] = s;
     }
 }
+
 
 // sums[k] += sum over blocks of block_sums[3 * b + k]   (one workgroup)
 __global__ __launch_bounds__(kThreads) void loss_finalize_kernel(int n_blocks, const double *__restrict__ block_sums,
@@ -61,129 +63,130 @@ __global__ __launch_bounds__(kThreads) void loss_finalize_kernel(int n_blocks, c
     }
 }
 
-// Both passes work on 32x8-pixel tiles: the tile plus its one-pixel halo is staged through LDS with coalesced
-// row reads (each input element is read from HBM/L2 about 1.4 times instead of 9), the 3x3 window then reads LDS.
-constexpr int kTileW = 32, kTileH = 8, kHaloW = kTileW + 2, kHaloH = kTileH + 2;
+// ---- the per-view loss and its gradient: one wave per (image strip, colour channel), sliding windows in registers ----
+// r01-r03 staged 32 x 8 tiles with halos through LDS and read every 3 x 3 window out of it: ~150 LDS reads per pixel, 75 us for
+// the 75 MB a 1080p view moves (1.0 TB/s; profiles/r03_train_step_summary.md).  Both box filters of the loss are separable
+// -- the 3 x 3 statistics behind SSIM, and the adjoint of that filter applied to SSIM's partial derivatives -- so a lane
+// that walks DOWN one image column needs, per row, only the row's horizontal 3-sums (its two neighbours' values: two
+// whole-wave DPP shifts, no LDS) and keeps the last two rows' sums in registers:
+//   lane l of a wave = column x0 + l - 2 of the strip (x0 = 60 strip): 64 columns loaded, 62 with statistics, 60 written;
+//   the three waves of a workgroup = the three colour channels of the same strip (their strided loads and stores meet
+//   in the CU's L1 / the XCD's L2 as whole lines);
+//   rows y0 - 2 .. y0 + R + 1 are read (R = kStripRows), statistics exist for y0 - 1 .. y0 + R, gradients for y0 .. y0 + R - 1:
+//   row i gives h(i) = horizontal sums of (a, b, a^2, b^2, a b); h(i - 2) + h(i - 1) + h(i) = the window sums centred on row
+//   i - 1 -> SSIM and its partials P(i - 1) w.r.t. (mu_a, E[a^2], E[a b]) -> their horizontal sums hP(i - 1);
+//   hP(i - 3) + hP(i - 2) + hP(i - 1) = the adjoint box filter centred on row i - 2 -> the gradient of that row.
+// No LDS, no barrier; rows are fetched four at a time, the next four in flight under the arithmetic of the current ones.
+//   v_render = grad_scale * [ (1 - lambda) sign(a - b) - lambda * d SSIM ] / (3 H W)     (straight-through clamp)
+// with zero padding and divisor 9 (avg_pool2d(3, 1, padding=1), count_include_pad), partials zero outside the image.
+constexpr int kStripCols = 60, kStripRows = 28, kStripChunk = 4;
+static_assert((kStripRows + 4) % kStripChunk == 0, "whole chunks of input rows");
 
-// Stage `nch` floats per pixel of the tile at (x0, y0) with its halo into lds[(yy * kHaloW + xx) * nch + c];
-// outside the image: zeros (the zero padding of avg_pool2d).  CLAMP applies clamp(., 0, 1) on the way in.
-template <bool CLAMP>
-__device__ __forceinline__ void stage_tile(float *__restrict__ lds, const float *__restrict__ src, int nch, int x0, int y0,
-                                           int width, int height) {
-    const int row_floats = kHaloW * nch;
-    for (int i = threadIdx.x; i < kHaloH * row_floats; i += kThreads) {
-        const int yy = i / row_floats, rest = i - yy * row_floats;
-        const int y = y0 - 1 + yy, xf = (x0 - 1) * nch + rest;       // float offset inside image row y
-        float v = 0.f;
-        if (y >= 0 && y < height && xf >= 0 && xf < width * nch) {
-            v = src[(long)y * width * nch + xf];
-            if (CLAMP) v = clamp01(v);
-        }
-        lds[i] = v;
-    }
+// the value of the lane below / above (0 at the wave's ends): DPP wave shifts, folded into the adds that use them
+__device__ __forceinline__ float lane_below(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xF, 0xF, true));
 }
-
-// One pass: a block stages its 32x8 tile of a = clamp(render) and b = target with a TWO-pixel halo, computes the 3x3
-// box statistics (zero padding, divisor 9 -- avg_pool2d(3, 1, padding=1) with count_include_pad) and from them the SSIM
-// value and its partial derivatives with respect to mu_a, E[a^2], E[ab] for the tile plus its ONE-pixel halo into LDS,
-// then every tile pixel applies the adjoint of the box filter to those partials:
-//   v_render = grad_scale * [ (1 - lambda) sign(a - b) - lambda * d SSIM ] / (3 H W)     (straight-through clamp).
-// The partials never travel through HBM (as a two-kernel version they were 36 B per pixel out and back).
-constexpr int kHalo2W = kTileW + 4, kHalo2H = kTileH + 4;
-
-template <bool CLAMP>
-__device__ __forceinline__ void stage_tile2(float *__restrict__ lds, const float *__restrict__ src, int x0, int y0, int width,
-                                            int height) {
-    const int row_floats = kHalo2W * 3;
-    for (int i = threadIdx.x; i < kHalo2H * row_floats; i += kThreads) {
-        const int yy = i / row_floats, rest = i - yy * row_floats;
-        const int y = y0 - 2 + yy, xf = (x0 - 2) * 3 + rest;
-        float v = 0.f;
-        if (y >= 0 && y < height && xf >= 0 && xf < width * 3) {
-            v = src[(long)y * width * 3 + xf];
-            if (CLAMP) v = clamp01(v);
-        }
-        lds[i] = v;
-    }
+__device__ __forceinline__ float lane_above(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xF, 0xF, true));
 }
+__device__ __forceinline__ float hsum3(float v) { return (lane_below(v) + v) + lane_above(v); }
 
-__global__ __launch_bounds__(kThreads) void loss_fused_kernel(int width, int height, const float *__restrict__ render,
-                                                              const float *__restrict__ target, float lambda_dssim,
-                                                              float grad_scale, float *__restrict__ v_render,
-                                                              double *__restrict__ block_sums) {
-    __shared__ float sa[kHalo2H * kHalo2W * 3], sb[kHalo2H * kHalo2W * 3];
-    __shared__ float sp[kHaloH * kHaloW * 9];
-    const int tiles_x = (width + kTileW - 1) / kTileW;
-    const int x0 = (blockIdx.x % tiles_x) * kTileW, y0 = (blockIdx.x / tiles_x) * kTileH;
-    stage_tile2<true>(sa, render, x0, y0, width, height);
-    stage_tile2<false>(sb, target, x0, y0, width, height);
-    __syncthreads();
-    double l1 = 0, ssim = 0, mse = 0;
-    // partials of the tile and its one-pixel halo (positions outside the image have no window: zeros)
-    for (int i = threadIdx.x; i < kHaloH * kHaloW; i += kThreads) {
-        const int hy = i / kHaloW, hx = i - hy * kHaloW;
-        const int x = x0 - 1 + hx, y = y0 - 1 + hy;
-        float *out = sp + i * 9;
-        if (x < 0 || x >= width || y < 0 || y >= height) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) out[k] = 0.f;
-            continue;
-        }
-        const bool interior = hx >= 1 && hx <= kTileW && hy >= 1 && hy <= kTileH;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float s_a = 0.f, s_b = 0.f, saa = 0.f, sbb = 0.f, sab = 0.f;
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int q = ((hy + dy) * kHalo2W + hx + dx) * 3 + c;
-                    const float a = sa[q], b = sb[q];
-                    s_a += a; s_b += b; saa += a * a; sbb += b * b; sab += a * b;
-                }
-            const float inv9 = 1.f / 9.f;
-            const float mu_a = s_a * inv9, mu_b = s_b * inv9;
-            const float var_a = saa * inv9 - mu_a * mu_a, var_b = sbb * inv9 - mu_b * mu_b;
-            const float cov = sab * inv9 - mu_a * mu_b;
-            const float A1 = 2.f * mu_a * mu_b + kC1, A2 = 2.f * cov + kC2;
-            const float B1 = mu_a * mu_a + mu_b * mu_b + kC1, B2 = var_a + var_b + kC2;
-            const float inv = 1.f / (B1 * B2);
-            const float S = A1 * A2 * inv;
-            // d S / d mu_a with E[a^2], E[ab] held fixed: var_a and cov depend on mu_a too
-            const float dA1 = 2.f * mu_b, dA2 = -2.f * mu_b, dB1 = 2.f * mu_a, dB2 = -2.f * mu_a;
-            out[c * 3 + 0] = ((dA1 * A2 + A1 * dA2) - S * (dB1 * B2 + B1 * dB2)) * inv;
-            out[c * 3 + 1] = -S / B2;            // B2 contains + E[a^2]
-            out[c * 3 + 2] = 2.f * A1 * inv;     // A2 contains + 2 E[ab]
-            if (interior) {
-                const int q0 = ((hy + 1) * kHalo2W + hx + 1) * 3 + c;
-                const float d0 = sa[q0] - sb[q0];
-                l1 += fabsf(d0); mse += (double)d0 * d0; ssim += S;
-            }
-        }
-    }
-    block_add3(l1, ssim, mse, block_sums);   // (contains the barrier that publishes sp)
-    if (!v_render) return;
-    const int lx = threadIdx.x % kTileW, ly = threadIdx.x / kTileW;
-    const int x = x0 + lx, y = y0 + ly;
-    if (x >= width || y >= height) return;
-    const long p = (long)y * width + x;
+template <bool WANT_GRAD>
+__global__ __launch_bounds__(3 * GSA_WAVE) void loss_strip_kernel(int width, int height, int strips,
+                                                                    const float *__restrict__ render,
+                                                                    const float *__restrict__ target, float lambda_dssim,
+                                                                    float grad_scale, float *__restrict__ v_render,
+                                                                    double *__restrict__ wave_sums) {
+    const int lane = threadIdx.x & 63, c = threadIdx.x >> 6;      // the wave's colour channel
+    const int strip = blockIdx.x % strips, band = blockIdx.x / strips;
+    const int x = strip * kStripCols + lane - 2, y0 = band * kStripRows;
+    const bool col_in = x >= 0 && x < width;
+    const bool col_out = col_in && lane >= 2 && lane < 2 + kStripCols;   // the columns this wave writes and counts
+    const long xc = (long)min(max(x, 0), width - 1) * 3 + c;
     const float inv_count = grad_scale / (3.f * (float)width * (float)height);
+    const float w_l1 = (1.f - lambda_dssim) * inv_count, w_ss = lambda_dssim * inv_count * (1.f / 9.f);
+
+    // input rows i = 0 .. kStripRows + 3 are image rows y0 - 2 + i; loads are clamped, not predicated (in flight together)
+    auto fetch = [&](int i, float &a, float &b) {
+        const int y = y0 - 2 + i;
+        const long o = (long)min(max(y, 0), height - 1) * width * 3 + xc;
+        a = render[o];
+        b = target[o];
+    };
+    float na[kStripChunk], nb[kStripChunk];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float s_mu = 0.f, s_aa = 0.f, s_ab = 0.f;
+    for (int k = 0; k < kStripChunk; ++k) fetch(k, na[k], nb[k]);
+
+    float h1[5] = {0, 0, 0, 0, 0}, h2[5] = {0, 0, 0, 0, 0};   // horizontal sums of rows i - 1, i - 2
+    float p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};               // horizontal sums of the partials of rows i - 2, i - 3
+    float a1 = 0.f, b1 = 0.f, a2 = 0.f, b2 = 0.f;             // a, b of rows i - 1, i - 2
+    float l1 = 0.f, ssim = 0.f, mse = 0.f;
+    for (int i0 = 0; i0 < kStripRows + 4; i0 += kStripChunk) {
+        float ca[kStripChunk], cb[kStripChunk];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+        for (int k = 0; k < kStripChunk; ++k) { ca[k] = na[k]; cb[k] = nb[k]; }
+        if (i0 + kStripChunk < kStripRows + 4) {
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const float *in = sp + (((ly + dy) * kHaloW + lx + dx) * 3 + c) * 3;
-                s_mu += in[0]; s_aa += in[1]; s_ab += in[2];
+            for (int k = 0; k < kStripChunk; ++k) fetch(i0 + kStripChunk + k, na[k], nb[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < kStripChunk; ++k) {
+            const int i = i0 + k, y = y0 - 2 + i;
+            const bool in = col_in && y >= 0 && y < height;
+            const float a = in ? clamp01(ca[k]) : 0.f, b = in ? cb[k] : 0.f;
+            float h[5] = {hsum3(a), hsum3(b), hsum3(a * a), hsum3(b * b), hsum3(a * b)};
+            // ---- statistics centred on row y - 1 (needs rows y - 2 .. y)
+            float P[3] = {0.f, 0.f, 0.f};
+            const int yc = y - 1;
+            if (i >= 2) {   // (uniform)
+                const float inv9 = 1.f / 9.f;
+                const float mu_a = ((h2[0] + h1[0]) + h[0]) * inv9, mu_b = ((h2[1] + h1[1]) + h[1]) * inv9;
+                const float e_aa = ((h2[2] + h1[2]) + h[2]) * inv9, e_bb = ((h2[3] + h1[3]) + h[3]) * inv9;
+                const float e_ab = ((h2[4] + h1[4]) + h[4]) * inv9;
+                const float var_a = e_aa - mu_a * mu_a, var_b = e_bb - mu_b * mu_b, cov = e_ab - mu_a * mu_b;
+                const float A1 = 2.f * mu_a * mu_b + kC1, A2 = 2.f * cov + kC2;
+                const float B1 = mu_a * mu_a + mu_b * mu_b + kC1, B2 = var_a + var_b + kC2;
+                const float den = B1 * B2;
+                float inv = __builtin_amdgcn_rcpf(den);
+                inv = inv * (2.f - den * inv);            // one Newton step: as good as the division
+                const float S = A1 * A2 * inv;
+                const bool valid = col_in && yc >= 0 && yc < height;   // (outside the image there is no window: zeros)
+                // d S / d mu_a with E[a^2], E[ab] held fixed (var_a and cov depend on mu_a too); d S / d E[a^2]; d S / d E[ab]
+                P[0] = valid ? (2.f * mu_b * (A2 - A1) - S * 2.f * mu_a * (B2 - B1)) * inv : 0.f;
+                P[1] = valid ? -S * B1 * inv : 0.f;
+                P[2] = valid ? 2.f * A1 * inv : 0.f;
+                if (valid && col_out && yc >= y0 && yc < y0 + kStripRows) {
+                    const float d = a1 - b1;
+                    l1 += fabsf(d); mse = __builtin_fmaf(d, d, mse); ssim += S;
+                }
             }
-        const int q0 = ((ly + 2) * kHalo2W + lx + 2) * 3 + c;
-        const float a = sa[q0], b = sb[q0];
-        const float d_ssim = (s_mu + 2.f * a * s_aa + b * s_ab) * (1.f / 9.f);
-        const float d = a - b;
-        const float sign = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-        v_render[p * 3 + c] = inv_count * ((1.f - lambda_dssim) * sign - lambda_dssim * d_ssim);
+            const float hp[3] = {hsum3(P[0]), hsum3(P[1]), hsum3(P[2])};
+            // ---- the gradient of row y - 2 (needs the partials of rows y - 3 .. y - 1)
+            if (WANT_GRAD && i >= 4) {
+                const int yo = y - 2;
+                if (col_out && yo < height && yo < y0 + kStripRows) {
+                    const float s_mu = (p2[0] + p1[0]) + hp[0], s_aa = (p2[1] + p1[1]) + hp[1], s_ab = (p2[2] + p1[2]) + hp[2];
+                    const float d_ssim = s_mu + 2.f * a2 * s_aa + b2 * s_ab;
+                    const float d = a2 - b2;
+                    const float sign = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+                    v_render[((long)yo * width + x) * 3 + c] = w_l1 * sign - w_ss * d_ssim;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 5; ++q) { h2[q] = h1[q]; h1[q] = h[q]; }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { p2[q] = p1[q]; p1[q] = hp[q]; }
+            a2 = a1; b2 = b1; a1 = a; b1 = b;
+        }
+    }
+    double s0 = l1, s1 = ssim, s2 = mse;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        s0 += __shfl_xor(s0, d); s1 += __shfl_xor(s1, d); s2 += __shfl_xor(s2, d);
+    }
+    if (lane == 0) {
+        double *out = wave_sums + 3 * ((long)blockIdx.x * 3 + c);
+        out[0] = s0; out[1] = s1; out[2] = s2;
     }
 }
 
@@ -404,10 +407,13 @@ extern "C" int gsa_densify_gather(long long n_old, long long n_new, int n_fields
     return GSA_OK;
 }
 
+static long view_loss_waves(int width, int height) {
+    return 3L * gsa_div_up(width, kStripCols) * gsa_div_up(height, kStripRows);
+}
+
 extern "C" size_t gsa_view_loss_workspace_bytes(int width, int height) {
     if (width <= 0 || height <= 0) return 0;
-    const size_t blocks = (size_t)gsa_div_up(width, kTileW) * gsa_div_up(height, kTileH);
-    return blocks * 3 * sizeof(double);   // the per-block sums
+    return (size_t)view_loss_waves(width, height) * 3 * sizeof(double);   // the per-wave sums
 }
 
 extern "C" int gsa_view_loss(int width, int height, const float *render, const float *target, float lambda_dssim,
@@ -417,12 +423,17 @@ extern "C" int gsa_view_loss(int width, int height, const float *render, const f
     GSA_RETURN_IF(workspace_bytes < gsa_view_loss_workspace_bytes(width, height), GSA_ERR_WORKSPACE_TOO_SMALL);
     GSA_RETURN_IF((reinterpret_cast<uintptr_t>(workspace) & 7) != 0, GSA_ERR_INVALID_ARGUMENT);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int grid = gsa_div_up(width, kTileW) * gsa_div_up(height, kTileH);
-    double *block_sums = static_cast<double *>(workspace);
-    loss_fused_kernel<<<grid, kThreads, 0, s>>>(width, height, render, target, lambda_dssim, grad_scale, v_render,
-                                               block_sums);
+    const int strips = gsa_div_up(width, kStripCols);
+    const int grid = strips * gsa_div_up(height, kStripRows);
+    double *wave_sums = static_cast<double *>(workspace);
+    if (v_render)
+        loss_strip_kernel<true><<<grid, 3 * GSA_WAVE, 0, s>>>(width, height, strips, render, target, lambda_dssim, grad_scale,
+                                                             v_render, wave_sums);
+    else
+        loss_strip_kernel<false><<<grid, 3 * GSA_WAVE, 0, s>>>(width, height, strips, render, target, lambda_dssim, grad_scale,
+                                                              nullptr, wave_sums);
     GSA_LAUNCH_CHECK();
-    loss_finalize_kernel<<<1, kThreads, 0, s>>>(grid, block_sums, sums);
+    loss_finalize_kernel<<<1, kThreads, 0, s>>>((int)view_loss_waves(width, height), wave_sums, sums);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }

@@ -377,11 +377,16 @@ class ViewParallelTrainer:
         self.group, self.rank, self.world = process_group, rank, world_size
         self.iteration = 0
         self.fused = bool(fused)
-        # fused step: True / "front" (default) -- the next view's front end on a side stream; "alternate" -- whole views on two
-        # alternating streams, their speculation checked once in front of the optimizer (bench.py's scheme; measured equal
-        # here, 3.32 against 3.29 ms per 4-view step at C3: a step of four views that ends in a host read-back has little
-        # for the host to run ahead into); False -- one stream (3.41 ms)
-        self.overlap_views = overlap_views if overlap_views in ("alternate", "front") else ("front" if overlap_views else False)
+        # fused step: truthy (default) -- whole views on two alternating HIP streams, their speculation checked once in front
+        # of the optimizer (gsplat_amd.pipeline.ViewPipeline, the orchestrator bench.py times); False -- one stream
+        self.overlap_views = bool(overlap_views)
+        # fused step: ``async_metrics = True`` returns the metrics of the PREVIOUS step (the first step returns its own):
+        # the step then ends without a host read-back and the host queues the next step while this one runs -- what the
+        # reference's loop needs them for (a progress line, trainer.py:513-519) does not care which step they are of.
+        # Default False: a step returns its own metrics (the golden tests compare step by step).
+        self.async_metrics = False
+        self._pending_report = None
+        self._pipe = None
         if self.fused and not model.flat.is_cuda:
             raise RuntimeError("ViewParallelTrainer(fused=True) needs the model on a HIP device (no CPU path)")
         # fused: the SH-coefficient gradient is kept (and, for world > 1, exchanged) in factored form
@@ -529,7 +534,7 @@ class ViewParallelTrainer:
         through autograd's accumulation: the activations (trainer.py:399-406) are evaluated once without a graph,
         every view's backward ADDS its activated-parameter gradients into one bucket (``grad_accumulate``), and the
         activation derivatives are applied once, writing the raw-parameter gradients into ``flat_grad``.
-        One host read-back, at the end (the metrics).
+        One host read-back, at the end (the metrics) -- none with ``async_metrics`` (they then arrive one step late).
 
         ``factored`` (default): 48 of the 59 gradient floats per gaussian are the SH-coefficient gradient, and per view
         that is the outer product SH-basis(view direction) x d loss / d rgb.  The backward passes therefore leave only
@@ -564,92 +569,70 @@ class ViewParallelTrainer:
                 for j, view in enumerate(batch[r_::self.world]):
                     poses_all[r_, j] = view["pose"]
         # The views of the batch are independent until their gradients meet in the bucket, and a view's front end
-        # (projection + binning: HBM- and latency-bound, ~25 short kernels) uses what its sweep (compositor forward,
-        # loss, compositor backward: VALU-bound) leaves idle.  So view j + 1's front end runs on a side stream while
-        # view j is swept on the main one.  No autograd here: the stages are called directly.
+        # (projection + binning: HBM- and latency-bound) uses what its sweeps (compositor forward, loss, compositor backward:
+        # VALU-bound) leave idle: whole views alternate on two streams, nobody waits for a view's control words until all
+        # are queued, a step whose speculation failed is rendered again with exact sizes (nothing was applied yet) -- all
+        # of it the product's one orchestrator, pipeline.ViewPipeline.  No autograd here: the stages are called directly.
         main = torch.cuda.current_stream()
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=dev)
-        alternate = self.overlap_views == "alternate" and not exact
-        side = self._side if self.overlap_views == "front" else main
+        if self._pipe is None or bool(self._pipe.streams) != self.overlap_views:
+            from .pipeline import ViewPipeline
+            self._pipe = ViewPipeline(dev, 2 if self.overlap_views else 1)
         cull = S.DEFAULT_CULL_MODE
         Kc, bgc = K[0].contiguous(), bg[0].contiguous()
         params_ready = torch.cuda.Event()
         params_ready.record(main)
-
-        def front(view, exact=exact, side=side):
-            with torch.cuda.stream(side):
-                side.wait_event(params_ready)
-                pose = view["pose"].to(torch.float32).contiguous()
-                W, H = view["width"], view["height"]
-                bt = S.bin_tile_for(W, H, cull)   # 32 x 32 bins where the fused binning applies
-                kr = S.key_range_buffer(leaves[0].shape[0], dev)   # the view's depth-key range: the depth ordering plans its buckets from it
-                splat, radii, tiles, keys, rects, aux = S.project_fwd(leaves[0], leaves[1], leaves[2], leaves[3],
-                                                                      leaves[4], degree, pose, Kc, W, H, cull,
-                                                                      return_rects=True, return_aux=True, bin_tile=bt,
-                                                                      key_range=kr)
-                bins = S.bin_tiles(splat, radii, tiles, keys, W, H, cull, tile_rects=rects, exact=exact, bin_tile=bt,
-                                   key_range=kr)
-                order = S.tile_schedule(bins.tile_offsets, W, H, bt)
-                done = torch.cuda.Event()
-                done.record(side)
-                if side is not main:   # the sweep reads these on the main stream: keep their memory until it has
-                    for t in (pose, splat, radii, bins.sorted_gid_buffer, bins.sorted_mask, bins.tile_offsets, order, aux):
-                        if t is not None:
-                            t.record_stream(main)
-            return pose, splat, radii, bins, order, done, aux
-
         mine = list(batch[self.rank::self.world])
         scale = self.loss_scale if self.amp else 1.0   # loss scale: the backward passes see v_render times it
-        sums, first = [], True
+        sums = [None] * len(mine)
 
-        def sweep(j, view, pose, splat, radii, bins, order, aux, before_bucket=None):
-            """compositor forward, loss, compositor backward, projection backward of view j on the current stream"""
+        def front(view, exact):
+            pose = view["pose"].to(torch.float32).contiguous()
             W, H = view["width"], view["height"]
+            bt = S.bin_tile_for(W, H, cull)   # 32 x 32 bins where the fused binning applies
+            kr = S.key_range_buffer(leaves[0].shape[0], dev)   # the view's depth-key range: the depth ordering plans its buckets from it
+            splat, radii, tiles, keys, rects, aux = S.project_fwd(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4],
+                                                                  degree, pose, Kc, W, H, cull, return_rects=True,
+                                                                  return_aux=True, bin_tile=bt, key_range=kr)
+            bins = S.bin_tiles(splat, radii, tiles, keys, W, H, cull, tile_rects=rects, exact=exact, bin_tile=bt,
+                               key_range=kr)
+            order = S.tile_schedule(bins.tile_offsets, W, H, bt)
+            return pose, splat, radii, bins, order, aux
+
+        def forward(j, deferred):
+            """front end, compositor forward and the loss of view j on the current stream"""
+            from .pipeline import ViewState
+            view = mine[j]
+            W, H = view["width"], view["height"]
+            pose, splat, radii, bins, order, aux = front(view, exact=False)
+            if not deferred and not bins.finalize()[1]:   # (a remembered capacity / key range did not hold: exact sizes)
+                pose, splat, radii, bins, order, aux = front(view, exact=True)
+                bins.finalize()
             bt = bins.bin_tile
             render, _, final_T, last_id, lists = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bgc, W,
                                                                  H, 3, order, want_lists=True, bin_tile=bt,
                                                                  sorted_mask=bins.sorted_mask)
             s3, v = S.view_loss(render, view["image"], c.lambda_dssim, grad_scale=scale / n_views)
+            res = s3 / float(v.numel())            # -> l1, ssim, mse of this view
+            if torch.cuda.current_stream() != main:
+                res.record_stream(main)
+            sums[j] = res
+            return ViewState((view, pose, splat, radii, bins, order, aux, final_T, last_id, lists, v),
+                             (lambda: bins.finalize()[1]) if deferred else (lambda: True))
+
+        def backward(j, state, before_bucket):
+            view, pose, splat, radii, bins, order, aux, final_T, last_id, lists, v = state.payload
+            W, H = view["width"], view["height"]
             v_splat = S.composite_bwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bgc, final_T, last_id, v, None,
-                                      W, H, 3, order, quad_lists=lists, bin_tile=bt)
+                                      W, H, 3, order, quad_lists=lists, bin_tile=bins.bin_tile)
             if before_bucket is not None:   # (the bucket is summed into in view order)
                 torch.cuda.current_stream().wait_event(before_bucket)
             S.project_bwd(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], degree, pose, Kc, W, H, splat, radii,
                           v_splat, out=grad_out, accumulate=j > 0,
                           v_rgb_out=vr_all[self.rank, j] if factored else None, sh_aux=aux)
-            return s3 / float(v.numel())            # -> l1, ssim, mse of this view
 
-        if alternate:
-            # whole views on two alternating streams; nobody waits for a view's control words until all are queued
-            streams, pending, bucket_done = (main, self._side), [], None
-            for j, view in enumerate(mine):
-                st = streams[j % 2]
-                pose, splat, radii, bins, order, done, aux = front(view, side=st)
-                with torch.cuda.stream(st):
-                    res = sweep(j, view, pose, splat, radii, bins, order, aux, before_bucket=bucket_done)
-                    bucket_done = torch.cuda.Event()
-                    bucket_done.record(st)
-                    if st is not main:
-                        res.record_stream(main)
-                sums.append(res)
-                pending.append(bins)
-                first = False
-            if bucket_done is not None:
-                main.wait_event(bucket_done)
-            if not all(b.finalize()[1] for b in pending):   # a remembered capacity / key range did not hold: the step again,
-                return self._training_step_fused(batch, exact=True)   # one stream, exact sizes (nothing was applied yet)
-        else:
-            ahead = front(mine[0]) if mine else None
-            for j, view in enumerate(mine):
-                pose, splat, radii, bins, order, done, aux = ahead
-                if not bins.finalize()[1]:       # record capacity missed (the scene grew): bin again with exact sizes
-                    pose, splat, radii, bins, order, done, aux = front(view, exact=True)
-                    bins.finalize()
-                ahead = front(mine[j + 1]) if j + 1 < len(mine) else None
-                main.wait_event(done)
-                sums.append(sweep(j, view, pose, splat, radii, bins, order, aux))
-                first = False
+        self._pipe.run(len(mine), forward, backward, inputs_ready=params_ready, defer=not exact)
+        sums = [x for x in sums if x is not None]
+        first = not mine
         if first:                                          # this rank rendered nothing
             m.flat_grad.zero_()
             for g in (g_quats, g_scales, g_opac):
@@ -701,14 +684,18 @@ class ViewParallelTrainer:
         self._all_reduce(report)
         if found_inf is not None:
             report = torch.cat([report, found_inf.double()])
-        r = report.tolist()                                        # the step's one host read-back
-        if found_inf is not None:                                  # GradScaler.update()
-            if r[5] != 0.0:
-                self.optimizer.step_count -= 1                     # the update was skipped on the device
-                self.loss_scale, self._good_steps = self.loss_scale * 0.5, 0
-                self.skipped_steps += 1
-            else:
-                self._good_steps += 1
-                if self._good_steps >= 2000:
-                    self.loss_scale, self._good_steps = self.loss_scale * 2.0, 0
+        self._pipe.mark_bucket_used()
+        if self.async_metrics and found_inf is None:   # (mixed precision: the loss-scale update wants THIS step's flag)
+            # no read-back in the step: the report goes to pinned memory behind the step's kernels, and what is returned is
+            # the report the PREVIOUS step left there (its copy finished long ago: the host is about one step ahead)
+            host = torch.empty(report.shape, dtype=report.dtype, pin_memory=True)
+            host.copy_(report, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            prev, self._pending_report = self._pending_report, (host, ev)
+            host, ev = prev if prev is not None else self._pending_report
+            ev.synchronize()
+            r = host.tolist()
+        else:
+            r = report.tolist()                                    # the step's one host read-back
         return {"loss": r[3], "l1": r[0] / n_views, "ssim": r[1] / n_views, "psnr": r[2] / n_views, "scale_reg": r[4]}

@@ -124,22 +124,29 @@ def bin_tile_for(width: int, height: int, cull_mode: int) -> int:
     return bt if bool(lib.gsa_tile_bins_supported(width, height, bt)) else TILE_SIZE
 
 
-_PINNED = {}
-_PINNED_SLOTS = 16   # record-count read-backs that may be in flight per device before a slot is reused
+_PINNED = {}          # (device type, index) -> [free (words, event) slots]
+_PINNED_BLOCK = 16    # slots allocated at a time (one pinned [16, 4] int32 tensor)
 
 
 def _pinned_scalar(dev):
-    """Four pinned int32 (record count, min / max depth key, spare) + an event for ONE read-back of a view's control words: every ``TileBins`` gets its own slot of a small ring per
-    device (allocated once), so bins that are finalized late or out of order -- a deeper look-ahead, stage-level use,
-    two host threads -- never read another view's count."""
-    key = (dev.type, dev.index)
-    if key not in _PINNED:
-        _PINNED[key] = [torch.zeros(_PINNED_SLOTS, 4, dtype=torch.int32, pin_memory=True),
-                        [torch.cuda.Event() for _ in range(_PINNED_SLOTS)], 0, [0] * _PINNED_SLOTS]
-    words, events, nxt, gens = _PINNED[key]
-    _PINNED[key][2] = (nxt + 1) % _PINNED_SLOTS
-    gens[nxt] += 1   # a TileBins finalized after its slot went round the ring finds another generation: an error, not
-    return words[nxt], events[nxt], (gens, nxt, gens[nxt])   # another view's count
+    """Four pinned int32 (record count, min / max depth key, status) + an event for ONE read-back of a view's control words.
+    Every ``TileBins`` takes a slot of its own from a per-device free list and gives it back when it is finalized, so any
+    number of views may be in flight un-finalized (a deferred-check step, a multi-camera call, several host threads):
+    the pool grows by ``_PINNED_BLOCK`` slots whenever it runs dry (r03 had a fixed ring of 16 and raised beyond it).
+    A ``TileBins`` that is dropped un-finalized keeps its slot out of circulation (16 bytes): its kernel may still write."""
+    free = _PINNED.setdefault((dev.type, dev.index), [])
+    if not free:
+        block = torch.zeros(_PINNED_BLOCK, 4, dtype=torch.int32, pin_memory=True)
+        free.extend((block[i], torch.cuda.Event()) for i in range(_PINNED_BLOCK))
+    words, event = free.pop()
+    return words, event, free
+
+
+def _release_slot(slot) -> None:
+    """Back to the free list (the control words have been read; nothing on the device will write them again)."""
+    words, event, _, free = slot
+    if free is not None:
+        free.append((words, event))
 
 
 def key_range_buffer(n: int, dev) -> torch.Tensor:
@@ -177,11 +184,6 @@ def _wait_slot(slot) -> None:
 
 def _wait_slot_impl(slot) -> None:
     words, event, token = slot[:3]
-    if len(slot) > 3 and slot[3] is not None:
-        gens, idx, gen = slot[3]
-        if gens[idx] != gen:
-            raise RuntimeError(f"gsplat_amd: more than {_PINNED_SLOTS} un-finalized TileBins per device: this one's "
-                               "read-back slot has been reused")
     if token is None:
         event.synchronize()
         return
@@ -288,6 +290,8 @@ class TileBins:
                 REPAIR_STATS["capacity_misses"] += 1
             elif not self._keys_ok:
                 REPAIR_STATS["key_range_repairs"] += 1
+            _release_slot(self._slot)
+            self._slot = None
         return self._m, self._m <= self.capacity and self._keys_ok
 
     def __iter__(self):   # sorted_tile, sorted_gid, tile_offsets = bin_tiles(...)
@@ -334,6 +338,12 @@ _BIN_DIRECT = os.environ.get("GSPLAT_AMD_BIN_DIRECT", "1") != "0"
 # them a net loss and is now only what the other binning paths fall back to when masks are asked for explicitly
 # (``bin_tiles(quad_masks=True)``).  GSPLAT_AMD_QUAD_MASKS=0 switches the masks off (A/B).
 _QUAD_MASKS = os.environ.get("GSPLAT_AMD_QUAD_MASKS", "1") != "0"
+# ... for the front GSPLAT_AMD_MASK_DEPTH (default 0.5) of the records in depth order; the deep rest gets all-ones masks (the
+# compositor's own reach test then decides).  Where masks pay -- lists long enough that gathering candidates dominates -- a
+# quadrant's pixels saturate within the first third of its list, so the deep half of every list is never scanned and its
+# masks would be computed for nothing; in a sparse scene the unmasked half costs what r03 paid for every record.
+# ``bin_tiles(quad_masks=True)`` masks every record.
+_MASK_DEPTH_Q8 = max(1, min(256, int(round(256 * float(os.environ.get("GSPLAT_AMD_MASK_DEPTH", "0.5"))))))
 # (device, W, H, cull_mode) -> [records per gaussian the next call provisions for, consecutive low counts].
 # Keyed WITHOUT N: densify / prune changes N every 100 iterations (trainer.py:794-797) and a changed N predicts its
 # capacity from the remembered ratio instead of costing a blocking read-back.  Grows at once, shrinks only after many
@@ -568,10 +578,10 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
             dws_bytes = lib.gsa_depth_order_msd_workspace_bytes(N)
             dws = torch.empty(dws_bytes, dtype=torch.uint8, device=dev)
             # the kernel leaves the control words in a pinned slot itself (tagged with a token the host polls for)
-            m_host, m_event, guard = _pinned_scalar(dev)
+            m_host, m_event, pool = _pinned_scalar(dev)
             token = _next_token()
             m_host[3] = 0
-            slot = (m_host, m_event, token, guard)
+            slot = (m_host, m_event, token, pool)
             if len(plan) == 5:   # the shape's own table: built by this call (with a margin) or by an earlier one
                 plan[4].record_stream(torch.cuda.current_stream())
                 _call("gsa_depth_order", lib.gsa_depth_order_msd_table, N, _ptr(depth_keys), _ptr(tile_rects),
@@ -605,10 +615,10 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
         _call("gsa_scan_tiles", lib.gsa_scan_tiles, N, _ptr(tiles_touched), _ptr(order), _ptr(offsets), _ptr(total),
               _ptr(ws), ws_bytes, st)
     if slot is None:   # (every path but the bucketed ordering: a 16-byte copy behind the scan, and an event)
-        m_host, m_event, guard = _pinned_scalar(dev)
+        m_host, m_event, pool = _pinned_scalar(dev)
         m_host.copy_(ctl, non_blocking=True)
         m_event.record()
-        slot = (m_host, m_event, None, guard)
+        slot = (m_host, m_event, None, pool)
     m_known = None
     if cap is None:
         _wait_slot(slot)
@@ -618,6 +628,8 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
             keys_ok = _note_keys(key, int(m_host[1]) & 0xFFFFFFFF, int(m_host[2]) & 0xFFFFFFFF, key_bits,
                                  int(m_host[3]) if isinstance(key_bits, tuple) else 0)
         cap = m_known
+        _release_slot(slot)   # (read: this call's TileBins knows its count)
+        slot = None
         if fused:   # first call of a scene shape / repair: the block table needs the count, scan once more
             offsets.copy_(counts_copy)
             block_owner = scan(cap)
@@ -641,7 +653,8 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
         _call("gsa_tile_bin16", lib.gsa_tile_bin16, N, _ptr(order), _ptr(offsets), _ptr(rects), _ptr(block_owner), width,
               height, bin_tile, cap,
               _ptr(total), _ptr(k_tmp), _ptr(v_tmp), _ptr(sorted_tile), _ptr(sorted_gid), _ptr(tile_offsets),
-              _ptr(splat) if masks_inline else None, _ptr(sorted_mask) if masks_inline else None, _ptr(ws2), ws2_bytes, st)
+              _ptr(splat) if masks_inline else None, _ptr(sorted_mask) if masks_inline else None,
+              256 if quad_masks else _MASK_DEPTH_Q8, _ptr(ws2), ws2_bytes, st)
         if masks_pass:
             _call("gsa_quadrant_masks", lib.gsa_quadrant_masks, cap, _ptr(total), _ptr(sorted_tile), _ptr(sorted_gid),
                   _ptr(splat), N, width, height, bin_tile, _ptr(sorted_mask), st)

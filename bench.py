@@ -264,12 +264,6 @@ def main() -> None:
     ap.add_argument("--view-streams", type=int, default=DEFAULT_VIEW_STREAMS,
                     help="HIP streams the views of a step alternate on (2: view j + 1's HBM- / latency-bound front end "
                          "runs beside view j's VALU-bound sweeps; 1: strictly one view after the other)")
-    ap.add_argument("--overlap", default="alternate", choices=("front", "alternate"),
-                    help="with --view-streams >= 2: 'alternate' -- whole views on alternating streams, the backward passes "
-                         "ordered by events (the bucket is summed into in view order); 'front' -- every view's projection / "
-                         "depth ordering / binning on a side stream (rasterization(front_stream=...)), all sweeps in view "
-                         "order on the main stream (measured slower: the binning kernels want 35-128 KB of LDS per "
-                         "workgroup, which a running sweep never leaves free, so they sit out the sweep beside them)")
     ap.add_argument("--no-defer-check", action="store_true",
                     help="multi-view steps: wait for every view's control words inside its rasterization() call (the r03 "
                          "behaviour) instead of checking the step's views once, behind the last one (defer_check=True)")
@@ -320,10 +314,9 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=flag_group)
         return bool(t.item())
 
-    import contextlib
-
     import gsplat_amd
     from gsplat_amd import scene, stages
+    from gsplat_amd.pipeline import ViewPipeline, ViewState
 
     B = max(1, args.views_per_gpu)
     n, width, height, deg = WORKLOADS[args.workload]
@@ -357,67 +350,51 @@ def main() -> None:
             rings[v] = torch.stack([scene.make_camera(i, v) for i in range(v)]).to(dev)
         return rings[v]
 
-    # (front mode: the side stream is a HIGH-PRIORITY one -- the dispatcher serves the oldest kernel first, so the small
-    # kernels of a front end that becomes ready while a sweep fills the chip would otherwise wait for the sweep's tail)
-    prio = int(os.environ.get("GSPLAT_AMD_BENCH_FRONT_PRIORITY", "-1")) if args.overlap == "front" else 0
-    streams = [torch.cuda.Stream(device=dev, priority=prio if i == 0 else 0)
-               for i in range(max(1, args.view_streams))] if args.view_streams > 1 else []
-
     def make_step(form: str, views: int, n_streams: int, ring_size: int):
         """One step = `views` views on this rank (cameras j * world + rank of the step's window of the ring), forward +
-        backward each, their gradients summed into the bucket, then the exchange.  form: "factored" | "allreduce"."""
+        backward each, their gradients summed into the bucket, then the exchange.  form: "factored" | "allreduce".
+        The views are queued by the product's own orchestrator (gsplat_amd.pipeline.ViewPipeline): alternating streams,
+        bucket summed in view order, the speculation of all views checked once behind the last one."""
         # one process, one view: nothing to sum, the backward writes the whole gradient itself
         factored = form == "factored" and (world > 1 or views > 1)
         ex = Exchange(dist, world, rank, n, views, factored, dev, expand=stages.sh_grad_expand)
-        front = streams[0] if n_streams > 1 and args.overlap == "front" else None
-        use = streams[:n_streams] if n_streams > 1 and front is None else []
-        inputs_ready = torch.cuda.Event()
-        bwd_done = [torch.cuda.Event() for _ in range(views)]
-        step_done = torch.cuda.Event()
-        state = {"first": True}
+        pipe = ViewPipeline(dev, n_streams)
         cams, windows = ring(ring_size), {}
-
         defer = views > 1 and not args.no_defer_check   # the views' speculation is checked once per step, behind the last view
 
-        def step(i: int = 0, deferred: bool = defer):
+        def step(i: int = 0):
             for t in leaves:
                 t.grad = None
-            metas = []
             base = (i * views * world) % ring_size
-            main = torch.cuda.current_stream()
-            if front is not None:   # the front ends of this step's views read the parameters as the step in front left them
-                inputs_ready.record(main)
-                front.wait_event(inputs_ready)
-            for j in range(views):
-                st = use[j % len(use)] if use else None
-                with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
-                    vm = cams[(base + j * world + rank) % ring_size][None]
-                    # the backward pass writes every gradient element straight into the bucket (no zero-fill, no copy);
-                    # views after the first ADD to it.  (opacities [N,1] -> [N] as the reference backend does it,
-                    # gsplat_backend.py:157-158)
-                    r, a, meta = gsplat_amd.rasterization(leaves[0], leaves[1], leaves[2], opac.squeeze(-1), leaves[4], vm, K,
-                                                          width, height, sh_degree=deg, backgrounds=bg,
-                                                          cull_mode=args.cull_mode, grad_out=grad_views,
-                                                          grad_accumulate=j > 0, sh_grad_factored=ex.view_target(j),
-                                                          front_stream=front, defer_check=deferred)
-                    metas.append(meta)
-                    if st is not None:   # the bucket is summed into in view order; nothing else orders the streams
-                        if j > 0:
-                            st.wait_event(bwd_done[j - 1])
-                        elif not state["first"]:
-                            st.wait_event(step_done)
-                    r.backward(v_render)
-                    if st is not None:
-                        bwd_done[j].record(st)
-                    if dist is not None and stages.TIMER.enabled and j == views - 1:   # instrumented pass: the exchange's tail
-                        x0 = torch.cuda.Event(enable_timing=True)
-                        x0.record()
-                    ex.after_view(j)
+            marks = {}
+
+            def forward(j: int, deferred: bool) -> ViewState:
+                vm = cams[(base + j * world + rank) % ring_size][None]
+                # the backward pass writes every gradient element straight into the bucket (no zero-fill, no copy);
+                # views after the first ADD to it.  (opacities [N,1] -> [N] as the reference backend does it,
+                # gsplat_backend.py:157-158)
+                r, a, meta = gsplat_amd.rasterization(leaves[0], leaves[1], leaves[2], opac.squeeze(-1), leaves[4], vm, K,
+                                                      width, height, sh_degree=deg, backgrounds=bg,
+                                                      cull_mode=args.cull_mode, grad_out=grad_views,
+                                                      grad_accumulate=j > 0, sh_grad_factored=ex.view_target(j),
+                                                      defer_check=deferred)
                 if "M" not in info:   # (once: with 32 x 32 bins in the hot path the 16 x 16 record count is a reduction + read-back)
                     info["M"] = meta["n_isects"]
                     info["binned"] = meta["n_binned"]
-            for j in range(views if use else 0):
-                main.wait_event(bwd_done[j])
+                return ViewState(r, (lambda: bool(meta["speculation_ok"])) if deferred else (lambda: True))
+
+            def backward(j: int, state: ViewState, before_bucket) -> None:
+                if before_bucket is not None:
+                    torch.cuda.current_stream().wait_event(before_bucket)
+                state.payload.backward(v_render)
+
+            def after_view(j: int) -> None:
+                if dist is not None and stages.TIMER.enabled and j == views - 1:   # instrumented pass: the exchange's tail
+                    marks["x0"] = torch.cuda.Event(enable_timing=True)
+                    marks["x0"].record()
+                ex.after_view(j)
+
+            pipe.run(views, forward, backward, after_view=after_view, agree=agree if dist is not None else None, defer=defer)
             if factored or dist is not None:
                 if base not in windows:   # the cameras of the step's views, entry j * world + r = rank r's view j
                     windows[base] = cams[(base + torch.arange(views * world, device=dev)) % ring_size].contiguous()
@@ -425,19 +402,11 @@ def main() -> None:
             if dist is not None and stages.TIMER.enabled:
                 x1 = torch.cuda.Event(enable_timing=True)
                 x1.record()
-                stages.TIMER.records.append(("exchange_tail", x0, x1))
-            if use:
-                step_done.record(main)
-                state["first"] = False
-            # the step's views were queued without waiting for their control words; what a trainer does in front of its
-            # optimizer: ask now (the device is a view or more behind), and render the step again if a view's remembered
-            # capacity or key range did not hold
-            # (every rank takes the same decision: the repeated step repeats its collectives)
-            if deferred and not agree(all(m["speculation_ok"] for m in metas)):
-                info["deferred_repairs"] = info.get("deferred_repairs", 0) + 1
-                step(i, deferred=False)
+                stages.TIMER.records.append(("exchange_tail", marks["x0"], x1))
+            pipe.mark_bucket_used()
 
         step.exchange = ex
+        step.pipe = pipe
         return step
 
     def fence():
@@ -497,7 +466,7 @@ def main() -> None:
                 "per_step_ms": [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)] if per_step else None}
 
     p = width * height
-    n_streams = max(1, len(streams)) if B > 1 else 1
+    n_streams = max(1, args.view_streams) if B > 1 else 1
     if args.profile_run:
         prof_step = make_step(args.exchange, 1, 1, world)
         res = timed(prof_step, args.steps, args.warmup)
@@ -605,8 +574,8 @@ def main() -> None:
                                        "step, SH gradient rebuilt locally" if args.exchange == "factored" else
                                        ", RCCL all-reduce of 59N-float grads") if world > 1 else ""),
                        "views_per_gpu_per_step": B, "view_streams": n_streams,
-                       "overlap": (args.overlap if n_streams > 1 else "none"),
-                       "speculation_check": ("per step, repairs: %d" % info.get("deferred_repairs", 0)) if B > 1 and not args.no_defer_check else "per view",
+                       "overlap": ("alternate" if n_streams > 1 else "none"),
+                       "speculation_check": ("per step, repairs: %d" % head_step.pipe.repairs) if B > 1 and not args.no_defer_check else "per view",
                        "ms_per_view": round(ms_per_view, 4),
                        "intersections_M": m, "bin_tile": stages.bin_tile_for(width, height, stages.DEFAULT_CULL_MODE if args.cull_mode is None else args.cull_mode), "binned_records": info.get("binned"),
                        "grad_l1": round(grad_l1_head, 3), "grad_l1_single_view": round(grad_l1, 3),

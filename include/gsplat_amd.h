@@ -136,7 +136,10 @@ int gsa_scan_tiles(int n, const int32_t *tiles_touched, const uint32_t *order, u
  * also stores, beside every gaussian id, which 8 x 8 quadrants of the record's bin the alpha >= 1/255 ellipse of the
  * gaussian can reach -- bit order as gsa_quadrant_masks; a superset of the per-pixel rule -- computed where the record
  * is generated (the records of a gaussian are consecutive there: no per-record gather).  gsa_composite_fwd's
- * sorted_mask.  Both NULL: no masks (the other paths of gsa_tile_bin16 never write any). */
+ * sorted_mask.  Both NULL: no masks (the other paths of gsa_tile_bin16 never write any).  mask_depth_q8 (1 .. 256): the
+ * front mask_depth_q8 / 256 of the records IN DEPTH ORDER get computed masks, the rest all-ones (for which the compositor
+ * falls back to its own reach test): in a scene dense enough for the masks to matter a quadrant's pixels saturate within
+ * the first third of its list, and the deep half is never scanned.  256: every record. */
 #define GSA_BIN_BLOCK 4096
 int gsa_tile_bin16_supported(int width, int height);
 int gsa_tile_bin16_direct(int width, int height, int bin_tile);
@@ -213,7 +216,7 @@ int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offsets, const 
                    const int32_t *block_owner, int width, int height, int bin_tile, uint32_t m_capacity,
                    const uint32_t *m_dev, uint16_t *tile_tmp,
                    uint32_t *gid_tmp, uint16_t *sorted_tile, uint32_t *sorted_gid, int32_t *tile_offsets,
-                   const float *splat, uint16_t *sorted_mask,
+                   const float *splat, uint16_t *sorted_mask, int mask_depth_q8,
                    void *workspace, size_t workspace_bytes, gsa_stream_t stream);
 
 /* For k in depth order, g = order[k]: write that gaussian's tile ids and its index g at

@@ -34,6 +34,22 @@ AMB_TOL_STAGE = 1e-4     # identical inputs on both sides: alpha differs by ~1e-
 MAX_AMB_FRACTION = 2e-2
 
 
+# Stage-level tensors that may take max(1e-4, 2 x the fp32 oracle's own distance from the fp64 oracle) instead of the
+# outright 1e-4 -- each with the measured value that put it here.  EMPTY: every stage tensor holds 1e-4 outright
+# (measured values: profiles/r04_parity_stage.json, written by the tests when GSPLAT_AMD_EVIDENCE is set).
+STAGE_RELAXED = set()
+
+
+def _evidence(name, payload):
+    """With GSPLAT_AMD_EVIDENCE=<dir> in the environment the parity tests leave their measured errors there (one JSON
+    file per test case) -- what profiles/r04_parity_*.json are assembled from."""
+    d = os.environ.get("GSPLAT_AMD_EVIDENCE")
+    if d:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, name + ".json"), "w") as f:
+            json.dump(payload, f, indent=1, sort_keys=True)
+
+
 def _amb_tol_e2e(W, H):
     """Relative window for end-to-end runs: d alpha/alpha <= conic(<=3.3) * d(~3 px) * ulp(mean2d)."""
     return max(1e-4, 10.0 * float(np.spacing(np.float32(max(W, H)))))
@@ -129,7 +145,7 @@ def _bwd_modes():
     """Backward list sweeps this build of the library has: the product library only the two-phase one (2)."""
     import ctypes
     from gsplat_amd._lib import LIB_PATH
-    return (2, 1, 0) if hasattr(ctypes.CDLL(LIB_PATH), "gsa_debug_set_bwd_mode") else (2,)
+    return (2,)
 
 
 class _bwd_mode:
@@ -235,17 +251,27 @@ def test_projection_and_binning_match_oracle(gsa, deg):
     for key in ("means2d", "conics", "depths"):
         x, y = m1[key].cpu()[0][same], m0[key][0][same]
         assert _rel(x, y) < 5e-5, key
+    # The integer outputs are compared on the gaussians whose radii agree: the (<= 3) gaussians whose ceil() landed on the
+    # other side of an fp32 rounding are dropped from BOTH sides' record lists -- the block always runs (r03 skipped it
+    # whenever one radius differed).
+    ok_g = same
+    assert torch.equal(m1["tiles_per_gauss"].cpu()[0][ok_g], m0["tiles_per_gauss"][0][ok_g])
+    f1, f0 = m1["flatten_ids"].cpu(), m0["flatten_ids"]
+    ids1, ids0 = m1["isect_ids"].cpu(), m0["isect_ids"]
+    k1, k0 = ok_g[f1 % N], ok_g[f0 % N]
+    assert int((~k1).sum()) <= 3 * 64 and int((~k0).sum()) <= 3 * 64   # (a handful of records)
+    assert torch.equal(f1[k1], f0[k0]), "sorted gaussian ids (tile, depth, index order)"
+    # 64-bit keys: the tile half must agree exactly -- with it the per-tile record counts, i.e. isect_offsets; the depth
+    # half holds fp32 bits of camera-space z, whose last bits depend on how t + R.m is fused (cancellation when the camera
+    # sits inside the cloud) -- compare as floats
+    assert torch.equal((ids1 >> 32)[k1], (ids0 >> 32)[k0])
     if bool(same.all()):
-        assert torch.equal(m1["tiles_per_gauss"].cpu(), m0["tiles_per_gauss"])
-        assert torch.equal(m1["flatten_ids"].cpu(), m0["flatten_ids"])
         assert torch.equal(m1["isect_offsets"].cpu(), m0["isect_offsets"])
-        # 64-bit keys: the tile half must agree exactly; the depth half holds fp32 bits of camera-space z, whose last
-        # bits depend on how t + R.m is fused (cancellation when the camera sits inside the cloud) -- compare as floats
-        ids1, ids0 = m1["isect_ids"].cpu(), m0["isect_ids"]
-        assert torch.equal(ids1 >> 32, ids0 >> 32)
-        z1 = (ids1 & 0xFFFFFFFF).to(torch.int32).view(torch.float32)
-        z0 = (ids0 & 0xFFFFFFFF).to(torch.int32).view(torch.float32)
-        assert float((z1 - z0).abs().max()) <= 5e-5 * float(z0.abs().max())
+    n_t = m0["isect_offsets"].numel()
+    assert torch.equal(torch.bincount((ids1 >> 32)[k1], minlength=n_t), torch.bincount((ids0 >> 32)[k0], minlength=n_t))
+    z1 = (ids1 & 0xFFFFFFFF).to(torch.int32).view(torch.float32)[k1]
+    z0 = (ids0 & 0xFFFFFFFF).to(torch.int32).view(torch.float32)[k0]
+    assert float((z1 - z0).abs().max()) <= 5e-5 * float(z0.abs().max())
     k3 = (~m0["ambiguous"]).float()[..., None]
     assert float(1 - k3.mean()) <= MAX_AMB_FRACTION
     assert _rel(r1.cpu() * k3, r0 * k3) < REL_TOL and _rel(a1.cpu() * k3, a0 * k3) < REL_TOL
@@ -303,9 +329,14 @@ def test_stage_composite_fwd_bwd(gsa, W, H, N, cull_mode, with_bg):
     checks = [("render", img1.cpu() * k3, img32 * k3, img0 * k3), ("alpha", al1.cpu() * k3, al32 * k3, al0 * k3),
               ("v_means2d", v_splat[:, 0:2], g32[0], g0[0]), ("v_conics", v_splat[:, 2:5], g32[1], g0[1]),
               ("v_opacity", v_splat[:, 5], g32[2], g0[2]), ("v_rgb", v_splat[:, 6:9], g32[3], g0[3])]
+    report = {}
     for name, got, o32, o64 in checks:
         eh, e32 = _rel(got, o64), _rel(o32, o64)
-        assert eh <= max(REL_TOL, 2 * e32), (name, eh, e32)
+        report[name] = (eh, e32)
+        # 1e-4 outright (r03 allowed max(1e-4, 2 x the fp32 oracle's own error)); STAGE_RELAXED names what may not hold it
+        bound = max(REL_TOL, 2 * e32) if (name, W, N) in STAGE_RELAXED else REL_TOL
+        assert eh <= bound, (name, eh, e32, report)
+    _evidence(f"stage_composite_{W}x{H}_{N}", {k: {"hip_vs_fp64": v[0], "fp32_oracle_vs_fp64": v[1]} for k, v in report.items()})
     assert float(v_splat[:, 9:].abs().max()) == 0
     if big:
         assert int((last >= 0).sum()) > 0.9 * W * H
@@ -374,9 +405,13 @@ def test_stage_project_bwd(gsa, deg, aux):
         return [leaves[0].grad, leaves[1].grad, leaves[2].grad, leaves[3].grad[:, 0], col_leaf.grad]
 
     ref64, ref32 = oracle(torch.float64), oracle(torch.float32)
+    report = {}
     for name, x, y64, y32 in zip(["v_means", "v_quats", "v_scales", "v_opacities", "v_colors"], got, ref64, ref32):
         eh, e32 = _rel(x, y64), _rel(y32, y64)
-        assert eh <= max(REL_TOL, 2 * e32), (name, eh, e32)
+        report[name] = (eh, e32)
+        bound = max(REL_TOL, 2 * e32) if (name, "project_bwd", deg) in STAGE_RELAXED else REL_TOL
+        assert eh <= bound, (name, eh, e32, report)
+    _evidence(f"stage_project_bwd_deg{deg}_aux{int(aux)}", {k: {"hip_vs_fp64": v[0], "fp32_oracle_vs_fp64": v[1]} for k, v in report.items()})
     if deg is not None and deg < 3:
         assert float(got[4][:, (deg + 1) ** 2:].abs().max()) == 0  # zeros above the active degree
 
@@ -562,12 +597,14 @@ def test_population_change_keeps_the_pipeline_asynchronous(gsa):
     b1, m1 = bins(N)
     b2, m2 = bins(N - N // 20)
     assert m1 != m2 and b2.finalize()[0] == m2 and b1.finalize()[0] == m1
-    # ... and one whose slot went round the ring before it was finalized says so instead of reading another view's count
-    stale, _ = bins(N)
-    later = [bins(N)[0] for _ in range(S._PINNED_SLOTS)]
-    with pytest.raises(RuntimeError, match="un-finalized"):
-        stale.finalize()
-    assert all(b.finalize()[1] for b in later)
+    # ... and ANY number of bins may wait un-finalized (a deferred-check step over many views, a 40-camera call): the
+    # pool of read-back slots grows on demand (r03: a ring of 16 that raised beyond it), every one still reads its own count
+    old, m_old = bins(N - N // 20)
+    later = [bins(N) for _ in range(3 * S._PINNED_BLOCK)]
+    assert old.finalize() == (m_old, True)
+    assert all(b.finalize() == (m, True) for b, m in later)
+    free = S._PINNED[("cuda", torch.cuda.current_device())]
+    assert len(free) >= 3 * S._PINNED_BLOCK                # ... and the slots are back in the pool
 
 
 def test_two_cameras_in_one_call_equal_two_calls(gsa):
@@ -707,66 +744,108 @@ def test_backend_plugin_surface(gsa):
     assert batch["images"].shape == (2, 3, H, W) and batch["alphas"].shape == (2, 1, H, W)
 
 
-def test_config_c2_100k_1080p_deg3(gsa):
-    """BASELINE config C2: 100k gaussians, 1920x1080, SH degree 3, forward+backward, vs the CPU oracle."""
-    from gsplat_amd import scene
-    W, H = 1920, 1080
-    sc = scene.make_scene(100_000, seed=0, sh_degree=3)
-    m1, m0, errs = _compare(sc, scene.make_camera(0, 1), scene.make_intrinsics(W, H), W, H, 3,
-                            bg=torch.zeros(3), use_v_alpha=False, checkpoint=True)
-    print("C2 (err HIP vs fp64, err fp32-oracle vs fp64):", errs, "M =", m1["flatten_ids"].numel())
-    # evidence: per tensor (err of HIP vs the fp64 oracle, err of the fp32 oracle vs the fp64 oracle), the masked
-    # pixel fraction -- written where the GPU run's artefacts are collected (committed copy: profiles/r02_parity_c2.json)
-    record = {"config": "C2: 100000 gaussians, 1920x1080, SH degree 3, forward+backward, view 0",
-              "metric": "max|a - b| / max|b| per tensor, b = fp64 oracle; pixels whose threshold comparisons are "
-                        "ambiguous in the fp64 oracle are masked on both sides",
-              "masked_pixel_fraction": errs["ambiguous_fraction"], "intersections_M": int(m1["flatten_ids"].numel()),
-              "masked_pixels": errs["masked_pixels"],
-              "tensors": {k: {"err_hip": v[0], "err_fp32_oracle": v[1]} for k, v in errs.items()
-                          if k not in ("ambiguous_fraction", "masked_pixels")}}
+def _parity_record(name, record):
+    """Evidence file of a config-sized parity test: where the GPU run's artefacts are collected (committed copies:
+    profiles/r04_parity_*.json)."""
     try:
         out_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
                                "gpurun_out")
         os.makedirs(out_dir, exist_ok=True)
-        with open(os.path.join(out_dir, "parity_c2.json"), "w") as fh:
+        with open(os.path.join(out_dir, name + ".json"), "w") as fh:
             json.dump(record, fh, indent=1)
     except OSError:
         pass
+
+
+_ERR_KEYS = ("ambiguous_fraction", "masked_pixels")
+
+
+@pytest.mark.parametrize("cam", [(0, 1), (3, 8)])
+def test_config_c2_100k_1080p_deg3(gsa, cam):
+    """BASELINE config C2: 100k gaussians, 1920x1080, SH degree 3, forward+backward, vs the CPU oracle -- on view 0
+    (identity rotation) and on ring camera 3 of 8 (rotated by 135 degrees: every entry of R is in play)."""
+    from gsplat_amd import scene
+    W, H = 1920, 1080
+    sc = scene.make_scene(100_000, seed=0, sh_degree=3)
+    m1, m0, errs = _compare(sc, scene.make_camera(*cam), scene.make_intrinsics(W, H), W, H, 3,
+                            bg=torch.zeros(3), use_v_alpha=False, checkpoint=True)
+    print("C2 (err HIP vs fp64, err fp32-oracle vs fp64):", errs, "M =", m1["flatten_ids"].numel())
+    # evidence: per tensor (err of HIP vs the fp64 oracle, err of the fp32 oracle vs the fp64 oracle), the masked pixels
+    _parity_record(f"parity_c2_cam{cam[0]}of{cam[1]}", {
+        "config": f"C2: 100000 gaussians, 1920x1080, SH degree 3, forward+backward, ring camera {cam[0]} of {cam[1]}",
+        "metric": "max|a - b| / max|b| per tensor, b = fp64 oracle; pixels whose threshold comparisons are "
+                  "ambiguous in the fp64 oracle are masked on both sides and checked against their flip bound instead",
+        "masked_pixel_fraction": errs["ambiguous_fraction"], "intersections_M": int(m1["flatten_ids"].numel()),
+        "masked_pixels": errs["masked_pixels"],
+        "tensors": {k: {"err_hip": v[0], "err_fp32_oracle": v[1]} for k, v in errs.items() if k not in _ERR_KEYS}})
     assert 0 < m1["flatten_ids"].numel() <= m0["flatten_ids"].numel() + 64  # default cull_mode drops unreachable tiles
 
 
-def test_config_c3_density_crop_1m(gsa):
+@pytest.mark.parametrize("cam", [(0, 1), (3, 8)])
+def test_config_c3_density_crop_1m(gsa, cam):
     """BASELINE config C3's DENSITY against the oracle: a central crop (shifted principal point -- the construction of
-    bench.py's cpu_baseline) of the 1M-gaussian 1080p view 0, SH degree 3, forward+backward: ~1500 records per tile,
+    bench.py's cpu_baseline) of the 1M-gaussian 1080p view, SH degree 3, forward+backward: ~1500 records per tile,
     where the T <= 1e-4 stop, the early-out and the blended-record lists decide (C2 has ~100).  Image and all five
-    gradients against the fp64 oracle, 1e-4 outright; the masked pixels within their flip bound.  The crop is 384x216
-    (24 x 14 tiles): the fp64 oracle with its ambiguity bookkeeping needs minutes for the 1280x720 crop bench.py times in
-    fp32, and what this test is after -- the list length per tile -- does not depend on the crop's size."""
+    gradients against the fp64 oracle, 1e-4 outright; the masked pixels within their flip bound.  View 0 and ring camera
+    3 of 8 (rotated).  The crop is 384x216 (24 x 14 tiles): the fp64 oracle with its ambiguity bookkeeping needs minutes
+    for the 1280x720 crop bench.py times in fp32, and what this test is after -- the list length per tile -- does not
+    depend on the crop's size."""
     from gsplat_amd import scene
     W, H, cw, ch = 1920, 1080, 384, 216
     sc = scene.make_scene(1_000_000, seed=0, sh_degree=3)
     K = scene.make_intrinsics(W, H).clone()
     K[0, 2] -= (W - cw) / 2.0
     K[1, 2] -= (H - ch) / 2.0
-    m1, m0, errs = _compare(sc, scene.make_camera(0, 1), K, cw, ch, 3, bg=torch.zeros(3), use_v_alpha=False, checkpoint=True)
+    m1, m0, errs = _compare(sc, scene.make_camera(*cam), K, cw, ch, 3, bg=torch.zeros(3), use_v_alpha=False, checkpoint=True)
     print("C3 crop (err HIP vs fp64, err fp32-oracle vs fp64):", errs, "M =", m1["flatten_ids"].numel())
-    record = {"config": f"C3 density: central {cw}x{ch} crop (principal point shifted) of the 1000000-gaussian 1920x1080 view 0, "
-                        "SH degree 3, forward+backward",
-              "metric": "max|a - b| / max|b| per tensor, b = fp64 oracle; pixels whose threshold comparisons are ambiguous "
-                        "in the fp64 oracle are masked on both sides and checked against their flip bound instead",
-              "masked_pixel_fraction": errs["ambiguous_fraction"], "masked_pixels": errs["masked_pixels"],
-              "intersections_M": int(m1["flatten_ids"].numel()),
-              "records_per_tile": int(m1["flatten_ids"].numel()) / (((cw + 15) // 16) * ((ch + 15) // 16)),
-              "tensors": {k: {"err_hip": v[0], "err_fp32_oracle": v[1]} for k, v in errs.items()
-                          if k not in ("ambiguous_fraction", "masked_pixels")}}
-    try:
-        out_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
-                               "gpurun_out")
-        os.makedirs(out_dir, exist_ok=True)
-        with open(os.path.join(out_dir, "parity_c3crop.json"), "w") as fh:
-            json.dump(record, fh, indent=1)
-    except OSError:
-        pass
+    _parity_record(f"parity_c3crop_cam{cam[0]}of{cam[1]}", {
+        "config": f"C3 density: central {cw}x{ch} crop (principal point shifted) of the 1000000-gaussian 1920x1080 view, "
+                  f"ring camera {cam[0]} of {cam[1]}, SH degree 3, forward+backward",
+        "metric": "max|a - b| / max|b| per tensor, b = fp64 oracle; pixels whose threshold comparisons are ambiguous "
+                  "in the fp64 oracle are masked on both sides and checked against their flip bound instead",
+        "masked_pixel_fraction": errs["ambiguous_fraction"], "masked_pixels": errs["masked_pixels"],
+        "intersections_M": int(m1["flatten_ids"].numel()),
+        "records_per_tile": int(m1["flatten_ids"].numel()) / (((cw + 15) // 16) * ((ch + 15) // 16)),
+        "tensors": {k: {"err_hip": v[0], "err_fp32_oracle": v[1]} for k, v in errs.items() if k not in _ERR_KEYS}})
+
+
+def test_config_c3_density_right_edge_window_1m(gsa):
+    """C3's density where the pixel coordinates are LARGE: mean2d is an fp32 pixel coordinate, its ulp is 1.2e-4 beyond
+    x = 1024, and the shifted principal point of the crop test above moves every coordinate back to the small ones.  Here
+    the frame stays 1920 x 1080 with the true camera and the SCENE is cut instead: the gaussians whose tile rectangle
+    touches the window x in [1536, 1920), y in [432, 648) (24 x 14 tiles at the right edge) -- 1M-gaussian density inside
+    the window, an empty frame around it, so the fp64 oracle finishes -- forward + backward, image and all five gradients
+    against the fp64 oracle, 1e-4 outright, masked pixels within their flip bounds."""
+    from gsplat_amd import scene, stages as S
+    W, H = 1920, 1080
+    x0, x1, y0, y1 = 1536, 1920, 432, 648
+    sc = scene.make_scene(1_000_000, seed=0, sh_degree=3)
+    vm, K = scene.make_camera(0, 1), scene.make_intrinsics(W, H)
+    d = {k: v.cuda().contiguous() for k, v in sc.items()}
+    splat, radii, _, _ = S.project_fwd(d["means3D"], d["rotations"], d["scales"], d["opacities"][:, 0].contiguous(), d["shs"],
+                                       3, vm.cuda(), K.cuda(), W, H, 0)
+    mx, my, rx, ry = splat[:, 0], splat[:, 1], radii[:, 0].float(), radii[:, 1].float()
+    # one more tile of margin than the rectangles need: every gaussian that can reach a window pixel is in
+    touch = ((radii > 0).all(-1) & (mx + rx > x0 - 16) & (mx - rx < x1 + 16) & (my + ry > y0 - 16) & (my - ry < y1 + 16)).cpu()
+    sub = {k: v[touch].contiguous() for k, v in sc.items()}
+    n_sub = int(touch.sum())
+    assert 20_000 < n_sub < 200_000, n_sub
+    del d, splat, radii
+    m1, m0, errs = _compare(sub, vm, K, W, H, 3, bg=torch.zeros(3), use_v_alpha=False, checkpoint=True)
+    offs = m1["isect_offsets"][0].cpu()
+    tw = (W + 15) // 16
+    per_tile = torch.diff(torch.cat([offs.flatten(), torch.tensor([int(m1["flatten_ids"].numel())])])).view(-1, tw)
+    inside = per_tile[y0 // 16:y1 // 16, x0 // 16:x1 // 16].float().mean()
+    print("C3 right-edge window (err HIP vs fp64, err fp32-oracle vs fp64):", errs, "records per window tile =", float(inside))
+    assert float(inside) > 1000      # C3's density (1 673 per tile at the frame's centre)
+    _parity_record("parity_c3_right_edge", {
+        "config": f"C3 density at large pixel coordinates: the {n_sub} of 1000000 gaussians that touch the window "
+                  f"x in [{x0}, {x1}), y in [{y0}, {y1}) of the 1920x1080 view 0 (true camera, full frame), SH degree 3, "
+                  "forward+backward",
+        "metric": "max|a - b| / max|b| per tensor, b = fp64 oracle; masked pixels checked against their flip bound",
+        "masked_pixel_fraction_of_the_frame": errs["ambiguous_fraction"], "masked_pixels": errs["masked_pixels"],
+        "records_per_window_tile": float(inside), "intersections_M": int(m1["flatten_ids"].numel()),
+        "tensors": {k: {"err_hip": v[0], "err_fp32_oracle": v[1]} for k, v in errs.items() if k not in _ERR_KEYS}})
 
 
 def test_grad_out_writes_into_caller_bucket(gsa):

@@ -21,10 +21,8 @@ for fused in ((True,) if os.environ.get("FUSED_ONLY") else (False, True)):
                                     features_rest=sc["shs"][:, 1:].to(dev),
                                     opacity=torch.logit(sc["opacities"].clamp(1e-4, 1 - 1e-4)).to(dev),
                                     scaling=torch.log(sc["scales"]).to(dev), rotation=sc["rotations"].to(dev))
-    tr = ViewParallelTrainer(model, gsplat_amd.HipBackend(K), fused=fused,
-                             overlap_views={"0": False, "alternate": "alternate"}.get(os.environ.get("OVERLAP", "front"), "front"))
-    if os.environ.get("SIDE_PRIORITY"):
-        tr._side = torch.cuda.Stream(device=dev, priority=int(os.environ["SIDE_PRIORITY"]))
+    tr = ViewParallelTrainer(model, gsplat_amd.HipBackend(K), fused=fused, overlap_views=os.environ.get("OVERLAP", "1") != "0")
+    tr.async_metrics = fused and os.environ.get("ASYNC_METRICS", "1") != "0"   # (the loop's way: metrics one step late)
     tr.iteration = 5000   # SH degree 3
     for _ in range(3):
         tr.training_step(batch)
