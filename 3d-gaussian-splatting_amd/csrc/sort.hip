@@ -81,7 +81,8 @@ constexpr int kTabLut = 0;                   // 4096 bytes: cell -> bucket
 constexpr int kTabCs = 1024;                 // 257 words: bucket -> first cell (then the end)
 constexpr int kTabPlan = 1284;               // g0, shift, cells, flags
 constexpr int kTabWords = 1288;
-constexpr uint32_t kPlanWide = 1u;           // the key range is wider than 250 x 65536 keys: 16-bit local sorts cannot order it
+constexpr uint32_t kPlanWide = 1u;           // the key range is wider than 250 x 2^24 keys (no float depth range is): 24-bit local sorts cannot order it
+constexpr uint32_t kLocalBits = 24;          // key bits a bucket's local sort covers (r04; 16 before: two octaves of depth per view)
 
 struct DepthPlan { uint32_t g0, shift, cells, flags; };
 
@@ -111,7 +112,7 @@ __device__ __forceinline__ uint32_t tab_excl_scan(uint32_t v, uint32_t *scratch,
 
 // ONE workgroup, in front of the histogram pass: the view's depth table from what gsa_project_fwd left per wave.
 __global__ __launch_bounds__(kTabThreads) void depth_table_kernel(const uint4 *__restrict__ ranges, int n_waves,
-                                                                  uint32_t *__restrict__ table_out, int margin) {
+                                                                  uint32_t *__restrict__ table_out) {
     __shared__ __attribute__((aligned(16))) uint8_t s_lut[kCellsMax];
     __shared__ uint32_t s_fine[kCellsMax], s_cs[260], scratch[8 * (kTabThreads / 64)];
     const int t = threadIdx.x;
@@ -167,13 +168,8 @@ __global__ __launch_bounds__(kTabThreads) void depth_table_kernel(const uint4 *_
 #pragma unroll
     for (int w = 0; w < NW; ++w) { lo = min(lo, scratch[4 * NW + w]); hi = max(hi, scratch[5 * NW + w]); }
     DepthPlan pl{0u, 0u, 1u, 0u};
-    if (margin && lo <= hi) {   // a table that is to serve LATER views of the shape as well: 1/16 of the range more at either end
-        const uint32_t m = ((hi - lo) >> 4) + 1u;
-        lo = lo > m ? lo - m : 0u;
-        hi = hi < 0xFFFFFFFEu - m ? hi + m : 0xFFFFFFFEu;
-    }
     if (lo <= hi) {
-        if ((unsigned long long)hi - lo + 1ull > 250ull * 65536ull) pl.flags = kPlanWide;   // (250: the cells' alignment and
+        if ((unsigned long long)hi - lo + 1ull > (250ull << kLocalBits)) pl.flags = kPlanWide;   // (250: the cells' alignment and
                                                                                               // rounding need the rest of the 254)
         uint32_t sh = 0;
         while ((hi >> sh) - (lo >> sh) + 1u > (uint32_t)kCellsMax) ++sh;   // (aligned cells of 2^sh keys; <= 21 trips)
@@ -182,7 +178,7 @@ __global__ __launch_bounds__(kTabThreads) void depth_table_kernel(const uint4 *_
         pl.cells = (hi >> sh) - pl.g0 + 1u;
     }
     const uint32_t G = pl.cells;
-    const uint32_t max_cells = pl.shift >= 16u ? 1u : (65536u >> pl.shift);   // cells whose keys fit 16-bit offsets (flagged if too few)
+    const uint32_t max_cells = pl.shift >= kLocalBits ? 1u : ((1u << kLocalBits) >> pl.shift);   // cells whose keys fit the local sorts' offsets (flagged if too few)
     // ---- the sample, per cell
     uint32_t n_smp = 0;
 #pragma unroll
@@ -307,6 +303,29 @@ __device__ __forceinline__ unsigned sort_block_id() {
 __device__ __forceinline__ unsigned live_block_id(unsigned live) {
     const unsigned p = blockIdx.x, q = live >> 3, r = live & 7u, x = p & 7u, i = p >> 3;
     return i < q + (x < r ? 1u : 0u) ? x * q + min(x, r) + i : 0xFFFFFFFFu;
+}
+
+// ... for a launch whose first `front` live chunks cost more than the rest (emit_place: the blocks that compute quadrant
+// masks): every XCD owns a consecutive run of the front chunks AND a consecutive run of the others, so that the expensive
+// ones are spread over all eight XCDs (with live_block_id they would all sit on the first XCDs, which then decide the
+// kernel's duration) while a bin's region is still filled by few fronts per XCD.
+__device__ __forceinline__ unsigned split_block_id(unsigned live, unsigned front) {
+    // XCD x runs the workgroups x, x + 8, ...: floor((grid - x + 7) / 8) of them, and a launch for an EXACT record count has
+    // grid == live -- so the two runs of an XCD must add up to its share of `live` exactly: the front's remainder goes to the
+    // XCDs 0 .. rf - 1, the others' remainder to the XCDs that follow them (rf, rf + 1, ... modulo 8).
+    const unsigned p = blockIdx.x, x = p & 7u, i = p >> 3;
+    const unsigned qf = front >> 3, rf = front & 7u, nf = qf + (x < rf ? 1u : 0u);
+    if (i < nf) return x * qf + min(x, rf) + i;
+    const unsigned back = live - front, qb = back >> 3, rb = back & 7u;
+    unsigned start = x * qb, mine = qb;
+#pragma unroll
+    for (unsigned xx = 0; xx < 8u; ++xx) {
+        const unsigned extra = ((xx + 8u - rf) & 7u) < rb ? 1u : 0u;
+        if (xx < x) start += extra;
+        if (xx == x) mine += extra;
+    }
+    const unsigned j = i - nf;
+    return j < mine ? front + start + j : 0xFFFFFFFFu;
 }
 
 // ---- pass 1: per-block digit histogram, written digit-major: hist[d * nblocks + block] -------------
@@ -1340,7 +1359,9 @@ __global__ __launch_bounds__(kSortThreads, 4) void emit_place_kernel(
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t m_total = m_dev ? min(m_cap, *m_dev) : m_cap;
     const unsigned live = (unsigned)(((uint64_t)m_total + kSortChunk - 1) / kSortChunk);
-    const unsigned bid = GSA_PLACE_XCD ? live_block_id(live) : blockIdx.x;
+    // (the blocks in front of mask_front compute masks: see below)
+    const unsigned mask_front = MASK_Q != 0 ? (unsigned)(((uint64_t)live * mask_q8 + 255u) >> 8) : 0u;
+    const unsigned bid = !GSA_PLACE_XCD ? blockIdx.x : MASK_Q != 0 ? split_block_id(live, min(mask_front, live)) : live_block_id(live);
     if (bid >= live) return;
     SORT_TRACE_BEGIN();
     const EmitLoads el = emit_owner_loads(offsets, rects, order, block_owner, nblocks, m_total, true, bid, n);
@@ -1374,7 +1395,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void emit_place_kernel(
     // all-ones (the compositor then falls back to its own reach test for those entries).  A record block holds records of
     // one depth range, i.e. the same relative position in every bin's list -- and where the scene is dense enough for the
     // masks to matter, a quadrant's pixels saturate within the first third of its list: the deep half is never scanned.
-    const bool compute_masks = MASK_Q != 0 && (uint64_t)bid * 256u < (uint64_t)live * mask_q8;
+    const bool compute_masks = MASK_Q != 0 && bid < mask_front;
     if constexpr (MASK_Q != 0) {
         if (!compute_masks) {
             load_bases();
@@ -1621,11 +1642,12 @@ extern "C" int gsa_depth_order(int n, const uint32_t *depth_keys, const uint32_t
 // ctl[1..2]); the caller then repeats with the LSD path.
 constexpr int kLocalThreads = 1024, kLocalWaves = kLocalThreads / 64, kLocalCap = 8192;
 constexpr unsigned long long kGranuleReady = 1ull << 63;
-constexpr uint32_t kStatusOverflow = 1u, kStatusTimeout = 2u, kStatusWide = 4u, kStatusRange = 8u;
+constexpr uint32_t kStatusOverflow = 1u, kStatusTimeout = 2u, kStatusWide = 4u;
 
 struct BucketLds {
     uint32_t val[2][kLocalCap];           // gaussian ids, ping-pong; after the sort the idle half holds the record counts
-    uint16_t key[2][kLocalCap];           // the key's offset inside its bucket
+    uint16_t key[2][kLocalCap];           // the key's offset inside its bucket (wide buckets: its bits 8 .. 23)
+    uint8_t low[kLocalCap];               // wide buckets (more than 65536 keys wide): bits 0 .. 7 of the offset -- the first local pass's digit
     uint16_t rk[kLocalCap];               // rank of an item among the items of its digit in its wave's range
     uint32_t wcnt[kLocalWaves][kRadix];   // per wave range and digit: count, then first slot
     uint32_t dbase[kRadix];
@@ -1662,6 +1684,7 @@ __device__ __forceinline__ uint32_t block1024_max(uint32_t v, uint32_t *scratch)
 }
 
 // one stable counting-sort pass over the mm items of L.key/val[src] on key bits [bs, bs + 8) into [src ^ 1]
+// (bs < 0: on the byte L.low[i] of every item -- the first pass of a wide bucket, over items still in load order)
 __device__ __forceinline__ void bucket_local_pass(BucketLds &L, int src, int mm, int bs) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int R = ((mm + kLocalThreads - 1) / kLocalThreads) * 64;   // items per wave range (a multiple of 64)
@@ -1680,7 +1703,7 @@ __device__ __forceinline__ void bucket_local_pass(BucketLds &L, int src, int mm,
         for (int i0 = wave * R; i0 < end; i0 += 64) {
             const int i = i0 + lane;
             const bool valid = i < end;
-            const uint32_t d = valid ? ((uint32_t)L.key[src][i] >> bs) & (kRadix - 1) : 0u;
+            const uint32_t d = !valid ? 0u : bs < 0 ? (uint32_t)L.low[i] : ((uint32_t)L.key[src][i] >> bs) & (kRadix - 1);
             const uint32_t rank = wave_rank_round(mask, cnt, d, valid, lane);
             if (valid) L.rk[i] = (uint16_t)rank;
         }
@@ -1701,7 +1724,7 @@ __device__ __forceinline__ void bucket_local_pass(BucketLds &L, int src, int mm,
     __syncthreads();
     for (int i = t; i < mm; i += kLocalThreads) {
         const uint32_t k = L.key[src][i];
-        const uint32_t d = (k >> bs) & (kRadix - 1);
+        const uint32_t d = bs < 0 ? (uint32_t)L.low[i] : (k >> bs) & (kRadix - 1);
         const uint32_t pos = L.dbase[d] + L.wcnt[i / R][d] + L.rk[i];
         L.key[src ^ 1][pos] = (uint16_t)k;
         L.val[src ^ 1][pos] = L.val[src][i];
@@ -1752,7 +1775,9 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
         width = (uint32_t)((((unsigned long long)(d + 1) << 32) + scale - 1u) / scale) - lo_d;
         sub = key_min + lo_d;
     }
-    const uint32_t mask = 0xFFFFu;
+    // a bucket wider than 65536 keys (a view whose visible depths span more than ~2 octaves) sorts on 24 bits: the low
+    // byte of the offset goes to L.low and is the first pass's digit, bits 8 .. 23 are the 16-bit key of the other two
+    const bool wide = width > 65536u;                  // (uniform)
     // (loads in groups of four strides with CLAMPED indices, all of a group in flight at once: a plain strided loop
     // waits for every load before it issues the next -- one memory round trip per 1024 items)
     constexpr int kStrides = kLocalCap / kLocalThreads;
@@ -1771,15 +1796,19 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
         for (int j = 0; j < 4; ++j) {
             const int i = (g4 + j) * kLocalThreads + t;
             if (i < mm) {
-                L.key[0][i] = (uint16_t)((kk[j] - sub) & mask);
+                const uint32_t x = kk[j] - sub;        // (< width <= 2^24, unless a key lies outside the planned range: reported)
+                L.key[0][i] = (uint16_t)((wide ? x >> 8 : x) & 0xFFFFu);
+                if (wide) L.low[i] = (uint8_t)x;
                 L.val[0][i] = vv[j];
             }
         }
     }
     __syncthreads();
     SORT_TRACE_MARK(0);   // ticket, bucket bounds, key / value loads
-    if (mm > 0 && width > 1u) { bucket_local_pass(L, cur, mm, 0); cur ^= 1; }   // (mm, width: uniform)
-    if (mm > 0 && width > 256u) { bucket_local_pass(L, cur, mm, 8); cur ^= 1; }
+    const uint32_t width16 = wide ? (width + 255u) >> 8 : width;   // distinct values of the 16-bit key
+    if (mm > 0 && wide) { bucket_local_pass(L, cur, mm, -1); cur ^= 1; }
+    if (mm > 0 && width16 > 1u) { bucket_local_pass(L, cur, mm, 0); cur ^= 1; }   // (mm, width: uniform)
+    if (mm > 0 && width16 > 256u) { bucket_local_pass(L, cur, mm, 8); cur ^= 1; }
 
     SORT_TRACE_MARK(1);   // local passes
     // rectangles and record counts of the bucket's gaussians, now in depth order
@@ -1851,10 +1880,6 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
             // which the host polls for.  (A block can only time out on a granule this block waits for as well, so the
             // status read here is final.)
             if (table && (table[kTabPlan + 3] & kPlanWide)) atomicOr(&ctl[3], kStatusWide);   // the range was too wide for 16-bit local sorts
-            if (table && ctl[1] <= ctl[2]) {   // a table built for ANOTHER view: do this view's visible keys lie inside its cells?
-                const uint32_t sh = table[kTabPlan + 1], g0 = table[kTabPlan], cells = table[kTabPlan + 2];
-                if ((ctl[1] >> sh) < g0 || (ctl[2] >> sh) - g0 >= cells) atomicOr(&ctl[3], kStatusRange);
-            }
             if (ctl_host) {
                 __threadfence();
                 const uint32_t st = __hip_atomic_load(&ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1901,7 +1926,7 @@ extern "C" size_t gsa_depth_order_msd_workspace_bytes(int n) {
            gsa_sort_workspace_bytes(n) + (size_t)(2 * kRadix + 16 + kTabWords) * sizeof(uint32_t) + 16;
 }
 
-extern "C" int gsa_depth_order_msd_max_width(void) { return 65536; }
+extern "C" int gsa_depth_order_msd_max_width(void) { return 1 << kLocalBits; }
 
 // where gsa_depth_order_msd(key_range_dev) leaves the view's depth table inside its workspace (diagnostics and tests):
 // byte offset from a 16-byte-aligned workspace base; gsa_depth_order_msd_table_words() uint32 -- bytes [0, 4096): bucket of
@@ -1915,14 +1940,13 @@ extern "C" size_t gsa_depth_order_msd_table_offset(int n) {
 }
 extern "C" int gsa_depth_order_msd_table_words(void) { return kTabWords; }
 
-static int depth_order_msd_impl(int n, const uint32_t *depth_keys, const uint32_t *tile_rects, uint32_t key_min,
-                                uint32_t scale, const uint32_t *key_range_dev, uint32_t *table_ext, uint32_t *order,
-                                uint32_t *rects, uint32_t *offsets, int32_t *block_owner,
-                                int n_blocks, uint32_t *ctl, uint32_t *ctl_host, uint32_t token, void *workspace,
-                                size_t workspace_bytes, gsa_stream_t stream) {
-    // (scale >= 2^16: a bucket is at most 2^32 / scale + 1 <= 65537 keys wide -- 16-bit local sorts; exactly 2^16 is the
-    // power-of-two case shift = 16)
-    GSA_RETURN_IF(n < 0 || (!key_range_dev && !table_ext && scale < 65536u) || !ctl || n_blocks < 0 ||
+extern "C" int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint32_t *tile_rects, uint32_t key_min,
+                                   uint32_t scale, const uint32_t *key_range_dev, uint32_t *order, uint32_t *rects,
+                                   uint32_t *offsets, int32_t *block_owner,
+                                   int n_blocks, uint32_t *ctl, uint32_t *ctl_host, uint32_t token, void *workspace,
+                                   size_t workspace_bytes, gsa_stream_t stream) {
+    // (scale > 2^8: a bucket is at most 2^32 / scale + 1 <= 2^24 keys wide -- what the 24-bit local sorts cover)
+    GSA_RETURN_IF(n < 0 || (!key_range_dev && scale <= 256u) || !ctl || n_blocks < 0 ||
                   (n_blocks > 0 && !block_owner), GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF((reinterpret_cast<uintptr_t>(key_range_dev) & 15) != 0, GSA_ERR_INVALID_ARGUMENT);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1951,12 +1975,10 @@ static int depth_order_msd_impl(int n, const uint32_t *depth_keys, const uint32_
     uint32_t *ticket = reinterpret_cast<uint32_t *>(granule + kRadix);
     // key_range_dev: what gsa_project_fwd left per wave -> one workgroup builds this view's depth table behind the ticket
     // for the launches that follow (the row scan zeroes only granules, ticket and ctl[3])
-    // table_ext: the caller's table -- built here, with a margin, if key_range_dev is given; used as it is otherwise
-    uint32_t *table = table_ext ? table_ext : (key_range_dev ? ticket + 16 : nullptr);
+    uint32_t *table = key_range_dev ? ticket + 16 : nullptr;
     const RadixDigit dg{(int)scale, key_min, table ? 2 : 1, table, nullptr, 0u};
     if (key_range_dev) {
-        depth_table_kernel<<<1, kTabThreads, 0, s>>>(reinterpret_cast<const uint4 *>(key_range_dev), gsa_div_up(n, 64), table,
-                                                     table_ext ? 1 : 0);
+        depth_table_kernel<<<1, kTabThreads, 0, s>>>(reinterpret_cast<const uint4 *>(key_range_dev), gsa_div_up(n, 64), table);
         GSA_LAUNCH_CHECK();
     }
     radix_hist_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(n, nullptr, depth_keys, dg, nblocks, hist, block_range);
@@ -1974,29 +1996,6 @@ static int depth_order_msd_impl(int n, const uint32_t *depth_keys, const uint32_
                                                               granule, ticket, ctl, ctl_host, token, table);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
-}
-
-extern "C" int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint32_t *tile_rects, uint32_t key_min,
-                                   uint32_t scale, const uint32_t *key_range_dev, uint32_t *order, uint32_t *rects,
-                                   uint32_t *offsets, int32_t *block_owner,
-                                   int n_blocks, uint32_t *ctl, uint32_t *ctl_host, uint32_t token, void *workspace,
-                                   size_t workspace_bytes, gsa_stream_t stream) {
-    return depth_order_msd_impl(n, depth_keys, tile_rects, key_min, scale, key_range_dev, nullptr, order, rects, offsets,
-                                block_owner, n_blocks, ctl, ctl_host, token, workspace, workspace_bytes, stream);
-}
-
-// ... with the depth table in the CALLER's memory (gsa_depth_order_msd_table_words() uint32): built from key_range_dev with a
-// margin of 1/16 of the key range at either end when that is given, used as it is when it is NULL -- a table one view built
-// then orders the later views of the same scene shape without a table launch of their own.  The ordering never depends
-// on the table; a view whose visible keys leave the table's cells is REPORTED (ctl[3] bit 3), like a bucket overflow.
-extern "C" int gsa_depth_order_msd_table(int n, const uint32_t *depth_keys, const uint32_t *tile_rects,
-                                         const uint32_t *key_range_dev, uint32_t *table, uint32_t *order, uint32_t *rects,
-                                         uint32_t *offsets, int32_t *block_owner, int n_blocks, uint32_t *ctl,
-                                         uint32_t *ctl_host, uint32_t token, void *workspace, size_t workspace_bytes,
-                                         gsa_stream_t stream) {
-    GSA_RETURN_IF(!table || (reinterpret_cast<uintptr_t>(table) & 15) != 0, GSA_ERR_INVALID_ARGUMENT);
-    return depth_order_msd_impl(n, depth_keys, tile_rects, 0u, 0u, key_range_dev, table, order, rects, offsets, block_owner,
-                                n_blocks, ctl, ctl_host, token, workspace, workspace_bytes, stream);
 }
 
 static int tile_emit_impl(int n, const uint32_t *order, const uint32_t *offsets, const float *splat,

@@ -698,4 +698,13 @@ class ViewParallelTrainer:
             r = host.tolist()
         else:
             r = report.tolist()                                    # the step's one host read-back
+        if found_inf is not None:                                  # GradScaler.update()
+            if r[5] != 0.0:
+                self.optimizer.step_count -= 1                     # the update was skipped on the device
+                self.loss_scale, self._good_steps = self.loss_scale * 0.5, 0
+                self.skipped_steps += 1
+            else:
+                self._good_steps += 1
+                if self._good_steps >= 2000:
+                    self.loss_scale, self._good_steps = self.loss_scale * 2.0, 0
         return {"loss": r[3], "l1": r[0] / n_views, "ssim": r[1] / n_views, "psnr": r[2] / n_views, "scale_reg": r[4]}

@@ -172,6 +172,24 @@ WAIT_STATS = [0, 0.0]   # read-backs waited for, seconds spent waiting: the host
 REPAIR_STATS = {"views": 0, "capacity_misses": 0, "key_range_repairs": 0}
 
 
+# which depth ordering the views took: the bucketed one on host-planned equal buckets / on the view's own device-built depth
+# table, or the LSD passes (first call of a shape, repair, back-off, populations beyond _MSD_MAX_N) -- bench.py reports them
+PATH_STATS = {"bucketed_host_plan": 0, "bucketed_device_table": 0, "lsd": 0}
+
+
+def last_key_span_octaves(dev, width: int, height: int, cull_mode: int = 0) -> Optional[float]:
+    """Octaves of depth between the smallest and the largest visible depth key remembered for this scene shape (the union
+    over its recent views): log2(z_max / z_min)."""
+    import struct
+    for bt in (32, 64, 16):
+        ent = _KEY_RANGE.get((dev.type, dev.index, width, height, cull_mode, bt))
+        if ent is not None and ent[0] <= ent[1]:
+            z0 = struct.unpack("f", struct.pack("I", ent[0]))[0]
+            z1 = struct.unpack("f", struct.pack("I", ent[1]))[0]
+            return round(math.log2(max(z1, 1e-30) / max(z0, 1e-30)), 2)
+    return None
+
+
 def _wait_slot(slot) -> None:
     """Blocks until the slot's control words are there: an event (copied slots) or the kernel-written token."""
     t_in = time.perf_counter()
@@ -338,12 +356,12 @@ _BIN_DIRECT = os.environ.get("GSPLAT_AMD_BIN_DIRECT", "1") != "0"
 # them a net loss and is now only what the other binning paths fall back to when masks are asked for explicitly
 # (``bin_tiles(quad_masks=True)``).  GSPLAT_AMD_QUAD_MASKS=0 switches the masks off (A/B).
 _QUAD_MASKS = os.environ.get("GSPLAT_AMD_QUAD_MASKS", "1") != "0"
-# ... for the front GSPLAT_AMD_MASK_DEPTH (default 0.5) of the records in depth order; the deep rest gets all-ones masks (the
+# ... for the front GSPLAT_AMD_MASK_DEPTH (default 0.4) of the records in depth order; the deep rest gets all-ones masks (the
 # compositor's own reach test then decides).  Where masks pay -- lists long enough that gathering candidates dominates -- a
 # quadrant's pixels saturate within the first third of its list, so the deep half of every list is never scanned and its
 # masks would be computed for nothing; in a sparse scene the unmasked half costs what r03 paid for every record.
 # ``bin_tiles(quad_masks=True)`` masks every record.
-_MASK_DEPTH_Q8 = max(1, min(256, int(round(256 * float(os.environ.get("GSPLAT_AMD_MASK_DEPTH", "0.5"))))))
+_MASK_DEPTH_Q8 = max(1, min(256, int(round(256 * float(os.environ.get("GSPLAT_AMD_MASK_DEPTH", "0.4"))))))
 # (device, W, H, cull_mode) -> [records per gaussian the next call provisions for, consecutive low counts].
 # Keyed WITHOUT N: densify / prune changes N every 100 iterations (trainer.py:794-797) and a changed N predicts its
 # capacity from the remembered ratio instead of costing a blocking read-back.  Grows at once, shrinks only after many
@@ -376,16 +394,6 @@ _MSD_MIN_N = 32768        # below this the 256 x 1024-thread bucket launch costs
 _MSD_MAX_N = 1_400_000    # above this an average bucket (N / 255, x1.5 for skew) no longer fits the 8192-key LDS capacity
 _MSD_BACKOFF = {}         # scene shape -> calls left before the bucketed ordering is tried again after an overflow
 _MSD_STREAK = {}          # scene shape -> overflows of the device-planned ordering in a row (escalates the back-off)
-# GSPLAT_AMD_TABLE_REUSE=1: a depth table built (with a margin) for one view of a scene shape orders the later views of the
-# shape as well -- no table launch of their own, buckets levelled as far as the views resemble one another -- until a view
-# does not fit it (reported, repaired, the shape back on the other plans for _REUSE_BACKOFF_VIEWS views)
-_TABLE_REUSE = os.environ.get("GSPLAT_AMD_TABLE_REUSE", "0") != "0"
-_REUSE_BACKOFF_VIEWS, _REUSE_AFTER_GOOD = 256, 8
-_SHAPE_TABLE = {}         # scene shape -> the table (device tensor) its views are ordered with
-_SHAPE_GOOD = {}          # scene shape -> host-planned views in a row that held
-_REUSE_BACKOFF = {}       # scene shape -> views left before a table is built for reuse again
-_TABLE_GRAVEYARD = []     # tables dropped while kernels of another stream may still read them (kept a while)
-
 
 def _key_bits_needed(lo: int, hi: int) -> int:
     """Whole 8-bit passes that order keys in [lo, hi] completely: the bits in which the two ends differ."""
@@ -404,7 +412,7 @@ def _msd_plan(lo: int, hi: int):
     a, b = max(0, lo - margin), min(0xFFFFFFFE, hi + margin)
     span = max(b - a + 1, 256)
     scale = (255 << 32) // span          # (span >= 256: scale < 2^32)
-    if scale < (1 << 32) // _MSD_MAX_WIDTH:
+    if scale <= (1 << 32) // _MSD_MAX_WIDTH:   # (a bucket wider than the local sorts' 24 bits: no float depth range is)
         return None
     return (a, scale)
 
@@ -432,23 +440,8 @@ def _note_keys(key, lo: int, hi: int, assumed, status: int = 0) -> bool:
             else:
                 ent[2] = 0
     if isinstance(assumed, tuple):
-        if len(assumed) >= 3:   # planned on the device (the view's own table, or the shape's: assumed[3], [4]): only the status can say no
-            if len(assumed) == 5:
-                mode, tab = assumed[3], assumed[4]
-                if status == 0 and mode == "build":
-                    while len(_SHAPE_TABLE) >= _CAPACITY_MAX_KEYS and key not in _SHAPE_TABLE:
-                        _TABLE_GRAVEYARD.append(_SHAPE_TABLE.pop(next(iter(_SHAPE_TABLE))))
-                    _SHAPE_TABLE[key] = tab
-                elif status != 0:   # the shape's table does not fit this view (bit 3) or overflowed a bucket with it (bit 0)
-                    old = _SHAPE_TABLE.pop(key, None)
-                    if old is not None:
-                        _TABLE_GRAVEYARD.append(old)
-                    del _TABLE_GRAVEYARD[:-8]
-                    _REUSE_BACKOFF[key] = _REUSE_BACKOFF_VIEWS
-                    _SHAPE_GOOD.pop(key, None)
-                    if mode == "reuse" and not (status & 6):   # (a table of ANOTHER view did not fit this one -- range, or a
-                        return False                            # bucket it did not level: the other plans take the next view at once)
-            if status & 4:      # the range is beyond 16-bit local sorts: no table helps
+        if len(assumed) >= 3:   # planned on the device (the view's own depth table): only the status can say no
+            if status & 4:      # the keys span more than the local sorts cover (no range of float depths does)
                 _MSD_BACKOFF[key] = 64
             elif status & 1:    # a bucket overflowed although its table was built from the view's own keys (a cluster of equal
                 streak = _MSD_STREAK.get(key, 0)          # depths, or an unlucky sample): back off, longer when it repeats
@@ -466,10 +459,7 @@ def _note_keys(key, lo: int, hi: int, assumed, status: int = 0) -> bool:
             return False                      # from here on (no back-off: the next attempt runs on the device's plan)
         if status & 5:     # a depth cluster overflowed a bucket's LDS / the view's range is beyond 16-bit local sorts: every
             _MSD_BACKOFF[key] = 64   # such call costs a repair, so back off
-        kmin, scale = assumed
-        held = status == 0 and (lo > hi or (lo >= kmin and _msd_bucket(hi - kmin, scale) <= 254))
-        _SHAPE_GOOD[key] = _SHAPE_GOOD.get(key, 0) + 1 if held else 0
-        return held
+        return ok
     return _key_bits_needed(lo, hi) <= assumed
 
 
@@ -552,25 +542,18 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
             _MSD_BACKOFF[key] = backoff - 1
         use_msd = depth_msd if depth_msd is not None else (_DEPTH_MSD_DEFAULT and _MSD_MIN_N <= N <= _MSD_MAX_N and backoff == 0)
         plan = None
-        if cap is not None and use_msd and _TABLE_REUSE and key_range is not None and _DEPTH_TABLE == "auto":
-            wait = _REUSE_BACKOFF.get(key, 0)
-            if wait:
-                _REUSE_BACKOFF[key] = wait - 1
-            elif key in _SHAPE_TABLE:
-                plan = (0, 0, "device", "reuse", _SHAPE_TABLE[key])
-            elif _SHAPE_GOOD.get(key, 0) >= _REUSE_AFTER_GOOD:   # (views alike enough for ONE equal-bucket plan: try one table)
-                plan = (0, 0, "device", "build", torch.empty(lib.gsa_depth_order_msd_table_words(), dtype=torch.int32, device=dev))
-        if plan is None and cap is not None and use_msd:
+        if cap is not None and use_msd:
             left = _TABLE_MODE.get(key, 0)
-            if left > 0:
-                _TABLE_MODE[key] = left - 1
             want_table = _DEPTH_TABLE == "1" or (_DEPTH_TABLE == "auto" and left > 0)
             if want_table and key_range is not None:
+                if left > 0:
+                    _TABLE_MODE[key] = left - 1
                 plan = (0, 0, "device")     # the view's own depth table, built on the device
-            elif want_table and _DEPTH_TABLE == "auto":
-                plan = None                 # (equal buckets are known not to fit and the caller brought no key range: LSD)
             elif rng is not None:
+                # (a caller without a key range -- the stage API, tile_lists()'s re-binning -- stays on the host's equal
+                # buckets with their normal back-off, and does not use up the shape's views on the device plan)
                 plan = _msd_plan(rng[0], rng[1])
+        PATH_STATS["lsd" if plan is None else ("bucketed_device_table" if len(plan) == 3 else "bucketed_host_plan")] += 1
         if plan is not None:
             key_bits = plan
             n_blocks = (cap + BIN_BLOCK - 1) // BIN_BLOCK
@@ -582,17 +565,10 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
             token = _next_token()
             m_host[3] = 0
             slot = (m_host, m_event, token, pool)
-            if len(plan) == 5:   # the shape's own table: built by this call (with a margin) or by an earlier one
-                plan[4].record_stream(torch.cuda.current_stream())
-                _call("gsa_depth_order", lib.gsa_depth_order_msd_table, N, _ptr(depth_keys), _ptr(tile_rects),
-                      _ptr(key_range) if plan[3] == "build" else None, _ptr(plan[4]),
-                      _ptr(order), _ptr(rects), _ptr(offsets), _ptr(block_owner), n_blocks, _ptr(ctl),
-                      ctypes.c_void_p(m_host.data_ptr()), token, _ptr(dws), dws_bytes, st)
-            else:
-                _call("gsa_depth_order", lib.gsa_depth_order_msd, N, _ptr(depth_keys), _ptr(tile_rects), plan[0], plan[1],
-                      _ptr(key_range) if len(plan) == 3 else None,
-                      _ptr(order), _ptr(rects), _ptr(offsets), _ptr(block_owner), n_blocks, _ptr(ctl),
-                      ctypes.c_void_p(m_host.data_ptr()), token, _ptr(dws), dws_bytes, st)
+            _call("gsa_depth_order", lib.gsa_depth_order_msd, N, _ptr(depth_keys), _ptr(tile_rects), plan[0], plan[1],
+                  _ptr(key_range) if len(plan) == 3 else None,
+                  _ptr(order), _ptr(rects), _ptr(offsets), _ptr(block_owner), n_blocks, _ptr(ctl),
+                  ctypes.c_void_p(m_host.data_ptr()), token, _ptr(dws), dws_bytes, st)
         else:
             if rng is not None:
                 key_bits = _key_bits_needed(rng[0], rng[1])

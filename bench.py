@@ -155,6 +155,36 @@ def cpu_baseline_protocol():
                     "not the target; 1 warm-up + median of 5", "cores": cores, "cpu_model": cpu_model(), "runs": rows}
 
 
+def train_step_leg(sc, n, width, height, deg, views, dev, steps):
+    """BASELINE config C3's "full Adam loop" step on the product's fused harness (gsplat_amd.harness.ViewParallelTrainer,
+    fused=True: activations, B x (render, loss, backward), SH rebuild, Adam; metrics read back one step late): ms per
+    step and Mpix/s.  Reported beside `value`, never part of it."""
+    import gsplat_amd
+    from gsplat_amd import scene
+    from gsplat_amd.harness import SplatModel, ViewParallelTrainer
+    K = scene.make_intrinsics(width, height).to(dev)
+    batch = [{"image": torch.rand(height, width, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(7 + v)),
+              "pose": scene.make_camera(v, views).to(dev), "width": width, "height": height} for v in range(views)]
+    model = SplatModel(n, dev).load(xyz=sc["means3D"].to(dev), features_dc=sc["shs"][:, :1].to(dev),
+                                    features_rest=sc["shs"][:, 1:].to(dev),
+                                    opacity=torch.logit(sc["opacities"].clamp(1e-4, 1 - 1e-4)).to(dev),
+                                    scaling=torch.log(sc["scales"]).to(dev), rotation=sc["rotations"].to(dev))
+    tr = ViewParallelTrainer(model, gsplat_amd.HipBackend(K), fused=True)
+    tr.async_metrics = True
+    tr.iteration = 1000 * deg     # the SH degree of the workload (trainer.py:77-87)
+    for _ in range(4):
+        tr.training_step(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = tr.training_step(batch)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"what": "fused harness step: activations, %d x (render, loss, backward), SH rebuild, Adam; metrics one step late" % views,
+            "views": views, "steps": steps, "ms_per_step": round(dt * 1e3, 4),
+            "value": round(views * width * height / dt / 1e6, 3), "unit": "Mpix/s", "loss": round(float(out["loss"]), 5)}
+
+
 def self_launch(args) -> int:
     """``--gpus N`` without a launcher environment: start N ranks with torch.distributed.run as a CHILD process
     (nothing in this process has touched the GPU yet), relay its output, return its exit code."""
@@ -256,6 +286,7 @@ def main() -> None:
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--cull-mode", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the (untimed-by-value) training-step leg")
     ap.add_argument("--exchange", default="factored", choices=("factored", "allreduce"),
                     help="how the gaussian gradients of the views are summed (see DESIGN.md section 6)")
     ap.add_argument("--views-per-gpu", type=int, default=DEFAULT_VIEWS_PER_GPU,
@@ -302,16 +333,27 @@ def main() -> None:
     if dist is not None:
         try:
             flag_group = dist.new_group(backend="gloo")
-        except Exception as exc:   # noqa: BLE001  (no usable host interface for gloo: every view is checked inside its own call)
+        except Exception as exc:   # noqa: BLE001  (no usable host interface for gloo)
             flag_error = f"{type(exc).__name__}: {exc}"
+        # every rank must take the SAME decision (a rank that defers alone would wait in an all-reduce the others never
+        # enter): one collective on the default group says whether all of them got the host-side group
+        have = torch.tensor([0 if flag_group is None else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(have, op=dist.ReduceOp.MIN)
+        if int(have.item()) == 0:
+            flag_group = None
             args.no_defer_check = True
-            print(f"[bench] rank {rank}: no host-side group for the per-step check ({flag_error}); checking per view", file=sys.stderr)
+            print(f"[bench] rank {rank}: no host-side group for the per-step check on every rank ({flag_error}); "
+                  "checking per view", file=sys.stderr)
+    agree_stats = [0, 0.0]   # agreements, seconds spent in them (host side)
 
     def agree(ok: bool) -> bool:
         if dist is None:
             return ok
+        t0 = time.perf_counter()
         t = torch.tensor([1 if ok else 0], dtype=torch.int32)
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=flag_group)
+        agree_stats[0] += 1
+        agree_stats[1] += time.perf_counter() - t0
         return bool(t.item())
 
     import gsplat_amd
@@ -350,7 +392,7 @@ def main() -> None:
             rings[v] = torch.stack([scene.make_camera(i, v) for i in range(v)]).to(dev)
         return rings[v]
 
-    def make_step(form: str, views: int, n_streams: int, ring_size: int):
+    def make_step(form: str, views: int, n_streams: int, ring_size: int, cams_override=None):
         """One step = `views` views on this rank (cameras j * world + rank of the step's window of the ring), forward +
         backward each, their gradients summed into the bucket, then the exchange.  form: "factored" | "allreduce".
         The views are queued by the product's own orchestrator (gsplat_amd.pipeline.ViewPipeline): alternating streams,
@@ -359,7 +401,7 @@ def main() -> None:
         factored = form == "factored" and (world > 1 or views > 1)
         ex = Exchange(dist, world, rank, n, views, factored, dev, expand=stages.sh_grad_expand)
         pipe = ViewPipeline(dev, n_streams)
-        cams, windows = ring(ring_size), {}
+        cams, windows = (ring(ring_size) if cams_override is None else cams_override), {}
         defer = views > 1 and not args.no_defer_check   # the views' speculation is checked once per step, behind the last view
 
         def step(i: int = 0):
@@ -448,6 +490,7 @@ def main() -> None:
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if per_step else None
         fence()
         stages.WAIT_STATS[:] = [0, 0.0]
+        agree_stats[:] = [0, 0.0]
         t0 = time.perf_counter()
         if per_step:
             marks[0].record()
@@ -463,6 +506,7 @@ def main() -> None:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         return {"s": dt, "warmup_effective": warmup + extra, "host_wait_ms": wait_ms,
+                "agree_ms": agree_stats[1] / max(steps, 1) * 1e3,
                 "per_step_ms": [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)] if per_step else None}
 
     p = width * height
@@ -485,6 +529,25 @@ def main() -> None:
     if args.dump_grad and rank == 0:
         torch.save(flat_grad.detach().cpu(), args.dump_grad)
     dist_ms = timed(head_step, args.steps, 0, per_step=True)["per_step_ms"]   # the same steps, one event per step
+    c4 = None
+    if dist is not None and B > 1:   # BASELINE config C4 as written: ONE view per GPU per step (a world-view batch)
+        c4_step = make_step(args.exchange, 1, 1, world)
+        c4 = timed(c4_step, args.steps, 2, converge=True)
+        stages.TIMER.reset(enabled=True)
+        for i in range(min(args.steps, 20)):
+            c4_step(i)
+        fence()
+        tail1 = stages.TIMER.summary().get("exchange_tail", (0, 0.0))
+        stages.TIMER.reset(enabled=False)
+        c4["exchange_tail_ms"] = tail1[1] / max(tail1[0], 1)
+        # ... and the B-view step's tail, the same way
+        stages.TIMER.reset(enabled=True)
+        for i in range(min(args.steps, 20)):
+            head_step(i)
+        fence()
+        tailb = stages.TIMER.summary().get("exchange_tail", (0, 0.0))
+        stages.TIMER.reset(enabled=False)
+        c4["exchange_tail_ms_B"] = tailb[1] / max(tailb[0], 1)
     other = None
     if dist is not None:   # the same steps with the other exchange form, for the comparison figure only
         other_form = "allreduce" if args.exchange == "factored" else "factored"
@@ -515,6 +578,26 @@ def main() -> None:
             stages.REPAIR_STATS[k] = 0
         rot = timed(rot_step, args.steps, 0)
         rot["stats"] = dict(stages.REPAIR_STATS)
+    # ---- wide depth: the same scene seen from INSIDE the cloud (ring of radius 0.35: visible depths from the near plane to
+    # ~2.3, i.e. 8 octaves of depth-key span where the ring of radius 4 shows 0.7) -- which depth ordering ran, how often
+    wide = None
+    if world == 1 and args.views > 1:
+        wide_cams = torch.stack([scene.make_camera(i, args.views, radius=0.35) for i in range(args.views)]).to(dev)
+        wide_step = make_step(args.exchange, 1, 1, args.views, cams_override=wide_cams)
+        for i in range(2 * args.views):
+            wide_step(i)
+        for k in stages.REPAIR_STATS:
+            stages.REPAIR_STATS[k] = 0
+        for k in stages.PATH_STATS:
+            stages.PATH_STATS[k] = 0
+        wide = timed(wide_step, args.steps, 0)
+        wide["stats"], wide["paths"] = dict(stages.REPAIR_STATS), dict(stages.PATH_STATS)
+        wide["key_span_octaves"] = stages.last_key_span_octaves(dev, width, height)
+    # ---- the optimisation step around the rasterizer (BASELINE config C3 "full Adam loop"): the fused harness step -- loss,
+    # backward, SH rebuild, Adam -- on the same scene and views; NOT part of `value`
+    train = None
+    if world == 1 and args.workload in ("C3", "T") and not args.no_train_step:
+        train = train_step_leg(sc, n, width, height, deg, B, dev, max(5, min(args.steps, 20)))
     copy_peak = measured_copy_peak(dev) if rank == 0 else 0.0   # after the timed regions
 
     ex = head_step.exchange
@@ -570,6 +653,7 @@ def main() -> None:
             "config": {"workload": f"{args.workload}: {n} gaussians, {width}x{height}, SH degree {deg}, "
                                    f"{B} view{'s' if B > 1 else ''} per GPU per step ({world * B} ring cameras per step), "
                                    f"forward+backward into one 59N-float gradient bucket"
+                                   + ("; speculation checked per view (no host group)" if flag_error and world > 1 else "")
                                    + ((", RCCL all-gather of 3N rgb grads per view + one all-reduce of 11N geometry grads per "
                                        "step, SH gradient rebuilt locally" if args.exchange == "factored" else
                                        ", RCCL all-reduce of 59N-float grads") if world > 1 else ""),
@@ -590,7 +674,7 @@ def main() -> None:
                             "warmup_effective": solo["warmup_effective"]},
             # `bound`: the roofline `achieved` / `peak` are priced against is HBM (no MFMA on this path);
             # `limiter`: what the PMC counters say the dominant kernel actually waits for
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"protocol": "single_view", "bound": "hbm", "kernel": dominant, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "limiter": counters.get("limiter"), "valu_util": counters.get("valu_util"),
                          "atomic_requests": counters.get("atomic_requests"), "counters_from": counters_from,
@@ -601,6 +685,7 @@ def main() -> None:
                                     "achieved_GBs": round(total_bytes / (ms_per_view * 1e-3) / 1e9, 2),
                                     "frac": round(total_bytes / (ms_per_view * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                                     "frac_single_view": round(total_bytes / (solo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "stage_ms_protocol": "single_view",
             "stage_ms": {k: round(v, 4) for k, v in sorted(per.items())},
             "stage_abi_calls": {k: round(v, 2) for k, v in sorted(launches.items())},   # (C-ABI calls per view; binning: 3 calls, 12 kernels)
             "stage_algorithmic_GBs": stage_gbs,
@@ -610,11 +695,17 @@ def main() -> None:
                          + (["whole_step"] if total_bytes / (ms_per_view * 1e-3) / 1e9 > HBM_PEAK_GBS else []),
         }
         if measured_bytes:
+            # counter bytes of the SINGLE-VIEW step's kernels (profiles/*_traffic.json), over the time of a view of the
+            # pipelined step (`frac_of_peak`: the bytes are the same, the kernels overlap) and of a view alone
             gbs = measured_bytes / (ms_per_view * 1e-3) / 1e9
+            gbs1 = measured_bytes / (solo_ms * 1e-3) / 1e9
             line["roofline_measured"] = {"hbm_bytes_per_view": int(measured_bytes), "achieved_GBs": round(gbs, 1),
                                          "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
                                          "frac_of_copy_ceiling": round(gbs / max(copy_peak, 1.0), 4),
+                                         "achieved_GBs_single_view": round(gbs1, 1),
+                                         "frac_of_peak_single_view": round(gbs1 / HBM_PEAK_GBS, 4),
                                          "counters_from": counters_from}
+            line["roofline_whole_step"]["frac_measured"] = round(gbs / HBM_PEAK_GBS, 4)
         if rot is not None:
             st = rot["stats"]
             per100 = 100.0 / max(st["views"], 1)
@@ -623,7 +714,26 @@ def main() -> None:
                                 "ms_per_view": round(rot["s"] / args.steps * 1e3, 4),
                                 "capacity_misses_per_100": round(st["capacity_misses"] * per100, 2),
                                 "key_range_repairs_per_100": round(st["key_range_repairs"] * per100, 2)}
+        if wide is not None:
+            st = wide["stats"]
+            per100 = 100.0 / max(st["views"], 1)
+            line["wide_depth"] = {"what": f"one view per step cycling {args.views} cameras on a ring of radius 0.35 INSIDE the cloud",
+                                  "key_span_octaves": wide["key_span_octaves"],
+                                  "ms_per_view": round(wide["s"] / args.steps * 1e3, 4),
+                                  "value": round(p * args.steps / wide["s"] / 1e6, 3),
+                                  "depth_ordering_paths": wide["paths"],
+                                  "capacity_misses_per_100": round(st["capacity_misses"] * per100, 2),
+                                  "key_range_repairs_per_100": round(st["key_range_repairs"] * per100, 2)}
+        if train is not None:
+            line["train_step"] = train
         if dist is not None:
+            line["agree_ms_per_step"] = round(head["agree_ms"], 4)
+            if c4 is not None:
+                line["value_c4"] = round(world * p * args.steps / c4["s"] / 1e6, 3)
+                line["c4"] = {"what": "BASELINE config C4 as written: ONE view per GPU per step (a %d-view batch)" % world,
+                              "ms_per_step": round(c4["s"] / args.steps * 1e3, 4),
+                              "exchange_tail_ms": round(c4["exchange_tail_ms"], 4),
+                              "exchange_tail_ms_at_%d_views_per_gpu" % B: round(c4["exchange_tail_ms_B"], 4)}
             other_value = world * B * p * args.steps / other["s"] / 1e6
             fact = args.exchange == "factored"
             tail = stage_ms.get("exchange_tail", (0, 0.0))

@@ -185,11 +185,14 @@ int gsa_depth_order(int n, const uint32_t *depth_keys, const uint32_t *tile_rect
  * key_range_dev (ABI 7; optional, may be NULL; 16-byte aligned): the 4 * ceil(n / 64) words gsa_project_fwd left for THIS
  * view.  key_min / scale are then ignored: the first launch builds the view's own DEPTH TABLE on the device -- the exact
  * key range cut into <= 4096 aligned cells, the sample keys counted per cell, consecutive cells grouped into <= 255
- * buckets of about equal key count and at most 65536 keys of width -- so the buckets fit the view at hand whatever views
+ * buckets of about equal key count and at most 2^24 keys of width -- so the buckets fit the view at hand whatever views
  * came before, and however unevenly depth is distributed (with 255 EQUAL buckets the diagonal cameras of the bench ring
  * put 3.5 x the mean into one bucket, beyond the local sorts' capacity).  The order produced does not depend on the
- * table (any monotone table gives the same order).  ctl[3] bit 2: the view's key range is wider than 250 x 65536 keys
- * (about two octaves of depth); the caller repeats with gsa_depth_order. */
+ * table (any monotone table gives the same order).
+ * ABI 10: a bucket's local sort covers 24 bits of key offset (16 before: about two octaves of depth per VIEW) -- a bucket
+ * wider than 65536 keys takes a third local pass -- so any range of positive float depths fits 255 buckets (scale > 256;
+ * gsa_depth_order_msd_max_width() = 2^24).  ctl[3] bit 2 (the view's key range is wider than 250 x 2^24 keys) can only be
+ * raised by keys that are no depths. */
 size_t gsa_depth_order_msd_workspace_bytes(int n);
 int gsa_depth_order_msd_max_width(void);
 /* (diagnostics) where gsa_depth_order_msd(key_range_dev) leaves the view's depth table inside its workspace: byte offset from
@@ -201,15 +204,6 @@ int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint32_t *tile_
                         const uint32_t *key_range_dev, uint32_t *order, uint32_t *rects, uint32_t *offsets, int32_t *block_owner,
                         int n_blocks, uint32_t *ctl, uint32_t *ctl_host, uint32_t token, void *workspace,
                         size_t workspace_bytes, gsa_stream_t stream);
-/* ABI 9 -- the same with the depth table in the CALLER's memory (gsa_depth_order_msd_table_words() uint32, 16-byte aligned):
- * built from key_range_dev, with 1/16 of the key range as margin at either end, when that is given; used as it is when
- * key_range_dev is NULL -- the table of one view orders the later views of the same scene shape without a table launch of
- * their own.  A view whose visible keys leave the table's cells is reported (ctl[3] bit 3, like a bucket overflow: bit 0);
- * the ordering itself never depends on the table. */
-int gsa_depth_order_msd_table(int n, const uint32_t *depth_keys, const uint32_t *tile_rects, const uint32_t *key_range_dev,
-                              uint32_t *table, uint32_t *order, uint32_t *rects, uint32_t *offsets, int32_t *block_owner,
-                              int n_blocks, uint32_t *ctl, uint32_t *ctl_host, uint32_t token, void *workspace,
-                              size_t workspace_bytes, gsa_stream_t stream);
 int gsa_scan_tiles_sorted(int n, uint32_t *counts_offsets, int32_t *block_owner, int n_blocks, uint32_t *total,
                           void *workspace, size_t workspace_bytes, gsa_stream_t stream);
 int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offsets, const uint32_t *rects,

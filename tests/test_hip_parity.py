@@ -1264,7 +1264,7 @@ def test_full_size_properties_c3_1m_1080p(gsa):
 
 
 @pytest.mark.parametrize("n,dist", [(200_000, "uniform"), (1_000_003, "bench"), (5000, "uniform"), (70_000, "ties"),
-                                    (300, "uniform"), (50_000, "all_culled")])
+                                    (300, "uniform"), (50_000, "all_culled"), (400_000, "wide"), (1_200_000, "wide")])
 def test_bucketed_depth_order_equals_lsd_sort(gsa, n, dist):
     """gsa_depth_order_msd (one global bucket pass + a local LDS sort per bucket fused with the scan) == gsa_depth_order
     + gsa_scan_tiles_sorted (LSD passes, separate scan), bit for bit, on every entry that belongs to a visible gaussian:
@@ -1274,6 +1274,9 @@ def test_bucketed_depth_order_equals_lsd_sort(gsa, n, dist):
     g = torch.Generator().manual_seed(n)
     if dist == "bench":      # float bits of depths in [3, 5]: twice as dense above 4.0
         keys = (torch.rand(n, generator=g) * 2 + 3).to(torch.float32).view(torch.int32).long()
+    elif dist == "wide":     # depths log-uniform over 0.05 .. 500 (13 octaves, 112 M keys: buckets ~440 k keys wide -> the
+        z = torch.exp(torch.rand(n, generator=g, dtype=torch.float64) * math.log(1e4) + math.log(0.05))   # 24-bit local sorts)
+        keys = z.to(torch.float32).view(torch.int32).long()
     elif dist == "ties":     # many equal keys: stability
         keys = torch.randint(0x40400000, 0x40400000 + 3000, (n,), generator=g)
     else:
@@ -1358,7 +1361,7 @@ def test_bucketed_depth_order_equals_lsd_sort(gsa, n, dist):
 
 def test_depth_table_levels_the_buckets(gsa):
     """The table the bucketed ordering builds for a view (cells -> buckets, from the per-wave sample of keys): valid --
-    monotone, every bucket at most 65536 keys wide -- and LEVEL: on keys as unevenly distributed as the diagonal cameras of
+    monotone, every bucket at most 2^24 keys wide -- and LEVEL: on keys as unevenly distributed as the diagonal cameras of
     the bench ring see them (3.5 x the mean in the fullest of 255 equal buckets, more than the local sorts hold) the fullest
     bucket stays well inside the 8192-key capacity, and the ordering reports no overflow."""
     from gsplat_amd import scene, stages as S
@@ -1403,7 +1406,7 @@ def test_depth_table_levels_the_buckets(gsa):
         assert 0 < cells <= 4096 and (hi >> shift) - g0 + 1 == cells and lo >> shift == g0
         assert int(lut[0]) == 0 and bool((lut[1:] >= lut[:-1]).all()) and int(lut.max()) <= 254
         for v in range(int(lut.max()) + 1):
-            assert bool((lut[int(cs[v]):int(cs[v + 1])] == v).all()) and (int(cs[v + 1]) - int(cs[v])) << shift <= 65536, v
+            assert bool((lut[int(cs[v]):int(cs[v + 1])] == v).all()) and (int(cs[v + 1]) - int(cs[v])) << shift <= lib.gsa_depth_order_msd_max_width(), v
         assert int(cs[int(lut.max()) + 1]) == cells
         fullest = int(torch.bincount(lut[(k >> shift) - g0], minlength=255).max())
         print(f"view {view}: {n_vis} visible keys, {cells} cells of 2^{shift} keys, {int(lut.max()) + 1} buckets; fullest bucket "
@@ -1437,14 +1440,8 @@ def test_bucketed_depth_order_reports_what_it_cannot_do(gsa):
     check(lib.gsa_depth_order_msd(n, k32.data_ptr(), pairs.data_ptr(), narrow[0], narrow[1], None, out[0].data_ptr(), out[1].data_ptr(),
                                   out[2].data_ptr(), owner.data_ptr(), 63, ctl.data_ptr(), None, 0, ws.data_ptr(), ws.numel(), st), "msd")
     assert not S._note_keys(("t", 1), int(ctl[1]), int(ctl[2]), narrow, int(ctl[3]))
-    # a device-planned ordering over a range beyond two octaves of depth says so (status bit 2) instead of mis-sorting silently
-    wide = torch.full(((n + 63) // 64, 4), -1, dtype=torch.int32)
-    wide[:, 1] = 0
-    wide[0, 0], wide[0, 1] = 0x3F000000, 0x42000000
-    wide = wide.cuda()
-    check(lib.gsa_depth_order_msd(n, k32.data_ptr(), pairs.data_ptr(), 0, 0, wide.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
-                                  out[2].data_ptr(), owner.data_ptr(), 63, ctl.data_ptr(), None, 0, ws.data_ptr(), ws.numel(), st), "msd")
-    assert int(ctl[3]) & 4 and not S._note_keys(("t", 2), int(ctl[1]), int(ctl[2]), (0, 0, "device"), int(ctl[3]))
+    # (r03 also reported ranges beyond two octaves of depth -- status bit 2; with 24-bit local sorts every range of positive
+    # float depths fits, see the "wide" case of test_bucketed_depth_order_equals_lsd_sort)
     S._MSD_BACKOFF.pop(("t", 2), None)
     S._KEY_RANGE.pop(("t", 2), None)
     S._KEY_RANGE.pop(("t", 0), None)
@@ -1480,55 +1477,6 @@ def test_views_equal_buckets_do_not_fit_move_the_shape_to_depth_tables(gsa):
     assert torch.equal(again[0], first[3]) and torch.equal(again[1], first[0]) and torch.equal(again[3], first[2])
     for t in (S._CAPACITY, S._KEY_RANGE, S._MSD_BACKOFF, S._TABLE_MODE, S._MSD_STREAK):
         t.pop(key, None)
-
-
-def test_a_shapes_depth_table_is_reused_until_a_view_does_not_fit_it(gsa):
-    """GSPLAT_AMD_TABLE_REUSE: after eight host-planned views that held, ONE view builds the shape's depth table (with a margin)
-    and the views after it are ordered with that table -- no table launch, the same images as the exact path -- until a
-    view's keys leave its cells (the camera backs off to twice the distance): reported, repaired, and the shape is back on
-    the other plans."""
-    from gsplat_amd import scene, stages as S
-    N, W, H = 200_000, 640, 480
-    sc = scene.make_scene(N, seed=1, sh_degree=1)
-    d = {k: v.cuda().contiguous() for k, v in sc.items()}
-    K = scene.make_intrinsics(W, H).cuda()[None]
-    key = ("cuda", torch.cuda.current_device(), W, H, 0, S.bin_tile_for(W, H, 0))
-    tables = (S._CAPACITY, S._KEY_RANGE, S._MSD_BACKOFF, S._TABLE_MODE, S._MSD_STREAK, S._SHAPE_TABLE, S._SHAPE_GOOD, S._REUSE_BACKOFF)
-    for t in tables:
-        t.pop(key, None)
-    for k in S.REPAIR_STATS:
-        S.REPAIR_STATS[k] = 0
-    was, was_min = S._TABLE_REUSE, S._MSD_MIN_N
-    S._TABLE_REUSE, S._MSD_MIN_N = True, 0
-
-    def render(v, far=1.0):
-        vm = scene.make_camera(v, 4).cuda()      # (a quarter turn apart: the box looks alike from both)
-        vm = vm.clone()
-        vm[:3, 3] *= far
-        with torch.no_grad():
-            r, a, meta = gsa.rasterization(d["means3D"], d["rotations"], d["scales"], d["opacities"][:, 0].contiguous(), d["shs"],
-                                           vm[None], K, W, H, sh_degree=1)
-        return r
-
-    try:
-        exact = {v: render(v) for v in (0, 1)}                      # (first calls of the shape: exact sizes, LSD ordering)
-        calls = 0
-        while key not in S._SHAPE_TABLE and calls < 16:                            # host-planned views, then the one that builds the table
-            assert torch.equal(render(calls % 2), exact[calls % 2])
-            calls += 1
-        assert key in S._SHAPE_TABLE and calls >= S._REUSE_AFTER_GOOD and S._SHAPE_GOOD.get(key, 0) >= S._REUSE_AFTER_GOOD
-        tab = S._SHAPE_TABLE[key]
-        for i in range(6):
-            assert torch.equal(render(i % 2), exact[i % 2])                        # ... and these are ordered with it
-        assert S._SHAPE_TABLE.get(key) is tab and S.REPAIR_STATS["key_range_repairs"] == 0
-        far_exact = render(0, far=2.0)                                             # keys beyond the table's cells: reported + repaired
-        assert S.REPAIR_STATS["key_range_repairs"] == 1 and key not in S._SHAPE_TABLE and S._REUSE_BACKOFF.get(key, 0) > 0
-        assert torch.equal(render(0, far=2.0), far_exact) and torch.equal(render(1), exact[1])
-        assert S.REPAIR_STATS["key_range_repairs"] <= 2
-    finally:
-        S._TABLE_REUSE, S._MSD_MIN_N = was, was_min
-        for t in tables:
-            t.pop(key, None)
 
 
 def test_depth_cluster_falls_back_to_the_lsd_path(gsa):
