@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kBlock, GSA_PROJ_FWD_WAVES) void project_fwd_kernel
     const float *__restrict__ viewmat, const float *__restrict__ intrin, int width, int height, int tile_w,
     int tile_h, int cull_mode, float *__restrict__ splat, int32_t *__restrict__ radii,
     int32_t *__restrict__ tiles_touched, uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ tile_rects,
-    float *__restrict__ sh_aux, int bin_tile, uint32_t *__restrict__ key_range) {
+    float *__restrict__ sh_aux, int bin_tile, uint32_t *__restrict__ key_range, uint32_t *__restrict__ qbox) {
     __shared__ float4 sh_lds[STAGE ? (kBlock / 64) * kWaveLds : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Blocks walk the gaussians from the LAST to the first (GSA_PROJ_FWD_REVERSE): the kernel that ran before this one in
@@ -171,6 +171,7 @@ __global__ __launch_bounds__(kBlock, GSA_PROJ_FWD_WAVES) void project_fwd_kernel
     int rx = 0, ry = 0, count = 0;
     uint32_t key = 0xFFFFFFFFu, rect = 0u;
     uint2 bin_pair = make_uint2(0u, 0u);   // (packed rectangle, record count) in BIN tiles -- what the fused binning reads
+    uint32_t qb = 0u;                      // the quadrant bounding box of the alpha >= 1/255 ellipse (see below)
     if (visible) {
     // ---- colour (A.3)
     float r, g, b;
@@ -243,6 +244,25 @@ __global__ __launch_bounds__(kBlock, GSA_PROJ_FWD_WAVES) void project_fwd_kernel
         bin_pair = make_uint2(bc > 0 ? ((uint32_t)br.x0 | ((uint32_t)br.y0 << 10) | ((uint32_t)(br.x1 - br.x0) << 20)) : 0u,
                               (uint32_t)bc);
     }
+    // qbox (optional): the 8 x 8 quadrants whose pixel centres the BOUNDING BOX of the alpha >= 1/255 ellipse covers --
+    // half extents sqrt(2 t Sigma_xx), sqrt(2 t Sigma_yy) with t = ln(255 o), the margin of the compositor's reach test --
+    // packed first column | first row << 10 | (columns - 1) << 20 | (rows - 1) << 26; 0xFFFFFFFF: more than 64 quadrants
+    // a side or a grid beyond 1024.  What the record placement turns into per-record quadrant masks without looking at the
+    // conic again (gsa_tile_bin16): of the records of a 32 x 32 bin 22 % reach a given quadrant, of those inside the box 78 %.
+    if (qbox) {
+        const float t2 = 2.f * (sig_max * 1.0001f + 1e-4f);
+        const float hx = __builtin_amdgcn_sqrtf(t2 * fmaxf(p.c00, 0.f)) * 1.00001f + 1e-3f;
+        const float hy = __builtin_amdgcn_sqrtf(t2 * fmaxf(p.c11, 0.f)) * 1.00001f + 1e-3f;
+        // pixel centres 8 q + 0.5 + i in [m - h, m + h]: (a box one pixel larger than needed at worst)
+        const float qw_max = (float)((width + 7) / 8 - 1), qh_max = (float)((height + 7) / 8 - 1);
+        const float x0 = fminf(fmaxf(floorf((p.mx - hx - 0.5f) * 0.125f), 0.f), qw_max);
+        const float x1 = fminf(fmaxf(floorf((p.mx + hx - 0.5f) * 0.125f), 0.f), qw_max);
+        const float y0 = fminf(fmaxf(floorf((p.my - hy - 0.5f) * 0.125f), 0.f), qh_max);
+        const float y1 = fminf(fmaxf(floorf((p.my + hy - 0.5f) * 0.125f), 0.f), qh_max);
+        const uint32_t ux0 = (uint32_t)x0, uy0 = (uint32_t)y0, uw = (uint32_t)(x1 - x0), uh = (uint32_t)(y1 - y0);
+        qb = (qw_max < 1024.f && qh_max < 1024.f && uw < 64u && uh < 64u) ? (ux0 | (uy0 << 10) | (uw << 20) | (uh << 26))
+                                                                           : 0xFFFFFFFFu;
+    }
     o0 = make_float4(p.mx, p.my, p.qa, p.qb);
     o1 = make_float4(p.qc, opac, r, g);
     o2 = make_float4(b, p.z, sig_max, __uint_as_float(rect));
@@ -311,6 +331,7 @@ __global__ __launch_bounds__(kBlock, GSA_PROJ_FWD_WAVES) void project_fwd_kernel
     depth_keys[i] = key;
     // dense (rectangle, count) pairs for the fused binning: one 8-B gather per gaussian brings both into depth order
     if (tile_rects) reinterpret_cast<uint2 *>(tile_rects)[i] = bin_pair;
+    if (qbox) qbox[i] = qb;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -630,19 +651,19 @@ int launch_fwd(bool stage, int n, const float *means, const float *quats, const 
                const float *opacities, const float *colors, int sh_coeffs, const float *viewmat,
                const float *intrin, int width, int height, int cull_mode, float *splat, int32_t *radii,
                int32_t *tiles_touched, uint32_t *depth_keys, uint32_t *tile_rects, float *sh_aux, int bin_tile,
-               uint32_t *key_range, hipStream_t s) {
+               uint32_t *key_range, uint32_t *qbox, hipStream_t s) {
     int tile_w = gsa_div_up(width, GSA_TILE_SIZE), tile_h = gsa_div_up(height, GSA_TILE_SIZE);
     dim3 grid(gsa_div_up(n, kBlock)), block(kBlock);
     if (stage)
         project_fwd_kernel<DEG, true><<<grid, block, 0, s>>>(n, means, quats, scales, opacities, colors, sh_coeffs,
                                                              viewmat, intrin, width, height, tile_w, tile_h, cull_mode,
                                                              splat, radii, tiles_touched, depth_keys, tile_rects, sh_aux,
-                                                             bin_tile, key_range);
+                                                             bin_tile, key_range, qbox);
     else
         project_fwd_kernel<DEG, false><<<grid, block, 0, s>>>(n, means, quats, scales, opacities, colors, sh_coeffs,
                                                               viewmat, intrin, width, height, tile_w, tile_h,
                                                               cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects,
-                                                              sh_aux, bin_tile, key_range);
+                                                              sh_aux, bin_tile, key_range, qbox);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }
@@ -691,7 +712,7 @@ extern "C" int gsa_project_fwd(int n, const float *means, const float *quats, co
                                const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
                                const float *viewmat, const float *intrin, int width, int height, int cull_mode,
                                float *splat, int32_t *radii, int32_t *tiles_touched, uint32_t *depth_keys,
-                               uint32_t *tile_rects, float *sh_aux, int bin_tile, uint32_t *key_range,
+                               uint32_t *tile_rects, float *sh_aux, int bin_tile, uint32_t *key_range, uint32_t *qbox,
                                gsa_stream_t stream) {
     GSA_RETURN_IF(n < 0 || width <= 0 || height <= 0, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_degree < -1 || sh_degree > 3, GSA_ERR_INVALID_ARGUMENT);
@@ -713,7 +734,7 @@ extern "C" int gsa_project_fwd(int n, const float *means, const float *quats, co
     bool stage = can_stage(colors, sh_degree, sh_coeffs) && sh_degree >= 1;
 #define GSA_FWD(D)                                                                                              \
     return launch_fwd<D>(stage, n, means, quats, scales, opacities, colors, sh_coeffs, viewmat, intrin, width, \
-                         height, cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects, sh_aux, bin_tile, key_range, s)
+                         height, cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects, sh_aux, bin_tile, key_range, qbox, s)
     switch (sh_degree) {
         case -1: GSA_FWD(-1);
         case 0: GSA_FWD(0);

@@ -305,29 +305,6 @@ __device__ __forceinline__ unsigned live_block_id(unsigned live) {
     return i < q + (x < r ? 1u : 0u) ? x * q + min(x, r) + i : 0xFFFFFFFFu;
 }
 
-// ... for a launch whose first `front` live chunks cost more than the rest (emit_place: the blocks that compute quadrant
-// masks): every XCD owns a consecutive run of the front chunks AND a consecutive run of the others, so that the expensive
-// ones are spread over all eight XCDs (with live_block_id they would all sit on the first XCDs, which then decide the
-// kernel's duration) while a bin's region is still filled by few fronts per XCD.
-__device__ __forceinline__ unsigned split_block_id(unsigned live, unsigned front) {
-    // XCD x runs the workgroups x, x + 8, ...: floor((grid - x + 7) / 8) of them, and a launch for an EXACT record count has
-    // grid == live -- so the two runs of an XCD must add up to its share of `live` exactly: the front's remainder goes to the
-    // XCDs 0 .. rf - 1, the others' remainder to the XCDs that follow them (rf, rf + 1, ... modulo 8).
-    const unsigned p = blockIdx.x, x = p & 7u, i = p >> 3;
-    const unsigned qf = front >> 3, rf = front & 7u, nf = qf + (x < rf ? 1u : 0u);
-    if (i < nf) return x * qf + min(x, rf) + i;
-    const unsigned back = live - front, qb = back >> 3, rb = back & 7u;
-    unsigned start = x * qb, mine = qb;
-#pragma unroll
-    for (unsigned xx = 0; xx < 8u; ++xx) {
-        const unsigned extra = ((xx + 8u - rf) & 7u) < rb ? 1u : 0u;
-        if (xx < x) start += extra;
-        if (xx == x) mine += extra;
-    }
-    const unsigned j = i - nf;
-    return j < mine ? front + start + j : 0xFFFFFFFFu;
-}
-
 // ---- pass 1: per-block digit histogram, written digit-major: hist[d * nblocks + block] -------------
 // Plain per-lane LDS atomics: measured faster than aggregating same-digit lanes with ballots first (the LDS
 // resolves same-address adds of one instruction cheaply; the 8 ballots per key cost more than they save).
@@ -1169,9 +1146,6 @@ constexpr int kBinsDirect = 2048;
 #define GSA_COL_BINS 32   // bins (128 contiguous bytes of every row) per workgroup of bin_colscan: 8 -> 15.8 us, 16 -> 10.5, 32 -> 8.8, 64 -> 30.5 (32 workgroups)
 #endif
 constexpr int kColBins = GSA_COL_BINS, kColSegs = 1024 / kColBins, kColThreads = kColSegs * kColBins;
-#ifndef GSA_MASK_GROUP
-#define GSA_MASK_GROUP 2   // records whose splat-row words emit_place keeps in flight while it computes quadrant masks
-#endif
 #ifndef GSA_PLACE_XCD
 #define GSA_PLACE_XCD 1   // emit_binhist / emit_place: a workgroup's record block by live_block_id (1) or by its index (0: binning +22 us)
 #endif
@@ -1282,10 +1256,11 @@ __global__ __launch_bounds__(kColThreads) void bin_colscan_kernel(uint32_t m_cap
     __syncthreads();
     if (!s_last) return;
     // the last workgroup: exclusive scan of the nb (<= 2048) totals, two per thread
-    uint32_t a[2], mine = 0;
+    constexpr int kPerT = 2;
+    uint32_t a[kPerT], mine = 0;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int i = 2 * t + q;
+    for (int q = 0; q < kPerT; ++q) {
+        const int i = kPerT * t + q;
         a[q] = i < nb ? __hip_atomic_load(&totals[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         mine += a[q];
     }
@@ -1297,8 +1272,8 @@ __global__ __launch_bounds__(kColThreads) void bin_colscan_kernel(uint32_t m_cap
     for (int w = 0; w < wave; ++w) off += scratch[w];
     uint32_t ex = off + inc - mine;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int i = 2 * t + q;
+    for (int q = 0; q < kPerT; ++q) {
+        const int i = kPerT * t + q;
         if (i <= n_tiles) tile_offsets[i] = (int32_t)ex;   // (bins at and beyond n_tiles hold no records: entry n_tiles is the count)
         ex += a[q];
     }
@@ -1308,6 +1283,7 @@ __global__ __launch_bounds__(kColThreads) void bin_colscan_kernel(uint32_t m_cap
 // rank of this lane's record among the wave's records of the same bin so far (wave_rank_round for 11-bit ids): the lanes
 // of a bin find one another through the peer word of the id's low 8 bits and three ballots over its high bits; the
 // counters are 16-bit (a wave ranks 1024 records per block)
+template <int BITS = 11>
 __device__ __forceinline__ uint32_t wave_rank_round_bins(unsigned long long *mask, uint16_t *cnt, uint32_t bin, bool valid,
                                                          int lane) {
     const unsigned long long bit = 1ull << lane;
@@ -1318,7 +1294,7 @@ __device__ __forceinline__ uint32_t wave_rank_round_bins(unsigned long long *mas
     const unsigned long long raw = valid ? mask[d] : 0ull;
     unsigned long long peers = raw;
 #pragma unroll
-    for (int b = 8; b < 11; ++b) {
+    for (int b = 8; b < BITS; ++b) {
         const bool set = (bin >> b) & 1u;
         const unsigned long long bal = __ballot(valid && set);
         peers &= set ? bal : ~bal;
@@ -1333,19 +1309,44 @@ __device__ __forceinline__ uint32_t wave_rank_round_bins(unsigned long long *mas
 }
 
 // MASK_Q (0: none; 2 / 4: a bin is MASK_Q x MASK_Q quadrants of 8 x 8 pixels -- 16 x 16 tiles / 32 x 32 bins): the record's
-// QUADRANT MASK is computed where the record is generated and stored beside its gaussian id (masks_out): which 8 x 8
-// quadrants of its bin the alpha >= 1/255 ellipse of the gaussian can reach (gsa_reach_mask) -- what a forward-compositor
-// wave tests, one bit per list entry, before it gathers anything.  The gaussian's mean / conic / ln(255 o) come out of its
-// 64-B splat row: the records of one gaussian are CONSECUTIVE slots here (3.9 of them at the bench scene), so neighbouring
-// lanes read the same line -- ~1.3 M distinct row fetches for 3.6 M records, under the LDS-bound ranking -- where a pass
-// over the PLACED records (gsa_quadrant_masks, round 3) paid one random row per record: 0.070 ms for 0.024 ms saved.
+// QUADRANT MASK is stored beside its gaussian id (masks_out): which 8 x 8 quadrants of its bin lie inside the gaussian's
+// quadrant bounding box (gsa_project_fwd's qbox: the box of the alpha >= 1/255 ellipse, four small integers per gaussian) --
+// what a forward-compositor wave tests, one bit per list entry, before it gathers anything.  About thirty integer
+// instructions per record and one 4-B load from a 4-MB array the records of a gaussian share (they are consecutive slots
+// here).  Not exact -- 78 % of the (quadrant, record) pairs it lets through reach a pixel, the ellipse test in the
+// compositor's staging step weeds out the rest -- but the exact form (gsa_reach_mask: ~150 instructions and three loads
+// from the 64-B splat row per record) cost this kernel 0.021-0.026 ms for the 0.030 ms it saved the forward sweep, and a
+// pass over the PLACED records (gsa_quadrant_masks, round 3: one random row per record) 0.070 ms.
+__device__ __forceinline__ uint32_t qbox_mask2(uint32_t qb, int bx, int by) {   // Q = 2: bit (qy << 1) | qx
+    if (qb == 0xFFFFFFFFu) return 0xFu;
+    const int x0 = (int)(qb & 1023u) - 2 * bx, y0 = (int)((qb >> 10) & 1023u) - 2 * by;
+    const int x1 = x0 + (int)((qb >> 20) & 63u), y1 = y0 + (int)(qb >> 26);
+    const uint32_t cols = (x0 <= 0 && x1 >= 0 ? 1u : 0u) | (x0 <= 1 && x1 >= 1 ? 2u : 0u);
+    const uint32_t rows = (y0 <= 0 && y1 >= 0 ? 1u : 0u) | (y0 <= 1 && y1 >= 1 ? 2u : 0u);
+    return (rows & 1u ? cols : 0u) | (rows & 2u ? cols << 2 : 0u);
+}
+__device__ __forceinline__ uint32_t qbox_mask4(uint32_t qb, int bx, int by) {
+    // Q = 4: bit (((j >> 1) << 1 | (i >> 1)) << 2) | ((j & 1) << 1) | (i & 1) for quadrant column i, row j of the bin
+    if (qb == 0xFFFFFFFFu) return 0xFFFFu;
+    const int x0 = (int)(qb & 1023u) - 4 * bx, y0 = (int)((qb >> 10) & 1023u) - 4 * by;
+    const int x1 = x0 + (int)((qb >> 20) & 63u), y1 = y0 + (int)(qb >> 26);
+    // columns / rows lo .. hi of the bin inside the box, as 4-bit sets (empty if hi < lo)
+    const int cl = max(x0, 0), ch = min(x1, 3), rl = max(y0, 0), rh = min(y1, 3);
+    const uint32_t cols = ch >= cl ? ((2u << ch) - 1u) & ~((1u << cl) - 1u) : 0u;
+    const uint32_t rows = rh >= rl ? ((2u << rh) - 1u) & ~((1u << rl) - 1u) : 0u;
+    // a row's columns land on bits {0, 1, 4, 5} shifted by {0, 2, 8, 10}: disjoint, so the set product is a multiplication
+    const uint32_t cmap = (cols & 3u) | ((cols & 12u) << 2);
+    const uint32_t rmul = (rows & 1u) | ((rows & 2u) << 1) | ((rows & 4u) << 6) | ((rows & 8u) << 7);
+    return __umul24(cmap, rmul);
+}
+
 template <int MASK_Q>
 __global__ __launch_bounds__(kSortThreads, 4) void emit_place_kernel(
     int n, const uint32_t *__restrict__ order, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ rects,
     const int32_t *__restrict__ block_owner, int tile_w, uint32_t m_cap, const uint32_t *__restrict__ m_dev,
     uint16_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int nblocks, int nb, int n_tiles,
-    const uint32_t *__restrict__ mat, const int32_t *__restrict__ tile_offsets, const float *__restrict__ splat,
-    uint16_t *__restrict__ masks_out, uint32_t mask_q8) {
+    const uint32_t *__restrict__ mat, const int32_t *__restrict__ tile_offsets, const uint32_t *__restrict__ qbox,
+    uint16_t *__restrict__ masks_out) {
     __shared__ uint32_t scratch[4];
     // two regions, each with two lives: the generation's (slot owners | staged gaussians) and the placement's (peer
     // words + the bins' first slots | wave-private 16-bit bin counters)
@@ -1359,24 +1360,18 @@ __global__ __launch_bounds__(kSortThreads, 4) void emit_place_kernel(
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t m_total = m_dev ? min(m_cap, *m_dev) : m_cap;
     const unsigned live = (unsigned)(((uint64_t)m_total + kSortChunk - 1) / kSortChunk);
-    // (the blocks in front of mask_front compute masks: see below)
-    const unsigned mask_front = MASK_Q != 0 ? (unsigned)(((uint64_t)live * mask_q8 + 255u) >> 8) : 0u;
-    const unsigned bid = !GSA_PLACE_XCD ? blockIdx.x : MASK_Q != 0 ? split_block_id(live, min(mask_front, live)) : live_block_id(live);
+    const unsigned bid = GSA_PLACE_XCD ? live_block_id(live) : blockIdx.x;
     if (bid >= live) return;
     SORT_TRACE_BEGIN();
     const EmitLoads el = emit_owner_loads(offsets, rects, order, block_owner, nblocks, m_total, true, bid, n);
-    // (first slot of every bin for this block: in flight under the generation -- with masks, whose arithmetic needs the
-    // registers, under the mask computation instead)
+    // (first slot of every bin for this block: in flight under the generation)
     uint32_t base_r[kBinsDirect / kSortThreads];
     const uint32_t *row = mat + (size_t)bid * nb;
-    auto load_bases = [&]() {
 #pragma unroll
-        for (int j = 0; j < kBinsDirect / kSortThreads; ++j) {
-            const int i = min(j * kSortThreads + t, nb - 1);
-            base_r[j] = row[i] + (uint32_t)tile_offsets[min(i, n_tiles)];
-        }
-    };
-    if constexpr (MASK_Q == 0) load_bases();
+    for (int j = 0; j < kBinsDirect / kSortThreads; ++j) {
+        const int i = min(j * kSortThreads + t, nb - 1);
+        base_r[j] = row[i] + (uint32_t)tile_offsets[min(i, n_tiles)];
+    }
     const EmitBlock eb = emit_owners(el, offsets, m_total, s_val, s_g, scratch, bid);
     SORT_TRACE_MARK(0);   // loads + slot owners
     const uint32_t wbase = wave * (kSortChunk / 4);
@@ -1391,43 +1386,18 @@ __global__ __launch_bounds__(kSortThreads, 4) void emit_place_kernel(
             v[r] = min(v[r], (uint32_t)n - 1u);   // (the compositor gathers splat rows by this id, unchecked)
         }
     }
-    // mask_q8 / 256: the fraction of the records, in DEPTH order, that get a computed mask; the blocks behind it store
-    // all-ones (the compositor then falls back to its own reach test for those entries).  A record block holds records of
-    // one depth range, i.e. the same relative position in every bin's list -- and where the scene is dense enough for the
-    // masks to matter, a quadrant's pixels saturate within the first third of its list: the deep half is never scanned.
-    const bool compute_masks = MASK_Q != 0 && bid < mask_front;
     if constexpr (MASK_Q != 0) {
-        if (!compute_masks) {
-            load_bases();
-#pragma unroll
-            for (int r = 0; r < kSortItems; ++r) k[r] |= 0xFFFF0000u;
-        }
-    }
-    if (compute_masks) {
-        load_bases();
-        // kMaskGroup records' row words in flight at a time (all sixteen at once: 268 registers); the mask rides in the
-        // upper half of the bin id through the ranking, so it costs no register of its own.  (bin -> (x, y) by a reciprocal:
-        // (bin + 0.5) / tile_w is at least 0.5 / tile_w away from an integer, ids and widths are below 2^11 -- exact.)
-        constexpr int kMaskGroup = GSA_MASK_GROUP;
+        // the mask rides in the upper half of the bin id through the ranking, so it costs no register of its own.  (bin ->
+        // (x, y) by a reciprocal: (bin + 0.5) / tile_w is at least 0.5 / tile_w away from an integer, ids and widths are
+        // below 2^11 -- exact.)  Slots beyond the block's records hold id 0: a valid entry, an unused mask.
         const float inv_tw = __builtin_amdgcn_rcpf((float)tile_w);
+        uint32_t qb[kSortItems];
 #pragma unroll
-        for (int r0 = 0; r0 < kSortItems; r0 += kMaskGroup) {
-            float4 g4[kMaskGroup];
-            float cc[kMaskGroup], smax[kMaskGroup];
+        for (int r = 0; r < kSortItems; ++r) qb[r] = qbox[v[r]];
 #pragma unroll
-            for (int j = 0; j < kMaskGroup; ++j) {   // (slots beyond the block's records hold id 0: a valid row, an unused mask)
-                const float *row = splat + (size_t)v[r0 + j] * GSA_SPLAT_STRIDE;
-                g4[j] = *reinterpret_cast<const float4 *>(row);
-                cc[j] = row[4];
-                smax[j] = row[10];
-            }
-#pragma unroll
-            for (int j = 0; j < kMaskGroup; ++j) {
-                const int by = (int)(((float)k[r0 + j] + 0.5f) * inv_tw), bx = (int)k[r0 + j] - by * tile_w;
-                k[r0 + j] |= gsa_reach_mask<MASK_Q>(g4[j].x, g4[j].y, g4[j].z, g4[j].w, cc[j], smax[j],
-                                                    (float)(bx * (8 * MASK_Q)), (float)(by * (8 * MASK_Q))) << 16;
-            }
-            asm volatile("" ::: "memory");   // (keeps the next group's loads behind this group's arithmetic)
+        for (int r = 0; r < kSortItems; ++r) {
+            const int by = (int)(((float)k[r] + 0.5f) * inv_tw), bx = (int)k[r] - by * tile_w;
+            k[r] |= (MASK_Q == 2 ? qbox_mask2(qb[r], bx, by) : qbox_mask4(qb[r], bx, by)) << 16;
         }
     }
     __syncthreads();   // owners and staged data consumed: the regions start their second life
@@ -1580,6 +1550,12 @@ extern "C" int gsa_scan_tiles_sorted(int n, uint32_t *counts_offsets, int32_t *b
                            workspace_bytes, stream);
 }
 
+// (Measured and dropped in r04: LSD passes on 12-bit digits built from the direct binning's kernels -- a per-block row of
+// 4096 counts, the column scan, every key stored straight at its place -- two passes instead of three for the 24 key bits
+// the visible depths differ in.  At 5 M keys a placement pass took 158 us (+ 14 us histogram + 20 us column scan) against
+// 61 + 20 + 6 us for an 8-bit pass: with 4096 bins per block of 4096 keys the per-bin work of a block -- 16 KB of bases, 32 KB
+// of wave counters, the waves' first ranks -- is as large as the per-key work, and every key goes to a line of its own.
+// C5 binning 0.54 -> 0.65 ms.)
 extern "C" size_t gsa_depth_order_workspace_bytes(int n) {
     if (n < 0) n = 0;
     // two key and two value ping-pong buffers, the per-block key ranges, the sort's histograms
@@ -2106,12 +2082,11 @@ extern "C" int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offs
                               const int32_t *block_owner, int width, int height, int bin_tile, uint32_t m_capacity,
                               const uint32_t *m_dev, uint16_t *tile_tmp,
                               uint32_t *gid_tmp, uint16_t *sorted_tile, uint32_t *sorted_gid, int32_t *tile_offsets,
-                              const float *splat, uint16_t *sorted_mask, int mask_depth_q8,
+                              const uint32_t *qbox, uint16_t *sorted_mask,
                               void *workspace, size_t workspace_bytes, gsa_stream_t stream) {
     GSA_RETURN_IF(n < 0 || !tile_offsets, GSA_ERR_INVALID_ARGUMENT);
-    GSA_RETURN_IF(sorted_mask && (mask_depth_q8 < 1 || mask_depth_q8 > 256), GSA_ERR_INVALID_ARGUMENT);
     // (masks: only where the records are placed in one pass and a bin has at most 16 quadrants -- gsa_tile_bin16_masks)
-    GSA_RETURN_IF(sorted_mask && (!splat || !gsa_tile_bin16_masks(width, height, bin_tile) || tile_tmp || gid_tmp),
+    GSA_RETURN_IF(sorted_mask && (!qbox || !gsa_tile_bin16_masks(width, height, bin_tile) || tile_tmp || gid_tmp),
                   GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(!gsa_tile_bins_supported(width, height, bin_tile), GSA_ERR_UNSUPPORTED);
     GSA_RETURN_IF(m_capacity >= 0x7FFFFFFFu - (uint32_t)kSortChunk, GSA_ERR_UNSUPPORTED);
@@ -2147,7 +2122,7 @@ extern "C" int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offs
 #define GSA_PLACE(Q)                                                                                                     \
     emit_place_kernel<Q><<<nblocks, kSortThreads, 0, s>>>(n, order, offsets, rects, block_owner, tile_w, m_capacity, m_dev, \
                                                           sorted_tile, sorted_gid, nblocks, nb, n_tiles, mat, tile_offsets, \
-                                                          splat, sorted_mask, (uint32_t)mask_depth_q8)
+                                                          qbox, sorted_mask)
         if (!sorted_mask) GSA_PLACE(0);
         else if (bin_tile == GSA_TILE_SIZE) GSA_PLACE(2);
         else GSA_PLACE(4);

@@ -22,7 +22,7 @@ P = c_void_p  # every device pointer and the stream cross the boundary as void*
 SIGNATURES = {
     "gsa_abi_version": (c_int, []),
     "gsa_error_string": (c_char_p, [c_int]),
-    "gsa_project_fwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, c_int, P, P, P, P, P, P, c_int, P, P]),
+    "gsa_project_fwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, c_int, P, P, P, P, P, P, c_int, P, P, P]),
     "gsa_sort_workspace_bytes": (c_size_t, [c_int]),
     "gsa_sort_pairs_u32": (c_int, [c_int, P, P, P, P, P, P, c_int, c_int, P, c_size_t, P]),
     "gsa_scan_tiles": (c_int, [c_int, P, P, P, P, P, c_size_t, P]),
@@ -40,7 +40,7 @@ SIGNATURES = {
     "gsa_depth_order_msd_table_words": (c_int, []),
     "gsa_depth_order_msd": (c_int, [c_int, P, P, c_uint32, c_uint32, P, P, P, P, P, c_int, P, P, c_uint32, P, c_size_t, P]),
     "gsa_scan_tiles_sorted": (c_int, [c_int, P, P, c_int, P, P, c_size_t, P]),
-    "gsa_tile_bin16": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_uint32, P, P, P, P, P, P, P, P, c_int, P, c_size_t, P]),
+    "gsa_tile_bin16": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_uint32, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "gsa_tile_emit": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_uint32, P, P, P]),
     "gsa_tile_offsets": (c_int, [c_uint32, P, c_int, P, P]),
     "gsa_sort_pairs_u32_dev": (c_int, [c_int, P, P, P, P, P, P, P, c_int, c_int, P, c_size_t, P]),

@@ -590,11 +590,12 @@ class ViewParallelTrainer:
             W, H = view["width"], view["height"]
             bt = S.bin_tile_for(W, H, cull)   # 32 x 32 bins where the fused binning applies
             kr = S.key_range_buffer(leaves[0].shape[0], dev)   # the view's depth-key range: the depth ordering plans its buckets from it
+            qb = S.qbox_buffer(leaves[0].shape[0], dev)        # the gaussians' quadrant boxes: the forward sweep's masks
             splat, radii, tiles, keys, rects, aux = S.project_fwd(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4],
                                                                   degree, pose, Kc, W, H, cull, return_rects=True,
-                                                                  return_aux=True, bin_tile=bt, key_range=kr)
+                                                                  return_aux=True, bin_tile=bt, key_range=kr, qbox=qb)
             bins = S.bin_tiles(splat, radii, tiles, keys, W, H, cull, tile_rects=rects, exact=exact, bin_tile=bt,
-                               key_range=kr)
+                               key_range=kr, qbox=qb)
             order = S.tile_schedule(bins.tile_offsets, W, H, bt)
             return pose, splat, radii, bins, order, aux
 

@@ -47,14 +47,15 @@ class _RasterizeOneCamera(torch.autograd.Function):
         main = torch.cuda.current_stream() if front_stream is not None else None
         with (torch.cuda.stream(front_stream) if front_stream is not None else contextlib.nullcontext()):
             kr = S.key_range_buffer(means_c.shape[0], means_c.device)   # this view's depth-key range, for the depth ordering's bucket plan
+            qb = S.qbox_buffer(means_c.shape[0], means_c.device)        # the gaussians' quadrant boxes, for the forward sweep's masks
             proj = S.project_fwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
-                                 cull_mode, return_rects=True, return_aux=want_lists, bin_tile=bt, key_range=kr)
+                                 cull_mode, return_rects=True, return_aux=want_lists, bin_tile=bt, key_range=kr, qbox=qb)
             splat, radii, tiles_touched, depth_keys, rects = proj[:5]
             sh_aux = proj[5] if want_lists else None
             # the host does not wait for the record count: bins are sized for a remembered capacity, the compositor is
             # queued, and only then is the count (long since copied back) checked -- a miss repeats with exact sizes
             bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, tile_rects=rects,
-                               bin_tile=bt, key_range=kr)
+                               bin_tile=bt, key_range=kr, qbox=qb)
             tile_order = S.tile_schedule(bins.tile_offsets, width, height, bt)   # longest record lists first (speed only)
             if front_stream is not None:
                 handed = torch.cuda.Event()
@@ -73,7 +74,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
             deferred.append(bins)
         elif not bins.finalize()[1]:
             bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, exact=True,
-                               tile_rects=rects, bin_tile=bt)
+                               tile_rects=rects, bin_tile=bt, qbox=qb)
             tile_order = S.tile_schedule(bins.tile_offsets, width, height, bt)
             out = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg_c, width, height, channels,
                                   tile_order, want_lists=want_lists, bin_tile=bt, sorted_mask=bins.sorted_mask)

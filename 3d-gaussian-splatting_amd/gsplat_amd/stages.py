@@ -227,13 +227,15 @@ _SH_AUX = os.environ.get("GSPLAT_AMD_SH_AUX", "1") != "0"
 
 def project_fwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat, Kmat, width: int, height: int,
                 cull_mode: int = 0, return_rects: bool = False, return_aux: bool = False, bin_tile: int = TILE_SIZE,
-                key_range: Optional[torch.Tensor] = None):
+                key_range: Optional[torch.Tensor] = None, qbox: Optional[torch.Tensor] = None):
     """-> splat [N,16], radii [N,2] i32, tiles_touched [N] i32, depth_keys [N] (uint32 bits in int32 storage)
     [, tile_rects [N,2] i32: (packed tile rectangle, record count) pairs the fused binning reads, with
     ``return_rects`` -- in tiles of ``bin_tile`` pixels: 16, or 32 for ``bin_tiles(..., bin_tile=32)``]
     [, sh_aux [N,12] f32 or None (sh_degree < 1): the 48-B digest of each coefficient row that lets
     ``project_bwd`` skip the rows, with ``return_aux``].
-    ``key_range``: a ``key_range_buffer`` that receives the view's depth-key range (for ``bin_tiles(key_range=...)``)."""
+    ``key_range``: a ``key_range_buffer`` that receives the view's depth-key range (for ``bin_tiles(key_range=...)``).
+    ``qbox``: an int32 [N] tensor that receives every gaussian's quadrant bounding box (for ``bin_tiles(qbox=...)``: the
+    forward compositor's per-record quadrant masks)."""
     dev, N = means.device, means.shape[0]
     sh_coeffs = colors.shape[1] if sh_degree >= 0 else 0
     splat = torch.empty(N, SPLAT_STRIDE, dtype=torch.float32, device=dev)
@@ -245,7 +247,7 @@ def project_fwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat
     _call("gsa_project_fwd", lib.gsa_project_fwd, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
           _ptr(colors), sh_degree, sh_coeffs, _ptr(viewmat), _ptr(Kmat), width, height, cull_mode, _ptr(splat),
           _ptr(radii), _ptr(tiles_touched), _ptr(depth_keys), _ptr(tile_rects), _ptr(sh_aux), bin_tile, _ptr(key_range),
-          _stream())
+          _ptr(qbox), _stream())
     out = (splat, radii, tiles_touched, depth_keys)
     if return_rects:
         out += (tile_rects,)
@@ -349,19 +351,20 @@ def tile_ids(sorted_tile: torch.Tensor) -> torch.Tensor:
 _BIN_FUSED_DEFAULT = os.environ.get("GSPLAT_AMD_BIN_FUSED", "1") != "0"
 # GSPLAT_AMD_BIN_DIRECT=0: the two-pass tile sort where gsa_tile_bin16_direct offers the one-pass placement (A/B timing)
 _BIN_DIRECT = os.environ.get("GSPLAT_AMD_BIN_DIRECT", "1") != "0"
-# Per-record quadrant masks for the forward compositor (which then gathers only the records that can reach its quadrant:
-# 0.152 -> 0.128 ms at C3).  Where the records are placed in one pass (gsa_tile_bin16_masks) the placement kernel computes
-# them as it generates the records -- the records of one gaussian are consecutive there, so its splat row is fetched about
-# once; round 3's separate pass over the PLACED records (gsa_quadrant_masks: one random 64-B row per record, 0.070 ms) made
-# them a net loss and is now only what the other binning paths fall back to when masks are asked for explicitly
-# (``bin_tiles(quad_masks=True)``).  GSPLAT_AMD_QUAD_MASKS=0 switches the masks off (A/B).
+# Per-record quadrant masks for the forward compositor, which then gathers only the records that may reach its quadrant
+# (0.158 -> ~0.13 ms at C3: of the records of a 32 x 32 bin 22 % reach a given 8 x 8 quadrant).  The masks come out of the
+# one-pass placement (gsa_tile_bin16_masks) from the gaussians' quadrant bounding boxes (``project_fwd(qbox=...)`` ->
+# ``bin_tiles(qbox=...)``): ~30 integer instructions per record.  r03's exact masks from a pass over the PLACED records
+# (gsa_quadrant_masks: one random 64-B row per record, 0.070 ms) remain what ``bin_tiles(quad_masks=True)`` without a qbox
+# falls back to.  GSPLAT_AMD_QUAD_MASKS=0: no masks (A/B).
 _QUAD_MASKS = os.environ.get("GSPLAT_AMD_QUAD_MASKS", "1") != "0"
-# ... for the front GSPLAT_AMD_MASK_DEPTH (default 0.4) of the records in depth order; the deep rest gets all-ones masks (the
-# compositor's own reach test then decides).  Where masks pay -- lists long enough that gathering candidates dominates -- a
-# quadrant's pixels saturate within the first third of its list, so the deep half of every list is never scanned and its
-# masks would be computed for nothing; in a sparse scene the unmasked half costs what r03 paid for every record.
-# ``bin_tiles(quad_masks=True)`` masks every record.
-_MASK_DEPTH_Q8 = max(1, min(256, int(round(256 * float(os.environ.get("GSPLAT_AMD_MASK_DEPTH", "0.4"))))))
+
+
+def qbox_buffer(n: int, dev) -> torch.Tensor:
+    """int32 [n] for ``project_fwd(qbox=...)`` / ``bin_tiles(qbox=...)`` -- None when the masks are switched off."""
+    return torch.empty(n, dtype=torch.int32, device=dev) if _QUAD_MASKS else None
+
+
 # (device, W, H, cull_mode) -> [records per gaussian the next call provisions for, consecutive low counts].
 # Keyed WITHOUT N: densify / prune changes N every 100 iterations (trainer.py:794-797) and a changed N predicts its
 # capacity from the remembered ratio instead of costing a blocking read-back.  Grows at once, shrinks only after many
@@ -393,6 +396,7 @@ _TABLE_MODE = {}          # scene shape -> views left on the device-built table
 _MSD_MIN_N = 32768        # below this the 256 x 1024-thread bucket launch costs more than the LSD passes it replaces
 _MSD_MAX_N = 1_400_000    # above this an average bucket (N / 255, x1.5 for skew) no longer fits the 8192-key LDS capacity
 _MSD_BACKOFF = {}         # scene shape -> calls left before the bucketed ordering is tried again after an overflow
+_HOST_PLAN_BACKOFF = {}   # scene shape -> calls left before a HOST-planned (equal-bucket) ordering is tried again after a miss
 _MSD_STREAK = {}          # scene shape -> overflows of the device-planned ordering in a row (escalates the back-off)
 
 def _key_bits_needed(lo: int, hi: int) -> int:
@@ -452,13 +456,15 @@ def _note_keys(key, lo: int, hi: int, assumed, status: int = 0) -> bool:
             return status == 0
         kmin, scale = assumed
         ok = status == 0 and (lo > hi or (lo >= kmin and _msd_bucket(hi - kmin, scale) <= 254))
-        if not ok and _DEPTH_TABLE == "auto" and not (status & 4):
-            while len(_TABLE_MODE) >= _CAPACITY_MAX_KEYS and key not in _TABLE_MODE:
-                _TABLE_MODE.pop(next(iter(_TABLE_MODE)))
-            _TABLE_MODE[key] = _TABLE_VIEWS   # equal buckets over a remembered range do not fit these views: level tables
-            return False                      # from here on (no back-off: the next attempt runs on the device's plan)
-        if status & 5:     # a depth cluster overflowed a bucket's LDS / the view's range is beyond 16-bit local sorts: every
-            _MSD_BACKOFF[key] = 64   # such call costs a repair, so back off
+        if not ok:
+            # equal buckets over a remembered range did not fit this view: callers that bring the view's key range run on
+            # level tables built on the device from here on (auto mode; no back-off for them), callers that do not -- the
+            # stage API -- leave the host plan alone for a while instead of paying a repair per call
+            _HOST_PLAN_BACKOFF[key] = 64
+            if _DEPTH_TABLE == "auto" and not (status & 4):
+                while len(_TABLE_MODE) >= _CAPACITY_MAX_KEYS and key not in _TABLE_MODE:
+                    _TABLE_MODE.pop(next(iter(_TABLE_MODE)))
+                _TABLE_MODE[key] = _TABLE_VIEWS
         return ok
     return _key_bits_needed(lo, hi) <= assumed
 
@@ -490,12 +496,16 @@ def _note_count(key, n: int, m: int) -> None:
 
 def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, cull_mode: int = 0,
               exact: bool = False, fused: Optional[bool] = None, tile_rects=None, depth_msd: Optional[bool] = None,
-              bin_tile: int = TILE_SIZE, quad_masks: Optional[bool] = None, key_range: Optional[torch.Tensor] = None) -> TileBins:
+              bin_tile: int = TILE_SIZE, quad_masks: Optional[bool] = None, key_range: Optional[torch.Tensor] = None,
+              qbox: Optional[torch.Tensor] = None) -> TileBins:
     """Depth-order the gaussians, emit their tile records in that order, stable-sort the records by tile.
     -> TileBins(sorted_tile, sorted_gid, tile_offsets [n_tiles+1] i32).  ``sorted_tile`` holds 16-bit tile ids (an
     int16 tensor of uint16 bit patterns) on the fused path, int32 otherwise: read it through ``tile_ids``.
     ``key_range``: the buffer ``project_fwd(key_range=...)`` filled for THIS view: the bucketed depth ordering then plans
     its buckets from the view's own key range on the device (no remembered range, no repair when the views differ).
+    ``qbox``: the quadrant bounding boxes ``project_fwd(qbox=...)`` left for THIS view: where the records are placed in one
+    pass the placement also leaves ``TileBins.sorted_mask`` (``quad_masks=False`` declines; ``quad_masks=True`` without a
+    qbox takes the exact masks of a pass of their own).
     ``bin_tile`` = 32 (fused path only, ``tile_rects`` from ``project_fwd(bin_tile=32)``): the records are binned into
     32 x 32 bins instead -- tile ids, ``tile_offsets`` and the record count are then those of the bin grid, and the
     compositor stages must be told (their ``bin_tile``).
@@ -551,8 +561,12 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
                 plan = (0, 0, "device")     # the view's own depth table, built on the device
             elif rng is not None:
                 # (a caller without a key range -- the stage API, tile_lists()'s re-binning -- stays on the host's equal
-                # buckets with their normal back-off, and does not use up the shape's views on the device plan)
-                plan = _msd_plan(rng[0], rng[1])
+                # buckets, with a back-off of their own after a miss, and does not use up the shape's views on the device plan)
+                wait = _HOST_PLAN_BACKOFF.get(key, 0)
+                if wait and depth_msd is None:
+                    _HOST_PLAN_BACKOFF[key] = wait - 1
+                else:
+                    plan = _msd_plan(rng[0], rng[1])
         PATH_STATS["lsd" if plan is None else ("bucketed_device_table" if len(plan) == 3 else "bucketed_host_plan")] += 1
         if plan is not None:
             key_bits = plan
@@ -612,10 +626,10 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
     tile_offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
     if fused:
         direct = _BIN_DIRECT and bool(lib.gsa_tile_bin16_direct(width, height, bin_tile))
-        # quadrant masks: from the placement pass itself where there is one (default on); from a pass of their own over the
-        # placed records only on explicit request (quad_masks=True on a grid the one-pass placement does not take)
-        masks_inline = direct and bool(lib.gsa_tile_bin16_masks(width, height, bin_tile)) and \
-            (_QUAD_MASKS if quad_masks is None else quad_masks)
+        # quadrant masks: from the placement pass itself where there is one and the caller brought the boxes; from a pass of
+        # their own over the placed records only on explicit request
+        masks_inline = direct and qbox is not None and quad_masks is not False and \
+            bool(lib.gsa_tile_bin16_masks(width, height, bin_tile))
         masks_pass = bool(quad_masks) and not masks_inline and bin_tile <= 2 * TILE_SIZE
         # (direct placement: no 16-bit ids unless the mask pass wants them, no second-pass buffers)
         sorted_tile = None if direct and not masks_pass else torch.empty(cap, dtype=torch.int16, device=dev)   # uint16 tile ids (see tile_ids)
@@ -629,8 +643,7 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
         _call("gsa_tile_bin16", lib.gsa_tile_bin16, N, _ptr(order), _ptr(offsets), _ptr(rects), _ptr(block_owner), width,
               height, bin_tile, cap,
               _ptr(total), _ptr(k_tmp), _ptr(v_tmp), _ptr(sorted_tile), _ptr(sorted_gid), _ptr(tile_offsets),
-              _ptr(splat) if masks_inline else None, _ptr(sorted_mask) if masks_inline else None,
-              256 if quad_masks else _MASK_DEPTH_Q8, _ptr(ws2), ws2_bytes, st)
+              _ptr(qbox) if masks_inline else None, _ptr(sorted_mask) if masks_inline else None, _ptr(ws2), ws2_bytes, st)
         if masks_pass:
             _call("gsa_quadrant_masks", lib.gsa_quadrant_masks, cap, _ptr(total), _ptr(sorted_tile), _ptr(sorted_gid),
                   _ptr(splat), N, width, height, bin_tile, _ptr(sorted_mask), st)

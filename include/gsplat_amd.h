@@ -88,12 +88,17 @@ const char *gsa_error_string(int code);
  *          gaussians the (min, max) of the depth keys of its VISIBLE members ((0xFFFFFFFF, 0) when it has none) and the
  *          keys of its members 0 and 32 (a sample; 0xFFFFFFFF if culled or beyond n); every entry is written.
  *          gsa_depth_order_msd(key_range_dev) builds the view's depth table from them on the device.
+ *  qbox (ABI 10; optional, may be NULL): n uint32 -- per gaussian the 8 x 8 quadrants (pixel centres 8 q + 0.5 .. 8 q + 7.5
+ *          a side) the bounding box of its alpha >= 1/255 ellipse covers: first column | first row << 10 | (columns - 1) << 20
+ *          | (rows - 1) << 26; 0xFFFFFFFF = unbounded (more than 64 quadrants a side, grids beyond 1024); unspecified for
+ *          culled gaussians.  gsa_tile_bin16 turns it into per-record quadrant masks for gsa_composite_fwd.
  */
 int gsa_project_fwd(int n, const float *means, const float *quats, const float *scales,
                     const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
                     const float *viewmat, const float *intrin, int width, int height, int cull_mode,
                     float *splat, int32_t *radii, int32_t *tiles_touched, uint32_t *depth_keys,
-                    uint32_t *tile_rects, float *sh_aux, int bin_tile, uint32_t *key_range, gsa_stream_t stream);
+                    uint32_t *tile_rects, float *sh_aux, int bin_tile, uint32_t *key_range, uint32_t *qbox,
+                    gsa_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stage 2 (row a3.3): tile binning.  Replaces gsplat's isect_tiles + 64-bit radix sort +
@@ -132,14 +137,11 @@ int gsa_scan_tiles(int n, const int32_t *tiles_touched, const uint32_t *order, u
  * bin's list (no digit passes, no search for the list boundaries).  sorted_tile may then be NULL (not written): the
  * lists are sorted_gid + tile_offsets.  Same output, bit for bit, as the two-pass path.
  * ABI 10 -- quadrant masks from the placement pass.  Where gsa_tile_bin16_masks says 1 (the direct path, bins of 16 or 32
- * pixels) a caller may pass splat (gsa_project_fwd's records) and sorted_mask[m_capacity] (uint16): the placement then
- * also stores, beside every gaussian id, which 8 x 8 quadrants of the record's bin the alpha >= 1/255 ellipse of the
- * gaussian can reach -- bit order as gsa_quadrant_masks; a superset of the per-pixel rule -- computed where the record
- * is generated (the records of a gaussian are consecutive there: no per-record gather).  gsa_composite_fwd's
- * sorted_mask.  Both NULL: no masks (the other paths of gsa_tile_bin16 never write any).  mask_depth_q8 (1 .. 256): the
- * front mask_depth_q8 / 256 of the records IN DEPTH ORDER get computed masks, the rest all-ones (for which the compositor
- * falls back to its own reach test): in a scene dense enough for the masks to matter a quadrant's pixels saturate within
- * the first third of its list, and the deep half is never scanned.  256: every record. */
+ * pixels) a caller may pass qbox (gsa_project_fwd's quadrant boxes) and sorted_mask[m_capacity] (uint16): the placement then
+ * also stores, beside every gaussian id, which 8 x 8 quadrants of the record's bin lie inside the gaussian's box -- bit
+ * order as gsa_quadrant_masks; a superset of the per-pixel rule (78 % of the pairs it lets through reach a pixel at the
+ * bench scene, where 22 % of a bin's records reach a given quadrant) -- for about thirty integer instructions per record.
+ * gsa_composite_fwd's sorted_mask.  Both NULL: no masks (the other paths of gsa_tile_bin16 never write any). */
 #define GSA_BIN_BLOCK 4096
 int gsa_tile_bin16_supported(int width, int height);
 int gsa_tile_bin16_direct(int width, int height, int bin_tile);
@@ -210,7 +212,7 @@ int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offsets, const 
                    const int32_t *block_owner, int width, int height, int bin_tile, uint32_t m_capacity,
                    const uint32_t *m_dev, uint16_t *tile_tmp,
                    uint32_t *gid_tmp, uint16_t *sorted_tile, uint32_t *sorted_gid, int32_t *tile_offsets,
-                   const float *splat, uint16_t *sorted_mask, int mask_depth_q8,
+                   const uint32_t *qbox, uint16_t *sorted_mask,
                    void *workspace, size_t workspace_bytes, gsa_stream_t stream);
 
 /* For k in depth order, g = order[k]: write that gaussian's tile ids and its index g at

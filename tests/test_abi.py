@@ -41,9 +41,9 @@ def test_error_codes_and_strings():
     assert b"invalid" in lib.gsa_error_string(-1)
     assert b"workspace" in lib.gsa_error_string(-2)
     # argument validation happens on the host before any launch
-    assert lib.gsa_project_fwd(-1, None, None, None, None, None, 3, 16, None, None, 64, 64, 0, None, None, None, None, None, None, 0, None, None) == -1
-    assert lib.gsa_project_fwd(10, None, None, None, None, None, 3, 16, None, None, 64, 64, 0, None, None, None, None, None, None, 0, None, None) == -1
-    assert lib.gsa_project_fwd(10, None, None, None, None, None, 7, 16, None, None, 64, 64, 0, None, None, None, None, None, None, 0, None, None) == -1
+    assert lib.gsa_project_fwd(-1, None, None, None, None, None, 3, 16, None, None, 64, 64, 0, None, None, None, None, None, None, 0, None, None, None) == -1
+    assert lib.gsa_project_fwd(10, None, None, None, None, None, 3, 16, None, None, 64, 64, 0, None, None, None, None, None, None, 0, None, None, None) == -1
+    assert lib.gsa_project_fwd(10, None, None, None, None, None, 7, 16, None, None, 64, 64, 0, None, None, None, None, None, None, 0, None, None, None) == -1
     assert lib.gsa_composite_fwd(64, 64, 5, None, None, None, None, None, None, None, None, None, None, None, None, None, 0, 0, None) == -1
     assert lib.gsa_composite_fwd(64, 64, 3, None, None, None, None, None, None, None, None, None, None, None, None, None, 0, 24, None) == -1   # bin_tile
     assert lib.gsa_quadrant_masks(10, None, None, None, None, 5, 64, 64, 64, None, None) == -1   # masks: bins of 16 or 32 only
