@@ -174,27 +174,6 @@ __device__ __forceinline__ bool quadrant_reach(float mx, float my, float a, floa
     return best <= thr;
 }
 
-// One thread per binned record: the quadrant mask of (bin, gaussian).  The forward compositor's waves test ONE bit of it
-// per list entry before they gather anything: of the records of a 32 x 32 bin only a fifth reach a given 8 x 8 quadrant.
-template <int SHIFT>
-__global__ __launch_bounds__(256) void quadrant_mask_kernel(uint32_t m_cap, const uint32_t *__restrict__ m_dev,
-                                                            const uint16_t *__restrict__ sorted_bin,
-                                                            const uint32_t *__restrict__ sorted_gid,
-                                                            const float *__restrict__ splat, int bin_w, int n,
-                                                            uint16_t *__restrict__ mask_out) {
-    const uint32_t m = m_dev ? min(m_cap, *m_dev) : m_cap;
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= m) return;
-    const uint32_t gid = min(sorted_gid[p], (uint32_t)n - 1u);
-    const uint32_t bin = sorted_bin[p];
-    const float4 *row = reinterpret_cast<const float4 *>(splat + (size_t)gid * GSA_SPLAT_STRIDE);
-    const float4 r0 = row[0], r1 = row[1], r2 = row[2];
-    const int by = (int)bin / bin_w, bx = (int)bin - by * bin_w;
-    constexpr int Q = 2 << SHIFT;
-    mask_out[p] = (uint16_t)gsa_reach_mask<Q>(r0.x, r0.y, r0.z, r0.w, r1.x, r2.z, (float)(bx * (kTile << SHIFT)),
-                                          (float)(by * (kTile << SHIFT)));
-}
-
 // Lane `lane` writes its record (list position idx) into slot `lane` of the wave's LDS image and tests it against
 // the quadrant; the wave compacts the hits into st.list.  Returns the number of listed records (wave-uniform);
 // `any_cap` tells whether a listed record's opacity exceeds the 0.999 alpha cap.
@@ -430,14 +409,16 @@ __device__ __forceinline__ bool walk_fwd(const ST &st, int n, float yrel, FwdPix
 
 // ---- the forward kernel ------------------------------------------------------------------------------------------
 // A (tile, quadrant) wave walks its bin's depth-ordered record list in three decoupled steps:
-//   SCAN   128 list entries at a time: (gaussian id, quadrant mask) pairs, coalesced; the entries whose mask has this
-//          wave's quadrant bit (gsa_quadrant_masks: ~22 % in a 32 x 32 bin) are appended to a small queue in LDS -- ballot
-//          + mbcnt, about a dozen vector instructions per 64 entries, nothing gathered for the others;
+//   SCAN   128 list entries at a time, coalesced: with BOXES (gsa_tile_bin16 given the gaussians' quadrant boxes) the top
+//          byte of an entry says which quadrants of the bin the gaussian's bounding box covers -- first / last column,
+//          first / last row, two bits each -- and only the entries whose box covers this wave's quadrant (~28 % in a 32 x 32
+//          bin) are appended to a small queue in LDS: ballot + mbcnt, about a dozen vector instructions per 64 entries,
+//          nothing gathered for the others;
 //   STAGE  64 queued candidates at a time: one 64-B splat record per lane (the gather is in flight while the previous
 //          batch is blended), re-tested against the bounding box of the pixels that are still accumulating, and the
 //          survivors written to CONSECUTIVE slots of the wave's LDS image -- so that
 //   WALK   needs no offset list: slot i of the image is entry i of the walk (walk_fwd with a dense image).
-// Without masks (sorted_mask == NULL: the 32-bit binning paths) every entry is a candidate and STAGE's test is the filter.
+// Without boxes (the other binning paths) every entry is a candidate and STAGE's test is the filter.
 // The wave's LDS image, three float4 per staged record:
 //   [0] s0  gx  gy  A          (the record's alpha exponent for THIS quadrant: sigma_form / alpha_exponent)
 //   [1] B  C  r  g
@@ -456,11 +437,10 @@ struct Dense {
 // sweep then visits exactly those, without a reach test and in full batches.
 // (register budget: seven waves per SIMD for the three-channel instances -- 72 registers; a handful of values of the
 // prologue and the staging step then live in scratch, none of the walk's; the four-channel instances keep what they need)
-template <int CH, int LISTS, bool HAS_MASK>
+template <int CH, int LISTS, bool HAS_BOX>
 __global__ __launch_bounds__(kWave, (CH == 3 ? 7 : GSA_FWD_WAVES)) void composite_fwd_kernel(
     int width, int height, int tile_w, int n_tiles, int bin_shift, const float *__restrict__ splat,
-    const uint32_t *__restrict__ sorted_gid, const uint16_t *__restrict__ sorted_mask,
-    const int32_t *__restrict__ tile_offsets,
+    const uint32_t *__restrict__ sorted_gid, const int32_t *__restrict__ tile_offsets,
     const float *__restrict__ background, const int32_t *__restrict__ tile_order, float *__restrict__ render,
     float *__restrict__ alpha_out, float *__restrict__ final_T, int32_t *__restrict__ last_id,
     uint32_t *__restrict__ quad_list, int32_t *__restrict__ quad_count, float4 *__restrict__ zero4, long n_zero4) {
@@ -489,7 +469,9 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 7 : GSA_FWD_WAVES)) void composit
     const float xrel = (float)(lane & 7) - 3.5f, yrel = (float)(lane >> 3) - 3.5f;    // this lane's pixel centre relative to it
     int start, end, slice;   // this tile's record list (its bin's), and which of the bin's quadrant slices is this wave's
     tile_list(tile_offsets, tile, tile_w, bin_shift, q, start, end, slice);
-    const uint32_t my_bit = HAS_MASK ? 1u << slice : 1u;   // (no masks: every entry carries 0xFFFF)
+    // this wave's quadrant column / row inside its bin (the bin's quadrant slices are (sub-tile << 2) | quadrant)
+    const uint32_t my_col = (uint32_t)((((slice >> 2) & ((1 << bin_shift) - 1)) << 1) | (q & 1));
+    const uint32_t my_row = (uint32_t)((((slice >> 2) >> bin_shift) << 1) | (q >> 1));
 
     FwdPixel<CH> px;
     px.T = 1.f; px.Tend = 1.f; px.dead = inside ? 0u : kSign; px.last = -1;
@@ -502,13 +484,12 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 7 : GSA_FWD_WAVES)) void composit
     if (__ballot(inside) != 0ull && start < end) {
         // ---- SCAN state: the entries [p, p + 128) are in registers (loads clamped, not predicated: in flight together)
         int p = start, head = 0, tail = 0;   // (wave-uniform)
-        uint32_t s_gid[kScanWin], s_mask[kScanWin];
+        uint32_t s_gid[kScanWin];
         auto scan_issue = [&]() {
 #pragma unroll
             for (int w = 0; w < kScanWin; ++w) {
                 const int idx = p + w * kBatch + lane, ic = min(idx, end - 1);
                 s_gid[w] = sorted_gid[ic];
-                s_mask[w] = HAS_MASK ? (uint32_t)sorted_mask[ic] : 0xFFFFu;
             }
         };
         auto scan_until = [&](int want) {   // append candidates until `want` are queued or the list ends
@@ -516,11 +497,14 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 7 : GSA_FWD_WAVES)) void composit
 #pragma unroll
                 for (int w = 0; w < kScanWin; ++w) {
                     const int idx = p + w * kBatch + lane;
-                    const bool hit = idx < end && (s_mask[w] & my_bit) != 0u;
+                    // (box: columns [b & 3, (b >> 2) & 3], rows [(b >> 4) & 3, b >> 6] of the bin's quadrants; empty: first > last)
+                    const uint32_t bx_ = s_gid[w] >> 24;
+                    const bool hit = idx < end && (!HAS_BOX || (my_col >= (bx_ & 3u) && my_col <= ((bx_ >> 2) & 3u) &&
+                                                                my_row >= ((bx_ >> 4) & 3u) && my_row <= (bx_ >> 6)));
                     const unsigned long long b = __ballot(hit);
                     if (b) {
                         const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
-                        if (hit) st.queue[(tail + rank) & (kQueue - 1)] = make_uint2(s_gid[w], (uint32_t)idx);
+                        if (hit) st.queue[(tail + rank) & (kQueue - 1)] = make_uint2(HAS_BOX ? s_gid[w] & 0xFFFFFFu : s_gid[w], (uint32_t)idx);
                         tail += __builtin_popcountll(b);
                     }
                 }
@@ -761,7 +745,7 @@ __device__ __forceinline__ void walk_bwd(const Staged<F4> &st, int n, int lane, 
 template <int CH>
 __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_kernel(
     int width, int height, int tile_w, int n_tiles, int bin_shift, const float *__restrict__ splat,
-    const uint32_t *__restrict__ sorted_gid, const int32_t *__restrict__ tile_offsets,
+    const uint32_t *__restrict__ sorted_gid, uint32_t gid_mask, const int32_t *__restrict__ tile_offsets,
     const float *__restrict__ background, const int32_t *__restrict__ tile_order, const float *__restrict__ final_T,
     const int32_t *__restrict__ last_id, const float *__restrict__ v_render, const float *__restrict__ v_alpha,
     float *__restrict__ v_splat) {
@@ -796,7 +780,7 @@ __global__ __launch_bounds__(kWave, GSA_BWD_WAVES) void composite_bwd_kernel(
     // software pipeline as in the forward; lane l of batch j holds list position qmax - 64 j - l (walk order)
     auto load_gid = [&](int j) -> uint32_t {
         const int p = qmax - j * kBatch - lane;
-        return p >= start ? sorted_gid[p] : 0u;
+        return p >= start ? sorted_gid[p] & gid_mask : 0u;
     };
     uint32_t gid_next = load_gid(0);
     const float Tf = inside ? final_T[pix] : 1.f;
@@ -897,7 +881,7 @@ __device__ __forceinline__ int stage_listed(TwoPhase<F4> &tp, int lane, const Ro
 template <int CH>
 __global__ __launch_bounds__(kWave, (CH == 3 ? 5 : GSA_BWD_WAVES)) void composite_bwd_2p_kernel(
     int width, int height, int tile_w, int n_tiles, int bin_shift, const float *__restrict__ splat,
-    const uint32_t *__restrict__ sorted_gid, const int32_t *__restrict__ tile_offsets,
+    const uint32_t *__restrict__ sorted_gid, uint32_t gid_mask, const int32_t *__restrict__ tile_offsets,
     const float *__restrict__ background, const int32_t *__restrict__ tile_order, const float *__restrict__ final_T,
     const int32_t *__restrict__ last_id, const float *__restrict__ v_render, const float *__restrict__ v_alpha,
     const uint32_t *__restrict__ quad_list, const int32_t *__restrict__ quad_count, float *__restrict__ v_splat) {
@@ -927,7 +911,7 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 5 : GSA_BWD_WAVES)) void composit
         const int e = count - 1 - j * kBatch - lane;
         return e >= 0 ? (int)my_list[e] : -1;
     };
-    auto load_gid = [&](int pos) -> uint32_t { return pos >= 0 ? sorted_gid[pos] : 0u; };
+    auto load_gid = [&](int pos) -> uint32_t { return pos >= 0 ? sorted_gid[pos] & gid_mask : 0u; };
     int pos_cur = load_pos(0);
     int pos_next = load_pos(1);
     uint32_t gid_cur = load_gid(pos_cur);
@@ -1240,27 +1224,8 @@ extern "C" int gsa_debug_set_trace(unsigned long long *buf) {
 }
 #endif
 
-extern "C" int gsa_quadrant_masks(uint32_t m_capacity, const uint32_t *m_dev, const uint16_t *sorted_bin,
-                                  const uint32_t *sorted_gid, const float *splat, int n, int width, int height, int bin_tile,
-                                  uint16_t *sorted_mask, gsa_stream_t stream) {
-    GSA_RETURN_IF(width <= 0 || height <= 0 || n < 0, GSA_ERR_INVALID_ARGUMENT);
-    const int bin_shift = bin_shift_of(bin_tile);
-    GSA_RETURN_IF(bin_shift < 0 || bin_shift > 1, GSA_ERR_INVALID_ARGUMENT);   // 16 masks 4 quadrants, 32 masks 16
-    if (m_capacity == 0 || n == 0) return GSA_OK;
-    GSA_RETURN_IF(!sorted_bin || !sorted_gid || !splat || !sorted_mask, GSA_ERR_INVALID_ARGUMENT);
-    const int bin_w = gsa_div_up(width, kTile << bin_shift);
-    const unsigned grid = (unsigned)gsa_div_up((long long)m_capacity, 256);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (bin_shift == 0)
-        quadrant_mask_kernel<0><<<grid, 256, 0, s>>>(m_capacity, m_dev, sorted_bin, sorted_gid, splat, bin_w, n, sorted_mask);
-    else
-        quadrant_mask_kernel<1><<<grid, 256, 0, s>>>(m_capacity, m_dev, sorted_bin, sorted_gid, splat, bin_w, n, sorted_mask);
-    GSA_LAUNCH_CHECK();
-    return GSA_OK;
-}
-
 extern "C" int gsa_composite_fwd(int width, int height, int channels, const float *splat,
-                                 const uint32_t *sorted_gid, const uint16_t *sorted_mask, const int32_t *tile_offsets,
+                                 const uint32_t *sorted_gid, int gid_boxes, const int32_t *tile_offsets,
                                  const float *background,
                                  const int32_t *tile_order, float *render, float *alpha, float *final_T,
                                  int32_t *last_id, uint32_t *quad_list, int32_t *quad_count, float *v_splat_zero,
@@ -1268,7 +1233,7 @@ extern "C" int gsa_composite_fwd(int width, int height, int channels, const floa
     GSA_RETURN_IF(width <= 0 || height <= 0 || (channels != 3 && channels != 4), GSA_ERR_INVALID_ARGUMENT);
     const int bin_shift = bin_shift_of(bin_tile);
     GSA_RETURN_IF(bin_shift < 0, GSA_ERR_INVALID_ARGUMENT);
-    GSA_RETURN_IF(sorted_mask && bin_shift > 1, GSA_ERR_INVALID_ARGUMENT);   // (a 64 x 64 bin has 64 quadrants)
+    GSA_RETURN_IF((gid_boxes != 0 && gid_boxes != 1) || (gid_boxes && bin_shift > 1), GSA_ERR_INVALID_ARGUMENT);   // (a 64 x 64 bin has 8 x 8 quadrants)
     GSA_RETURN_IF(!tile_offsets || !render || !alpha || !final_T || !last_id, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF((quad_list == nullptr) != (quad_count == nullptr), GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(n_zero_rows < 0 || (reinterpret_cast<uintptr_t>(v_splat_zero) & 15) != 0, GSA_ERR_INVALID_ARGUMENT);
@@ -1280,9 +1245,9 @@ extern "C" int gsa_composite_fwd(int width, int height, int channels, const floa
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define GSA_FWD_LAUNCH(C, L, M)                                                                                       \
     composite_fwd_kernel<C, L, M><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid, \
-                                                        sorted_mask, tile_offsets, background, tile_order, render, alpha, \
+                                                        tile_offsets, background, tile_order, render, alpha,            \
                                                         final_T, last_id, quad_list, quad_count, zero4, n_zero4)
-#define GSA_FWD_LAUNCH_CL(C, L) do { if (sorted_mask) GSA_FWD_LAUNCH(C, L, true); else GSA_FWD_LAUNCH(C, L, false); } while (0)
+#define GSA_FWD_LAUNCH_CL(C, L) do { if (gid_boxes) GSA_FWD_LAUNCH(C, L, true); else GSA_FWD_LAUNCH(C, L, false); } while (0)
     if (quad_list) {
         if (channels == 3) GSA_FWD_LAUNCH_CL(3, GSA_LIST_MODE); else GSA_FWD_LAUNCH_CL(4, GSA_LIST_MODE);
     } else {
@@ -1295,7 +1260,7 @@ extern "C" int gsa_composite_fwd(int width, int height, int channels, const floa
 }
 
 extern "C" int gsa_composite_bwd(int width, int height, int channels, const float *splat,
-                                 const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
+                                 const uint32_t *sorted_gid, int gid_boxes, const int32_t *tile_offsets, const float *background,
                                  const int32_t *tile_order, const float *final_T, const int32_t *last_id,
                                  const float *v_render, const float *v_alpha, float *v_splat, int bin_tile,
                                  gsa_stream_t stream) {
@@ -1307,19 +1272,22 @@ extern "C" int gsa_composite_bwd(int width, int height, int channels, const floa
     const int n_tiles = tile_w * tile_h;
     const int grid = 32 * gsa_div_up(n_tiles, 8);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t gid_mask = gid_boxes ? 0xFFFFFFu : 0xFFFFFFFFu;
     if (channels == 3)
-        composite_bwd_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid, tile_offsets,
-                                                      background, tile_order, final_T, last_id, v_render, v_alpha, v_splat);
+        composite_bwd_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid, gid_mask,
+                                                      tile_offsets, background, tile_order, final_T, last_id, v_render, v_alpha,
+                                                      v_splat);
     else
-        composite_bwd_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid, tile_offsets,
-                                                      background, tile_order, final_T, last_id, v_render, v_alpha, v_splat);
+        composite_bwd_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid, gid_mask,
+                                                      tile_offsets, background, tile_order, final_T, last_id, v_render, v_alpha,
+                                                      v_splat);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }
 
 
 extern "C" int gsa_composite_bwd_lists(int width, int height, int channels, const float *splat,
-                                       const uint32_t *sorted_gid, const int32_t *tile_offsets,
+                                       const uint32_t *sorted_gid, int gid_boxes, const int32_t *tile_offsets,
                                        const float *background, const int32_t *tile_order, const float *final_T,
                                        const int32_t *last_id, const float *v_render, const float *v_alpha,
                                        const uint32_t *quad_list, const int32_t *quad_count, float *v_splat,
@@ -1333,12 +1301,13 @@ extern "C" int gsa_composite_bwd_lists(int width, int height, int channels, cons
     const int n_tiles = tile_w * tile_h;
     const int grid = 32 * gsa_div_up(n_tiles, 8);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t gid_mask = gid_boxes ? 0xFFFFFFu : 0xFFFFFFFFu;
     if (channels == 3)
-        composite_bwd_2p_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid,
+        composite_bwd_2p_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid, gid_mask,
                                                          tile_offsets, background, tile_order, final_T, last_id,
                                                          v_render, v_alpha, quad_list, quad_count, v_splat);
     else
-        composite_bwd_2p_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid,
+        composite_bwd_2p_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid, gid_mask,
                                                          tile_offsets, background, tile_order, final_T, last_id,
                                                          v_render, v_alpha, quad_list, quad_count, v_splat);
     GSA_LAUNCH_CHECK();

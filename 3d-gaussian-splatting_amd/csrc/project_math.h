@@ -227,48 +227,3 @@ __device__ __forceinline__ uint32_t gsa_quadrant_mask(float mx, float my, float 
     }
     return m;
 }
-
-// Which 8 x 8 quadrants of a block of Q x Q quadrants (origin (X0, Y0): pixel coordinates of its first pixel) can the
-// alpha >= 1/255 region of a splat reach?  Bit order = the compositor's quadrant slices (composite.hip: tile_list): Q = 2: (qy << 1) | qx;
-// Q = 4 (a 32 x 32 bin): (((j >> 1) << 1 | (i >> 1)) << 2) | ((j & 1) << 1) | (i & 1) for quadrant column i, row j.
-// Per row of quadrants (a band of 8 pixel-centre rows, v = y - mean.y in [w0, w1] after clipping to the ellipse's extent)
-// the reachable region is an INTERVAL in u = x - mean.x.  The ellipse's chord at height v is k v +- e(v) with k = -b / a and
-// e(v) = sqrt(2 t a - D v^2) / a, which shrinks with |v|: over the band, u <= max(k w0, k w1) + e(v*) with v* the band's
-// point nearest the centre line -- ONE square root per band (r03's form took the exact extreme of k v + e(v): two per band,
-// and 270 instructions per mask where this one has ~150; the bound is exact for axis-aligned splats and a fraction of a
-// pixel wide of it for slanted ones).  A SUPERSET of the per-pixel rule is all the compositor needs (it re-tests what it
-// stages, and a record that passes no pixel's alpha test blends nothing): the threshold carries the margin of
-// composite.hip's quadrant_reach, the interval another 1e-3 px, and a conic too ill-conditioned for the closed form
-// (needle-like splats) gets every bit.  (Square roots are the raw v_sqrt_f32 -- 1 ulp, i.e. 1e-5 px on a 100-px extent, far
-// inside the margin; the IEEE-exact form is fifteen instructions each.)
-template <int Q>
-__device__ __forceinline__ uint32_t gsa_reach_mask(float mx, float my, float a, float b, float c, float sig_max, float X0,
-                                                   float Y0) {
-    constexpr uint32_t kAll = Q == 2 ? 0xFu : 0xFFFFu;
-    const float t2 = 2.f * (sig_max * 1.0001f + 1e-4f);
-    const float D = a * c - b * b;
-    if (!(D > 1e-3f * a * c) || !(t2 > 0.f)) return kAll;
-    const float ra = __builtin_amdgcn_rcpf(a), t2a = t2 * a;
-    const float vmax = __builtin_amdgcn_sqrtf(t2a * __builtin_amdgcn_rcpf(D)) + 1e-3f;   // the ellipse's extent in y
-    const float k = -b * ra;                                                              // centre line: u = k v
-    const float eps = 1e-3f;
-    const float c0 = (X0 + 0.5f) - mx;                                                    // first pixel centre - mean
-    uint32_t m = 0;
-#pragma unroll
-    for (int j = 0; j < Q; ++j) {
-        const float v0 = (Y0 + 8.f * j + 0.5f) - my, v1 = v0 + 7.f;            // pixel centre - mean
-        const float w0 = fmaxf(v0, -vmax), w1 = fminf(v1, vmax);
-        const bool band = w0 <= w1;
-        const float vs = fminf(fmaxf(0.f, w0), w1);                            // the band's widest chord
-        const float e = __builtin_amdgcn_sqrtf(fmaxf(0.f, __builtin_fmaf(-D * vs, vs, t2a))) * ra + eps;
-        const float kw0 = k * w0, kw1 = k * w1;
-        const float R = fmaxf(kw0, kw1) + e, Lm7 = (fminf(kw0, kw1) - e) - 7.f;
-#pragma unroll
-        for (int i = 0; i < Q; ++i) {
-            const float u0 = c0 + 8.f * i;                                     // the column's first pixel centre (its last: + 7)
-            const int bit = Q == 2 ? ((j << 1) | i) : (((((j >> 1) << 1) | (i >> 1)) << 2) | ((j & 1) << 1) | (i & 1));
-            m |= (band && Lm7 <= u0 && R >= u0) ? (1u << bit) : 0u;
-        }
-    }
-    return m;
-}

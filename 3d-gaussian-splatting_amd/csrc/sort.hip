@@ -1308,45 +1308,32 @@ __device__ __forceinline__ uint32_t wave_rank_round_bins(unsigned long long *mas
     return seen + below;
 }
 
-// MASK_Q (0: none; 2 / 4: a bin is MASK_Q x MASK_Q quadrants of 8 x 8 pixels -- 16 x 16 tiles / 32 x 32 bins): the record's
-// QUADRANT MASK is stored beside its gaussian id (masks_out): which 8 x 8 quadrants of its bin lie inside the gaussian's
-// quadrant bounding box (gsa_project_fwd's qbox: the box of the alpha >= 1/255 ellipse, four small integers per gaussian) --
-// what a forward-compositor wave tests, one bit per list entry, before it gathers anything.  About thirty integer
-// instructions per record and one 4-B load from a 4-MB array the records of a gaussian share (they are consecutive slots
-// here).  Not exact -- 78 % of the (quadrant, record) pairs it lets through reach a pixel, the ellipse test in the
-// compositor's staging step weeds out the rest -- but the exact form (gsa_reach_mask: ~150 instructions and three loads
-// from the 64-B splat row per record) cost this kernel 0.021-0.026 ms for the 0.030 ms it saved the forward sweep, and a
-// pass over the PLACED records (gsa_quadrant_masks, round 3: one random row per record) 0.070 ms.
-__device__ __forceinline__ uint32_t qbox_mask2(uint32_t qb, int bx, int by) {   // Q = 2: bit (qy << 1) | qx
-    if (qb == 0xFFFFFFFFu) return 0xFu;
-    const int x0 = (int)(qb & 1023u) - 2 * bx, y0 = (int)((qb >> 10) & 1023u) - 2 * by;
+// BOX_Q (0: none; 2 / 4: a bin is BOX_Q x BOX_Q quadrants of 8 x 8 pixels -- 16 x 16 tiles / 32 x 32 bins): the top byte of
+// every stored gaussian id (ids are below 2^24) receives the part of the gaussian's QUADRANT BOX (gsa_project_fwd's qbox:
+// the bounding box of its alpha >= 1/255 ellipse, in quadrants) that lies inside the record's bin -- first / last column,
+// first / last row, two bits each; first > last: none -- which a forward-compositor wave compares with its own quadrant
+// before it gathers anything: of the records of a 32 x 32 bin 22 % reach a given quadrant, of those whose box covers it 78 %.
+// About fifteen integer instructions per record, one 4-B load from a 4-MB array the records of a gaussian share (they are
+// consecutive slots here), and NOT ONE STORE more: what r04 measured on the way -- exact 16-bit ellipse masks in an array
+// of their own -- cost this kernel 0.021 ms for the second scattered store stream alone (3.6 M two-byte stores), whatever
+// the masks cost to compute, and a pass over the PLACED records (round 3) 0.070 ms.
+template <int Q>
+__device__ __forceinline__ uint32_t qbox_in_bin(uint32_t qb, int bx, int by) {
+    if (qb == 0xFFFFFFFFu) return (uint32_t)(((Q - 1) << 2) | ((Q - 1) << 6));   // unbounded: the whole bin
+    const int x0 = (int)(qb & 1023u) - Q * bx, y0 = (int)((qb >> 10) & 1023u) - Q * by;
     const int x1 = x0 + (int)((qb >> 20) & 63u), y1 = y0 + (int)(qb >> 26);
-    const uint32_t cols = (x0 <= 0 && x1 >= 0 ? 1u : 0u) | (x0 <= 1 && x1 >= 1 ? 2u : 0u);
-    const uint32_t rows = (y0 <= 0 && y1 >= 0 ? 1u : 0u) | (y0 <= 1 && y1 >= 1 ? 2u : 0u);
-    return (rows & 1u ? cols : 0u) | (rows & 2u ? cols << 2 : 0u);
-}
-__device__ __forceinline__ uint32_t qbox_mask4(uint32_t qb, int bx, int by) {
-    // Q = 4: bit (((j >> 1) << 1 | (i >> 1)) << 2) | ((j & 1) << 1) | (i & 1) for quadrant column i, row j of the bin
-    if (qb == 0xFFFFFFFFu) return 0xFFFFu;
-    const int x0 = (int)(qb & 1023u) - 4 * bx, y0 = (int)((qb >> 10) & 1023u) - 4 * by;
-    const int x1 = x0 + (int)((qb >> 20) & 63u), y1 = y0 + (int)(qb >> 26);
-    // columns / rows lo .. hi of the bin inside the box, as 4-bit sets (empty if hi < lo)
-    const int cl = max(x0, 0), ch = min(x1, 3), rl = max(y0, 0), rh = min(y1, 3);
-    const uint32_t cols = ch >= cl ? ((2u << ch) - 1u) & ~((1u << cl) - 1u) : 0u;
-    const uint32_t rows = rh >= rl ? ((2u << rh) - 1u) & ~((1u << rl) - 1u) : 0u;
-    // a row's columns land on bits {0, 1, 4, 5} shifted by {0, 2, 8, 10}: disjoint, so the set product is a multiplication
-    const uint32_t cmap = (cols & 3u) | ((cols & 12u) << 2);
-    const uint32_t rmul = (rows & 1u) | ((rows & 2u) << 1) | ((rows & 4u) << 6) | ((rows & 8u) << 7);
-    return __umul24(cmap, rmul);
+    const bool none = x1 < 0 || x0 > Q - 1 || y1 < 0 || y0 > Q - 1;
+    const uint32_t box = (uint32_t)max(x0, 0) | ((uint32_t)min(x1, Q - 1) << 2) | ((uint32_t)max(y0, 0) << 4) |
+                         ((uint32_t)min(y1, Q - 1) << 6);
+    return none ? 3u : box;   // (3: columns 3 .. 0 -- empty)
 }
 
-template <int MASK_Q>
+template <int BOX_Q>
 __global__ __launch_bounds__(kSortThreads, 4) void emit_place_kernel(
     int n, const uint32_t *__restrict__ order, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ rects,
     const int32_t *__restrict__ block_owner, int tile_w, uint32_t m_cap, const uint32_t *__restrict__ m_dev,
     uint16_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int nblocks, int nb, int n_tiles,
-    const uint32_t *__restrict__ mat, const int32_t *__restrict__ tile_offsets, const uint32_t *__restrict__ qbox,
-    uint16_t *__restrict__ masks_out) {
+    const uint32_t *__restrict__ mat, const int32_t *__restrict__ tile_offsets, const uint32_t *__restrict__ qbox) {
     __shared__ uint32_t scratch[4];
     // two regions, each with two lives: the generation's (slot owners | staged gaussians) and the placement's (peer
     // words + the bins' first slots | wave-private 16-bit bin counters)
@@ -1386,10 +1373,9 @@ __global__ __launch_bounds__(kSortThreads, 4) void emit_place_kernel(
             v[r] = min(v[r], (uint32_t)n - 1u);   // (the compositor gathers splat rows by this id, unchecked)
         }
     }
-    if constexpr (MASK_Q != 0) {
-        // the mask rides in the upper half of the bin id through the ranking, so it costs no register of its own.  (bin ->
-        // (x, y) by a reciprocal: (bin + 0.5) / tile_w is at least 0.5 / tile_w away from an integer, ids and widths are
-        // below 2^11 -- exact.)  Slots beyond the block's records hold id 0: a valid entry, an unused mask.
+    if constexpr (BOX_Q != 0) {
+        // (bin -> (x, y) by a reciprocal: (bin + 0.5) / tile_w is at least 0.5 / tile_w away from an integer, ids and widths
+        // are below 2^11 -- exact.  Slots beyond the block's records hold id 0: a valid entry, never stored.)
         const float inv_tw = __builtin_amdgcn_rcpf((float)tile_w);
         uint32_t qb[kSortItems];
 #pragma unroll
@@ -1397,7 +1383,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void emit_place_kernel(
 #pragma unroll
         for (int r = 0; r < kSortItems; ++r) {
             const int by = (int)(((float)k[r] + 0.5f) * inv_tw), bx = (int)k[r] - by * tile_w;
-            k[r] |= (MASK_Q == 2 ? qbox_mask2(qb[r], bx, by) : qbox_mask4(qb[r], bx, by)) << 16;
+            v[r] = (v[r] & 0xFFFFFFu) | (qbox_in_bin<BOX_Q>(qb[r], bx, by) << 24);
         }
     }
     __syncthreads();   // owners and staged data consumed: the regions start their second life
@@ -1414,7 +1400,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void emit_place_kernel(
     unsigned long long *mask = reinterpret_cast<unsigned long long *>(s_val) + wave * kRadix;
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r)
-        rk[r] = wave_rank_round_bins(mask, cnt, k[r] & 0xFFFFu, wbase + r * 64 + lane < eb.live, lane);
+        rk[r] = wave_rank_round_bins(mask, cnt, k[r], wbase + r * 64 + lane < eb.live, lane);
     __syncthreads();
     SORT_TRACE_MARK(2);   // bases to LDS + ranking
 #pragma unroll
@@ -1429,12 +1415,10 @@ __global__ __launch_bounds__(kSortThreads, 4) void emit_place_kernel(
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         if (wbase + r * 64 + lane < eb.live) {
-            const uint32_t bin = k[r] & 0xFFFFu;
-            const uint32_t pos = s_base[bin] + (uint32_t)cnt[bin] + rk[r];
+            const uint32_t pos = s_base[k[r]] + (uint32_t)cnt[k[r]] + rk[r];
             if (pos < m_total) {   // (always, unless the depth ordering in front failed and reported it)
                 vals_out[pos] = v[r];
-                if (keys_out) keys_out[pos] = (uint16_t)bin;
-                if constexpr (MASK_Q != 0) masks_out[pos] = (uint16_t)(k[r] >> 16);
+                if (keys_out) keys_out[pos] = (uint16_t)k[r];
             }
         }
     }
@@ -2058,11 +2042,11 @@ extern "C" int gsa_tile_bin16_direct(int width, int height, int bin_tile) {
     return n_tiles > kRadix && n_tiles + 1 <= kBinsDirect ? 1 : 0;
 }
 
-// 1: gsa_tile_bin16 can leave per-record quadrant masks for this grid (sorted_mask): the one-pass placement, bins of at
-// most 4 x 4 quadrants (16 x 16 tiles or 32 x 32 bins)
-extern "C" int gsa_tile_bin16_masks(int width, int height, int bin_tile) {
+// 1: gsa_tile_bin16 given qbox leaves every record's quadrant box in the top byte of its id for this grid and population:
+// the one-pass placement, bins of at most 4 x 4 quadrants (16 x 16 tiles or 32 x 32 bins), ids below 2^24
+extern "C" int gsa_tile_bin16_boxes(int width, int height, int bin_tile, int n) {
     if (bin_tile == 0) bin_tile = GSA_TILE_SIZE;
-    return gsa_tile_bin16_direct(width, height, bin_tile) && bin_tile <= 2 * GSA_TILE_SIZE ? 1 : 0;
+    return gsa_tile_bin16_direct(width, height, bin_tile) && bin_tile <= 2 * GSA_TILE_SIZE && n >= 0 && n <= (1 << 24) ? 1 : 0;
 }
 
 // workspace of gsa_tile_bin16 for either of its paths
@@ -2082,12 +2066,12 @@ extern "C" int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offs
                               const int32_t *block_owner, int width, int height, int bin_tile, uint32_t m_capacity,
                               const uint32_t *m_dev, uint16_t *tile_tmp,
                               uint32_t *gid_tmp, uint16_t *sorted_tile, uint32_t *sorted_gid, int32_t *tile_offsets,
-                              const uint32_t *qbox, uint16_t *sorted_mask,
+                              const uint32_t *qbox,
                               void *workspace, size_t workspace_bytes, gsa_stream_t stream) {
     GSA_RETURN_IF(n < 0 || !tile_offsets, GSA_ERR_INVALID_ARGUMENT);
-    // (masks: only where the records are placed in one pass and a bin has at most 16 quadrants -- gsa_tile_bin16_masks)
-    GSA_RETURN_IF(sorted_mask && (!qbox || !gsa_tile_bin16_masks(width, height, bin_tile) || tile_tmp || gid_tmp),
-                  GSA_ERR_INVALID_ARGUMENT);
+    // (boxes: only where the records are placed in one pass, a bin has at most 4 x 4 quadrants and ids fit 24 bits --
+    // gsa_tile_bin16_boxes)
+    GSA_RETURN_IF(qbox && (!gsa_tile_bin16_boxes(width, height, bin_tile, n) || tile_tmp || gid_tmp), GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(!gsa_tile_bins_supported(width, height, bin_tile), GSA_ERR_UNSUPPORTED);
     GSA_RETURN_IF(m_capacity >= 0x7FFFFFFFu - (uint32_t)kSortChunk, GSA_ERR_UNSUPPORTED);
     // bin_tile: the side of the tiles the records are binned into -- GSA_TILE_SIZE (0 = the same), or twice that for
@@ -2122,8 +2106,8 @@ extern "C" int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offs
 #define GSA_PLACE(Q)                                                                                                     \
     emit_place_kernel<Q><<<nblocks, kSortThreads, 0, s>>>(n, order, offsets, rects, block_owner, tile_w, m_capacity, m_dev, \
                                                           sorted_tile, sorted_gid, nblocks, nb, n_tiles, mat, tile_offsets, \
-                                                          qbox, sorted_mask)
-        if (!sorted_mask) GSA_PLACE(0);
+                                                          qbox)
+        if (!qbox) GSA_PLACE(0);
         else if (bin_tile == GSA_TILE_SIZE) GSA_PLACE(2);
         else GSA_PLACE(4);
 #undef GSA_PLACE

@@ -28,7 +28,7 @@ SIGNATURES = {
     "gsa_scan_tiles": (c_int, [c_int, P, P, P, P, P, c_size_t, P]),
     "gsa_tile_bin16_supported": (c_int, [c_int, c_int]),
     "gsa_tile_bin16_direct": (c_int, [c_int, c_int, c_int]),
-    "gsa_tile_bin16_masks": (c_int, [c_int, c_int, c_int]),
+    "gsa_tile_bin16_boxes": (c_int, [c_int, c_int, c_int, c_int]),
     "gsa_tile_bin16_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_uint32]),
     "gsa_tile_bins_supported": (c_int, [c_int, c_int, c_int]),
     "gsa_scan_tiles_rect": (c_int, [c_int, P, P, P, P, P, c_int, P, P, c_size_t, P]),
@@ -40,18 +40,17 @@ SIGNATURES = {
     "gsa_depth_order_msd_table_words": (c_int, []),
     "gsa_depth_order_msd": (c_int, [c_int, P, P, c_uint32, c_uint32, P, P, P, P, P, c_int, P, P, c_uint32, P, c_size_t, P]),
     "gsa_scan_tiles_sorted": (c_int, [c_int, P, P, c_int, P, P, c_size_t, P]),
-    "gsa_tile_bin16": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_uint32, P, P, P, P, P, P, P, P, P, c_size_t, P]),
+    "gsa_tile_bin16": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_uint32, P, P, P, P, P, P, P, P, c_size_t, P]),
     "gsa_tile_emit": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_uint32, P, P, P]),
     "gsa_tile_offsets": (c_int, [c_uint32, P, c_int, P, P]),
     "gsa_sort_pairs_u32_dev": (c_int, [c_int, P, P, P, P, P, P, P, c_int, c_int, P, c_size_t, P]),
     "gsa_tile_emit_dev": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_uint32, P, P, P, P]),
     "gsa_tile_offsets_dev": (c_int, [c_uint32, P, P, c_int, P, P]),
-    "gsa_composite_fwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, c_longlong, c_int, P]),
-    "gsa_quadrant_masks": (c_int, [c_uint32, P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "gsa_composite_fwd": (c_int, [c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P, P, P, P, P, c_longlong, c_int, P]),
     "gsa_composite_bwd_prepare": (c_int, [c_longlong, P, c_int, P, P, P]),
-    "gsa_composite_bwd_lists": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, c_int, P]),
+    "gsa_composite_bwd_lists": (c_int, [c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, P]),
     "gsa_tile_schedule": (c_int, [c_int, P, P, c_int, c_int, P]),
-    "gsa_composite_bwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, c_int, P]),
+    "gsa_composite_bwd": (c_int, [c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P, P, P, c_int, P]),
     "gsa_densify_gather": (c_int, [c_longlong, c_longlong, c_int, P, c_int, c_int, c_float, P, P, P, P, P, P, P, P, P, P]),
     "gsa_view_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
     "gsa_view_loss": (c_int, [c_int, c_int, P, P, c_float, c_float, P, c_size_t, P, P, P]),

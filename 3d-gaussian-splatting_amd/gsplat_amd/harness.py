@@ -611,7 +611,7 @@ class ViewParallelTrainer:
             bt = bins.bin_tile
             render, _, final_T, last_id, lists = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bgc, W,
                                                                  H, 3, order, want_lists=True, bin_tile=bt,
-                                                                 sorted_mask=bins.sorted_mask)
+                                                                 gid_boxes=bins.boxed)
             s3, v = S.view_loss(render, view["image"], c.lambda_dssim, grad_scale=scale / n_views)
             res = s3 / float(v.numel())            # -> l1, ssim, mse of this view
             if torch.cuda.current_stream() != main:
@@ -624,7 +624,7 @@ class ViewParallelTrainer:
             view, pose, splat, radii, bins, order, aux, final_T, last_id, lists, v = state.payload
             W, H = view["width"], view["height"]
             v_splat = S.composite_bwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bgc, final_T, last_id, v, None,
-                                      W, H, 3, order, quad_lists=lists, bin_tile=bins.bin_tile)
+                                      W, H, 3, order, quad_lists=lists, bin_tile=bins.bin_tile, gid_boxes=bins.boxed)
             if before_bucket is not None:   # (the bucket is summed into in view order)
                 torch.cuda.current_stream().wait_event(before_bucket)
             S.project_bwd(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], degree, pose, Kc, W, H, splat, radii,

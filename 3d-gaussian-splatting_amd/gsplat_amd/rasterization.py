@@ -63,11 +63,11 @@ class _RasterizeOneCamera(torch.autograd.Function):
         if front_stream is not None:
             main.wait_event(handed)
             for t in (splat, radii, tiles_touched, depth_keys, rects, sh_aux, bins.sorted_gid_buffer, bins.tile_offsets,
-                      bins.sorted_mask, bins._tile, tile_order):
+                      bins._tile, tile_order):
                 if t is not None:
                     t.record_stream(main)
         out = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg_c, width, height, channels,
-                              tile_order, want_lists=want_lists, bin_tile=bt, sorted_mask=bins.sorted_mask)
+                              tile_order, want_lists=want_lists, bin_tile=bt, gid_boxes=bins.boxed)
         if deferred is not None:
             # the caller checks the speculation (record capacity, depth-key range) later, for several views at once
             # (meta['speculation_ok']): the host does not wait here for this view's control words and runs ahead
@@ -77,20 +77,22 @@ class _RasterizeOneCamera(torch.autograd.Function):
                                tile_rects=rects, bin_tile=bt, qbox=qb)
             tile_order = S.tile_schedule(bins.tile_offsets, width, height, bt)
             out = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg_c, width, height, channels,
-                                  tile_order, want_lists=want_lists, bin_tile=bt, sorted_mask=bins.sorted_mask)
+                                  tile_order, want_lists=want_lists, bin_tile=bt, gid_boxes=bins.boxed)
         render, alpha, final_T, last_id = out[:4]
         quad_list, quad_count = out[4] if want_lists else (None, None)
         ctx.zeroed_records = out[4].zeroed if want_lists else None   # cleared by the forward kernel; used once
+        gid_buffer = bins.sorted_gid_buffer        # what the backward sweep reads (ids, boxed or not: ctx.gid_boxes)
         if deferred is not None:   # (capacity-sized: rasterization() cuts them to the record count when somebody looks)
             sorted_tile = bins._tile if bins._tile is not None else torch.empty(0, dtype=torch.int16, device=splat.device)
-            sorted_gid, tile_offsets = bins.sorted_gid_buffer, bins.tile_offsets
+            sorted_gid, tile_offsets = gid_buffer, bins.tile_offsets
         else:
             sorted_tile, sorted_gid, tile_offsets = bins.sorted_tile_stored, bins.sorted_gid, bins.tile_offsets
 
         ctx.save_for_backward(means_c, quats_c, scales_c, opac_c, colors_c, view_c, K_c, bg_c, splat, radii,
-                              sorted_gid, tile_offsets, final_T, last_id, tile_order, quad_list, quad_count, sh_aux)
+                              gid_buffer, tile_offsets, final_T, last_id, tile_order, quad_list, quad_count, sh_aux)
         ctx.dims = (width, height, sh_degree, channels)
         ctx.bin_tile = bt
+        ctx.gid_boxes = bins.boxed
         ctx.grad_out = grad_out
         ctx.grad_accumulate = bool(grad_accumulate)
         ctx.sh_grad_factored = sh_grad_factored
@@ -115,7 +117,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
             lists.zeroed, ctx.zeroed_records = ctx.zeroed_records, None
         v_splat = S.composite_bwd(splat, sorted_gid, tile_offsets, bg_c, final_T, last_id, v_render, v_alpha_c,
                                   width, height, channels, tile_order,
-                                  quad_lists=lists, bin_tile=ctx.bin_tile)
+                                  quad_lists=lists, bin_tile=ctx.bin_tile, gid_boxes=ctx.gid_boxes)
         grads = S.project_bwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
                               splat, radii, v_splat, out=ctx.grad_out, accumulate=ctx.grad_accumulate,
                               v_rgb_out=ctx.sh_grad_factored, sh_aux=sh_aux)
@@ -249,7 +251,7 @@ def rasterization(
             for c, b in enumerate(pending):
                 m = b.finalize()[0]
                 pc = list(per_cam[c])
-                pc[3], pc[4] = (pc[3][:m] if pc[3].numel() else pc[3]), pc[4][:m]
+                pc[3], pc[4] = (pc[3][:m] if pc[3].numel() else pc[3]), (pc[4][:m] & 0xFFFFFF if b.boxed else pc[4][:m])
                 per_cam[c] = tuple(pc)
             pending.clear()
         return per_cam

@@ -275,10 +275,11 @@ class TileBins:
     ``finalize()`` which the caller runs after it has queued the work that consumes the bins."""
 
     def __init__(self, sorted_tile, sorted_gid, tile_offsets, capacity, m_known, key, slot=None, n=0, key_bits=32,
-                 keys_ok=True, sorted_mask=None):
+                 keys_ok=True, boxed=False):
         self._tile, self._gid, self.tile_offsets = sorted_tile, sorted_gid, tile_offsets
-        # per record: which 8 x 8 quadrants of its tile / bin it can reach (gsa_quadrant_masks; None on the 32-bit paths)
-        self.sorted_mask = sorted_mask
+        # boxed: the top byte of every entry of the id buffer is the record's quadrant box (gsa_tile_bin16 given qbox), the
+        # gaussian id its low 24 bits -- what the compositor stages must be told (their ``gid_boxes``)
+        self.boxed = bool(boxed)
         self.capacity, self._m, self._key, self._slot, self._n = capacity, m_known, key, slot, n
         # what the depth ordering assumed about the visible keys -- bits an LSD sort covered, or (key_min, scale) of the
         # bucketed one; None: nothing to check -- and the result of the check
@@ -333,7 +334,14 @@ class TileBins:
 
     @property
     def sorted_gid(self):
-        return self._gid[:self.finalize()[0]]
+        g = self._gid[:self.finalize()[0]]
+        return g & 0xFFFFFF if self.boxed else g
+
+    @property
+    def sorted_boxes(self):
+        """Per record the quadrant box inside its bin as a uint8-valued int32 tensor (first column | last column << 2 | first
+        row << 4 | last row << 6; first > last: none) -- None without boxes."""
+        return (self._gid[:self.finalize()[0]] >> 24) & 0xFF if self.boxed else None
 
 
 def tile_ids_from_offsets(tile_offsets: torch.Tensor) -> torch.Tensor:
@@ -351,17 +359,16 @@ def tile_ids(sorted_tile: torch.Tensor) -> torch.Tensor:
 _BIN_FUSED_DEFAULT = os.environ.get("GSPLAT_AMD_BIN_FUSED", "1") != "0"
 # GSPLAT_AMD_BIN_DIRECT=0: the two-pass tile sort where gsa_tile_bin16_direct offers the one-pass placement (A/B timing)
 _BIN_DIRECT = os.environ.get("GSPLAT_AMD_BIN_DIRECT", "1") != "0"
-# Per-record quadrant masks for the forward compositor, which then gathers only the records that may reach its quadrant
-# (0.158 -> ~0.13 ms at C3: of the records of a 32 x 32 bin 22 % reach a given 8 x 8 quadrant).  The masks come out of the
-# one-pass placement (gsa_tile_bin16_masks) from the gaussians' quadrant bounding boxes (``project_fwd(qbox=...)`` ->
-# ``bin_tiles(qbox=...)``): ~30 integer instructions per record.  r03's exact masks from a pass over the PLACED records
-# (gsa_quadrant_masks: one random 64-B row per record, 0.070 ms) remain what ``bin_tiles(quad_masks=True)`` without a qbox
-# falls back to.  GSPLAT_AMD_QUAD_MASKS=0: no masks (A/B).
-_QUAD_MASKS = os.environ.get("GSPLAT_AMD_QUAD_MASKS", "1") != "0"
+# Per-record quadrant BOXES for the forward compositor, which then gathers only the records whose bounding box covers its
+# quadrant (of the records of a 32 x 32 bin 22 % reach a given 8 x 8 quadrant; of those the box lets through, 78 %).  The
+# boxes come out of the one-pass placement (gsa_tile_bin16_boxes) from the gaussians' quadrant bounding boxes
+# (``project_fwd(qbox=...)`` -> ``bin_tiles(qbox=...)``), packed into the top byte of the record's gaussian id: ~15 integer
+# instructions per record and no store of their own.  GSPLAT_AMD_QUAD_BOXES=0: plain ids (A/B).
+_QUAD_MASKS = os.environ.get("GSPLAT_AMD_QUAD_BOXES", "1") != "0"
 
 
 def qbox_buffer(n: int, dev) -> torch.Tensor:
-    """int32 [n] for ``project_fwd(qbox=...)`` / ``bin_tiles(qbox=...)`` -- None when the masks are switched off."""
+    """int32 [n] for ``project_fwd(qbox=...)`` / ``bin_tiles(qbox=...)`` -- None when the boxes are switched off."""
     return torch.empty(n, dtype=torch.int32, device=dev) if _QUAD_MASKS else None
 
 
@@ -496,7 +503,7 @@ def _note_count(key, n: int, m: int) -> None:
 
 def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, cull_mode: int = 0,
               exact: bool = False, fused: Optional[bool] = None, tile_rects=None, depth_msd: Optional[bool] = None,
-              bin_tile: int = TILE_SIZE, quad_masks: Optional[bool] = None, key_range: Optional[torch.Tensor] = None,
+              bin_tile: int = TILE_SIZE, key_range: Optional[torch.Tensor] = None,
               qbox: Optional[torch.Tensor] = None) -> TileBins:
     """Depth-order the gaussians, emit their tile records in that order, stable-sort the records by tile.
     -> TileBins(sorted_tile, sorted_gid, tile_offsets [n_tiles+1] i32).  ``sorted_tile`` holds 16-bit tile ids (an
@@ -504,8 +511,7 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
     ``key_range``: the buffer ``project_fwd(key_range=...)`` filled for THIS view: the bucketed depth ordering then plans
     its buckets from the view's own key range on the device (no remembered range, no repair when the views differ).
     ``qbox``: the quadrant bounding boxes ``project_fwd(qbox=...)`` left for THIS view: where the records are placed in one
-    pass the placement also leaves ``TileBins.sorted_mask`` (``quad_masks=False`` declines; ``quad_masks=True`` without a
-    qbox takes the exact masks of a pass of their own).
+    pass (and N <= 2^24) the placement packs every record's box into the top byte of its id (``TileBins.boxed``).
     ``bin_tile`` = 32 (fused path only, ``tile_rects`` from ``project_fwd(bin_tile=32)``): the records are binned into
     32 x 32 bins instead -- tile ids, ``tile_offsets`` and the record count are then those of the bin grid, and the
     compositor stages must be told (their ``bin_tile``).
@@ -626,15 +632,10 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
     tile_offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
     if fused:
         direct = _BIN_DIRECT and bool(lib.gsa_tile_bin16_direct(width, height, bin_tile))
-        # quadrant masks: from the placement pass itself where there is one and the caller brought the boxes; from a pass of
-        # their own over the placed records only on explicit request
-        masks_inline = direct and qbox is not None and quad_masks is not False and \
-            bool(lib.gsa_tile_bin16_masks(width, height, bin_tile))
-        masks_pass = bool(quad_masks) and not masks_inline and bin_tile <= 2 * TILE_SIZE
-        # (direct placement: no 16-bit ids unless the mask pass wants them, no second-pass buffers)
-        sorted_tile = None if direct and not masks_pass else torch.empty(cap, dtype=torch.int16, device=dev)   # uint16 tile ids (see tile_ids)
+        # quadrant boxes in the ids' top byte: where the placement is one pass and the caller brought the gaussians' boxes
+        boxed = direct and qbox is not None and bool(lib.gsa_tile_bin16_boxes(width, height, bin_tile, N))
+        sorted_tile = None if direct else torch.empty(cap, dtype=torch.int16, device=dev)   # uint16 tile ids (see tile_ids)
         sorted_gid = torch.empty(cap, dtype=torch.int32, device=dev)
-        sorted_mask = torch.empty(cap, dtype=torch.int16, device=dev) if (masks_inline or masks_pass) else None
         two = n_tiles > 256 and not direct   # (n_tiles: of the bin grid)
         k_tmp = torch.empty(cap, dtype=torch.int16, device=dev) if two else None
         v_tmp = torch.empty(cap, dtype=torch.int32, device=dev) if two else None
@@ -643,11 +644,8 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
         _call("gsa_tile_bin16", lib.gsa_tile_bin16, N, _ptr(order), _ptr(offsets), _ptr(rects), _ptr(block_owner), width,
               height, bin_tile, cap,
               _ptr(total), _ptr(k_tmp), _ptr(v_tmp), _ptr(sorted_tile), _ptr(sorted_gid), _ptr(tile_offsets),
-              _ptr(qbox) if masks_inline else None, _ptr(sorted_mask) if masks_inline else None, _ptr(ws2), ws2_bytes, st)
-        if masks_pass:
-            _call("gsa_quadrant_masks", lib.gsa_quadrant_masks, cap, _ptr(total), _ptr(sorted_tile), _ptr(sorted_gid),
-                  _ptr(splat), N, width, height, bin_tile, _ptr(sorted_mask), st)
-        return TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key, slot, N, key_bits, keys_ok, sorted_mask)
+              _ptr(qbox) if boxed else None, _ptr(ws2), ws2_bytes, st)
+        return TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key, slot, N, key_bits, keys_ok, boxed)
     isect_tile = torch.empty(cap, dtype=torch.int32, device=dev)
     isect_gid = torch.empty(cap, dtype=torch.int32, device=dev)
     _call("gsa_tile_emit", lib.gsa_tile_emit_dev, N, _ptr(order), _ptr(offsets), _ptr(splat), _ptr(radii), width,
@@ -691,8 +689,9 @@ class QuadLists(tuple):
 
 
 def composite_fwd(splat, sorted_gid, tile_offsets, background, width: int, height: int, channels: int,
-                  tile_order=None, want_lists: bool = False, bin_tile: int = TILE_SIZE, sorted_mask=None):
-    """``sorted_mask``: ``TileBins.sorted_mask`` of the same bins (optional; speed only).
+                  tile_order=None, want_lists: bool = False, bin_tile: int = TILE_SIZE, gid_boxes: bool = False):
+    """``sorted_gid``: ``TileBins.sorted_gid_buffer``; ``gid_boxes``: ``TileBins.boxed`` of the same bins (the entries' top
+    byte is a quadrant box; speed only).
     -> render [H,W,channels], alpha [H,W,1], final_T [H,W], last_id [H,W] i32
     [, QuadLists(quad_list [4 * len(sorted_gid)] i32, quad_count [n_tiles,4] i32) with ``want_lists``: per 8x8 quadrant
     the records that were blended there -- what ``composite_bwd(..., quad_lists=...)`` sweeps]."""
@@ -708,10 +707,8 @@ def composite_fwd(splat, sorted_gid, tile_offsets, background, width: int, heigh
         quad_list = torch.empty(slices * max(int(sorted_gid.numel()), 1), dtype=torch.int32, device=dev)
         quad_count = torch.empty(tile_w * tile_h, 4, dtype=torch.int32, device=dev)
         zeroed = torch.empty_like(splat)   # the backward sweep's gradient records: the forward kernel clears them
-    if sorted_mask is not None and (sorted_mask.numel() < sorted_gid.numel() or sorted_mask.dtype != torch.int16):
-        raise ValueError("composite_fwd: sorted_mask must be the int16 tensor of the same bins as sorted_gid")
     _call("gsa_composite_fwd", lib.gsa_composite_fwd, width, height, channels, _ptr(splat), _ptr(sorted_gid),
-          _ptr(sorted_mask), _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(render), _ptr(alpha), _ptr(final_T),
+          1 if gid_boxes else 0, _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(render), _ptr(alpha), _ptr(final_T),
           _ptr(last_id), _ptr(quad_list), _ptr(quad_count), _ptr(zeroed), 0 if zeroed is None else zeroed.shape[0],
           bin_tile, _stream())
     if want_lists:
@@ -751,7 +748,8 @@ def record_grads_to_moments(splat: torch.Tensor, g: torch.Tensor) -> torch.Tenso
 
 
 def composite_bwd(splat, sorted_gid, tile_offsets, background, final_T, last_id, v_render, v_alpha, width: int,
-                  height: int, channels: int, tile_order=None, quad_lists=None, bin_tile: int = TILE_SIZE):
+                  height: int, channels: int, tile_order=None, quad_lists=None, bin_tile: int = TILE_SIZE,
+                  gid_boxes: bool = False):
     """-> v_splat [N,16]: per gaussian the raw moments of u = d loss / d sigma over d = mean2d - pixel
     (sum u dx, u dy, u dx^2, u dx dy, u dy^2, u) and sum fac * v_out per channel -- the gradient record
     ``project_bwd`` consumes (``moments_to_record_grads`` gives the mean / conic / opacity gradients)."""
@@ -771,12 +769,12 @@ def composite_bwd(splat, sorted_gid, tile_offsets, background, final_T, last_id,
             _call("gsa_composite_bwd_prepare", lib.gsa_composite_bwd_prepare, splat.shape[0] if fill else 0, _ptr(v_splat),
                   tile_w * tile_h, _ptr(quad_count), _ptr(tile_order), _stream())
         _call("gsa_composite_bwd", lib.gsa_composite_bwd_lists, width, height, channels, _ptr(splat), _ptr(sorted_gid),
-              _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(final_T), _ptr(last_id), _ptr(v_render),
+              1 if gid_boxes else 0, _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(final_T), _ptr(last_id), _ptr(v_render),
               _ptr(v_alpha), _ptr(quad_list), _ptr(quad_count), _ptr(v_splat), bin_tile, _stream())
         return v_splat
     v_splat = torch.zeros_like(splat)
     _call("gsa_composite_bwd", lib.gsa_composite_bwd, width, height, channels, _ptr(splat), _ptr(sorted_gid),
-          _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(final_T), _ptr(last_id), _ptr(v_render),
+          1 if gid_boxes else 0, _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(final_T), _ptr(last_id), _ptr(v_render),
           _ptr(v_alpha), _ptr(v_splat), bin_tile, _stream())
     return v_splat
 

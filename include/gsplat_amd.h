@@ -91,7 +91,7 @@ const char *gsa_error_string(int code);
  *  qbox (ABI 10; optional, may be NULL): n uint32 -- per gaussian the 8 x 8 quadrants (pixel centres 8 q + 0.5 .. 8 q + 7.5
  *          a side) the bounding box of its alpha >= 1/255 ellipse covers: first column | first row << 10 | (columns - 1) << 20
  *          | (rows - 1) << 26; 0xFFFFFFFF = unbounded (more than 64 quadrants a side, grids beyond 1024); unspecified for
- *          culled gaussians.  gsa_tile_bin16 turns it into per-record quadrant masks for gsa_composite_fwd.
+ *          culled gaussians.  gsa_tile_bin16 turns it into per-record quadrant boxes for gsa_composite_fwd.
  */
 int gsa_project_fwd(int n, const float *means, const float *quats, const float *scales,
                     const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
@@ -136,16 +136,18 @@ int gsa_scan_tiles(int n, const int32_t *tiles_touched, const uint32_t *order, u
  * themselves, a column scan that also writes tile_offsets, and every gaussian id stored straight at its place in its
  * bin's list (no digit passes, no search for the list boundaries).  sorted_tile may then be NULL (not written): the
  * lists are sorted_gid + tile_offsets.  Same output, bit for bit, as the two-pass path.
- * ABI 10 -- quadrant masks from the placement pass.  Where gsa_tile_bin16_masks says 1 (the direct path, bins of 16 or 32
- * pixels) a caller may pass qbox (gsa_project_fwd's quadrant boxes) and sorted_mask[m_capacity] (uint16): the placement then
- * also stores, beside every gaussian id, which 8 x 8 quadrants of the record's bin lie inside the gaussian's box -- bit
- * order as gsa_quadrant_masks; a superset of the per-pixel rule (78 % of the pairs it lets through reach a pixel at the
- * bench scene, where 22 % of a bin's records reach a given quadrant) -- for about thirty integer instructions per record.
- * gsa_composite_fwd's sorted_mask.  Both NULL: no masks (the other paths of gsa_tile_bin16 never write any). */
+ * ABI 10 -- quadrant boxes from the placement pass.  Where gsa_tile_bin16_boxes says 1 (the direct path, bins of 16 or 32
+ * pixels, at most 2^24 gaussians) a caller may pass qbox (gsa_project_fwd's quadrant boxes): the TOP BYTE of every
+ * sorted_gid entry then holds the part of the gaussian's box that lies inside the record's bin, in quadrants of the bin --
+ * bits 24-25 first column, 26-27 last column, 28-29 first row, 30-31 last row; first > last: no quadrant -- and the id is
+ * the low 24 bits.  gsa_composite_fwd / _bwd / _bwd_lists must be told (gid_boxes = 1): the forward sweep then gathers only
+ * the records whose box covers a wave's quadrant (a superset of the per-pixel rule: at the bench scene 78 % of the pairs it
+ * lets through reach a pixel, where 22 % of a bin's records reach a given quadrant) -- for about fifteen integer
+ * instructions per record in the placement and not one store more.  qbox == NULL: plain ids (gid_boxes = 0). */
 #define GSA_BIN_BLOCK 4096
 int gsa_tile_bin16_supported(int width, int height);
 int gsa_tile_bin16_direct(int width, int height, int bin_tile);
-int gsa_tile_bin16_masks(int width, int height, int bin_tile);
+int gsa_tile_bin16_boxes(int width, int height, int bin_tile, int n);
 size_t gsa_tile_bin16_workspace_bytes(int width, int height, int bin_tile, uint32_t m_capacity);
 /* ... for bins of bin_tile pixels (16 / 32 / 64): an 8K image has too many 16 x 16 tiles for 16-bit ids, but not 32 x 32 bins */
 int gsa_tile_bins_supported(int width, int height, int bin_tile);
@@ -212,7 +214,7 @@ int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offsets, const 
                    const int32_t *block_owner, int width, int height, int bin_tile, uint32_t m_capacity,
                    const uint32_t *m_dev, uint16_t *tile_tmp,
                    uint32_t *gid_tmp, uint16_t *sorted_tile, uint32_t *sorted_gid, int32_t *tile_offsets,
-                   const uint32_t *qbox, uint16_t *sorted_mask,
+                   const uint32_t *qbox,
                    void *workspace, size_t workspace_bytes, gsa_stream_t stream);
 
 /* For k in depth order, g = order[k]: write that gaussian's tile ids and its index g at
@@ -259,28 +261,18 @@ int gsa_tile_offsets(uint32_t m, const uint32_t *sorted_tile, int n_tiles, int32
  * tile_offsets[n_bins + 1] indexes the bins (row-major on ceil(width / 32) x ceil(height / 32)), the four tiles of a bin
  * walk its list, and quad_list holds 16 M uint32 (16 quadrant slices per bin, at 16 * offsets[bin] + (4 * sub-tile +
  * quadrant) * list length).
- * sorted_mask (ABI 7; optional, NULL = every record is a candidate everywhere): per record of the sorted list the 8 x 8
- * quadrants of its tile / bin that the record can reach (gsa_quadrant_masks).  A quadrant's wave then gathers and
- * stages only the records whose mask has its bit; results do not depend on it (a record outside a quadrant's mask
- * fails the alpha test at every pixel of the quadrant).  bin_tile 16 or 32 only.
+ * gid_boxes (ABI 10; 0 or 1; here and in gsa_composite_bwd / _bwd_lists): 1 -- the top byte of every sorted_gid entry is
+ * the quadrant box gsa_tile_bin16 left there (its qbox argument) and the gaussian id is the low 24 bits: a quadrant's
+ * wave gathers and stages only the records whose box covers it.  Results do not depend on it (a record whose bounding box
+ * misses a quadrant fails the alpha test at every pixel of it).  bin_tile 16 or 32 only.  0: plain 32-bit ids, every
+ * record of a list is a candidate for every quadrant.
  */
 int gsa_composite_fwd(int width, int height, int channels, const float *splat,
-                      const uint32_t *sorted_gid, const uint16_t *sorted_mask, const int32_t *tile_offsets,
+                      const uint32_t *sorted_gid, int gid_boxes, const int32_t *tile_offsets,
                       const float *background,
                       const int32_t *tile_order, float *render, float *alpha, float *final_T, int32_t *last_id,
                       uint32_t *quad_list, int32_t *quad_count, float *v_splat_zero, long long n_zero_rows,
                       int bin_tile, gsa_stream_t stream);
-
-/* ABI 7 -- quadrant masks for stage 3 (replaces the per-quadrant reach test gsplat's rasterize_to_pixels does not have
- * either: it walks every record of a tile at every pixel; reference call site gsplat_backend.py:168-182).
- * sorted_mask[i], i < min(m_capacity, *m_dev) (m_dev may be NULL: m_capacity is the count): bit s is set when the
- * alpha >= 1/255 region of record i's gaussian can reach a pixel centre of quadrant slice s of the record's tile / bin
- * (bin_tile 16: s = 2 qy + qx; bin_tile 32: s = 4 * sub-tile + 2 qy + qx, sub-tile = 2 (tile_y & 1) + (tile_x & 1) -- the
- * slice numbering of quad_list).  A superset of the per-pixel rule (conservative margins).  sorted_bin: the 16-bit
- * tile / bin ids of the sorted records (gsa_tile_bin16's sorted_tile); n: number of gaussians (ids are clamped to it). */
-int gsa_quadrant_masks(uint32_t m_capacity, const uint32_t *m_dev, const uint16_t *sorted_bin,
-                       const uint32_t *sorted_gid, const float *splat, int n, int width, int height, int bin_tile,
-                       uint16_t *sorted_mask, gsa_stream_t stream);
 
 /* Launch order for stages 3 and 4 (optional; speed only, never results): tile_order[8 * ceil(n_tiles / 8)] receives,
  * for each of the 8 tile bands, the band's tiles with the longest record lists first (-1 pads the last band). Pass it
@@ -294,7 +286,7 @@ int gsa_tile_schedule(int n_tiles, const int32_t *tile_offsets, int32_t *tile_or
  *   [6..8] sum fac * v_render(rgb)  [9] sum fac * v_render(depth)   (fac = alpha * T in front)
  * d loss / d (mean2d, conic, opacity) are linear in them; gsa_project_bwd finishes that per gaussian. */
 int gsa_composite_bwd(int width, int height, int channels, const float *splat,
-                      const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
+                      const uint32_t *sorted_gid, int gid_boxes, const int32_t *tile_offsets, const float *background,
                       const int32_t *tile_order, const float *final_T, const int32_t *last_id,
                       const float *v_render, const float *v_alpha, float *v_splat, int bin_tile, gsa_stream_t stream);
 
@@ -309,7 +301,7 @@ int gsa_composite_bwd_prepare(long long n, float *v_splat, int n_tiles, const in
  * gsa_composite_fwd): same result, but no reach test and no record that blends nowhere in the quadrant (in a dense
  * scene ~10 % of what the plain sweep walks), in full batches of 64. */
 int gsa_composite_bwd_lists(int width, int height, int channels, const float *splat,
-                            const uint32_t *sorted_gid, const int32_t *tile_offsets, const float *background,
+                            const uint32_t *sorted_gid, int gid_boxes, const int32_t *tile_offsets, const float *background,
                             const int32_t *tile_order, const float *final_T, const int32_t *last_id,
                             const float *v_render, const float *v_alpha, const uint32_t *quad_list,
                             const int32_t *quad_count, float *v_splat, int bin_tile, gsa_stream_t stream);

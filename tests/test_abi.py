@@ -44,9 +44,9 @@ def test_error_codes_and_strings():
     assert lib.gsa_project_fwd(-1, None, None, None, None, None, 3, 16, None, None, 64, 64, 0, None, None, None, None, None, None, 0, None, None, None) == -1
     assert lib.gsa_project_fwd(10, None, None, None, None, None, 3, 16, None, None, 64, 64, 0, None, None, None, None, None, None, 0, None, None, None) == -1
     assert lib.gsa_project_fwd(10, None, None, None, None, None, 7, 16, None, None, 64, 64, 0, None, None, None, None, None, None, 0, None, None, None) == -1
-    assert lib.gsa_composite_fwd(64, 64, 5, None, None, None, None, None, None, None, None, None, None, None, None, None, 0, 0, None) == -1
-    assert lib.gsa_composite_fwd(64, 64, 3, None, None, None, None, None, None, None, None, None, None, None, None, None, 0, 24, None) == -1   # bin_tile
-    assert lib.gsa_quadrant_masks(10, None, None, None, None, 5, 64, 64, 64, None, None) == -1   # masks: bins of 16 or 32 only
+    assert lib.gsa_composite_fwd(64, 64, 5, None, None, 0, None, None, None, None, None, None, None, None, None, None, 0, 0, None) == -1
+    assert lib.gsa_composite_fwd(64, 64, 3, None, None, 0, None, None, None, None, None, None, None, None, None, None, 0, 24, None) == -1   # bin_tile
+    assert lib.gsa_composite_fwd(64, 64, 3, None, None, 1, None, None, None, None, None, None, None, None, None, None, 0, 64, None) == -1   # boxes: bins of 16 or 32 only
     assert lib.gsa_tile_schedule(0, None, None, 0, 0, None) == -1
     assert lib.gsa_sort_pairs_u32(16, None, None, None, None, None, None, 0, 40, None, 0, None) == -1
     assert lib.gsa_sort_workspace_bytes(1_000_000) > 0

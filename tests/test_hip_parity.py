@@ -928,27 +928,29 @@ def test_random_shapes_fused_paths_agree_with_plain_ones(gsa):
         sc = _scene(N, seed=100 + trial, s_min=s_max * 0.05, s_max=s_max)
         vm, K = scene.make_camera(int(rng.integers(0, 9)), 9).cuda(), scene.make_intrinsics(W, H).cuda()
         d = {k: v.cuda().contiguous() for k, v in sc.items()}
+        qb = torch.empty(N, dtype=torch.int32, device="cuda")
         splat, radii, tiles, keys, rects = S.project_fwd(d["means3D"], d["rotations"], d["scales"],
                                                          d["opacities"][:, 0].contiguous(), d["shs"], 3, vm, K, W, H, 0,
-                                                         return_rects=True)
+                                                         return_rects=True, qbox=qb)
         a = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, fused=False)
-        b = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, fused=True, tile_rects=rects, quad_masks=True)
+        b = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, fused=True, tile_rects=rects, qbox=qb)
         tag = (trial, W, H, N, s_max)
         assert a.finalize()[0] == b.finalize()[0] == int(tiles.sum()), tag
         assert torch.equal(b.sorted_gid, a.sorted_gid) and torch.equal(b.tile_offsets, a.tile_offsets), tag
         assert torch.equal(S.tile_ids(b.sorted_tile), S.tile_ids(a.sorted_tile)), tag
         bg = torch.tensor([0.2, 0.4, 0.6]).cuda()
         gid, offs = b.sorted_gid_buffer, b.tile_offsets
-        r0, a0, T0, l0 = S.composite_fwd(splat, gid, offs, bg, W, H, 3)
-        r1, a1, T1, l1, lists = S.composite_fwd(splat, gid, offs, bg, W, H, 3, S.tile_schedule(offs, W, H), want_lists=True)
+        # (the reference image: the plain ids of the unfused path, every record a candidate for every quadrant)
+        r0, a0, T0, l0 = S.composite_fwd(splat, a.sorted_gid_buffer, a.tile_offsets, bg, W, H, 3)
+        # with the quadrant boxes the one-pass placement packs into the ids (grids of 257 .. 2047 tiles) a wave gathers
+        # only the records whose box covers its quadrant: the same image, bit for bit
+        assert b.boxed == bool(gsa.lib.gsa_tile_bin16_boxes(W, H, 16, N)) and not a.boxed, tag
+        r1, a1, T1, l1, lists = S.composite_fwd(splat, gid, offs, bg, W, H, 3, S.tile_schedule(offs, W, H), want_lists=True,
+                                                gid_boxes=b.boxed)
         assert torch.equal(r0, r1) and torch.equal(T0, T1) and torch.equal(a0, a1), tag
-        # with the per-record quadrant masks of the fused binning a wave gathers only what can reach its quadrant: same image
-        assert b.sorted_mask is not None and a.sorted_mask is None, tag
-        rm, am, Tm, lm = S.composite_fwd(splat, gid, offs, bg, W, H, 3, sorted_mask=b.sorted_mask)
-        assert torch.equal(rm, r0) and torch.equal(Tm, T0) and torch.equal(am, a0), tag
         v_r = torch.from_numpy(rng.uniform(-1, 1, (H, W, 3)).astype(np.float32)).cuda()
-        g0 = S.composite_bwd(splat, gid, offs, bg, T0, l0, v_r, None, W, H, 3)
-        g1 = S.composite_bwd(splat, gid, offs, bg, T1, l1, v_r, None, W, H, 3, quad_lists=lists)
+        g0 = S.composite_bwd(splat, a.sorted_gid_buffer, a.tile_offsets, bg, T0, l0, v_r, None, W, H, 3)
+        g1 = S.composite_bwd(splat, gid, offs, bg, T1, l1, v_r, None, W, H, 3, quad_lists=lists, gid_boxes=b.boxed)
         scale = g0.abs().amax(0).clamp_min(1e-30)
         assert float(((g0 - g1).abs().amax(0) / scale).max()) < 5e-5, tag
         # the same view through 32 x 32 (and 64 x 64) BINS: fewer records sorted, the tiles of a bin share its list -- the
@@ -956,63 +958,57 @@ def test_random_shapes_fused_paths_agree_with_plain_ones(gsa):
         for bt in (32, 64):
             rects_b = S.project_fwd(d["means3D"], d["rotations"], d["scales"], d["opacities"][:, 0].contiguous(), d["shs"],
                                     3, vm, K, W, H, 0, return_rects=True, bin_tile=bt)[4]
-            bb = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, tile_rects=rects_b, bin_tile=bt, quad_masks=True)
+            bb = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, tile_rects=rects_b, bin_tile=bt, qbox=qb)
             assert bb.bin_tile == bt and bb.finalize()[0] <= int(tiles.sum()), tag
+            assert bb.boxed == (bt == 32 and bool(gsa.lib.gsa_tile_bin16_boxes(W, H, bt, N))), (tag, bt)   # (64: 8 x 8 quadrants a bin)
             gb, ob = bb.sorted_gid_buffer, bb.tile_offsets
             rb, ab, Tb, lb, lists_b = S.composite_fwd(splat, gb, ob, bg, W, H, 3, S.tile_schedule(ob, W, H, bt),
-                                                      want_lists=True, bin_tile=bt)
+                                                      want_lists=True, bin_tile=bt, gid_boxes=bb.boxed)
             assert torch.equal(rb, r0) and torch.equal(Tb, T0) and torch.equal(ab, a0), (tag, bt)
-            sweeps = [S.composite_bwd(splat, gb, ob, bg, Tb, lb, v_r, None, W, H, 3, bin_tile=bt)]
-            if bt == 32:   # masked walk: the image bit for bit, and the lists it leaves drive the same sweep
-                rm, am, Tm, lm, lists_m = S.composite_fwd(splat, gb, ob, bg, W, H, 3, S.tile_schedule(ob, W, H, bt),
-                                                          want_lists=True, bin_tile=bt, sorted_mask=bb.sorted_mask)
-                assert torch.equal(rm, r0) and torch.equal(Tm, T0) and torch.equal(am, a0), (tag, bt)
-                sweeps.append(S.composite_bwd(splat, gb, ob, bg, Tm, lm, v_r, None, W, H, 3, quad_lists=lists_m, bin_tile=bt))
-            else:
-                assert bb.sorted_mask is None
-            for mode in _bwd_modes():
-                with _bwd_mode(mode):
-                    sweeps.append(S.composite_bwd(splat, gb, ob, bg, Tb, lb, v_r, None, W, H, 3, quad_lists=lists_b,
-                                                  bin_tile=bt))
+            # the plain sweep (ids masked), the sweep over the forward's lists, and -- boxed -- the same bins WITHOUT the boxes
+            sweeps = [S.composite_bwd(splat, gb, ob, bg, Tb, lb, v_r, None, W, H, 3, bin_tile=bt, gid_boxes=bb.boxed),
+                      S.composite_bwd(splat, gb, ob, bg, Tb, lb, v_r, None, W, H, 3, quad_lists=lists_b, bin_tile=bt,
+                                      gid_boxes=bb.boxed)]
+            if bb.boxed:
+                plain = bb.sorted_gid.contiguous()
+                rp, ap, Tp, lp = S.composite_fwd(splat, plain, ob, bg, W, H, 3, bin_tile=bt)
+                assert torch.equal(rp, r0) and torch.equal(Tp, T0) and torch.equal(ap, a0), (tag, bt)
             for gsw in sweeps:
                 assert float(((g0 - gsw).abs().amax(0) / scale).max()) < 5e-5, (tag, bt)
 
 
-@pytest.mark.parametrize("source", ["pass", "qbox"])
 @pytest.mark.parametrize("bt", [16, 32])
 @pytest.mark.parametrize("N,s_min,s_max", [(6000, 0.004, 0.05), (1500, 0.01, 0.6), (4000, 0.0005, 0.3)])
-def test_quadrant_masks_cover_the_per_pixel_rule(gsa, bt, N, s_min, s_max, source):
-    """Both mask sources -- gsa_quadrant_masks (a pass over the placed records: the exact ellipse) and the placement pass's own
-    masks from the gaussians' quadrant bounding boxes (project_fwd's qbox: the product's default) -- must set bit s of a
-    record's mask whenever ONE pixel centre of quadrant slice s of the record's bin passes the per-pixel alpha test
-    (sigma <= ln(255 o)): checked against a brute-force evaluation of sigma at every pixel of every record's bin (fp64).
-    Also reports how tight the masks are (bits needed / bits set)."""
+def test_quadrant_boxes_cover_the_per_pixel_rule(gsa, bt, N, s_min, s_max):
+    """The quadrant box the placement pass packs into a record's id (from project_fwd's qbox: the bounding box of the
+    gaussian's alpha >= 1/255 ellipse) must cover every quadrant of the record's bin in which ONE pixel centre passes the
+    per-pixel alpha test (sigma <= ln(255 o)) -- checked against a brute-force evaluation of sigma at every pixel of every
+    record's bin (fp64) -- and the ids must be the plain binning's.  Also reports how tight the boxes are (quadrants
+    needed / quadrants covered)."""
     from gsplat_amd import scene, stages as S
     W, H = 653, 401          # partial border bins; more than 256 bins of either size (the one-pass placement's grids)
     sc = _scene(N, seed=5, s_min=s_min, s_max=s_max)
-    if s_max > 0.5:          # needle-like splats: the closed form's fallback
+    if s_max > 0.5:          # needle-like splats
         sc["scales"][:, 0] *= 0.02
     vm, K = scene.make_camera(1, 5).cuda(), scene.make_intrinsics(W, H).cuda()
     d = {k: v.cuda().contiguous() for k, v in sc.items()}
-    qb = torch.full((N,), 0x12345678, dtype=torch.int32, device="cuda") if source == "qbox" else None
+    qb = torch.full((N,), 0x12345678, dtype=torch.int32, device="cuda")
     splat, radii, tiles, keys, rects = S.project_fwd(d["means3D"], d["rotations"], d["scales"], d["opacities"][:, 0].contiguous(),
                                                      d["shs"], 3, vm, K, W, H, 0, return_rects=True, bin_tile=bt, qbox=qb)
-    if source == "qbox":
-        assert gsa.lib.gsa_tile_bin16_masks(W, H, bt) == 1      # (a grid the one-pass placement takes)
-        bins = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, tile_rects=rects, bin_tile=bt, qbox=qb)
-        assert bins._tile is None                                # no pass over the placed records ran
-    else:
-        bins = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, tile_rects=rects, bin_tile=bt, quad_masks=True)
+    assert gsa.lib.gsa_tile_bin16_boxes(W, H, bt, N) == 1      # (a grid the one-pass placement takes)
+    bins = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, tile_rects=rects, bin_tile=bt, qbox=qb)
+    plain = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=True, tile_rects=rects, bin_tile=bt)
     m = bins.finalize()[0]
-    assert bins.sorted_mask is not None and m > 1000
+    assert bins.boxed and not plain.boxed and m > 1000
+    assert torch.equal(bins.sorted_gid, plain.sorted_gid) and torch.equal(bins.tile_offsets, plain.tile_offsets)
     gid = bins.sorted_gid.long()
     bin_id = S.tile_ids(bins.sorted_tile)
-    mask = bins.sorted_mask[:m].long() & 0xFFFF
+    box = bins.sorted_boxes.long()
     bw = (W + bt - 1) // bt
     sp = splat.double()[gid]                                           # [m,16]
     q = bt // 8                                                        # quadrants per bin side
     ys, xs = torch.meshgrid(torch.arange(bt, device="cuda"), torch.arange(bt, device="cuda"), indexing="ij")
-    need = torch.zeros(m, dtype=torch.long, device="cuda")
+    need = torch.zeros(m, q, q, dtype=torch.bool, device="cuda")
     for lo in range(0, m, 4096):
         hi = min(m, lo + 4096)
         r = sp[lo:hi]
@@ -1022,17 +1018,17 @@ def test_quadrant_masks_cover_the_per_pixel_rule(gsa, bt, N, s_min, s_max, sourc
         dy = r[:, 1, None, None] - (Y0 + ys[None] + 0.5)
         sig = 0.5 * (r[:, 2, None, None] * dx * dx + r[:, 4, None, None] * dy * dy) + r[:, 3, None, None] * dx * dy
         ok = (sig >= 0) & (sig <= r[:, 10, None, None])                 # alpha = o exp(-sigma) >= 1/255
-        okq = ok.view(-1, q, 8, q, 8).any(4).any(2)                     # [m', qy, qx]
-        for j in range(q):
-            for i in range(q):
-                bit = (j << 1) | i if q == 2 else (((((j >> 1) << 1) | (i >> 1)) << 2) | ((j & 1) << 1) | (i & 1))
-                need[lo:hi] |= okq[:, j, i].long() << bit
-    missing = need & ~mask
-    assert int((missing != 0).sum()) == 0, f"{int((missing != 0).sum())} records miss a quadrant they reach"
-    def pop(x):
-        return sum(int(((x >> b) & 1).sum()) for b in range(16))
-    print(f"mask tightness (bin {bt}): {pop(mask)} bits set for {pop(need)} needed, of {m * q * q} possible")
-    assert pop(mask) <= 1.6 * pop(need) + 0.02 * m * q * q or s_max > 0.5
+        ok &= ((X0 + xs[None]) < W) & ((Y0 + ys[None]) < H)             # (pixels of a border bin beyond the image do not exist)
+        need[lo:hi] = ok.view(-1, q, 8, q, 8).any(4).any(2)             # [m', qy, qx]
+    c0, c1, r0_, r1 = box & 3, (box >> 2) & 3, (box >> 4) & 3, (box >> 6) & 3
+    qi = torch.arange(q, device="cuda")
+    cover = ((qi[None, None, :] >= c0[:, None, None]) & (qi[None, None, :] <= c1[:, None, None]) &
+             (qi[None, :, None] >= r0_[:, None, None]) & (qi[None, :, None] <= r1[:, None, None]))   # [m, qy, qx]
+    assert int(max(int(c1.max()), int(r1.max()))) <= q - 1
+    missing = need & ~cover
+    assert int(missing.sum()) == 0, f"{int(missing.any(-1).any(-1).sum())} records miss a quadrant they reach"
+    print(f"box tightness (bin {bt}): {int(cover.sum())} quadrants covered for {int(need.sum())} needed, of {m * q * q} possible")
+    assert int(cover.sum()) <= 1.9 * int(need.sum()) + 0.03 * m * q * q or s_max > 0.5
 
 
 @pytest.mark.parametrize("W,H,N,cull_mode,channels", [(640, 360, 20_000, 0, 3), (250, 130, 3000, 1, 4),
@@ -1138,7 +1134,7 @@ def test_one_pass_placement_equals_the_two_pass_tile_sort(gsa, N, W, H, bt):
     """gsa_tile_bin16 without second-pass buffers (per-bin histogram rows, column scan, every id stored at its final
     place) == the two-pass tile sort + boundary search: sorted_gid and tile_offsets bit for bit, at the bench's bin grid
     (2040 bins; 170 and ~1100 record blocks: one and several rows per column-scan segment, beyond the rows a thread keeps
-    in registers), on 16 x 16 tiles, and on frames that are no multiple of the bin (704 and 608 bins); with ids on request (what gsa_quadrant_masks reads) and with a remembered
+    in registers), on 16 x 16 tiles, and on frames that are no multiple of the bin (704 and 608 bins); with a remembered
     capacity above the count."""
     from gsplat_amd import scene, stages as S
     sc = scene.make_scene(N, seed=5, sh_degree=0)
@@ -1155,20 +1151,18 @@ def test_one_pass_placement_equals_the_two_pass_tile_sort(gsa, N, W, H, bt):
         try:
             # (depth_msd=False: the LSD ordering -- 1.25 M gaussians overflow the bucketed one's LDS, which is another test's subject)
             res[direct] = [S.bin_tiles(splat, radii, tiles, keys, W, H, 0, exact=e, fused=True, tile_rects=rects, bin_tile=bt,
-                                       quad_masks=q, depth_msd=False)
-                           for e, q in ((True, False), (False, False), (False, bt == 32))]
+                                       depth_msd=False)
+                           for e in (True, False)]
         finally:
             S._BIN_DIRECT = real
     m = res[False][0].finalize()[0]
     assert m > (4_300_000 if N > 1_000_000 else 30_000)
-    assert res[True][0]._tile is None and (res[True][2]._tile is not None) == (bt == 32)   # ids only on request (the mask PASS reads them)
+    assert res[True][0]._tile is None and res[True][1]._tile is None   # (the one-pass placement stores no tile ids)
     for a, b in zip(res[False], res[True]):
         assert b.finalize() == (m, True) == a.finalize()
         assert torch.equal(b.tile_offsets, a.tile_offsets) and int(b.tile_offsets[-1]) == m
         assert torch.equal(b.sorted_gid, a.sorted_gid)
         assert torch.equal(S.tile_ids(b.sorted_tile), S.tile_ids(a.sorted_tile))
-    if bt == 32:
-        assert torch.equal(res[True][2].sorted_mask[:m], res[False][2].sorted_mask[:m])
     # a view without a single record, queued for the remembered capacity: every list is empty
     none = rects.clone()
     none[:, 1] = 0
