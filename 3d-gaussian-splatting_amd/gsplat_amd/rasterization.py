@@ -8,7 +8,6 @@ One ``torch.autograd.Function`` per camera chains the C-ABI stages (``stages.py`
 
 from __future__ import annotations
 
-import contextlib
 import math
 from typing import Dict, Optional, Tuple
 
@@ -28,7 +27,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, colors, viewmat, Kmat, background,
                 width: int, height: int, sh_degree: int, channels: int, cull_mode: int, grad_out, grad_accumulate,
-                sh_grad_factored, front_stream=None, deferred=None):
+                sh_grad_factored, deferred=None):
         means_c, quats_c, scales_c = S.f32c(means, "means"), S.f32c(quats, "quats"), S.f32c(scales, "scales")
         opac_c, colors_c = S.f32c(opacities, "opacities"), S.f32c(colors, "colors")
         view_c, K_c = S.f32c(viewmat, "viewmats"), S.f32c(Kmat, "Ks")
@@ -40,32 +39,17 @@ class _RasterizeOneCamera(torch.autograd.Function):
         # the records are binned into 32 x 32 BINS where the fused binning applies (S.bin_tile_for): the four 16 x 16
         # tiles of a bin walk the bin's list -- a compositor wave re-tests every record against its 8 x 8 quadrant anyway
         bt = S.bin_tile_for(width, height, cull_mode)
-        # The FRONT END (projection, depth ordering, binning: HBM- and latency-bound) may be queued on a stream of its own,
-        # where it runs beside the sweeps of the view in front (vector-issue-bound) instead of behind them; the sweeps stay
-        # on the current stream and wait for it.  Its buffers are allocated under that stream and handed over by
-        # record_stream.
-        main = torch.cuda.current_stream() if front_stream is not None else None
-        with (torch.cuda.stream(front_stream) if front_stream is not None else contextlib.nullcontext()):
-            kr = S.key_range_buffer(means_c.shape[0], means_c.device)   # this view's depth-key range, for the depth ordering's bucket plan
-            qb = S.qbox_buffer(means_c.shape[0], means_c.device)        # the gaussians' quadrant boxes, for the forward sweep's masks
-            proj = S.project_fwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
-                                 cull_mode, return_rects=True, return_aux=want_lists, bin_tile=bt, key_range=kr, qbox=qb)
-            splat, radii, tiles_touched, depth_keys, rects = proj[:5]
-            sh_aux = proj[5] if want_lists else None
-            # the host does not wait for the record count: bins are sized for a remembered capacity, the compositor is
-            # queued, and only then is the count (long since copied back) checked -- a miss repeats with exact sizes
-            bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, tile_rects=rects,
-                               bin_tile=bt, key_range=kr, qbox=qb)
-            tile_order = S.tile_schedule(bins.tile_offsets, width, height, bt)   # longest record lists first (speed only)
-            if front_stream is not None:
-                handed = torch.cuda.Event()
-                handed.record(front_stream)
-        if front_stream is not None:
-            main.wait_event(handed)
-            for t in (splat, radii, tiles_touched, depth_keys, rects, sh_aux, bins.sorted_gid_buffer, bins.tile_offsets,
-                      bins._tile, tile_order):
-                if t is not None:
-                    t.record_stream(main)
+        kr = S.key_range_buffer(means_c.shape[0], means_c.device)   # this view's depth-key range, for the depth ordering's bucket plan
+        qb = S.qbox_buffer(means_c.shape[0], means_c.device)        # the gaussians' quadrant boxes, for the forward sweep's candidate test
+        proj = S.project_fwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
+                             cull_mode, return_rects=True, return_aux=want_lists, bin_tile=bt, key_range=kr, qbox=qb)
+        splat, radii, tiles_touched, depth_keys, rects = proj[:5]
+        sh_aux = proj[5] if want_lists else None
+        # the host does not wait for the record count: bins are sized for a remembered capacity, the compositor is
+        # queued, and only then is the count (long since copied back) checked -- a miss repeats with exact sizes
+        bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, tile_rects=rects,
+                           bin_tile=bt, key_range=kr, qbox=qb)
+        tile_order = S.tile_schedule(bins.tile_offsets, width, height, bt)   # longest record lists first (speed only)
         out = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg_c, width, height, channels,
                               tile_order, want_lists=want_lists, bin_tile=bt, gid_boxes=bins.boxed)
         if deferred is not None:
@@ -122,10 +106,10 @@ class _RasterizeOneCamera(torch.autograd.Function):
                               splat, radii, v_splat, out=ctx.grad_out, accumulate=ctx.grad_accumulate,
                               v_rgb_out=ctx.sh_grad_factored, sh_aux=sh_aux)
         if ctx.grad_accumulate:   # the sums live in the caller's buffers; autograd gets nothing to accumulate
-            return (None,) * 18
+            return (None,) * 17
         need = ctx.needs_input_grad
         grads = tuple(g.view(shp) if (nd and g is not None) else None for g, shp, nd in zip(grads, ctx.in_shapes, need[:5]))
-        return grads + (None,) * 13
+        return grads + (None,) * 12
 
 
 def rasterization(
@@ -151,7 +135,6 @@ def rasterization(
     grad_out=None,
     grad_accumulate: bool = False,
     sh_grad_factored: Optional[torch.Tensor] = None,
-    front_stream: Optional[torch.cuda.Stream] = None,
     defer_check: bool = False,
     **unsupported,
 ) -> Tuple[torch.Tensor, torch.Tensor, Dict]:
@@ -169,12 +152,6 @@ def rasterization(
     gaussian instead of the [N,K,3] SH-coefficient gradient (``colors`` then gets no gradient; ``grad_out[4]`` is not
     written).  The coefficient gradient is the outer product of the view's SH basis with it
     (``stages.sh_grad_expand``): the form in which view-parallel ranks exchange it -- 3 floats instead of 48.
-    ``front_stream`` (extension): a HIP stream for the view's FRONT END -- projection, depth ordering, binning; HBM- and
-    latency-bound -- while the sweeps (and the backward pass) stay on the current stream and wait for it.  Queued on a
-    stream of its own it runs beside the sweeps of the view in front, which are vector-issue-bound, instead of behind
-    them.  The caller orders that stream after whatever last wrote the inputs (``front_stream.wait_event(...)`` after an
-    optimizer step; nothing for further views of the same parameters) -- the call itself only makes the current
-    stream wait for the front end.
     ``defer_check`` (extension): the bins are sized for a remembered record capacity and the depth ordering assumes a
     remembered key range; by default the call waits (host side) for the view's control words once its sweep is queued and
     repeats the binning if either was too small, so what it returns is always right.  With ``defer_check=True`` it does
@@ -235,7 +212,7 @@ def rasterization(
                 bg = torch.cat([bg, bg.new_zeros(1)])
         out = _RasterizeOneCamera.apply(means, quats, scales, opacities, colors, viewmats[c], Ks[c], bg,
                                         width, height, deg, channels, cull, grad_out, grad_accumulate, sh_grad_factored,
-                                        front_stream, pending)
+                                        pending)
         render, alpha = out[0], out[1]
         if render_mode in ("ED", "RGB+ED"):
             render = torch.cat([render[..., :3], render[..., 3:] / alpha.clamp(min=1e-10)], dim=-1)

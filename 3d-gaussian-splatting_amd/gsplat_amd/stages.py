@@ -217,12 +217,10 @@ def _wait_slot_impl(slot) -> None:
             return
 
 
-# GSPLAT_AMD_SH_AUX=0: project_fwd leaves no digest of the coefficient rows and project_bwd reads the 192-B rows again
-# (for A/B timing).  With the digest (48 B per gaussian written by the forward, read by the backward instead of the row)
-# a 1 M-gaussian / 1080p view measured fwd 0.089 + bwd 0.072 ms against 0.073 + 0.101 ms without.  (Without it the
-# forward looks faster than it is: back to back, it finds half of the rows the previous view's backward streamed
-# still in the 256-MB memory-side cache.)
-_SH_AUX = os.environ.get("GSPLAT_AMD_SH_AUX", "1") != "0"
+# project_fwd leaves a 48-B digest of every SH coefficient row for project_bwd, which then never reads the 192-B rows: a
+# 1 M-gaussian / 1080p view measured fwd 0.089 + bwd 0.072 ms against 0.073 + 0.101 ms without.  (Module attribute, not an
+# environment switch: tests and tools/ set it for A/B.)
+_SH_AUX = True
 
 
 def project_fwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat, Kmat, width: int, height: int,
@@ -356,20 +354,20 @@ def tile_ids(sorted_tile: torch.Tensor) -> torch.Tensor:
     return t & 0xFFFF if sorted_tile.dtype == torch.int16 else t
 
 
-_BIN_FUSED_DEFAULT = os.environ.get("GSPLAT_AMD_BIN_FUSED", "1") != "0"
-# GSPLAT_AMD_BIN_DIRECT=0: the two-pass tile sort where gsa_tile_bin16_direct offers the one-pass placement (A/B timing)
-_BIN_DIRECT = os.environ.get("GSPLAT_AMD_BIN_DIRECT", "1") != "0"
+_BIN_FUSED_DEFAULT = True   # records generated inside the binning passes (False: emit + 32-bit sort; A/B from tests / tools)
+# False: the two-pass tile sort where gsa_tile_bin16_direct offers the one-pass placement (A/B from tests / tools)
+_BIN_DIRECT = True
 # Per-record quadrant BOXES for the forward compositor, which then gathers only the records whose bounding box covers its
 # quadrant (of the records of a 32 x 32 bin 22 % reach a given 8 x 8 quadrant; of those the box lets through, 78 %).  The
 # boxes come out of the one-pass placement (gsa_tile_bin16_boxes) from the gaussians' quadrant bounding boxes
 # (``project_fwd(qbox=...)`` -> ``bin_tiles(qbox=...)``), packed into the top byte of the record's gaussian id: ~15 integer
 # instructions per record and no store of their own.  GSPLAT_AMD_QUAD_BOXES=0: plain ids (A/B).
-_QUAD_MASKS = os.environ.get("GSPLAT_AMD_QUAD_BOXES", "1") != "0"
+_QUAD_BOXES = os.environ.get("GSPLAT_AMD_QUAD_BOXES", "1") != "0"
 
 
 def qbox_buffer(n: int, dev) -> torch.Tensor:
     """int32 [n] for ``project_fwd(qbox=...)`` / ``bin_tiles(qbox=...)`` -- None when the boxes are switched off."""
-    return torch.empty(n, dtype=torch.int32, device=dev) if _QUAD_MASKS else None
+    return torch.empty(n, dtype=torch.int32, device=dev) if _QUAD_BOXES else None
 
 
 # (device, W, H, cull_mode) -> [records per gaussian the next call provisions for, consecutive low counts].
@@ -389,7 +387,7 @@ SPECULATION_SETTLE_VIEWS = _SHRINK_AFTER + 8
 # launched for this range and the view's actual range is checked afterwards, like the record capacity.
 _KEY_RANGE = {}
 _MSD_MAX_WIDTH = int(lib.gsa_depth_order_msd_max_width())
-_DEPTH_MSD_DEFAULT = os.environ.get("GSPLAT_AMD_DEPTH_MSD", "1") != "0"
+_DEPTH_MSD_DEFAULT = True   # bucketed depth ordering (False: LSD passes; A/B from tests / tools)
 # How the bucketed depth ordering gets its buckets.  "host": 255 EQUAL buckets over the union of the key ranges of the views of
 # this scene shape seen so far (planned here; 4 launches) -- the fastest when it fits, but one wide view empties the buckets
 # of all the others and unevenly distributed depths (the diagonal cameras of the bench ring: 3.5 x the mean in one bucket)
@@ -535,7 +533,7 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
     can_fuse = cull_mode == 0 and bool(lib.gsa_tile_bins_supported(width, height, bin_tile))
     if fused and not can_fuse:
         raise ValueError("bin_tiles(fused=True): needs cull_mode 0 and a tile grid gsa_tile_bin16_supported accepts")
-    if fused is None:   # (GSPLAT_AMD_BIN_FUSED=0: the emit + 32-bit sort path, kept for A/B timing)
+    if fused is None:   # (_BIN_FUSED_DEFAULT = False: the emit + 32-bit sort path, kept for A/B timing)
         fused = can_fuse and (_BIN_FUSED_DEFAULT or bin_tile != TILE_SIZE)
     if bin_tile != TILE_SIZE and not (fused and tile_rects is not None):
         raise ValueError("bin_tiles(bin_tile=32): needs the fused path and the tile_rects of project_fwd(bin_tile=32)")
@@ -676,9 +674,9 @@ def tile_schedule(tile_offsets: torch.Tensor, width: int, height: int, bin_tile:
     return order
 
 
-# GSPLAT_AMD_BWD_REORDER=0: the backward sweep keeps the forward's launch order (by list length) instead of ordering the
-# tiles once more by the records their quadrants blended -- one launch less, a less even sweep (A/B)
-_BWD_REORDER = os.environ.get("GSPLAT_AMD_BWD_REORDER", "1") != "0"
+# False: the backward sweep keeps the forward's launch order (by list length) instead of ordering the tiles once more by
+# the records their quadrants blended -- one launch less, a less even sweep: the same step time (A/B from tools)
+_BWD_REORDER = True
 
 
 class QuadLists(tuple):

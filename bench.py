@@ -631,7 +631,7 @@ def main() -> None:
         # tools/make_traffic_json.py): HBM bytes of every kernel, VALU utilisation, float-atomic requests, and the
         # bound the counters point at.  NOT measured in this run: `counters_from` names the file and the sources' revision.
         traffic, counters, counters_from, measured_bytes = None, {}, None, None
-        for fname in ("r03_traffic.json", "r02_traffic.json"):
+        for fname in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fname)) as fh:
                     doc = json.load(fh)
