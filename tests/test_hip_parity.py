@@ -20,6 +20,7 @@ Integer outputs (radii, tile counts, sorted ids, offsets) are compared exactly, 
 whose ceil() lands on the other side of an fp32 rounding."""
 import json
 import math
+import contextlib
 import os
 
 import numpy as np
@@ -139,31 +140,6 @@ def _compare(sc, vm, K, W, H, deg, bg, seed=2, use_v_alpha=True, checkpoint=Fals
     print("parity report:", report)
     assert not bad, f"HIP error vs fp64 oracle exceeds its bound (1e-4; `relaxed` tensors max(1e-4, 2 x fp32-oracle error)): {bad}; all: {report}"
     return m1, m32, report
-
-
-def _bwd_modes():
-    """Backward list sweeps this build of the library has: the product library only the two-phase one (2)."""
-    import ctypes
-    from gsplat_amd._lib import LIB_PATH
-    return (2,)
-
-
-class _bwd_mode:
-    def __init__(self, mode):
-        self.mode = mode
-
-    def _set(self, mode):
-        import ctypes
-        from gsplat_amd._lib import LIB_PATH
-        h = ctypes.CDLL(LIB_PATH)
-        if hasattr(h, "gsa_debug_set_bwd_mode"):
-            h.gsa_debug_set_bwd_mode(int(mode))
-
-    def __enter__(self):
-        self._set(self.mode)
-
-    def __exit__(self, *exc):
-        self._set(2)
 
 
 @pytest.fixture(scope="module")
@@ -534,7 +510,8 @@ def test_deferred_check_reports_a_miss_and_the_next_call_is_right(gsa):
     """``defer_check=True``: the call does not wait for the view's control words (the host queues views far ahead of the
     device); ``meta['speculation_ok']`` says afterwards whether the remembered capacity / key range held.  In steady state
     it is True and image, gradients and meta entries equal the checked call's; after a simulated threefold growth it is
-    False, and rendering the view again gives the checked call's result.  Also with the front end on a stream of its own."""
+    False, and rendering the view again gives the checked call's result.  Also with the whole call on a stream of its own
+    (how ViewPipeline runs the views of a step)."""
     from gsplat_amd import scene, stages as S
     W, H, N = 320, 200, 20_000
     sc = _scene(N, seed=3, s_min=0.005, s_max=0.08)
@@ -553,8 +530,11 @@ def test_deferred_check_reports_a_miss_and_the_next_call_is_right(gsa):
     run()                                                                   # first call of the shape: exact sizes
     r0, a0, m0, g0 = run()
     key = ("cuda", torch.cuda.current_device(), W, H, S.DEFAULT_CULL_MODE, S.bin_tile_for(W, H, S.DEFAULT_CULL_MODE))
-    for kw in ({"defer_check": True}, {"defer_check": True, "front_stream": side}, {"front_stream": side}):
-        r1, a1, m1, g1 = run(**kw)
+    for kw, st in (({"defer_check": True}, None), ({"defer_check": True}, side), ({}, side)):
+        if st is not None:
+            st.wait_stream(torch.cuda.current_stream())
+        with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+            r1, a1, m1, g1 = run(**kw)
         assert m1["speculation_ok"] is True
         assert torch.equal(r1, r0) and torch.equal(a1, a0)
         assert all(_rel(x.reshape(-1).cpu(), y.reshape(-1).cpu()) < 1e-5 for x, y in zip(g1, g0)), kw   # (float atomics: not bit-equal run to run)
@@ -627,9 +607,9 @@ def test_two_cameras_in_one_call_equal_two_calls(gsa):
 
     run([0, 1])                                        # (first call of the shape: exact sizes)
     r2, a2, m2, g2 = run([0, 1])
-    # the same call without waiting for either camera's control words, front ends on a side stream: same results, and the
-    # meta entries that depend on the record counts wait for them on access
-    rd, ad, md, gd = run([0, 1], defer_check=True, front_stream=torch.cuda.Stream())
+    # the same call without waiting for either camera's control words: same results, and the meta entries that depend on
+    # the record counts wait for them on access
+    rd, ad, md, gd = run([0, 1], defer_check=True)
     assert md["speculation_ok"] is True and torch.equal(rd, r2) and torch.equal(ad, a2)
     assert md["n_isects"] == m2["n_isects"] and torch.equal(md["flatten_ids"], m2["flatten_ids"])
     assert torch.equal(md["isect_ids"], m2["isect_ids"]) and torch.equal(md["isect_offsets"], m2["isect_offsets"])
@@ -1071,14 +1051,9 @@ def test_backward_sweep_over_blended_record_lists(gsa, W, H, N, cull_mode, chann
                 assert seen.size and int(lst[-1]) <= int(seen.max())
     g0 = S.composite_bwd(splat, sorted_gid, tile_offsets, bg, T0, l0, v_r, v_a, W, H, channels)
     scale = g0.abs().amax(0).clamp_min(1e-30)
-    # the sweep over the lists: the two-phase kernel (the only one in the product library); a developer build
-    # (-DGSA_DEV_KERNELS) also has 1 = record-parallel with prefix scans over the records and 0 = pixel-parallel with the
-    # transpose-reduce, selected through gsa_debug_set_bwd_mode
-    for mode in _bwd_modes():
-        with _bwd_mode(mode):
-            g1 = S.composite_bwd(splat, sorted_gid, tile_offsets, bg, T0, l0, v_r, v_a, W, H, channels,
-                                 quad_lists=(qlist, qcount))
-        assert float(((g0 - g1).abs().amax(0) / scale).max()) < 2e-5, mode
+    # the sweep over the lists (the two-phase kernel) against the sweep over the tiles' whole slices
+    g1 = S.composite_bwd(splat, sorted_gid, tile_offsets, bg, T0, l0, v_r, v_a, W, H, channels, quad_lists=(qlist, qcount))
+    assert float(((g0 - g1).abs().amax(0) / scale).max()) < 2e-5
 
 
 @pytest.mark.parametrize("W,H,N,s_max,giants", [(640, 360, 30_000, 0.05, 0), (160, 96, 4000, 0.3, 0),
