@@ -37,7 +37,7 @@ def first(pattern):
 
 
 out_dir, tag = sys.argv[1], sys.argv[2]
-OURS = "composite|project|radix|scan_|emit_|tile_|depth_bucket|bwd_prepare"
+OURS = "composite|project|radix|scan_|emit_|tile_|depth_bucket|depth_table|bin_col|bwd_prepare"
 fetch = per_kernel(first(f"{out_dir}/fetch/*/*counter_collection.csv"), OURS)
 write = per_kernel(first(f"{out_dir}/write/*/*counter_collection.csv"), OURS)
 insts = per_kernel(first(f"{out_dir}/insts/*/*counter_collection.csv"), "composite") if first(f"{out_dir}/insts/*/*counter_collection.csv") else {}
