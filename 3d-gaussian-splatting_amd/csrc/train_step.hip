@@ -193,11 +193,30 @@ __global__ __launch_bounds__(3 * GSA_WAVE) void loss_strip_kernel(int width, int
 // One Adam step over a flat bucket.  seg_end[k] = one past the last element of segment k (ascending), lr[k] its
 // learning rate.  Mirrors torch.optim.Adam's single-tensor arithmetic:
 //   m += (g - m)(1 - b1);  v = b2 v + (1 - b2) g g;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+// A segment may be STRIPED: its elements repeat with `period`, and the first `head` of every period take lr_head instead
+// of lr (the [N,16,3] SH table kept as ONE segment: the 3 floats of coefficient 0 are the reference's "f_dc" group, the
+// other 45 its "f_rest" group at a twentieth of the rate, trainer.py:333-334).  period 0: a plain segment.
 struct AdamSegments {
     long end[8];
-    float lr[8];
+    float lr[8], lr_head[8];
+    int period[8], head[8];
     int count;
 };
+
+__device__ __forceinline__ float adam_lr(const AdamSegments &seg, long i) {
+    float lr = 0.f;
+    long begin = 0;
+    int k_hit = 0;
+#pragma unroll
+    for (int k = 7; k >= 0; --k)
+        if (k < seg.count && i < seg.end[k]) { lr = seg.lr[k]; k_hit = k; }
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+        if (k < k_hit) begin = seg.end[k];
+    const int period = seg.period[k_hit];
+    if (period > 0 && (int)((unsigned long)(i - begin) % (unsigned)period) < seg.head[k_hit]) lr = seg.lr_head[k_hit];
+    return lr;
+}
 
 __global__ __launch_bounds__(kThreads) void adam_kernel(long n, float *__restrict__ param, const float *__restrict__ grad,
                                                         float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq,
@@ -216,10 +235,7 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(long n, float *__restric
         const float *gg = &g4.x;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float lr = 0.f;
-#pragma unroll
-            for (int k = 7; k >= 0; --k)
-                if (k < seg.count && i0 + j < seg.end[k]) lr = seg.lr[k];
+            const float lr = adam_lr(seg, i0 + j);
             const float g = gg[j];
             const float m = mm[j] + (g - mm[j]) * w1;
             const float v = vv[j] * beta2 + w2 * g * g;
@@ -232,9 +248,7 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(long n, float *__restric
         *reinterpret_cast<float4 *>(exp_avg_sq + i0) = v4;
     } else {
         for (long i = i0; i < n; ++i) {
-            float lr = 0.f;
-            for (int k = seg.count - 1; k >= 0; --k)
-                if (i < seg.end[k]) lr = seg.lr[k];
+            const float lr = adam_lr(seg, i);
             const float g = grad[i];
             const float m = exp_avg[i] + (g - exp_avg[i]) * w1;
             const float v = exp_avg_sq[i] * beta2 + w2 * g * g;
@@ -304,7 +318,7 @@ __global__ __launch_bounds__(kThreads) void activate_fwd_kernel(long n, const fl
                                                                 float *__restrict__ scales, float *__restrict__ quats,
                                                                 float *__restrict__ opac, float *__restrict__ shs) {
     const long q = (long)blockIdx.x * kThreads + threadIdx.x;
-    if (q < 12 * n) {
+    if (shs && q < 12 * n) {   // (no table to build when the model keeps its coefficients as [N,16,3] rows already)
         const long g = q / 12;
         const int j0 = (int)(q - g * 12) * 4;
         float v[4];
@@ -438,20 +452,28 @@ extern "C" int gsa_view_loss(int width, int height, const float *render, const f
     return GSA_OK;
 }
 
-extern "C" int gsa_adam_step(long long n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
-                             int n_segments, const long long *segment_end, const float *segment_lr, double beta1,
-                             double beta2, double eps, int step, const uint32_t *skip_if_nonzero, gsa_stream_t stream) {
+extern "C" int gsa_adam_step_striped(long long n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                                     int n_segments, const long long *segment_end, const float *segment_lr,
+                                     const int *segment_period, const int *segment_head, const float *segment_head_lr,
+                                     double beta1, double beta2, double eps, int step, const uint32_t *skip_if_nonzero,
+                                     gsa_stream_t stream) {
     GSA_RETURN_IF(n < 0 || n_segments < 1 || n_segments > 8 || step < 1, GSA_ERR_INVALID_ARGUMENT);
     if (n == 0) return GSA_OK;
     GSA_RETURN_IF(!param || !grad || !exp_avg || !exp_avg_sq || !segment_end || !segment_lr, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(segment_period && (!segment_head || !segment_head_lr), GSA_ERR_INVALID_ARGUMENT);
     AdamSegments seg;
     seg.count = n_segments;
     long long prev = 0;
     for (int k = 0; k < 8; ++k) {
         seg.end[k] = k < n_segments ? (long)segment_end[k] : (long)n;
         seg.lr[k] = k < n_segments ? segment_lr[k] : 0.f;
+        seg.period[k] = (k < n_segments && segment_period) ? segment_period[k] : 0;
+        seg.head[k] = seg.period[k] > 0 ? segment_head[k] : 0;
+        seg.lr_head[k] = seg.period[k] > 0 ? segment_head_lr[k] : 0.f;
         if (k < n_segments) {
-            GSA_RETURN_IF(segment_end[k] < prev, GSA_ERR_INVALID_ARGUMENT);
+            GSA_RETURN_IF(segment_end[k] < prev || seg.period[k] < 0 || seg.head[k] < 0 || seg.head[k] > seg.period[k],
+                          GSA_ERR_INVALID_ARGUMENT);
+            GSA_RETURN_IF(seg.period[k] > 0 && (segment_end[k] - prev) % seg.period[k] != 0, GSA_ERR_INVALID_ARGUMENT);
             prev = segment_end[k];
         }
     }
@@ -466,6 +488,13 @@ extern "C" int gsa_adam_step(long long n, float *param, const float *grad, float
                                                                         skip_if_nonzero);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
+}
+
+extern "C" int gsa_adam_step(long long n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                             int n_segments, const long long *segment_end, const float *segment_lr, double beta1,
+                             double beta2, double eps, int step, const uint32_t *skip_if_nonzero, gsa_stream_t stream) {
+    return gsa_adam_step_striped(n, param, grad, exp_avg, exp_avg_sq, n_segments, segment_end, segment_lr, nullptr, nullptr,
+                                 nullptr, beta1, beta2, eps, step, skip_if_nonzero, stream);
 }
 
 // Loss-scale bookkeeping of a mixed-precision step (torch's GradScaler.unscale_, trainer.py:505-511): grad *= inv_scale
@@ -499,6 +528,63 @@ extern "C" int gsa_grad_unscale(long long n, float *grad, float inv_scale, uint3
     return GSA_OK;
 }
 
+// The step's metrics in ONE launch (the trainer's bookkeeping around the loss, src/training/trainer.py:485-519, otherwise
+// ~25 five-microsecond torch kernels between the Adam step and the next step's first kernel): per local view
+// l1 / ssim / mse = sums / count, psnr = mse < 1e-10 ? 100 : -10 log10(mse) (:70-75), loss = (1 - lambda) l1 + lambda
+// (1 - ssim); the regulariser = reg_factor * sum(reg_partials).  report = { sum l1, sum ssim, sum psnr,
+// sum loss / n_views_total + reg (if add_reg), reg (if add_reg) } -- what the ranks then sum.
+struct ReportViews {
+    double inv_count[16];
+    int count;
+};
+
+__global__ __launch_bounds__(kThreads) void step_report_kernel(ReportViews views, const double *__restrict__ view_sums,
+                                                               double lambda, double inv_views_total,
+                                                               const double *__restrict__ reg_partials, long n_partials,
+                                                               double reg_factor, int add_reg, double *__restrict__ report) {
+    __shared__ double red[kThreads / GSA_WAVE];
+    double acc = 0;
+    for (long b = threadIdx.x; b < n_partials; b += kThreads) acc += reg_partials[b];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double reg = 0;
+        for (int w = 0; w < kThreads / GSA_WAVE; ++w) reg += red[w];
+        reg *= reg_factor;
+        double l1 = 0, ssim = 0, psnr = 0, loss = 0;
+        for (int j = 0; j < views.count; ++j) {
+            const double a = view_sums[3 * j] * views.inv_count[j], b = view_sums[3 * j + 1] * views.inv_count[j],
+                         mse = view_sums[3 * j + 2] * views.inv_count[j];
+            l1 += a; ssim += b;
+            psnr += mse < 1e-10 ? 100.0 : -10.0 * log10(fmax(mse, 1e-300));
+            loss += (1.0 - lambda) * a + lambda * (1.0 - b);
+        }
+        report[0] = l1; report[1] = ssim; report[2] = psnr;
+        report[3] = loss * inv_views_total + (add_reg ? reg : 0.0);
+        report[4] = add_reg ? reg : 0.0;
+    }
+}
+
+extern "C" int gsa_step_report(int n_local_views, const double *view_sums, const double *view_inv_count, double lambda_dssim,
+                               int n_views_total, const double *reg_partials, long long n_partials, double reg_factor,
+                               int add_reg, double *report, gsa_stream_t stream) {
+    GSA_RETURN_IF(n_local_views < 0 || n_local_views > 16 || n_views_total < 1 || n_partials < 0 || !report,
+                  GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF((n_local_views > 0 && (!view_sums || !view_inv_count)) || (n_partials > 0 && !reg_partials),
+                  GSA_ERR_INVALID_ARGUMENT);
+    ReportViews views;
+    views.count = n_local_views;
+    for (int j = 0; j < 16; ++j) views.inv_count[j] = j < n_local_views ? view_inv_count[j] : 0.0;   // (a HOST array)
+    step_report_kernel<<<1, kThreads, 0, static_cast<hipStream_t>(stream)>>>(views, view_sums, lambda_dssim,
+                                                                             1.0 / (double)n_views_total, reg_partials,
+                                                                             (long)n_partials, reg_factor, add_reg ? 1 : 0,
+                                                                             report);
+    GSA_LAUNCH_CHECK();
+    return GSA_OK;
+}
+
 extern "C" size_t gsa_activate_partials(long long n) {   // doubles gsa_activate_bwd's reg_partials must hold
     return n <= 0 ? 0 : 3 * (size_t)gsa_div_up(n, kThreads);
 }
@@ -508,12 +594,11 @@ extern "C" int gsa_activate_fwd(long long n, const float *scaling, const float *
                                 float *opacities, float *shs, gsa_stream_t stream) {
     GSA_RETURN_IF(n < 0, GSA_ERR_INVALID_ARGUMENT);
     if (n == 0) return GSA_OK;
-    GSA_RETURN_IF(!scaling || !rotation || !opacity || !features_dc || !features_rest || !scales || !quats ||
-                      !opacities || !shs,
-                  GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(!scaling || !rotation || !opacity || !scales || !quats || !opacities, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(shs && (!features_dc || !features_rest), GSA_ERR_INVALID_ARGUMENT);   // shs NULL: geometry only
     GSA_RETURN_IF(((reinterpret_cast<uintptr_t>(quats) | reinterpret_cast<uintptr_t>(shs)) & 15) != 0,
                   GSA_ERR_INVALID_ARGUMENT);
-    activate_fwd_kernel<<<gsa_div_up(12 * n, kThreads), kThreads, 0, static_cast<hipStream_t>(stream)>>>(
+    activate_fwd_kernel<<<gsa_div_up(shs ? 12 * n : n, kThreads), kThreads, 0, static_cast<hipStream_t>(stream)>>>(
         (long)n, scaling, rotation, opacity, features_dc, features_rest, scales, quats, opacities, shs);
     GSA_LAUNCH_CHECK();
     return GSA_OK;

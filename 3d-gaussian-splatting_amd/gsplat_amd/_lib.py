@@ -13,7 +13,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_u
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # GSPLAT_AMD_LIB: developer override to A/B another build of the SAME C ABI (still a HIP library; no fallback)
 LIB_PATH = os.environ.get("GSPLAT_AMD_LIB") or os.path.join(_PKG_ROOT, "lib", "libgsplat_amd.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 SPLAT_STRIDE = 16
 
 P = c_void_p  # every device pointer and the stream cross the boundary as void*
@@ -55,7 +55,9 @@ SIGNATURES = {
     "gsa_view_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
     "gsa_view_loss": (c_int, [c_int, c_int, P, P, c_float, c_float, P, c_size_t, P, P, P]),
     "gsa_adam_step": (c_int, [c_longlong, P, P, P, P, c_int, P, P, c_double, c_double, c_double, c_int, P, P]),
+    "gsa_adam_step_striped": (c_int, [c_longlong, P, P, P, P, c_int, P, P, P, P, P, c_double, c_double, c_double, c_int, P, P]),
     "gsa_grad_unscale": (c_int, [c_longlong, P, c_float, P, P]),
+    "gsa_step_report": (c_int, [c_int, P, P, c_double, c_int, P, c_longlong, c_double, c_int, P, P]),
     "gsa_project_bwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, P, P, P, P, P, P, P, P, P, P]),
     "gsa_project_bwd_factored": (c_int, [c_int, P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, P, P, P, P, P, P, P, P, c_int, P, P]),
     "gsa_sh_grad_expand_split": (c_int, [c_int, P, c_int, c_int, c_int, P, P, P, P, P, P]),

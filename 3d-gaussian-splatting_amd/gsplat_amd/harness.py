@@ -31,6 +31,39 @@ import torch.nn.functional as F
 FIELDS = (("xyz", (3,)), ("features_dc", (1, 3)), ("features_rest", (15, 3)), ("opacity", (1,)),
           ("scaling", (3,)), ("rotation", (4,)))
 FLOATS_PER_GAUSSIAN = sum(math.prod(s) for _, s in FIELDS)  # 59
+# How the flat buckets (parameters, gradients, Adam moments) are laid out: segment-major, and the SH coefficients as ONE
+# segment of [N,16,3] rows -- exactly what the rasterizer reads and its backward writes, so a step neither assembles
+# cat(features_dc, features_rest) (192 B per gaussian read + written) nor splits the gradient again.  ``features_dc`` /
+# ``features_rest`` are the strided views [:, :1] / [:, 1:] of those rows.  The rows come first: their 16-byte alignment
+# (the kernels move them as float4) then never depends on N.
+STORAGE = (("sh", 48), ("xyz", 3), ("opacity", 1), ("scaling", 3), ("rotation", 4))
+_ADAM_GROUP_FIELD = {"xyz": "xyz", "f_dc": "features_dc", "f_rest": "features_rest", "opacity": "opacity",
+                     "scaling": "scaling", "rotation": "rotation"}
+
+
+def bucket_views(flat: torch.Tensor, n: int) -> Dict[str, torch.Tensor]:
+    """The named views of a flat 59 n bucket: the six fields of the reference model + ``sh`` (the [n,16,3] rows)."""
+    out, off = {}, 0
+    for seg, width in STORAGE:
+        part = flat[off:off + n * width]
+        if seg == "sh":
+            rows = part.view(n, 16, 3)
+            out["sh"], out["features_dc"], out["features_rest"] = rows, rows[:, :1], rows[:, 1:]
+        else:
+            out[seg] = part.view(n, width)
+        off += n * width
+    return out
+
+
+def pack_bucket(get, n: int) -> torch.Tensor:
+    """A flat bucket in STORAGE order from per-field tensors (``get(name)``)."""
+    parts = []
+    for seg, width in STORAGE:
+        if seg == "sh":
+            parts.append(torch.cat([get("features_dc").reshape(n, 1, 3), get("features_rest").reshape(n, 15, 3)], dim=1).reshape(-1))
+        else:
+            parts.append(get(seg).reshape(-1))
+    return torch.cat(parts)
 
 
 @dataclass
@@ -89,14 +122,14 @@ class SplatModel:
         self.n = n
         self.flat = flat
         self.flat_grad = torch.zeros_like(flat)
-        off = 0
+        views, grads = bucket_views(self.flat, n), bucket_views(self.flat_grad, n)
         for name, shape in FIELDS:
-            cnt = n * math.prod(shape)
-            p = self.flat[off:off + cnt].view(n, *shape)
+            p = views[name]
+            assert tuple(p.shape) == (n, *shape)
             p.requires_grad_(True)
-            p.grad = self.flat_grad[off:off + cnt].view(n, *shape)
+            p.grad = grads[name]
             setattr(self, name, p)
-            off += cnt
+        self.sh, self.sh_grad = views["sh"], grads["sh"]   # the coefficient rows as the rasterizer takes them (no copy)
         dev = flat.device
         self.xyz_gradient_accum = torch.zeros(n, 3, device=dev)
         self.xyz_gradient_count = torch.zeros(n, 1, device=dev)
@@ -173,12 +206,14 @@ class SplatModel:
         if isinstance(optimizer, FusedBucketAdam):
             old_m, old_v = optimizer.exp_avg, optimizer.exp_avg_sq
         elif optimizer is not None:                                      # torch.optim.Adam: gather its per-parameter state
-            old_m = torch.cat([optimizer.state[p]["exp_avg"].reshape(-1) if p in optimizer.state else
-                               torch.zeros_like(p).reshape(-1) for p in self.parameters()])
-            old_v = torch.cat([optimizer.state[p]["exp_avg_sq"].reshape(-1) if p in optimizer.state else
-                               torch.zeros_like(p).reshape(-1) for p in self.parameters()])
-        widths = [math.prod(shape) for _, shape in FIELDS]
-        names = [name for name, _ in FIELDS]
+            def moment(key):
+                def get(name):
+                    p = getattr(self, name)
+                    return optimizer.state[p][key] if p in optimizer.state and key in optimizer.state[p] else torch.zeros_like(p)
+                return pack_bucket(get, n)
+            old_m, old_v = moment("exp_avg"), moment("exp_avg_sq")
+        widths = [width for _, width in STORAGE]
+        names = [name for name, _ in STORAGE]
         new_p, new_m, new_v = S.densify_gather(n, widths, names.index("xyz"), names.index("scaling"), float(log_split),
                                                src_f, kind_f, noise_f, self.flat.detach(), old_m, old_v)
         old_params = self.parameters()
@@ -188,17 +223,15 @@ class SplatModel:
         if isinstance(optimizer, FusedBucketAdam):
             optimizer.rebind(self, new_m, new_v)
         elif optimizer is not None:
-            off = 0
-            for group, old, new in zip(optimizer.param_groups, old_params, self.parameters()):
+            m_views, v_views = bucket_views(new_m, self.n), bucket_views(new_v, self.n)
+            for group, old, (name, _) in zip(optimizer.param_groups, old_params, FIELDS):
+                new = getattr(self, name)
                 state = optimizer.state.pop(old, None)
                 group["params"] = [new]
                 if state is not None:
-                    cnt = new.numel()
                     state = dict(state)
-                    state["exp_avg"] = new_m[off:off + cnt].view(new.shape)
-                    state["exp_avg_sq"] = new_v[off:off + cnt].view(new.shape)
+                    state["exp_avg"], state["exp_avg_sq"] = m_views[name], v_views[name]
                     optimizer.state[new] = state
-                off += new.numel()
         stats["n_after"] = self.n
         return stats
 
@@ -210,15 +243,13 @@ class SplatModel:
         exchange and the densify gather work on ``flat`` / ``flat_grad``.  Rebinding ``p.data`` -- what the reference's
         opacity reset does (trainer.py:850) -- detaches a parameter silently; use ``reset_opacity`` /
         ``clamp_scaling`` (in place) instead."""
-        off, item = 0, self.flat.element_size()
-        for name, shape in FIELDS:
-            p = getattr(self, name)
-            cnt = self.n * math.prod(shape)
-            if p.data_ptr() != self.flat.data_ptr() + off * item or p.numel() != cnt:
+        views, grads = bucket_views(self.flat, self.n), bucket_views(self.flat_grad, self.n)
+        for name, _ in FIELDS:
+            p, want = getattr(self, name), views[name]
+            if p.data_ptr() != want.data_ptr() or p.shape != want.shape or p.stride() != want.stride():
                 raise RuntimeError(f"SplatModel.{name} no longer lives in the flat parameter bucket (was .data rebound?)")
-            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + off * item:
+            if p.grad is None or p.grad.data_ptr() != grads[name].data_ptr() or p.grad.stride() != grads[name].stride():
                 raise RuntimeError(f"SplatModel.{name}.grad no longer lives in the flat gradient bucket")
-            off += cnt
 
     @torch.no_grad()
     def reset_opacity(self, ceiling: float = 0.01) -> None:
@@ -326,41 +357,38 @@ class FusedBucketAdam:
     def __init__(self, model: SplatModel, groups, betas=(0.9, 0.999), eps: float = 1e-15):
         self.model, self.betas, self.eps = model, betas, eps
         self.param_groups = groups
-        self.exp_avg = torch.zeros_like(model.flat)
-        self.exp_avg_sq = torch.zeros_like(model.flat)
         self.step_count = 0
-        self.segment_end, self.state, off = [], {}, 0
-        for g in groups:  # groups are in the order of FIELDS == the order of the flat layout
-            p = g["params"][0]
-            cnt = p.numel()
-            self.state[p] = {"exp_avg": self.exp_avg[off:off + cnt].view(p.shape),
-                             "exp_avg_sq": self.exp_avg_sq[off:off + cnt].view(p.shape)}
-            off += cnt
-            self.segment_end.append(off)
-        assert off == model.flat.numel()
+        self.rebind(model, torch.zeros_like(model.flat), torch.zeros_like(model.flat))
 
     def rebind(self, model: SplatModel, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor) -> None:
-        """After the model changed size (densify / prune): adopt the spliced moment buckets and the new parameters."""
+        """Adopt a model and its moment buckets (construction; after densify / prune: the spliced buckets)."""
+        assert exp_avg.numel() == exp_avg_sq.numel() == model.flat.numel()
         self.model, self.exp_avg, self.exp_avg_sq = model, exp_avg, exp_avg_sq
-        self.segment_end, self.state, off = [], {}, 0
-        for g, p in zip(self.param_groups, model.parameters()):
+        m_views, v_views = bucket_views(exp_avg, model.n), bucket_views(exp_avg_sq, model.n)
+        self.state = {}
+        for g in self.param_groups:   # the reference's six groups, by name (trainer.py:331-340)
+            field = _ADAM_GROUP_FIELD[g["name"]]
+            p = getattr(model, field)
             g["params"] = [p]
-            cnt = p.numel()
-            self.state[p] = {"exp_avg": exp_avg[off:off + cnt].view(p.shape),
-                             "exp_avg_sq": exp_avg_sq[off:off + cnt].view(p.shape)}
-            off += cnt
+            self.state[p] = {"exp_avg": m_views[field], "exp_avg_sq": v_views[field]}
+        self.segment_end, off = [], 0
+        for _, width in STORAGE:
+            off += model.n * width
             self.segment_end.append(off)
-        assert off == model.flat.numel()
 
     def step(self, skip_if_nonzero: Optional[torch.Tensor] = None) -> None:
         """``skip_if_nonzero`` (int32 [1] on the device): the update is skipped when it is set -- the caller then takes
         ``step_count`` back by one once it has read the flag (GradScaler.step does not call the optimizer at all)."""
         from . import stages as S
         self.step_count += 1
+        lr = {g["name"]: float(g["lr"]) for g in self.param_groups}
+        # one learning rate per segment; the coefficient rows are striped: 3 floats of f_dc, 45 of f_rest, per gaussian
+        lrs = [lr["f_rest"] if seg == "sh" else lr[seg] for seg, _ in STORAGE]
+        stripes = [(48, 3, lr["f_dc"]) if seg == "sh" else None for seg, _ in STORAGE]
         with torch.no_grad():
-            S.adam_step(self.model.flat, self.model.flat_grad, self.exp_avg, self.exp_avg_sq, self.segment_end,
-                        [g["lr"] for g in self.param_groups], self.step_count, self.betas[0], self.betas[1], self.eps,
-                        skip_if_nonzero=skip_if_nonzero)
+            S.adam_step(self.model.flat, self.model.flat_grad, self.exp_avg, self.exp_avg_sq, self.segment_end, lrs,
+                        self.step_count, self.betas[0], self.betas[1], self.eps, skip_if_nonzero=skip_if_nonzero,
+                        stripes=stripes)
 
 
 class ViewParallelTrainer:
@@ -551,23 +579,34 @@ class ViewParallelTrainer:
         K = self.backend.K.to(dev)[None]
         bg = torch.zeros(1, 3, device=dev)
         # activations (trainer.py:399-406), once, without a graph: one kernel
-        scales, quats, opac, shs = S.activate_fwd(m.scaling, m.rotation, m.opacity, m.features_dc, m.features_rest)
-        # gradient bucket of the ACTIVATED parameters; the xyz part IS the raw xyz gradient (identity activation)
+        # (geometry only: the coefficient rows of the model ARE what the rasterizer reads)
+        scales, quats, opac, _ = S.activate_fwd(m.scaling, m.rotation, m.opacity)
+        shs = m.sh.detach()
+        # gradient bucket of the ACTIVATED parameters; the xyz and coefficient parts ARE the raw gradients (identity)
         if getattr(self, "_act_grad", None) is None or self._act_grad[1].shape[0] != n:
-            self._act_grad = (None, torch.empty(n, 4, device=dev), torch.empty(n, 3, device=dev),
-                              torch.empty(n, device=dev), torch.empty(n, 16, 3, device=dev))
-        g_means = m.xyz.grad
-        _, g_quats, g_scales, g_opac, g_shs = self._act_grad
+            self._act_grad = (None, torch.empty(n, 4, device=dev), torch.empty(n, 3, device=dev), torch.empty(n, device=dev))
+        g_means, g_shs = m.xyz.grad, m.sh_grad
+        _, g_quats, g_scales, g_opac = self._act_grad
         grad_out = [g_means, g_quats, g_scales, g_opac, g_shs]
         leaves = [m.xyz.detach(), quats, scales, opac, shs]
         factored = self.factored
+        mine = list(batch[self.rank::self.world])
         if factored:  # slot (r, j) = the j-th view of rank r; ranks with fewer views leave zeros (skipped by the expand)
             slots = -(-n_views // self.world)
-            vr_all = torch.zeros(self.world, slots, n, 3, device=dev)
-            poses_all = torch.eye(4, device=dev).repeat(self.world, slots, 1, 1)
+            vr_all = torch.empty(self.world, slots, n, 3, device=dev)   # (every slot of a view is written whole by its backward)
+            if len(mine) < slots:
+                vr_all[self.rank, len(mine):].zero_()
+            eye = None
+            rows = []
             for r_ in range(self.world):
-                for j, view in enumerate(batch[r_::self.world]):
-                    poses_all[r_, j] = view["pose"]
+                theirs = batch[r_::self.world]
+                for j in range(slots):
+                    if j < len(theirs):
+                        rows.append(theirs[j]["pose"].to(dev, torch.float32))
+                    else:
+                        eye = torch.eye(4, device=dev) if eye is None else eye
+                        rows.append(eye)
+            poses_all = torch.stack(rows).view(self.world, slots, 4, 4)   # one kernel
         # The views of the batch are independent until their gradients meet in the bucket, and a view's front end
         # (projection + binning: HBM- and latency-bound) uses what its sweeps (compositor forward, loss, compositor backward:
         # VALU-bound) leave idle: whole views alternate on two streams, nobody waits for a view's control words until all
@@ -579,11 +618,13 @@ class ViewParallelTrainer:
             self._pipe = ViewPipeline(dev, 2 if self.overlap_views else 1)
         cull = S.DEFAULT_CULL_MODE
         Kc, bgc = K[0].contiguous(), bg[0].contiguous()
-        params_ready = torch.cuda.Event()
-        params_ready.record(main)
-        mine = list(batch[self.rank::self.world])
         scale = self.loss_scale if self.amp else 1.0   # loss scale: the backward passes see v_render times it
-        sums = [None] * len(mine)
+        # the views' loss sums (l1, ssim map, squared error), one row per local view: the step's metrics come out of ONE
+        # kernel behind the optimizer (gsa_step_report) instead of a few dozen tiny torch launches
+        view_sums = torch.zeros(max(len(mine), 1), 3, dtype=torch.float64, device=dev)
+        counts = [3 * view["width"] * view["height"] for view in mine]
+        params_ready = torch.cuda.Event()              # (behind everything the views read that this stream prepared)
+        params_ready.record(main)
 
         def front(view, exact):
             pose = view["pose"].to(torch.float32).contiguous()
@@ -612,11 +653,9 @@ class ViewParallelTrainer:
             render, _, final_T, last_id, lists = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bgc, W,
                                                                  H, 3, order, want_lists=True, bin_tile=bt,
                                                                  gid_boxes=bins.boxed)
-            s3, v = S.view_loss(render, view["image"], c.lambda_dssim, grad_scale=scale / n_views)
-            res = s3 / float(v.numel())            # -> l1, ssim, mse of this view
-            if torch.cuda.current_stream() != main:
-                res.record_stream(main)
-            sums[j] = res
+            if not deferred:
+                view_sums[j].zero_()               # (a step that is rendered again counts every view once)
+            _, v = S.view_loss(render, view["image"], c.lambda_dssim, grad_scale=scale / n_views, sums_out=view_sums[j])
             return ViewState((view, pose, splat, radii, bins, order, aux, final_T, last_id, lists, v),
                              (lambda: bins.finalize()[1]) if deferred else (lambda: True))
 
@@ -632,7 +671,6 @@ class ViewParallelTrainer:
                           v_rgb_out=vr_all[self.rank, j] if factored else None, sh_aux=aux)
 
         self._pipe.run(len(mine), forward, backward, inputs_ready=params_ready, defer=not exact)
-        sums = [x for x in sums if x is not None]
         first = not mine
         if first:                                          # this rank rendered nothing
             m.flat_grad.zero_()
@@ -640,48 +678,35 @@ class ViewParallelTrainer:
                 g.zero_()
         # chain rule of the activations + the scale regulariser (value everywhere, gradient on rank 0), one kernel,
         # written straight into the raw-parameter gradient views of flat_grad
-        reg = S.activate_bwd(m.scaling, m.rotation, m.opacity, g_scales, g_quats, g_opac, m.scaling.grad, m.rotation.grad,
-                             m.opacity.grad, c.scale_reg_max_ratio, c.scale_reg_weight * scale,
-                             add_reg_grad=self.rank == 0) / scale
+        reg_partials, reg_factor = S.activate_bwd(m.scaling, m.rotation, m.opacity, g_scales, g_quats, g_opac, m.scaling.grad,
+                                                  m.rotation.grad, m.opacity.grad, c.scale_reg_max_ratio,
+                                                  c.scale_reg_weight * scale, add_reg_grad=self.rank == 0,
+                                                  return_partials=True)
         if factored:
             # the SH-coefficient gradient of the whole batch, rebuilt from the 3 floats per gaussian and view the
-            # backward passes left (summed in batch order), straight into features_dc.grad / features_rest.grad.
-            # world > 1: those 3 N floats per view are all-gathered and only the 11 N geometry floats are summed (xyz |
-            # opacity, scaling, rotation are the two ends of the bucket); the rebuild runs beside the all-reduces.
-            summed = []
+            # backward passes left (summed in batch order), straight into the gradient bucket's coefficient rows.
+            # world > 1: those 3 N floats per view are all-gathered and only the 11 N geometry floats are summed (the
+            # bucket's tail); the rebuild runs beside the all-reduce.
+            summed = None
             if self.world > 1:
                 gathered = self._all_gather_slabs(vr_all)
-                summed = [self._all_reduce(m.flat_grad[:3 * n], async_op=True),
-                          self._all_reduce(m.flat_grad[51 * n:], async_op=True)]
+                summed = self._all_reduce(m.flat_grad[48 * n:], async_op=True)
                 gathered.wait()
-            S.sh_grad_expand(leaves[0].detach(), degree, poses_all.view(-1, 4, 4), K, vr_all.view(-1, n, 3),
-                             m.features_dc.grad, v_rest=m.features_rest.grad)
-            for work in summed:
-                work.wait()
+            S.sh_grad_expand(leaves[0].detach(), degree, poses_all.view(-1, 4, 4), K, vr_all.view(-1, n, 3), m.sh_grad)
+            if summed is not None:
+                summed.wait()
         else:
-            with torch.no_grad():
-                if first:
-                    g_shs.zero_()
-                m.features_dc.grad.copy_(g_shs[:, :1])
-                m.features_rest.grad.copy_(g_shs[:, 1:])
-            self._all_reduce(m.flat_grad)  # the one exchange step: 59*N floats, SUM
+            self._all_reduce(m.flat_grad)  # the one exchange step: 59*N floats, SUM (the views wrote the rows in place)
         found_inf = None
         if self.amp:   # GradScaler.unscale_ + the skip decision, on the exchanged bucket (identical on every rank)
             found_inf = torch.zeros(1, dtype=torch.int32, device=dev)
             S.grad_unscale(m.flat_grad, 1.0 / scale, found_inf)
         self.optimizer.step(skip_if_nonzero=found_inf)
 
-        report = torch.zeros(5, dtype=torch.float64, device=dev)  # l1, ssim, psnr sums over local views; loss share; reg
-        if sums:
-            per_view = torch.stack(sums)                           # [B_local, 3]
-            mse = per_view[:, 2]
-            psnr_v = torch.where(mse < 1e-10, torch.full_like(mse, 100.0), -10.0 * torch.log10(mse.clamp_min(1e-300)))
-            loss_v = (1.0 - c.lambda_dssim) * per_view[:, 0] + c.lambda_dssim * (1.0 - per_view[:, 1])
-            report[0], report[1], report[2] = per_view[:, 0].sum(), per_view[:, 1].sum(), psnr_v.sum()
-            report[3] = loss_v.sum() / n_views
-        if self.rank == 0:                                         # (the regulariser is the same on every rank)
-            report[3] += reg.detach().double()
-            report[4] = reg.detach().double()
+        # l1, ssim, psnr sums over the local views; their loss share + the regulariser (the same on every rank: counted on
+        # rank 0); the regulariser -- one kernel
+        report = S.step_report(view_sums if mine else None, counts, c.lambda_dssim, n_views, reg_partials, reg_factor / scale,
+                               self.rank == 0, dev)
         self._all_reduce(report)
         if found_inf is not None:
             report = torch.cat([report, found_inf.double()])

@@ -48,6 +48,7 @@ TIMER = StageTimer()
 def _call(name: str, fn, *args) -> None:
     """Launch one C-ABI stage on the current stream; raise on a non-zero return code."""
     guard, _GUARD.device = getattr(_GUARD, "device", None), None   # (of THIS call's tensors: consumed, never sticky)
+    held, _GUARD.held = getattr(_GUARD, "held", None), None        # (ditto: the tensors behind this call's pointers)
     if guard is not None and torch.cuda.current_device() != guard:
         raise RuntimeError(f"gsplat_amd: {name} was given tensors on cuda:{guard} while the current device is "
                            f"cuda:{torch.cuda.current_device()}; launches go to the current device's stream -- call "
@@ -60,6 +61,7 @@ def _call(name: str, fn, *args) -> None:
         end = torch.cuda.Event(enable_timing=True)
         end.record()
         TIMER.records.append((name, start, end))
+    del held   # only now: the launch is queued, the caching allocator hands the memory out again in stream order
 
 
 _GUARD = threading.local()   # .device: index of the device the tensors of the stage being launched live on (set by _ptr
@@ -73,6 +75,12 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
         return None
     if t.is_cuda:
         _GUARD.device = t.device.index
+        # The tensor may be a temporary (``_ptr(f32c(x, ...))`` of a strided or non-fp32 x makes a copy): it has to outlive
+        # the evaluation of the call's other arguments, or the next temporary is given the same block before the launch.
+        held = getattr(_GUARD, "held", None)
+        if held is None:
+            held = _GUARD.held = []
+        held.append(t)
     return t.data_ptr()
 
 
@@ -816,17 +824,23 @@ def project_bwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat
 
 # ---- training-step stages around the rasterizer ------------------------------------
 def view_loss(render: torch.Tensor, target: torch.Tensor, lambda_dssim: float, grad_scale: float = 1.0,
-              want_grad: bool = True):
+              want_grad: bool = True, sums_out: Optional[torch.Tensor] = None):
     """The reference's per-view loss (trainer.py:485-492) and its gradient in one pass over render and target.
     render / target: [H,W,3] fp32 on the device.  -> (sums [3] float64 on the device: sum |d|, sum SSIM map,
-    sum d^2 over the 3HW elements; v_render [H,W,3] = grad_scale * d loss / d render, or None)."""
+    sum d^2 over the 3HW elements; v_render [H,W,3] = grad_scale * d loss / d render, or None).
+    ``sums_out``: a ZEROED contiguous float64 [3] device tensor to accumulate into (a row of the step's table)."""
     if render.shape != target.shape or render.dim() != 3 or render.shape[2] != 3:
         raise ValueError("render and target must both be [H,W,3]")
     h, w = int(render.shape[0]), int(render.shape[1])
     r, t = f32c(render, "render"), f32c(target, "target")
     ws_bytes = lib.gsa_view_loss_workspace_bytes(w, h)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=r.device)
-    sums = torch.zeros(3, dtype=torch.float64, device=r.device)
+    if sums_out is not None:
+        if sums_out.shape != (3,) or sums_out.dtype != torch.float64 or not sums_out.is_contiguous() or sums_out.device != r.device:
+            raise ValueError("view_loss: `sums_out` must be a contiguous float64 [3] tensor on the render's device")
+        sums = sums_out
+    else:
+        sums = torch.zeros(3, dtype=torch.float64, device=r.device)
     v = torch.empty_like(r) if want_grad else None
     _call("gsa_view_loss", lib.gsa_view_loss, w, h, _ptr(r), _ptr(t), float(lambda_dssim), float(grad_scale), _ptr(ws),
           ws_bytes, _ptr(v), _ptr(sums), _stream())
@@ -843,9 +857,11 @@ def grad_unscale(grad: torch.Tensor, inv_scale: float, found_inf: torch.Tensor) 
 
 def adam_step(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
               segment_end, segment_lr, step: int, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-15,
-              skip_if_nonzero: Optional[torch.Tensor] = None) -> None:
+              skip_if_nonzero: Optional[torch.Tensor] = None, stripes=None) -> None:
     """One fused Adam update of a flat fp32 bucket in place (torch.optim.Adam arithmetic, per-segment lr).
-    ``skip_if_nonzero``: int32 [1] on the device; a non-zero value skips the whole update (GradScaler.step)."""
+    ``skip_if_nonzero``: int32 [1] on the device; a non-zero value skips the whole update (GradScaler.step).
+    ``stripes``: per segment ``None`` or ``(period, head, head_lr)`` -- the first ``head`` elements of every ``period``
+    take ``head_lr`` (the SH table as one [N,16,3] segment with the reference's two learning rates)."""
     import ctypes
     n = param.numel()
     for t in (param, grad, exp_avg, exp_avg_sq):
@@ -854,6 +870,18 @@ def adam_step(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, ex
     k = len(segment_end)
     ends = (ctypes.c_longlong * k)(*[int(e) for e in segment_end])
     lrs = (ctypes.c_float * k)(*[float(x) for x in segment_lr])
+    if stripes is not None and any(st is not None for st in stripes):
+        if len(stripes) != k:
+            raise ValueError("adam_step: one stripe entry per segment")
+        st = [x if x is not None else (0, 0, 0.0) for x in stripes]
+        period = (ctypes.c_int * k)(*[int(x[0]) for x in st])
+        head = (ctypes.c_int * k)(*[int(x[1]) for x in st])
+        head_lr = (ctypes.c_float * k)(*[float(x[2]) for x in st])
+        _call("gsa_adam_step_striped", lib.gsa_adam_step_striped, n, _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
+              k, ctypes.cast(ends, ctypes.c_void_p), ctypes.cast(lrs, ctypes.c_void_p), ctypes.cast(period, ctypes.c_void_p),
+              ctypes.cast(head, ctypes.c_void_p), ctypes.cast(head_lr, ctypes.c_void_p), beta1, beta2, eps, int(step),
+              _ptr(skip_if_nonzero), _stream())
+        return
     _call("gsa_adam_step", lib.gsa_adam_step, n, _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), k,
           ctypes.cast(ends, ctypes.c_void_p), ctypes.cast(lrs, ctypes.c_void_p), beta1, beta2, eps, int(step),
           _ptr(skip_if_nonzero), _stream())
@@ -906,26 +934,49 @@ def sh_grad_expand(means, sh_degree: int, viewmats, Kmat, v_rgb_all, v_colors, a
           1 if accumulate else 0, _stream())
 
 
-def activate_fwd(scaling, rotation, opacity, features_dc, features_rest):
+def activate_fwd(scaling, rotation, opacity, features_dc=None, features_rest=None):
     """Raw parameters of the reference model -> (scales [N,3], quats [N,4], opacities [N], shs [N,16,3]) in one pass
-    (gaussian_model.py:86-108)."""
+    (gaussian_model.py:86-108).  Without the two feature tensors only the geometry is activated and ``shs`` is None
+    (a model that keeps its coefficients as [N,16,3] rows hands those to the rasterizer as they are)."""
     n, dev = scaling.shape[0], scaling.device
-    if features_dc.shape[1:] != (1, 3) or features_rest.shape[1:] != (15, 3):
+    with_sh = features_dc is not None
+    if with_sh and (features_rest is None or features_dc.shape[1:] != (1, 3) or features_rest.shape[1:] != (15, 3)):
         raise ValueError("activate_fwd: features_dc [N,1,3] and features_rest [N,15,3] expected")
     scales = torch.empty(n, 3, device=dev)
     quats = torch.empty(n, 4, device=dev)
     opac = torch.empty(n, device=dev)
-    shs = torch.empty(n, 16, 3, device=dev)
+    shs = torch.empty(n, 16, 3, device=dev) if with_sh else None
     _call("gsa_activate_fwd", lib.gsa_activate_fwd, n, _ptr(f32c(scaling, "scaling")), _ptr(f32c(rotation, "rotation")),
-          _ptr(f32c(opacity, "opacity")), _ptr(f32c(features_dc, "features_dc")), _ptr(f32c(features_rest, "features_rest")),
+          _ptr(f32c(opacity, "opacity")), _ptr(f32c(features_dc, "features_dc")) if with_sh else None,
+          _ptr(f32c(features_rest, "features_rest")) if with_sh else None,
           _ptr(scales), _ptr(quats), _ptr(opac), _ptr(shs), _stream())
     return scales, quats, opac, shs
 
 
+def step_report(view_sums: Optional[torch.Tensor], view_counts, lambda_dssim: float, n_views_total: int,
+                reg_partials: Optional[torch.Tensor], reg_factor: float, add_reg: bool, device) -> torch.Tensor:
+    """The step's metrics in one launch (``gsa_step_report``): -> float64 [5] on the device = sum l1, sum ssim, sum psnr
+    over the LOCAL views, their loss share (+ the regulariser with ``add_reg``), the regulariser.  ``view_sums``: the
+    [B_local,3] table the views' ``view_loss(sums_out=row)`` calls filled; ``view_counts``: 3 H W of every local view."""
+    import ctypes
+    b = len(view_counts)
+    if b > 16:
+        raise ValueError("step_report: at most 16 local views")
+    if b and (view_sums is None or view_sums.shape != (b, 3) or view_sums.dtype != torch.float64 or not view_sums.is_contiguous()):
+        raise ValueError("step_report: `view_sums` must be a contiguous float64 [B_local,3] device tensor")
+    report = torch.empty(5, dtype=torch.float64, device=device)
+    inv = (ctypes.c_double * max(b, 1))(*[1.0 / float(c) for c in view_counts])
+    _call("gsa_step_report", lib.gsa_step_report, b, _ptr(view_sums) if b else None, ctypes.cast(inv, ctypes.c_void_p),
+          float(lambda_dssim), int(n_views_total), _ptr(reg_partials), 0 if reg_partials is None else reg_partials.numel(),
+          float(reg_factor), 1 if add_reg else 0, _ptr(report), _stream())
+    return report
+
+
 def activate_bwd(scaling, rotation, opacity, v_scales, v_quats, v_opac, out_scaling, out_rotation, out_opacity,
-                 reg_max_ratio: float, reg_weight: float, add_reg_grad: bool) -> torch.Tensor:
+                 reg_max_ratio: float, reg_weight: float, add_reg_grad: bool, return_partials: bool = False):
     """Chain rule of ``activate_fwd`` into the raw-parameter gradient buffers (overwritten) + the scale-ratio
-    regulariser (trainer.py:434-445): its gradient is added when ``add_reg_grad``; returns its value (0-d, fp64)."""
+    regulariser (trainer.py:434-445): its gradient is added when ``add_reg_grad``; returns its value (0-d, fp64) -- or,
+    with ``return_partials``, (partial sums on the device, the factor their sum is multiplied by) for ``step_report``."""
     n = scaling.shape[0]
     for t, name in ((out_scaling, "out_scaling"), (out_rotation, "out_rotation"), (out_opacity, "out_opacity")):
         if not (t.is_contiguous() and t.dtype == torch.float32):
@@ -935,4 +986,6 @@ def activate_bwd(scaling, rotation, opacity, v_scales, v_quats, v_opac, out_scal
           _ptr(f32c(opacity, "opacity")), _ptr(f32c(v_scales, "v_scales")), _ptr(f32c(v_quats, "v_quats")),
           _ptr(f32c(v_opac, "v_opacities")), float(reg_max_ratio), float(reg_weight), 1 if add_reg_grad else 0,
           _ptr(out_scaling), _ptr(out_rotation), _ptr(out_opacity), _ptr(partials), _stream())
+    if return_partials:
+        return partials, float(reg_weight) / max(n, 1)
     return partials.sum() * (float(reg_weight) / max(n, 1))

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSA_ABI_VERSION 10
+#define GSA_ABI_VERSION 11
 #define GSA_SPLAT_STRIDE 16
 
 #define GSA_OK 0
@@ -388,6 +388,16 @@ int gsa_view_loss(int width, int height, const float *render, const float *targe
 int gsa_adam_step(long long n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                   int n_segments, const long long *segment_end, const float *segment_lr, double beta1,
                   double beta2, double eps, int step, const uint32_t *skip_if_nonzero, gsa_stream_t stream);
+/* The same step with STRIPED segments: segment k's elements repeat with segment_period[k] (0: a plain segment; else its
+ * length must be a multiple), and the first segment_head[k] elements of every period take segment_head_lr[k] instead of
+ * segment_lr[k].  What a model that keeps the SH table as ONE [N,16,3] segment needs: the 3 floats of coefficient 0 are
+ * the reference's "f_dc" optimizer group, the other 45 its "f_rest" group (src/training/trainer.py:333-334).  The three
+ * arrays may all be NULL (= gsa_adam_step). */
+int gsa_adam_step_striped(long long n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                          int n_segments, const long long *segment_end, const float *segment_lr,
+                          const int *segment_period, const int *segment_head, const float *segment_head_lr,
+                          double beta1, double beta2, double eps, int step, const uint32_t *skip_if_nonzero,
+                          gsa_stream_t stream);
 /* Mixed-precision bookkeeping (the reference trains with GradScaler, src/training/trainer.py:31,505-511: the upstream
  * gradient of the rasterizer arrives multiplied by the loss scale): grad *= inv_scale in place, and *found_inf
  * (uint32 on the device, ACCUMULATED: zero it first) becomes 1 if any element is not finite -- torch's
@@ -395,10 +405,21 @@ int gsa_adam_step(long long n, float *param, const float *grad, float *exp_avg, 
  * GradScaler.step does. */
 int gsa_grad_unscale(long long n, float *grad, float inv_scale, uint32_t *found_inf, gsa_stream_t stream);
 
+/* The metrics of a step in one launch (the bookkeeping of src/training/trainer.py:485-519 and :70-75): view_sums
+ * [n_local_views,3] (device, the sums gsa_view_loss leaves per view), view_inv_count[n_local_views] (HOST array: 1 / (3 H W)
+ * of every view; at most 16 views), reg_partials[n_partials] (device: gsa_activate_bwd's partial sums; the regulariser is
+ * reg_factor times their sum).  report[5] (device, double, overwritten) = { sum l1, sum ssim, sum psnr,
+ * sum((1 - lambda) l1 + lambda (1 - ssim)) / n_views_total + reg, reg } with psnr = mse < 1e-10 ? 100 : -10 log10(mse);
+ * the two reg terms only with add_reg (rank 0: the ranks sum their reports). */
+int gsa_step_report(int n_local_views, const double *view_sums, const double *view_inv_count, double lambda_dssim,
+                    int n_views_total, const double *reg_partials, long long n_partials, double reg_factor, int add_reg,
+                    double *report, gsa_stream_t stream);
+
 /* Activations of the reference model's raw parameters (src/gaussians/gaussian_model.py:86-108 as the trainer calls them,
  * trainer.py:399-406) in one pass: scales = exp(scaling) [N,3], quats = rotation / max(|rotation|, 1e-12) [N,4],
  * opacities = sigmoid(opacity) [N], shs = cat(features_dc [N,1,3], features_rest [N,15,3]) [N,16,3].
- * quats and shs must be 16-byte aligned. */
+ * quats and shs must be 16-byte aligned.  shs may be NULL (features_dc / features_rest then too): geometry only, for a
+ * model whose coefficients already are [N,16,3] rows. */
 int gsa_activate_fwd(long long n, const float *scaling, const float *rotation, const float *opacity,
                      const float *features_dc, const float *features_rest, float *scales, float *quats,
                      float *opacities, float *shs, gsa_stream_t stream);

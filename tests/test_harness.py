@@ -73,7 +73,12 @@ def test_flat_bucket_layout():
     assert FLOATS_PER_GAUSSIAN == 59 and m.flat.numel() == 59 * 7
     m.features_rest.grad.fill_(2.0)
     assert float(m.flat_grad.sum()) == 2.0 * 7 * 45
-    assert m.xyz.data_ptr() == m.flat.data_ptr()
+    # the SH coefficients are ONE segment of [N,16,3] rows at the front of the bucket (what the rasterizer reads and its
+    # backward writes: no cat / split per step); features_dc / features_rest are strided views of those rows
+    assert m.sh.data_ptr() == m.flat.data_ptr() == m.features_dc.data_ptr() and m.sh.shape == (7, 16, 3)
+    assert m.features_rest.data_ptr() == m.flat.data_ptr() + 12 and m.features_rest.stride() == (48, 3, 1)
+    assert m.xyz.data_ptr() == m.flat.data_ptr() + 4 * 48 * 7 and float(m.sh_grad[:, 1:].sum()) == 2.0 * 7 * 45
+    m.check_bound()
     assert set(m.activated()) == {"means3D", "scales", "rotations", "opacities", "shs"}
     assert m.activated()["shs"].shape == (7, 16, 3) and m.activated()["opacities"].shape == (7, 1)
 
@@ -148,8 +153,10 @@ def test_view_parallel_two_ranks_equal_one_rank(gold, tmp_path):
     out = str(tmp_path / "rank0.npz")
     mp.spawn(_rank_main, args=(2, _free_port(), out), nprocs=2, join=True)
     got = np.load(out)
-    ref_flat = np.concatenate([gold[f"step2_param_{k}"].reshape(-1) for k in LEAVES])
-    ref_grad = np.concatenate([gold[f"step2_grad_{k}"].reshape(-1) for k in LEAVES])
+    from gsplat_amd.harness import pack_bucket      # (the bucket's own order: coefficient rows first)
+    n = gold["step2_param_xyz"].shape[0]
+    ref_flat = pack_bucket(lambda k: torch.from_numpy(gold[f"step2_param_{k}"]), n).numpy()
+    ref_grad = pack_bucket(lambda k: torch.from_numpy(gold[f"step2_grad_{k}"]), n).numpy()
     assert _rel(got["flat"], ref_flat) < 1e-6
     assert _rel(got["grad"], ref_grad) < 2e-5
     ref_m = np.stack([gold["step1_metrics"], gold["step2_metrics"]])
@@ -213,6 +220,11 @@ def test_activation_kernels_match_torch_autograd(n):
     assert torch.allclose(quats, F.normalize(model.rotation.detach(), dim=-1), rtol=0, atol=2e-7)
     assert torch.allclose(opac, torch.sigmoid(model.opacity.detach())[:, 0], rtol=0, atol=2e-7)
     assert torch.equal(shs, torch.cat([model.features_dc, model.features_rest], dim=1).detach())
+    assert torch.equal(shs, model.sh)                  # (the model's own rows: what the fused step hands to the rasterizer)
+    # (both feature tensors are STRIDED views here, so the binding makes two contiguous temporaries for one launch: they
+    # must both outlive the evaluation of the argument list -- r04 found the second taking the first's block)
+    s2, q2, o2, none = S.activate_fwd(model.scaling, model.rotation, model.opacity)       # geometry only
+    assert none is None and torch.equal(s2, scales) and torch.equal(q2, quats) and torch.equal(o2, opac)
     gs, gq, go = (torch.randn(n, k, generator=g).cuda() for k in (3, 4, 1))
     max_ratio, weight = 10.0, 0.1
     for with_reg in (True, False):
@@ -329,7 +341,7 @@ def test_densify_and_prune_matches_reference_model(case, opt_kind):
     the reference's GaussianModel.densify_and_prune with its optimizer-state splicing (gaussian_model.py:9-50,110-366)
     on the same inputs and the same split noise: statistics, all six parameter tensors, all twelve Adam moments.
     'capped' exercises the max_gaussians top-k path."""
-    from gsplat_amd.harness import FIELDS, FusedBucketAdam, SplatModel, _adam_groups, StepConfig
+    from gsplat_amd.harness import FIELDS, FusedBucketAdam, SplatModel, _adam_groups, StepConfig, pack_bucket
     g = {k: v for k, v in np.load(DENSIFY_GOLDEN).items()}
     names = [n for n, _ in FIELDS]
     n = g[f"{case}_in_xyz"].shape[0]
@@ -339,8 +351,8 @@ def test_densify_and_prune_matches_reference_model(case, opt_kind):
     groups = _adam_groups(model, StepConfig())
     if opt_kind == "fused":
         opt = FusedBucketAdam(model, groups)
-        opt.exp_avg.copy_(torch.cat([_t(g[f"{case}_in_m_{k}"], "cuda").reshape(-1) for k in names]))
-        opt.exp_avg_sq.copy_(torch.cat([_t(g[f"{case}_in_v_{k}"], "cuda").reshape(-1) for k in names]))
+        opt.exp_avg.copy_(pack_bucket(lambda k: _t(g[f"{case}_in_m_{k}"], "cuda"), n))
+        opt.exp_avg_sq.copy_(pack_bucket(lambda k: _t(g[f"{case}_in_v_{k}"], "cuda"), n))
     else:
         opt = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
         for k in names:
