@@ -72,7 +72,8 @@ HIP-event average bench.py reports in `roofline.avg_launch_ms` (un-profiled; the
 The same kernels in the whole bench (the command at the top: mostly {pj['config']['views_per_gpu_per_step']}-view steps on two streams).  Here a
 kernel's duration INCLUDES the time it waits beside another stream's sweep -- the LDS-hungry binning kernels
 (`radix_scatter`, `depth_bucket_sort`, `emit_binhist`, `emit_place`, `bin_colscan`) sit out a sweep that leaves a CU no
-LDS, `project_fwd` runs beside one at half speed (`profiles/r03_host_pipeline.md`) -- so the averages are longer than
+LDS, `project_fwd` runs beside one at half speed (`profiles/r03_host_pipeline.md`); the training-step leg's kernels
+(`loss_strip`, `adam`, `sh_grad_expand`, `activate_*`, `step_report`) are in this table too -- so the averages are longer than
 above although the views are shorter:
 
 {table}
@@ -82,7 +83,8 @@ buckets) + `depth_bucket_sort_kernel` (local sorts fused with the scan and the b
 control words in the caller's pinned slot -- no copy kernel), then `emit_binhist` + `bin_colscan` + `emit_place` (records
 generated from the depth-ordered rectangles -- of the 32 x 32 bins: {pj['config'].get('binned_records')} records where the 16 x 16 rule has
 {pj['config']['intersections_M']} -- counted per bin and block, the counts scanned into the lists' offsets, every id stored
-at its final place: `profiles/r03_binning_direct.md`) + `tile_schedule`: 8 launches, 13 per forward + backward view.
+at its final place, since r04 with the record's QUADRANT BOX inside its bin in the id's top byte:
+`profiles/r03_binning_direct.md`, `profiles/r04_sweep_ablation.md`) + `tile_schedule`: 8 launches, 13 per forward + backward view.
 The `scan_*` kernels, `tile_offsets_kernel` and the second / third `radix_*<unsigned int>` calls belong to the first call
 of the scene shape (LSD path, which learns the key range); `__amd_rocclr_copyBuffer` is the scene upload and that first
 call's read-back.
