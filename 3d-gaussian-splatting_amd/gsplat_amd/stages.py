@@ -412,6 +412,14 @@ _MSD_BACKOFF = {}         # scene shape -> calls left before the bucketed orderi
 _HOST_PLAN_BACKOFF = {}   # scene shape -> calls left before a HOST-planned (equal-bucket) ordering is tried again after a miss
 _MSD_STREAK = {}          # scene shape -> overflows of the device-planned ordering in a row (escalates the back-off)
 
+def reset_speculation() -> None:
+    """Forget what the scene shapes seen so far taught (record capacities, depth-key ranges, bucket plans, back-offs): the
+    next call of every shape is a first call (exact sizes, one blocking read-back).  For a process that moves on to another
+    scene of the same image size -- e.g. ``bench.py`` between its wide-depth pass and the training-step leg."""
+    for d in (_CAPACITY, _KEY_RANGE, _MSD_BACKOFF, _TABLE_MODE, _MSD_STREAK, _HOST_PLAN_BACKOFF):
+        d.clear()
+
+
 def _key_bits_needed(lo: int, hi: int) -> int:
     """Whole 8-bit passes that order keys in [lo, hi] completely: the bits in which the two ends differ."""
     if lo > hi:           # no visible gaussian

@@ -597,6 +597,7 @@ def main() -> None:
     # backward, SH rebuild, Adam -- on the same scene and views; NOT part of `value`
     train = None
     if world == 1 and args.workload in ("C3", "T") and not args.no_train_step:
+        stages.reset_speculation()   # (the wide-depth cameras above left the image size on device depth tables and their capacity)
         train = train_step_leg(sc, n, width, height, deg, B, dev, max(5, min(args.steps, 20)))
     copy_peak = measured_copy_peak(dev) if rank == 0 else 0.0   # after the timed regions
 
