@@ -470,8 +470,10 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 7 : GSA_FWD_WAVES)) void composit
     int start, end, slice;   // this tile's record list (its bin's), and which of the bin's quadrant slices is this wave's
     tile_list(tile_offsets, tile, tile_w, bin_shift, q, start, end, slice);
     // this wave's quadrant column / row inside its bin (the bin's quadrant slices are (sub-tile << 2) | quadrant)
-    const uint32_t my_col = (uint32_t)((((slice >> 2) & ((1 << bin_shift) - 1)) << 1) | (q & 1));
-    const uint32_t my_row = (uint32_t)((((slice >> 2) >> bin_shift) << 1) | (q >> 1));
+    // (in the units of the records' boxes: quadrants, or pairs of quadrants in a 64 x 64 bin)
+    const int box_shift = bin_shift > 1 ? 1 : 0;
+    const uint32_t my_col = (uint32_t)((((slice >> 2) & ((1 << bin_shift) - 1)) << 1) | (q & 1)) >> box_shift;
+    const uint32_t my_row = (uint32_t)((((slice >> 2) >> bin_shift) << 1) | (q >> 1)) >> box_shift;
 
     FwdPixel<CH> px;
     px.T = 1.f; px.Tend = 1.f; px.dead = inside ? 0u : kSign; px.last = -1;
@@ -1233,7 +1235,7 @@ extern "C" int gsa_composite_fwd(int width, int height, int channels, const floa
     GSA_RETURN_IF(width <= 0 || height <= 0 || (channels != 3 && channels != 4), GSA_ERR_INVALID_ARGUMENT);
     const int bin_shift = bin_shift_of(bin_tile);
     GSA_RETURN_IF(bin_shift < 0, GSA_ERR_INVALID_ARGUMENT);
-    GSA_RETURN_IF((gid_boxes != 0 && gid_boxes != 1) || (gid_boxes && bin_shift > 1), GSA_ERR_INVALID_ARGUMENT);   // (a 64 x 64 bin has 8 x 8 quadrants)
+    GSA_RETURN_IF(gid_boxes != 0 && gid_boxes != 1, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(!tile_offsets || !render || !alpha || !final_T || !last_id, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF((quad_list == nullptr) != (quad_count == nullptr), GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(n_zero_rows < 0 || (reinterpret_cast<uintptr_t>(v_splat_zero) & 15) != 0, GSA_ERR_INVALID_ARGUMENT);

@@ -1317,14 +1317,17 @@ __device__ __forceinline__ uint32_t wave_rank_round_bins(unsigned long long *mas
 // consecutive slots here), and NOT ONE STORE more: what r04 measured on the way -- exact 16-bit ellipse masks in an array
 // of their own -- cost this kernel 0.021 ms for the second scattered store stream alone (3.6 M two-byte stores), whatever
 // the masks cost to compute, and a pass over the PLACED records (round 3) 0.070 ms.
+// Q = quadrants per bin side.  The four fields have 2 bits: a 64 x 64 bin (Q = 8) gets its box in units of TWO quadrants
+// (16 pixels) -- coarser, still a pre-test the forward sweep applies before it gathers anything.
 template <int Q>
 __device__ __forceinline__ uint32_t qbox_in_bin(uint32_t qb, int bx, int by) {
-    if (qb == 0xFFFFFFFFu) return (uint32_t)(((Q - 1) << 2) | ((Q - 1) << 6));   // unbounded: the whole bin
+    constexpr int SH = Q > 4 ? 1 : 0, U = (Q >> SH) - 1;   // units per side - 1
+    if (qb == 0xFFFFFFFFu) return (uint32_t)((U << 2) | (U << 6));   // unbounded: the whole bin
     const int x0 = (int)(qb & 1023u) - Q * bx, y0 = (int)((qb >> 10) & 1023u) - Q * by;
     const int x1 = x0 + (int)((qb >> 20) & 63u), y1 = y0 + (int)(qb >> 26);
     const bool none = x1 < 0 || x0 > Q - 1 || y1 < 0 || y0 > Q - 1;
-    const uint32_t box = (uint32_t)max(x0, 0) | ((uint32_t)min(x1, Q - 1) << 2) | ((uint32_t)max(y0, 0) << 4) |
-                         ((uint32_t)min(y1, Q - 1) << 6);
+    const uint32_t box = (uint32_t)(max(x0, 0) >> SH) | ((uint32_t)(min(x1, Q - 1) >> SH) << 2) |
+                         ((uint32_t)(max(y0, 0) >> SH) << 4) | ((uint32_t)(min(y1, Q - 1) >> SH) << 6);
     return none ? 3u : box;   // (3: columns 3 .. 0 -- empty)
 }
 
@@ -2046,7 +2049,7 @@ extern "C" int gsa_tile_bin16_direct(int width, int height, int bin_tile) {
 // the one-pass placement, bins of at most 4 x 4 quadrants (16 x 16 tiles or 32 x 32 bins), ids below 2^24
 extern "C" int gsa_tile_bin16_boxes(int width, int height, int bin_tile, int n) {
     if (bin_tile == 0) bin_tile = GSA_TILE_SIZE;
-    return gsa_tile_bin16_direct(width, height, bin_tile) && bin_tile <= 2 * GSA_TILE_SIZE && n >= 0 && n <= (1 << 24) ? 1 : 0;
+    return gsa_tile_bin16_direct(width, height, bin_tile) && bin_tile <= 4 * GSA_TILE_SIZE && n >= 0 && n <= (1 << 24) ? 1 : 0;
 }
 
 // workspace of gsa_tile_bin16 for either of its paths
@@ -2109,7 +2112,8 @@ extern "C" int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offs
                                                           qbox)
         if (!qbox) GSA_PLACE(0);
         else if (bin_tile == GSA_TILE_SIZE) GSA_PLACE(2);
-        else GSA_PLACE(4);
+        else if (bin_tile == 2 * GSA_TILE_SIZE) GSA_PLACE(4);
+        else GSA_PLACE(8);
 #undef GSA_PLACE
         GSA_LAUNCH_CHECK();
         return GSA_OK;

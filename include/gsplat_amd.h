@@ -136,11 +136,11 @@ int gsa_scan_tiles(int n, const int32_t *tiles_touched, const uint32_t *order, u
  * themselves, a column scan that also writes tile_offsets, and every gaussian id stored straight at its place in its
  * bin's list (no digit passes, no search for the list boundaries).  sorted_tile may then be NULL (not written): the
  * lists are sorted_gid + tile_offsets.  Same output, bit for bit, as the two-pass path.
- * ABI 10 -- quadrant boxes from the placement pass.  Where gsa_tile_bin16_boxes says 1 (the direct path, bins of 16 or 32
- * pixels, at most 2^24 gaussians) a caller may pass qbox (gsa_project_fwd's quadrant boxes): the TOP BYTE of every
- * sorted_gid entry then holds the part of the gaussian's box that lies inside the record's bin, in quadrants of the bin --
- * bits 24-25 first column, 26-27 last column, 28-29 first row, 30-31 last row; first > last: no quadrant -- and the id is
- * the low 24 bits.  gsa_composite_fwd / _bwd / _bwd_lists must be told (gid_boxes = 1): the forward sweep then gathers only
+ * ABI 10 -- quadrant boxes from the placement pass.  Where gsa_tile_bin16_boxes says 1 (the direct path, at most 2^24
+ * gaussians) a caller may pass qbox (gsa_project_fwd's quadrant boxes): the TOP BYTE of every sorted_gid entry then holds
+ * the part of the gaussian's box that lies inside the record's bin, in quadrants of the bin (bins of 16 or 32 pixels) or
+ * in PAIRS of quadrants (64-pixel bins: 8 x 8 quadrants, 2-bit fields; ABI 11) -- bits 24-25 first column, 26-27 last
+ * column, 28-29 first row, 30-31 last row; first > last: none -- and the id is the low 24 bits.  gsa_composite_fwd / _bwd / _bwd_lists must be told (gid_boxes = 1): the forward sweep then gathers only
  * the records whose box covers a wave's quadrant (a superset of the per-pixel rule: at the bench scene 78 % of the pairs it
  * lets through reach a pixel, where 22 % of a bin's records reach a given quadrant) -- for about fifteen integer
  * instructions per record in the placement and not one store more.  qbox == NULL: plain ids (gid_boxes = 0). */
