@@ -79,7 +79,13 @@ __global__ __launch_bounds__(kThreads) void loss_finalize_kernel(int n_blocks, c
 // No LDS, no barrier; rows are fetched four at a time, the next four in flight under the arithmetic of the current ones.
 //   v_render = grad_scale * [ (1 - lambda) sign(a - b) - lambda * d SSIM ] / (3 H W)     (straight-through clamp)
 // with zero padding and divisor 9 (avg_pool2d(3, 1, padding=1), count_include_pad), partials zero outside the image.
-constexpr int kStripCols = 60, kStripRows = 28, kStripChunk = 4;
+#ifndef GSA_LOSS_ROWS
+#define GSA_LOSS_ROWS 28
+#endif
+#ifndef GSA_LOSS_CHUNK
+#define GSA_LOSS_CHUNK 4
+#endif
+constexpr int kStripCols = 60, kStripRows = GSA_LOSS_ROWS, kStripChunk = GSA_LOSS_CHUNK;
 static_assert((kStripRows + 4) % kStripChunk == 0, "whole chunks of input rows");
 
 // the value of the lane below / above (0 at the wave's ends): DPP wave shifts, folded into the adds that use them
