@@ -21,11 +21,17 @@ Nothing here imports the CPU oracle.
 from __future__ import annotations
 
 import math
+import warnings
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
 import torch
 import torch.nn.functional as F
+
+# features_dc / features_rest are strided views of the [N,16,3] coefficient rows, and so are their .grad tensors: autograd
+# (the non-fused path) accumulates into those views in place, which is the point -- torch notes that such a layout "may
+# impair performance" once per process; the copy it would prefer is what the layout saves.
+warnings.filterwarnings("ignore", message="grad and param do not obey the gradient layout contract")
 
 # (name, per-gaussian shape) in the order of the reference's optimizer groups (trainer.py:331-340)
 FIELDS = (("xyz", (3,)), ("features_dc", (1, 3)), ("features_rest", (15, 3)), ("opacity", (1,)),
