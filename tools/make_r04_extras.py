@@ -133,6 +133,27 @@ The driver's command on the same box (`python bench.py --steps 20 --warmup 5`, `
 | per-gaussian box (`qbox`) expanded to a u16 mask array in `emit_place` | +0.024 | 0.135 | +0.003 |
 | **per-gaussian box packed into the id's top byte (built)** | **+0.008** | **0.137** | **-0.012** |
 
+## The alpha exponent on the matrix pipe -- built, measured, reverted
+
+s[pixel][record] = sum_k basis_k(pixel) coef_k(record), basis = (1, x, y, x^2, x y, y^2), IS a small contraction, and
+`v_mfma_f32_4x4x1_16b_f32` computes it in the layout the walk wants: D[v][lane] += A[4 (lane / 4) + v] * B[lane]
+(`tools/mfma_4x4x1_layout.hip` verifies that on the device), so with A = coefficient k of record (lane & 3) of a group of four
+and B = basis k at the lane's pixel, register v of every lane holds record v's exponent at the lane's own pixel -- six
+dependent MFMAs per four records instead of 20 fused multiply-adds, the coefficients fetched with 2 LDS reads per group
+instead of 2 broadcasts per record.  Built into both sweeps (record image repacked to [s0 gx gy A | B C depth - | r g b pos]):
+parity green (the stage, small-scene, C2 and C3-density tests), same box, `bench.py --steps 50` (`tools/r04_mfma_ab.sh`):
+
+| build | forward | backward | single view | 4-view step, per view |
+|---|---:|---:|---:|---:|
+| vector polynomial (control, same repacked image) | 0.1461 | 0.2076 | 0.6387 | 0.5774 |
+| MFMA exponent, forward at 6 waves per SIMD (80 registers) | 0.1477 | 0.2076 | 0.6401 | 0.5665 |
+| MFMA exponent, forward at 7 waves per SIMD (72 registers: 36 spills) | 0.1750 | 0.2071 | 0.6654 | 0.6003 |
+
+No gain: the f32 MFMA rate equals the f32 vector rate (4x4x1 has K = 1: 256 multiply-adds in 8 cycles), what it could win is
+the overlap of the two pipes, and a 2-pass MFMA hides about one vector instruction -- while six DEPENDENT MFMAs (the
+compiler spaces them with s_nop) lengthen the chain to the first exponent where the vector form has four independent chains
+of five.  Reverted; the vector polynomial stays.
+
 Not built, costed (DESIGN.md section 5): phase B of the backward on MFMA (fills 28 % of f32 tiles whose rate equals the vector
 rate: 512 cycles per sub-batch against ~300); one `v_rcp` per sub-batch instead of one per record by batch inversion (saves
 ~8 of ~110 cycles per record visit for 8 more live registers at the 96-register budget).
