@@ -963,13 +963,16 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 5 : GSA_BWD_WAVES)) void composit
         for (int s0 = 0; s0 < n; s0 += kSub) {
             const int nv = min(kSub, n - s0);
             // ---- phase A: lane = pixel, the records of the sub-batch in walk order
-            auto phase_a = [&](auto clamp_tag, auto all_on_tag) {
+            auto phase_a = [&](auto clamp_tag, auto all_on_tag, auto full_tag) {
                 constexpr bool CLAMP = decltype(clamp_tag)::value;
                 constexpr bool ALL_ON = decltype(all_on_tag)::value;   // every pixel is behind every record of the sub-batch
+                // FULL: a whole sub-batch (all but a list's last one) -- straight-line code for its eight records instead of
+                // a uniform branch and a re-materialised LDS address per record: -1 % of the sweep's time
+                constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
                 for (int r = 0; r < kSub; ++r) {
                     float u = 0.f, fac = 0.f;
-                    if (r < nv) {   // (uniform)
+                    if (FULL || r < nv) {   // (uniform)
                         const float4 *p = &tp.rec[F4 * (s0 + r)];
                         const float4 q0 = p[0], q1 = p[1], q2 = p[2];
                         // the pixel stopped in front of this record (its list position is beyond the pixel's last one)
@@ -995,9 +998,14 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 5 : GSA_BWD_WAVES)) void composit
             const int pos_hi = __builtin_amdgcn_readfirstlane(__float_as_int(tp.rec[F4 * s0 + 2].y));
             const bool all_on = __ballot(binf >= pos_hi) == ~0ull;
             if (any_cap) {
-                if (all_on) phase_a(std::true_type{}, std::true_type{}); else phase_a(std::true_type{}, std::false_type{});
+                if (all_on) phase_a(std::true_type{}, std::true_type{}, std::false_type{});
+                else phase_a(std::true_type{}, std::false_type{}, std::false_type{});
+            } else if (nv == kSub) {
+                if (all_on) phase_a(std::false_type{}, std::true_type{}, std::true_type{});
+                else phase_a(std::false_type{}, std::false_type{}, std::true_type{});
             } else {
-                if (all_on) phase_a(std::false_type{}, std::true_type{}); else phase_a(std::false_type{}, std::false_type{});
+                if (all_on) phase_a(std::false_type{}, std::true_type{}, std::false_type{});
+                else phase_a(std::false_type{}, std::false_type{}, std::false_type{});
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();

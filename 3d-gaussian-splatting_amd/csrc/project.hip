@@ -106,14 +106,21 @@ __device__ __forceinline__ void rows_to_lanes(float4 *wrows, int lane, const flo
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int DEG, bool STAGE>
-__global__ __launch_bounds__(kBlock, GSA_PROJ_FWD_WAVES) void project_fwd_kernel(
+#ifndef GSA_PROJ_BATCH_WAVES
+#define GSA_PROJ_BATCH_WAVES 1   // register budget of the multi-camera instances (waves per SIMD the compiler must leave room for)
+#endif
+template <int DEG, bool STAGE, bool BATCH>
+__global__ __launch_bounds__(kBlock, (BATCH ? GSA_PROJ_BATCH_WAVES : GSA_PROJ_FWD_WAVES)) void project_fwd_kernel(
     int n, const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
     const float *__restrict__ opacities, const float *__restrict__ colors, int sh_coeffs,
-    const float *__restrict__ viewmat, const float *__restrict__ intrin, int width, int height, int tile_w,
-    int tile_h, int cull_mode, float *__restrict__ splat, int32_t *__restrict__ radii,
-    int32_t *__restrict__ tiles_touched, uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ tile_rects,
-    float *__restrict__ sh_aux, int bin_tile, uint32_t *__restrict__ key_range, uint32_t *__restrict__ qbox) {
+    const float *__restrict__ viewmat_all, const float *__restrict__ intrin_all, int n_cams, int intrin_stride, int width,
+    int height, int tile_w, int tile_h, int cull_mode, float *__restrict__ splat_all, int32_t *__restrict__ radii_all,
+    int32_t *__restrict__ tiles_touched_all, uint32_t *__restrict__ depth_keys_all, uint32_t *__restrict__ tile_rects_all,
+    float *__restrict__ sh_aux_all, int bin_tile, uint32_t *__restrict__ key_range_all, uint32_t *__restrict__ qbox_all) {
+    // n_cams (gsa_project_fwd_batch): the SAME gaussians seen by several cameras -- the views of one optimisation step.  The
+    // thread keeps its gaussian's geometry and coefficient row (236 B of the 376 B a single-camera launch moves) and runs
+    // the per-camera part once per camera; camera c's outputs are the c-th slabs of [n_cams, ...] arrays.  Per camera the
+    // arithmetic IS the single-camera kernel's (this one, with n_cams = 1): the results are the same bits.
     __shared__ float4 sh_lds[STAGE ? (kBlock / 64) * kWaveLds : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Blocks walk the gaussians from the LAST to the first (GSA_PROJ_FWD_REVERSE): the kernel that ran before this one in
@@ -145,25 +152,39 @@ __global__ __launch_bounds__(kBlock, GSA_PROJ_FWD_WAVES) void project_fwd_kernel
         issue_row_loads<NQ>(reinterpret_cast<const float4 *>(colors) + wave_base * kRowQ, last, lane, stg);
     }
     const bool inside = i < n;   // lanes beyond n stay for the wave-cooperative record store below
-
-    GsaCamera cam = gsa_load_camera(viewmat, intrin);
-    GsaProj p = gsa_project_one(cam, g_mean, g_quat, g_scale, width, height);
     const float opac = g_opac;
-
-    bool visible = inside && p.ok && (opac >= GSA_ALPHA_THRESHOLD);
-    float sig_max = logf(fmaxf(opac, GSA_ALPHA_THRESHOLD) * 255.0f);  // alpha >= 1/255  <=>  sigma <= ln(255 o)
-    float ext = fminf(GSA_RADIUS_EXTEND, sqrtf(2.0f * sig_max));
-    float rxf = ceilf(ext * sqrtf(fmaxf(p.c00, 0.f)));
-    float ryf = ceilf(ext * sqrtf(fmaxf(p.c11, 0.f)));
-    visible = visible && !(rxf <= GSA_RADIUS_CLIP && ryf <= GSA_RADIUS_CLIP);
-    visible = visible && !(p.mx + rxf <= 0.f || p.mx - rxf >= (float)width || p.my + ryf <= 0.f ||
-                           p.my - ryf >= (float)height);
+    const float sig_max = logf(fmaxf(opac, GSA_ALPHA_THRESHOLD) * 255.0f);  // alpha >= 1/255  <=>  sigma <= ln(255 o)
+    const float ext = fminf(GSA_RADIUS_EXTEND, sqrtf(2.0f * sig_max));
 
     // the coefficient rows, through the wave's LDS image half by half: lane l ends up with row l (every lane takes
     // part, visible or not; a wave only touches its own 64 rows, so no workgroup barrier)
     constexpr int NC = DEG < 0 ? 1 : 3 * (DEG + 1) * (DEG + 1);
     float c[NC];
     if constexpr (ROWS_IN) rows_to_lanes<NQ, NC>(&sh_lds[wave * kWaveLds], lane, stg, c);
+
+    const long n_waves = ((long)n + 63) / 64;
+    const int cams = BATCH ? n_cams : 1;   // (one camera: a compile-time 1 -- the single-camera instances keep their code)
+    for (int ci = 0; ci < cams; ++ci) {
+    const float *__restrict__ viewmat = viewmat_all + 16 * ci;
+    const float *__restrict__ intrin = intrin_all + (long)intrin_stride * ci;
+    float *__restrict__ splat = splat_all + (long)ci * n * GSA_SPLAT_STRIDE;
+    int32_t *__restrict__ radii = radii_all + (long)ci * n * 2;
+    int32_t *__restrict__ tiles_touched = tiles_touched_all + (long)ci * n;
+    uint32_t *__restrict__ depth_keys = depth_keys_all + (long)ci * n;
+    uint32_t *__restrict__ tile_rects = tile_rects_all ? tile_rects_all + (long)ci * n * 2 : nullptr;
+    float *__restrict__ sh_aux = sh_aux_all ? sh_aux_all + (long)ci * n * 12 : nullptr;
+    uint32_t *__restrict__ key_range = key_range_all ? key_range_all + (long)ci * n_waves * 4 : nullptr;
+    uint32_t *__restrict__ qbox = qbox_all ? qbox_all + (long)ci * n : nullptr;
+
+    GsaCamera cam = gsa_load_camera(viewmat, intrin);
+    GsaProj p = gsa_project_one(cam, g_mean, g_quat, g_scale, width, height);
+
+    bool visible = inside && p.ok && (opac >= GSA_ALPHA_THRESHOLD);
+    float rxf = ceilf(ext * sqrtf(fmaxf(p.c00, 0.f)));
+    float ryf = ceilf(ext * sqrtf(fmaxf(p.c11, 0.f)));
+    visible = visible && !(rxf <= GSA_RADIUS_CLIP && ryf <= GSA_RADIUS_CLIP);
+    visible = visible && !(p.mx + rxf <= 0.f || p.mx - rxf >= (float)width || p.my + ryf <= 0.f ||
+                           p.my - ryf >= (float)height);
 
     // what a culled gaussian leaves: a zero record, zero radii / count, the largest depth key
     float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0, o2 = o0;
@@ -325,13 +346,15 @@ __global__ __launch_bounds__(kBlock, GSA_PROJ_FWD_WAVES) void project_fwd_kernel
         if (lane == 0 && blk * kBlock + wave * 64 < (long)n)
             reinterpret_cast<uint4 *>(key_range)[blk * (kBlock / 64) + wave] = make_uint4(lo, hi, s0, s1);
     }
-    if (!inside) return;
-    *reinterpret_cast<int2 *>(radii + 2 * i) = make_int2(rx, ry);
-    tiles_touched[i] = count;
-    depth_keys[i] = key;
-    // dense (rectangle, count) pairs for the fused binning: one 8-B gather per gaussian brings both into depth order
-    if (tile_rects) reinterpret_cast<uint2 *>(tile_rects)[i] = bin_pair;
-    if (qbox) qbox[i] = qb;
+    if (inside) {
+        *reinterpret_cast<int2 *>(radii + 2 * i) = make_int2(rx, ry);
+        tiles_touched[i] = count;
+        depth_keys[i] = key;
+        // dense (rectangle, count) pairs for the fused binning: one 8-B gather per gaussian brings both into depth order
+        if (tile_rects) reinterpret_cast<uint2 *>(tile_rects)[i] = bin_pair;
+        if (qbox) qbox[i] = qb;
+    }
+    }   // cameras
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -649,21 +672,22 @@ __global__ __launch_bounds__(kBlock, GSA_PROJ_BWD_WAVES) void project_bwd_kernel
 template <int DEG>
 int launch_fwd(bool stage, int n, const float *means, const float *quats, const float *scales,
                const float *opacities, const float *colors, int sh_coeffs, const float *viewmat,
-               const float *intrin, int width, int height, int cull_mode, float *splat, int32_t *radii,
-               int32_t *tiles_touched, uint32_t *depth_keys, uint32_t *tile_rects, float *sh_aux, int bin_tile,
-               uint32_t *key_range, uint32_t *qbox, hipStream_t s) {
+               const float *intrin, int n_cams, int intrin_stride, int width, int height, int cull_mode, float *splat,
+               int32_t *radii, int32_t *tiles_touched, uint32_t *depth_keys, uint32_t *tile_rects, float *sh_aux,
+               int bin_tile, uint32_t *key_range, uint32_t *qbox, hipStream_t s) {
     int tile_w = gsa_div_up(width, GSA_TILE_SIZE), tile_h = gsa_div_up(height, GSA_TILE_SIZE);
     dim3 grid(gsa_div_up(n, kBlock)), block(kBlock);
-    if (stage)
-        project_fwd_kernel<DEG, true><<<grid, block, 0, s>>>(n, means, quats, scales, opacities, colors, sh_coeffs,
-                                                             viewmat, intrin, width, height, tile_w, tile_h, cull_mode,
-                                                             splat, radii, tiles_touched, depth_keys, tile_rects, sh_aux,
-                                                             bin_tile, key_range, qbox);
-    else
-        project_fwd_kernel<DEG, false><<<grid, block, 0, s>>>(n, means, quats, scales, opacities, colors, sh_coeffs,
-                                                              viewmat, intrin, width, height, tile_w, tile_h,
-                                                              cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects,
-                                                              sh_aux, bin_tile, key_range, qbox);
+#define GSA_FWD_LAUNCH(ST, BA)                                                                                         \
+    project_fwd_kernel<DEG, ST, BA><<<grid, block, 0, s>>>(n, means, quats, scales, opacities, colors, sh_coeffs, viewmat, \
+                                                           intrin, n_cams, intrin_stride, width, height, tile_w, tile_h,     \
+                                                           cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects,   \
+                                                           sh_aux, bin_tile, key_range, qbox)
+    if (n_cams > 1) {
+        if (stage) GSA_FWD_LAUNCH(true, true); else GSA_FWD_LAUNCH(false, true);
+    } else {
+        if (stage) GSA_FWD_LAUNCH(true, false); else GSA_FWD_LAUNCH(false, false);
+    }
+#undef GSA_FWD_LAUNCH
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }
@@ -708,13 +732,14 @@ bool can_stage(const float *colors, int sh_degree, int sh_coeffs) {
 
 }  // namespace
 
-extern "C" int gsa_project_fwd(int n, const float *means, const float *quats, const float *scales,
-                               const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
-                               const float *viewmat, const float *intrin, int width, int height, int cull_mode,
-                               float *splat, int32_t *radii, int32_t *tiles_touched, uint32_t *depth_keys,
-                               uint32_t *tile_rects, float *sh_aux, int bin_tile, uint32_t *key_range, uint32_t *qbox,
-                               gsa_stream_t stream) {
-    GSA_RETURN_IF(n < 0 || width <= 0 || height <= 0, GSA_ERR_INVALID_ARGUMENT);
+static int project_fwd_impl(int n, const float *means, const float *quats, const float *scales,
+                            const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
+                            const float *viewmat, const float *intrin, int n_cams, int intrin_stride, int width, int height,
+                            int cull_mode, float *splat, int32_t *radii, int32_t *tiles_touched, uint32_t *depth_keys,
+                            uint32_t *tile_rects, float *sh_aux, int bin_tile, uint32_t *key_range, uint32_t *qbox,
+                            gsa_stream_t stream) {
+    GSA_RETURN_IF(n < 0 || width <= 0 || height <= 0 || n_cams < 1 || (intrin_stride != 0 && intrin_stride != 9),
+                  GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_degree < -1 || sh_degree > 3, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_degree >= 0 && sh_coeffs < (sh_degree + 1) * (sh_degree + 1), GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(cull_mode != 0 && cull_mode != 1, GSA_ERR_INVALID_ARGUMENT);
@@ -732,9 +757,10 @@ extern "C" int gsa_project_fwd(int n, const float *means, const float *quats, co
     hipStream_t s = static_cast<hipStream_t>(stream);
     // degree 0 needs 12 B of each 192-B row: direct loads beat staging whole rows
     bool stage = can_stage(colors, sh_degree, sh_coeffs) && sh_degree >= 1;
-#define GSA_FWD(D)                                                                                              \
-    return launch_fwd<D>(stage, n, means, quats, scales, opacities, colors, sh_coeffs, viewmat, intrin, width, \
-                         height, cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects, sh_aux, bin_tile, key_range, qbox, s)
+#define GSA_FWD(D)                                                                                                      \
+    return launch_fwd<D>(stage, n, means, quats, scales, opacities, colors, sh_coeffs, viewmat, intrin, n_cams,         \
+                         intrin_stride, width, height, cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects, \
+                         sh_aux, bin_tile, key_range, qbox, s)
     switch (sh_degree) {
         case -1: GSA_FWD(-1);
         case 0: GSA_FWD(0);
@@ -743,6 +769,30 @@ extern "C" int gsa_project_fwd(int n, const float *means, const float *quats, co
         default: GSA_FWD(3);
     }
 #undef GSA_FWD
+}
+
+extern "C" int gsa_project_fwd(int n, const float *means, const float *quats, const float *scales,
+                               const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
+                               const float *viewmat, const float *intrin, int width, int height, int cull_mode,
+                               float *splat, int32_t *radii, int32_t *tiles_touched, uint32_t *depth_keys,
+                               uint32_t *tile_rects, float *sh_aux, int bin_tile, uint32_t *key_range, uint32_t *qbox,
+                               gsa_stream_t stream) {
+    return project_fwd_impl(n, means, quats, scales, opacities, colors, sh_degree, sh_coeffs, viewmat, intrin, 1, 0, width,
+                            height, cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects, sh_aux, bin_tile,
+                            key_range, qbox, stream);
+}
+
+extern "C" int gsa_project_fwd_batch(int n, const float *means, const float *quats, const float *scales,
+                                     const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
+                                     int n_cams, const float *viewmats, const float *intrins, int intrin_stride, int width,
+                                     int height, int cull_mode, float *splat, int32_t *radii, int32_t *tiles_touched,
+                                     uint32_t *depth_keys, uint32_t *tile_rects, float *sh_aux, int bin_tile,
+                                     uint32_t *key_range, uint32_t *qbox, gsa_stream_t stream) {
+    // (camera c's slabs start c * n rows into the [n_cams, n, ...] arrays: 64 / 48 / 16 / 8 / 4 bytes a row, so every slab keeps
+    // the alignment its vector stores need whatever n is)
+    return project_fwd_impl(n, means, quats, scales, opacities, colors, sh_degree, sh_coeffs, viewmats, intrins, n_cams,
+                            intrin_stride, width, height, cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects,
+                            sh_aux, bin_tile, key_range, qbox, stream);
 }
 
 static int project_bwd_impl(int n, const float *means, const float *quats, const float *scales, const float *opacities,

@@ -50,7 +50,8 @@ class ViewPipeline:
     def run(self, n_views: int, forward: Callable[[int, bool], ViewState],
             backward: Callable[[int, ViewState, Optional[torch.cuda.Event]], None], *,
             after_view: Optional[Callable[[int], None]] = None, agree: Optional[Callable[[bool], bool]] = None,
-            inputs_ready: Optional[torch.cuda.Event] = None, defer: bool = True) -> Sequence[ViewState]:
+            inputs_ready: Optional[torch.cuda.Event] = None, defer: bool = True,
+            prepare: Optional[Callable[[], Sequence[torch.Tensor]]] = None) -> Sequence[ViewState]:
         """Queues ``n_views`` views, forward + backward each, and returns their states once the step is known good.
 
         ``forward(j, deferred)``: queue view j's front end and forward sweep (and whatever sits between the sweeps, e.g. the
@@ -62,6 +63,9 @@ class ViewPipeline:
         ``agree(ok)``: the ranks' conjunction (every rank must repeat a step, and its collectives, or none).
         ``inputs_ready``: an event behind which the step's inputs (the parameters) are valid; every stream waits for it
         before its first view.  None: the inputs did not change since the streams last saw them.
+        ``prepare()``: what the step's views SHARE, queued once in front of the first view on its stream -- the projection of
+        the gaussians for all cameras of the step in one launch (``project_cameras``); the other streams wait for it.  It
+        returns the tensors it allocated: they are used on every stream of the pipeline, which the allocator is told.
         """
         self.steps += 1
         main = torch.cuda.current_stream()
@@ -71,12 +75,30 @@ class ViewPipeline:
         done: List[torch.cuda.Event] = []
         prev: Optional[torch.cuda.Event] = None
         seen = set()
+        shared: Optional[torch.cuda.Event] = None
+        if prepare is not None:
+            st = use[0] if use else None
+            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+                if st is not None and inputs_ready is not None:
+                    st.wait_event(inputs_ready)
+                    seen.add(id(st))
+                made = prepare()
+                if st is not None:
+                    shared = torch.cuda.Event()
+                    shared.record(st)
+                    for t in made or ():
+                        for other in use[1:]:
+                            t.record_stream(other)
+        waited = {id(use[0])} if (use and shared is not None) else set()
         for j in range(n_views):
             st = use[j % len(use)] if use else None
             with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
                 if st is not None and inputs_ready is not None and id(st) not in seen:
                     st.wait_event(inputs_ready)
                     seen.add(id(st))
+                if st is not None and shared is not None and id(st) not in waited:
+                    st.wait_event(shared)
+                    waited.add(id(st))
                 state = forward(j, defer)
                 # the bucket is summed into in view order; the first view also waits for the previous step's last use of it
                 before = prev if j > 0 else (self._step_done if st is not None else None)

@@ -27,7 +27,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, colors, viewmat, Kmat, background,
                 width: int, height: int, sh_degree: int, channels: int, cull_mode: int, grad_out, grad_accumulate,
-                sh_grad_factored, deferred=None):
+                sh_grad_factored, deferred=None, projection=None):
         means_c, quats_c, scales_c = S.f32c(means, "means"), S.f32c(quats, "quats"), S.f32c(scales, "scales")
         opac_c, colors_c = S.f32c(opacities, "opacities"), S.f32c(colors, "colors")
         view_c, K_c = S.f32c(viewmat, "viewmats"), S.f32c(Kmat, "Ks")
@@ -39,12 +39,22 @@ class _RasterizeOneCamera(torch.autograd.Function):
         # the records are binned into 32 x 32 BINS where the fused binning applies (S.bin_tile_for): the four 16 x 16
         # tiles of a bin walk the bin's list -- a compositor wave re-tests every record against its 8 x 8 quadrant anyway
         bt = S.bin_tile_for(width, height, cull_mode)
-        kr = S.key_range_buffer(means_c.shape[0], means_c.device)   # this view's depth-key range, for the depth ordering's bucket plan
-        qb = S.qbox_buffer(means_c.shape[0], means_c.device)        # the gaussians' quadrant boxes, for the forward sweep's candidate test
-        proj = S.project_fwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
-                             cull_mode, return_rects=True, return_aux=want_lists, bin_tile=bt, key_range=kr, qbox=qb)
-        splat, radii, tiles_touched, depth_keys, rects = proj[:5]
-        sh_aux = proj[5] if want_lists else None
+        if projection is not None:
+            # this camera's slice of a multi-camera projection (project_cameras: one launch for the views of a step)
+            if projection.dims != (width, height, cull_mode, sh_degree) or projection.bin_tile != bt or \
+                    projection.splat.shape[0] != means_c.shape[0]:
+                raise ValueError("rasterization(projection=...): made for another frame size, cull mode, SH degree or scene")
+            kr, qb = projection.key_range, projection.qbox
+            splat, radii, tiles_touched = projection.splat, projection.radii, projection.tiles_touched
+            depth_keys, rects = projection.depth_keys, projection.tile_rects
+            sh_aux = projection.sh_aux if want_lists else None
+        else:
+            kr = S.key_range_buffer(means_c.shape[0], means_c.device)   # this view's depth-key range, for the depth ordering's bucket plan
+            qb = S.qbox_buffer(means_c.shape[0], means_c.device)        # the gaussians' quadrant boxes, for the forward sweep's candidate test
+            proj = S.project_fwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
+                                 cull_mode, return_rects=True, return_aux=want_lists, bin_tile=bt, key_range=kr, qbox=qb)
+            splat, radii, tiles_touched, depth_keys, rects = proj[:5]
+            sh_aux = proj[5] if want_lists else None
         # the host does not wait for the record count: bins are sized for a remembered capacity, the compositor is
         # queued, and only then is the count (long since copied back) checked -- a miss repeats with exact sizes
         bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, tile_rects=rects,
@@ -106,10 +116,28 @@ class _RasterizeOneCamera(torch.autograd.Function):
                               splat, radii, v_splat, out=ctx.grad_out, accumulate=ctx.grad_accumulate,
                               v_rgb_out=ctx.sh_grad_factored, sh_aux=sh_aux)
         if ctx.grad_accumulate:   # the sums live in the caller's buffers; autograd gets nothing to accumulate
-            return (None,) * 17
+            return (None,) * 18
         need = ctx.needs_input_grad
         grads = tuple(g.view(shp) if (nd and g is not None) else None for g, shp, nd in zip(grads, ctx.in_shapes, need[:5]))
-        return grads + (None,) * 12
+        return grads + (None,) * 13
+
+
+def project_cameras(means, quats, scales, opacities, colors, viewmats, Ks, width: int, height: int,
+                    sh_degree: Optional[int] = None, cull_mode: Optional[int] = None, for_backward: Optional[bool] = None):
+    """The projection stage of ``rasterization`` for the C cameras of ``viewmats`` [C,4,4] in ONE launch (same argument
+    meaning as there; ``Ks`` [C,3,3] or [3,3]) -> a list of C per-camera projections for ``rasterization(projection=...)``.
+    What it is for: the B views of an optimisation step are rendered from the same parameters
+    (/root/reference/src/training/trainer.py:458-506), so their projections can share the read of every gaussian's
+    geometry and SH coefficient row -- 236 of the 376 bytes a single-camera projection moves per gaussian.
+    ``for_backward`` (default: any input requires grad): also leave the 48-B digest of each coefficient row the backward
+    projection reads instead of the row."""
+    deg = -1 if sh_degree is None else int(sh_degree)
+    cull = S.DEFAULT_CULL_MODE if cull_mode is None else int(cull_mode)
+    if for_backward is None:
+        for_backward = any(t.requires_grad for t in (means, quats, scales, opacities, colors))
+    return S.project_views(S.f32c(means, "means"), S.f32c(quats, "quats"), S.f32c(scales, "scales"),
+                           S.f32c(opacities, "opacities"), S.f32c(colors, "colors"), deg, viewmats, Ks, int(width), int(height),
+                           cull, return_aux=bool(for_backward))
 
 
 def rasterization(
@@ -136,6 +164,7 @@ def rasterization(
     grad_accumulate: bool = False,
     sh_grad_factored: Optional[torch.Tensor] = None,
     defer_check: bool = False,
+    projection=None,
     **unsupported,
 ) -> Tuple[torch.Tensor, torch.Tensor, Dict]:
     """Returns ``(renders [C,H,W,D], alphas [C,H,W,1], meta)``; ``meta['means2d']`` [C,N,2] and
@@ -158,6 +187,10 @@ def rasterization(
     not wait: the host queues view after view, far ahead of the device, and the CALLER asks ``meta['speculation_ok']``
     -- a bool, waiting for the control words only then -- before it trusts the view (image, gradients), and renders it
     again (without ``defer_check``) if it is False.  A training loop asks once per step, in front of the optimizer.
+    ``projection`` (extension): what ``project_cameras`` returned for these cameras (one entry per camera, or the single
+    entry itself for one camera): the projection stage is then not run again.  The views of an optimisation step share
+    their gaussians, and ONE multi-camera launch reads a gaussian's geometry and coefficient row once for all of them; a
+    call with C > 1 cameras does this by itself.
     """
     for k, v in unsupported.items():
         ok = (k in ("sparse_grad", "absgrad", "distributed") and not v) or \
@@ -204,6 +237,13 @@ def rasterization(
 
     renders, alphas, per_cam = [], [], []
     pending = [] if defer_check else None   # TileBins per camera whose control words nobody has waited for yet
+    if projection is not None and not isinstance(projection, (list, tuple)):
+        projection = [projection]
+    if projection is not None and len(projection) != C:
+        raise ValueError("rasterization(projection=...): one entry per camera")
+    if projection is None and C > 1:   # several cameras: project for all of them in one launch
+        projection = project_cameras(means, quats, scales, opacities, colors, viewmats, Ks, width, height, sh_degree=sh_degree,
+                                     cull_mode=cull)
     for c in range(C):
         bg = None
         if backgrounds is not None:
@@ -212,7 +252,7 @@ def rasterization(
                 bg = torch.cat([bg, bg.new_zeros(1)])
         out = _RasterizeOneCamera.apply(means, quats, scales, opacities, colors, viewmats[c], Ks[c], bg,
                                         width, height, deg, channels, cull, grad_out, grad_accumulate, sh_grad_factored,
-                                        pending)
+                                        pending, None if projection is None else projection[c])
         render, alpha = out[0], out[1]
         if render_mode in ("ED", "RGB+ED"):
             render = torch.cat([render[..., :3], render[..., 3:] / alpha.clamp(min=1e-10)], dim=-1)

@@ -262,6 +262,49 @@ def project_fwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat
     return out
 
 
+class ViewProjection:
+    """The projection of the gaussians for ONE camera, as ``project_fwd`` leaves it (with ``return_rects``, ``return_aux``,
+    a key range and quadrant boxes): what the binning, the sweeps and ``project_bwd`` of that view need."""
+
+    __slots__ = ("splat", "radii", "tiles_touched", "depth_keys", "tile_rects", "sh_aux", "key_range", "qbox", "viewmat",
+                 "Kmat", "bin_tile", "dims")
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw.get(k))
+
+
+def project_views(means, quats, scales, opacities, colors, sh_degree: int, viewmats, Kmats, width: int, height: int,
+                  cull_mode: int = 0, return_aux: bool = False, bin_tile: Optional[int] = None):
+    """The gaussians projected for the C cameras of ``viewmats`` [C,4,4] in ONE launch (``gsa_project_fwd_batch``): geometry
+    and coefficient rows are read once for all cameras -- the views of an optimisation step share them.  ``Kmats``: [C,3,3],
+    or one [3,3] matrix for all cameras.  -> C ``ViewProjection``s whose tensors are the per-camera slabs of [C, ...]
+    buffers; each holds the same bits ``project_fwd`` with that camera writes."""
+    dev, N = means.device, means.shape[0]
+    C = int(viewmats.shape[0])
+    if viewmats.shape != (C, 4, 4) or Kmats.shape not in ((C, 3, 3), (3, 3)):
+        raise ValueError("project_views: viewmats must be [C,4,4] and Kmats [C,3,3] or [3,3]")
+    bt = bin_tile_for(width, height, cull_mode) if bin_tile is None else bin_tile
+    sh_coeffs = colors.shape[1] if sh_degree >= 0 else 0
+    splat = torch.empty(C, N, SPLAT_STRIDE, dtype=torch.float32, device=dev)
+    radii = torch.empty(C, N, 2, dtype=torch.int32, device=dev)
+    tiles_touched = torch.empty(C, N, dtype=torch.int32, device=dev)
+    depth_keys = torch.empty(C, N, dtype=torch.int32, device=dev)
+    tile_rects = torch.empty(C, N, 2, dtype=torch.int32, device=dev)
+    sh_aux = torch.empty(C, N, 12, dtype=torch.float32, device=dev) if (return_aux and sh_degree >= 1 and _SH_AUX) else None
+    key_range = torch.empty(C, (N + 63) // 64, 4, dtype=torch.int32, device=dev)
+    qbox = torch.empty(C, N, dtype=torch.int32, device=dev) if _QUAD_BOXES else None
+    vm, km = f32c(viewmats, "viewmats"), f32c(Kmats, "Ks")
+    _call("gsa_project_fwd", lib.gsa_project_fwd_batch, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
+          _ptr(colors), sh_degree, sh_coeffs, C, _ptr(vm), _ptr(km), 9 if km.dim() == 3 else 0, width, height, cull_mode,
+          _ptr(splat), _ptr(radii), _ptr(tiles_touched), _ptr(depth_keys), _ptr(tile_rects), _ptr(sh_aux), bt,
+          _ptr(key_range), _ptr(qbox), _stream())
+    return [ViewProjection(splat=splat[c], radii=radii[c], tiles_touched=tiles_touched[c], depth_keys=depth_keys[c],
+                           tile_rects=tile_rects[c], sh_aux=None if sh_aux is None else sh_aux[c], key_range=key_range[c],
+                           qbox=None if qbox is None else qbox[c], viewmat=vm[c], Kmat=km[c] if km.dim() == 3 else km,
+                           bin_tile=bt, dims=(width, height, cull_mode, sh_degree)) for c in range(C)]
+
+
 def sort_pairs(n: int, keys: torch.Tensor, vals: Optional[torch.Tensor], begin_bit: int, end_bit: int):
     """Stable radix sort of int32-typed storage holding uint32 keys; returns (sorted_keys, sorted_vals)."""
     dev = keys.device

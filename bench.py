@@ -301,6 +301,9 @@ def main() -> None:
     ap.add_argument("--views", type=int, default=8,
                     help="ring size of the ROTATING-view pass (the reference samples random views every step, "
                          "trainer.py:315-317): one view per step, cycling through this many cameras")
+    ap.add_argument("--no-batch-projection", action="store_true",
+                    help="project the gaussians once per view instead of once per step for all its views "
+                         "(gsplat_amd.project_cameras: geometry and SH rows read once)")
     ap.add_argument("--dump-grad", default=None,
                     help="(tests) rank 0 saves the gradient bucket of the last step of the timed region to this .pt file")
     ap.add_argument("--profile-run", action="store_true",
@@ -404,11 +407,28 @@ def main() -> None:
         cams, windows = (ring(ring_size) if cams_override is None else cams_override), {}
         defer = views > 1 and not args.no_defer_check   # the views' speculation is checked once per step, behind the last view
 
+        # the projection of the gaussians for all views of the step in ONE launch (their geometry and coefficient rows
+        # read once), queued in front of the first view; --no-batch-projection: one projection launch per view
+        batch_proj = views > 1 and not args.no_batch_projection
+        shared, step_cams = {}, {}
+
         def step(i: int = 0):
             for t in leaves:
                 t.grad = None
             base = (i * views * world) % ring_size
             marks = {}
+
+            def prepare():
+                if base not in step_cams:   # this rank's cameras of the step, one [views, 4, 4] tensor per window of the ring
+                    idx = torch.tensor([(base + j * world + rank) % ring_size for j in range(views)], device=dev)
+                    step_cams[base] = cams[idx].contiguous()
+                shared["proj"] = gsplat_amd.project_cameras(leaves[0], leaves[1], leaves[2], opac.squeeze(-1), leaves[4],
+                                                            step_cams[base], K[0], width, height, sh_degree=deg,
+                                                            cull_mode=args.cull_mode)
+                p0 = shared["proj"][0]
+                return [t._base if t._base is not None else t for t in
+                        (p0.splat, p0.radii, p0.tiles_touched, p0.depth_keys, p0.tile_rects, p0.sh_aux, p0.key_range, p0.qbox)
+                        if t is not None]
 
             def forward(j: int, deferred: bool) -> ViewState:
                 vm = cams[(base + j * world + rank) % ring_size][None]
@@ -419,7 +439,8 @@ def main() -> None:
                                                       width, height, sh_degree=deg, backgrounds=bg,
                                                       cull_mode=args.cull_mode, grad_out=grad_views,
                                                       grad_accumulate=j > 0, sh_grad_factored=ex.view_target(j),
-                                                      defer_check=deferred)
+                                                      defer_check=deferred,
+                                                      projection=shared["proj"][j] if batch_proj else None)
                 if "M" not in info:   # (once: with 32 x 32 bins in the hot path the 16 x 16 record count is a reduction + read-back)
                     info["M"] = meta["n_isects"]
                     info["binned"] = meta["n_binned"]
@@ -436,7 +457,8 @@ def main() -> None:
                     marks["x0"].record()
                 ex.after_view(j)
 
-            pipe.run(views, forward, backward, after_view=after_view, agree=agree if dist is not None else None, defer=defer)
+            pipe.run(views, forward, backward, after_view=after_view, agree=agree if dist is not None else None, defer=defer,
+                     prepare=prepare if batch_proj else None)
             if factored or dist is not None:
                 if base not in windows:   # the cameras of the step's views, entry j * world + r = rank r's view j
                     windows[base] = cams[(base + torch.arange(views * world, device=dev)) % ring_size].contiguous()

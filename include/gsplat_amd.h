@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSA_ABI_VERSION 11
+#define GSA_ABI_VERSION 12
 #define GSA_SPLAT_STRIDE 16
 
 #define GSA_OK 0
@@ -99,6 +99,21 @@ int gsa_project_fwd(int n, const float *means, const float *quats, const float *
                     float *splat, int32_t *radii, int32_t *tiles_touched, uint32_t *depth_keys,
                     uint32_t *tile_rects, float *sh_aux, int bin_tile, uint32_t *key_range, uint32_t *qbox,
                     gsa_stream_t stream);
+
+/* ABI 12 -- the SAME gaussians seen by n_cams cameras in one launch: the views of one optimisation step (the reference
+ * renders the B views of a batch one after the other from the same parameters, src/training/trainer.py:458-506; gsplat's
+ * own operator takes viewmats [C,4,4]).  A gaussian's geometry and its 192-B coefficient row are read ONCE for all
+ * cameras (236 of the 376 bytes a single-camera launch moves per gaussian).  viewmats: n_cams x 16 floats; intrins:
+ * n_cams x 9 floats with intrin_stride = 9, or ONE 3 x 3 matrix shared by all cameras with intrin_stride = 0.  Every
+ * output is an [n_cams, ...] array of per-camera slabs laid out exactly like gsa_project_fwd's outputs (camera c's slab
+ * starts c * n rows in; key_range: c * 4 * ceil(n / 64) words in); optional outputs as there.  Camera c's slabs hold the
+ * same bits a gsa_project_fwd call with camera c writes. */
+int gsa_project_fwd_batch(int n, const float *means, const float *quats, const float *scales,
+                          const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
+                          int n_cams, const float *viewmats, const float *intrins, int intrin_stride, int width,
+                          int height, int cull_mode, float *splat, int32_t *radii, int32_t *tiles_touched,
+                          uint32_t *depth_keys, uint32_t *tile_rects, float *sh_aux, int bin_tile,
+                          uint32_t *key_range, uint32_t *qbox, gsa_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stage 2 (row a3.3): tile binning.  Replaces gsplat's isect_tiles + 64-bit radix sort +

@@ -470,6 +470,41 @@ def test_key_range_store_stays_inside_an_exact_size_buffer(gsa, rem):
     assert bool((kr[:, 0] != 0x5A5A5A5A).all())      # ... and every entry inside was written
 
 
+@pytest.mark.parametrize("n,deg,shared_k", [(5000, 3, True), (777, 3, False), (4097, 1, True), (3000, 0, False), (1234, -1, True)])
+def test_multi_camera_projection_equals_single_camera_launches(gsa, n, deg, shared_k):
+    """``stages.project_views`` (gsa_project_fwd_batch: the views of a step projected in one launch, geometry and
+    coefficient rows read once) leaves, per camera, the same BITS as ``project_fwd`` with that camera -- records, radii,
+    counts, depth keys, bin rectangles, coefficient digests, per-wave key ranges, quadrant boxes -- for populations that are
+    no multiple of the wave or the block, every SH degree, shared and per-camera intrinsics."""
+    from gsplat_amd import scene, stages as S
+    W, H, C = 320, 200, 3
+    sc = _scene(n, seed=5, deg=max(deg, 0))
+    means, quats, scales = sc["means3D"].cuda(), sc["rotations"].cuda(), sc["scales"].cuda()
+    opac = sc["opacities"][:, 0].contiguous().cuda()
+    colors = sc["shs"].cuda() if deg >= 0 else torch.rand(n, 3, device="cuda")
+    vms = torch.stack([scene.make_camera(k, 7) for k in (0, 2, 5)]).cuda()
+    K1 = scene.make_intrinsics(W, H).cuda()
+    Ks = K1 if shared_k else torch.stack([K1, K1 * torch.tensor([[1.1], [0.9], [1.0]], device="cuda"), K1]).contiguous()
+    bt = S.bin_tile_for(W, H, 0)
+    views = S.project_views(means, quats, scales, opac, colors, deg, vms, Ks, W, H, 0, return_aux=True, bin_tile=bt)
+    assert len(views) == C
+    for c, v in enumerate(views):
+        kr, qb = S.key_range_buffer(n, means.device), S.qbox_buffer(n, means.device)
+        one = S.project_fwd(means, quats, scales, opac, colors, deg, vms[c].contiguous(), (Ks if shared_k else Ks[c]).contiguous(),
+                            W, H, 0, return_rects=True, return_aux=True, bin_tile=bt, key_range=kr, qbox=qb)
+        got = (v.splat, v.radii, v.tiles_touched, v.depth_keys, v.tile_rects, v.sh_aux)
+        for name, a, b in zip(("splat", "radii", "tiles_touched", "depth_keys", "tile_rects", "sh_aux"), got, one):
+            assert (a is None) == (b is None), name
+            if a is not None:
+                assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a,
+                                   b.view(torch.int32) if b.dtype == torch.float32 else b), (name, c)
+        assert torch.equal(v.key_range, kr), c
+        vis = one[2] > 0    # (quadrant boxes: unspecified for culled gaussians)
+        assert (qb is None) == (v.qbox is None)
+        if qb is not None:
+            assert torch.equal(v.qbox[vis], qb[vis]), c
+
+
 def test_cull_modes_give_identical_images(gsa):
     """Exact ellipse culling only removes (tile, splat) pairs whose every pixel fails alpha >= 1/255."""
     from gsplat_amd import scene
