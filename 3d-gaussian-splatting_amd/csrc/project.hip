@@ -357,6 +357,104 @@ __global__ __launch_bounds__(kBlock, (BATCH ? GSA_PROJ_BATCH_WAVES : GSA_PROJ_FW
     }   // cameras
 }
 
+// The chain rule of the projection for ONE gaussian and ONE camera: the sweep's raw moments (v0, v1, v2: the gradient
+// record, composite.hip) and the view-direction part of the colour gradient (vdir) -> d loss / d (mean, quaternion,
+// scale, opacity).  One function for the single-camera and the multi-camera backward kernels: the same arithmetic.
+__device__ __forceinline__ void project_chain_bwd(const GsaCamera &cam, const float (&g_mean)[3], const float (&g_quat)[4],
+                                                  const float (&g_scale)[3], float opac, int width, int height,
+                                                  const float4 v0, const float4 v1, const float4 v2, const float (&vdir)[3],
+                                                  float (&vm)[3], float (&vq)[4], float (&vs)[3], float &vo) {
+    GsaProj p = gsa_project_one(cam, g_mean, g_quat, g_scale, width, height);
+    // The sweep leaves the raw moments of u = d loss / d sigma over d = mean2d - pixel (composite.hip):
+    // sigma = (a dx^2 + c dy^2) / 2 + b dx dy and alpha = o * exp(-sigma) make every gradient linear in them.
+    const float m_dx = v0.x, m_dy = v0.y, m_dxdx = v0.z, m_dxdy = v0.w, m_dydy = v1.x, m_u = v1.y;
+    const float s_opac = opac;
+    float v_mx = p.qa * m_dx + p.qb * m_dy, v_my = p.qb * m_dx + p.qc * m_dy;
+    float v_a = 0.5f * m_dxdx, v_b = m_dxdy, v_c = 0.5f * m_dydy;
+    vo = -m_u / s_opac;   // d alpha / d o = alpha / o  and  u = -alpha * v_alpha
+    float v_depth = v2.y;
+
+
+    // ---- conic -> blurred cov2d:  G = -Q V Q,  V = [[v_a, v_b/2], [v_b/2, v_c]]
+    float a = p.qa, b = p.qb, c = p.qc, hb = 0.5f * v_b;
+    float q00 = a * v_a + b * hb, q01 = a * hb + b * v_c;
+    float q10 = b * v_a + c * hb, q11 = b * hb + c * v_c;
+    float G00 = -(q00 * a + q01 * b);
+    float G01 = -(q00 * b + q01 * c);
+    float G11 = -(q10 * b + q11 * c);
+
+    // ---- cov2d = J Sc J^T
+    float J00 = p.J00, J02 = p.J02, J11 = p.J11, J12 = p.J12;
+    float vS00 = J00 * J00 * G00;
+    float vS01 = J00 * J11 * G01;
+    float vS02 = J00 * (G00 * J02 + G01 * J12);
+    float vS11 = J11 * J11 * G11;
+    float vS12 = J11 * (G01 * J02 + G11 * J12);
+    float vS22 = J02 * J02 * G00 + 2.f * J02 * J12 * G01 + J12 * J12 * G11;
+    float T00 = J00 * p.S00 + J02 * p.S02, T01 = J00 * p.S01 + J02 * p.S12, T02 = J00 * p.S02 + J02 * p.S22;
+    float T10 = J11 * p.S01 + J12 * p.S02, T11 = J11 * p.S11 + J12 * p.S12, T12 = J11 * p.S12 + J12 * p.S22;
+    float vJ00 = 2.f * (G00 * T00 + G01 * T10);
+    float vJ02 = 2.f * (G00 * T02 + G01 * T12);
+    float vJ11 = 2.f * (G01 * T01 + G11 * T11);
+    float vJ12 = 2.f * (G01 * T02 + G11 * T12);
+
+    // ---- camera-space mean
+    float fx = cam.fx, fy = cam.fy, rz = p.rz, rz2 = p.rz2, rz3 = p.rz2 * p.rz;
+    float vx = fx * rz * v_mx;
+    float vy = fy * rz * v_my;
+    float vz = -(fx * p.x * v_mx + fy * p.y * v_my) * rz2 + v_depth;
+    if (p.x_in) vx += -fx * rz2 * vJ02; else vz += -fx * rz3 * vJ02 * p.tx;
+    if (p.y_in) vy += -fy * rz2 * vJ12; else vz += -fy * rz3 * vJ12 * p.ty;
+    vz += -fx * rz2 * vJ00 - fy * rz2 * vJ11 + 2.f * fx * p.tx * rz3 * vJ02 + 2.f * fy * p.ty * rz3 * vJ12;
+    const float *R = cam.R;
+    vm[0] = R[0] * vx + R[3] * vy + R[6] * vz;
+    vm[1] = R[1] * vx + R[4] * vy + R[7] * vz;
+    vm[2] = R[2] * vx + R[5] * vy + R[8] * vz;
+    vm[0] += vdir[0]; vm[1] += vdir[1]; vm[2] += vdir[2];
+
+    // ---- Sigma_c = R Sigma R^T  ->  vSig = R^T vSc R
+    float U00 = vS00 * R[0] + vS01 * R[3] + vS02 * R[6], U01 = vS00 * R[1] + vS01 * R[4] + vS02 * R[7],
+          U02 = vS00 * R[2] + vS01 * R[5] + vS02 * R[8];
+    float U10 = vS01 * R[0] + vS11 * R[3] + vS12 * R[6], U11 = vS01 * R[1] + vS11 * R[4] + vS12 * R[7],
+          U12 = vS01 * R[2] + vS11 * R[5] + vS12 * R[8];
+    float U20 = vS02 * R[0] + vS12 * R[3] + vS22 * R[6], U21 = vS02 * R[1] + vS12 * R[4] + vS22 * R[7],
+          U22 = vS02 * R[2] + vS12 * R[5] + vS22 * R[8];
+    float W[9];
+    W[0] = R[0] * U00 + R[3] * U10 + R[6] * U20; W[1] = R[0] * U01 + R[3] * U11 + R[6] * U21;
+    W[2] = R[0] * U02 + R[3] * U12 + R[6] * U22;
+    W[3] = R[1] * U00 + R[4] * U10 + R[7] * U20; W[4] = R[1] * U01 + R[4] * U11 + R[7] * U21;
+    W[5] = R[1] * U02 + R[4] * U12 + R[7] * U22;
+    W[6] = R[2] * U00 + R[5] * U10 + R[8] * U20; W[7] = R[2] * U01 + R[5] * U11 + R[8] * U21;
+    W[8] = R[2] * U02 + R[5] * U12 + R[8] * U22;
+
+    // ---- Sigma = M M^T, M = Rq diag(s):  vM = 2 vSig M
+    const float *Rq = p.Rq;
+    float s[3] = {p.sx, p.sy, p.sz};
+    float vM[9];
+#pragma unroll
+    for (int r_ = 0; r_ < 3; ++r_)
+#pragma unroll
+        for (int c_ = 0; c_ < 3; ++c_)
+            vM[r_ * 3 + c_] = 2.f * (W[r_ * 3 + 0] * Rq[0 * 3 + c_] + W[r_ * 3 + 1] * Rq[1 * 3 + c_] +
+                                     W[r_ * 3 + 2] * Rq[2 * 3 + c_]) * s[c_];
+    float vR[9];
+#pragma unroll
+    for (int c_ = 0; c_ < 3; ++c_) {
+        vs[c_] = Rq[0 * 3 + c_] * vM[0 * 3 + c_] + Rq[1 * 3 + c_] * vM[1 * 3 + c_] + Rq[2 * 3 + c_] * vM[2 * 3 + c_];
+#pragma unroll
+        for (int r_ = 0; r_ < 3; ++r_) vR[r_ * 3 + c_] = vM[r_ * 3 + c_] * s[c_];
+    }
+    // ---- rotation matrix -> normalised quaternion -> raw quaternion
+    float w = p.qw, x = p.qx, y = p.qy, z = p.qz;
+    float gw = 2.f * (x * (vR[7] - vR[5]) + y * (vR[2] - vR[6]) + z * (vR[3] - vR[1]));
+    float gx = 2.f * (-2.f * x * (vR[4] + vR[8]) + y * (vR[1] + vR[3]) + z * (vR[2] + vR[6]) + w * (vR[7] - vR[5]));
+    float gy = 2.f * (-2.f * y * (vR[0] + vR[8]) + x * (vR[1] + vR[3]) + z * (vR[5] + vR[7]) + w * (vR[2] - vR[6]));
+    float gz = 2.f * (-2.f * z * (vR[0] + vR[4]) + x * (vR[2] + vR[6]) + y * (vR[5] + vR[7]) + w * (vR[3] - vR[1]));
+    float dotq = gw * w + gx * x + gy * y + gz * z;
+    vq[0] = (gw - dotq * w) * p.qinv; vq[1] = (gx - dotq * x) * p.qinv;
+    vq[2] = (gy - dotq * y) * p.qinv; vq[3] = (gz - dotq * z) * p.qinv;
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward (A.7)
 // ------------------------------------------------------------------------------------------------
@@ -498,95 +596,7 @@ __global__ __launch_bounds__(kBlock, GSA_PROJ_BWD_WAVES) void project_bwd_kernel
         }
         __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from interleaving the two chains: register pressure)
 
-        GsaProj p = gsa_project_one(cam, g_mean, g_quat, g_scale, width, height);
-        // The sweep leaves the raw moments of u = d loss / d sigma over d = mean2d - pixel (composite.hip):
-        // sigma = (a dx^2 + c dy^2) / 2 + b dx dy and alpha = o * exp(-sigma) make every gradient linear in them.
-        const float m_dx = v0.x, m_dy = v0.y, m_dxdx = v0.z, m_dxdy = v0.w, m_dydy = v1.x, m_u = v1.y;
-        const float s_opac = g_opac;
-        float v_mx = p.qa * m_dx + p.qb * m_dy, v_my = p.qb * m_dx + p.qc * m_dy;
-        float v_a = 0.5f * m_dxdx, v_b = m_dxdy, v_c = 0.5f * m_dydy;
-        vo = -m_u / s_opac;   // d alpha / d o = alpha / o  and  u = -alpha * v_alpha
-        float v_depth = v2.y;
-
-
-        // ---- conic -> blurred cov2d:  G = -Q V Q,  V = [[v_a, v_b/2], [v_b/2, v_c]]
-        float a = p.qa, b = p.qb, c = p.qc, hb = 0.5f * v_b;
-        float q00 = a * v_a + b * hb, q01 = a * hb + b * v_c;
-        float q10 = b * v_a + c * hb, q11 = b * hb + c * v_c;
-        float G00 = -(q00 * a + q01 * b);
-        float G01 = -(q00 * b + q01 * c);
-        float G11 = -(q10 * b + q11 * c);
-
-        // ---- cov2d = J Sc J^T
-        float J00 = p.J00, J02 = p.J02, J11 = p.J11, J12 = p.J12;
-        float vS00 = J00 * J00 * G00;
-        float vS01 = J00 * J11 * G01;
-        float vS02 = J00 * (G00 * J02 + G01 * J12);
-        float vS11 = J11 * J11 * G11;
-        float vS12 = J11 * (G01 * J02 + G11 * J12);
-        float vS22 = J02 * J02 * G00 + 2.f * J02 * J12 * G01 + J12 * J12 * G11;
-        float T00 = J00 * p.S00 + J02 * p.S02, T01 = J00 * p.S01 + J02 * p.S12, T02 = J00 * p.S02 + J02 * p.S22;
-        float T10 = J11 * p.S01 + J12 * p.S02, T11 = J11 * p.S11 + J12 * p.S12, T12 = J11 * p.S12 + J12 * p.S22;
-        float vJ00 = 2.f * (G00 * T00 + G01 * T10);
-        float vJ02 = 2.f * (G00 * T02 + G01 * T12);
-        float vJ11 = 2.f * (G01 * T01 + G11 * T11);
-        float vJ12 = 2.f * (G01 * T02 + G11 * T12);
-
-        // ---- camera-space mean
-        float fx = cam.fx, fy = cam.fy, rz = p.rz, rz2 = p.rz2, rz3 = p.rz2 * p.rz;
-        float vx = fx * rz * v_mx;
-        float vy = fy * rz * v_my;
-        float vz = -(fx * p.x * v_mx + fy * p.y * v_my) * rz2 + v_depth;
-        if (p.x_in) vx += -fx * rz2 * vJ02; else vz += -fx * rz3 * vJ02 * p.tx;
-        if (p.y_in) vy += -fy * rz2 * vJ12; else vz += -fy * rz3 * vJ12 * p.ty;
-        vz += -fx * rz2 * vJ00 - fy * rz2 * vJ11 + 2.f * fx * p.tx * rz3 * vJ02 + 2.f * fy * p.ty * rz3 * vJ12;
-        const float *R = cam.R;
-        vm[0] = R[0] * vx + R[3] * vy + R[6] * vz;
-        vm[1] = R[1] * vx + R[4] * vy + R[7] * vz;
-        vm[2] = R[2] * vx + R[5] * vy + R[8] * vz;
-        vm[0] += vdir[0]; vm[1] += vdir[1]; vm[2] += vdir[2];
-
-        // ---- Sigma_c = R Sigma R^T  ->  vSig = R^T vSc R
-        float U00 = vS00 * R[0] + vS01 * R[3] + vS02 * R[6], U01 = vS00 * R[1] + vS01 * R[4] + vS02 * R[7],
-              U02 = vS00 * R[2] + vS01 * R[5] + vS02 * R[8];
-        float U10 = vS01 * R[0] + vS11 * R[3] + vS12 * R[6], U11 = vS01 * R[1] + vS11 * R[4] + vS12 * R[7],
-              U12 = vS01 * R[2] + vS11 * R[5] + vS12 * R[8];
-        float U20 = vS02 * R[0] + vS12 * R[3] + vS22 * R[6], U21 = vS02 * R[1] + vS12 * R[4] + vS22 * R[7],
-              U22 = vS02 * R[2] + vS12 * R[5] + vS22 * R[8];
-        float W[9];
-        W[0] = R[0] * U00 + R[3] * U10 + R[6] * U20; W[1] = R[0] * U01 + R[3] * U11 + R[6] * U21;
-        W[2] = R[0] * U02 + R[3] * U12 + R[6] * U22;
-        W[3] = R[1] * U00 + R[4] * U10 + R[7] * U20; W[4] = R[1] * U01 + R[4] * U11 + R[7] * U21;
-        W[5] = R[1] * U02 + R[4] * U12 + R[7] * U22;
-        W[6] = R[2] * U00 + R[5] * U10 + R[8] * U20; W[7] = R[2] * U01 + R[5] * U11 + R[8] * U21;
-        W[8] = R[2] * U02 + R[5] * U12 + R[8] * U22;
-
-        // ---- Sigma = M M^T, M = Rq diag(s):  vM = 2 vSig M
-        const float *Rq = p.Rq;
-        float s[3] = {p.sx, p.sy, p.sz};
-        float vM[9];
-#pragma unroll
-        for (int r_ = 0; r_ < 3; ++r_)
-#pragma unroll
-            for (int c_ = 0; c_ < 3; ++c_)
-                vM[r_ * 3 + c_] = 2.f * (W[r_ * 3 + 0] * Rq[0 * 3 + c_] + W[r_ * 3 + 1] * Rq[1 * 3 + c_] +
-                                         W[r_ * 3 + 2] * Rq[2 * 3 + c_]) * s[c_];
-        float vR[9];
-#pragma unroll
-        for (int c_ = 0; c_ < 3; ++c_) {
-            vs[c_] = Rq[0 * 3 + c_] * vM[0 * 3 + c_] + Rq[1 * 3 + c_] * vM[1 * 3 + c_] + Rq[2 * 3 + c_] * vM[2 * 3 + c_];
-#pragma unroll
-            for (int r_ = 0; r_ < 3; ++r_) vR[r_ * 3 + c_] = vM[r_ * 3 + c_] * s[c_];
-        }
-        // ---- rotation matrix -> normalised quaternion -> raw quaternion
-        float w = p.qw, x = p.qx, y = p.qy, z = p.qz;
-        float gw = 2.f * (x * (vR[7] - vR[5]) + y * (vR[2] - vR[6]) + z * (vR[3] - vR[1]));
-        float gx = 2.f * (-2.f * x * (vR[4] + vR[8]) + y * (vR[1] + vR[3]) + z * (vR[2] + vR[6]) + w * (vR[7] - vR[5]));
-        float gy = 2.f * (-2.f * y * (vR[0] + vR[8]) + x * (vR[1] + vR[3]) + z * (vR[5] + vR[7]) + w * (vR[2] - vR[6]));
-        float gz = 2.f * (-2.f * z * (vR[0] + vR[4]) + x * (vR[2] + vR[6]) + y * (vR[5] + vR[7]) + w * (vR[3] - vR[1]));
-        float dotq = gw * w + gx * x + gy * y + gz * z;
-        vq[0] = (gw - dotq * w) * p.qinv; vq[1] = (gx - dotq * x) * p.qinv;
-        vq[2] = (gy - dotq * y) * p.qinv; vq[3] = (gz - dotq * z) * p.qinv;
+        project_chain_bwd(cam, g_mean, g_quat, g_scale, g_opac, width, height, v0, v1, v2, vdir, vm, vq, vs, vo);
 
     }
 
@@ -666,6 +676,161 @@ __global__ __launch_bounds__(kBlock, GSA_PROJ_BWD_WAVES) void project_bwd_kernel
             for (int k = 0; k < sh_coeffs * 3; ++k) row[k] = 0.f;
 #pragma unroll
         for (int k = 0; k < NB * 3; ++k) row[k] = vc[k] + (accumulate ? row[k] : 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward for the cameras of one optimisation step in ONE launch (gsa_project_bwd_batch)
+// ------------------------------------------------------------------------------------------------
+// The B views of a step are rendered from the same parameters and their gradients are summed.  One launch per view reads a
+// gaussian's geometry B times, read-modify-writes the geometry gradients B - 1 times and -- in the factored form the step
+// uses -- leaves 3 floats per view for one more kernel to expand into the 192-B coefficient gradient.  This kernel keeps the
+// gaussian in registers, runs the per-camera chain rule (project_chain_bwd: the single-camera kernel's arithmetic, summed in
+// camera order exactly as the accumulating launches sum) once per camera over that camera's gradient record and
+// coefficient digest, accumulates  sum_c basis_j(dir_c) x d loss / d rgb_c  in registers, and writes every gradient ONCE:
+// 760 B per gaussian at four cameras where four launches + gsa_sh_grad_expand move 1308.
+// View-dependent SH colour with the forward's digest only (sh_degree >= 1, sh_aux), rows of 16 coefficients.
+constexpr int kMaxBatchCams = 8;
+struct BwdCamRows {
+    const int32_t *radii[kMaxBatchCams];
+    const float *v_splat[kMaxBatchCams];
+    const float *sh_aux[kMaxBatchCams];
+};
+
+template <int DEG>
+__global__ __launch_bounds__(kBlock, 1) void project_bwd_batch_kernel(
+    int n, const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
+    const float *__restrict__ opacities, const float *__restrict__ viewmats, const float *__restrict__ intrins, int n_cams,
+    int intrin_stride, int width, int height, BwdCamRows rows_of, float *__restrict__ v_means, float *__restrict__ v_quats,
+    float *__restrict__ v_scales, float *__restrict__ v_opacities, float *__restrict__ v_colors, int accumulate) {
+    static_assert(DEG >= 1, "view-dependent colour only");
+    __shared__ float4 sh_lds[(kBlock / 64) * kWaveLds];   // rows out
+    const int wave = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    const long wave_base = (long)blockIdx.x * kBlock + wave * 64;
+    const long rows = min((long)64, (long)n - wave_base);
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    const bool active = i < n;
+    const long ic = active ? i : 0;   // (clamped, not predicated: every lane's loads are issued together)
+
+    float g_mean[3], g_quat[4], g_scale[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { g_mean[k] = means[ic * 3 + k]; g_scale[k] = scales[ic * 3 + k]; }
+    const float4 q4 = *reinterpret_cast<const float4 *>(quats + ic * 4);
+    g_quat[0] = q4.x; g_quat[1] = q4.y; g_quat[2] = q4.z; g_quat[3] = q4.w;
+    const float g_opac = opacities[ic];
+
+    // one camera's rows of this gaussian: radii, gradient record, coefficient digest -- loaded one camera AHEAD of the chain
+    struct CamRow { int rx, ry; float4 v0, v1, v2, a0, a1, a2; };
+    auto load_cam = [&](int ci) -> CamRow {
+        CamRow r;
+        const int2 rr = *reinterpret_cast<const int2 *>(rows_of.radii[ci] + 2 * ic);
+        r.rx = rr.x; r.ry = rr.y;
+        const float4 *vrow = reinterpret_cast<const float4 *>(rows_of.v_splat[ci] + ic * GSA_SPLAT_STRIDE);
+        r.v0 = vrow[0]; r.v1 = vrow[1]; r.v2 = vrow[2];
+        const float4 *arow = reinterpret_cast<const float4 *>(rows_of.sh_aux[ci]) + ic * 3;
+        r.a0 = arow[0]; r.a1 = arow[1]; r.a2 = arow[2];
+        return r;
+    };
+    CamRow cur = load_cam(0);
+
+    float sm[3] = {0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f}, ss[3] = {0.f, 0.f, 0.f}, so = 0.f;
+    float vc[NB * 3];
+#pragma unroll
+    for (int k = 0; k < NB * 3; ++k) vc[k] = 0.f;
+
+    for (int ci = 0; ci < n_cams; ++ci) {
+        CamRow nxt = cur;
+        if (ci + 1 < n_cams) nxt = load_cam(ci + 1);   // (uniform)
+        if (active && cur.rx > 0 && cur.ry > 0) {
+            GsaCamera cam = gsa_load_camera(viewmats + 16 * ci, intrins + (long)intrin_stride * ci);
+            const float4 v0 = cur.v0, v1 = cur.v1, v2 = cur.v2;
+            const float v_rgb[3] = {v1.z, v1.w, v2.x};
+            // ---- colour first (as the single-camera kernel): d loss / d rgb after the clamp mask, the view-direction part of
+            // the mean gradient from the digest, and this camera's share of the coefficient gradient
+            float vdir[3];
+            {
+                const float dx = g_mean[0] - cam.campos[0], dy = g_mean[1] - cam.campos[1], dz = g_mean[2] - cam.campos[2];
+                const float inv = rsqrtf(dx * dx + dy * dy + dz * dz);
+                float B[NB];
+                gsa_sh_basis<DEG>(dx * inv, dy * inv, dz * inv, B);
+                const float vr[3] = {cur.a0.w != 0.f ? v_rgb[0] : 0.f, cur.a1.w != 0.f ? v_rgb[1] : 0.f,
+                                     cur.a2.w != 0.f ? v_rgb[2] : 0.f};
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    vc[3 * j] = __builtin_fmaf(B[j], vr[0], vc[3 * j]);
+                    vc[3 * j + 1] = __builtin_fmaf(B[j], vr[1], vc[3 * j + 1]);
+                    vc[3 * j + 2] = __builtin_fmaf(B[j], vr[2], vc[3 * j + 2]);
+                }
+                vdir[0] = cur.a0.x * vr[0] + cur.a1.x * vr[1] + cur.a2.x * vr[2];
+                vdir[1] = cur.a0.y * vr[0] + cur.a1.y * vr[1] + cur.a2.y * vr[2];
+                vdir[2] = cur.a0.z * vr[0] + cur.a1.z * vr[1] + cur.a2.z * vr[2];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from interleaving the two chains: register pressure)
+            float vm[3], vq[4], vs[3], vo;
+            project_chain_bwd(cam, g_mean, g_quat, g_scale, g_opac, width, height, v0, v1, v2, vdir, vm, vq, vs, vo);
+            // summed in camera order, as the accumulating single-camera launches sum
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { sm[k] += vm[k]; ss[k] += vs[k]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sq[k] += vq[k];
+            so += vo;
+        }
+        cur = nxt;
+    }
+
+    if (active) {
+        if (accumulate) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { sm[k] += v_means[i * 3 + k]; ss[k] += v_scales[i * 3 + k]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sq[k] += v_quats[i * 4 + k];
+            so += v_opacities[i];
+        }
+        v_means[i * 3] = sm[0]; v_means[i * 3 + 1] = sm[1]; v_means[i * 3 + 2] = sm[2];
+        v_quats[i * 4] = sq[0]; v_quats[i * 4 + 1] = sq[1]; v_quats[i * 4 + 2] = sq[2]; v_quats[i * 4 + 3] = sq[3];
+        v_scales[i * 3] = ss[0]; v_scales[i * 3 + 1] = ss[1]; v_scales[i * 3 + 2] = ss[2];
+        v_opacities[i] = so;
+    }
+
+    // ---- the coefficient-gradient rows leave through the wave's LDS image, 32 whole rows a pass (as the single-camera kernel)
+    float4 *wrows = &sh_lds[wave * kWaveLds];
+    float4 *dst = reinterpret_cast<float4 *>(v_colors) + wave_base * kRowQ;
+    auto elem = [&](int e) { return e < NB * 3 ? vc[e] : 0.f; };
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    constexpr int NPL = kPassRows * kRowQ / 64;   // 6 float4 per lane and pass
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if (p == 1) wave_lds_sync();   // the first 32 rows have left
+        if ((lane >> 5) == p) {
+#pragma unroll
+            for (int q = 0; q < kRowQ; ++q)
+                wrows[(lane & 31) * kRowPad + q] = make_float4(elem(4 * q), elem(4 * q + 1), elem(4 * q + 2), elem(4 * q + 3));
+        }
+        wave_lds_sync();
+        const int live = (int)rows - p * kPassRows;   // rows of this pass that exist (wave-uniform)
+        float old[4 * NPL];
+        if (accumulate && live > 0) {   // (rows clamped, not predicated: all six loads in flight at once)
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                const int idx = k * 64 + lane, r_ = min(idx / kRowQ, live - 1), c_ = idx % kRowQ;
+                const float4 o = dst[(p * kPassRows + r_) * kRowQ + c_];
+                old[4 * k] = o.x; old[4 * k + 1] = o.y; old[4 * k + 2] = o.z; old[4 * k + 3] = o.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4 * NPL; ++k) old[k] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const int idx = k * 64 + lane, r_ = idx / kRowQ, c_ = idx - r_ * kRowQ;
+            if (r_ < live) {
+                float4 v = wrows[r_ * kRowPad + c_];
+                v.x += old[4 * k]; v.y += old[4 * k + 1]; v.z += old[4 * k + 2]; v.w += old[4 * k + 3];
+                dst[(p * kPassRows) * kRowQ + idx] = v;
+            }
+        }
     }
 }
 
@@ -1015,4 +1180,44 @@ extern "C" int gsa_sh_grad_expand_split(int n, const float *means, int sh_degree
                                         float *v_rest, gsa_stream_t stream) {
     GSA_RETURN_IF(n > 0 && (!v_rest || sh_coeffs < 2), GSA_ERR_INVALID_ARGUMENT);
     return sh_grad_expand_impl(n, means, sh_degree, sh_coeffs, n_views, viewmats, intrin, v_rgb, v_dc, 0, v_rest, stream);
+}
+
+extern "C" int gsa_project_bwd_batch(int n, const float *means, const float *quats, const float *scales,
+                                     const float *opacities, int sh_degree, int sh_coeffs, int n_cams, const float *viewmats,
+                                     const float *intrins, int intrin_stride, int width, int height,
+                                     const int32_t *const *radii, const float *const *v_splat, const float *const *sh_aux,
+                                     float *v_means, float *v_quats, float *v_scales, float *v_opacities, float *v_colors,
+                                     int accumulate, gsa_stream_t stream) {
+    GSA_RETURN_IF(n < 0 || width <= 0 || height <= 0 || n_cams < 1 || (intrin_stride != 0 && intrin_stride != 9),
+                  GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(sh_degree < 1 || sh_degree > 3 || sh_coeffs != 16 || n_cams > kMaxBatchCams, GSA_ERR_UNSUPPORTED);
+    if (n == 0) return GSA_OK;
+    GSA_RETURN_IF(!means || !quats || !scales || !opacities || !viewmats || !intrins || !radii || !v_splat || !sh_aux ||
+                      !v_means || !v_quats || !v_scales || !v_opacities || !v_colors,
+                  GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF((reinterpret_cast<uintptr_t>(v_colors) & 15) != 0 || (reinterpret_cast<uintptr_t>(quats) & 15) != 0,
+                  GSA_ERR_INVALID_ARGUMENT);
+    BwdCamRows rows{};
+    for (int c = 0; c < kMaxBatchCams; ++c) {   // (unused slots repeat the last camera: never read)
+        const int k = c < n_cams ? c : n_cams - 1;
+        GSA_RETURN_IF(!radii[k] || !v_splat[k] || !sh_aux[k], GSA_ERR_INVALID_ARGUMENT);
+        GSA_RETURN_IF(((reinterpret_cast<uintptr_t>(v_splat[k]) | reinterpret_cast<uintptr_t>(sh_aux[k])) & 15) != 0 ||
+                          (reinterpret_cast<uintptr_t>(radii[k]) & 7) != 0,
+                      GSA_ERR_INVALID_ARGUMENT);
+        rows.radii[c] = radii[k]; rows.v_splat[c] = v_splat[k]; rows.sh_aux[c] = sh_aux[k];
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dim3 grid(gsa_div_up(n, kBlock)), block(kBlock);
+#define GSA_BWDB(D)                                                                                                        \
+    project_bwd_batch_kernel<D><<<grid, block, 0, s>>>(n, means, quats, scales, opacities, viewmats, intrins, n_cams,      \
+                                                       intrin_stride, width, height, rows, v_means, v_quats, v_scales,    \
+                                                       v_opacities, v_colors, accumulate ? 1 : 0)
+    switch (sh_degree) {
+        case 1: GSA_BWDB(1); break;
+        case 2: GSA_BWDB(2); break;
+        default: GSA_BWDB(3); break;
+    }
+#undef GSA_BWDB
+    GSA_LAUNCH_CHECK();
+    return GSA_OK;
 }

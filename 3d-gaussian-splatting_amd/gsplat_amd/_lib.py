@@ -62,6 +62,8 @@ SIGNATURES = {
     "gsa_step_report": (c_int, [c_int, P, P, c_double, c_int, P, c_longlong, c_double, c_int, P, P]),
     "gsa_project_bwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, P, P, P, P, P, P, P, P, P, P]),
     "gsa_project_bwd_factored": (c_int, [c_int, P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, P, P, P, P, P, P, P, P, c_int, P, P]),
+    "gsa_project_bwd_batch": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P,
+                                      c_int, P]),
     "gsa_sh_grad_expand_split": (c_int, [c_int, P, c_int, c_int, c_int, P, P, P, P, P, P]),
     "gsa_activate_fwd": (c_int, [c_longlong, P, P, P, P, P, P, P, P, P, P]),
     "gsa_activate_partials": (c_size_t, [c_longlong]),

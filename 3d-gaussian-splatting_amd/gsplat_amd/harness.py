@@ -595,8 +595,15 @@ class ViewParallelTrainer:
         _, g_quats, g_scales, g_opac = self._act_grad
         grad_out = [g_means, g_quats, g_scales, g_opac, g_shs]
         leaves = [m.xyz.detach(), quats, scales, opac, shs]
-        factored = self.factored
         mine = list(batch[self.rank::self.world])
+        # The views of the step share their gaussians: ONE projection launch for all of them reads every gaussian's geometry
+        # and coefficient row once (stages.project_views); views of different frame sizes are projected one by one.  In one
+        # process their projection BACKWARD is one launch as well, behind the last sweep (stages.project_views_bwd: geometry
+        # read once, every gradient written once, the coefficient gradient formed in registers -- no per-view rgb gradients
+        # and no expansion kernel).  With several ranks the per-view factored form stays: its gathers overlap the next view.
+        same_frame = len(mine) > 1 and len({(v["width"], v["height"]) for v in mine}) == 1
+        batch_bwd = same_frame and self.world == 1 and degree >= 1 and len(mine) <= 8 and m.sh.shape[1] == 16
+        factored = self.factored and not batch_bwd
         if factored:  # slot (r, j) = the j-th view of rank r; ranks with fewer views leave zeros (skipped by the expand)
             slots = -(-n_views // self.world)
             vr_all = torch.empty(self.world, slots, n, 3, device=dev)   # (every slot of a view is written whole by its backward)
@@ -632,15 +639,32 @@ class ViewParallelTrainer:
         params_ready = torch.cuda.Event()              # (behind everything the views read that this stream prepared)
         params_ready.record(main)
 
-        def front(view, exact):
-            pose = view["pose"].to(torch.float32).contiguous()
+        shared = {}
+
+        def prepare():
+            poses = torch.stack([v["pose"].to(dev, torch.float32) for v in mine]).contiguous()
+            shared["views"] = S.project_views(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], degree, poses, Kc,
+                                              mine[0]["width"], mine[0]["height"], cull, return_aux=True)
+            p0 = shared["views"][0]
+            return [t._base if t._base is not None else t for t in
+                    (p0.splat, p0.radii, p0.tiles_touched, p0.depth_keys, p0.tile_rects, p0.sh_aux, p0.key_range, p0.qbox)
+                    if t is not None]
+
+        def front(j, exact):
+            view = mine[j]
             W, H = view["width"], view["height"]
             bt = S.bin_tile_for(W, H, cull)   # 32 x 32 bins where the fused binning applies
-            kr = S.key_range_buffer(leaves[0].shape[0], dev)   # the view's depth-key range: the depth ordering plans its buckets from it
-            qb = S.qbox_buffer(leaves[0].shape[0], dev)        # the gaussians' quadrant boxes: the forward sweep's masks
-            splat, radii, tiles, keys, rects, aux = S.project_fwd(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4],
-                                                                  degree, pose, Kc, W, H, cull, return_rects=True,
-                                                                  return_aux=True, bin_tile=bt, key_range=kr, qbox=qb)
+            if "views" in shared:
+                pv = shared["views"][j]
+                pose, kr, qb = pv.viewmat, pv.key_range, pv.qbox
+                splat, radii, tiles, keys, rects, aux = pv.splat, pv.radii, pv.tiles_touched, pv.depth_keys, pv.tile_rects, pv.sh_aux
+            else:
+                pose = view["pose"].to(torch.float32).contiguous()
+                kr = S.key_range_buffer(leaves[0].shape[0], dev)   # the view's depth-key range: the depth ordering plans its buckets from it
+                qb = S.qbox_buffer(leaves[0].shape[0], dev)        # the gaussians' quadrant boxes: the forward sweep's masks
+                splat, radii, tiles, keys, rects, aux = S.project_fwd(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4],
+                                                                      degree, pose, Kc, W, H, cull, return_rects=True,
+                                                                      return_aux=True, bin_tile=bt, key_range=kr, qbox=qb)
             bins = S.bin_tiles(splat, radii, tiles, keys, W, H, cull, tile_rects=rects, exact=exact, bin_tile=bt,
                                key_range=kr, qbox=qb)
             order = S.tile_schedule(bins.tile_offsets, W, H, bt)
@@ -651,9 +675,9 @@ class ViewParallelTrainer:
             from .pipeline import ViewState
             view = mine[j]
             W, H = view["width"], view["height"]
-            pose, splat, radii, bins, order, aux = front(view, exact=False)
+            pose, splat, radii, bins, order, aux = front(j, exact=False)
             if not deferred and not bins.finalize()[1]:   # (a remembered capacity / key range did not hold: exact sizes)
-                pose, splat, radii, bins, order, aux = front(view, exact=True)
+                pose, splat, radii, bins, order, aux = front(j, exact=True)
                 bins.finalize()
             bt = bins.bin_tile
             render, _, final_T, last_id, lists = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bgc, W,
@@ -670,13 +694,24 @@ class ViewParallelTrainer:
             W, H = view["width"], view["height"]
             v_splat = S.composite_bwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bgc, final_T, last_id, v, None,
                                       W, H, 3, order, quad_lists=lists, bin_tile=bins.bin_tile, gid_boxes=bins.boxed)
+            if batch_bwd:   # (finished for all views at once, below)
+                shared.setdefault("v_splat", {})[j] = v_splat
+                return
             if before_bucket is not None:   # (the bucket is summed into in view order)
                 torch.cuda.current_stream().wait_event(before_bucket)
             S.project_bwd(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], degree, pose, Kc, W, H, splat, radii,
                           v_splat, out=grad_out, accumulate=j > 0,
                           v_rgb_out=vr_all[self.rank, j] if factored else None, sh_aux=aux)
 
-        self._pipe.run(len(mine), forward, backward, inputs_ready=params_ready, defer=not exact)
+        def finish():
+            ok = S.project_views_bwd(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], degree, shared["views"],
+                                     [shared["v_splat"][j] for j in range(len(mine))], mine[0]["width"], mine[0]["height"],
+                                     grad_out)
+            assert ok, "project_views_bwd refused a configuration batch_bwd admitted"
+            shared.pop("v_splat")
+
+        self._pipe.run(len(mine), forward, backward, inputs_ready=params_ready, defer=not exact,
+                       prepare=prepare if same_frame else None, finish=finish if batch_bwd else None)
         first = not mine
         if first:                                          # this rank rendered nothing
             m.flat_grad.zero_()

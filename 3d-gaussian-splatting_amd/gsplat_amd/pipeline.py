@@ -51,7 +51,8 @@ class ViewPipeline:
             backward: Callable[[int, ViewState, Optional[torch.cuda.Event]], None], *,
             after_view: Optional[Callable[[int], None]] = None, agree: Optional[Callable[[bool], bool]] = None,
             inputs_ready: Optional[torch.cuda.Event] = None, defer: bool = True,
-            prepare: Optional[Callable[[], Sequence[torch.Tensor]]] = None) -> Sequence[ViewState]:
+            prepare: Optional[Callable[[], Sequence[torch.Tensor]]] = None,
+            finish: Optional[Callable[[], None]] = None) -> Sequence[ViewState]:
         """Queues ``n_views`` views, forward + backward each, and returns their states once the step is known good.
 
         ``forward(j, deferred)``: queue view j's front end and forward sweep (and whatever sits between the sweeps, e.g. the
@@ -66,6 +67,8 @@ class ViewPipeline:
         ``prepare()``: what the step's views SHARE, queued once in front of the first view on its stream -- the projection of
         the gaussians for all cameras of the step in one launch (``project_cameras``); the other streams wait for it.  It
         returns the tensors it allocated: they are used on every stream of the pipeline, which the allocator is told.
+        ``finish()``: queued once on the caller's stream behind ALL views' backward passes -- the projection backward of
+        all cameras in one launch (``project_cameras_backward``) when the views' own backward passes stop behind their sweeps.
         """
         self.steps += 1
         main = torch.cuda.current_stream()
@@ -112,6 +115,8 @@ class ViewPipeline:
             states.append(state)
         for ev in done:
             main.wait_event(ev)
+        if finish is not None:
+            finish()
         if use:
             self._step_done = torch.cuda.Event()
             self._step_done.record(main)
@@ -121,7 +126,8 @@ class ViewPipeline:
                 ok = agree(ok)
             if not ok:
                 self.repairs += 1
-                return self.run(n_views, forward, backward, after_view=after_view, agree=None, inputs_ready=None, defer=False)
+                return self.run(n_views, forward, backward, after_view=after_view, agree=None, inputs_ready=None, defer=False,
+                                finish=finish)
         return states
 
     def mark_bucket_used(self) -> None:

@@ -91,6 +91,9 @@ class _RasterizeOneCamera(torch.autograd.Function):
         ctx.grad_accumulate = bool(grad_accumulate)
         ctx.sh_grad_factored = sh_grad_factored
         ctx.in_shapes = (means.shape, quats.shape, scales.shape, opacities.shape, colors.shape)
+        # (project_cameras(defer_backward=True): this camera's backward pass stops behind the sweep and leaves its gradient
+        # record with the projection; project_cameras_backward finishes all cameras of the step in one launch)
+        ctx.deferred_projection = projection if (projection is not None and projection.defer_backward) else None
         extras = (splat, radii, tiles_touched, sorted_tile, sorted_gid, tile_offsets, last_id)
         ctx.mark_non_differentiable(*extras)
         ctx.set_materialize_grads(False)  # no zero tensors for the seven outputs nobody differentiates
@@ -112,6 +115,9 @@ class _RasterizeOneCamera(torch.autograd.Function):
         v_splat = S.composite_bwd(splat, sorted_gid, tile_offsets, bg_c, final_T, last_id, v_render, v_alpha_c,
                                   width, height, channels, tile_order,
                                   quad_lists=lists, bin_tile=ctx.bin_tile, gid_boxes=ctx.gid_boxes)
+        if ctx.deferred_projection is not None:
+            ctx.deferred_projection.v_splat = v_splat
+            return (None,) * 18
         grads = S.project_bwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
                               splat, radii, v_splat, out=ctx.grad_out, accumulate=ctx.grad_accumulate,
                               v_rgb_out=ctx.sh_grad_factored, sh_aux=sh_aux)
@@ -123,21 +129,53 @@ class _RasterizeOneCamera(torch.autograd.Function):
 
 
 def project_cameras(means, quats, scales, opacities, colors, viewmats, Ks, width: int, height: int,
-                    sh_degree: Optional[int] = None, cull_mode: Optional[int] = None, for_backward: Optional[bool] = None):
+                    sh_degree: Optional[int] = None, cull_mode: Optional[int] = None, for_backward: Optional[bool] = None,
+                    defer_backward: bool = False):
     """The projection stage of ``rasterization`` for the C cameras of ``viewmats`` [C,4,4] in ONE launch (same argument
     meaning as there; ``Ks`` [C,3,3] or [3,3]) -> a list of C per-camera projections for ``rasterization(projection=...)``.
     What it is for: the B views of an optimisation step are rendered from the same parameters
     (/root/reference/src/training/trainer.py:458-506), so their projections can share the read of every gaussian's
     geometry and SH coefficient row -- 236 of the 376 bytes a single-camera projection moves per gaussian.
     ``for_backward`` (default: any input requires grad): also leave the 48-B digest of each coefficient row the backward
-    projection reads instead of the row."""
+    projection reads instead of the row.
+    ``defer_backward``: the backward pass of a ``rasterization(projection=...)`` call then stops behind its sweep (its
+    ``grad_out`` / ``sh_grad_factored`` arguments are not used, the inputs get no ``.grad``), and
+    ``project_cameras_backward`` finishes ALL cameras in one launch: geometry read once, every gradient written once.
+    Needs SH colours of degree >= 1 with [N,16,3] rows; otherwise the flag is dropped and every camera's backward is its own."""
     deg = -1 if sh_degree is None else int(sh_degree)
     cull = S.DEFAULT_CULL_MODE if cull_mode is None else int(cull_mode)
     if for_backward is None:
         for_backward = any(t.requires_grad for t in (means, quats, scales, opacities, colors))
-    return S.project_views(S.f32c(means, "means"), S.f32c(quats, "quats"), S.f32c(scales, "scales"),
-                           S.f32c(opacities, "opacities"), S.f32c(colors, "colors"), deg, viewmats, Ks, int(width), int(height),
-                           cull, return_aux=bool(for_backward))
+    views = S.project_views(S.f32c(means, "means"), S.f32c(quats, "quats"), S.f32c(scales, "scales"),
+                            S.f32c(opacities, "opacities"), S.f32c(colors, "colors"), deg, viewmats, Ks, int(width), int(height),
+                            cull, return_aux=bool(for_backward))
+    can_defer = bool(defer_backward) and deg >= 1 and colors.dim() == 3 and colors.shape[1] == 16 and len(views) <= 8 and \
+        all(v.sh_aux is not None for v in views)
+    for v in views:
+        v.defer_backward, v.v_splat = can_defer, None
+    return views
+
+
+def project_cameras_backward(projections, means, quats, scales, opacities, colors, grad_out, accumulate: bool = False) -> None:
+    """Finishes the backward passes of the cameras of ``project_cameras(defer_backward=True)`` in ONE launch, once every
+    camera's ``rasterization(projection=...)`` output has been backpropagated (on the current stream, or on streams the
+    current one has been made to wait for): the gradients of the five inputs, SUMMED over the cameras, are written into
+    ``grad_out`` = (means, quats, scales, opacities [N], colors [N,16,3] shaped tensors; ``accumulate``: added to them).
+    What it saves against one projection backward per camera: the geometry is read once instead of once per camera, no
+    gradient is read back and added to, and the SH-coefficient gradient -- sum over the cameras of basis(direction) x
+    d loss / d rgb -- is formed in registers instead of by an expansion kernel."""
+    if not projections or not all(p.defer_backward for p in projections):
+        raise ValueError("project_cameras_backward: needs the projections of project_cameras(defer_backward=True)")
+    if any(p.v_splat is None for p in projections):
+        raise RuntimeError("project_cameras_backward: a camera's output has not been backpropagated yet")
+    width, height, _, deg = projections[0].dims
+    done = S.project_views_bwd(S.f32c(means, "means"), S.f32c(quats, "quats"), S.f32c(scales, "scales"),
+                               S.f32c(opacities, "opacities"), S.f32c(colors, "colors"), deg, projections,
+                               [p.v_splat for p in projections], width, height, grad_out, accumulate=accumulate)
+    if not done:
+        raise RuntimeError("project_cameras_backward: the batched kernel does not cover this configuration")
+    for p in projections:
+        p.v_splat = None
 
 
 def rasterization(

@@ -267,7 +267,7 @@ class ViewProjection:
     a key range and quadrant boxes): what the binning, the sweeps and ``project_bwd`` of that view need."""
 
     __slots__ = ("splat", "radii", "tiles_touched", "depth_keys", "tile_rects", "sh_aux", "key_range", "qbox", "viewmat",
-                 "Kmat", "bin_tile", "dims")
+                 "Kmat", "bin_tile", "dims", "defer_backward", "v_splat")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -302,7 +302,39 @@ def project_views(means, quats, scales, opacities, colors, sh_degree: int, viewm
     return [ViewProjection(splat=splat[c], radii=radii[c], tiles_touched=tiles_touched[c], depth_keys=depth_keys[c],
                            tile_rects=tile_rects[c], sh_aux=None if sh_aux is None else sh_aux[c], key_range=key_range[c],
                            qbox=None if qbox is None else qbox[c], viewmat=vm[c], Kmat=km[c] if km.dim() == 3 else km,
-                           bin_tile=bt, dims=(width, height, cull_mode, sh_degree)) for c in range(C)]
+                           bin_tile=bt, dims=(width, height, cull_mode, sh_degree), defer_backward=False, v_splat=None)
+            for c in range(C)]
+
+
+def project_views_bwd(means, quats, scales, opacities, colors, sh_degree: int, views, v_splats, width: int, height: int,
+                      out, accumulate: bool = False) -> bool:
+    """The backward projection of ALL of ``views`` (``ViewProjection``s of one ``project_views`` call, or any per-camera
+    projections with digests) in ONE launch (``gsa_project_bwd_batch``): ``v_splats[c]`` is camera c's gradient record from
+    ``composite_bwd``; ``out`` = (v_means, v_quats, v_scales, v_opacities, v_colors) receives the gradients summed over the
+    cameras -- written once (``accumulate``: added).  -> False (nothing launched) where the batched kernel does not apply
+    (no digests: SH degree < 1; more than 8 cameras; coefficient rows that are not [N,16,3]): the caller then runs
+    ``project_bwd`` per camera."""
+    C = len(views)
+    if C < 1 or C > 8 or sh_degree < 1 or colors.dim() != 3 or colors.shape[1] != 16 or any(v.sh_aux is None for v in views):
+        return False
+    N = means.shape[0]
+    v_means, v_quats, v_scales, v_opac, v_colors = out
+    for got, like in zip(out, (means, quats, scales, opacities, colors)):
+        if got.numel() != like.numel() or got.dtype != torch.float32 or not got.is_contiguous() or got.device != like.device:
+            raise ValueError("project_views_bwd: out tensors must be contiguous fp32, sized like the inputs, on their device")
+    vms = torch.stack([v.viewmat for v in views]).contiguous()
+    shared_k = all(v.Kmat is views[0].Kmat or v.Kmat.data_ptr() == views[0].Kmat.data_ptr() for v in views)
+    kms = views[0].Kmat.contiguous() if shared_k else torch.stack([v.Kmat for v in views]).contiguous()
+    keep = [f32c(v, "v_splat") for v in v_splats]
+    arr = ctypes.c_void_p * C
+    radii = arr(*[v.radii.data_ptr() for v in views])
+    vsp = arr(*[t.data_ptr() for t in keep])
+    aux = arr(*[v.sh_aux.data_ptr() for v in views])
+    _call("gsa_project_bwd", lib.gsa_project_bwd_batch, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), sh_degree,
+          int(colors.shape[1]), C, _ptr(vms), _ptr(kms), 0 if shared_k else 9, width, height,
+          ctypes.cast(radii, ctypes.c_void_p), ctypes.cast(vsp, ctypes.c_void_p), ctypes.cast(aux, ctypes.c_void_p),
+          _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac), _ptr(v_colors), 1 if accumulate else 0, _stream())
+    return True
 
 
 def sort_pairs(n: int, keys: torch.Tensor, vals: Optional[torch.Tensor], begin_bit: int, end_bit: int):

@@ -304,6 +304,9 @@ def main() -> None:
     ap.add_argument("--no-batch-projection", action="store_true",
                     help="project the gaussians once per view instead of once per step for all its views "
                          "(gsplat_amd.project_cameras: geometry and SH rows read once)")
+    ap.add_argument("--no-batch-backward", action="store_true",
+                    help="one projection backward per view (+ the SH expansion) instead of one launch for all views of the step "
+                         "(gsplat_amd.project_cameras_backward; single process only)")
     ap.add_argument("--dump-grad", default=None,
                     help="(tests) rank 0 saves the gradient bucket of the last step of the timed region to this .pt file")
     ap.add_argument("--profile-run", action="store_true",
@@ -400,16 +403,20 @@ def main() -> None:
         backward each, their gradients summed into the bucket, then the exchange.  form: "factored" | "allreduce".
         The views are queued by the product's own orchestrator (gsplat_amd.pipeline.ViewPipeline): alternating streams,
         bucket summed in view order, the speculation of all views checked once behind the last one."""
+        # the projection of the gaussians for all views of the step in ONE launch (their geometry and coefficient rows
+        # read once), queued in front of the first view; --no-batch-projection: one projection launch per view
+        batch_proj = views > 1 and not args.no_batch_projection
+        # ... and, in one process, their projection BACKWARD in one launch behind the last sweep (geometry read once, every
+        # gradient written once, the SH-coefficient gradient formed in registers: no per-view rgb gradients, no expansion
+        # kernel).  With several ranks the per-view factored form stays: its all-gathers travel under the next view.
+        batch_bwd = batch_proj and dist is None and deg >= 1 and not args.no_batch_backward
         # one process, one view: nothing to sum, the backward writes the whole gradient itself
-        factored = form == "factored" and (world > 1 or views > 1)
+        factored = form == "factored" and (world > 1 or views > 1) and not batch_bwd
         ex = Exchange(dist, world, rank, n, views, factored, dev, expand=stages.sh_grad_expand)
         pipe = ViewPipeline(dev, n_streams)
         cams, windows = (ring(ring_size) if cams_override is None else cams_override), {}
         defer = views > 1 and not args.no_defer_check   # the views' speculation is checked once per step, behind the last view
 
-        # the projection of the gaussians for all views of the step in ONE launch (their geometry and coefficient rows
-        # read once), queued in front of the first view; --no-batch-projection: one projection launch per view
-        batch_proj = views > 1 and not args.no_batch_projection
         shared, step_cams = {}, {}
 
         def step(i: int = 0):
@@ -424,7 +431,7 @@ def main() -> None:
                     step_cams[base] = cams[idx].contiguous()
                 shared["proj"] = gsplat_amd.project_cameras(leaves[0], leaves[1], leaves[2], opac.squeeze(-1), leaves[4],
                                                             step_cams[base], K[0], width, height, sh_degree=deg,
-                                                            cull_mode=args.cull_mode)
+                                                            cull_mode=args.cull_mode, defer_backward=batch_bwd)
                 p0 = shared["proj"][0]
                 return [t._base if t._base is not None else t for t in
                         (p0.splat, p0.radii, p0.tiles_touched, p0.depth_keys, p0.tile_rects, p0.sh_aux, p0.key_range, p0.qbox)
@@ -457,8 +464,12 @@ def main() -> None:
                     marks["x0"].record()
                 ex.after_view(j)
 
+            def finish():   # the projection backward of all views of the step: one launch, straight into the bucket
+                gsplat_amd.project_cameras_backward(shared["proj"], leaves[0], leaves[1], leaves[2], opac.squeeze(-1), leaves[4],
+                                                    grad_views)
+
             pipe.run(views, forward, backward, after_view=after_view, agree=agree if dist is not None else None, defer=defer,
-                     prepare=prepare if batch_proj else None)
+                     prepare=prepare if batch_proj else None, finish=finish if batch_bwd else None)
             if factored or dist is not None:
                 if base not in windows:   # the cameras of the step's views, entry j * world + r = rank r's view j
                     windows[base] = cams[(base + torch.arange(views * world, device=dev)) % ring_size].contiguous()
@@ -682,6 +693,10 @@ def main() -> None:
                                        ", RCCL all-reduce of 59N-float grads") if world > 1 else ""),
                        "views_per_gpu_per_step": B, "view_streams": n_streams,
                        "overlap": ("alternate" if n_streams > 1 else "none"),
+                       # what the views of a step share: one projection launch (and, in one process, one projection-backward
+                       # launch) for all of them -- gsplat_amd.project_cameras / project_cameras_backward
+                       "projection": ("per step: %s" % ("forward + backward" if (world == 1 and deg >= 1 and not args.no_batch_backward)
+                                                        else "forward")) if (B > 1 and not args.no_batch_projection) else "per view",
                        "speculation_check": ("per step, repairs: %d" % head_step.pipe.repairs) if B > 1 and not args.no_defer_check else "per view",
                        "ms_per_view": round(ms_per_view, 4),
                        "intersections_M": m, "bin_tile": stages.bin_tile_for(width, height, stages.DEFAULT_CULL_MODE if args.cull_mode is None else args.cull_mode), "binned_records": info.get("binned"),

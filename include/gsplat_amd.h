@@ -362,6 +362,23 @@ int gsa_sh_grad_expand(int n, const float *means, int sh_degree, int sh_coeffs, 
                        const float *viewmats, const float *intrin, const float *v_rgb, float *v_colors,
                        int accumulate, gsa_stream_t stream);
 
+/* ABI 12 -- the backward projection for the n_cams cameras of one optimisation step in ONE launch, the counterpart of
+ * gsa_project_fwd_batch: per camera the chain rule of gsa_project_bwd on that camera's gradient record and coefficient
+ * digest, the geometry gradients SUMMED over the cameras in camera order (the sums a chain of gsa_project_bwd_acc calls
+ * leaves) and the SH-coefficient gradient  sum_c basis(dir_c) (x) d loss / d rgb_c  -- what gsa_project_bwd_factored per
+ * camera + gsa_sh_grad_expand rebuild -- every output element written once (accumulate != 0: added to what the buffers hold).
+ * radii / v_splat / sh_aux: HOST arrays of n_cams DEVICE pointers (camera c's radii [N,2], gradient records [N,16] from
+ * gsa_composite_bwd*, digests [N,12] from gsa_project_fwd*); viewmats / intrins / intrin_stride as gsa_project_fwd_batch.
+ * A gaussian's geometry is read once and its gradients are written once: 760 B per gaussian at four cameras where four
+ * launches and the expansion move 1308.  GSA_ERR_UNSUPPORTED unless 1 <= sh_degree <= 3, sh_coeffs == 16 and n_cams <= 8
+ * (the caller then runs the per-camera entry points). */
+int gsa_project_bwd_batch(int n, const float *means, const float *quats, const float *scales,
+                          const float *opacities, int sh_degree, int sh_coeffs, int n_cams, const float *viewmats,
+                          const float *intrins, int intrin_stride, int width, int height,
+                          const int32_t *const *radii, const float *const *v_splat, const float *const *sh_aux,
+                          float *v_means, float *v_quats, float *v_scales, float *v_opacities, float *v_colors,
+                          int accumulate, gsa_stream_t stream);
+
 /* gsa_sh_grad_expand with the output split the way the reference model stores the coefficients: v_dc [N,1,3] and
  * v_rest [N, sh_coeffs - 1, 3] (both overwritten). */
 int gsa_sh_grad_expand_split(int n, const float *means, int sh_degree, int sh_coeffs, int n_views,

@@ -77,7 +77,11 @@ def main():
         return S.composite_bwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg, final_T, last_id, v_render, None, W, H,
                                3, order, quad_lists=lists, bin_tile=bt, gid_boxes=bins.boxed)
 
+    skip = {"back": False}
+
     def back(j, f, v_splat):
+        if skip["back"]:
+            return
         splat, radii, bins, order, aux = f
         S.project_bwd(means, quats, scales, opac, shs, deg, cams[j], K, W, H, splat, radii, v_splat, out=grad_out,
                       accumulate=j > 0, v_rgb_out=vr[j], sh_aux=aux)
@@ -247,7 +251,17 @@ def main():
                 emu["on"] = False
         return run
 
+    def noback(fn):
+        def run():
+            skip["back"] = True
+            try:
+                return fn()
+            finally:
+                skip["back"] = False
+        return run
+
     variants = {
+        "noP2 emuP1 alt2": noback(emulated(lambda: step_alt(2))),
         "emuP1 phased f2 b1": emulated(lambda: step_phased(2, 1)),
         "emuP1 alt2": emulated(lambda: step_alt(2)),
         "fronts s1": lambda: step_fronts(1),
