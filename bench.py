@@ -309,6 +309,8 @@ def main() -> None:
                          "(gsplat_amd.project_cameras_backward; single process only)")
     ap.add_argument("--dump-grad", default=None,
                     help="(tests) rank 0 saves the gradient bucket of the last step of the timed region to this .pt file")
+    ap.add_argument("--profile-views", type=int, default=1,
+                    help="with --profile-run: views per step (default 1: single-view steps)")
     ap.add_argument("--profile-run", action="store_true",
                     help="for rocprofv3: only `warmup` + `steps` single-view steps (one view per step, one stream, fixed "
                          "camera), no settling, no extra passes; prints a minimal line")
@@ -545,7 +547,10 @@ def main() -> None:
     p = width * height
     n_streams = max(1, args.view_streams) if B > 1 else 1
     if args.profile_run:
-        prof_step = make_step(args.exchange, 1, 1, world)
+        # (--profile-views V: V-view steps on ONE stream -- the kernels of the multi-view step, the per-step projection
+        # launches among them, one after the other: what the PMC passes of tools/collect_pmc.sh read their bytes from)
+        pv = max(1, args.profile_views)
+        prof_step = make_step(args.exchange, pv, 1, world * pv)
         res = timed(prof_step, args.steps, args.warmup)
         if rank == 0:
             print(json.dumps({"profile_run": True, "steps": args.steps, "warmup": args.warmup,
@@ -664,7 +669,7 @@ def main() -> None:
         # measured per launch, from separate rocprofv3 --pmc passes of the single-view step (profiles/*_traffic.json,
         # tools/make_traffic_json.py): HBM bytes of every kernel, VALU utilisation, float-atomic requests, and the
         # bound the counters point at.  NOT measured in this run: `counters_from` names the file and the sources' revision.
-        traffic, counters, counters_from, measured_bytes = None, {}, None, None
+        traffic, counters, counters_from, measured_bytes, step_bytes = None, {}, None, None, None
         for fname in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fname)) as fh:
@@ -674,6 +679,9 @@ def main() -> None:
                     traffic = counters["hbm_bytes_per_launch"]
                     measured_bytes = sum(k.get("hbm_bytes_per_launch", 0) * k.get("launches_per_view", 1)
                                          for grp in ("kernels", "binning_kernels") for k in doc.get(grp, {}).values())
+                    # the kernels of the MULTI-VIEW step (per-step projection launches: 1 / views of a launch per view)
+                    step_bytes = sum(k.get("hbm_bytes_per_launch", 0) * k.get("launches_per_view", 1)
+                                     for k in doc.get("step_kernels", {}).values()) or None
                     counters_from = f"profiles/{fname} @ csrc {doc.get('csrc_rev', 'of round ' + fname[1:3])}"
                     break
             except (OSError, KeyError, ValueError, TypeError):
@@ -735,9 +743,13 @@ def main() -> None:
         if measured_bytes:
             # counter bytes of the SINGLE-VIEW step's kernels (profiles/*_traffic.json), over the time of a view of the
             # pipelined step (`frac_of_peak`: the bytes are the same, the kernels overlap) and of a view alone
-            gbs = measured_bytes / (ms_per_view * 1e-3) / 1e9
+            # (the multi-view step's own kernels where the counter file has them: its per-step projection launches move
+            # fewer bytes per view than the single-view step's)
+            in_step = step_bytes if (step_bytes and B > 1 and not args.no_batch_projection and world == 1) else measured_bytes
+            gbs = in_step / (ms_per_view * 1e-3) / 1e9
             gbs1 = measured_bytes / (solo_ms * 1e-3) / 1e9
-            line["roofline_measured"] = {"hbm_bytes_per_view": int(measured_bytes), "achieved_GBs": round(gbs, 1),
+            line["roofline_measured"] = {"hbm_bytes_per_view": int(in_step), "hbm_bytes_per_view_single_view": int(measured_bytes),
+                                         "achieved_GBs": round(gbs, 1),
                                          "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
                                          "frac_of_copy_ceiling": round(gbs / max(copy_peak, 1.0), 4),
                                          "achieved_GBs_single_view": round(gbs1, 1),

@@ -84,6 +84,21 @@ for k in sorted(set(fetch) | set(write)):
         res["binning_kernels"][k] = row
     else:
         res["kernels"]["bwd_prepare"] = row
+# the kernels of the MULTI-VIEW step (4 views on one stream: tools/collect_pmc.sh's *_step passes): the per-step projection
+# launches serve all views of the step (launches_per_view = 1 / views), everything else runs once a view
+fs, ws = first(f"{out_dir}/fetch_step/*/*counter_collection.csv"), first(f"{out_dir}/write_step/*/*counter_collection.csv")
+if fs and ws:
+    VIEWS = 4
+    fstep, wstep = per_kernel(fs, OURS), per_kernel(ws, OURS)
+    res["step_kernels"] = {}
+    for k in sorted(set(fstep) | set(wstep)):
+        f = fstep.get(k, {}).get("FETCH_SIZE", 0.0) * 1024.0
+        w = wstep.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0
+        per_step = bool(re.search(r"project_fwd_kernel<[^>]*true>$|project_bwd_batch_kernel|sh_grad_expand", k))
+        res["step_kernels"][k] = {"kernel": k, "fetch_bytes_corrected": 2 * f, "write_bytes": w, "hbm_bytes_per_launch": 2 * f + w,
+                                  "launches_per_view": 1.0 / VIEWS if per_step else 1}
+    res["_about_step_kernels"] = (f"the same counters for the kernels of the {VIEWS}-view step (bench.py --profile-run --profile-views "
+                                  f"{VIEWS}: one stream); launches_per_view: 1 / {VIEWS} for the per-step projection launches")
 json.dump(res, open(sys.argv[3], "w"), indent=1)
 print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk in ("hbm_bytes_per_launch", "valu_util", "limiter", "atomic_requests")}
                   for k, v in res["kernels"].items()}, indent=1))
