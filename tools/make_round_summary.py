@@ -101,5 +101,24 @@ Counters of the compositor kernels (`profiles/{name}_traffic.json`, separate `--
 HBM traffic per launch of the projection kernels (MB): {proj}.
 HBM traffic per launch of the binning kernels (MB): {binning}.
 """
+if tr.get("step_kernels"):
+    sk = tr["step_kernels"]
+    total = sum(v["hbm_bytes_per_launch"] * v["launches_per_view"] for v in sk.values())
+    rows = "\n".join(f"| `{k}` | {v['hbm_bytes_per_launch'] / 1e6:.1f} | {v['launches_per_view']:g} |"
+                     for k, v in sorted(sk.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_per_view"])
+                     if v["hbm_bytes_per_launch"] * v["launches_per_view"] >= 1e5)
+    text += f"""
+The kernels of the MULTI-VIEW step (`bench.py --profile-run --profile-views 4`: 4 views per step on one stream; same PMC
+passes).  The views of a step share ONE projection launch (`project_fwd_kernel<3, true, true>`: geometry and SH rows read
+once for the 4 cameras) and ONE projection-backward launch (`project_bwd_batch_kernel<3>`: every gradient written once, the
+SH-coefficient gradient formed in registers -- no per-view `project_bwd`, no `sh_grad_expand`):
+
+| kernel | HBM MB per launch | launches per view |
+|---|---:|---:|
+{rows}
+
+HBM bytes per view of the 4-view step: {total / 1e6:.0f} MB (the single-view step: the sum of the per-launch figures above,
+with 376 + 400 MB of projection per view where the shared launches move 199 + 190).
+"""
 open(f"{out}/{name}_summary.md", "w").write(text)
 print(f"wrote {out}/{name}_summary.md ({len(text)} bytes)")
