@@ -14,6 +14,7 @@
 // /root/reference/src/backends/gsplat_backend.py:168-182.
 
 #include "project_math.h"
+#include "tile_schedule.h"
 
 #ifdef GSA_TRACE   // developer build: per-workgroup phase times of the binning kernels (tools/trace_sort.py)
 __device__ unsigned long long *g_sort_trace = nullptr;
@@ -1336,7 +1337,8 @@ __global__ __launch_bounds__(kSortThreads, 4) void emit_place_kernel(
     int n, const uint32_t *__restrict__ order, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ rects,
     const int32_t *__restrict__ block_owner, int tile_w, uint32_t m_cap, const uint32_t *__restrict__ m_dev,
     uint16_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int nblocks, int nb, int n_tiles,
-    const uint32_t *__restrict__ mat, const int32_t *__restrict__ tile_offsets, const uint32_t *__restrict__ qbox) {
+    const uint32_t *__restrict__ mat, const int32_t *__restrict__ tile_offsets, const uint32_t *__restrict__ qbox,
+    int32_t *__restrict__ sched_order, int sched_tiles, int sched_tile_w, int sched_shift) {
     __shared__ uint32_t scratch[4];
     // two regions, each with two lives: the generation's (slot owners | staged gaussians) and the placement's (peer
     // words + the bins' first slots | wave-private 16-bit bin counters)
@@ -1348,6 +1350,17 @@ __global__ __launch_bounds__(kSortThreads, 4) void emit_place_kernel(
     uint16_t(*wave_cnt)[kBinsDirect] = reinterpret_cast<uint16_t(*)[kBinsDirect]>(s_pool);
     uint32_t *s_base = s_val + 2 * 4 * kRadix;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // sched_order (gsa_tile_bin16_scheduled): EIGHT workgroups behind the placement's -- one per XCD band -- write the
+    // compositor's launch order from the lists' offsets (complete since the column scan) beside the placement, instead of a
+    // launch of their own (gsa_tile_schedule: 5 us and a kernel boundary per view)
+    if (blockIdx.x >= (unsigned)nblocks) {
+        int *cnt = reinterpret_cast<int *>(s_val), *first = cnt + kSchedBuckets;
+        const int band = (int)blockIdx.x - nblocks;
+        if (sched_shift == 0) tile_schedule_band<0, kSortThreads>(band, sched_tiles, tile_offsets, sched_order, sched_tile_w, cnt, first);
+        else if (sched_shift == 1) tile_schedule_band<1, kSortThreads>(band, sched_tiles, tile_offsets, sched_order, sched_tile_w, cnt, first);
+        else tile_schedule_band<2, kSortThreads>(band, sched_tiles, tile_offsets, sched_order, sched_tile_w, cnt, first);
+        return;
+    }
     const uint32_t m_total = m_dev ? min(m_cap, *m_dev) : m_cap;
     const unsigned live = (unsigned)(((uint64_t)m_total + kSortChunk - 1) / kSortChunk);
     const unsigned bid = GSA_PLACE_XCD ? live_block_id(live) : blockIdx.x;
@@ -2065,13 +2078,17 @@ extern "C" size_t gsa_tile_bin16_workspace_bytes(int width, int height, int bin_
     return bytes;
 }
 
-extern "C" int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offsets, const uint32_t *rects,
-                              const int32_t *block_owner, int width, int height, int bin_tile, uint32_t m_capacity,
-                              const uint32_t *m_dev, uint16_t *tile_tmp,
-                              uint32_t *gid_tmp, uint16_t *sorted_tile, uint32_t *sorted_gid, int32_t *tile_offsets,
-                              const uint32_t *qbox,
-                              void *workspace, size_t workspace_bytes, gsa_stream_t stream) {
+static int tile_bin16_impl(int n, const uint32_t *order, const uint32_t *offsets, const uint32_t *rects,
+                           const int32_t *block_owner, int width, int height, int bin_tile, uint32_t m_capacity,
+                           const uint32_t *m_dev, uint16_t *tile_tmp,
+                           uint32_t *gid_tmp, uint16_t *sorted_tile, uint32_t *sorted_gid, int32_t *tile_offsets,
+                           const uint32_t *qbox, int32_t *tile_order,
+                           void *workspace, size_t workspace_bytes, gsa_stream_t stream) {
     GSA_RETURN_IF(n < 0 || !tile_offsets, GSA_ERR_INVALID_ARGUMENT);
+    // (the launch order comes out of the one-pass placement's last launch only, and not for an empty view)
+    GSA_RETURN_IF(tile_order && (!gsa_tile_bin16_direct(width, height, bin_tile) || tile_tmp || gid_tmp || n == 0 ||
+                                 m_capacity == 0),
+                  GSA_ERR_INVALID_ARGUMENT);
     // (boxes: only where the records are placed in one pass, a bin has at most 4 x 4 quadrants and ids fit 24 bits --
     // gsa_tile_bin16_boxes)
     GSA_RETURN_IF(qbox && (!gsa_tile_bin16_boxes(width, height, bin_tile, n) || tile_tmp || gid_tmp), GSA_ERR_INVALID_ARGUMENT);
@@ -2106,10 +2123,14 @@ extern "C" int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offs
         bin_colscan_kernel<<<nb / kColBins, kColThreads, 0, s>>>(m_capacity, m_dev, nb, n_tiles, mat, totals, tile_offsets,
                                                                   done_counter);
         GSA_LAUNCH_CHECK();
+        // (tile_order: eight more workgroups write the compositor's launch order beside the placement)
+        const int sched_shift = bin_tile == 4 * GSA_TILE_SIZE ? 2 : bin_tile == 2 * GSA_TILE_SIZE ? 1 : 0;
+        const int sched_w = gsa_div_up(width, GSA_TILE_SIZE), sched_tiles = sched_w * gsa_div_up(height, GSA_TILE_SIZE);
+        const int place_grid = nblocks + (tile_order ? 8 : 0);
 #define GSA_PLACE(Q)                                                                                                     \
-    emit_place_kernel<Q><<<nblocks, kSortThreads, 0, s>>>(n, order, offsets, rects, block_owner, tile_w, m_capacity, m_dev, \
-                                                          sorted_tile, sorted_gid, nblocks, nb, n_tiles, mat, tile_offsets, \
-                                                          qbox)
+    emit_place_kernel<Q><<<place_grid, kSortThreads, 0, s>>>(n, order, offsets, rects, block_owner, tile_w, m_capacity, m_dev, \
+                                                             sorted_tile, sorted_gid, nblocks, nb, n_tiles, mat, tile_offsets, \
+                                                             qbox, tile_order, sched_tiles, sched_w, sched_shift)
         if (!qbox) GSA_PLACE(0);
         else if (bin_tile == GSA_TILE_SIZE) GSA_PLACE(2);
         else if (bin_tile == 2 * GSA_TILE_SIZE) GSA_PLACE(4);
@@ -2151,4 +2172,24 @@ extern "C" int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offs
         GSA_LAUNCH_CHECK();
     }
     return tile_offsets_impl<uint16_t>(m_capacity, m_dev, sorted_tile, n_tiles, tile_offsets, stream);
+}
+
+extern "C" int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offsets, const uint32_t *rects,
+                              const int32_t *block_owner, int width, int height, int bin_tile, uint32_t m_capacity,
+                              const uint32_t *m_dev, uint16_t *tile_tmp,
+                              uint32_t *gid_tmp, uint16_t *sorted_tile, uint32_t *sorted_gid, int32_t *tile_offsets,
+                              const uint32_t *qbox,
+                              void *workspace, size_t workspace_bytes, gsa_stream_t stream) {
+    return tile_bin16_impl(n, order, offsets, rects, block_owner, width, height, bin_tile, m_capacity, m_dev, tile_tmp, gid_tmp,
+                           sorted_tile, sorted_gid, tile_offsets, qbox, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int gsa_tile_bin16_scheduled(int n, const uint32_t *order, const uint32_t *offsets, const uint32_t *rects,
+                                        const int32_t *block_owner, int width, int height, int bin_tile,
+                                        uint32_t m_capacity, const uint32_t *m_dev, uint16_t *sorted_tile,
+                                        uint32_t *sorted_gid, int32_t *tile_offsets, const uint32_t *qbox,
+                                        int32_t *tile_order, void *workspace, size_t workspace_bytes, gsa_stream_t stream) {
+    GSA_RETURN_IF(!tile_order, GSA_ERR_INVALID_ARGUMENT);
+    return tile_bin16_impl(n, order, offsets, rects, block_owner, width, height, bin_tile, m_capacity, m_dev, nullptr, nullptr,
+                           sorted_tile, sorted_gid, tile_offsets, qbox, tile_order, workspace, workspace_bytes, stream);
 }

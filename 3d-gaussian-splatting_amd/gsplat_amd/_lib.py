@@ -43,6 +43,7 @@ SIGNATURES = {
     "gsa_depth_order_msd": (c_int, [c_int, P, P, c_uint32, c_uint32, P, P, P, P, P, c_int, P, P, c_uint32, P, c_size_t, P]),
     "gsa_scan_tiles_sorted": (c_int, [c_int, P, P, c_int, P, P, c_size_t, P]),
     "gsa_tile_bin16": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_uint32, P, P, P, P, P, P, P, P, c_size_t, P]),
+    "gsa_tile_bin16_scheduled": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_uint32, P, P, P, P, P, P, P, c_size_t, P]),
     "gsa_tile_emit": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_uint32, P, P, P]),
     "gsa_tile_offsets": (c_int, [c_uint32, P, c_int, P, P]),
     "gsa_sort_pairs_u32_dev": (c_int, [c_int, P, P, P, P, P, P, P, c_int, c_int, P, c_size_t, P]),

@@ -667,7 +667,7 @@ class ViewParallelTrainer:
                                                                       return_aux=True, bin_tile=bt, key_range=kr, qbox=qb)
             bins = S.bin_tiles(splat, radii, tiles, keys, W, H, cull, tile_rects=rects, exact=exact, bin_tile=bt,
                                key_range=kr, qbox=qb)
-            order = S.tile_schedule(bins.tile_offsets, W, H, bt)
+            order = S.tile_schedule(bins, W, H, bt)
             return pose, splat, radii, bins, order, aux
 
         def forward(j, deferred):

@@ -59,7 +59,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
         # queued, and only then is the count (long since copied back) checked -- a miss repeats with exact sizes
         bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, tile_rects=rects,
                            bin_tile=bt, key_range=kr, qbox=qb)
-        tile_order = S.tile_schedule(bins.tile_offsets, width, height, bt)   # longest record lists first (speed only)
+        tile_order = S.tile_schedule(bins, width, height, bt)   # longest record lists first (speed only)
         out = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg_c, width, height, channels,
                               tile_order, want_lists=want_lists, bin_tile=bt, gid_boxes=bins.boxed)
         if deferred is not None:
@@ -69,7 +69,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
         elif not bins.finalize()[1]:
             bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, exact=True,
                                tile_rects=rects, bin_tile=bt, qbox=qb)
-            tile_order = S.tile_schedule(bins.tile_offsets, width, height, bt)
+            tile_order = S.tile_schedule(bins, width, height, bt)
             out = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg_c, width, height, channels,
                                   tile_order, want_lists=want_lists, bin_tile=bt, gid_boxes=bins.boxed)
         render, alpha, final_T, last_id = out[:4]

@@ -365,6 +365,8 @@ class TileBins:
         # what the depth ordering assumed about the visible keys -- bits an LSD sort covered, or (key_min, scale) of the
         # bucketed one; None: nothing to check -- and the result of the check
         self.key_bits, self._keys_ok = key_bits, keys_ok
+        # the compositor's launch order (tile_schedule's output), where the one-pass placement wrote it on the side
+        self.tile_order = None
 
     @property
     def bin_tile(self) -> int:   # side of the tiles these bins index (16, or 32: see bin_tiles)
@@ -730,11 +732,22 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
         v_tmp = torch.empty(cap, dtype=torch.int32, device=dev) if two else None
         ws2_bytes = lib.gsa_tile_bin16_workspace_bytes(width, height, bin_tile, cap) if direct else lib.gsa_sort_workspace_bytes(cap)
         ws2 = torch.empty(ws2_bytes, dtype=torch.uint8, device=dev)
-        _call("gsa_tile_bin16", lib.gsa_tile_bin16, N, _ptr(order), _ptr(offsets), _ptr(rects), _ptr(block_owner), width,
-              height, bin_tile, cap,
-              _ptr(total), _ptr(k_tmp), _ptr(v_tmp), _ptr(sorted_tile), _ptr(sorted_gid), _ptr(tile_offsets),
-              _ptr(qbox) if boxed else None, _ptr(ws2), ws2_bytes, st)
-        return TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key, slot, N, key_bits, keys_ok, boxed)
+        tile_order = None
+        if direct and _SCHEDULE_IN_PLACEMENT and N > 0 and cap > 0:
+            # the compositor's launch order out of the placement launch itself (eight extra workgroups): no tile_schedule launch
+            tw16, th16 = tile_grid(width, height)
+            tile_order = torch.empty(8 * ((tw16 * th16 + 7) // 8), dtype=torch.int32, device=dev)
+            _call("gsa_tile_bin16", lib.gsa_tile_bin16_scheduled, N, _ptr(order), _ptr(offsets), _ptr(rects), _ptr(block_owner),
+                  width, height, bin_tile, cap, _ptr(total), _ptr(sorted_tile), _ptr(sorted_gid), _ptr(tile_offsets),
+                  _ptr(qbox) if boxed else None, _ptr(tile_order), _ptr(ws2), ws2_bytes, st)
+        else:
+            _call("gsa_tile_bin16", lib.gsa_tile_bin16, N, _ptr(order), _ptr(offsets), _ptr(rects), _ptr(block_owner), width,
+                  height, bin_tile, cap,
+                  _ptr(total), _ptr(k_tmp), _ptr(v_tmp), _ptr(sorted_tile), _ptr(sorted_gid), _ptr(tile_offsets),
+                  _ptr(qbox) if boxed else None, _ptr(ws2), ws2_bytes, st)
+        bins = TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key, slot, N, key_bits, keys_ok, boxed)
+        bins.tile_order = tile_order
+        return bins
     isect_tile = torch.empty(cap, dtype=torch.int32, device=dev)
     isect_gid = torch.empty(cap, dtype=torch.int32, device=dev)
     _call("gsa_tile_emit", lib.gsa_tile_emit_dev, N, _ptr(order), _ptr(offsets), _ptr(splat), _ptr(radii), width,
@@ -755,9 +768,19 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
     return TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key, slot, N, None, True)
 
 
-def tile_schedule(tile_offsets: torch.Tensor, width: int, height: int, bin_tile: int = TILE_SIZE) -> torch.Tensor:
+# the one-pass placement writes the compositor's launch order in eight extra workgroups of its last launch (False: a
+# tile_schedule launch per view; A/B from tests / tools)
+_SCHEDULE_IN_PLACEMENT = True
+
+
+def tile_schedule(tile_offsets, width: int, height: int, bin_tile: int = TILE_SIZE) -> torch.Tensor:
     """-> tile_order [8 * ceil(n_tiles / 8)] i32: per tile band, the tiles with the longest record lists first (launch
-    order of the compositor kernels; speed only).  ``bin_tile``: what ``tile_offsets`` indexes (see ``bin_tiles``)."""
+    order of the compositor kernels; speed only).  ``bin_tile``: what ``tile_offsets`` indexes (see ``bin_tiles``).
+    Given the ``TileBins`` themselves it returns the order their placement launch wrote on the side, if it did."""
+    if isinstance(tile_offsets, TileBins):
+        if tile_offsets.tile_order is not None:
+            return tile_offsets.tile_order
+        tile_offsets = tile_offsets.tile_offsets
     tile_w, tile_h = tile_grid(width, height)
     n_tiles = tile_w * tile_h
     order = torch.empty(8 * ((n_tiles + 7) // 8), dtype=torch.int32, device=tile_offsets.device)

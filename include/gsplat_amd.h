@@ -232,6 +232,17 @@ int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offsets, const 
                    const uint32_t *qbox,
                    void *workspace, size_t workspace_bytes, gsa_stream_t stream);
 
+/* ABI 12 -- gsa_tile_bin16 on the one-pass placement path (gsa_tile_bin16_direct, n > 0, m_capacity > 0) that ALSO writes
+ * gsa_tile_schedule's output: eight extra workgroups of the placement launch order every XCD band's 16 x 16 tiles by the
+ * length of the lists they walk (tile_order[8 * ceil(n_tiles16 / 8)], n_tiles16 = the frame's 16 x 16 tiles) while the
+ * records are being placed -- one launch and one kernel boundary less per view than gsa_tile_bin16 + gsa_tile_schedule,
+ * the same tile_order up to the order inside a bucket (which only moves work in time). */
+int gsa_tile_bin16_scheduled(int n, const uint32_t *order, const uint32_t *offsets, const uint32_t *rects,
+                             const int32_t *block_owner, int width, int height, int bin_tile, uint32_t m_capacity,
+                             const uint32_t *m_dev, uint16_t *sorted_tile, uint32_t *sorted_gid, int32_t *tile_offsets,
+                             const uint32_t *qbox, int32_t *tile_order, void *workspace, size_t workspace_bytes,
+                             gsa_stream_t stream);
+
 /* For k in depth order, g = order[k]: write that gaussian's tile ids and its index g at
  * [offsets[k], offsets[k] + tiles_touched[g]).  Must use the cull_mode of gsa_project_fwd. */
 int gsa_tile_emit(int n, const uint32_t *order, const uint32_t *offsets, const float *splat,

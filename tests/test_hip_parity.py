@@ -582,6 +582,57 @@ def test_deferred_projection_backward_of_a_step_equals_per_camera_autograd(gsa):
         assert _rel(a.reshape(b.shape), b) <= 1e-5, (name, _rel(a.reshape(b.shape), b))
 
 
+@pytest.mark.parametrize("W,H,N,s_max", [(1920, 1080, 60_000, 0.05), (1000, 600, 20_000, 0.1), (3840, 2160, 50_000, 0.05)])
+def test_launch_order_from_the_placement_launch_equals_tile_schedule(gsa, W, H, N, s_max):
+    """``bin_tiles`` on the one-pass placement leaves the compositor's launch order itself (gsa_tile_bin16_scheduled: eight
+    extra workgroups of the placement launch): per XCD band the same tiles as ``gsa_tile_schedule`` writes, in the same
+    bucket order (list length / 64, longest first; the order inside a bucket is free: LDS atomics), the tiles of one bin on
+    consecutive places, the same padding -- and the image rendered with it is the image."""
+    from gsplat_amd import scene, stages as S
+    sc = _scene(N, seed=13, s_max=s_max)
+    means, quats, scales = sc["means3D"].cuda(), sc["rotations"].cuda(), sc["scales"].cuda()
+    opac, colors = sc["opacities"][:, 0].contiguous().cuda(), sc["shs"].cuda()
+    vm, K = scene.make_camera(1, 6).cuda().contiguous(), scene.make_intrinsics(W, H).cuda()
+    bt = S.bin_tile_for(W, H, 0)
+    assert bt in (32, 64)
+
+    def run():
+        kr, qb = S.key_range_buffer(N, means.device), S.qbox_buffer(N, means.device)
+        splat, radii, tiles, keys, rects = S.project_fwd(means, quats, scales, opac, colors, 3, vm, K, W, H, 0, return_rects=True,
+                                                         bin_tile=bt, key_range=kr, qbox=qb)
+        return splat, S.bin_tiles(splat, radii, tiles, keys, W, H, 0, tile_rects=rects, bin_tile=bt, key_range=kr, qbox=qb)
+
+    run()[1].finalize()                      # (first call of the shape: exact sizes)
+    splat, bins = run()
+    assert bins.finalize()[1] and bins.tile_order is not None and S.tile_schedule(bins, W, H, bt) is bins.tile_order
+    ref = S.tile_schedule(bins.tile_offsets, W, H, bt)          # a launch of its own
+    got = bins.tile_order
+    assert got.shape == ref.shape
+    tw, th = S.tile_grid(W, H)
+    n_tiles, chunk = tw * th, (tw * th + 7) // 8
+    side = bt // 16
+    bw = (tw + side - 1) // side
+    offs = bins.tile_offsets.cpu().long()
+
+    def bucket(tile):
+        ty, tx = divmod(int(tile), tw)
+        idx = (ty // side) * bw + tx // side
+        return 63 - min(63, int(offs[idx + 1] - offs[idx]) >> 6)
+
+    g, r = got.cpu().tolist(), ref.cpu().tolist()
+    for band in range(8):
+        lo, hi = band * chunk, min(n_tiles, (band + 1) * chunk)
+        gb, rb = g[lo:lo + chunk], r[lo:lo + chunk]
+        live = max(hi - lo, 0)
+        assert sorted(gb[:live]) == list(range(lo, hi)) == sorted(rb[:live]) and all(t == -1 for t in gb[live:])
+        keys = [bucket(t) for t in gb[:live]]
+        assert keys == sorted(keys) and keys == [bucket(t) for t in rb[:live]]
+    bg = torch.zeros(3, device="cuda")
+    a = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg, W, H, 3, got, bin_tile=bt, gid_boxes=bins.boxed)
+    b = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg, W, H, 3, ref, bin_tile=bt, gid_boxes=bins.boxed)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[3], b[3])
+
+
 def test_cull_modes_give_identical_images(gsa):
     """Exact ellipse culling only removes (tile, splat) pairs whose every pixel fails alpha >= 1/255."""
     from gsplat_amd import scene
@@ -786,9 +837,29 @@ def test_degenerate_inputs(gsa):
     one = [t[:1].cuda() for t in base]
     r, a, meta = gsa.rasterization(*one, vm, K, W, H, sh_degree=3)
     assert r.shape == (1, H, W, 3) and torch.isfinite(r).all()
+    # the shared (multi-camera) projection on the same degenerate scenes: everything culled for both cameras -> zero
+    # gradients out of the one projection-backward launch; an EMPTY scene for two cameras
+    vm2, K2 = torch.cat([vm, vm]), torch.cat([K, K])
+    leaves = [t.cuda().clone().requires_grad_(True) for t in base]
+    with torch.no_grad():
+        leaves[0][:, 2] = -10.0
+    proj = gsa.project_cameras(*leaves, vm2, K2, W, H, sh_degree=3, defer_backward=True)
+    for c in range(2):
+        r, a, meta = gsa.rasterization(*leaves, vm2[c:c + 1], K2[c:c + 1], W, H, sh_degree=3, backgrounds=bg, projection=proj[c])
+        assert torch.allclose(r[0], bg[0].expand(H, W, 3)) and float(a.abs().max()) == 0
+        r.sum().backward()
+    out = [torch.full_like(t.detach(), float("nan")) for t in leaves]
+    gsa.project_cameras_backward(proj, *leaves, out)
+    assert all(float(t.abs().max()) == 0 for t in out)
+    none = [t[:0].cuda() for t in base]
+    r, a, meta = gsa.rasterization(*none, vm2, K2, W, H, sh_degree=3)
+    assert r.shape == (2, H, W, 3) and float(r.abs().max()) == 0 and float(a.abs().max()) == 0
     # wrong shapes / devices raise, they do not crash
     with pytest.raises(ValueError):
         gsa.rasterization(one[0], one[1], one[2], one[3][:, None], one[4], vm, K, W, H, sh_degree=3)
+    with pytest.raises(ValueError):   # a projection made for another frame
+        gsa.rasterization(*one, vm, K, W, H, sh_degree=3,
+                          projection=gsa.project_cameras(*one, vm, K, 2 * W, H, sh_degree=3)[0])
     with pytest.raises(RuntimeError):
         gsa.rasterization(*[t.cpu() for t in one], vm.cpu(), K.cpu(), W, H, sh_degree=3)
 

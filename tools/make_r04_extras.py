@@ -174,7 +174,10 @@ streams, the speculation checked once per step; `single_view` is one view per st
 {line("bench_c5.json")}
 ```
 
-{c5['config']['ms_per_view']} ms per 4K view in the 4-view step ({c5['value']} Mpix/s), {c5['single_view']['ms']} ms for a view alone (r03: 2.10 / 2.35; r02: 2.58).
+{c5['config']['ms_per_view']} ms per 4K view in the 4-view step ({c5['value']} Mpix/s), {c5['single_view']['ms']} ms for a view alone (r03: 2.10 / 2.35; r02: 2.58;
+this round before the views of a step shared their projection and projection-backward launches: 2.12 / 2.34 -- at 5 M gaussians
+the two projection stages are 0.69 of a single view's 2.33 ms, and the shared launches move 199 + 190 instead of 376 + 400 bytes
+per gaussian and view).
 Stages (single view): binning {s5['binning']}, forward {s5['gsa_composite_fwd']}, backward {s5['gsa_composite_bwd']}, projection {s5['gsa_project_fwd']} + {s5['gsa_project_bwd']} ms.
 `over_peak` / `roofline_whole_step.frac` > 1: SURVEY's formula prices {c5['config']['intersections_M']} records of the 16 x 16 rule where
 {c5['config']['binned_records']} records of 64 x 64 bins are placed, and whole SH rows where the backward reads the digest -- the contractual
@@ -184,8 +187,8 @@ Not improved this round (VERDICT r03 item 2 asked for binning <= 0.38 ms): 5 M g
 ordering (255 buckets of <= 8192 keys), so three LSD passes order the depths (`radix_scatter<unsigned int>` x 3 per view
 below).  12-bit LSD passes were built and measured: `key_place` 158 us per pass against 61 us for an 8-bit scatter (4096-counter
 LDS histograms and the ranking cost), binning 0.54 -> 0.65 ms; reverted.  More than 255 buckets costed in DESIGN.md section 5:
-no better than the LSD path with the 8-bit machinery.  64 x 64 bins have 8 x 8 quadrants, which the 8-bit box of the ids
-cannot address: C5 runs with plain ids (`emit_place_kernel<0>`, `composite_fwd_kernel<3, 2, false>`).
+no better than the LSD path with the 8-bit machinery.  The forward sweep did improve (0.506 -> 0.44 ms): the ids of 64 x 64
+bins carry quadrant boxes too, in pairs of quadrants (`emit_place_kernel<8>`, `composite_fwd_kernel<3, 2, true>`).
 
 `rocprofv3 --kernel-trace --stats -- python3 bench.py --workload C5 --profile-run --steps 10 --warmup 3` (single-view steps):
 
@@ -215,7 +218,10 @@ What changed in r04 besides the rasterizer (DESIGN.md section 8):
   not split again; the reference's two learning rates alternate inside the segment (`gsa_adam_step_striped`);
 * `loss_strip_kernel`: column-walking lanes, DPP neighbours, no LDS: 34.5 us per view alone (r03: 75.6 us);
 * `step_report_kernel`: the step's metrics in one launch (r03: ~25 torch kernels of ~5 us between Adam and the next step);
-* the views go through `pipeline.ViewPipeline` (deferred speculation checks: no host wait inside the step).
+* the views go through `pipeline.ViewPipeline` (deferred speculation checks: no host wait inside the step);
+* the views of the step share ONE projection launch (`project_fwd_kernel<3, true, true>`) and ONE projection-backward launch
+  (`project_bwd_batch_kernel<3>`), which writes the SH-coefficient gradient itself: no per-view `project_bwd`, no
+  `sh_grad_expand` (before, same box class: 2.75-2.81 ms per step).
 
 `rocprofv3 --kernel-trace --stats -- python3 tools/bench_train_step.py` (FUSED_ONLY=1: 3 warm-up + 10 timed steps of 4 views;
 durations INCLUDE the time a kernel waits beside another stream's sweep, which is why the short kernels read long):
