@@ -14,7 +14,7 @@
 namespace {
 
 #ifndef GSA_PROJ_BLOCK
-#define GSA_PROJ_BLOCK 256
+#define GSA_PROJ_BLOCK 128   // (256: the same 4-view step, project_bwd of a single view 0.072 -> 0.067 ms at 128; 512: slower)
 #endif
 constexpr int kBlock = GSA_PROJ_BLOCK;
 #ifndef GSA_EXP_AUX
