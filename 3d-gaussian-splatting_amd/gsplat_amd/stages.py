@@ -788,11 +788,11 @@ def tile_schedule(tile_offsets, width: int, height: int, bin_tile: int = TILE_SI
     return order
 
 
-# False (default since the views of a step share their projection launches): the backward sweep keeps the forward's launch
-# order (by list length) instead of ordering the tiles once more by the records their quadrants blended -- one launch and
-# one kernel boundary less per view, a less even sweep (0.197 -> 0.203 ms): the same single view, the 4-view step 0.7 %
-# faster (tools/bench_noreorder.py A/B).  True: gsa_composite_bwd_prepare orders them.
-_BWD_REORDER = False
+# False: the backward sweep keeps the forward's launch order (by list length) instead of ordering the tiles once more by
+# the records their quadrants blended -- one launch and one kernel boundary less per view, a less even sweep (0.197 ->
+# 0.203 ms): a single view 0.5 % slower, the 4-view step 0.7 % faster (tools/bench_noreorder.py A/B).  Kept on: the sweep is
+# the path's dominant kernel and a view alone is what rounds are compared on.
+_BWD_REORDER = True
 
 
 class QuadLists(tuple):
