@@ -69,14 +69,18 @@ class HipBackend:
 
     def render_batch(self, gaussian_params: Dict, view_matrices: torch.Tensor, proj_matrices: torch.Tensor,
                      width: int, height: int, bg_color: torch.Tensor, device: str) -> Dict:
-        """gsplat_backend.py:12-55: a loop of single views, images returned channel-first."""
+        """gsplat_backend.py:12-55 (there a loop of single views with a "real batch processing" TODO): ONE operator call for
+        the B cameras -- the gaussians are projected for all of them in one launch (geometry and SH rows read once); per
+        camera the same image as ``render_single``; images returned channel-first."""
         n_views = view_matrices.shape[0]
-        images = torch.zeros(n_views, 3, height, width, device=device)
-        alphas = torch.zeros(n_views, 1, height, width, device=device)
-        for i in range(n_views):
-            view = {"world_view_transform": view_matrices[i], "projection_matrix": proj_matrices[i],
-                    "image_width": width, "image_height": height}
-            r = self.render_single(gaussian_params, view, bg_color)
-            images[i] = r["render"].permute(2, 0, 1)
-            alphas[i] = r["alpha"].permute(2, 0, 1)
-        return {"images": images, "alphas": alphas}
+        degree = 3 if gaussian_params.get("shs") is not None else None
+        colors = gaussian_params["shs"] if degree is not None else gaussian_params.get("colors", gaussian_params.get("features"))
+        opacities = gaussian_params["opacities"]
+        if opacities.dim() == 2:
+            opacities = opacities.squeeze(-1)
+        renders, alphas, _ = self.rasterization(
+            means=gaussian_params["means3D"], quats=gaussian_params["rotations"], scales=gaussian_params["scales"],
+            opacities=opacities, colors=colors, viewmats=view_matrices,
+            Ks=self.K.to(view_matrices.device)[None].expand(n_views, 3, 3).contiguous(), width=width, height=height,
+            packed=False, render_mode="RGB+ED", sh_degree=degree, backgrounds=bg_color[None].expand(n_views, 3))
+        return {"images": renders[..., :3].permute(0, 3, 1, 2).contiguous(), "alphas": alphas.permute(0, 3, 1, 2).contiguous()}

@@ -905,6 +905,10 @@ def test_backend_plugin_surface(gsa):
     batch = be.render_batch(sc_d, vm.cuda()[None].repeat(2, 1, 1), torch.eye(4, device="cuda")[None].repeat(2, 1, 1),
                             W, H, torch.zeros(3, device="cuda"), "cuda")
     assert batch["images"].shape == (2, 3, H, W) and batch["alphas"].shape == (2, 1, H, W)
+    # (one multi-camera operator call -- a shared projection launch -- gives every camera the single-view image)
+    for c in range(2):
+        assert torch.equal(batch["images"][c], single["render"].permute(2, 0, 1))
+        assert torch.equal(batch["alphas"][c], single["alpha"].permute(2, 0, 1))
 
 
 def _parity_record(name, record):
