@@ -331,9 +331,17 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # GSPLAT_AMD_BENCH_FORCE_DIST=1: a process group even for ONE rank -- the exchange's RCCL branch (all-gather per view,
+    # all-reduce per step, the host-side flag group) then executes on a one-GPU box, with nothing to exchange (tests)
+    if world > 1 or os.environ.get("GSPLAT_AMD_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     # the ranks agree on "did every view's speculation hold" through a HOST-side group: a collective on the device would
     # sit behind the step's kernels in stream order, and the host is a step ahead of those

@@ -338,6 +338,37 @@ def test_bench_multi_view_step_overlapped_equals_serial_and_one_process(tmp_path
     assert line["config"]["speculation_check"] == "per view" and line["config"]["overlap"] == "alternate"
 
 
+def test_bench_exchange_executes_over_rccl_with_one_rank(tmp_path):
+    """The RCCL branch of bench.py's exchange on the device: ONE rank with a real ``nccl`` process group
+    (GSPLAT_AMD_BENCH_FORCE_DIST=1) -- ``all_gather_into_tensor`` behind every view's backward, the asynchronous
+    all-reduce of the geometry floats, the host-side gloo flag group, the local SH rebuild -- leaves the gradient bucket of
+    the plain one-process run (which finishes its views' projection backward in one launch instead).  What this cannot
+    show is a second rank; that a collective's arguments are what RCCL accepts, it does."""
+    import json
+    import subprocess
+    n = 20_000
+
+    def run(tag, force):
+        out = os.path.join(str(tmp_path), f"{tag}.pt")
+        env = dict(os.environ)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GSPLAT_AMD_BENCH_BACKEND"):
+            env.pop(k, None)
+        if force:
+            env["GSPLAT_AMD_BENCH_FORCE_DIST"] = "1"
+        cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "1", "--workload", "T", "--steps", "3",
+               "--warmup", "1", "--views-per-gpu", "4", "--no-cpu-baseline", "--no-train-step", "--views", "1", "--dump-grad", out]
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-3000:]
+        return torch.load(out), json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+
+    plain, line_p = run("plain", False)
+    rccl, line_r = run("rccl", True)
+    assert "exchange" not in line_p and line_p["config"]["projection"] == "per step: forward + backward"
+    assert line_r["exchange"]["backend"] == "nccl" and line_r["exchange"]["world_size"] == 1
+    scale = float(plain.abs().max())
+    assert scale > 0 and float((rccl - plain).abs().max()) <= 2e-5 * scale
+
+
 def test_c5_run_iteration_through_a_densify_event_then_renders_at_the_new_population():
     """BASELINE config C5 as the loop runs it: ``ViewParallelTrainer.run`` at 5M gaussians / 3840x2160 / SH 3 (fused step) for two
     iterations -- the first ends in a densify / prune event (clones, cut by the ``max_gaussians`` cap), the second
