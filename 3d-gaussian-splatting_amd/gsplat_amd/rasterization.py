@@ -27,7 +27,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, colors, viewmat, Kmat, background,
                 width: int, height: int, sh_degree: int, channels: int, cull_mode: int, grad_out, grad_accumulate,
-                sh_grad_factored, deferred=None, projection=None):
+                sh_grad_factored, deferred=None, projection=None, collector=None):
         means_c, quats_c, scales_c = S.f32c(means, "means"), S.f32c(quats, "quats"), S.f32c(scales, "scales")
         opac_c, colors_c = S.f32c(opacities, "opacities"), S.f32c(colors, "colors")
         view_c, K_c = S.f32c(viewmat, "viewmats"), S.f32c(Kmat, "Ks")
@@ -76,11 +76,13 @@ class _RasterizeOneCamera(torch.autograd.Function):
         quad_list, quad_count = out[4] if want_lists else (None, None)
         ctx.zeroed_records = out[4].zeroed if want_lists else None   # cleared by the forward kernel; used once
         gid_buffer = bins.sorted_gid_buffer        # what the backward sweep reads (ids, boxed or not: ctx.gid_boxes)
-        if deferred is not None:   # (capacity-sized: rasterization() cuts them to the record count when somebody looks)
-            sorted_tile = bins._tile if bins._tile is not None else torch.empty(0, dtype=torch.int16, device=splat.device)
-            sorted_gid, tile_offsets = gid_buffer, bins.tile_offsets
-        else:
-            sorted_tile, sorted_gid, tile_offsets = bins.sorted_tile_stored, bins.sorted_gid, bins.tile_offsets
+        # (capacity-sized and with the boxes in the ids' top byte: rasterization() cuts them to the record count and masks
+        # them when somebody looks at meta's lists -- nothing in a training loop does; cutting and masking here cost every
+        # checked call an elementwise kernel over the records, 6 us of a 1 M-gaussian view)
+        sorted_tile = bins._tile if bins._tile is not None else torch.empty(0, dtype=torch.int16, device=splat.device)
+        sorted_gid, tile_offsets = gid_buffer, bins.tile_offsets
+        if collector is not None:
+            collector.append(bins)
 
         ctx.save_for_backward(means_c, quats_c, scales_c, opac_c, colors_c, view_c, K_c, bg_c, splat, radii,
                               gid_buffer, tile_offsets, final_T, last_id, tile_order, quad_list, quad_count, sh_aux)
@@ -117,15 +119,15 @@ class _RasterizeOneCamera(torch.autograd.Function):
                                   quad_lists=lists, bin_tile=ctx.bin_tile, gid_boxes=ctx.gid_boxes)
         if ctx.deferred_projection is not None:
             ctx.deferred_projection.v_splat = v_splat
-            return (None,) * 18
+            return (None,) * 19
         grads = S.project_bwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
                               splat, radii, v_splat, out=ctx.grad_out, accumulate=ctx.grad_accumulate,
                               v_rgb_out=ctx.sh_grad_factored, sh_aux=sh_aux)
         if ctx.grad_accumulate:   # the sums live in the caller's buffers; autograd gets nothing to accumulate
-            return (None,) * 18
+            return (None,) * 19
         need = ctx.needs_input_grad
         grads = tuple(g.view(shp) if (nd and g is not None) else None for g, shp, nd in zip(grads, ctx.in_shapes, need[:5]))
-        return grads + (None,) * 13
+        return grads + (None,) * 14
 
 
 def project_cameras(means, quats, scales, opacities, colors, viewmats, Ks, width: int, height: int,
@@ -275,6 +277,7 @@ def rasterization(
 
     renders, alphas, per_cam = [], [], []
     pending = [] if defer_check else None   # TileBins per camera whose control words nobody has waited for yet
+    all_bins = []                           # TileBins of every camera (checked or not): the lists' record counts and id format
     if projection is not None and not isinstance(projection, (list, tuple)):
         projection = [projection]
     if projection is not None and len(projection) != C:
@@ -290,7 +293,7 @@ def rasterization(
                 bg = torch.cat([bg, bg.new_zeros(1)])
         out = _RasterizeOneCamera.apply(means, quats, scales, opacities, colors, viewmats[c], Ks[c], bg,
                                         width, height, deg, channels, cull, grad_out, grad_accumulate, sh_grad_factored,
-                                        pending, None if projection is None else projection[c])
+                                        pending, None if projection is None else projection[c], all_bins)
         render, alpha = out[0], out[1]
         if render_mode in ("ED", "RGB+ED"):
             render = torch.cat([render[..., :3], render[..., 3:] / alpha.clamp(min=1e-10)], dim=-1)
@@ -302,13 +305,15 @@ def rasterization(
 
     def settled():
         """per_cam with the record buffers cut to the record counts (deferred check: waits for the control words now)."""
-        if pending:
-            for c, b in enumerate(pending):
+        if all_bins:
+            for c, b in enumerate(all_bins):
                 m = b.finalize()[0]
                 pc = list(per_cam[c])
                 pc[3], pc[4] = (pc[3][:m] if pc[3].numel() else pc[3]), (pc[4][:m] & 0xFFFFFF if b.boxed else pc[4][:m])
                 per_cam[c] = tuple(pc)
-            pending.clear()
+            all_bins.clear()
+            if pending:
+                pending.clear()
         return per_cam
 
     checked = list(pending) if pending else []
