@@ -411,10 +411,10 @@ __device__ __forceinline__ bool walk_fwd(const ST &st, int n, float yrel, FwdPix
 // ---- the forward kernel ------------------------------------------------------------------------------------------
 // A (tile, quadrant) wave walks its bin's depth-ordered record list in three decoupled steps:
 //   SCAN   128 list entries at a time, coalesced: with BOXES (gsa_tile_bin16 given the gaussians' quadrant boxes) the top
-//          byte of an entry says which quadrants of the bin the gaussian's bounding box covers -- first / last column,
-//          first / last row, two bits each -- and only the entries whose box covers this wave's quadrant (~28 % in a 32 x 32
-//          bin) are appended to a small queue in LDS: ballot + mbcnt, about a dozen vector instructions per 64 entries,
-//          nothing gathered for the others;
+//          byte of an entry says which quadrants of the bin the gaussian's bounding box covers -- a 4-bit mask of its
+//          columns, a 4-bit mask of its rows -- and only the entries whose box covers this wave's quadrant (one AND, one
+//          compare; ~28 % in a 32 x 32 bin) are appended to a small queue in LDS: ballot + mbcnt, half a dozen vector
+//          instructions per 64 entries, nothing gathered for the others;
 //   STAGE  64 queued candidates at a time: one 64-B splat record per lane (the gather is in flight while the previous
 //          batch is blended), re-tested against the bounding box of the pixels that are still accumulating, and the
 //          survivors written to CONSECUTIVE slots of the wave's LDS image -- so that
@@ -475,6 +475,7 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 7 : GSA_FWD_WAVES)) void composit
     const int box_shift = bin_shift > 1 ? 1 : 0;
     const uint32_t my_col = (uint32_t)((((slice >> 2) & ((1 << bin_shift) - 1)) << 1) | (q & 1)) >> box_shift;
     const uint32_t my_row = (uint32_t)((((slice >> 2) >> bin_shift) << 1) | (q >> 1)) >> box_shift;
+    const uint32_t my_sel = (1u << (24 + my_col)) | (1u << (28 + my_row));   // (wave-uniform: an SGPR)
 
     FwdPixel<CH> px;
     px.T = 1.f; px.Tend = 1.f; px.dead = inside ? 0u : kSign; px.last = -1;
@@ -500,10 +501,9 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 7 : GSA_FWD_WAVES)) void composit
 #pragma unroll
                 for (int w = 0; w < kScanWin; ++w) {
                     const int idx = p + w * kBatch + lane;
-                    // (box: columns [b & 3, (b >> 2) & 3], rows [(b >> 4) & 3, b >> 6] of the bin's quadrants; empty: first > last)
-                    const uint32_t bx_ = s_gid[w] >> 24;
-                    const bool hit = idx < end && (!HAS_BOX || (my_col >= (bx_ & 3u) && my_col <= ((bx_ >> 2) & 3u) &&
-                                                                my_row >= ((bx_ >> 4) & 3u) && my_row <= (bx_ >> 6)));
+                    // (box: bits 24-27 the column units, bits 28-31 the row units of the bin the record's box covers -- one AND
+                    // and one compare against this wave's two bits)
+                    const bool hit = idx < end && (!HAS_BOX || (s_gid[w] & my_sel) == my_sel);
                     const unsigned long long b = __ballot(hit);
                     if (b) {
                         const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));

@@ -1311,25 +1311,30 @@ __device__ __forceinline__ uint32_t wave_rank_round_bins(unsigned long long *mas
 
 // BOX_Q (0: none; 2 / 4: a bin is BOX_Q x BOX_Q quadrants of 8 x 8 pixels -- 16 x 16 tiles / 32 x 32 bins): the top byte of
 // every stored gaussian id (ids are below 2^24) receives the part of the gaussian's QUADRANT BOX (gsa_project_fwd's qbox:
-// the bounding box of its alpha >= 1/255 ellipse, in quadrants) that lies inside the record's bin -- first / last column,
-// first / last row, two bits each; first > last: none -- which a forward-compositor wave compares with its own quadrant
+// the bounding box of its alpha >= 1/255 ellipse, in quadrants) that lies inside the record's bin -- a 4-bit mask of the
+// columns and a 4-bit mask of the rows it covers; zero: none -- which a forward-compositor wave tests against its own quadrant
 // before it gathers anything: of the records of a 32 x 32 bin 22 % reach a given quadrant, of those whose box covers it 78 %.
 // About fifteen integer instructions per record, one 4-B load from a 4-MB array the records of a gaussian share (they are
 // consecutive slots here), and NOT ONE STORE more: what r04 measured on the way -- exact 16-bit ellipse masks in an array
 // of their own -- cost this kernel 0.021 ms for the second scattered store stream alone (3.6 M two-byte stores), whatever
 // the masks cost to compute, and a pass over the PLACED records (round 3) 0.070 ms.
-// Q = quadrants per bin side.  The four fields have 2 bits: a 64 x 64 bin (Q = 8) gets its box in units of TWO quadrants
+// Q = quadrants per bin side.  The masks have 4 bits: a 64 x 64 bin (Q = 8) gets its box in units of TWO quadrants
 // (16 pixels) -- coarser, still a pre-test the forward sweep applies before it gathers anything.
 template <int Q>
 __device__ __forceinline__ uint32_t qbox_in_bin(uint32_t qb, int bx, int by) {
     constexpr int SH = Q > 4 ? 1 : 0, U = (Q >> SH) - 1;   // units per side - 1
-    if (qb == 0xFFFFFFFFu) return (uint32_t)((U << 2) | (U << 6));   // unbounded: the whole bin
+    // The byte holds the box as two 4-bit MASKS -- bit c of the low nibble: the box covers column c of the bin's (up to) four
+    // column units, bit r of the high nibble: row r -- so that a compositor wave tests "does it cover MY quadrant" with one
+    // AND and one compare against a wave-uniform two-bit selector (first / last column and row in 2-bit fields cost that test
+    // nine vector instructions per scanned entry, in a sweep that is bound by vector issue)
+    if (qb == 0xFFFFFFFFu) return ((2u << U) - 1u) * 0x11u;   // unbounded: every column and row unit of the bin
     const int x0 = (int)(qb & 1023u) - Q * bx, y0 = (int)((qb >> 10) & 1023u) - Q * by;
     const int x1 = x0 + (int)((qb >> 20) & 63u), y1 = y0 + (int)(qb >> 26);
     const bool none = x1 < 0 || x0 > Q - 1 || y1 < 0 || y0 > Q - 1;
-    const uint32_t box = (uint32_t)(max(x0, 0) >> SH) | ((uint32_t)(min(x1, Q - 1) >> SH) << 2) |
-                         ((uint32_t)(max(y0, 0) >> SH) << 4) | ((uint32_t)(min(y1, Q - 1) >> SH) << 6);
-    return none ? 3u : box;   // (3: columns 3 .. 0 -- empty)
+    const uint32_t c0 = (uint32_t)(max(x0, 0) >> SH), c1 = (uint32_t)(min(x1, Q - 1) >> SH);
+    const uint32_t r0 = (uint32_t)(max(y0, 0) >> SH), r1 = (uint32_t)(min(y1, Q - 1) >> SH);
+    const uint32_t cols = (2u << c1) - (1u << c0), rows = (2u << r1) - (1u << r0);   // bits c0 .. c1, r0 .. r1
+    return none ? 0u : (cols & 15u) | ((rows & 15u) << 4);
 }
 
 template <int BOX_Q>

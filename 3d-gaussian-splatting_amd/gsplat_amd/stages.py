@@ -422,8 +422,9 @@ class TileBins:
 
     @property
     def sorted_boxes(self):
-        """Per record the quadrant box inside its bin as a uint8-valued int32 tensor (first column | last column << 2 | first
-        row << 4 | last row << 6; first > last: none) -- None without boxes."""
+        """Per record the quadrant box inside its bin as a uint8-valued int32 tensor: bits 0-3 the columns, bits 4-7 the rows of
+        the bin's (up to four) units the box covers (units: quadrants; pairs of quadrants in a 64-pixel bin); 0: none --
+        None without boxes."""
         return (self._gid[:self.finalize()[0]] >> 24) & 0xFF if self.boxed else None
 
 

@@ -154,8 +154,9 @@ int gsa_scan_tiles(int n, const int32_t *tiles_touched, const uint32_t *order, u
  * ABI 10 -- quadrant boxes from the placement pass.  Where gsa_tile_bin16_boxes says 1 (the direct path, at most 2^24
  * gaussians) a caller may pass qbox (gsa_project_fwd's quadrant boxes): the TOP BYTE of every sorted_gid entry then holds
  * the part of the gaussian's box that lies inside the record's bin, in quadrants of the bin (bins of 16 or 32 pixels) or
- * in PAIRS of quadrants (64-pixel bins: 8 x 8 quadrants, 2-bit fields; ABI 11) -- bits 24-25 first column, 26-27 last
- * column, 28-29 first row, 30-31 last row; first > last: none -- and the id is the low 24 bits.  gsa_composite_fwd / _bwd / _bwd_lists must be told (gid_boxes = 1): the forward sweep then gathers only
+ * in PAIRS of quadrants (64-pixel bins: 8 x 8 quadrants; ABI 11) -- since ABI 12 as two MASKS: bit 24 + c set: the box
+ * covers column unit c (0..3) of the bin, bit 28 + r: row unit r; both nibbles zero: none -- so a wave tests "my quadrant"
+ * with one AND and one compare -- and the id is the low 24 bits.  gsa_composite_fwd / _bwd / _bwd_lists must be told (gid_boxes = 1): the forward sweep then gathers only
  * the records whose box covers a wave's quadrant (a superset of the per-pixel rule: at the bench scene 78 % of the pairs it
  * lets through reach a pixel, where 22 % of a bin's records reach a given quadrant) -- for about fifteen integer
  * instructions per record in the placement and not one store more.  qbox == NULL: plain ids (gid_boxes = 0). */

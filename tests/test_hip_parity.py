@@ -1187,12 +1187,16 @@ def test_quadrant_boxes_cover_the_per_pixel_rule(gsa, bt, N, s_min, s_max):
         ok = (sig >= 0) & (sig <= r[:, 10, None, None])                 # alpha = o exp(-sigma) >= 1/255
         ok &= ((X0 + xs[None]) < W) & ((Y0 + ys[None]) < H)             # (pixels of a border bin beyond the image do not exist)
         need[lo:hi] = ok.view(-1, q, 8, q, 8).any(4).any(2)             # [m', qy, qx]
-    c0, c1, r0_, r1 = box & 3, (box >> 2) & 3, (box >> 4) & 3, (box >> 6) & 3
-    sh = 1 if bt == 64 else 0        # (a 64-pixel bin has 8 x 8 quadrants: its 2-bit fields count PAIRS of quadrants)
+    cols, rows = box & 15, (box >> 4) & 15       # masks of the column / row units the box covers
+    sh = 1 if bt == 64 else 0        # (a 64-pixel bin has 8 x 8 quadrants: its masks count PAIRS of quadrants)
     qi = torch.arange(q, device="cuda") >> sh
-    cover = ((qi[None, None, :] >= c0[:, None, None]) & (qi[None, None, :] <= c1[:, None, None]) &
-             (qi[None, :, None] >= r0_[:, None, None]) & (qi[None, :, None] <= r1[:, None, None]))   # [m, qy, qx]
-    assert int(max(int(c1.max()), int(r1.max()))) <= (q >> sh) - 1
+    cover = (((cols[:, None, None] >> qi[None, None, :]) & 1) & ((rows[:, None, None] >> qi[None, :, None]) & 1)).bool()   # [m, qy, qx]
+    units = q >> sh
+    assert int(max(int(cols.max()), int(rows.max()))) < (1 << units)
+    for mask in (cols, rows):        # a box: contiguous bits (x & (x + lowest bit) == 0), or none at all (both masks zero)
+        low = mask & -mask
+        assert bool(((mask & (mask + low)) == 0).all())
+    assert bool(((cols == 0) == (rows == 0)).all())
     missing = need & ~cover
     assert int(missing.sum()) == 0, f"{int(missing.any(-1).any(-1).sum())} records miss a quadrant they reach"
     print(f"box tightness (bin {bt}): {int(cover.sum())} quadrants covered for {int(need.sum())} needed, of {m * q * q} possible")

@@ -78,8 +78,8 @@ per variant; raw files under `gpurun_out/r04x/pmc_*` of the authoring session). 
    x, y in {{-3.5 .. 3.5}} lane constants; alpha = exp2(-s); the skip test is |s| <= log2(255) on the exponent.  6 words per
    record in LDS instead of 9; no dx / dy subtractions and no opacity multiply per (pixel, record).
 2. **Quadrant boxes in the id's top byte** (forward).  `project_fwd` leaves the box of every gaussian's alpha >= 1/255
-   ellipse in units of 8 x 8 quadrants, `emit_place` clips it to the record's bin and packs first / last column and row
-   (2 bits each) into bits 24..31 of the sorted id; the forward's scan drops the entries whose box misses the wave's quadrant
+   ellipse in units of 8 x 8 quadrants, `emit_place` clips it to the record's bin and packs it -- a 4-bit mask of the
+   bin's columns, a 4-bit mask of its rows -- into bits 24..31 of the sorted id; the forward's scan drops the entries whose box misses the wave's quadrant
    before anything is gathered.
 3. **LDS diet of the backward**: record image 3 float4, means in the padding of the (u, fac) matrix, matrix rows reused as the
    totals tile: 7 936 B per wave (r03: 8.4 KB); 90 VGPRs (r03: 95); 5 waves per SIMD as before.
