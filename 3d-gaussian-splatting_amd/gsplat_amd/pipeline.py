@@ -79,12 +79,16 @@ class ViewPipeline:
         prev: Optional[torch.cuda.Event] = None
         seen = set()
         shared: Optional[torch.cuda.Event] = None
-        if prepare is not None:
-            st = use[0] if use else None
-            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
-                if st is not None and inputs_ready is not None:
-                    st.wait_event(inputs_ready)
-                    seen.add(id(st))
+        # (the current stream is switched with set_stream and put back at the end: torch.cuda.stream()'s context manager
+        # builds two Stream objects per use, ~25 us of host time per view of a loop that has to stay ahead of the device)
+        try:
+            if prepare is not None:
+                st = use[0] if use else None
+                if st is not None:
+                    torch.cuda.set_stream(st)
+                    if inputs_ready is not None:
+                        st.wait_event(inputs_ready)
+                        seen.add(id(st))
                 made = prepare()
                 if st is not None:
                     shared = torch.cuda.Event()
@@ -92,16 +96,17 @@ class ViewPipeline:
                     for t in made or ():
                         for other in use[1:]:
                             t.record_stream(other)
-        waited = {id(use[0])} if (use and shared is not None) else set()
-        for j in range(n_views):
-            st = use[j % len(use)] if use else None
-            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
-                if st is not None and inputs_ready is not None and id(st) not in seen:
-                    st.wait_event(inputs_ready)
-                    seen.add(id(st))
-                if st is not None and shared is not None and id(st) not in waited:
-                    st.wait_event(shared)
-                    waited.add(id(st))
+            waited = {id(use[0])} if (use and shared is not None) else set()
+            for j in range(n_views):
+                st = use[j % len(use)] if use else None
+                if st is not None:
+                    torch.cuda.set_stream(st)
+                    if inputs_ready is not None and id(st) not in seen:
+                        st.wait_event(inputs_ready)
+                        seen.add(id(st))
+                    if shared is not None and id(st) not in waited:
+                        st.wait_event(shared)
+                        waited.add(id(st))
                 state = forward(j, defer)
                 # the bucket is summed into in view order; the first view also waits for the previous step's last use of it
                 before = prev if j > 0 else (self._step_done if st is not None else None)
@@ -112,7 +117,10 @@ class ViewPipeline:
                     done.append(prev)
                 if after_view is not None:
                     after_view(j)
-            states.append(state)
+                states.append(state)
+        finally:
+            if use:
+                torch.cuda.set_stream(main)
         for ev in done:
             main.wait_event(ev)
         if finish is not None:

@@ -20,6 +20,7 @@ Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import socket
@@ -206,7 +207,7 @@ def percentiles(xs):
     xs = sorted(xs)
     pick = lambda q: xs[min(len(xs) - 1, max(0, int(round(q * (len(xs) - 1)))))]  # noqa: E731
     return {"mean": round(sum(xs) / len(xs), 4), "median": round(pick(0.5), 4), "p10": round(pick(0.1), 4),
-            "p90": round(pick(0.9), 4)}
+            "p90": round(pick(0.9), 4), "max": round(xs[-1], 4)}
 
 
 class Exchange:
@@ -464,7 +465,9 @@ def main() -> None:
                 return ViewState(r, (lambda: bool(meta["speculation_ok"])) if deferred else (lambda: True))
 
             def backward(j: int, state: ViewState, before_bucket) -> None:
-                if before_bucket is not None:
+                # (with the shared projection backward a view's own backward pass stops behind its sweep and never touches
+                # the bucket: nothing to wait for)
+                if before_bucket is not None and not batch_bwd:
                     torch.cuda.current_stream().wait_event(before_bucket)
                 state.payload.backward(v_render)
 
@@ -531,6 +534,12 @@ def main() -> None:
             step(i)
         extra = settle(step) if converge else 0
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if per_step else None
+        # The host queues a step in ~1.2 ms of Python against ~2 ms of device time; what eats its lead on a slower host is
+        # the cyclic collector walking the long-lived objects of the set-up (scene tensors, modules, the interpreter's own)
+        # every few hundred allocations: 0.2 ms per step (tools/bench_nogc.py).  Freezing what exists now -- the usual
+        # measure for a long-running loop after its initialisation -- leaves the collector on for what the steps create.
+        gc.collect()
+        gc.freeze()
         fence()
         stages.WAIT_STATS[:] = [0, 0.0]
         agree_stats[:] = [0, 0.0]
@@ -720,6 +729,8 @@ def main() -> None:
                        "cull_mode": stages.DEFAULT_CULL_MODE if args.cull_mode is None else args.cull_mode},
             "warmup_effective": head["warmup_effective"],   # steps actually run before the timed window (see settle())
             "step_ms": percentiles(dist_ms),
+            # (where the slow steps of the per-step pass sit: their indices -- a burst, or spread out?)
+            "slow_steps": [i for i, x in enumerate(dist_ms) if x > 1.25 * sorted(dist_ms)[len(dist_ms) // 2]][:16],
             # how long per step the host sat waiting for the device's control words (it runs that far ahead)
             "host_wait_ms_per_step": round(head["host_wait_ms"], 4),
             # ONE view per step on one stream with a fixed camera -- the serial latency of a view, what rounds 1 and 2
