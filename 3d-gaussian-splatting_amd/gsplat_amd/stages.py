@@ -326,6 +326,15 @@ def project_views_bwd(means, quats, scales, opacities, colors, sh_degree: int, v
     shared_k = all(v.Kmat is views[0].Kmat or v.Kmat.data_ptr() == views[0].Kmat.data_ptr() for v in views)
     kms = views[0].Kmat.contiguous() if shared_k else torch.stack([v.Kmat for v in views]).contiguous()
     keep = [f32c(v, "v_splat") for v in v_splats]
+    # The cameras' rows were allocated on the streams their views ran on and are read HERE, on the current stream, typically
+    # released by the caller right behind this call: the allocator must not hand their blocks out again (in their own
+    # streams' order) before this launch has finished with them.
+    here = torch.cuda.current_stream()
+    for t in keep:
+        t.record_stream(here)
+    for v in views:
+        v.radii.record_stream(here)
+        v.sh_aux.record_stream(here)
     arr = ctypes.c_void_p * C
     radii = arr(*[v.radii.data_ptr() for v in views])
     vsp = arr(*[t.data_ptr() for t in keep])
