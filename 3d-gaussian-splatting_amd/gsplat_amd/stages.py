@@ -47,8 +47,8 @@ TIMER = StageTimer()
 
 def _call(name: str, fn, *args) -> None:
     """Launch one C-ABI stage on the current stream; raise on a non-zero return code."""
-    guard, _GUARD.device = getattr(_GUARD, "device", None), None   # (of THIS call's tensors: consumed, never sticky)
-    held, _GUARD.held = getattr(_GUARD, "held", None), None        # (ditto: the tensors behind this call's pointers)
+    held, _GUARD.held = getattr(_GUARD, "held", None), None        # (the tensors behind THIS call's pointers: consumed, never sticky)
+    guard = held[-1].device.index if held else None                 # (one of them speaks for all: a stage's tensors share a device)
     if guard is not None and torch.cuda.current_device() != guard:
         raise RuntimeError(f"gsplat_amd: {name} was given tensors on cuda:{guard} while the current device is "
                            f"cuda:{torch.cuda.current_device()}; launches go to the current device's stream -- call "
@@ -64,23 +64,22 @@ def _call(name: str, fn, *args) -> None:
     del held   # only now: the launch is queued, the caching allocator hands the memory out again in stream order
 
 
-_GUARD = threading.local()   # .device: index of the device the tensors of the stage being launched live on (set by _ptr
-                             # while the arguments of ONE _call are evaluated, consumed by that _call; per host thread)
+_GUARD = threading.local()   # .held: the tensors behind the pointers of the stage being launched (collected by _ptr while
+                             # the arguments of ONE _call are evaluated, consumed by that _call; per host thread)
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
-    """Device pointer of a tensor argument; notes its device so that ``_call`` can refuse a launch whose tensors are
-    not on the current device (the stream handed to the library is the CURRENT device's)."""
+    """Device pointer of a tensor argument; keeps the tensor for ``_call``, which refuses a launch whose tensors are not
+    on the current device (the stream handed to the library is the CURRENT device's).  (~45 calls per view: kept short.)"""
     if t is None:
         return None
     if t.is_cuda:
-        _GUARD.device = t.device.index
         # The tensor may be a temporary (``_ptr(f32c(x, ...))`` of a strided or non-fp32 x makes a copy): it has to outlive
         # the evaluation of the call's other arguments, or the next temporary is given the same block before the launch.
-        held = getattr(_GUARD, "held", None)
-        if held is None:
-            held = _GUARD.held = []
-        held.append(t)
+        try:
+            _GUARD.held.append(t)
+        except AttributeError:   # (first pointer of this call, or of this thread)
+            _GUARD.held = [t]
     return t.data_ptr()
 
 

@@ -420,7 +420,7 @@ def main() -> None:
         # ... and, in one process, their projection BACKWARD in one launch behind the last sweep (geometry read once, every
         # gradient written once, the SH-coefficient gradient formed in registers: no per-view rgb gradients, no expansion
         # kernel).  With several ranks the per-view factored form stays: its all-gathers travel under the next view.
-        batch_bwd = batch_proj and dist is None and deg >= 1 and not args.no_batch_backward
+        batch_bwd = batch_proj and dist is None and deg >= 1 and views <= 8 and not args.no_batch_backward   # (the kernel's camera limit)
         # one process, one view: nothing to sum, the backward writes the whole gradient itself
         factored = form == "factored" and (world > 1 or views > 1) and not batch_bwd
         ex = Exchange(dist, world, rank, n, views, factored, dev, expand=stages.sh_grad_expand)
@@ -495,6 +495,7 @@ def main() -> None:
 
         step.exchange = ex
         step.pipe = pipe
+        step.batch_proj, step.batch_bwd = batch_proj, batch_bwd
         return step
 
     def fence():
@@ -720,8 +721,8 @@ def main() -> None:
                        "overlap": ("alternate" if n_streams > 1 else "none"),
                        # what the views of a step share: one projection launch (and, in one process, one projection-backward
                        # launch) for all of them -- gsplat_amd.project_cameras / project_cameras_backward
-                       "projection": ("per step: %s" % ("forward + backward" if (world == 1 and deg >= 1 and not args.no_batch_backward)
-                                                        else "forward")) if (B > 1 and not args.no_batch_projection) else "per view",
+                       "projection": ("per step: %s" % ("forward + backward" if head_step.batch_bwd else "forward"))
+                                     if head_step.batch_proj else "per view",
                        "speculation_check": ("per step, repairs: %d" % head_step.pipe.repairs) if B > 1 and not args.no_defer_check else "per view",
                        "ms_per_view": round(ms_per_view, 4),
                        "intersections_M": m, "bin_tile": stages.bin_tile_for(width, height, stages.DEFAULT_CULL_MODE if args.cull_mode is None else args.cull_mode), "binned_records": info.get("binned"),
@@ -764,7 +765,7 @@ def main() -> None:
             # pipelined step (`frac_of_peak`: the bytes are the same, the kernels overlap) and of a view alone
             # (the multi-view step's own kernels where the counter file has them: its per-step projection launches move
             # fewer bytes per view than the single-view step's)
-            in_step = step_bytes if (step_bytes and B > 1 and not args.no_batch_projection and world == 1) else measured_bytes
+            in_step = step_bytes if (step_bytes and head_step.batch_bwd) else measured_bytes
             gbs = in_step / (ms_per_view * 1e-3) / 1e9
             gbs1 = measured_bytes / (solo_ms * 1e-3) / 1e9
             line["roofline_measured"] = {"hbm_bytes_per_view": int(in_step), "hbm_bytes_per_view_single_view": int(measured_bytes),
