@@ -39,8 +39,9 @@ class ViewState:
 
 
 class ViewPipeline:
-    def __init__(self, device, n_streams: int = 2, priority: int = 0):
+    def __init__(self, device, n_streams: int = 2, priority: int = 0, single_thread_autograd: bool = True):
         self.device = device
+        self.single_thread_autograd = bool(single_thread_autograd)
         self.streams: List[torch.cuda.Stream] = (
             [torch.cuda.Stream(device=device, priority=priority) for _ in range(n_streams)] if n_streams > 1 else [])
         self._step_done: Optional[torch.cuda.Event] = None   # the previous step's last use of the bucket (caller's stream)
@@ -81,43 +82,48 @@ class ViewPipeline:
         shared: Optional[torch.cuda.Event] = None
         # (the current stream is switched with set_stream and put back at the end: torch.cuda.stream()'s context manager
         # builds two Stream objects per use, ~25 us of host time per view of a loop that has to stay ahead of the device)
+        # (backward passes called inside run on THIS thread: autograd otherwise hands every backward() to a per-device worker
+        # thread and waits for it -- 125 us of host time per view, a third of what queueing a view costs, in a loop whose
+        # only job is to stay ahead of the device.  One process drives one GPU here: nothing to run in parallel.)
+        autograd_here = torch.autograd.set_multithreading_enabled(False) if self.single_thread_autograd else contextlib.nullcontext()
         try:
-            if prepare is not None:
-                st = use[0] if use else None
-                if st is not None:
-                    torch.cuda.set_stream(st)
-                    if inputs_ready is not None:
-                        st.wait_event(inputs_ready)
-                        seen.add(id(st))
-                made = prepare()
-                if st is not None:
-                    shared = torch.cuda.Event()
-                    shared.record(st)
-                    for t in made or ():
-                        for other in use[1:]:
-                            t.record_stream(other)
-            waited = {id(use[0])} if (use and shared is not None) else set()
-            for j in range(n_views):
-                st = use[j % len(use)] if use else None
-                if st is not None:
-                    torch.cuda.set_stream(st)
-                    if inputs_ready is not None and id(st) not in seen:
-                        st.wait_event(inputs_ready)
-                        seen.add(id(st))
-                    if shared is not None and id(st) not in waited:
-                        st.wait_event(shared)
-                        waited.add(id(st))
-                state = forward(j, defer)
-                # the bucket is summed into in view order; the first view also waits for the previous step's last use of it
-                before = prev if j > 0 else (self._step_done if st is not None else None)
-                backward(j, state, before)
-                if st is not None:
-                    prev = torch.cuda.Event()
-                    prev.record(st)
-                    done.append(prev)
-                if after_view is not None:
-                    after_view(j)
-                states.append(state)
+            with autograd_here:
+                if prepare is not None:
+                    st = use[0] if use else None
+                    if st is not None:
+                        torch.cuda.set_stream(st)
+                        if inputs_ready is not None:
+                            st.wait_event(inputs_ready)
+                            seen.add(id(st))
+                    made = prepare()
+                    if st is not None:
+                        shared = torch.cuda.Event()
+                        shared.record(st)
+                        for t in made or ():
+                            for other in use[1:]:
+                                t.record_stream(other)
+                waited = {id(use[0])} if (use and shared is not None) else set()
+                for j in range(n_views):
+                    st = use[j % len(use)] if use else None
+                    if st is not None:
+                        torch.cuda.set_stream(st)
+                        if inputs_ready is not None and id(st) not in seen:
+                            st.wait_event(inputs_ready)
+                            seen.add(id(st))
+                        if shared is not None and id(st) not in waited:
+                            st.wait_event(shared)
+                            waited.add(id(st))
+                    state = forward(j, defer)
+                    # the bucket is summed into in view order; the first view also waits for the previous step's last use of it
+                    before = prev if j > 0 else (self._step_done if st is not None else None)
+                    backward(j, state, before)
+                    if st is not None:
+                        prev = torch.cuda.Event()
+                        prev.record(st)
+                        done.append(prev)
+                    if after_view is not None:
+                        after_view(j)
+                    states.append(state)
         finally:
             if use:
                 torch.cuda.set_stream(main)
