@@ -504,7 +504,7 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    def settle(step, limit=200, chunk=5, tol=0.02):
+    def settle(step, limit=400, chunk=10, tol=0.01):
         """Un-timed steps until three consecutive chunks of `chunk` steps take the same time within `tol` (bounded): the
         first calls of a shape take the exact-size / LSD paths, the clocks ramp, and a short timed window right behind a
         short warm-up measures that instead of the steady state.  -> steps run."""
@@ -534,6 +534,20 @@ def main() -> None:
         for i in range(warmup):
             step(i)
         extra = settle(step) if converge else 0
+        if converge:
+            # ... and until the caching allocator has stopped growing: in a window of `steps` steps without a host wait the
+            # host runs further ahead than in settle()'s chunks, more of the steps' buffers are alive at once, and the pool
+            # answers with new segments -- hipMalloc calls in the middle of the window (two 0.44-GiB segments in the second
+            # 20-step window of a run: 40.5 -> 39.5 -> 37.7 ms for three identical windows).  Un-timed windows of the same
+            # length until one allocates nothing (at most five).
+            for _ in range(5):
+                grown = torch.cuda.memory_stats().get("segment.all.allocated", 0)
+                for i in range(steps):
+                    step(i)
+                fence()
+                extra += steps
+                if torch.cuda.memory_stats().get("segment.all.allocated", 0) == grown:
+                    break
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if per_step else None
         # The host queues a step in ~1.2 ms of Python against ~2 ms of device time; what eats its lead on a slower host is
         # the cyclic collector walking the long-lived objects of the set-up (scene tensors, modules, the interpreter's own)
@@ -544,16 +558,39 @@ def main() -> None:
         fence()
         stages.WAIT_STATS[:] = [0, 0.0]
         agree_stats[:] = [0, 0.0]
+        dbg = os.environ.get("GSPLAT_AMD_BENCH_DEBUG") == "1"
+        if dbg:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        if dbg:
+            e0.record()
         if per_step:
             marks[0].record()
+        host_t = []
         for i in range(steps):
             step(i)
             if per_step:
                 marks[i + 1].record()
+            if dbg:
+                host_t.append((time.perf_counter() - t0, stages.WAIT_STATS[1]))
+        if dbg:
+            prev_t, prev_w, rows = 0.0, 0.0, []
+            for t_, w_ in host_t[:20]:
+                rows.append(f"{(t_ - prev_t) * 1e3:.2f}({(w_ - prev_w) * 1e3:.2f})")
+                prev_t, prev_w = t_, w_
+            print("[bench debug] host ms per step (of which waiting for control words): " + " ".join(rows), file=sys.stderr)
         wait_ms = stages.WAIT_STATS[1] / max(steps, 1) * 1e3   # (before the closing fence)
+        if dbg:
+            e1.record()
+            tq = time.perf_counter() - t0
         fence()
         dt = time.perf_counter() - t0
+        if dbg:
+            ms_ = torch.cuda.memory_stats()
+            print(f"[bench debug] segments allocated so far {ms_.get('segment.all.allocated')}, freed {ms_.get('segment.all.freed')}, "
+                  f"reserved {ms_.get('reserved_bytes.all.current', 0) / 2**30:.2f} GiB", file=sys.stderr)
+            print(f"[bench debug] steps {steps} per_step {per_step}: wall {dt * 1e3:.3f} ms, host done queueing at {tq * 1e3:.3f} ms, "
+                  f"device span (main stream events) {e0.elapsed_time(e1):.3f} ms", file=sys.stderr, flush=True)
         if dist is not None:
             tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -732,6 +769,7 @@ def main() -> None:
             "step_ms": percentiles(dist_ms),
             # (where the slow steps of the per-step pass sit: their indices -- a burst, or spread out?)
             "slow_steps": [i for i, x in enumerate(dist_ms) if x > 1.25 * sorted(dist_ms)[len(dist_ms) // 2]][:16],
+            "step_ms_first_20": [round(x, 3) for x in dist_ms[:20]],
             # how long per step the host sat waiting for the device's control words (it runs that far ahead)
             "host_wait_ms_per_step": round(head["host_wait_ms"], 4),
             # ONE view per step on one stream with a fixed camera -- the serial latency of a view, what rounds 1 and 2
