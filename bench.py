@@ -534,27 +534,28 @@ def main() -> None:
         for i in range(warmup):
             step(i)
         extra = settle(step) if converge else 0
-        if converge:
-            # ... and until the caching allocator has stopped growing: in a window of `steps` steps without a host wait the
-            # host runs further ahead than in settle()'s chunks, more of the steps' buffers are alive at once, and the pool
-            # answers with new segments -- hipMalloc calls in the middle of the window (two 0.44-GiB segments in the second
-            # 20-step window of a run: 40.5 -> 39.5 -> 37.7 ms for three identical windows).  Un-timed windows of the same
-            # length until one allocates nothing (at most five).
-            for _ in range(5):
-                grown = torch.cuda.memory_stats().get("segment.all.allocated", 0)
-                for i in range(steps):
-                    step(i)
-                fence()
-                extra += steps
-                if torch.cuda.memory_stats().get("segment.all.allocated", 0) == grown:
-                    break
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if per_step else None
-        # The host queues a step in ~1.2 ms of Python against ~2 ms of device time; what eats its lead on a slower host is
+        # The host queues a step in ~1.3 ms of Python against ~1.9 ms of device time; what eats its lead on a slower host is
         # the cyclic collector walking the long-lived objects of the set-up (scene tensors, modules, the interpreter's own)
         # every few hundred allocations: 0.2 ms per step (tools/bench_nogc.py).  Freezing what exists now -- the usual
         # measure for a long-running loop after its initialisation -- leaves the collector on for what the steps create.
         gc.collect()
         gc.freeze()
+        # LAST in front of the window, because the device must not sit idle there: after ~10 ms without work the shader clock
+        # needs ~20 ms of load to come back (tools/ramp_stages.py: the two sweeps of a view 0.628 + 0.902 ms behind a 34-ms
+        # stall, 0.552 + 0.783 ten steps later; projection and binning do not move) -- the collection above is such a gap,
+        # and a 20-step window behind it is all ramp.  So: un-timed windows of the same length, the fence, the window.
+        # With `converge` they also run until the caching allocator has stopped growing (in a window without a host wait
+        # the host runs further ahead than in settle()'s chunks, more buffers are alive at once, and new segments mean
+        # hipMalloc calls inside the window), at most five.
+        for k in range(5 if converge else 1):
+            grown = torch.cuda.memory_stats().get("segment.all.allocated", 0)
+            for i in range(steps):
+                step(i)
+            extra += steps
+            if torch.cuda.memory_stats().get("segment.all.allocated", 0) == grown:
+                break
+            fence()
         fence()
         stages.WAIT_STATS[:] = [0, 0.0]
         agree_stats[:] = [0, 0.0]
