@@ -16,9 +16,9 @@ import sys as _sys
 from . import harness, scene, stages  # noqa: F401
 from ._lib import ABI_VERSION, LIB_PATH, GsaError, lib  # noqa: F401
 from .backend import HipBackend  # noqa: F401
-from .rasterization import project_cameras, project_cameras_backward, rasterization  # noqa: F401
+from .rasterization import project_cameras, project_cameras_backward, projection_buffers, rasterization  # noqa: F401
 
-__all__ = ["rasterization", "project_cameras", "project_cameras_backward", "HipBackend", "install_as_gsplat", "scene", "stages", "harness", "lib", "LIB_PATH", "ABI_VERSION"]
+__all__ = ["rasterization", "project_cameras", "project_cameras_backward", "projection_buffers", "HipBackend", "install_as_gsplat", "scene", "stages", "harness", "lib", "LIB_PATH", "ABI_VERSION"]
 
 
 def install_as_gsplat() -> None:

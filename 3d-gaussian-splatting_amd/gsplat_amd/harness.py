@@ -645,10 +645,8 @@ class ViewParallelTrainer:
             poses = torch.stack([v["pose"].to(dev, torch.float32) for v in mine]).contiguous()
             shared["views"] = S.project_views(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], degree, poses, Kc,
                                               mine[0]["width"], mine[0]["height"], cull, return_aux=True)
-            p0 = shared["views"][0]
-            return [t._base if t._base is not None else t for t in
-                    (p0.splat, p0.radii, p0.tiles_touched, p0.depth_keys, p0.tile_rects, p0.sh_aux, p0.key_range, p0.qbox)
-                    if t is not None]
+            from .rasterization import projection_buffers
+            return projection_buffers(shared["views"])
 
         def front(j, exact):
             view = mine[j]

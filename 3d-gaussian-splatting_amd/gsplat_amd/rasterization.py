@@ -158,6 +158,15 @@ def project_cameras(means, quats, scales, opacities, colors, viewmats, Ks, width
     return views
 
 
+def projection_buffers(projections):
+    """The tensors behind the projections of ONE ``project_cameras`` call (the [C, ...] slabs the per-camera projections are
+    slices of): what a caller that uses them on OTHER streams than the one they were made on hands the allocator
+    (``Tensor.record_stream``) -- ``ViewPipeline.run(prepare=...)`` does it with what ``prepare`` returns."""
+    p0 = projections[0]
+    return [t._base if t._base is not None else t for t in
+            (p0.splat, p0.radii, p0.tiles_touched, p0.depth_keys, p0.tile_rects, p0.sh_aux, p0.key_range, p0.qbox) if t is not None]
+
+
 def project_cameras_backward(projections, means, quats, scales, opacities, colors, grad_out, accumulate: bool = False) -> None:
     """Finishes the backward passes of the cameras of ``project_cameras(defer_backward=True)`` in ONE launch, once every
     camera's ``rasterization(projection=...)`` output has been backpropagated (on the current stream, or on streams the

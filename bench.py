@@ -443,10 +443,7 @@ def main() -> None:
                 shared["proj"] = gsplat_amd.project_cameras(leaves[0], leaves[1], leaves[2], opac.squeeze(-1), leaves[4],
                                                             step_cams[base], K[0], width, height, sh_degree=deg,
                                                             cull_mode=args.cull_mode, defer_backward=batch_bwd)
-                p0 = shared["proj"][0]
-                return [t._base if t._base is not None else t for t in
-                        (p0.splat, p0.radii, p0.tiles_touched, p0.depth_keys, p0.tile_rects, p0.sh_aux, p0.key_range, p0.qbox)
-                        if t is not None]
+                return gsplat_amd.projection_buffers(shared["proj"])
 
             def forward(j: int, deferred: bool) -> ViewState:
                 vm = cams[(base + j * world + rank) % ring_size][None]
