@@ -38,12 +38,26 @@ class ViewState:
         self.payload, self.check = payload, check
 
 
+# One set of side streams per (device, count, priority) for ALL pipelines of the process: the runtime multiplexes streams onto a
+# few hardware queues in creation order, and a process that builds several pipelines (bench.py's legs, a trainer beside an
+# evaluator) ended up with a pipeline whose two streams shared ONE queue -- its views then ran one after the other (the
+# training-step leg of bench.py 2.82 ms where the same step alone in a process takes 2.53).
+_STREAMS = {}
+
+
+def _side_streams(device, n: int, priority: int) -> List[torch.cuda.Stream]:
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), n, priority)
+    if key not in _STREAMS:
+        _STREAMS[key] = [torch.cuda.Stream(device=device, priority=priority) for _ in range(n)]
+    return _STREAMS[key]
+
+
 class ViewPipeline:
     def __init__(self, device, n_streams: int = 2, priority: int = 0, single_thread_autograd: bool = True):
         self.device = device
         self.single_thread_autograd = bool(single_thread_autograd)
-        self.streams: List[torch.cuda.Stream] = (
-            [torch.cuda.Stream(device=device, priority=priority) for _ in range(n_streams)] if n_streams > 1 else [])
+        self.streams: List[torch.cuda.Stream] = _side_streams(device, n_streams, priority) if n_streams > 1 else []
         self._step_done: Optional[torch.cuda.Event] = None   # the previous step's last use of the bucket (caller's stream)
         self.repairs = 0            # steps that were rendered again because a view's speculation failed
         self.steps = 0
