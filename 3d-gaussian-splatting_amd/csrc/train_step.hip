@@ -14,6 +14,8 @@
 //
 // All are HBM-streaming kernels (fp32, no MFMA).
 
+#include <type_traits>
+
 #include "gsa_common.h"
 
 namespace {
@@ -42,13 +44,26 @@ __device__ __forceinline__ void block_add3(double a, double b, double c, double 
 }
 
 
-// sums[k] += sum over blocks of block_sums[3 * b + k]   (one workgroup)
-__global__ __launch_bounds__(kThreads) void loss_finalize_kernel(int n_blocks, const double *__restrict__ block_sums,
-                                                                 double *__restrict__ sums) {
-    __shared__ double red[3][kThreads / GSA_WAVE];
+// sums[k] += sum over blocks of block_sums[3 * b + k]   (one workgroup of 1024; a thread's loads are issued together: the
+// 256-thread loop of dependent loads this replaces took 7 us for a 1080p view's 3744 entries)
+constexpr int kFinalizeThreads = 1024, kFinalizeBatch = 4;
+__global__ __launch_bounds__(kFinalizeThreads) void loss_finalize_kernel(int n_blocks, const double *__restrict__ block_sums,
+                                                                         double *__restrict__ sums) {
+    __shared__ double red[3][kFinalizeThreads / GSA_WAVE];
     double acc[3] = {0, 0, 0};
-    for (int b = threadIdx.x; b < n_blocks; b += kThreads)
-        for (int k = 0; k < 3; ++k) acc[k] += block_sums[3 * (long)b + k];
+    for (int b0 = threadIdx.x; b0 < n_blocks; b0 += kFinalizeBatch * kFinalizeThreads) {
+        double v[kFinalizeBatch][3];
+#pragma unroll
+        for (int j = 0; j < kFinalizeBatch; ++j) {
+            const int b = b0 + j * kFinalizeThreads;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[j][k] = b < n_blocks ? block_sums[3 * (long)b + k] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < kFinalizeBatch; ++j)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc[k] += v[j][k];
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1)
         for (int k = 0; k < 3; ++k) acc[k] += __shfl_xor(acc[k], d);
@@ -58,7 +73,7 @@ __global__ __launch_bounds__(kThreads) void loss_finalize_kernel(int n_blocks, c
     __syncthreads();
     if (threadIdx.x < 3) {
         double s = 0;
-        for (int w = 0; w < kThreads / GSA_WAVE; ++w) s += red[threadIdx.x][w];
+        for (int w = 0; w < kFinalizeThreads / GSA_WAVE; ++w) s += red[threadIdx.x][w];
         sums[threadIdx.x] += s;
     }
 }
@@ -95,7 +110,131 @@ __device__ __forceinline__ float lane_below(float v) {
 __device__ __forceinline__ float lane_above(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xF, 0xF, true));
 }
-__device__ __forceinline__ float hsum3(float v) { return (lane_below(v) + v) + lane_above(v); }
+__device__ __forceinline__ float hsum3(float v) {
+#pragma clang fp contract(off)   // v is often a product: fused into the first add it could not take the shifted operand (+1 move)
+    return (lane_below(v) + v) + lane_above(v);
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// A whole image as a buffer resource (base pointer from the kernel arguments, so in scalar registers): a row's byte offset
+// rides in the scalar offset of a buffer load / store and the lane's column in the 32-bit vector offset -- no 64-bit
+// address arithmetic per lane and row.  (The host side refuses images of 4 GiB and more.)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t image_resource(const float *image, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(image), 0, bytes, 0x00020000);
+}
+
+// One strip of one band.  EDGE: the strip touches the image border (zero padding, clamped fetches, partial bands);
+// interior strips (~90 % at 1080p) run the same arithmetic with every border test compiled out.  The rows of a strip
+// are walked as a first chunk (no statistics before input row 2, no gradient before input row 4), whole middle chunks
+// and a last chunk, so what a row has to do is known at compile time.
+template <bool WANT_GRAD, bool EDGE>
+__device__ __forceinline__ void loss_strip_rows(int width, int height, int lane, int c, int x, int y0,
+                                                const float *__restrict__ render, const float *__restrict__ target,
+                                                float w_l1, float w_ss, float *__restrict__ v_render, float &l1_out,
+                                                float &ssim_out, float &mse_out) {
+    static_assert(kStripChunk >= 4 && kStripRows + 4 >= 2 * kStripChunk, "first / middle / last chunks");
+    const bool col_in = !EDGE || (x >= 0 && x < width);
+    const bool col_out = col_in && lane >= 2 && lane < 2 + kStripCols;   // the columns this wave writes and counts
+    // byte offsets of the lane's column within a row (32-bit: a row base in scalar registers + this, no 64-bit lane math)
+    const unsigned col_bytes = (unsigned)((EDGE ? min(max(x, 0), width - 1) : x) * 3 + c) * 4u;
+    const unsigned row_bytes = (unsigned)width * 12u, image_bytes = (unsigned)height * row_bytes;
+    const __amdgpu_buffer_rsrc_t render_rows = image_resource(render, image_bytes), target_rows = image_resource(target, image_bytes),
+                                 grad_rows = image_resource(WANT_GRAD ? v_render : render, image_bytes);
+
+    // input rows i = 0 .. kStripRows + 3 are image rows y0 - 2 + i; loads are clamped, not predicated (in flight together)
+    auto fetch = [&](int i, float &a, float &b) {
+        const int y = y0 - 2 + i;
+        const unsigned row = (unsigned)(EDGE ? min(max(y, 0), height - 1) : y) * row_bytes;   // (uniform)
+        a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(render_rows, col_bytes, row, 0));
+        b = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(target_rows, col_bytes, row, 0));
+    };
+    float na[kStripChunk], nb[kStripChunk];
+#pragma unroll
+    for (int k = 0; k < kStripChunk; ++k) fetch(k, na[k], nb[k]);
+
+    // the statistics of the render and of the target go through the same arithmetic: kept as (a, b) pairs, which the packed
+    // fp32 instructions add / multiply two at a time
+    f32x2 h1_m = {0, 0}, h2_m = {0, 0}, h1_q = {0, 0}, h2_q = {0, 0};   // horizontal sums of (a, b), (a a, b b): rows i - 1, i - 2
+    float h1_x = 0.f, h2_x = 0.f;                                       // ... of a b
+    f32x2 p1_m = {0, 0}, p2_m = {0, 0};                                 // horizontal sums of the partials (mu, aa): rows i - 2, i - 3
+    float p1_x = 0.f, p2_x = 0.f;                                       // ... of the partial ab
+    float a1 = 0.f, b1 = 0.f, a2 = 0.f, b2 = 0.f;                       // a, b of rows i - 1, i - 2
+    float l1 = 0.f, ssim = 0.f, mse = 0.f;
+
+    // phase 0: the first chunk, 1: a middle chunk, 2: the last chunk
+    auto chunk = [&](auto phase, const int i0) {
+        constexpr int PHASE = decltype(phase)::value;
+        float ca[kStripChunk], cb[kStripChunk];
+#pragma unroll
+        for (int k = 0; k < kStripChunk; ++k) { ca[k] = na[k]; cb[k] = nb[k]; }
+        if (PHASE != 2) {
+#pragma unroll
+            for (int k = 0; k < kStripChunk; ++k) fetch(i0 + kStripChunk + k, na[k], nb[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < kStripChunk; ++k) {
+            const int i = i0 + k, y = y0 - 2 + i;
+            const bool in = !EDGE || (col_in && y >= 0 && y < height);
+            const float a = in ? clamp01(ca[k]) : 0.f, b = in ? cb[k] : 0.f;
+            const f32x2 ab = {a, b}, sq = ab * ab;
+            const f32x2 h_m = {hsum3(a), hsum3(b)}, h_q = {hsum3(sq.x), hsum3(sq.y)};
+            const float h_x = hsum3(a * b);
+            // ---- statistics centred on row y - 1 (needs rows y - 2 .. y)
+            f32x2 P_m = {0.f, 0.f};
+            float P_x = 0.f;
+            const int yc = y - 1;
+            if (PHASE != 0 || k >= 2) {
+                const float inv9 = 1.f / 9.f;
+                const f32x2 mu = ((h2_m + h1_m) + h_m) * inv9, mu_sq = mu * mu;
+                const f32x2 var = ((h2_q + h1_q) + h_q) * inv9 - mu_sq;
+                const float mu_ab = mu.x * mu.y, cov = ((h2_x + h1_x) + h_x) * inv9 - mu_ab;
+                const float A1 = 2.f * mu_ab + kC1, A2 = 2.f * cov + kC2;
+                const float B1 = mu_sq.x + mu_sq.y + kC1, B2 = var.x + var.y + kC2;
+                const float den = B1 * B2;
+                float inv = __builtin_amdgcn_rcpf(den);
+                inv = inv * (2.f - den * inv);            // one Newton step: as good as the division
+                const float S = A1 * A2 * inv;
+                // (outside the image there is no window: its partials are zeros)
+                const float inv_p = (!EDGE || (col_in && yc >= 0 && yc < height)) ? inv : 0.f;
+                // d S / d mu_a with E[a^2], E[ab] held fixed (var_a and cov depend on mu_a too); d S / d E[a^2]; d S / d E[ab]
+                P_m.x = (2.f * mu.y * (A2 - A1) - S * 2.f * mu.x * (B2 - B1)) * inv_p;
+                P_m.y = -S * B1 * inv_p;
+                P_x = 2.f * A1 * inv_p;
+                // the band's own rows: 3 <= i < kStripRows + 3 (lanes outside the written columns are dropped at the end)
+                const bool own = (PHASE == 0 ? k >= 3 : true) && (PHASE == 2 ? k < kStripChunk - 1 : true);
+                if (own) {
+                    const float d = a1 - b1;
+                    if (!EDGE || yc < height) {   // (uniform; rows above the image do not occur: y0 >= 0)
+                        l1 += fabsf(d); mse = __builtin_fmaf(d, d, mse); ssim += S;
+                    }
+                }
+            }
+            const f32x2 hp_m = {hsum3(P_m.x), hsum3(P_m.y)};
+            const float hp_x = hsum3(P_x);
+            // ---- the gradient of row y - 2 (needs the partials of rows y - 3 .. y - 1)
+            if (WANT_GRAD && (PHASE != 0 || k >= 4)) {
+                const int yo = y - 2;
+                if (col_out && (!EDGE || yo < height)) {
+                    const f32x2 s_m = (p2_m + p1_m) + hp_m;   // (mu, aa)
+                    const float s_ab = (p2_x + p1_x) + hp_x;
+                    const float d_ssim = s_m.x + 2.f * a2 * s_m.y + b2 * s_ab;
+                    const float d = a2 - b2;
+                    const float sign = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, w_l1 * sign - w_ss * d_ssim), grad_rows,
+                                                          col_bytes, (unsigned)yo * row_bytes, 0);
+                }
+            }
+            h2_m = h1_m; h1_m = h_m; h2_q = h1_q; h1_q = h_q; h2_x = h1_x; h1_x = h_x;
+            p2_m = p1_m; p1_m = hp_m; p2_x = p1_x; p1_x = hp_x;
+            a2 = a1; b2 = b1; a1 = a; b1 = b;
+        }
+    };
+    chunk(std::integral_constant<int, 0>{}, 0);
+    for (int i0 = kStripChunk; i0 < kStripRows + 4 - kStripChunk; i0 += kStripChunk) chunk(std::integral_constant<int, 1>{}, i0);
+    chunk(std::integral_constant<int, 2>{}, kStripRows + 4 - kStripChunk);
+    l1_out = col_out ? l1 : 0.f; ssim_out = col_out ? ssim : 0.f; mse_out = col_out ? mse : 0.f;
+}
 
 template <bool WANT_GRAD>
 __global__ __launch_bounds__(3 * GSA_WAVE) void loss_strip_kernel(int width, int height, int strips,
@@ -106,85 +245,16 @@ __global__ __launch_bounds__(3 * GSA_WAVE) void loss_strip_kernel(int width, int
     const int lane = threadIdx.x & 63, c = threadIdx.x >> 6;      // the wave's colour channel
     const int strip = blockIdx.x % strips, band = blockIdx.x / strips;
     const int x = strip * kStripCols + lane - 2, y0 = band * kStripRows;
-    const bool col_in = x >= 0 && x < width;
-    const bool col_out = col_in && lane >= 2 && lane < 2 + kStripCols;   // the columns this wave writes and counts
-    const long xc = (long)min(max(x, 0), width - 1) * 3 + c;
     const float inv_count = grad_scale / (3.f * (float)width * (float)height);
     const float w_l1 = (1.f - lambda_dssim) * inv_count, w_ss = lambda_dssim * inv_count * (1.f / 9.f);
-
-    // input rows i = 0 .. kStripRows + 3 are image rows y0 - 2 + i; loads are clamped, not predicated (in flight together)
-    auto fetch = [&](int i, float &a, float &b) {
-        const int y = y0 - 2 + i;
-        const long o = (long)min(max(y, 0), height - 1) * width * 3 + xc;
-        a = render[o];
-        b = target[o];
-    };
-    float na[kStripChunk], nb[kStripChunk];
-#pragma unroll
-    for (int k = 0; k < kStripChunk; ++k) fetch(k, na[k], nb[k]);
-
-    float h1[5] = {0, 0, 0, 0, 0}, h2[5] = {0, 0, 0, 0, 0};   // horizontal sums of rows i - 1, i - 2
-    float p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};               // horizontal sums of the partials of rows i - 2, i - 3
-    float a1 = 0.f, b1 = 0.f, a2 = 0.f, b2 = 0.f;             // a, b of rows i - 1, i - 2
-    float l1 = 0.f, ssim = 0.f, mse = 0.f;
-    for (int i0 = 0; i0 < kStripRows + 4; i0 += kStripChunk) {
-        float ca[kStripChunk], cb[kStripChunk];
-#pragma unroll
-        for (int k = 0; k < kStripChunk; ++k) { ca[k] = na[k]; cb[k] = nb[k]; }
-        if (i0 + kStripChunk < kStripRows + 4) {
-#pragma unroll
-            for (int k = 0; k < kStripChunk; ++k) fetch(i0 + kStripChunk + k, na[k], nb[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < kStripChunk; ++k) {
-            const int i = i0 + k, y = y0 - 2 + i;
-            const bool in = col_in && y >= 0 && y < height;
-            const float a = in ? clamp01(ca[k]) : 0.f, b = in ? cb[k] : 0.f;
-            float h[5] = {hsum3(a), hsum3(b), hsum3(a * a), hsum3(b * b), hsum3(a * b)};
-            // ---- statistics centred on row y - 1 (needs rows y - 2 .. y)
-            float P[3] = {0.f, 0.f, 0.f};
-            const int yc = y - 1;
-            if (i >= 2) {   // (uniform)
-                const float inv9 = 1.f / 9.f;
-                const float mu_a = ((h2[0] + h1[0]) + h[0]) * inv9, mu_b = ((h2[1] + h1[1]) + h[1]) * inv9;
-                const float e_aa = ((h2[2] + h1[2]) + h[2]) * inv9, e_bb = ((h2[3] + h1[3]) + h[3]) * inv9;
-                const float e_ab = ((h2[4] + h1[4]) + h[4]) * inv9;
-                const float var_a = e_aa - mu_a * mu_a, var_b = e_bb - mu_b * mu_b, cov = e_ab - mu_a * mu_b;
-                const float A1 = 2.f * mu_a * mu_b + kC1, A2 = 2.f * cov + kC2;
-                const float B1 = mu_a * mu_a + mu_b * mu_b + kC1, B2 = var_a + var_b + kC2;
-                const float den = B1 * B2;
-                float inv = __builtin_amdgcn_rcpf(den);
-                inv = inv * (2.f - den * inv);            // one Newton step: as good as the division
-                const float S = A1 * A2 * inv;
-                const bool valid = col_in && yc >= 0 && yc < height;   // (outside the image there is no window: zeros)
-                // d S / d mu_a with E[a^2], E[ab] held fixed (var_a and cov depend on mu_a too); d S / d E[a^2]; d S / d E[ab]
-                P[0] = valid ? (2.f * mu_b * (A2 - A1) - S * 2.f * mu_a * (B2 - B1)) * inv : 0.f;
-                P[1] = valid ? -S * B1 * inv : 0.f;
-                P[2] = valid ? 2.f * A1 * inv : 0.f;
-                if (valid && col_out && yc >= y0 && yc < y0 + kStripRows) {
-                    const float d = a1 - b1;
-                    l1 += fabsf(d); mse = __builtin_fmaf(d, d, mse); ssim += S;
-                }
-            }
-            const float hp[3] = {hsum3(P[0]), hsum3(P[1]), hsum3(P[2])};
-            // ---- the gradient of row y - 2 (needs the partials of rows y - 3 .. y - 1)
-            if (WANT_GRAD && i >= 4) {
-                const int yo = y - 2;
-                if (col_out && yo < height && yo < y0 + kStripRows) {
-                    const float s_mu = (p2[0] + p1[0]) + hp[0], s_aa = (p2[1] + p1[1]) + hp[1], s_ab = (p2[2] + p1[2]) + hp[2];
-                    const float d_ssim = s_mu + 2.f * a2 * s_aa + b2 * s_ab;
-                    const float d = a2 - b2;
-                    const float sign = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-                    v_render[((long)yo * width + x) * 3 + c] = w_l1 * sign - w_ss * d_ssim;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 5; ++q) { h2[q] = h1[q]; h1[q] = h[q]; }
-#pragma unroll
-            for (int q = 0; q < 3; ++q) { p2[q] = p1[q]; p1[q] = hp[q]; }
-            a2 = a1; b2 = b1; a1 = a; b1 = b;
-        }
-    }
+    // interior: all 64 columns and all kStripRows + 4 rows of the strip lie inside the image
+    const bool interior = strip > 0 && (strip + 1) * kStripCols + 2 <= width && band > 0 &&
+                          (band + 1) * kStripRows + 2 <= height;
+    float l1, ssim, mse;
+    if (interior)
+        loss_strip_rows<WANT_GRAD, false>(width, height, lane, c, x, y0, render, target, w_l1, w_ss, v_render, l1, ssim, mse);
+    else
+        loss_strip_rows<WANT_GRAD, true>(width, height, lane, c, x, y0, render, target, w_l1, w_ss, v_render, l1, ssim, mse);
     double s0 = l1, s1 = ssim, s2 = mse;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -442,6 +512,7 @@ extern "C" int gsa_view_loss(int width, int height, const float *render, const f
     GSA_RETURN_IF(width <= 0 || height <= 0 || !render || !target || !workspace || !sums, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(workspace_bytes < gsa_view_loss_workspace_bytes(width, height), GSA_ERR_WORKSPACE_TOO_SMALL);
     GSA_RETURN_IF((reinterpret_cast<uintptr_t>(workspace) & 7) != 0, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF((unsigned long long)width * height * 12ull >= (1ull << 32), GSA_ERR_INVALID_ARGUMENT);   // 32-bit byte offsets
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int strips = gsa_div_up(width, kStripCols);
     const int grid = strips * gsa_div_up(height, kStripRows);
@@ -453,7 +524,7 @@ extern "C" int gsa_view_loss(int width, int height, const float *render, const f
         loss_strip_kernel<false><<<grid, 3 * GSA_WAVE, 0, s>>>(width, height, strips, render, target, lambda_dssim, grad_scale,
                                                               nullptr, wave_sums);
     GSA_LAUNCH_CHECK();
-    loss_finalize_kernel<<<1, kThreads, 0, s>>>((int)view_loss_waves(width, height), wave_sums, sums);
+    loss_finalize_kernel<<<1, kFinalizeThreads, 0, s>>>((int)view_loss_waves(width, height), wave_sums, sums);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }

@@ -278,10 +278,11 @@ def test_fused_view_parallel_two_ranks_match_reference_trainer(gold, factored):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(32, 48), (67, 130), (1, 5)])
+@pytest.mark.parametrize("shape", [(32, 48), (67, 130), (1, 5), (95, 250)])
 def test_view_loss_kernel_matches_torch_formulation(gold, shape):
     """gsa_view_loss vs autograd through the harness's torch formulation of the reference's loss (trainer.py:485-492):
-    L1, SSIM, mse and d loss / d render; values outside [0, 1] exercise the straight-through clamp."""
+    L1, SSIM, mse and d loss / d render; values outside [0, 1] exercise the straight-through clamp.  95 x 250 has strips
+    that lie wholly inside the image (the kernel's border-free variant) next to border strips and a partial last band."""
     from gsplat_amd import stages as S
     from gsplat_amd.harness import view_loss
     h, w = shape
