@@ -216,7 +216,7 @@ What changed in r04 besides the rasterizer (DESIGN.md section 8):
 * the model keeps the SH coefficients as ONE [N,16,3] segment of its flat buckets -- what the rasterizer reads and its
   backward writes -- so `activate_fwd` no longer builds cat(features_dc, features_rest) (88.6 -> 11.6 us) and the gradient is
   not split again; the reference's two learning rates alternate inside the segment (`gsa_adam_step_striped`);
-* `loss_strip_kernel`: column-walking lanes, DPP neighbours, no LDS: 34.5 us per view alone (r03: 75.6 us);
+* `loss_strip_kernel`: column-walking lanes, DPP neighbours, no LDS, border-free instance for interior strips, packed fp32 pairs: 29.6 us per view alone (34.5 before these; r03: 75.6 us);
 * `step_report_kernel`: the step's metrics in one launch (r03: ~25 torch kernels of ~5 us between Adam and the next step);
 * the views go through `pipeline.ViewPipeline` (deferred speculation checks: no host wait inside the step);
 * the views of the step share ONE projection launch (`project_fwd_kernel<3, true, true>`) and ONE projection-backward launch
