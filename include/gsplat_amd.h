@@ -406,7 +406,8 @@ int gsa_sh_grad_expand_split(int n, const float *means, int sh_degree, int sh_co
  *   respect to the render.  render/target: [H,W,3] fp32.  sums[3] (double, ACCUMULATED: zero them first) receive
  *   sum |img - target|, sum SSIM map, sum (img - target)^2 over the 3 H W elements (L1 = sums[0] / 3HW, SSIM =
  *   sums[1] / 3HW, PSNR's mse = sums[2] / 3HW, :70-75).  v_render (may be NULL) = grad_scale * d loss / d render.
- *   workspace: gsa_view_loss_workspace_bytes(width, height).
+ *   workspace: gsa_view_loss_workspace_bytes(width, height).  Images of 4 GiB and more (12 H W bytes; rows are addressed
+ *   with 32-bit byte offsets) are refused with GSA_ERR_INVALID_ARGUMENT.
  *
  * gsa_adam_step: one torch.optim.Adam step (no weight decay, no amsgrad) over a flat bucket of n floats split into
  *   n_segments (<= 8) consecutive segments, segment k = [segment_end[k-1], segment_end[k]) with learning rate

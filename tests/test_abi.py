@@ -53,6 +53,12 @@ def test_error_codes_and_strings():
     # an 8K frame has too many 16 x 16 tiles for the 16-bit tile ids of the fused binning, but not 32 x 32 bins
     assert lib.gsa_tile_bin16_supported(1920, 1080) == 1 and lib.gsa_tile_bin16_supported(7680, 4320) == 0
     assert lib.gsa_tile_bins_supported(7680, 4320, 32) == 1 and lib.gsa_tile_bins_supported(7680, 4320, 24) == 0
+    # the loss kernel addresses image rows with 32-bit byte offsets: 12 H W >= 4 GiB is refused (fake non-null pointers:
+    # nothing is dereferenced before the checks)
+    fake, big = ctypes.c_void_p(4096), 20000
+    ws = lib.gsa_view_loss_workspace_bytes(big, big)
+    assert lib.gsa_view_loss(big, big, fake, fake, 0.2, 1.0, fake, ws, fake, fake, None) == -1
+    assert lib.gsa_view_loss(64, 64, fake, fake, 0.2, 1.0, fake, 8, fake, fake, None) == -2   # workspace too small
     with pytest.raises(GsaError):
         check(-1, "x")
 
