@@ -410,7 +410,7 @@ __device__ __forceinline__ bool walk_fwd(const ST &st, int n, float yrel, FwdPix
 
 // ---- the forward kernel ------------------------------------------------------------------------------------------
 // A (tile, quadrant) wave walks its bin's depth-ordered record list in three decoupled steps:
-//   SCAN   128 list entries at a time, coalesced: with BOXES (gsa_tile_bin16 given the gaussians' quadrant boxes) the top
+//   SCAN   64 list entries at a time, coalesced: with BOXES (gsa_tile_bin16 given the gaussians' quadrant boxes) the top
 //          byte of an entry says which quadrants of the bin the gaussian's bounding box covers -- a 4-bit mask of its
 //          columns, a 4-bit mask of its rows -- and only the entries whose box covers this wave's quadrant (one AND, one
 //          compare; ~28 % in a 32 x 32 bin) are appended to a small queue in LDS: ballot + mbcnt, half a dozen vector
@@ -424,8 +424,9 @@ __device__ __forceinline__ bool walk_fwd(const ST &st, int n, float yrel, FwdPix
 //   [0] s0  gx  gy  A          (the record's alpha exponent for THIS quadrant: sigma_form / alpha_exponent)
 //   [1] B  C  r  g
 //   [2] b  (int) position in the sorted list  depth  -
-constexpr int kQueue = 256;        // candidates: < 64 left over + 128 from one scan step
-constexpr int kScanWin = 2;        // windows of 64 entries per scan step
+constexpr int kQueue = 128;        // candidates: < 64 left over + 64 from one scan step
+constexpr int kScanWin = 1;        // windows of 64 entries per scan step (two windows, 128 entries in flight: forward sweep +4 % --
+                                   // a wave scans at most 64 entries past what its pixels still need, and waits for one load)
 template <int F4>
 struct Dense {
     static constexpr bool kDense = true;
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 7 : GSA_FWD_WAVES)) void composit
     uint32_t *my_list = LISTS ? quad_list + (((size_t)start << 2) << (2 * bin_shift)) + (size_t)slice * (size_t)(end - start) : nullptr;
 
     if (__ballot(inside) != 0ull && start < end) {
-        // ---- SCAN state: the entries [p, p + 128) are in registers (loads clamped, not predicated: in flight together)
+        // ---- SCAN state: the entries [p, p + 64 kScanWin) are in registers (loads clamped, not predicated)
         int p = start, head = 0, tail = 0;   // (wave-uniform)
         uint32_t s_gid[kScanWin];
         auto scan_issue = [&]() {
