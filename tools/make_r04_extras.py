@@ -154,6 +154,30 @@ the overlap of the two pipes, and a 2-pass MFMA hides about one vector instructi
 compiler spaces them with s_nop) lengthen the chain to the first exponent where the vector form has four independent chains
 of five.  Reverted; the vector polynomial stays.
 
+## Packed fp32 in the forward walk -- built, measured, reverted
+
+`v_pk_fma_f32` issues at `v_fma_f32`'s rate (`tools/microbench/pk_fma.hip`: 4.24 clk per wave-instruction for both at 8 waves per
+SIMD), so two records' alpha exponents cost five instructions instead of ten IF a field of two records sits in an aligned
+register pair.  Built: the forward's LDS image repacked in PAIRS of records, field by field
+([s0 s0' gx gx'] [gy gy' A A'] [B B' C C'] [r g r' g'] [b d b' d'] [pos pos']), exponents and weights packed, red + green
+accumulated by one packed multiply-add per record (each channel still adds its records one by one in depth order: images
+bit-identical to the scalar walk, all 159 GPU tests green).  47 instead of 61 vector instructions per group of four records.
+Same box, `tools/ab3.sh` (`bench.py --steps 40`, stage times on single-view steps), forward sweep in ms:
+
+| build | forward | 4-view step, per view |
+|---|---:|---:|
+| scalar walk (control) | 0.1342 - 0.1345 | 0.4676 - 0.4778 |
+| control + 12-byte load of the record's third quad | 0.1343 - 0.1349 | 0.4712 - 0.4714 |
+| paired image, packed walk, 6 waves per SIMD (80 registers, no spills) | 0.1423 - 0.1426 | 0.4712 - 0.4719 |
+| paired image, packed walk, colour reads pinned in front of the stop test, 7 waves per SIMD (72 registers: 21 spills) | 0.1661 - 0.1667 | 0.500 - 0.501 |
+| first cut (colour reads sunk behind the stop test; a dead fourth word of the gather's third quad reused as a temporary inside the walk: the walk waited for the gather) | 0.1449 - 0.1460 | 0.4782 - 0.4804 |
+
+No gain although a quarter of the vector instructions are gone: two packed dependent chains per group where four scalar
+chains interleaved, and 4-B scattered staging stores.  With the rows of DESIGN.md section 5 ("4 more INDEPENDENT instructions
+per record: +17 %"): independent instructions cost issue slots; removing instructions from a dependent chain buys nothing.
+What DID come out of the series: a scan step of 64 list entries instead of 128 (0.134 -> 0.130, kept), and packed pairs in the
+loss kernel, whose rows are independent (34.5 -> 29.6 us per view).
+
 Not built, costed (DESIGN.md section 5): phase B of the backward on MFMA (fills 28 % of f32 tiles whose rate equals the vector
 rate: 512 cycles per sub-batch against ~300); one `v_rcp` per sub-batch instead of one per record by batch inversion (saves
 ~8 of ~110 cycles per record visit for 8 more live registers at the 96-register budget).
