@@ -13,6 +13,7 @@ from typing import Dict, Optional
 import torch
 
 from .rasterization import rasterization
+from .stages import Speculation
 
 # render_mode -> ((result key, channel selector), ...)   (gsplat_backend.py:190-201)
 _MODE_OUTPUTS = {
@@ -28,6 +29,13 @@ class HipBackend:
     def __init__(self, K: torch.Tensor):
         self.rasterization = rasterization
         self.K = K
+        # what the asynchronous binning remembers about the frames THIS backend renders (record capacity, depth-key range):
+        # a trainer's backend and an evaluator's backend of the same frame size each keep their own
+        self.speculation = Speculation()
+
+    def _extra(self) -> Dict:
+        # (an injected operator -- a test's oracle, the published gsplat -- has no such keyword)
+        return {"speculation": self.speculation} if self.rasterization is rasterization else {}
 
     # -- the live entry point (gsplat_backend.py:129-210) -------------------------------------------
     def render_with_depth(self, gaussian_params: Dict, viewpoint: Dict, bg_color: Optional[torch.Tensor] = None,
@@ -47,7 +55,7 @@ class HipBackend:
             means=gaussian_params["means3D"], quats=gaussian_params["rotations"], scales=gaussian_params["scales"],
             opacities=opacities, colors=colors, viewmats=viewmat[None], Ks=self.K.to(viewmat.device)[None],
             width=viewpoint["image_width"], height=viewpoint["image_height"], packed=False,
-            render_mode=render_mode, sh_degree=sh_degree, backgrounds=bg_color[None])
+            render_mode=render_mode, sh_degree=sh_degree, backgrounds=bg_color[None], **self._extra())
         image = renders[0]
         result = {"alpha": alphas[0]}
         for key, channel in _MODE_OUTPUTS[render_mode]:
@@ -73,8 +81,14 @@ class HipBackend:
         the B cameras -- the gaussians are projected for all of them in one launch (geometry and SH rows read once); per
         camera the same image as ``render_single``; images returned channel-first."""
         n_views = view_matrices.shape[0]
+        if n_views == 0:   # (the reference's loop over no views: empty stacks)
+            dev = gaussian_params["means3D"].device
+            return {"images": torch.empty(0, 3, height, width, device=dev), "alphas": torch.empty(0, 1, height, width, device=dev)}
         degree = 3 if gaussian_params.get("shs") is not None else None
-        colors = gaussian_params["shs"] if degree is not None else gaussian_params.get("colors", gaussian_params.get("features"))
+        # the colours by render_with_depth's rule ('colors' wins over 'shs' when a dict carries both), so that a camera of the
+        # batch gets the image render_single gives it
+        colors = gaussian_params.get("colors", gaussian_params.get("shs")) if degree is not None else \
+            gaussian_params.get("colors", gaussian_params.get("features"))
         opacities = gaussian_params["opacities"]
         if opacities.dim() == 2:
             opacities = opacities.squeeze(-1)
@@ -82,5 +96,6 @@ class HipBackend:
             means=gaussian_params["means3D"], quats=gaussian_params["rotations"], scales=gaussian_params["scales"],
             opacities=opacities, colors=colors, viewmats=view_matrices,
             Ks=self.K.to(view_matrices.device)[None].expand(n_views, 3, 3).contiguous(), width=width, height=height,
-            packed=False, render_mode="RGB+ED", sh_degree=degree, backgrounds=bg_color[None].expand(n_views, 3))
+            packed=False, render_mode="RGB+ED", sh_degree=degree, backgrounds=bg_color[None].expand(n_views, 3),
+            **self._extra())
         return {"images": renders[..., :3].permute(0, 3, 1, 2).contiguous(), "alphas": alphas.permute(0, 3, 1, 2).contiguous()}

@@ -20,6 +20,7 @@ Nothing here imports the CPU oracle.
 
 from __future__ import annotations
 
+import contextlib
 import math
 import warnings
 from dataclasses import dataclass
@@ -28,10 +29,18 @@ from typing import Dict, List, Optional, Sequence
 import torch
 import torch.nn.functional as F
 
-# features_dc / features_rest are strided views of the [N,16,3] coefficient rows, and so are their .grad tensors: autograd
-# (the non-fused path) accumulates into those views in place, which is the point -- torch notes that such a layout "may
-# impair performance" once per process; the copy it would prefer is what the layout saves.
-warnings.filterwarnings("ignore", message="grad and param do not obey the gradient layout contract")
+
+
+@contextlib.contextmanager
+def _quiet_grad_layout():
+    """features_dc / features_rest are strided views of the [N,16,3] coefficient rows, and so are their .grad tensors: autograd
+    (the non-fused path) accumulates into those views in place, which is the point -- torch notes that such a layout "may
+    impair performance"; the copy it would prefer is what the layout saves.  The note is silenced only around THIS package's
+    own gradient binding and backward() calls: other models of the host process keep it."""
+    with warnings.catch_warnings():
+        warnings.filterwarnings("ignore", message="grad and param do not obey the gradient layout contract")
+        yield
+
 
 # (name, per-gaussian shape) in the order of the reference's optimizer groups (trainer.py:331-340)
 FIELDS = (("xyz", (3,)), ("features_dc", (1, 3)), ("features_rest", (15, 3)), ("opacity", (1,)),
@@ -133,7 +142,8 @@ class SplatModel:
             p = views[name]
             assert tuple(p.shape) == (n, *shape)
             p.requires_grad_(True)
-            p.grad = grads[name]
+            with _quiet_grad_layout():
+                p.grad = grads[name]
             setattr(self, name, p)
         self.sh, self.sh_grad = views["sh"], grads["sh"]   # the coefficient rows as the rasterizer takes them (no copy)
         dev = flat.device
@@ -545,8 +555,12 @@ class ViewParallelTrainer:
         reg = scale_ratio_reg(params["scales"], c.scale_reg_max_ratio, c.scale_reg_weight)
         if self.rank == 0:
             total = total + reg
-        if self.scaler is not None:      # trainer.py:505-508; the exchange sums the SCALED gradients, so every rank
-            self.scaler.scale(total).backward()   # unscales the same numbers and takes the same skip decision
+        with _quiet_grad_layout():
+            if self.scaler is not None:      # trainer.py:505-508; the exchange sums the SCALED gradients, so every rank
+                self.scaler.scale(total).backward()   # unscales the same numbers and takes the same skip decision
+            else:
+                total.backward()
+        if self.scaler is not None:
             self._all_reduce(m.flat_grad)
             before = self.scaler.get_scale()
             self.scaler.step(self.optimizer)      # unscale_ (in place, on the bucket views) + inf check + Adam
@@ -554,7 +568,6 @@ class ViewParallelTrainer:
             self.loss_scale = self.scaler.get_scale()
             self.skipped_steps += int(self.loss_scale < before)
         else:
-            total.backward()
             self._all_reduce(m.flat_grad)  # the one exchange step: 59*N floats, SUM
             self.optimizer.step()
 
@@ -628,7 +641,8 @@ class ViewParallelTrainer:
         main = torch.cuda.current_stream()
         if self._pipe is None or bool(self._pipe.streams) != self.overlap_views:
             from .pipeline import ViewPipeline
-            self._pipe = ViewPipeline(dev, 2 if self.overlap_views else 1)
+            # (the step speculates on what the trainer's own backend remembers about its frames: one memory per trainer)
+            self._pipe = ViewPipeline(dev, 2 if self.overlap_views else 1, speculation=getattr(self.backend, "speculation", None))
         cull = S.DEFAULT_CULL_MODE
         Kc, bgc = K[0].contiguous(), bg[0].contiguous()
         scale = self.loss_scale if self.amp else 1.0   # loss scale: the backward passes see v_render times it
@@ -664,7 +678,7 @@ class ViewParallelTrainer:
                                                                       degree, pose, Kc, W, H, cull, return_rects=True,
                                                                       return_aux=True, bin_tile=bt, key_range=kr, qbox=qb)
             bins = S.bin_tiles(splat, radii, tiles, keys, W, H, cull, tile_rects=rects, exact=exact, bin_tile=bt,
-                               key_range=kr, qbox=qb)
+                               key_range=kr, qbox=qb, speculation=self._pipe.speculation)
             order = S.tile_schedule(bins, W, H, bt)
             return pose, splat, radii, bins, order, aux
 

@@ -54,8 +54,16 @@ def _side_streams(device, n: int, priority: int) -> List[torch.cuda.Stream]:
 
 
 class ViewPipeline:
-    def __init__(self, device, n_streams: int = 2, priority: int = 0, single_thread_autograd: bool = True):
+    def __init__(self, device, n_streams: int = 2, priority: int = 0, single_thread_autograd: bool = True,
+                 speculation=None):
         self.device = device
+        # what the asynchronous binning remembers about the frames of THIS pipeline's views (stages.Speculation): the two
+        # callables hand it to rasterization(speculation=...) / bin_tiles(speculation=...); another pipeline of the same
+        # frame size -- an evaluator beside a trainer -- keeps its own
+        if speculation is None:
+            from .stages import Speculation
+            speculation = Speculation()
+        self.speculation = speculation
         self.single_thread_autograd = bool(single_thread_autograd)
         self.streams: List[torch.cuda.Stream] = _side_streams(device, n_streams, priority) if n_streams > 1 else []
         self._step_done: Optional[torch.cuda.Event] = None   # the previous step's last use of the bucket (caller's stream)
@@ -149,7 +157,9 @@ class ViewPipeline:
             self._step_done = torch.cuda.Event()
             self._step_done.record(main)
         if defer:
-            ok = all(s.check() for s in states)
+            # (every view is checked, also behind a failed one: a check finalizes the view's bins -- its pinned control-word slot
+            # goes back to the pool, its record count and key range reach what is remembered for the repair run)
+            ok = all([s.check() for s in states])
             if agree is not None:
                 ok = agree(ok)
             if not ok:

@@ -27,7 +27,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, colors, viewmat, Kmat, background,
                 width: int, height: int, sh_degree: int, channels: int, cull_mode: int, grad_out, grad_accumulate,
-                sh_grad_factored, deferred=None, projection=None, collector=None):
+                sh_grad_factored, deferred=None, projection=None, collector=None, speculation=None):
         means_c, quats_c, scales_c = S.f32c(means, "means"), S.f32c(quats, "quats"), S.f32c(scales, "scales")
         opac_c, colors_c = S.f32c(opacities, "opacities"), S.f32c(colors, "colors")
         view_c, K_c = S.f32c(viewmat, "viewmats"), S.f32c(Kmat, "Ks")
@@ -44,6 +44,15 @@ class _RasterizeOneCamera(torch.autograd.Function):
             if projection.dims != (width, height, cull_mode, sh_degree) or projection.bin_tile != bt or \
                     projection.splat.shape[0] != means_c.shape[0]:
                 raise ValueError("rasterization(projection=...): made for another frame size, cull mode, SH degree or scene")
+            # ... for THIS camera (the forward would blend the projection's splats while the backward differentiates the
+            # argument's camera) and from THESE parameter values (same storage, not written since): host-side compares of
+            # pointers and version counters, no device sync
+            if projection.camera_stamp is not None and projection.camera_stamp != S.input_stamp(view_c, K_c):
+                raise ValueError("rasterization(projection=...): viewmats / Ks are not the camera this projection was made for -- "
+                                 "pass the tensors given to project_cameras (or projection.viewmat / projection.Kmat)")
+            if projection.made_from is not None and projection.made_from != S.input_stamp(means, quats, scales, opacities, colors):
+                raise ValueError("rasterization(projection=...): the gaussians are not the tensors this projection was made from, "
+                                 "or were written since -- project the cameras again")
             kr, qb = projection.key_range, projection.qbox
             splat, radii, tiles_touched = projection.splat, projection.radii, projection.tiles_touched
             depth_keys, rects = projection.depth_keys, projection.tile_rects
@@ -58,7 +67,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
         # the host does not wait for the record count: bins are sized for a remembered capacity, the compositor is
         # queued, and only then is the count (long since copied back) checked -- a miss repeats with exact sizes
         bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, tile_rects=rects,
-                           bin_tile=bt, key_range=kr, qbox=qb)
+                           bin_tile=bt, key_range=kr, qbox=qb, speculation=speculation)
         tile_order = S.tile_schedule(bins, width, height, bt)   # longest record lists first (speed only)
         out = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg_c, width, height, channels,
                               tile_order, want_lists=want_lists, bin_tile=bt, gid_boxes=bins.boxed)
@@ -68,7 +77,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
             deferred.append(bins)
         elif not bins.finalize()[1]:
             bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, exact=True,
-                               tile_rects=rects, bin_tile=bt, qbox=qb)
+                               tile_rects=rects, bin_tile=bt, qbox=qb, speculation=speculation)
             tile_order = S.tile_schedule(bins, width, height, bt)
             out = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg_c, width, height, channels,
                                   tile_order, want_lists=want_lists, bin_tile=bt, gid_boxes=bins.boxed)
@@ -119,15 +128,15 @@ class _RasterizeOneCamera(torch.autograd.Function):
                                   quad_lists=lists, bin_tile=ctx.bin_tile, gid_boxes=ctx.gid_boxes)
         if ctx.deferred_projection is not None:
             ctx.deferred_projection.v_splat = v_splat
-            return (None,) * 19
+            return (None,) * 20
         grads = S.project_bwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
                               splat, radii, v_splat, out=ctx.grad_out, accumulate=ctx.grad_accumulate,
                               v_rgb_out=ctx.sh_grad_factored, sh_aux=sh_aux)
         if ctx.grad_accumulate:   # the sums live in the caller's buffers; autograd gets nothing to accumulate
-            return (None,) * 19
+            return (None,) * 20
         need = ctx.needs_input_grad
         grads = tuple(g.view(shp) if (nd and g is not None) else None for g, shp, nd in zip(grads, ctx.in_shapes, need[:5]))
-        return grads + (None,) * 14
+        return grads + (None,) * 15
 
 
 def project_cameras(means, quats, scales, opacities, colors, viewmats, Ks, width: int, height: int,
@@ -153,9 +162,18 @@ def project_cameras(means, quats, scales, opacities, colors, viewmats, Ks, width
                             cull, return_aux=bool(for_backward))
     can_defer = bool(defer_backward) and deg >= 1 and colors.dim() == 3 and colors.shape[1] == 16 and len(views) <= 8 and \
         all(v.sh_aux is not None for v in views)
+    stamp = S.input_stamp(means, quats, scales, opacities, colors)
     for v in views:
-        v.defer_backward, v.v_splat = can_defer, None
-    return views
+        v.defer_backward, v.v_splat, v.made_from = can_defer, None, stamp
+    out = CameraProjections(views)
+    out.deferred = can_defer   # (False although asked for: every camera's backward pass is its own -- see the docstring)
+    return out
+
+
+class CameraProjections(list):
+    """What ``project_cameras`` returns: the per-camera projections, and ``deferred`` -- whether the cameras' backward passes
+    stop behind their sweeps and wait for ``project_cameras_backward`` (``defer_backward`` asked for AND possible)."""
+    deferred = False
 
 
 def projection_buffers(projections):
@@ -176,7 +194,9 @@ def project_cameras_backward(projections, means, quats, scales, opacities, color
     gradient is read back and added to, and the SH-coefficient gradient -- sum over the cameras of basis(direction) x
     d loss / d rgb -- is formed in registers instead of by an expansion kernel."""
     if not projections or not all(p.defer_backward for p in projections):
-        raise ValueError("project_cameras_backward: needs the projections of project_cameras(defer_backward=True)")
+        raise ValueError("project_cameras_backward: these projections were not made with a deferred backward (project_cameras("
+                         "defer_backward=True) drops the flag where the shared launch does not apply -- its result's `.deferred` "
+                         "says so): every camera's own backward pass has written its gradients already")
     if any(p.v_splat is None for p in projections):
         raise RuntimeError("project_cameras_backward: a camera's output has not been backpropagated yet")
     width, height, _, deg = projections[0].dims
@@ -214,6 +234,7 @@ def rasterization(
     sh_grad_factored: Optional[torch.Tensor] = None,
     defer_check: bool = False,
     projection=None,
+    speculation=None,
     **unsupported,
 ) -> Tuple[torch.Tensor, torch.Tensor, Dict]:
     """Returns ``(renders [C,H,W,D], alphas [C,H,W,1], meta)``; ``meta['means2d']`` [C,N,2] and
@@ -240,6 +261,9 @@ def rasterization(
     entry itself for one camera): the projection stage is then not run again.  The views of an optimisation step share
     their gaussians, and ONE multi-camera launch reads a gaussian's geometry and coefficient row once for all of them; a
     call with C > 1 cameras does this by itself.
+    ``speculation`` (extension): the ``stages.Speculation`` object whose memory of this frame size (record capacity, depth-key
+    range, bucket plan) sizes the asynchronous binning and learns from the view -- a ``HipBackend`` / ``ViewPipeline`` passes
+    its own, so that two consumers of equal frame size do not perturb each other; default: the process-wide one.
     """
     for k, v in unsupported.items():
         ok = (k in ("sparse_grad", "absgrad", "distributed") and not v) or \
@@ -291,7 +315,8 @@ def rasterization(
         projection = [projection]
     if projection is not None and len(projection) != C:
         raise ValueError("rasterization(projection=...): one entry per camera")
-    if projection is None and C > 1:   # several cameras: project for all of them in one launch
+    own_projection = projection is None and C > 1
+    if own_projection:   # several cameras: project for all of them in one launch
         projection = project_cameras(means, quats, scales, opacities, colors, viewmats, Ks, width, height, sh_degree=sh_degree,
                                      cull_mode=cull)
     for c in range(C):
@@ -300,9 +325,12 @@ def rasterization(
             bg = backgrounds[c]
             if want_depth:
                 bg = torch.cat([bg, bg.new_zeros(1)])
-        out = _RasterizeOneCamera.apply(means, quats, scales, opacities, colors, viewmats[c], Ks[c], bg,
+        vm_c, K_c = viewmats[c], Ks[c]
+        if own_projection:   # (made above from these very arguments: its fp32 copies of the cameras are the cameras)
+            vm_c, K_c = projection[c].viewmat, projection[c].Kmat
+        out = _RasterizeOneCamera.apply(means, quats, scales, opacities, colors, vm_c, K_c, bg,
                                         width, height, deg, channels, cull, grad_out, grad_accumulate, sh_grad_factored,
-                                        pending, None if projection is None else projection[c], all_bins)
+                                        pending, None if projection is None else projection[c], all_bins, speculation)
         render, alpha = out[0], out[1]
         if render_mode in ("ED", "RGB+ED"):
             render = torch.cat([render[..., :3], render[..., 3:] / alpha.clamp(min=1e-10)], dim=-1)
@@ -352,7 +380,7 @@ def rasterization(
                     splat, radii, tiles = pc[0], pc[1], pc[2]
                     keys = torch.where((radii > 0).all(-1), splat[:, 9].contiguous().view(torch.int32),
                                        torch.full_like(tiles, -1))
-                    b = S.bin_tiles(splat, radii, tiles, keys, width, height, cull, exact=True)
+                    b = S.bin_tiles(splat, radii, tiles, keys, width, height, cull, exact=True, speculation=speculation)
                     out16.append((splat, radii, tiles, b.sorted_tile, b.sorted_gid, b.tile_offsets, pc[6]))
                 tiled["v"] = out16
         return tiled["v"]

@@ -184,12 +184,13 @@ REPAIR_STATS = {"views": 0, "capacity_misses": 0, "key_range_repairs": 0}
 PATH_STATS = {"bucketed_host_plan": 0, "bucketed_device_table": 0, "lsd": 0}
 
 
-def last_key_span_octaves(dev, width: int, height: int, cull_mode: int = 0) -> Optional[float]:
+def last_key_span_octaves(dev, width: int, height: int, cull_mode: int = 0, speculation=None) -> Optional[float]:
     """Octaves of depth between the smallest and the largest visible depth key remembered for this scene shape (the union
     over its recent views): log2(z_max / z_min)."""
     import struct
+    spec = speculation if speculation is not None else DEFAULT_SPECULATION
     for bt in (32, 64, 16):
-        ent = _KEY_RANGE.get((dev.type, dev.index, width, height, cull_mode, bt))
+        ent = spec.key_range.get((dev.type, dev.index, width, height, cull_mode, bt))
         if ent is not None and ent[0] <= ent[1]:
             z0 = struct.unpack("f", struct.pack("I", ent[0]))[0]
             z1 = struct.unpack("f", struct.pack("I", ent[1]))[0]
@@ -266,11 +267,17 @@ class ViewProjection:
     a key range and quadrant boxes): what the binning, the sweeps and ``project_bwd`` of that view need."""
 
     __slots__ = ("splat", "radii", "tiles_touched", "depth_keys", "tile_rects", "sh_aux", "key_range", "qbox", "viewmat",
-                 "Kmat", "bin_tile", "dims", "defer_backward", "v_splat")
+                 "Kmat", "bin_tile", "dims", "defer_backward", "v_splat", "made_from", "camera_stamp")
 
     def __init__(self, **kw):
         for k in self.__slots__:
             setattr(self, k, kw.get(k))
+
+
+def input_stamp(*tensors):
+    """(storage pointer, version counter, shape) of each tensor: what a projection remembers of the parameters it was made
+    from, and what ``rasterization(projection=...)`` compares -- on the host, no device sync -- before it uses it."""
+    return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
 
 
 def project_views(means, quats, scales, opacities, colors, sh_degree: int, viewmats, Kmats, width: int, height: int,
@@ -301,7 +308,8 @@ def project_views(means, quats, scales, opacities, colors, sh_degree: int, viewm
     return [ViewProjection(splat=splat[c], radii=radii[c], tiles_touched=tiles_touched[c], depth_keys=depth_keys[c],
                            tile_rects=tile_rects[c], sh_aux=None if sh_aux is None else sh_aux[c], key_range=key_range[c],
                            qbox=None if qbox is None else qbox[c], viewmat=vm[c], Kmat=km[c] if km.dim() == 3 else km,
-                           bin_tile=bt, dims=(width, height, cull_mode, sh_degree), defer_backward=False, v_splat=None)
+                           bin_tile=bt, dims=(width, height, cull_mode, sh_degree), defer_backward=False, v_splat=None,
+                           made_from=None, camera_stamp=input_stamp(vm[c], km[c] if km.dim() == 3 else km))
             for c in range(C)]
 
 
@@ -364,8 +372,9 @@ class TileBins:
     ``finalize()`` which the caller runs after it has queued the work that consumes the bins."""
 
     def __init__(self, sorted_tile, sorted_gid, tile_offsets, capacity, m_known, key, slot=None, n=0, key_bits=32,
-                 keys_ok=True, boxed=False):
+                 keys_ok=True, boxed=False, speculation=None):
         self._tile, self._gid, self.tile_offsets = sorted_tile, sorted_gid, tile_offsets
+        self._spec = speculation if speculation is not None else DEFAULT_SPECULATION   # who remembers what this view teaches
         # boxed: the top byte of every entry of the id buffer is the record's quadrant box (gsa_tile_bin16 given qbox), the
         # gaussian id its low 24 bits -- what the compositor stages must be told (their ``gid_boxes``)
         self.boxed = bool(boxed)
@@ -393,15 +402,16 @@ class TileBins:
             _wait_slot(self._slot)
             ctl_host = self._slot[0]
             self._m = int(ctl_host[0]) & 0xFFFFFFFF
-            _note_count(self._key, self._n, self._m)
+            _note_count(self._spec, self._key, self._n, self._m)
             if self.key_bits is not None:   # (the unfused path sorts all 32 bits and leaves no range)
-                self._keys_ok = _note_keys(self._key, int(ctl_host[1]) & 0xFFFFFFFF, int(ctl_host[2]) & 0xFFFFFFFF,
+                self._keys_ok = _note_keys(self._spec, self._key, int(ctl_host[1]) & 0xFFFFFFFF, int(ctl_host[2]) & 0xFFFFFFFF,
                                            self.key_bits, int(ctl_host[3]) & 0xFF if isinstance(self.key_bits, tuple) else 0)
-            REPAIR_STATS["views"] += 1
-            if self._m > self.capacity:
-                REPAIR_STATS["capacity_misses"] += 1
-            elif not self._keys_ok:
-                REPAIR_STATS["key_range_repairs"] += 1
+            for stats in (REPAIR_STATS, self._spec.repairs):   # (process-wide, and of the object this view speculated on)
+                stats["views"] += 1
+                if self._m > self.capacity:
+                    stats["capacity_misses"] += 1
+                elif not self._keys_ok:
+                    stats["key_range_repairs"] += 1
             _release_slot(self._slot)
             self._slot = None
         return self._m, self._m <= self.capacity and self._keys_ok
@@ -464,22 +474,41 @@ def qbox_buffer(n: int, dev) -> torch.Tensor:
     return torch.empty(n, dtype=torch.int32, device=dev) if _QUAD_BOXES else None
 
 
-# (device, W, H, cull_mode) -> [records per gaussian the next call provisions for, consecutive low counts].
-# Keyed WITHOUT N: densify / prune changes N every 100 iterations (trainer.py:794-797) and a changed N predicts its
-# capacity from the remembered ratio instead of costing a blocking read-back.  Grows at once, shrinks only after many
-# consecutive low counts (the views of one batch differ; alternating shrink / miss would re-run the binning).
-_CAPACITY = {}
+class Speculation:
+    """What the asynchronous binning REMEMBERS per scene shape (device, W, H, cull mode, bin side) -- its speculation state:
+
+    * ``capacity``: [records per gaussian the next call provisions for, consecutive low counts].  Keyed WITHOUT N: densify /
+      prune changes N every 100 iterations (trainer.py:794-797) and a changed N predicts its capacity from the remembered
+      ratio instead of costing a blocking read-back.  Grows at once, shrinks only after many consecutive low counts (the
+      views of one batch differ; alternating shrink / miss would re-run the binning).
+    * ``key_range``: [lo, hi, consecutive much-narrower views]: the union of the visible depth-key ranges seen so far (grows
+      at once, is reset after many consecutive views that need less than half of it).  The depth ordering is launched for
+      this range and the view's actual range is checked afterwards, like the record capacity.
+    * ``table_mode``: views left on the device-built depth table; ``msd_backoff`` / ``host_plan_backoff`` / ``msd_streak``:
+      calls left before the bucketed ordering (on host-planned equal buckets) is tried again after a miss.
+
+    One object per CONSUMER of views (r05; module globals before): a ``HipBackend``, a ``ViewPipeline`` and a trainer own
+    theirs, so a trainer and an evaluator that render frames of the same size from different scenes -- or different
+    camera sets -- in one process do not widen each other's remembered ranges or trigger each other's repairs; the bare
+    ``rasterization(...)`` / stage calls share ``DEFAULT_SPECULATION``."""
+
+    def __init__(self):
+        self.capacity, self.key_range, self.table_mode = {}, {}, {}
+        self.msd_backoff, self.host_plan_backoff, self.msd_streak = {}, {}, {}
+        self.repairs = {"views": 0, "capacity_misses": 0, "key_range_repairs": 0}   # of the views finalized against this object
+
+    def reset(self) -> None:
+        """Forget everything: the next call of every shape is a first call (exact sizes, one blocking read-back)."""
+        for d in (self.capacity, self.key_range, self.msd_backoff, self.table_mode, self.msd_streak, self.host_plan_backoff):
+            d.clear()
+
+
+DEFAULT_SPECULATION = Speculation()
 _CAPACITY_MAX_KEYS = 64
 _SHRINK_AFTER = 32
 # views of ONE camera after which what is remembered about a scene shape (record capacity, depth-key range) has settled on
 # that camera: a benchmark that goes from several cameras to one warms up this long before it times
 SPECULATION_SETTLE_VIEWS = _SHRINK_AFTER + 8
-
-
-# scene shape -> [lo, hi, consecutive much-narrower views]: the union of the visible depth-key ranges seen so far
-# (grows at once, is reset after many consecutive views that need less than half of it).  The depth ordering is
-# launched for this range and the view's actual range is checked afterwards, like the record capacity.
-_KEY_RANGE = {}
 _MSD_MAX_WIDTH = int(lib.gsa_depth_order_msd_max_width())
 _DEPTH_MSD_DEFAULT = True   # bucketed depth ordering (False: LSD passes; A/B from tests / tools)
 # How the bucketed depth ordering gets its buckets.  "host": 255 EQUAL buckets over the union of the key ranges of the views of
@@ -491,19 +520,13 @@ _DEPTH_MSD_DEFAULT = True   # bucketed depth ordering (False: LSD passes; A/B fr
 # be repaired; =1 / =0: always / never.
 _DEPTH_TABLE = os.environ.get("GSPLAT_AMD_DEPTH_TABLE", "auto")
 _TABLE_VIEWS = 4096
-_TABLE_MODE = {}          # scene shape -> views left on the device-built table
 _MSD_MIN_N = 32768        # below this the 256 x 1024-thread bucket launch costs more than the LSD passes it replaces
 _MSD_MAX_N = 1_400_000    # above this an average bucket (N / 255, x1.5 for skew) no longer fits the 8192-key LDS capacity
-_MSD_BACKOFF = {}         # scene shape -> calls left before the bucketed ordering is tried again after an overflow
-_HOST_PLAN_BACKOFF = {}   # scene shape -> calls left before a HOST-planned (equal-bucket) ordering is tried again after a miss
-_MSD_STREAK = {}          # scene shape -> overflows of the device-planned ordering in a row (escalates the back-off)
+
 
 def reset_speculation() -> None:
-    """Forget what the scene shapes seen so far taught (record capacities, depth-key ranges, bucket plans, back-offs): the
-    next call of every shape is a first call (exact sizes, one blocking read-back).  For a process that moves on to another
-    scene of the same image size -- e.g. ``bench.py`` between its wide-depth pass and the training-step leg."""
-    for d in (_CAPACITY, _KEY_RANGE, _MSD_BACKOFF, _TABLE_MODE, _MSD_STREAK, _HOST_PLAN_BACKOFF):
-        d.clear()
+    """``DEFAULT_SPECULATION.reset()``: what the bare ``rasterization`` / stage calls of this process remember."""
+    DEFAULT_SPECULATION.reset()
 
 
 def _key_bits_needed(lo: int, hi: int) -> int:
@@ -532,9 +555,11 @@ def _msd_bucket(x: int, scale: int) -> int:
     return (x * scale) >> 32
 
 
-def _note_keys(key, lo: int, hi: int, assumed, status: int = 0) -> bool:
+def _note_keys(spec: Speculation, key, lo: int, hi: int, assumed, status: int = 0) -> bool:
     """Remember the depth-key range of this view; -> whether the ordering that ran was complete.  ``assumed``: the
     number of key bits an LSD sort covered, or (key_min, scale) of a bucketed one."""
+    _KEY_RANGE, _MSD_BACKOFF, _MSD_STREAK = spec.key_range, spec.msd_backoff, spec.msd_streak
+    _HOST_PLAN_BACKOFF, _TABLE_MODE = spec.host_plan_backoff, spec.table_mode
     ent = _KEY_RANGE.get(key)
     if lo <= hi:
         if ent is None:
@@ -576,14 +601,15 @@ def _note_keys(key, lo: int, hi: int, assumed, status: int = 0) -> bool:
     return _key_bits_needed(lo, hi) <= assumed
 
 
-def _capacity_for(key, n: int) -> Optional[int]:
-    ent = _CAPACITY.get(key)
+def _capacity_for(spec: Speculation, key, n: int) -> Optional[int]:
+    ent = spec.capacity.get(key)
     if ent is None:
         return None
     return max(4096, int(ent[0] * max(n, 1) * 1.25) + 1024)
 
 
-def _note_count(key, n: int, m: int) -> None:
+def _note_count(spec: Speculation, key, n: int, m: int) -> None:
+    _CAPACITY = spec.capacity
     ratio = m / max(n, 1)
     ent = _CAPACITY.get(key)
     if ent is None:
@@ -604,7 +630,7 @@ def _note_count(key, n: int, m: int) -> None:
 def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, cull_mode: int = 0,
               exact: bool = False, fused: Optional[bool] = None, tile_rects=None, depth_msd: Optional[bool] = None,
               bin_tile: int = TILE_SIZE, key_range: Optional[torch.Tensor] = None,
-              qbox: Optional[torch.Tensor] = None) -> TileBins:
+              qbox: Optional[torch.Tensor] = None, speculation: Optional["Speculation"] = None) -> TileBins:
     """Depth-order the gaussians, emit their tile records in that order, stable-sort the records by tile.
     -> TileBins(sorted_tile, sorted_gid, tile_offsets [n_tiles+1] i32).  ``sorted_tile`` holds 16-bit tile ids (an
     int16 tensor of uint16 bit patterns) on the fused path, int32 otherwise: read it through ``tile_ids``.
@@ -615,6 +641,8 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
     ``bin_tile`` = 32 (fused path only, ``tile_rects`` from ``project_fwd(bin_tile=32)``): the records are binned into
     32 x 32 bins instead -- tile ids, ``tile_offsets`` and the record count are then those of the bin grid, and the
     compositor stages must be told (their ``bin_tile``).
+    ``speculation``: whose memory of this scene shape (record capacity, depth-key range, bucket plan) sizes the launch and
+    learns from the view (``Speculation``; default: the process-wide ``DEFAULT_SPECULATION``).
 
     The record count M is only known on the device.  Steady state (a capacity is remembered per scene shape): all
     kernels are queued for that capacity and read the live count from device memory, the host never waits; the
@@ -624,6 +652,8 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
     tile_w, tile_h = tile_grid(width, height, bin_tile)
     n_tiles = tile_w * tile_h
     st = _stream()
+    spec = speculation if speculation is not None else DEFAULT_SPECULATION
+    _KEY_RANGE, _MSD_BACKOFF, _TABLE_MODE, _HOST_PLAN_BACKOFF = spec.key_range, spec.msd_backoff, spec.table_mode, spec.host_plan_backoff
     key = (dev.type, dev.index, width, height, cull_mode, bin_tile)
     offsets = torch.empty(N, dtype=torch.int32, device=dev)
     ctl = torch.empty(4, dtype=torch.int32, device=dev)   # record count M, min / max visible depth key, spare
@@ -639,7 +669,7 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
         fused = can_fuse and (_BIN_FUSED_DEFAULT or bin_tile != TILE_SIZE)
     if bin_tile != TILE_SIZE and not (fused and tile_rects is not None):
         raise ValueError("bin_tiles(bin_tile=32): needs the fused path and the tile_rects of project_fwd(bin_tile=32)")
-    cap = None if exact else _capacity_for(key, N)
+    cap = None if exact else _capacity_for(spec, key, N)
     key_bits, keys_ok, slot = 32, True, None
     if fused:
         if tile_rects is None:   # callers that did not keep project_fwd's dense copy: word 11 of the records
@@ -719,9 +749,9 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
     if cap is None:
         _wait_slot(slot)
         m_known = int(m_host[0]) & 0xFFFFFFFF
-        _note_count(key, N, m_known)
+        _note_count(spec, key, N, m_known)
         if fused:
-            keys_ok = _note_keys(key, int(m_host[1]) & 0xFFFFFFFF, int(m_host[2]) & 0xFFFFFFFF, key_bits,
+            keys_ok = _note_keys(spec, key, int(m_host[1]) & 0xFFFFFFFF, int(m_host[2]) & 0xFFFFFFFF, key_bits,
                                  int(m_host[3]) if isinstance(key_bits, tuple) else 0)
         cap = m_known
         _release_slot(slot)   # (read: this call's TileBins knows its count)
@@ -754,7 +784,7 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
                   height, bin_tile, cap,
                   _ptr(total), _ptr(k_tmp), _ptr(v_tmp), _ptr(sorted_tile), _ptr(sorted_gid), _ptr(tile_offsets),
                   _ptr(qbox) if boxed else None, _ptr(ws2), ws2_bytes, st)
-        bins = TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key, slot, N, key_bits, keys_ok, boxed)
+        bins = TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key, slot, N, key_bits, keys_ok, boxed, spec)
         bins.tile_order = tile_order
         return bins
     isect_tile = torch.empty(cap, dtype=torch.int32, device=dev)
@@ -774,7 +804,7 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
         sorted_tile, sorted_gid = isect_tile, isect_gid
     _call("gsa_tile_offsets", lib.gsa_tile_offsets_dev, cap, _ptr(total), _ptr(sorted_tile), n_tiles,
           _ptr(tile_offsets), st)
-    return TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key, slot, N, None, True)
+    return TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key, slot, N, None, True, False, spec)
 
 
 # the one-pass placement writes the compositor's launch order in eight extra workgroups of its last launch (False: a
@@ -1078,7 +1108,16 @@ def step_report(view_sums: Optional[torch.Tensor], view_counts, lambda_dssim: fl
     import ctypes
     b = len(view_counts)
     if b > 16:
-        raise ValueError("step_report: at most 16 local views")
+        # (the kernel takes 16 views a launch; every entry of the report is a sum over the views, so chunks add up -- the
+        # regulariser is counted with the first chunk.  A trainer calls this BEHIND its optimizer step: it must not raise.)
+        if view_sums is None or view_sums.shape != (b, 3):
+            raise ValueError("step_report: `view_sums` must be a contiguous float64 [B_local,3] device tensor")
+        report = None
+        for lo in range(0, b, 16):
+            part = step_report(view_sums[lo:lo + 16], view_counts[lo:lo + 16], lambda_dssim, n_views_total,
+                               reg_partials if lo == 0 else None, reg_factor, add_reg and lo == 0, device)
+            report = part if report is None else report + part
+        return report
     if b and (view_sums is None or view_sums.shape != (b, 3) or view_sums.dtype != torch.float64 or not view_sums.is_contiguous()):
         raise ValueError("step_report: `view_sums` must be a contiguous float64 [B_local,3] device tensor")
     report = torch.empty(5, dtype=torch.float64, device=device)

@@ -203,6 +203,20 @@ def self_launch(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def step_cameras(i: int, views: int, world: int, rank: int, ring_size: int):
+    """Ring cameras of THIS rank's views of step i: the step renders the `views x world` consecutive cameras starting at
+    (i x views x world) mod ring_size, dealt round-robin -- view j of rank r is camera base + j x world + r (rank r
+    renders views {v : v mod R = r} of the batch)."""
+    base = (i * views * world) % ring_size
+    return [(base + j * world + rank) % ring_size for j in range(views)]
+
+
+def step_window(i: int, views: int, world: int, ring_size: int):
+    """All cameras of step i in batch order: entry j x world + r is rank r's view j (what the exchange's local SH rebuild sums over)."""
+    base = (i * views * world) % ring_size
+    return [(base + k) % ring_size for k in range(views * world)]
+
+
 def percentiles(xs):
     xs = sorted(xs)
     pick = lambda q: xs[min(len(xs) - 1, max(0, int(round(q * (len(xs) - 1)))))]  # noqa: E731
@@ -302,6 +316,11 @@ def main() -> None:
     ap.add_argument("--views", type=int, default=8,
                     help="ring size of the ROTATING-view pass (the reference samples random views every step, "
                          "trainer.py:315-317): one view per step, cycling through this many cameras")
+    ap.add_argument("--ring", type=int, default=0,
+                    help="cameras on the ring the HEADLINE step's views are taken from, step after step (0: max(8, 2 x gpus x "
+                         "views-per-gpu), so that consecutive steps render different cameras, as a trainer's do: "
+                         "trainer.py:315-317 samples random views); `value_fixed_cameras` is the same step on gpus x views-per-gpu "
+                         "cameras, i.e. the same cameras every step")
     ap.add_argument("--no-batch-projection", action="store_true",
                     help="project the gaussians once per view instead of once per step for all its views "
                          "(gsplat_amd.project_cameras: geometry and SH rows read once)")
@@ -438,7 +457,7 @@ def main() -> None:
 
             def prepare():
                 if base not in step_cams:   # this rank's cameras of the step, one [views, 4, 4] tensor per window of the ring
-                    idx = torch.tensor([(base + j * world + rank) % ring_size for j in range(views)], device=dev)
+                    idx = torch.tensor(step_cameras(i, views, world, rank, ring_size), device=dev)
                     step_cams[base] = cams[idx].contiguous()
                 shared["proj"] = gsplat_amd.project_cameras(leaves[0], leaves[1], leaves[2], opac.squeeze(-1), leaves[4],
                                                             step_cams[base], K[0], width, height, sh_degree=deg,
@@ -446,7 +465,8 @@ def main() -> None:
                 return gsplat_amd.projection_buffers(shared["proj"])
 
             def forward(j: int, deferred: bool) -> ViewState:
-                vm = cams[(base + j * world + rank) % ring_size][None]
+                # (with a shared projection: the camera tensor it was made for -- rasterization(projection=...) checks that)
+                vm = shared["proj"][j].viewmat[None] if batch_proj else cams[step_cameras(i, views, world, rank, ring_size)[j]][None]
                 # the backward pass writes every gradient element straight into the bucket (no zero-fill, no copy);
                 # views after the first ADD to it.  (opacities [N,1] -> [N] as the reference backend does it,
                 # gsplat_backend.py:157-158)
@@ -454,7 +474,7 @@ def main() -> None:
                                                       width, height, sh_degree=deg, backgrounds=bg,
                                                       cull_mode=args.cull_mode, grad_out=grad_views,
                                                       grad_accumulate=j > 0, sh_grad_factored=ex.view_target(j),
-                                                      defer_check=deferred,
+                                                      defer_check=deferred, speculation=pipe.speculation,
                                                       projection=shared["proj"][j] if batch_proj else None)
                 if "M" not in info:   # (once: with 32 x 32 bins in the hot path the 16 x 16 record count is a reduction + read-back)
                     info["M"] = meta["n_isects"]
@@ -482,7 +502,7 @@ def main() -> None:
                      prepare=prepare if batch_proj else None, finish=finish if batch_bwd else None)
             if factored or dist is not None:
                 if base not in windows:   # the cameras of the step's views, entry j * world + r = rank r's view j
-                    windows[base] = cams[(base + torch.arange(views * world, device=dev)) % ring_size].contiguous()
+                    windows[base] = cams[torch.tensor(step_window(i, views, world, ring_size), device=dev)].contiguous()
                 ex.finish(flat_grad, leaves[0], deg, windows[base], K, grad_views[4])
             if dist is not None and stages.TIMER.enabled:
                 x1 = torch.cuda.Event(enable_timing=True)
@@ -556,6 +576,11 @@ def main() -> None:
         fence()
         stages.WAIT_STATS[:] = [0, 0.0]
         agree_stats[:] = [0, 0.0]
+        pipe_ = getattr(step, "pipe", None)
+        if pipe_ is not None:   # what the window's views do to the step's own speculation state
+            for k in pipe_.speculation.repairs:
+                pipe_.speculation.repairs[k] = 0
+            repaired0 = pipe_.repairs
         dbg = os.environ.get("GSPLAT_AMD_BENCH_DEBUG") == "1"
         if dbg:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -595,7 +620,45 @@ def main() -> None:
             dt = float(tmax.item())
         return {"s": dt, "warmup_effective": warmup + extra, "host_wait_ms": wait_ms,
                 "agree_ms": agree_stats[1] / max(steps, 1) * 1e3,
+                "stats": dict(pipe_.speculation.repairs) if pipe_ is not None else None,
+                "repaired_steps": (pipe_.repairs - repaired0) if pipe_ is not None else None,
                 "per_step_ms": [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)] if per_step else None}
+
+    STAGES = ("gsa_project_fwd", "binning", "gsa_composite_fwd", "gsa_composite_bwd", "gsa_project_bwd")
+
+    def per_stage(summary, steps):
+        """StageTimer summary -> ({stage: ms per step}, {stage: C-ABI calls per step}); binning = depth ordering + record
+        generation + tile passes (everything that is not one of the four single-launch stages or named below)."""
+        per, launches = {}, {}
+        renames = {"gsa_sh_grad_expand": "sh_grad_rebuild", "gsa_composite_bwd_prepare": "bwd_prepare", "exchange_tail": "exchange_tail"}
+        for name, (calls, total) in summary.items():
+            key = name if name in STAGES else renames.get(name, "binning")
+            per[key] = per.get(key, 0.0) + total / steps
+            launches[key] = launches.get(key, 0) + calls / steps
+        return per, launches
+
+    def instrumented(step, steps):
+        """`steps` more steps with HIP events around every C-ABI stage (the event records cost a few percent: never the timed pass)."""
+        stages.TIMER.reset(enabled=True)
+        for i in range(steps):
+            step(i)
+        fence()
+        out = dict(stages.TIMER.summary())
+        stages.TIMER.reset(enabled=False)
+        return out
+
+    def count_records(cams_list):
+        """Mean 16 x 16-rule intersections (SURVEY's M) and binned records over the given cameras: one forward-only call each on
+        a throw-away speculation state (a reduction and a read-back per camera; outside every timed window)."""
+        spec = stages.Speculation()
+        ms, bs = [], []
+        with torch.no_grad():
+            for vm in cams_list:
+                _, _, meta = gsplat_amd.rasterization(leaves[0], leaves[1], leaves[2], opac.squeeze(-1), leaves[4], vm[None], K, width,
+                                                      height, sh_degree=deg, backgrounds=bg, cull_mode=args.cull_mode, speculation=spec)
+                ms.append(int(meta["n_isects"]))
+                bs.append(int(meta["n_binned"]))
+        return sum(ms) / len(ms), sum(bs) / len(bs)
 
     p = width * height
     n_streams = max(1, args.view_streams) if B > 1 else 1
@@ -614,12 +677,17 @@ def main() -> None:
             dist.destroy_process_group()
         return
     # ---- the timed region `value` comes from: B views per rank and step, the default exchange form
-    head_step = make_step(args.exchange, B, n_streams, world * B)
+    # (on a ring of more cameras than a step has views: consecutive steps render DIFFERENT cameras, so what the binning
+    # remembers -- record capacities, key ranges -- has to hold across cameras, as in a trainer's loop)
+    head_ring = args.ring if args.ring > 0 else max(8, 2 * world * B)
+    head_step = make_step(args.exchange, B, n_streams, head_ring)
     head = timed(head_step, args.steps, args.warmup, converge=True)
     grad_l1_head = float(flat_grad.double().abs().sum())   # of the last step's exchanged bucket (same on every rank)
     if args.dump_grad and rank == 0:
         torch.save(flat_grad.detach().cpu(), args.dump_grad)
     dist_ms = timed(head_step, args.steps, 0, per_step=True)["per_step_ms"]   # the same steps, one event per step
+    # the same step on the SAME cameras every step (r04's headline protocol), beside it
+    fixed = timed(make_step(args.exchange, B, n_streams, world * B), args.steps, 2, converge=True) if head_ring != world * B else head
     c4 = None
     if dist is not None and B > 1:   # BASELINE config C4 as written: ONE view per GPU per step (a world-view batch)
         c4_step = make_step(args.exchange, 1, 1, world)
@@ -642,7 +710,7 @@ def main() -> None:
     other = None
     if dist is not None:   # the same steps with the other exchange form, for the comparison figure only
         other_form = "allreduce" if args.exchange == "factored" else "factored"
-        other = timed(make_step(other_form, B, n_streams, world * B), args.steps, 2, converge=True)
+        other = timed(make_step(other_form, B, n_streams, head_ring), args.steps, 2, converge=True)
     # ---- ONE view per step, one stream, a fixed camera: the serial latency of a view (rounds 1 and 2's headline), then
     # the same steps with HIP events around every C-ABI stage for the roofline object (the event records cost a few
     # percent, which is why the instrumented pass is not the timed one)
@@ -651,12 +719,7 @@ def main() -> None:
     # one camera after 32 consecutive views of it, and the bucket plan with it -- inside the timed window otherwise, which
     # made this figure read 0.62 or 0.70 ms depending on where the switch fell)
     solo = timed(solo_step, args.steps, max(2, stages.SPECULATION_SETTLE_VIEWS), converge=True)
-    stages.TIMER.reset(enabled=True)
-    for i in range(args.steps):
-        solo_step(i)
-    fence()
-    stage_ms = {k: (c, t) for k, (c, t) in stages.TIMER.summary().items()}
-    stages.TIMER.reset(enabled=False)
+    stage_ms = instrumented(solo_step, args.steps)
     grad_l1 = float(flat_grad.double().abs().sum())   # of the last single-view step's exchanged gradient (same on every rank)
     # ---- rotating views: one view per step cycling a ring of cameras -- how often the speculation behind the
     # asynchronous binning (record capacity, depth-key range, bucket capacity) has to be repaired
@@ -665,10 +728,9 @@ def main() -> None:
         rot_step = make_step(args.exchange, 1, 1, args.views)
         for i in range(args.views):   # every camera once: the first call of a shape is exact by construction
             rot_step(i)
-        for k in stages.REPAIR_STATS:
-            stages.REPAIR_STATS[k] = 0
         rot = timed(rot_step, args.steps, 0)
-        rot["stats"] = dict(stages.REPAIR_STATS)
+        rot["stage_ms"] = per_stage(instrumented(rot_step, args.steps), args.steps)[0]
+        rot["M"], rot["binned"] = count_records(list(ring(args.views)))
     # ---- wide depth: the same scene seen from INSIDE the cloud (ring of radius 0.35: visible depths from the near plane to
     # ~2.3, i.e. 8 octaves of depth-key span where the ring of radius 4 shows 0.7) -- which depth ordering ran, how often
     wide = None
@@ -677,18 +739,34 @@ def main() -> None:
         wide_step = make_step(args.exchange, 1, 1, args.views, cams_override=wide_cams)
         for i in range(2 * args.views):
             wide_step(i)
-        for k in stages.REPAIR_STATS:
-            stages.REPAIR_STATS[k] = 0
         for k in stages.PATH_STATS:
             stages.PATH_STATS[k] = 0
         wide = timed(wide_step, args.steps, 0)
-        wide["stats"], wide["paths"] = dict(stages.REPAIR_STATS), dict(stages.PATH_STATS)
-        wide["key_span_octaves"] = stages.last_key_span_octaves(dev, width, height)
+        wide["paths"] = dict(stages.PATH_STATS)
+        wide["stage_ms"] = per_stage(instrumented(wide_step, args.steps), args.steps)[0]
+        wide["M"], wide["binned"] = count_records(list(wide_cams))
+        wide["key_span_octaves"] = stages.last_key_span_octaves(dev, width, height, speculation=wide_step.pipe.speculation)
+    # ---- forward only: what the reference's no_grad callers get (validation renders trainer.py:417-424, eval.py:171-183):
+    # backend.render_with_depth under no_grad, one view per call, a fixed camera, the call checking its own speculation
+    fwd_only = None
+    if world == 1:
+        backend = gsplat_amd.HipBackend(K[0])
+        params = {"means3D": leaves[0], "rotations": leaves[1], "scales": leaves[2], "opacities": opac, "shs": leaves[4]}
+        viewpoint = {"world_view_transform": ring(max(args.views, 1))[0], "image_width": width, "image_height": height}
+
+        def fwd_step(i=0):
+            with torch.no_grad():
+                backend.render_with_depth(params, viewpoint, bg_color=bg[0], render_mode="RGB", device=str(dev), sh_degree=deg)
+
+        fwd_only = timed(fwd_step, args.steps, 3)
+    # mean record counts over the cameras of the headline ring (its whole-step roofline is priced with THEIR intersections)
+    ring_M, ring_binned = count_records(list(ring(head_ring))) if rank == 0 else (None, None)
+    fixed_M = (count_records(list(ring(world * B)))[0] if head_ring != world * B else ring_M) if rank == 0 else None
     # ---- the optimisation step around the rasterizer (BASELINE config C3 "full Adam loop"): the fused harness step -- loss,
     # backward, SH rebuild, Adam -- on the same scene and views; NOT part of `value`
     train = None
     if world == 1 and args.workload in ("C3", "T") and not args.no_train_step:
-        stages.reset_speculation()   # (the wide-depth cameras above left the image size on device depth tables and their capacity)
+        # (no reset of what the passes above remembered: every pipeline / backend speculates on its own memory of the frame size)
         train = train_step_leg(sc, n, width, height, deg, B, dev, max(5, min(args.steps, 20)))
     copy_peak = measured_copy_peak(dev) if rank == 0 else 0.0   # after the timed regions
 
@@ -708,22 +786,17 @@ def main() -> None:
         ms_per_view = ms_per_step / B
         alg = algorithmic_bytes(n, m, p, deg)
         # per C-ABI stage: average device time per launch (binning = depth ordering + record generation + tile passes)
-        per, launches = {}, {}
-        for name, (calls, total) in stage_ms.items():
-            renames = {"gsa_sh_grad_expand": "sh_grad_rebuild", "gsa_composite_bwd_prepare": "bwd_prepare",
-                       "exchange_tail": "exchange_tail"}
-            key = name if name in alg else renames.get(name, "binning")
-            per[key] = per.get(key, 0.0) + total / args.steps
-            launches[key] = launches.get(key, 0) + calls / args.steps
+        per, launches = per_stage(stage_ms, args.steps)
         # the dominant KERNEL: "binning" is a stage of several short launches, the other four stages are one launch each
         dominant = max((k for k in per if k in alg and k != "binning"), key=lambda k: per[k])
         ach = alg[dominant] / (per[dominant] * 1e-3) / 1e9
-        total_bytes = sum(alg.values())
+        total_bytes = sum(alg.values())                                    # of camera 0's view (the single-view protocol)
+        ring_bytes = sum(algorithmic_bytes(n, ring_M, p, deg).values())    # mean over the headline ring's cameras
         # measured per launch, from separate rocprofv3 --pmc passes of the single-view step (profiles/*_traffic.json,
         # tools/make_traffic_json.py): HBM bytes of every kernel, VALU utilisation, float-atomic requests, and the
         # bound the counters point at.  NOT measured in this run: `counters_from` names the file and the sources' revision.
         traffic, counters, counters_from, measured_bytes, step_bytes = None, {}, None, None, None
-        for fname in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
+        for fname in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fname)) as fh:
                     doc = json.load(fh)
@@ -746,7 +819,8 @@ def main() -> None:
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {n} gaussians, {width}x{height}, SH degree {deg}, "
-                                   f"{B} view{'s' if B > 1 else ''} per GPU per step ({world * B} ring cameras per step), "
+                                   f"{B} view{'s' if B > 1 else ''} per GPU per step ({world * B} consecutive cameras of a ring of "
+                                   f"{head_ring} per step, the window moving on every step), "
                                    f"forward+backward into one 59N-float gradient bucket"
                                    + ("; speculation checked per view (no host group)" if flag_error and world > 1 else "")
                                    + ((", RCCL all-gather of 3N rgb grads per view + one all-reduce of 11N geometry grads per "
@@ -759,10 +833,18 @@ def main() -> None:
                        "projection": ("per step: %s" % ("forward + backward" if head_step.batch_bwd else "forward"))
                                      if head_step.batch_proj else "per view",
                        "speculation_check": ("per step, repairs: %d" % head_step.pipe.repairs) if B > 1 and not args.no_defer_check else "per view",
-                       "ms_per_view": round(ms_per_view, 4),
+                       "ms_per_view": round(ms_per_view, 4), "ring_cameras": head_ring,
+                       "intersections_M_ring_mean": round(ring_M, 1), "binned_records_ring_mean": round(ring_binned, 1),
                        "intersections_M": m, "bin_tile": stages.bin_tile_for(width, height, stages.DEFAULT_CULL_MODE if args.cull_mode is None else args.cull_mode), "binned_records": info.get("binned"),
                        "grad_l1": round(grad_l1_head, 3), "grad_l1_single_view": round(grad_l1, 3),
                        "cull_mode": stages.DEFAULT_CULL_MODE if args.cull_mode is None else args.cull_mode},
+            # the same step on the SAME gpus x views cameras every step (r04's protocol: remembered capacities / key ranges
+            # never move), and what the moving window cost the timed region in speculation
+            "value_fixed_cameras": round(world * B * p * args.steps / fixed["s"] / 1e6, 3),
+            "ms_per_view_fixed_cameras": round(fixed["s"] / args.steps * 1e3 / B, 4),
+            "speculation": {"repaired_steps": head["repaired_steps"], "views": head["stats"]["views"],
+                            "capacity_misses_per_100": round(100.0 * head["stats"]["capacity_misses"] / max(head["stats"]["views"], 1), 2),
+                            "key_range_repairs_per_100": round(100.0 * head["stats"]["key_range_repairs"] / max(head["stats"]["views"], 1), 2)},
             "warmup_effective": head["warmup_effective"],   # steps actually run before the timed window (see settle())
             "step_ms": percentiles(dist_ms),
             # (where the slow steps of the per-step pass sit: their indices -- a burst, or spread out?)
@@ -783,9 +865,12 @@ def main() -> None:
                          "measured_copy_peak": round(copy_peak, 1),
                          "algorithmic_bytes_per_launch": alg[dominant], "avg_launch_ms": round(per[dominant], 4)},
             # SURVEY 8d's compulsory bytes of one view over the time of one view of the timed region
-            "roofline_whole_step": {"algorithmic_bytes_per_view": total_bytes,
-                                    "achieved_GBs": round(total_bytes / (ms_per_view * 1e-3) / 1e9, 2),
-                                    "frac": round(total_bytes / (ms_per_view * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            # (the headline's views are the ring's cameras: priced with THEIR mean intersections)
+            "roofline_whole_step": {"algorithmic_bytes_per_view": int(ring_bytes),
+                                    "achieved_GBs": round(ring_bytes / (ms_per_view * 1e-3) / 1e9, 2),
+                                    "frac": round(ring_bytes / (ms_per_view * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                    "frac_fixed_cameras": round(sum(algorithmic_bytes(n, fixed_M, p, deg).values())
+                                                                / (fixed["s"] / args.steps / B) / 1e9 / HBM_PEAK_GBS, 5),
                                     "frac_single_view": round(total_bytes / (solo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
             "stage_ms_protocol": "single_view",
             "stage_ms": {k: round(v, 4) for k, v in sorted(per.items())},
@@ -794,7 +879,7 @@ def main() -> None:
             # a stage priced above the HBM peak is not moving SURVEY's bytes (it avoids them: digest instead of SH rows,
             # bins instead of tiles, early-out) -- the contractual fraction then flatters; see roofline_measured
             "over_peak": sorted(k for k, v in stage_gbs.items() if v > HBM_PEAK_GBS)
-                         + (["whole_step"] if total_bytes / (ms_per_view * 1e-3) / 1e9 > HBM_PEAK_GBS else []),
+                         + (["whole_step"] if ring_bytes / (ms_per_view * 1e-3) / 1e9 > HBM_PEAK_GBS else []),
         }
         if measured_bytes:
             # counter bytes of the SINGLE-VIEW step's kernels (profiles/*_traffic.json), over the time of a view of the
@@ -818,6 +903,8 @@ def main() -> None:
             line["rotating"] = {"views": args.views, "views_per_step": 1,
                                 "value_rotating": round(p * args.steps / rot["s"] / 1e6, 3),
                                 "ms_per_view": round(rot["s"] / args.steps * 1e3, 4),
+                                "stage_ms": {k: round(v, 4) for k, v in sorted(rot["stage_ms"].items())},
+                                "intersections_M": round(rot["M"], 1), "binned_records": round(rot["binned"], 1),
                                 "capacity_misses_per_100": round(st["capacity_misses"] * per100, 2),
                                 "key_range_repairs_per_100": round(st["key_range_repairs"] * per100, 2)}
         if wide is not None:
@@ -828,8 +915,15 @@ def main() -> None:
                                   "ms_per_view": round(wide["s"] / args.steps * 1e3, 4),
                                   "value": round(p * args.steps / wide["s"] / 1e6, 3),
                                   "depth_ordering_paths": wide["paths"],
+                                  "stage_ms": {k: round(v, 4) for k, v in sorted(wide["stage_ms"].items())},
+                                  "intersections_M": round(wide["M"], 1), "binned_records": round(wide["binned"], 1),
                                   "capacity_misses_per_100": round(st["capacity_misses"] * per100, 2),
                                   "key_range_repairs_per_100": round(st["key_range_repairs"] * per100, 2)}
+        if fwd_only is not None:
+            fo_ms = fwd_only["s"] / args.steps * 1e3
+            line["forward_only"] = {"what": "HipBackend.render_with_depth under no_grad (the reference's validation / eval callers, "
+                                            "trainer.py:417-424, eval.py:171-183), one view per call, fixed camera",
+                                    "ms": round(fo_ms, 4), "Mpix/s": round(p / fo_ms / 1e3, 3)}
         if train is not None:
             line["train_step"] = train
         if dist is not None:

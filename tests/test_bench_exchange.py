@@ -145,3 +145,80 @@ def test_single_process_factored_needs_no_collective():
     v_colors = torch.empty(n, 16, 3)
     ex.finish(torch.zeros(59 * n), torch.zeros(n, 3), 3, viewmats, torch.eye(3)[None], v_colors)
     assert torch.allclose(v_colors[:, 0, :], torch.full((n, 3), 10.0)) and ex.bytes_sent == 0
+
+
+@pytest.mark.parametrize("world,B,ring", [(8, 1, 16), (4, 2, 16), (8, 1, 8), (2, 4, 24), (8, 4, 64), (1, 4, 8), (3, 2, 7)])
+def test_step_camera_indexing_deals_the_window_round_robin(world, B, ring):
+    """bench.py's camera indexing for the shapes an 8-GPU node runs (BASELINE C4: 8 ranks x 1 view; 4 x 2; the default 8 x 4)
+    with a ring LARGER than a step's window: per step the ranks' views are disjoint, together they are the step's window of
+    `world x B` consecutive ring cameras, entry j x world + r of the window is rank r's view j (the order the local SH rebuild
+    sums in), and the window moves on from step to step."""
+    bench = _bench()
+    for i in range(5):
+        window = bench.step_window(i, B, world, ring)
+        assert window == [((i * B * world) + k) % ring for k in range(B * world)]
+        per_rank = [bench.step_cameras(i, B, world, r, ring) for r in range(world)]
+        assert all(len(c) == B for c in per_rank)
+        for j in range(B):
+            for r in range(world):
+                assert per_rank[r][j] == window[j * world + r]
+        if ring >= B * world:
+            assert sorted(c for cams in per_rank for c in cams) == sorted(window) and len(set(window)) == B * world
+    if ring > B * world:
+        assert bench.step_window(0, B, world, ring) != bench.step_window(1, B, world, ring)
+
+
+def _fake_view(cam: int, n: int):
+    """What a view of ring camera `cam` contributes: (11 n geometry floats, [n,3] rgb gradient) -- any function of the camera."""
+    g = torch.Generator().manual_seed(1000 + cam)
+    return torch.randn(11 * n, generator=g), torch.randn(n, 3, generator=g)
+
+
+def _exchange_rank(rank, world, B, ring, port, form):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        bench = _bench()
+        n = 53
+        factored = form == "factored"
+        ex = bench.Exchange(dist, world, rank, n, B, factored, "cpu", expand=_expand_ref)
+        for i in (0, 1, 3):
+            flat_grad = torch.zeros(59 * n)
+            for j, cam in enumerate(bench.step_cameras(i, B, world, rank, ring)):
+                geom, rgb = _fake_view(cam, n)
+                flat_grad[:11 * n] += geom
+                if factored:
+                    ex.view_target(j).copy_(rgb)
+                else:   # (the plain form: every view adds its whole coefficient gradient)
+                    one = torch.empty(n, 16, 3)
+                    vm = torch.zeros(1, 4, 4)
+                    vm[0, 0, 3] = cam + 1.0
+                    _expand_ref(None, 3, vm, None, rgb[None].contiguous(), one)
+                    flat_grad[11 * n:] += one.reshape(-1)
+                ex.after_view(j)
+            window = bench.step_window(i, B, world, ring)
+            viewmats = torch.zeros(B * world, 4, 4)
+            viewmats[:, 0, 3] = torch.tensor([c + 1.0 for c in window])
+            ex.finish(flat_grad, torch.zeros(n, 3), 3, viewmats, torch.eye(3)[None], flat_grad[11 * n:].view(n, 16, 3))
+            want_geom = sum(_fake_view(c, n)[0] for c in window)
+            want_sh = torch.empty(n, 16, 3)
+            _expand_ref(None, 3, viewmats, None, torch.stack([_fake_view(c, n)[1] for c in window]).contiguous(), want_sh)
+            assert torch.allclose(flat_grad[:11 * n], want_geom, rtol=1e-5, atol=1e-5), (rank, i, "geometry")
+            assert torch.allclose(flat_grad[11 * n:].view(n, 16, 3), want_sh, rtol=1e-5, atol=1e-4), (rank, i, "sh")
+        assert ex.steps == 3 and not ex.pending
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,B,form", [(8, 1, "factored"), (4, 2, "factored"), (8, 1, "allreduce")])
+def test_exchange_over_gloo_at_the_8_gpu_shapes(world, B, form):
+    """The exchange with the world sizes the driver's scaling run uses, over REAL collectives (gloo, CPU tensors; a GPU box
+    admits at most 6 processes on its card, so 8 ranks cannot share it): BASELINE C4 as written (8 ranks x 1 view) and 4 x 2,
+    ring of 16 cameras so that the window moves: on every rank the exchanged bucket is the sum over the step's 8 cameras --
+    geometry all-reduced, rgb gradients all-gathered per view and rebuilt locally in batch order -- for three steps."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_exchange_rank, args=(world, B, 16, port, form), nprocs=world, join=True)

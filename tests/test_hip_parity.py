@@ -661,7 +661,7 @@ def test_record_capacity_miss_is_repaired(gsa):
         r1, a1, m1 = gsa.rasterization(*args, W, H, sh_degree=3)          # steady state: capacity + device count
         key = ("cuda", torch.cuda.current_device(), W, H, S.DEFAULT_CULL_MODE, S.bin_tile_for(W, H, S.DEFAULT_CULL_MODE))
         assert S._capacity_for(key, N) >= m0["n_binned"]                   # (records of the bins the hot path sorts)
-        S._CAPACITY[key][0] = m0["n_binned"] / N / 3                       # pretend the scene grew threefold
+        S.DEFAULT_SPECULATION.capacity[key][0] = m0["n_binned"] / N / 3                       # pretend the scene grew threefold
         r2, a2, m2 = gsa.rasterization(*args, W, H, sh_degree=3)
     for r, a, m in ((r1, a1, m1), (r2, a2, m2)):
         assert torch.equal(r, r0) and torch.equal(a, a0)
@@ -703,7 +703,7 @@ def test_deferred_check_reports_a_miss_and_the_next_call_is_right(gsa):
         assert all(_rel(x.reshape(-1).cpu(), y.reshape(-1).cpu()) < 1e-5 for x, y in zip(g1, g0)), kw   # (float atomics: not bit-equal run to run)
         assert m1["n_binned"] == m0["n_binned"] and m1["n_isects"] == m0["n_isects"]
         assert torch.equal(m1["flatten_ids"], m0["flatten_ids"]) and torch.equal(m1["isect_ids"], m0["isect_ids"])
-    S._CAPACITY[key][0] = m0["n_binned"] / N / 3                            # pretend the scene grew threefold
+    S.DEFAULT_SPECULATION.capacity[key][0] = m0["n_binned"] / N / 3                            # pretend the scene grew threefold
     r2, a2, m2, g2 = run(defer_check=True)
     assert m2["speculation_ok"] is False                                    # ... reported, not repaired
     assert m2["n_binned"] < m0["n_binned"] <= S._capacity_for(key, N)       # (clamped to the capacity it ran with; the miss re-learned it)
@@ -721,7 +721,7 @@ def test_population_change_keeps_the_pipeline_asynchronous(gsa):
     sc = _scene(N + N // 20, seed=3, s_min=0.005, s_max=0.08)
     K, vm = scene.make_intrinsics(W, H).cuda(), scene.make_camera(1, 5).cuda()
     key = ("cuda", torch.cuda.current_device(), W, H, 0, 16)
-    S._CAPACITY.pop(key, None)
+    S.DEFAULT_SPECULATION.capacity.pop(key, None)
 
     def bins(n):
         t = [sc[k][:n].cuda().contiguous() for k in ("means3D", "rotations", "scales", "opacities", "shs")]
@@ -735,7 +735,7 @@ def test_population_change_keeps_the_pipeline_asynchronous(gsa):
         b, m = bins(n)
         assert b._m is None, "a changed population must not cost a blocking read-back"
         assert b.capacity >= m and b.finalize() == (m, True)
-    assert len(S._CAPACITY) <= S._CAPACITY_MAX_KEYS
+    assert len(S.DEFAULT_SPECULATION.capacity) <= S._CAPACITY_MAX_KEYS
     # two bins left un-finalized have their own read-back slots
     b1, m1 = bins(N)
     b2, m2 = bins(N - N // 20)
@@ -864,6 +864,87 @@ def test_degenerate_inputs(gsa):
         gsa.rasterization(*[t.cpu() for t in one], vm.cpu(), K.cpu(), W, H, sh_degree=3)
 
 
+def test_projection_is_checked_against_the_camera_and_the_parameters(gsa):
+    """``rasterization(projection=...)`` refuses a projection made for another camera, or from parameters that were written
+    since: the forward would blend the projection's splats while the backward differentiates the arguments.
+    Host-side compares of pointers and version counters; the legitimate uses stay silent."""
+    from gsplat_amd import scene
+    W, H, N = 160, 96, 1500
+    sc = _scene(N, seed=4)
+    leaves = [sc[k].cuda().clone().requires_grad_(True) for k in NAMES]
+    args = (leaves[0], leaves[1], leaves[2], leaves[3][:, 0], leaves[4])
+    vms = torch.stack([scene.make_camera(k, 5) for k in (0, 2)]).cuda()
+    K = scene.make_intrinsics(W, H).cuda()
+    proj = gsa.project_cameras(*args, vms, K, W, H, sh_degree=3)
+    assert proj.deferred is False   # (not asked for)
+    gsa.rasterization(*args, vms[1:2], K[None], W, H, sh_degree=3, projection=proj[1])
+    gsa.rasterization(*args, proj[0].viewmat[None], proj[0].Kmat[None], W, H, sh_degree=3, projection=proj[0])
+    with pytest.raises(ValueError, match="camera"):   # camera 0's tensors with camera 1's projection
+        gsa.rasterization(*args, vms[0:1], K[None], W, H, sh_degree=3, projection=proj[1])
+    with pytest.raises(ValueError, match="camera"):   # an equal-valued COPY is not the tensor either (no device compare)
+        gsa.rasterization(*args, vms[1:2].clone(), K[None], W, H, sh_degree=3, projection=proj[1])
+    with torch.no_grad():
+        leaves[0].add_(0.01)                           # an optimizer step
+    with pytest.raises(ValueError, match="written since"):
+        gsa.rasterization(*args, vms[1:2], K[None], W, H, sh_degree=3, projection=proj[1])
+    # a step that asks for the shared backward where it does not apply (colours without SH) is told so
+    flat = [leaves[0], leaves[1], leaves[2], leaves[3][:, 0], (leaves[4][:, 0, :] * 0.28 + 0.5).detach().requires_grad_(True)]
+    p2 = gsa.project_cameras(*flat, vms, K, W, H, sh_degree=None, defer_backward=True)
+    assert p2.deferred is False
+    with pytest.raises(ValueError, match="not made with a deferred backward"):
+        gsa.project_cameras_backward(p2, *flat, [torch.empty(1)] * 5)
+
+
+def test_two_backends_of_equal_frame_size_do_not_share_speculation(gsa):
+    """what the asynchronous binning remembers (record capacity, depth-key range, bucket plan) lives in
+    an object owned by the backend / pipeline, not in module globals keyed by frame size: a trainer's backend and an
+    evaluator's backend that render frames of the same size from DIFFERENT scenes and cameras interleave without a single
+    cross-induced repair, each remembers its own key range, and the process-wide default state never hears of the frame."""
+    from gsplat_amd import scene, stages as S
+    W, H, N = 640, 352, 40_000
+    K = scene.make_intrinsics(W, H).cuda()
+    a, b = gsa.HipBackend(K), gsa.HipBackend(K)
+    assert a.speculation is not b.speculation and a.speculation is not S.DEFAULT_SPECULATION
+    far = _scene(N, seed=31, s_max=0.03)                      # seen from the ring of radius 4: a narrow depth range, few records
+    near = _scene(N, seed=32, s_min=0.02, s_max=0.2)          # big splats seen from INSIDE the cloud: wide range, many records
+
+    def params(sc):
+        return {"means3D": sc["means3D"].cuda(), "rotations": sc["rotations"].cuda(), "scales": sc["scales"].cuda(),
+                "opacities": sc["opacities"].cuda(), "shs": sc["shs"].cuda()}
+
+    pa, pb = params(far), params(near)
+    cams_a = [scene.make_camera(k, 6).cuda() for k in range(6)]
+    cams_b = [scene.make_camera(k, 6, radius=0.35).cuda() for k in range(6)]
+    key = ("cuda", torch.cuda.current_device(), W, H, 0, S.bin_tile_for(W, H, 0))
+    S.DEFAULT_SPECULATION.capacity.pop(key, None)
+    S.DEFAULT_SPECULATION.key_range.pop(key, None)
+    bg = torch.zeros(3, device="cuda")
+
+    def view(backend, p, vm):
+        return backend.render_with_depth(p, {"world_view_transform": vm, "image_width": W, "image_height": H}, bg, "RGB", "cuda", 3)
+
+    with torch.no_grad():
+        alone = [view(gsa.HipBackend(K), pa, cams_a[0])["render"].clone()]   # (a backend of its own: the reference image)
+        for vm_a, vm_b in zip(cams_a, cams_b):                  # every camera once: first calls, growth of the remembered ranges
+            view(a, pa, vm_a), view(b, pb, vm_b)
+        for st in (a.speculation.repairs, b.speculation.repairs):
+            for k in st:
+                st[k] = 0
+        for _ in range(3):
+            for vm_a, vm_b in zip(cams_a, cams_b):
+                ra = view(a, pa, vm_a)
+                view(b, pb, vm_b)
+        again = view(a, pa, cams_a[0])["render"]
+    assert a.speculation.repairs["views"] == 18 and b.speculation.repairs["views"] == 18
+    assert a.speculation.repairs["capacity_misses"] == 0 and a.speculation.repairs["key_range_repairs"] == 0, a.speculation.repairs
+    assert b.speculation.repairs["capacity_misses"] == 0, b.speculation.repairs
+    ka, kb = a.speculation.key_range[key], b.speculation.key_range[key]
+    assert ka[:2] != kb[:2] and (kb[1] - kb[0]) > 4 * (ka[1] - ka[0])       # each remembers ITS cameras' depth range
+    assert a.speculation.capacity[key][0] < 0.5 * b.speculation.capacity[key][0]   # ... and ITS records per gaussian
+    assert key not in S.DEFAULT_SPECULATION.capacity and key not in S.DEFAULT_SPECULATION.key_range
+    assert torch.equal(again, alone[0])
+
+
 def test_backend_plugin_surface(gsa):
     """HipBackend.render_with_depth against the oracle backend, through the reference's dict-in/dict-out
     contract (/root/reference/src/backends/gsplat_backend.py:129-210)."""
@@ -946,6 +1027,59 @@ def test_config_c2_100k_1080p_deg3(gsa, cam):
         "masked_pixels": errs["masked_pixels"],
         "tensors": {k: {"err_hip": v[0], "err_fp32_oracle": v[1]} for k, v in errs.items() if k not in _ERR_KEYS}})
     assert 0 < m1["flatten_ids"].numel() <= m0["flatten_ids"].numel() + 64  # default cull_mode drops unreachable tiles
+
+
+def test_config_c2_step_of_4_cameras(gsa):
+    """The step form bench.py's `value` is quoted on, at BASELINE config C2's size, DIRECTLY against the oracle:
+    ``project_cameras(defer_backward=True)`` (one projection launch for the step's four cameras) -> 4 x
+    ``rasterization(projection=...)`` + ``backward()`` (each stops behind its sweep) -> ``project_cameras_backward`` (one
+    launch) -- the gradient bucket against the SUM of the fp64 oracle's per-camera gradients, every image against the fp64
+    oracle's, 1e-4 outright.  (Each camera's upstream gradient is masked at the pixels the fp64 oracle finds
+    threshold-ambiguous for that camera, on both sides, as in ``_compare``.)"""
+    from gsplat_amd import scene
+    from oracle import rasterization as oracle_rasterization
+    W, H, C = 1920, 1080, 4
+    sc = scene.make_scene(100_000, seed=0, sh_degree=3)
+    K = scene.make_intrinsics(W, H)
+    cams = [scene.make_camera(c, C) for c in range(C)]
+    bg = torch.zeros(3)
+    rng = np.random.default_rng(12)
+    v = [torch.from_numpy(rng.uniform(-1, 1, (H, W, 3))) for _ in range(C)]
+    want = {n: 0.0 for n in NAMES}
+    keeps, renders64, amb = [], [], []
+    for c in range(C):
+        o64, m64, keep = _run(oracle_rasterization, "cpu", torch.float64, sc, cams[c], K, W, H, 3, bg, v[c], None,
+                              ambiguity_tol=_amb_tol_e2e(W, H), checkpoint=True)
+        assert 1.0 - float(keep.mean()) <= MAX_AMB_FRACTION
+        amb.append(1.0 - float(keep.mean()))
+        keeps.append(keep)
+        renders64.append(o64["render"])
+        for n in NAMES:
+            want[n] = want[n] + o64["grad_" + n]
+    leaves = [sc[k].cuda().clone().requires_grad_(True) for k in NAMES]
+    args = (leaves[0], leaves[1], leaves[2], leaves[3][:, 0], leaves[4])
+    vms, Kd = torch.stack(cams).cuda(), K.cuda()
+    errs = {}
+    for attempt in range(2):   # (the first pass meets the first calls of the frame size: exact sizes, LSD ordering; the second the steady state)
+        proj = gsa.project_cameras(*args, vms, Kd, W, H, sh_degree=3, defer_backward=True)
+        assert proj.deferred
+        for c in range(C):
+            r, a, meta = gsa.rasterization(*args, vms[c:c + 1], Kd[None], W, H, sh_degree=3, backgrounds=bg[None].cuda(),
+                                           projection=proj[c])
+            errs[f"render_cam{c}"] = _rel(r.detach().cpu().double() * keeps[c][None, ..., None], renders64[c])
+            (r[0] * (v[c] * keeps[c][..., None]).float().cuda()).sum().backward()
+        assert all(t.grad is None for t in leaves)
+        bucket = [torch.full_like(t.detach(), float("nan")) for t in args]
+        gsa.project_cameras_backward(proj, *args, bucket)
+        for n, g in zip(NAMES, bucket):
+            errs["grad_" + n] = _rel(g.reshape(want[n].shape), want[n])
+        print(f"C2 step of 4 cameras, pass {attempt}:", errs)
+        assert all(e <= REL_TOL for e in errs.values()), errs
+    _parity_record("parity_c2_step", {
+        "config": "C2: 100000 gaussians, 1920x1080, SH degree 3; ONE step of the 4 ring cameras through project_cameras("
+                  "defer_backward=True) -> 4 x rasterization(projection=...) + backward -> project_cameras_backward",
+        "metric": "max|a - b| / max|b| per tensor; b = the fp64 oracle's image per camera / the SUM of its per-camera gradients",
+        "masked_pixel_fraction_per_camera": amb, "tensors": errs})
 
 
 @pytest.mark.parametrize("cam", [(0, 1), (3, 8)])
@@ -1614,10 +1748,10 @@ def test_bucketed_depth_order_reports_what_it_cannot_do(gsa):
     assert not S._note_keys(("t", 1), int(ctl[1]), int(ctl[2]), narrow, int(ctl[3]))
     # (r03 also reported ranges beyond two octaves of depth -- status bit 2; with 24-bit local sorts every range of positive
     # float depths fits, see the "wide" case of test_bucketed_depth_order_equals_lsd_sort)
-    S._MSD_BACKOFF.pop(("t", 2), None)
-    S._KEY_RANGE.pop(("t", 2), None)
-    S._KEY_RANGE.pop(("t", 0), None)
-    S._KEY_RANGE.pop(("t", 1), None)
+    S.DEFAULT_SPECULATION.msd_backoff.pop(("t", 2), None)
+    S.DEFAULT_SPECULATION.key_range.pop(("t", 2), None)
+    S.DEFAULT_SPECULATION.key_range.pop(("t", 0), None)
+    S.DEFAULT_SPECULATION.key_range.pop(("t", 1), None)
 
 
 def test_views_equal_buckets_do_not_fit_move_the_shape_to_depth_tables(gsa):
@@ -1631,7 +1765,7 @@ def test_views_equal_buckets_do_not_fit_move_the_shape_to_depth_tables(gsa):
     d = {k: v.cuda().contiguous() for k, v in sc.items()}
     K = scene.make_intrinsics(W, H).cuda()[None]
     key = ("cuda", torch.cuda.current_device(), W, H, 0, S.bin_tile_for(W, H, 0))
-    for t in (S._CAPACITY, S._KEY_RANGE, S._MSD_BACKOFF, S._TABLE_MODE, S._MSD_STREAK, S._HOST_PLAN_BACKOFF):
+    for t in (S.DEFAULT_SPECULATION.capacity, S.DEFAULT_SPECULATION.key_range, S.DEFAULT_SPECULATION.msd_backoff, S.DEFAULT_SPECULATION.table_mode, S.DEFAULT_SPECULATION.msd_streak, S.DEFAULT_SPECULATION.host_plan_backoff):
         t.pop(key, None)
     for k in S.REPAIR_STATS:
         S.REPAIR_STATS[k] = 0
@@ -1643,11 +1777,11 @@ def test_views_equal_buckets_do_not_fit_move_the_shape_to_depth_tables(gsa):
         return r
 
     first = [render(v) for v in (0, 0, 2, 1)]        # first call (exact), host-planned, host-planned, the diagonal view: repaired
-    assert S.REPAIR_STATS["key_range_repairs"] == 1 and S._TABLE_MODE.get(key, 0) > 0, (S.REPAIR_STATS, S._TABLE_MODE)
+    assert S.REPAIR_STATS["key_range_repairs"] == 1 and S.DEFAULT_SPECULATION.table_mode.get(key, 0) > 0, (S.REPAIR_STATS, S.DEFAULT_SPECULATION.table_mode)
     again = [render(v) for v in (1, 0, 3, 2, 5, 4, 7, 6)]
     assert S.REPAIR_STATS["key_range_repairs"] == 1 and S.REPAIR_STATS["capacity_misses"] <= 1, S.REPAIR_STATS
     assert torch.equal(again[0], first[3]) and torch.equal(again[1], first[0]) and torch.equal(again[3], first[2])
-    for t in (S._CAPACITY, S._KEY_RANGE, S._MSD_BACKOFF, S._TABLE_MODE, S._MSD_STREAK, S._HOST_PLAN_BACKOFF):
+    for t in (S.DEFAULT_SPECULATION.capacity, S.DEFAULT_SPECULATION.key_range, S.DEFAULT_SPECULATION.msd_backoff, S.DEFAULT_SPECULATION.table_mode, S.DEFAULT_SPECULATION.msd_streak, S.DEFAULT_SPECULATION.host_plan_backoff):
         t.pop(key, None)
 
 
@@ -1670,7 +1804,7 @@ def test_depth_cluster_falls_back_to_the_lsd_path(gsa):
     radii = torch.ones(N, 2, dtype=torch.int32, device="cuda")
     k32 = keys.to(torch.int32).cuda()
     key = ("cuda", torch.cuda.current_device(), W, H, 0, 16)
-    for d in (S._CAPACITY, S._KEY_RANGE, S._MSD_BACKOFF, S._TABLE_MODE, S._MSD_STREAK, S._HOST_PLAN_BACKOFF):
+    for d in (S.DEFAULT_SPECULATION.capacity, S.DEFAULT_SPECULATION.key_range, S.DEFAULT_SPECULATION.msd_backoff, S.DEFAULT_SPECULATION.table_mode, S.DEFAULT_SPECULATION.msd_streak, S.DEFAULT_SPECULATION.host_plan_backoff):
         d.pop(key, None)
 
     def bins(**kw):
@@ -1702,5 +1836,5 @@ def test_depth_cluster_falls_back_to_the_lsd_path(gsa):
     third = bins()                                     # backed off: LSD on the bits the keys differ in
     assert not isinstance(third.key_bits, tuple) and third.finalize() == (m, True)
     assert torch.equal(third.sorted_gid, ref_gid) and torch.equal(third.tile_offsets, ref_off)
-    for d in (S._CAPACITY, S._KEY_RANGE, S._MSD_BACKOFF, S._TABLE_MODE, S._MSD_STREAK, S._HOST_PLAN_BACKOFF):
+    for d in (S.DEFAULT_SPECULATION.capacity, S.DEFAULT_SPECULATION.key_range, S.DEFAULT_SPECULATION.msd_backoff, S.DEFAULT_SPECULATION.table_mode, S.DEFAULT_SPECULATION.msd_streak, S.DEFAULT_SPECULATION.host_plan_backoff):
         d.pop(key, None)
