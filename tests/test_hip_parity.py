@@ -660,13 +660,13 @@ def test_record_capacity_miss_is_repaired(gsa):
         ids0 = m0["flatten_ids"].clone()
         r1, a1, m1 = gsa.rasterization(*args, W, H, sh_degree=3)          # steady state: capacity + device count
         key = ("cuda", torch.cuda.current_device(), W, H, S.DEFAULT_CULL_MODE, S.bin_tile_for(W, H, S.DEFAULT_CULL_MODE))
-        assert S._capacity_for(key, N) >= m0["n_binned"]                   # (records of the bins the hot path sorts)
+        assert S._capacity_for(S.DEFAULT_SPECULATION, key, N) >= m0["n_binned"]                   # (records of the bins the hot path sorts)
         S.DEFAULT_SPECULATION.capacity[key][0] = m0["n_binned"] / N / 3                       # pretend the scene grew threefold
         r2, a2, m2 = gsa.rasterization(*args, W, H, sh_degree=3)
     for r, a, m in ((r1, a1, m1), (r2, a2, m2)):
         assert torch.equal(r, r0) and torch.equal(a, a0)
         assert m["n_isects"] == m0["n_isects"] and torch.equal(m["flatten_ids"], ids0)
-    assert S._capacity_for(key, N) >= m0["n_binned"]                       # the miss re-learned the capacity
+    assert S._capacity_for(S.DEFAULT_SPECULATION, key, N) >= m0["n_binned"]                       # the miss re-learned the capacity
 
 
 def test_deferred_check_reports_a_miss_and_the_next_call_is_right(gsa):
@@ -706,7 +706,7 @@ def test_deferred_check_reports_a_miss_and_the_next_call_is_right(gsa):
     S.DEFAULT_SPECULATION.capacity[key][0] = m0["n_binned"] / N / 3                            # pretend the scene grew threefold
     r2, a2, m2, g2 = run(defer_check=True)
     assert m2["speculation_ok"] is False                                    # ... reported, not repaired
-    assert m2["n_binned"] < m0["n_binned"] <= S._capacity_for(key, N)       # (clamped to the capacity it ran with; the miss re-learned it)
+    assert m2["n_binned"] < m0["n_binned"] <= S._capacity_for(S.DEFAULT_SPECULATION, key, N)       # (clamped to the capacity it ran with; the miss re-learned it)
     r3, a3, m3, g3 = run(defer_check=True)
     assert m3["speculation_ok"] is True and torch.equal(r3, r0)
     assert all(_rel(x.reshape(-1).cpu(), y.reshape(-1).cpu()) < 1e-5 for x, y in zip(g3, g0))
@@ -1420,7 +1420,7 @@ def test_fused_binning_equals_emit_and_sort(gsa, W, H, N, s_max, giants):
     assert c.finalize() == (m, True)
     assert torch.equal(c.sorted_gid, a.sorted_gid) and torch.equal(c.tile_offsets, a.tile_offsets)
     real = S._capacity_for
-    S._capacity_for = lambda key, n: max(1, m // 3)        # too small: kernels clamp to it, finalize() says so
+    S._capacity_for = lambda spec, key, n: max(1, m // 3)        # too small: kernels clamp to it, finalize() says so
     try:
         t = S.bin_tiles(splat, radii, tiles, keys, W, H, 0, fused=True)
     finally:
@@ -1740,12 +1740,12 @@ def test_bucketed_depth_order_reports_what_it_cannot_do(gsa):
     check(lib.gsa_depth_order_msd(n, k32.data_ptr(), pairs.data_ptr(), plan[0], plan[1], None, out[0].data_ptr(), out[1].data_ptr(),
                                   out[2].data_ptr(), owner.data_ptr(), 63, ctl.data_ptr(), None, 0, ws.data_ptr(), ws.numel(), st), "msd")
     assert int(ctl[3]) & 1, "bucket overflow must be reported"
-    assert not S._note_keys(("t", 0), int(ctl[1]), int(ctl[2]), plan, int(ctl[3]))
+    assert not S._note_keys(S.DEFAULT_SPECULATION, ("t", 0), int(ctl[1]), int(ctl[2]), plan, int(ctl[3]))
     # keys below the assumed minimum: the measured range tells
     narrow = (0x40400000, 1 << 24)   # (buckets 256 keys wide from there)
     check(lib.gsa_depth_order_msd(n, k32.data_ptr(), pairs.data_ptr(), narrow[0], narrow[1], None, out[0].data_ptr(), out[1].data_ptr(),
                                   out[2].data_ptr(), owner.data_ptr(), 63, ctl.data_ptr(), None, 0, ws.data_ptr(), ws.numel(), st), "msd")
-    assert not S._note_keys(("t", 1), int(ctl[1]), int(ctl[2]), narrow, int(ctl[3]))
+    assert not S._note_keys(S.DEFAULT_SPECULATION, ("t", 1), int(ctl[1]), int(ctl[2]), narrow, int(ctl[3]))
     # (r03 also reported ranges beyond two octaves of depth -- status bit 2; with 24-bit local sorts every range of positive
     # float depths fits, see the "wide" case of test_bucketed_depth_order_equals_lsd_sort)
     S.DEFAULT_SPECULATION.msd_backoff.pop(("t", 2), None)
