@@ -109,7 +109,15 @@ __device__ __forceinline__ void rows_to_lanes(float4 *wrows, int lane, const flo
 #ifndef GSA_PROJ_BATCH_WAVES
 #define GSA_PROJ_BATCH_WAVES 1   // register budget of the multi-camera instances (waves per SIMD the compiler must leave room for)
 #endif
-template <int DEG, bool STAGE, bool BATCH>
+// PART (r05, gsa_project_fwd_parts): what of the stage's outputs a launch produces.  kPartGeometry: what the BINNING needs --
+// radii, tile counts, depth keys, bin rectangles, quadrant boxes, the per-wave key ranges: 44 B in, 28 B out per gaussian and
+// camera, no colour, no coefficient row, no record.  kPartRecords: what the SWEEPS need -- the 64-B splat record (with the
+// colour) and the coefficient digest.  Both: the whole stage (gsa_project_fwd as before).  Each part recomputes the projection
+// (the same function of the same inputs: the same bits), so the two launches are independent of each other: the records part
+// runs on a stream of its own BESIDE the latency-bound binning chain, which only waits for the short geometry part -- the
+// HBM is idle under the binning (0.13 ms at 1.7 TB/s of traffic), and a view alone no longer pays the 192-B rows in front of it.
+constexpr int kPartGeometry = 1, kPartRecords = 2, kPartBoth = 3;
+template <int DEG, bool STAGE, bool BATCH, int PART = kPartBoth>
 __global__ __launch_bounds__(kBlock, (BATCH ? GSA_PROJ_BATCH_WAVES : GSA_PROJ_FWD_WAVES)) void project_fwd_kernel(
     int n, const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
     const float *__restrict__ opacities, const float *__restrict__ colors, int sh_coeffs,
@@ -121,6 +129,8 @@ __global__ __launch_bounds__(kBlock, (BATCH ? GSA_PROJ_BATCH_WAVES : GSA_PROJ_FW
     // thread keeps its gaussian's geometry and coefficient row (236 B of the 376 B a single-camera launch moves) and runs
     // the per-camera part once per camera; camera c's outputs are the c-th slabs of [n_cams, ...] arrays.  Per camera the
     // arithmetic IS the single-camera kernel's (this one, with n_cams = 1): the results are the same bits.
+    constexpr bool GEOM = (PART & kPartGeometry) != 0, RECS = (PART & kPartRecords) != 0;
+    static_assert(RECS || (DEG < 0 && !STAGE), "the geometry part has one instance per camera mode: no colour");
     __shared__ float4 sh_lds[STAGE ? (kBlock / 64) * kWaveLds : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Blocks walk the gaussians from the LAST to the first (GSA_PROJ_FWD_REVERSE): the kernel that ran before this one in
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(kBlock, (BATCH ? GSA_PROJ_BATCH_WAVES : GSA_PROJ_FW
     // SH rows: all of the wave's loads are issued now; they pass through LDS further down, when the coefficients are
     // needed
     constexpr int NQ = sh_needed_q<DEG>();
-    constexpr bool ROWS_IN = STAGE && DEG >= 1;
+    constexpr bool ROWS_IN = STAGE && DEG >= 1 && RECS;
     float stg[ROWS_IN ? 8 * row_loads_per_lane<NQ>() : 8];
     if constexpr (ROWS_IN) {
         const long wave_base = min(blk * kBlock + wave * 64, (long)n - 1);
@@ -195,8 +205,10 @@ __global__ __launch_bounds__(kBlock, (BATCH ? GSA_PROJ_BATCH_WAVES : GSA_PROJ_FW
     uint32_t qb = 0u;                      // the quadrant bounding box of the alpha >= 1/255 ellipse (see below)
     if (visible) {
     // ---- colour (A.3)
-    float r, g, b;
-    if constexpr (DEG < 0) {
+    float r = 0.f, g = 0.f, b = 0.f;
+    if constexpr (!RECS) {
+        // (the geometry part: no colour)
+    } else if constexpr (DEG < 0) {
         r = colors[i * 3]; g = colors[i * 3 + 1]; b = colors[i * 3 + 2];
     } else {
         constexpr int NB = (DEG + 1) * (DEG + 1);
@@ -245,7 +257,9 @@ __global__ __launch_bounds__(kBlock, (BATCH ? GSA_PROJ_BATCH_WAVES : GSA_PROJ_FW
     // ---- tile count (A.4)
     rx = (int)rxf; ry = (int)ryf;
     GsaTileRect tr = gsa_tile_rect(p.mx, p.my, rx, ry, tile_w, tile_h);
-    if (cull_mode == 0) {
+    if (!GEOM) {
+        // (the records part needs the rectangle for record word 11 only)
+    } else if (cull_mode == 0) {
         count = (tr.x1 - tr.x0) * (tr.y1 - tr.y0);
     } else {
         count = 0;
@@ -258,7 +272,7 @@ __global__ __launch_bounds__(kBlock, (BATCH ? GSA_PROJ_BATCH_WAVES : GSA_PROJ_FW
     const bool packable = tile_w < 1024 && tile_h < 1024;
     rect = packable ? ((uint32_t)tr.x0 | ((uint32_t)tr.y0 << 10) | ((uint32_t)(tr.x1 - tr.x0) << 20)) : 0u;
     bin_pair = make_uint2(count > 0 ? rect : 0u, (uint32_t)count);
-    if (bin_tile != GSA_TILE_SIZE) {   // coarser bins (cull_mode 0 only): the same rule on a grid of bin_tile pixels
+    if (GEOM && bin_tile != GSA_TILE_SIZE) {   // coarser bins (cull_mode 0 only): the same rule on a grid of bin_tile pixels
         const int bw = (width + bin_tile - 1) / bin_tile, bh = (height + bin_tile - 1) / bin_tile;
         const GsaTileRect br = gsa_tile_rect(p.mx, p.my, rx, ry, bw, bh, bin_tile);
         const int bc = (br.x1 - br.x0) * (br.y1 - br.y0);
@@ -270,7 +284,7 @@ __global__ __launch_bounds__(kBlock, (BATCH ? GSA_PROJ_BATCH_WAVES : GSA_PROJ_FW
     // packed first column | first row << 10 | (columns - 1) << 20 | (rows - 1) << 26; 0xFFFFFFFF: more than 64 quadrants
     // a side or a grid beyond 1024.  What the record placement turns into per-record quadrant masks without looking at the
     // conic again (gsa_tile_bin16): of the records of a 32 x 32 bin 22 % reach a given quadrant, of those inside the box 78 %.
-    if (qbox) {
+    if (GEOM && qbox) {
         const float t2 = 2.f * (sig_max * 1.0001f + 1e-4f);
         const float hx = __builtin_amdgcn_sqrtf(t2 * fmaxf(p.c00, 0.f)) * 1.00001f + 1e-3f;
         const float hy = __builtin_amdgcn_sqrtf(t2 * fmaxf(p.c11, 0.f)) * 1.00001f + 1e-3f;
@@ -292,7 +306,9 @@ __global__ __launch_bounds__(kBlock, (BATCH ? GSA_PROJ_BATCH_WAVES : GSA_PROJ_FW
 
     // ---- the 64-B records: through the wave's (now free) LDS rows, so that every store instruction writes 1 KB of
     // consecutive addresses instead of 16 B at a 64-B stride
-    if constexpr (STAGE && DEG >= 1) {
+    if constexpr (!RECS) {
+        // (the geometry part writes no record)
+    } else if constexpr (STAGE && DEG >= 1) {
         const long wave_base = blk * kBlock + wave * 64;
         const int rows = (int)min((long)64, (long)n - wave_base);
         float4 *wl = &sh_lds[wave * kWaveLds];
@@ -334,7 +350,7 @@ __global__ __launch_bounds__(kBlock, (BATCH ? GSA_PROJ_BATCH_WAVES : GSA_PROJ_FW
     // (Atomic min / max into a few shards were tried first: the waves of the kernel's first round all find the initial
     // values and all add -- 31 k atomics on two cache lines tripled this kernel's time, 64 shards on lines of their own
     // still cost 15 %.)
-    if (key_range) {
+    if (GEOM && key_range) {
         const uint32_t s0 = (uint32_t)__shfl((int)key, 0), s1 = (uint32_t)__shfl((int)key, 32);
         uint32_t lo = key, hi = key == 0xFFFFFFFFu ? 0u : key;
 #pragma unroll
@@ -346,7 +362,7 @@ __global__ __launch_bounds__(kBlock, (BATCH ? GSA_PROJ_BATCH_WAVES : GSA_PROJ_FW
         if (lane == 0 && blk * kBlock + wave * 64 < (long)n)
             reinterpret_cast<uint4 *>(key_range)[blk * (kBlock / 64) + wave] = make_uint4(lo, hi, s0, s1);
     }
-    if (inside) {
+    if (GEOM && inside) {
         *reinterpret_cast<int2 *>(radii + 2 * i) = make_int2(rx, ry);
         tiles_touched[i] = count;
         depth_keys[i] = key;
@@ -839,18 +855,24 @@ int launch_fwd(bool stage, int n, const float *means, const float *quats, const 
                const float *opacities, const float *colors, int sh_coeffs, const float *viewmat,
                const float *intrin, int n_cams, int intrin_stride, int width, int height, int cull_mode, float *splat,
                int32_t *radii, int32_t *tiles_touched, uint32_t *depth_keys, uint32_t *tile_rects, float *sh_aux,
-               int bin_tile, uint32_t *key_range, uint32_t *qbox, hipStream_t s) {
+               int bin_tile, uint32_t *key_range, uint32_t *qbox, int parts, hipStream_t s) {
     int tile_w = gsa_div_up(width, GSA_TILE_SIZE), tile_h = gsa_div_up(height, GSA_TILE_SIZE);
     dim3 grid(gsa_div_up(n, kBlock)), block(kBlock);
-#define GSA_FWD_LAUNCH(ST, BA)                                                                                         \
-    project_fwd_kernel<DEG, ST, BA><<<grid, block, 0, s>>>(n, means, quats, scales, opacities, colors, sh_coeffs, viewmat, \
+#define GSA_FWD_LAUNCH(ST, BA, PA)                                                                                     \
+    project_fwd_kernel<DEG, ST, BA, PA><<<grid, block, 0, s>>>(n, means, quats, scales, opacities, colors, sh_coeffs, viewmat, \
                                                            intrin, n_cams, intrin_stride, width, height, tile_w, tile_h,     \
                                                            cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects,   \
                                                            sh_aux, bin_tile, key_range, qbox)
-    if (n_cams > 1) {
-        if (stage) GSA_FWD_LAUNCH(true, true); else GSA_FWD_LAUNCH(false, true);
+    if (parts == kPartRecords) {
+        if (n_cams > 1) {
+            if (stage) GSA_FWD_LAUNCH(true, true, kPartRecords); else GSA_FWD_LAUNCH(false, true, kPartRecords);
+        } else {
+            if (stage) GSA_FWD_LAUNCH(true, false, kPartRecords); else GSA_FWD_LAUNCH(false, false, kPartRecords);
+        }
+    } else if (n_cams > 1) {
+        if (stage) GSA_FWD_LAUNCH(true, true, kPartBoth); else GSA_FWD_LAUNCH(false, true, kPartBoth);
     } else {
-        if (stage) GSA_FWD_LAUNCH(true, false); else GSA_FWD_LAUNCH(false, false);
+        if (stage) GSA_FWD_LAUNCH(true, false, kPartBoth); else GSA_FWD_LAUNCH(false, false, kPartBoth);
     }
 #undef GSA_FWD_LAUNCH
     GSA_LAUNCH_CHECK();
@@ -902,9 +924,10 @@ static int project_fwd_impl(int n, const float *means, const float *quats, const
                             const float *viewmat, const float *intrin, int n_cams, int intrin_stride, int width, int height,
                             int cull_mode, float *splat, int32_t *radii, int32_t *tiles_touched, uint32_t *depth_keys,
                             uint32_t *tile_rects, float *sh_aux, int bin_tile, uint32_t *key_range, uint32_t *qbox,
-                            gsa_stream_t stream) {
+                            gsa_stream_t stream, int parts = kPartBoth) {
     GSA_RETURN_IF(n < 0 || width <= 0 || height <= 0 || n_cams < 1 || (intrin_stride != 0 && intrin_stride != 9),
                   GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(parts != kPartGeometry && parts != kPartRecords && parts != kPartBoth, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_degree < -1 || sh_degree > 3, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_degree >= 0 && sh_coeffs < (sh_degree + 1) * (sh_degree + 1), GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(cull_mode != 0 && cull_mode != 1, GSA_ERR_INVALID_ARGUMENT);
@@ -916,16 +939,30 @@ static int project_fwd_impl(int n, const float *means, const float *quats, const
                       (reinterpret_cast<uintptr_t>(splat) & 15) != 0 || (reinterpret_cast<uintptr_t>(sh_aux) & 15) != 0,
                   GSA_ERR_INVALID_ARGUMENT);
     if (n == 0) return GSA_OK;
-    GSA_RETURN_IF(!means || !quats || !scales || !opacities || !colors || !viewmat || !intrin || !splat || !radii ||
-                      !tiles_touched || !depth_keys,
-                  GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF(!means || !quats || !scales || !opacities || !viewmat || !intrin, GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF((parts & kPartRecords) && (!colors || !splat), GSA_ERR_INVALID_ARGUMENT);
+    GSA_RETURN_IF((parts & kPartGeometry) && (!radii || !tiles_touched || !depth_keys), GSA_ERR_INVALID_ARGUMENT);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (parts == kPartGeometry) {   // no colour, no rows: one light instance per camera mode
+        int tile_w = gsa_div_up(width, GSA_TILE_SIZE), tile_h = gsa_div_up(height, GSA_TILE_SIZE);
+        dim3 grid(gsa_div_up(n, kBlock)), block(kBlock);
+        if (n_cams > 1)
+            project_fwd_kernel<-1, false, true, kPartGeometry><<<grid, block, 0, s>>>(
+                n, means, quats, scales, opacities, nullptr, 0, viewmat, intrin, n_cams, intrin_stride, width, height, tile_w,
+                tile_h, cull_mode, nullptr, radii, tiles_touched, depth_keys, tile_rects, nullptr, bin_tile, key_range, qbox);
+        else
+            project_fwd_kernel<-1, false, false, kPartGeometry><<<grid, block, 0, s>>>(
+                n, means, quats, scales, opacities, nullptr, 0, viewmat, intrin, n_cams, intrin_stride, width, height, tile_w,
+                tile_h, cull_mode, nullptr, radii, tiles_touched, depth_keys, tile_rects, nullptr, bin_tile, key_range, qbox);
+        GSA_LAUNCH_CHECK();
+        return GSA_OK;
+    }
     // degree 0 needs 12 B of each 192-B row: direct loads beat staging whole rows
     bool stage = can_stage(colors, sh_degree, sh_coeffs) && sh_degree >= 1;
 #define GSA_FWD(D)                                                                                                      \
     return launch_fwd<D>(stage, n, means, quats, scales, opacities, colors, sh_coeffs, viewmat, intrin, n_cams,         \
                          intrin_stride, width, height, cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects, \
-                         sh_aux, bin_tile, key_range, qbox, s)
+                         sh_aux, bin_tile, key_range, qbox, parts, s)
     switch (sh_degree) {
         case -1: GSA_FWD(-1);
         case 0: GSA_FWD(0);
@@ -958,6 +995,17 @@ extern "C" int gsa_project_fwd_batch(int n, const float *means, const float *qua
     return project_fwd_impl(n, means, quats, scales, opacities, colors, sh_degree, sh_coeffs, viewmats, intrins, n_cams,
                             intrin_stride, width, height, cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects,
                             sh_aux, bin_tile, key_range, qbox, stream);
+}
+
+extern "C" int gsa_project_fwd_parts(int parts, int n, const float *means, const float *quats, const float *scales,
+                                     const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
+                                     int n_cams, const float *viewmats, const float *intrins, int intrin_stride, int width,
+                                     int height, int cull_mode, float *splat, int32_t *radii, int32_t *tiles_touched,
+                                     uint32_t *depth_keys, uint32_t *tile_rects, float *sh_aux, int bin_tile,
+                                     uint32_t *key_range, uint32_t *qbox, gsa_stream_t stream) {
+    return project_fwd_impl(n, means, quats, scales, opacities, colors, sh_degree, sh_coeffs, viewmats, intrins, n_cams,
+                            intrin_stride, width, height, cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects,
+                            sh_aux, bin_tile, key_range, qbox, stream, parts);
 }
 
 static int project_bwd_impl(int n, const float *means, const float *quats, const float *scales, const float *opacities,

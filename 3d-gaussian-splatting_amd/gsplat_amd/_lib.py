@@ -13,7 +13,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_u
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # GSPLAT_AMD_LIB: developer override to A/B another build of the SAME C ABI (still a HIP library; no fallback)
 LIB_PATH = os.environ.get("GSPLAT_AMD_LIB") or os.path.join(_PKG_ROOT, "lib", "libgsplat_amd.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 SPLAT_STRIDE = 16
 
 P = c_void_p  # every device pointer and the stream cross the boundary as void*
@@ -25,6 +25,8 @@ SIGNATURES = {
     "gsa_project_fwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, c_int, P, P, P, P, P, P, c_int, P, P, P]),
     "gsa_project_fwd_batch": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P,
                                       c_int, P, P, P]),
+    "gsa_project_fwd_parts": (c_int, [c_int, c_int, P, P, P, P, P, c_int, c_int, c_int, P, P, c_int, c_int, c_int, c_int, P, P, P, P,
+                                      P, P, c_int, P, P, P]),
     "gsa_sort_workspace_bytes": (c_size_t, [c_int]),
     "gsa_sort_pairs_u32": (c_int, [c_int, P, P, P, P, P, P, c_int, c_int, P, c_size_t, P]),
     "gsa_scan_tiles": (c_int, [c_int, P, P, P, P, P, c_size_t, P]),

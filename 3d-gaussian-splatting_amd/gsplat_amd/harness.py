@@ -666,20 +666,27 @@ class ViewParallelTrainer:
             view = mine[j]
             W, H = view["width"], view["height"]
             bt = S.bin_tile_for(W, H, cull)   # 32 x 32 bins where the fused binning applies
+            ready = None
             if "views" in shared:
                 pv = shared["views"][j]
                 pose, kr, qb = pv.viewmat, pv.key_range, pv.qbox
                 splat, radii, tiles, keys, rects, aux = pv.splat, pv.radii, pv.tiles_touched, pv.depth_keys, pv.tile_rects, pv.sh_aux
+                ready = pv.records_ready
             else:
                 pose = view["pose"].to(torch.float32).contiguous()
                 kr = S.key_range_buffer(leaves[0].shape[0], dev)   # the view's depth-key range: the depth ordering plans its buckets from it
                 qb = S.qbox_buffer(leaves[0].shape[0], dev)        # the gaussians' quadrant boxes: the forward sweep's masks
+                forked = [] if S._SPLIT_PROJECTION else None   # (records part beside the binning chain: stages.project_fwd)
                 splat, radii, tiles, keys, rects, aux = S.project_fwd(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4],
                                                                       degree, pose, Kc, W, H, cull, return_rects=True,
-                                                                      return_aux=True, bin_tile=bt, key_range=kr, qbox=qb)
+                                                                      return_aux=True, bin_tile=bt, key_range=kr, qbox=qb,
+                                                                      records_ready=forked)
+                ready = forked[0] if forked else None
             bins = S.bin_tiles(splat, radii, tiles, keys, W, H, cull, tile_rects=rects, exact=exact, bin_tile=bt,
                                key_range=kr, qbox=qb, speculation=self._pipe.speculation)
             order = S.tile_schedule(bins, W, H, bt)
+            if ready is not None:   # the splat records (written on the projection side stream) are read from here on
+                torch.cuda.current_stream().wait_event(ready)
             return pose, splat, radii, bins, order, aux
 
         def forward(j, deferred):

@@ -57,18 +57,26 @@ class _RasterizeOneCamera(torch.autograd.Function):
             splat, radii, tiles_touched = projection.splat, projection.radii, projection.tiles_touched
             depth_keys, rects = projection.depth_keys, projection.tile_rects
             sh_aux = projection.sh_aux if want_lists else None
+            records_ready = projection.records_ready
         else:
             kr = S.key_range_buffer(means_c.shape[0], means_c.device)   # this view's depth-key range, for the depth ordering's bucket plan
             qb = S.qbox_buffer(means_c.shape[0], means_c.device)        # the gaussians' quadrant boxes, for the forward sweep's candidate test
+            # the projection in two launches: what the binning needs on this stream, the splat records (which stream the
+            # 192-B coefficient rows) on a side stream beside the binning chain -- joined in front of the sweep
+            forked = [] if S._SPLIT_PROJECTION else None
             proj = S.project_fwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
-                                 cull_mode, return_rects=True, return_aux=want_lists, bin_tile=bt, key_range=kr, qbox=qb)
+                                 cull_mode, return_rects=True, return_aux=want_lists, bin_tile=bt, key_range=kr, qbox=qb,
+                                 records_ready=forked)
             splat, radii, tiles_touched, depth_keys, rects = proj[:5]
             sh_aux = proj[5] if want_lists else None
+            records_ready = forked[0] if forked else None
         # the host does not wait for the record count: bins are sized for a remembered capacity, the compositor is
         # queued, and only then is the count (long since copied back) checked -- a miss repeats with exact sizes
         bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, tile_rects=rects,
                            bin_tile=bt, key_range=kr, qbox=qb, speculation=speculation)
         tile_order = S.tile_schedule(bins, width, height, bt)   # longest record lists first (speed only)
+        if records_ready is not None:   # (the records part of a split projection: everything below reads the splat records)
+            torch.cuda.current_stream().wait_event(records_ready)
         out = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bg_c, width, height, channels,
                               tile_order, want_lists=want_lists, bin_tile=bt, gid_boxes=bins.boxed)
         if deferred is not None:

@@ -45,8 +45,9 @@ class StageTimer:
 TIMER = StageTimer()
 
 
-def _call(name: str, fn, *args) -> None:
-    """Launch one C-ABI stage on the current stream; raise on a non-zero return code."""
+def _call(name: str, fn, *args, on=None) -> None:
+    """Launch one C-ABI stage on the current stream; raise on a non-zero return code.  ``on``: the torch stream the caller
+    passed to the stage instead of the current one (the timer's events are then recorded there)."""
     held, _GUARD.held = getattr(_GUARD, "held", None), None        # (the tensors behind THIS call's pointers: consumed, never sticky)
     guard = held[-1].device.index if held else None                 # (one of them speaks for all: a stage's tensors share a device)
     if guard is not None and torch.cuda.current_device() != guard:
@@ -55,11 +56,11 @@ def _call(name: str, fn, *args) -> None:
                            "torch.cuda.set_device(tensor.device) (one process per GPU) or use torch.cuda.device(...)")
     if TIMER.enabled:
         start = torch.cuda.Event(enable_timing=True)
-        start.record()
+        start.record(on) if on is not None else start.record()
     check(fn(*args), name)
     if TIMER.enabled:
         end = torch.cuda.Event(enable_timing=True)
-        end.record()
+        end.record(on) if on is not None else end.record()
         TIMER.records.append((name, start, end))
     del held   # only now: the launch is queued, the caching allocator hands the memory out again in stream order
 
@@ -231,9 +232,39 @@ def _wait_slot_impl(slot) -> None:
 _SH_AUX = True
 
 
+PROJECT_GEOMETRY, PROJECT_RECORDS = 1, 2   # gsa_project_fwd_parts
+# The projection of a view in two launches (r05): the GEOMETRY part (what the binning reads: 44 B in, 28 B out per gaussian) on
+# the caller's stream and the RECORDS part (the splat records with the colours and the coefficient digests: what the sweeps
+# read; it streams the 192-B coefficient rows) on a side stream BESIDE the view's binning chain, which is latency-bound and
+# leaves the HBM idle.  The caller's stream waits for the records in front of its forward sweep (``records_ready``).
+# GSPLAT_AMD_SPLIT_PROJECTION=0: one launch on the caller's stream, as before (A/B).
+_SPLIT_PROJECTION = os.environ.get("GSPLAT_AMD_SPLIT_PROJECTION", "1") != "0"
+_PROJ_STREAMS = {}
+
+
+def projection_stream(dev) -> torch.cuda.Stream:
+    """The side stream the records part of a split projection runs on (one per device and process)."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    st = _PROJ_STREAMS.get(key)
+    if st is None:
+        st = _PROJ_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def _fork_records(dev):
+    """-> the side stream, made to wait for everything queued on the current stream so far (the parameters it reads, and
+    whatever still uses the memory the caching allocator has just handed out for its outputs)."""
+    side = projection_stream(dev)
+    here = torch.cuda.Event()
+    here.record()
+    side.wait_event(here)
+    return side
+
+
 def project_fwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat, Kmat, width: int, height: int,
                 cull_mode: int = 0, return_rects: bool = False, return_aux: bool = False, bin_tile: int = TILE_SIZE,
-                key_range: Optional[torch.Tensor] = None, qbox: Optional[torch.Tensor] = None):
+                key_range: Optional[torch.Tensor] = None, qbox: Optional[torch.Tensor] = None,
+                records_ready: Optional[list] = None):
     """-> splat [N,16], radii [N,2] i32, tiles_touched [N] i32, depth_keys [N] (uint32 bits in int32 storage)
     [, tile_rects [N,2] i32: (packed tile rectangle, record count) pairs the fused binning reads, with
     ``return_rects`` -- in tiles of ``bin_tile`` pixels: 16, or 32 for ``bin_tiles(..., bin_tile=32)``]
@@ -241,7 +272,11 @@ def project_fwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat
     ``project_bwd`` skip the rows, with ``return_aux``].
     ``key_range``: a ``key_range_buffer`` that receives the view's depth-key range (for ``bin_tiles(key_range=...)``).
     ``qbox``: an int32 [N] tensor that receives every gaussian's quadrant bounding box (for ``bin_tiles(qbox=...)``: the
-    forward compositor's per-record quadrant masks)."""
+    forward compositor's per-record quadrant masks).
+    ``records_ready`` (a list): SPLIT the stage -- ``splat`` and ``sh_aux`` are written by a launch on the projection side
+    stream, everything else by a launch on the current stream (which may go straight on to ``bin_tiles``); the list receives
+    ONE event, and the caller makes its stream wait for it (``torch.cuda.current_stream().wait_event``) before anything reads
+    ``splat`` / ``sh_aux``.  Same bits as the one-launch stage."""
     dev, N = means.device, means.shape[0]
     sh_coeffs = colors.shape[1] if sh_degree >= 0 else 0
     splat = torch.empty(N, SPLAT_STRIDE, dtype=torch.float32, device=dev)
@@ -250,10 +285,23 @@ def project_fwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat
     depth_keys = torch.empty(N, dtype=torch.int32, device=dev)
     tile_rects = torch.empty(N, 2, dtype=torch.int32, device=dev) if return_rects else None
     sh_aux = torch.empty(N, 12, dtype=torch.float32, device=dev) if (return_aux and sh_degree >= 1 and _SH_AUX) else None
-    _call("gsa_project_fwd", lib.gsa_project_fwd, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
-          _ptr(colors), sh_degree, sh_coeffs, _ptr(viewmat), _ptr(Kmat), width, height, cull_mode, _ptr(splat),
-          _ptr(radii), _ptr(tiles_touched), _ptr(depth_keys), _ptr(tile_rects), _ptr(sh_aux), bin_tile, _ptr(key_range),
-          _ptr(qbox), _stream())
+    if records_ready is not None and N > 0:
+        side = _fork_records(dev)
+        _call("gsa_project_fwd_records", lib.gsa_project_fwd_parts, PROJECT_RECORDS, N, _ptr(means), _ptr(quats), _ptr(scales),
+              _ptr(opacities), _ptr(colors), sh_degree, sh_coeffs, 1, _ptr(viewmat), _ptr(Kmat), 0, width, height, cull_mode,
+              _ptr(splat), None, None, None, None, _ptr(sh_aux), bin_tile, None, None, side.cuda_stream, on=side)
+        done = torch.cuda.Event()
+        done.record(side)
+        records_ready.append(done)
+        _call("gsa_project_fwd", lib.gsa_project_fwd_parts, PROJECT_GEOMETRY, N, _ptr(means), _ptr(quats), _ptr(scales),
+              _ptr(opacities), None, sh_degree, sh_coeffs, 1, _ptr(viewmat), _ptr(Kmat), 0, width, height, cull_mode,
+              None, _ptr(radii), _ptr(tiles_touched), _ptr(depth_keys), _ptr(tile_rects), None, bin_tile, _ptr(key_range),
+              _ptr(qbox), _stream())
+    else:
+        _call("gsa_project_fwd", lib.gsa_project_fwd, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
+              _ptr(colors), sh_degree, sh_coeffs, _ptr(viewmat), _ptr(Kmat), width, height, cull_mode, _ptr(splat),
+              _ptr(radii), _ptr(tiles_touched), _ptr(depth_keys), _ptr(tile_rects), _ptr(sh_aux), bin_tile, _ptr(key_range),
+              _ptr(qbox), _stream())
     out = (splat, radii, tiles_touched, depth_keys)
     if return_rects:
         out += (tile_rects,)
@@ -267,7 +315,7 @@ class ViewProjection:
     a key range and quadrant boxes): what the binning, the sweeps and ``project_bwd`` of that view need."""
 
     __slots__ = ("splat", "radii", "tiles_touched", "depth_keys", "tile_rects", "sh_aux", "key_range", "qbox", "viewmat",
-                 "Kmat", "bin_tile", "dims", "defer_backward", "v_splat", "made_from", "camera_stamp")
+                 "Kmat", "bin_tile", "dims", "defer_backward", "v_splat", "made_from", "camera_stamp", "records_ready")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -281,11 +329,14 @@ def input_stamp(*tensors):
 
 
 def project_views(means, quats, scales, opacities, colors, sh_degree: int, viewmats, Kmats, width: int, height: int,
-                  cull_mode: int = 0, return_aux: bool = False, bin_tile: Optional[int] = None):
+                  cull_mode: int = 0, return_aux: bool = False, bin_tile: Optional[int] = None, split: Optional[bool] = None):
     """The gaussians projected for the C cameras of ``viewmats`` [C,4,4] in ONE launch (``gsa_project_fwd_batch``): geometry
     and coefficient rows are read once for all cameras -- the views of an optimisation step share them.  ``Kmats``: [C,3,3],
     or one [3,3] matrix for all cameras.  -> C ``ViewProjection``s whose tensors are the per-camera slabs of [C, ...]
-    buffers; each holds the same bits ``project_fwd`` with that camera writes."""
+    buffers; each holds the same bits ``project_fwd`` with that camera writes.
+    ``split`` (default: the module's ``_SPLIT_PROJECTION``): the records part (``splat``, ``sh_aux``) on the projection side
+    stream, the geometry part on the current stream -- every returned projection then carries ``records_ready``, the event a
+    stream waits for before it reads those two (``rasterization(projection=...)`` and the harness do)."""
     dev, N = means.device, means.shape[0]
     C = int(viewmats.shape[0])
     if viewmats.shape != (C, 4, 4) or Kmats.shape not in ((C, 3, 3), (3, 3)):
@@ -301,15 +352,30 @@ def project_views(means, quats, scales, opacities, colors, sh_degree: int, viewm
     key_range = torch.empty(C, (N + 63) // 64, 4, dtype=torch.int32, device=dev)
     qbox = torch.empty(C, N, dtype=torch.int32, device=dev) if _QUAD_BOXES else None
     vm, km = f32c(viewmats, "viewmats"), f32c(Kmats, "Ks")
-    _call("gsa_project_fwd", lib.gsa_project_fwd_batch, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
-          _ptr(colors), sh_degree, sh_coeffs, C, _ptr(vm), _ptr(km), 9 if km.dim() == 3 else 0, width, height, cull_mode,
-          _ptr(splat), _ptr(radii), _ptr(tiles_touched), _ptr(depth_keys), _ptr(tile_rects), _ptr(sh_aux), bt,
-          _ptr(key_range), _ptr(qbox), _stream())
+    stride = 9 if km.dim() == 3 else 0
+    done = None
+    if (_SPLIT_PROJECTION if split is None else split) and N > 0:
+        side = _fork_records(dev)
+        _call("gsa_project_fwd_records", lib.gsa_project_fwd_parts, PROJECT_RECORDS, N, _ptr(means), _ptr(quats), _ptr(scales),
+              _ptr(opacities), _ptr(colors), sh_degree, sh_coeffs, C, _ptr(vm), _ptr(km), stride, width, height, cull_mode,
+              _ptr(splat), None, None, None, None, _ptr(sh_aux), bt, None, None, side.cuda_stream, on=side)
+        done = torch.cuda.Event()
+        done.record(side)
+        _call("gsa_project_fwd", lib.gsa_project_fwd_parts, PROJECT_GEOMETRY, N, _ptr(means), _ptr(quats), _ptr(scales),
+              _ptr(opacities), None, sh_degree, sh_coeffs, C, _ptr(vm), _ptr(km), stride, width, height, cull_mode,
+              None, _ptr(radii), _ptr(tiles_touched), _ptr(depth_keys), _ptr(tile_rects), None, bt, _ptr(key_range),
+              _ptr(qbox), _stream())
+    else:
+        _call("gsa_project_fwd", lib.gsa_project_fwd_batch, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
+              _ptr(colors), sh_degree, sh_coeffs, C, _ptr(vm), _ptr(km), stride, width, height, cull_mode,
+              _ptr(splat), _ptr(radii), _ptr(tiles_touched), _ptr(depth_keys), _ptr(tile_rects), _ptr(sh_aux), bt,
+              _ptr(key_range), _ptr(qbox), _stream())
     return [ViewProjection(splat=splat[c], radii=radii[c], tiles_touched=tiles_touched[c], depth_keys=depth_keys[c],
                            tile_rects=tile_rects[c], sh_aux=None if sh_aux is None else sh_aux[c], key_range=key_range[c],
                            qbox=None if qbox is None else qbox[c], viewmat=vm[c], Kmat=km[c] if km.dim() == 3 else km,
                            bin_tile=bt, dims=(width, height, cull_mode, sh_degree), defer_backward=False, v_splat=None,
-                           made_from=None, camera_stamp=input_stamp(vm[c], km[c] if km.dim() == 3 else km))
+                           made_from=None, camera_stamp=input_stamp(vm[c], km[c] if km.dim() == 3 else km),
+                           records_ready=done)
             for c in range(C)]
 
 

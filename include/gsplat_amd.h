@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSA_ABI_VERSION 12
+#define GSA_ABI_VERSION 13
 #define GSA_SPLAT_STRIDE 16
 
 #define GSA_OK 0
@@ -109,6 +109,25 @@ int gsa_project_fwd(int n, const float *means, const float *quats, const float *
  * starts c * n rows in; key_range: c * 4 * ceil(n / 64) words in); optional outputs as there.  Camera c's slabs hold the
  * same bits a gsa_project_fwd call with camera c writes. */
 int gsa_project_fwd_batch(int n, const float *means, const float *quats, const float *scales,
+                          const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
+                          int n_cams, const float *viewmats, const float *intrins, int intrin_stride, int width,
+                          int height, int cull_mode, float *splat, int32_t *radii, int32_t *tiles_touched,
+                          uint32_t *depth_keys, uint32_t *tile_rects, float *sh_aux, int bin_tile,
+                          uint32_t *key_range, uint32_t *qbox, gsa_stream_t stream);
+
+/* ABI 13 -- the stage in PARTS, for callers that overlap them (n_cams >= 1; arguments as gsa_project_fwd_batch; n_cams = 1 with
+ * intrin_stride 0 is gsa_project_fwd).
+ *   GSA_PROJECT_GEOMETRY: only what the BINNING reads -- radii, tiles_touched, depth_keys, tile_rects, key_range, qbox
+ *       (44 B in, 28 B out per gaussian and camera; colors / splat / sh_aux are not touched and may be NULL);
+ *   GSA_PROJECT_RECORDS:  only what the SWEEPS and stage 5 read -- splat (with the colour) and sh_aux (the six geometry
+ *       outputs are not touched and may be NULL);
+ *   GSA_PROJECT_GEOMETRY | GSA_PROJECT_RECORDS: the whole stage.
+ * Each part recomputes the projection from the inputs, so the two launches are independent: the records part (which streams
+ * the 192-B coefficient rows) can run on a second stream beside the latency-bound binning chain of the same view, which only
+ * waits for the short geometry part.  Together the parts write the bits the whole stage writes. */
+#define GSA_PROJECT_GEOMETRY 1
+#define GSA_PROJECT_RECORDS 2
+int gsa_project_fwd_parts(int parts, int n, const float *means, const float *quats, const float *scales,
                           const float *opacities, const float *colors, int sh_degree, int sh_coeffs,
                           int n_cams, const float *viewmats, const float *intrins, int intrin_stride, int width,
                           int height, int cull_mode, float *splat, int32_t *radii, int32_t *tiles_touched,

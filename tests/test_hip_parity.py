@@ -505,6 +505,45 @@ def test_multi_camera_projection_equals_single_camera_launches(gsa, n, deg, shar
             assert torch.equal(v.qbox[vis], qb[vis]), c
 
 
+@pytest.mark.parametrize("n,deg,cams", [(5000, 3, 1), (777, 2, 1), (4097, 1, 3), (3000, 0, 2), (1234, -1, 1), (70_001, 3, 4)])
+def test_split_projection_parts_equal_the_whole_stage(gsa, n, deg, cams):
+    """``gsa_project_fwd_parts`` (ABI 13): the GEOMETRY part (what the binning reads) and the RECORDS part (splat records +
+    coefficient digests, launched on the projection side stream beside the binning) together write the bits the one-launch
+    stage writes -- single camera (``project_fwd(records_ready=...)``) and the per-step launch (``project_views(split=True)``)."""
+    from gsplat_amd import scene, stages as S
+    W, H = 640, 360
+    sc = _scene(n, seed=n % 97)
+    means, quats, scales = sc["means3D"].cuda(), sc["rotations"].cuda(), sc["scales"].cuda()
+    opac = sc["opacities"][:, 0].contiguous().cuda()
+    colors = sc["shs"].cuda() if deg >= 0 else (sc["shs"][:, 0, :] * 0.28 + 0.5).contiguous().cuda()
+    vms = torch.stack([scene.make_camera(k, 7) for k in range(cams)]).cuda()
+    K = scene.make_intrinsics(W, H).cuda()
+    bt = S.bin_tile_for(W, H, 0)
+    if cams == 1:
+        def run(split):
+            kr, qb = S.key_range_buffer(n, means.device), S.qbox_buffer(n, means.device)
+            forked = [] if split else None
+            out = S.project_fwd(means, quats, scales, opac, colors, deg, vms[0], K, W, H, 0, return_rects=True, return_aux=True,
+                                bin_tile=bt, key_range=kr, qbox=qb, records_ready=forked)
+            if split:
+                assert len(forked) == 1
+                torch.cuda.current_stream().wait_event(forked[0])
+            return [t for t in out if t is not None] + [kr, qb]
+        whole, parts = run(False), run(True)
+    else:
+        def run(split):
+            views = S.project_views(means, quats, scales, opac, colors, deg, vms, K, W, H, 0, return_aux=True, split=split)
+            assert (views[0].records_ready is not None) == split
+            if split:
+                torch.cuda.current_stream().wait_event(views[0].records_ready)
+            return [getattr(v, f) for v in views for f in ("splat", "radii", "tiles_touched", "depth_keys", "tile_rects", "sh_aux",
+                                                           "key_range", "qbox") if getattr(v, f) is not None]
+        whole, parts = run(False), run(True)
+    assert len(whole) == len(parts)
+    for a, b in zip(whole, parts):
+        assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a, b.view(torch.int32) if b.dtype == torch.float32 else b)
+
+
 @pytest.mark.parametrize("n,deg,accumulate,shared_k", [(5000, 3, False, True), (777, 2, True, False), (4097, 1, False, True),
                                                        (100_003, 3, True, True)])
 def test_multi_camera_projection_backward_equals_the_accumulating_launches(gsa, n, deg, accumulate, shared_k):
@@ -932,9 +971,8 @@ def test_two_backends_of_equal_frame_size_do_not_share_speculation(gsa):
                 st[k] = 0
         for _ in range(3):
             for vm_a, vm_b in zip(cams_a, cams_b):
-                ra = view(a, pa, vm_a)
+                view(a, pa, vm_a)
                 view(b, pb, vm_b)
-        again = view(a, pa, cams_a[0])["render"]
     assert a.speculation.repairs["views"] == 18 and b.speculation.repairs["views"] == 18
     assert a.speculation.repairs["capacity_misses"] == 0 and a.speculation.repairs["key_range_repairs"] == 0, a.speculation.repairs
     assert b.speculation.repairs["capacity_misses"] == 0, b.speculation.repairs
@@ -942,6 +980,8 @@ def test_two_backends_of_equal_frame_size_do_not_share_speculation(gsa):
     assert ka[:2] != kb[:2] and (kb[1] - kb[0]) > 4 * (ka[1] - ka[0])       # each remembers ITS cameras' depth range
     assert a.speculation.capacity[key][0] < 0.5 * b.speculation.capacity[key][0]   # ... and ITS records per gaussian
     assert key not in S.DEFAULT_SPECULATION.capacity and key not in S.DEFAULT_SPECULATION.key_range
+    with torch.no_grad():
+        again = view(a, pa, cams_a[0])["render"]
     assert torch.equal(again, alone[0])
 
 
