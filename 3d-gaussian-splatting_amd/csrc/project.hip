@@ -137,7 +137,12 @@ __global__ __launch_bounds__(kBlock, (BATCH ? GSA_PROJ_BATCH_WAVES : GSA_PROJ_FW
     // a training loop is the previous view's project_bwd, which streamed the same parameter arrays front to back -- the
     // 256-MB memory-side cache then still holds the rows of the last ~0.45 M gaussians, and reading those first hits
     // them before this kernel's own traffic pushes them out (front to back they would be gone by the time it got there).
-    const long blk = GSA_PROJ_FWD_REVERSE ? (long)gridDim.x - 1 - blockIdx.x : (long)blockIdx.x;
+    // (the records part may be launched with FEWER workgroups than blocks of gaussians -- a low-occupancy stream beside the
+    // binning chain of the same view, which needs the CUs' LDS: every workgroup then walks the blocks gridDim.x apart)
+    const long n_blk = ((long)n + kBlock - 1) / kBlock;
+    for (long blk_i = blockIdx.x; blk_i < (PART == kPartRecords ? n_blk : (long)blockIdx.x + 1); blk_i += gridDim.x) {
+    if (PART == kPartRecords && blk_i != (long)blockIdx.x) wave_lds_sync();   // (the wave's LDS image: the previous block's stores have read it)
+    const long blk = GSA_PROJ_FWD_REVERSE ? n_blk - 1 - blk_i : blk_i;
     const long i = blk * kBlock + threadIdx.x;
 
     // geometry first: these loads are in flight while the SH rows are staged (one memory round trip per wave less;
@@ -371,6 +376,7 @@ __global__ __launch_bounds__(kBlock, (BATCH ? GSA_PROJ_BATCH_WAVES : GSA_PROJ_FW
         if (qbox) qbox[i] = qb;
     }
     }   // cameras
+    }   // blocks of this workgroup
 }
 
 // The chain rule of the projection for ONE gaussian and ONE camera: the sweep's raw moments (v0, v1, v2: the gradient
@@ -855,7 +861,7 @@ int launch_fwd(bool stage, int n, const float *means, const float *quats, const 
                const float *opacities, const float *colors, int sh_coeffs, const float *viewmat,
                const float *intrin, int n_cams, int intrin_stride, int width, int height, int cull_mode, float *splat,
                int32_t *radii, int32_t *tiles_touched, uint32_t *depth_keys, uint32_t *tile_rects, float *sh_aux,
-               int bin_tile, uint32_t *key_range, uint32_t *qbox, int parts, hipStream_t s) {
+               int bin_tile, uint32_t *key_range, uint32_t *qbox, int parts, hipStream_t s, int records_blocks = 0) {
     int tile_w = gsa_div_up(width, GSA_TILE_SIZE), tile_h = gsa_div_up(height, GSA_TILE_SIZE);
     dim3 grid(gsa_div_up(n, kBlock)), block(kBlock);
 #define GSA_FWD_LAUNCH(ST, BA, PA)                                                                                     \
@@ -864,6 +870,7 @@ int launch_fwd(bool stage, int n, const float *means, const float *quats, const 
                                                            cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects,   \
                                                            sh_aux, bin_tile, key_range, qbox)
     if (parts == kPartRecords) {
+        if (records_blocks > 0 && (int)grid.x > records_blocks) grid.x = (unsigned)records_blocks;
         if (n_cams > 1) {
             if (stage) GSA_FWD_LAUNCH(true, true, kPartRecords); else GSA_FWD_LAUNCH(false, true, kPartRecords);
         } else {
@@ -927,6 +934,9 @@ static int project_fwd_impl(int n, const float *means, const float *quats, const
                             gsa_stream_t stream, int parts = kPartBoth) {
     GSA_RETURN_IF(n < 0 || width <= 0 || height <= 0 || n_cams < 1 || (intrin_stride != 0 && intrin_stride != 9),
                   GSA_ERR_INVALID_ARGUMENT);
+    const bool no_stage = (parts & 4) != 0;   // (developer A/B: the records part without the LDS row staging)
+    const int records_blocks = parts >> 8;     // (bits 8..: workgroups of a low-occupancy records launch; 0 = one per block of gaussians)
+    parts &= 3;
     GSA_RETURN_IF(parts != kPartGeometry && parts != kPartRecords && parts != kPartBoth, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_degree < -1 || sh_degree > 3, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(sh_degree >= 0 && sh_coeffs < (sh_degree + 1) * (sh_degree + 1), GSA_ERR_INVALID_ARGUMENT);
@@ -958,11 +968,11 @@ static int project_fwd_impl(int n, const float *means, const float *quats, const
         return GSA_OK;
     }
     // degree 0 needs 12 B of each 192-B row: direct loads beat staging whole rows
-    bool stage = can_stage(colors, sh_degree, sh_coeffs) && sh_degree >= 1;
+    bool stage = can_stage(colors, sh_degree, sh_coeffs) && sh_degree >= 1 && !no_stage;
 #define GSA_FWD(D)                                                                                                      \
     return launch_fwd<D>(stage, n, means, quats, scales, opacities, colors, sh_coeffs, viewmat, intrin, n_cams,         \
                          intrin_stride, width, height, cull_mode, splat, radii, tiles_touched, depth_keys, tile_rects, \
-                         sh_aux, bin_tile, key_range, qbox, parts, s)
+                         sh_aux, bin_tile, key_range, qbox, parts, s, records_blocks)
     switch (sh_degree) {
         case -1: GSA_FWD(-1);
         case 0: GSA_FWD(0);

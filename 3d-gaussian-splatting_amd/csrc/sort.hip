@@ -618,6 +618,112 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     SORT_TRACE_END(sizeof(KeyT) == 2 ? 1 : 0);
 }
 
+// ---- pass 3 for LARGE inputs (r05): the same stable scatter on 22 KB of LDS instead of 38 ---------------------------------
+// radix_scatter_kernel stages a block's keys AND values (2 x 16 KB) for the reorder: four blocks a CU, 1024 on the chip -- and
+// the depth sort of 5 M gaussians (BASELINE C5; the reference reports "~5.5M gaussians", src/training/trainer.py:92-96) has
+// 1221 blocks: a second round of workgroups for the last fifth of them, 61.9 us per pass = 0.16 of the HBM peak
+// (profiles/r04_c5_summary.md).  This instance reorders through ONE 16-KB buffer, keys first, values second: the
+// destination of a block-sorted slot comes from a 4-KB
+// digit image it leaves beside the buffer, so a round is stage -> barrier -> sixteen coalesced runs of stores.  Six blocks a
+// CU (1536 on the chip), two barriers more per block.  32-bit keys; same output, bit for bit (same ranks, same destinations).
+__global__ __launch_bounds__(kSortThreads, 5) void radix_scatter_compact_kernel(
+    int n, const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
+    uint32_t *__restrict__ vals_out, int shift, int nblocks, const uint32_t *__restrict__ hist,
+    const uint32_t *__restrict__ digit_total, const uint2 *__restrict__ pairs, uint32_t *__restrict__ pair_x_out,
+    uint32_t *__restrict__ pair_y_out) {
+    __shared__ uint32_t scratch[4];
+    __shared__ uint32_t gbase[kRadix];        // global slot of this block's first item of digit d
+    __shared__ uint32_t lexcl[kRadix];        // slot of that item in the block-sorted order
+    __shared__ uint32_t wave_cnt[4][kRadix];  // items of digit d wave w has ranked so far; then: its first block-sorted slot
+    __shared__ __attribute__((aligned(16))) uint32_t s_buf[kSortChunk];   // peer masks while ranking; then keys; then values
+    __shared__ uint8_t s_dig[kSortChunk];     // digit of the item in block-sorted slot lp
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const unsigned blk = sort_block_id();
+    if ((long)blk * kSortChunk >= n) return;
+    const RadixDigit dg{shift, 0u, 0, nullptr, nullptr, 0u};
+    const long base = (long)blk * kSortChunk + wave * (kSortChunk / 4);
+    uint32_t k[kSortItems], v[kSortItems], rk[kSortItems];
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const long i = base + r * 64 + lane;
+        k[r] = i < n ? keys_in[i] : 0xFFFFFFFFu;
+        v[r] = i < n ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
+    }
+    {
+        uint32_t tot, dt = digit_total[t];
+        const uint32_t mine = hist[(long)t * nblocks + blk];
+        const uint32_t next = (int)blk + 1 < nblocks ? hist[(long)t * nblocks + blk + 1] : dt;
+        const uint32_t dbase = block_excl_scan(dt, scratch, tot);
+        const uint32_t lbase = block_excl_scan(next - mine, scratch, tot);
+        gbase[t] = dbase + mine;
+        lexcl[t] = lbase;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            wave_cnt[w][t] = 0;
+            reinterpret_cast<unsigned long long *>(s_buf)[w * kRadix + t] = 0ull;
+        }
+    }
+    __syncthreads();
+    uint32_t *cnt = wave_cnt[wave];
+    unsigned long long *mask = reinterpret_cast<unsigned long long *>(s_buf) + wave * kRadix;
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r)
+        rk[r] = wave_rank_round(mask, cnt, digit_of(k[r], dg), base + r * 64 + lane < n, lane);
+    __syncthreads();
+    {
+        const uint32_t c0 = wave_cnt[0][t], c1 = wave_cnt[1][t], c2 = wave_cnt[2][t], o = lexcl[t];
+        wave_cnt[0][t] = o; wave_cnt[1][t] = o + c0; wave_cnt[2][t] = o + c0 + c1; wave_cnt[3][t] = o + c0 + c1 + c2;
+    }
+    __syncthreads();
+    // block-sorted slot of every item (kept in rk), its digit into the digit image, its key into the buffer
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        if (base + r * 64 + lane < n) {
+            const uint32_t d = digit_of(k[r], dg);
+            rk[r] = cnt[d] + rk[r];
+            s_dig[rk[r]] = (uint8_t)d;
+            s_buf[rk[r]] = k[r];
+        }
+    }
+    __syncthreads();
+    const int m = (int)min((long)kSortChunk, (long)n - (long)blk * kSortChunk);
+    // (the destination of slot lp is recomputed in both rounds from the digit image -- three LDS reads -- rather than kept in
+    // sixteen registers: the kernel has to stay within six waves' register budget to use the LDS it saves)
+    if (keys_out) {
+#pragma unroll 4
+        for (int r = 0; r < kSortItems; ++r) {
+            const int lp = r * kSortThreads + t;
+            if (lp < m) {
+                const uint32_t d = s_dig[lp];
+                keys_out[gbase[d] + ((uint32_t)lp - lexcl[d])] = s_buf[lp];
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r)
+        if (base + r * 64 + lane < n) s_buf[rk[r]] = v[r];
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < kSortItems; ++r) {
+        const int lp = r * kSortThreads + t;
+        if (lp < m) {
+            const uint32_t d = s_dig[lp];
+            const uint32_t pos = gbase[d] + ((uint32_t)lp - lexcl[d]);
+            const uint32_t val = s_buf[lp];
+            vals_out[pos] = val;
+            if (pairs) {
+                const uint2 pr = pairs[val];
+                pair_x_out[pos] = pr.x;
+                pair_y_out[pos] = pr.y;
+            }
+        }
+    }
+}
+
+// blocks beyond which the compact scatter pays: radix_scatter_kernel's 38 KB fit four blocks a CU
+constexpr int kCompactScatterBlocks = 1024;
+
 // ---- exclusive scan of tiles_touched in depth order ------------------------------------------------
 constexpr int kScanItems = 4;
 constexpr int kScanChunk = kSortThreads * kScanItems;
@@ -661,8 +767,14 @@ __global__ __launch_bounds__(kSortThreads) void scan_reduce_kernel(int n, const 
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
+// ctl_host (optional; gsa_scan_tiles_sorted_report): the caller's pinned host slot -- this launch's ONE workgroup leaves the
+// count and the key range ctl[1..2] (written by an earlier launch of the stream) there and releases the caller's token into
+// word 3, as the bucketed depth ordering does: no 16-byte copy kernel and no event behind the scan.
 __global__ __launch_bounds__(kSortThreads) void scan_blocks_kernel(int nblocks, uint32_t *__restrict__ block_sums,
-                                                                   uint32_t *__restrict__ total_out) {
+                                                                   uint32_t *__restrict__ total_out,
+                                                                   const uint32_t *__restrict__ ctl = nullptr,
+                                                                   uint32_t *__restrict__ ctl_host = nullptr,
+                                                                   uint32_t token = 0u) {
     __shared__ uint32_t scratch[4];
     uint32_t carry = 0;
     for (int base = 0; base < nblocks; base += kSortThreads) {
@@ -673,7 +785,16 @@ __global__ __launch_bounds__(kSortThreads) void scan_blocks_kernel(int nblocks, 
         if (i < nblocks) block_sums[i] = carry + ex;
         carry += total;
     }
-    if (threadIdx.x == 0) *total_out = carry;
+    if (threadIdx.x == 0) {
+        *total_out = carry;
+        if (ctl_host) {
+            ctl_host[0] = carry;
+            ctl_host[1] = ctl[1];
+            ctl_host[2] = ctl[2];
+            __threadfence_system();
+            __hip_atomic_store(&ctl_host[3], token << 8, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // in place: offsets[] holds the depth-ordered counts on entry (scan_reduce_kernel), their exclusive prefix on exit
@@ -1509,12 +1630,17 @@ extern "C" int gsa_sort_pairs_u32_dev(int capacity, const uint32_t *n_dev, const
 
 static int scan_tiles_impl(int n, const int32_t *tiles_touched, const uint32_t *order, const uint2 *tile_rects,
                            uint32_t *offsets, uint32_t *rects, int32_t *block_owner, int n_owner_blocks,
-                           uint32_t *total, void *workspace, size_t workspace_bytes, gsa_stream_t stream) {
+                           uint32_t *total, void *workspace, size_t workspace_bytes, gsa_stream_t stream,
+                           const uint32_t *ctl = nullptr, uint32_t *ctl_host = nullptr, uint32_t token = 0u) {
     GSA_RETURN_IF(n < 0, GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(!total, GSA_ERR_INVALID_ARGUMENT);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (n == 0) {
         hipError_t e = hipMemsetAsync(total, 0, sizeof(uint32_t), s);
+        if (ctl_host) {   // (no kernel runs: the host slot -- host memory -- is filled right here)
+            ctl_host[0] = 0u; ctl_host[1] = 0xFFFFFFFFu; ctl_host[2] = 0u;
+            __atomic_store_n(&ctl_host[3], token << 8, __ATOMIC_RELEASE);
+        }
         return (int)e;
     }
     GSA_RETURN_IF(!offsets || !workspace, GSA_ERR_INVALID_ARGUMENT);
@@ -1524,7 +1650,7 @@ static int scan_tiles_impl(int n, const int32_t *tiles_touched, const uint32_t *
     int nblocks = gsa_div_up(n, kScanChunk);
     scan_reduce_kernel<<<nblocks, kSortThreads, 0, s>>>(n, tiles_touched, order, block_sums, offsets, tile_rects, rects);
     GSA_LAUNCH_CHECK();
-    scan_blocks_kernel<<<1, kSortThreads, 0, s>>>(nblocks, block_sums, total);
+    scan_blocks_kernel<<<1, kSortThreads, 0, s>>>(nblocks, block_sums, total, ctl, ctl_host, token);
     GSA_LAUNCH_CHECK();
     scan_final_kernel<<<nblocks, kSortThreads, 0, s>>>(n, block_sums, offsets, n_owner_blocks > 0 ? block_owner : nullptr,
                                                        n_owner_blocks, total);
@@ -1561,6 +1687,15 @@ extern "C" int gsa_scan_tiles_sorted(int n, uint32_t *counts_offsets, int32_t *b
 // 61 + 20 + 6 us for an 8-bit pass: with 4096 bins per block of 4096 keys the per-bin work of a block -- 16 KB of bases, 32 KB
 // of wave counters, the waves' first ranks -- is as large as the per-key work, and every key goes to a line of its own.
 // C5 binning 0.54 -> 0.65 ms.)
+extern "C" int gsa_scan_tiles_sorted_report(int n, uint32_t *counts_offsets, int32_t *block_owner, int n_blocks, uint32_t *ctl,
+                                            uint32_t *ctl_host, uint32_t token, void *workspace, size_t workspace_bytes,
+                                            gsa_stream_t stream) {
+    GSA_RETURN_IF(n_blocks < 0 || (n_blocks > 0 && !block_owner) || !ctl || !ctl_host || token > 0xFFFFFFu,
+                  GSA_ERR_INVALID_ARGUMENT);
+    return scan_tiles_impl(n, nullptr, nullptr, nullptr, counts_offsets, nullptr, block_owner, n_blocks, ctl, workspace,
+                           workspace_bytes, stream, ctl, ctl_host, token);
+}
+
 extern "C" size_t gsa_depth_order_workspace_bytes(int n) {
     if (n < 0) n = 0;
     // two key and two value ping-pong buffers, the per-block key ranges, the sort's histograms
@@ -1599,9 +1734,14 @@ extern "C" int gsa_depth_order(int n, const uint32_t *depth_keys, const uint32_t
         radix_scan_rows_kernel<<<kRadix, kSortThreads, 0, s>>>(nblocks, hist, digit_total, p == 0 ? block_range : nullptr,
                                                                p == 0 ? key_range : nullptr);
         GSA_LAUNCH_CHECK();
-        radix_scatter_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(
-            n, nullptr, kin, vin, kout, vout, RadixDigit{8 * p, 0u, 0, nullptr, nullptr, 0u}, nblocks, hist, digit_total,
-            last ? reinterpret_cast<const uint2 *>(tile_rects) : nullptr, last ? rects : nullptr, last ? counts : nullptr);
+        if (nblocks > kCompactScatterBlocks)   // (populations beyond ~4 M: more blocks than the 38-KB instance has slots)
+            radix_scatter_compact_kernel<<<nblocks, kSortThreads, 0, s>>>(
+                n, kin, vin, kout, vout, 8 * p, nblocks, hist, digit_total,
+                last ? reinterpret_cast<const uint2 *>(tile_rects) : nullptr, last ? rects : nullptr, last ? counts : nullptr);
+        else
+            radix_scatter_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(
+                n, nullptr, kin, vin, kout, vout, RadixDigit{8 * p, 0u, 0, nullptr, nullptr, 0u}, nblocks, hist, digit_total,
+                last ? reinterpret_cast<const uint2 *>(tile_rects) : nullptr, last ? rects : nullptr, last ? counts : nullptr);
         GSA_LAUNCH_CHECK();
         kin = kout;
         vin = vout;

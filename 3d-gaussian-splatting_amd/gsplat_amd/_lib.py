@@ -18,6 +18,30 @@ SPLAT_STRIDE = 16
 
 P = c_void_p  # every device pointer and the stream cross the boundary as void*
 
+
+class ViewArgs(ctypes.Structure):
+    """``gsa_view_args`` of include/gsplat_amd.h (ABI 13), field for field: the arguments of one view's fused forward /
+    backward chain (``gsa_view_fwd`` / ``gsa_view_bwd``)."""
+    _fields_ = [
+        ("struct_bytes", c_uint32),
+        ("n", c_int), ("width", c_int), ("height", c_int), ("channels", c_int), ("bin_tile", c_int), ("gid_boxes", c_int),
+        ("n_blocks", c_int),
+        ("m_capacity", c_uint32), ("key_min", c_uint32), ("scale", c_uint32), ("token", c_uint32),
+        ("splat", P), ("depth_keys", P), ("tile_rects", P), ("key_range", P), ("qbox", P), ("background", P),
+        ("order", P), ("rects", P), ("offsets", P), ("block_owner", P), ("ctl", P), ("ctl_host", P),
+        ("depth_ws", P), ("depth_ws_bytes", c_size_t),
+        ("sorted_gid", P), ("tile_offsets", P), ("tile_order", P), ("bin_ws", P), ("bin_ws_bytes", c_size_t),
+        ("wait_event", P),
+        ("render", P), ("alpha", P), ("final_T", P), ("last_id", P), ("quad_list", P), ("quad_count", P), ("v_splat", P),
+        ("v_render", P), ("v_alpha", P), ("bwd_tile_order", P),
+        ("project_mode", c_int), ("accumulate", c_int), ("sh_degree", c_int), ("sh_coeffs", c_int),
+        ("wait_bucket", P),
+        ("means", P), ("quats", P), ("scales", P), ("opacities", P), ("colors", P), ("viewmat", P), ("intrin", P), ("sh_aux", P),
+        ("radii", P),
+        ("v_means", P), ("v_quats", P), ("v_scales", P), ("v_opacities", P), ("v_colors", P), ("v_rgb", P),
+    ]
+
+
 # name -> (restype, argtypes); mirrors include/gsplat_amd.h one to one
 SIGNATURES = {
     "gsa_abi_version": (c_int, []),
@@ -44,6 +68,7 @@ SIGNATURES = {
     "gsa_depth_order_msd_table_words": (c_int, []),
     "gsa_depth_order_msd": (c_int, [c_int, P, P, c_uint32, c_uint32, P, P, P, P, P, c_int, P, P, c_uint32, P, c_size_t, P]),
     "gsa_scan_tiles_sorted": (c_int, [c_int, P, P, c_int, P, P, c_size_t, P]),
+    "gsa_scan_tiles_sorted_report": (c_int, [c_int, P, P, c_int, P, P, c_uint32, P, c_size_t, P]),
     "gsa_tile_bin16": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_uint32, P, P, P, P, P, P, P, P, c_size_t, P]),
     "gsa_tile_bin16_scheduled": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_uint32, P, P, P, P, P, P, P, c_size_t, P]),
     "gsa_tile_emit": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_uint32, P, P, P]),
@@ -63,6 +88,9 @@ SIGNATURES = {
     "gsa_adam_step_striped": (c_int, [c_longlong, P, P, P, P, c_int, P, P, P, P, P, c_double, c_double, c_double, c_int, P, P]),
     "gsa_grad_unscale": (c_int, [c_longlong, P, c_float, P, P]),
     "gsa_step_report": (c_int, [c_int, P, P, c_double, c_int, P, c_longlong, c_double, c_int, P, P]),
+    "gsa_view_args_size": (c_size_t, []),
+    "gsa_view_fwd": (c_int, [ctypes.POINTER(ViewArgs), P]),
+    "gsa_view_bwd": (c_int, [ctypes.POINTER(ViewArgs), P]),
     "gsa_project_bwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, P, P, P, P, P, P, P, P, P, P]),
     "gsa_project_bwd_factored": (c_int, [c_int, P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, P, P, P, P, P, P, P, P, c_int, P, P]),
     "gsa_project_bwd_batch": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P,
@@ -90,6 +118,9 @@ def _load() -> ctypes.CDLL:
     got = lib.gsa_abi_version()
     if got != ABI_VERSION:
         raise ImportError(f"gsplat_amd: library ABI {got} != binding ABI {ABI_VERSION}; rebuild the library")
+    if lib.gsa_view_args_size() != ctypes.sizeof(ViewArgs):
+        raise ImportError(f"gsplat_amd: gsa_view_args is {lib.gsa_view_args_size()} bytes in the library, "
+                          f"{ctypes.sizeof(ViewArgs)} in the binding; rebuild the library")
     return lib
 
 

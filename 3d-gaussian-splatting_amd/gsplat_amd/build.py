@@ -14,7 +14,7 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 CSRC = os.path.join(PKG_ROOT, "csrc")
 LIB_DIR = os.path.join(PKG_ROOT, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libgsplat_amd.so")
-SOURCES = ["abi.hip", "project.hip", "sort.hip", "composite.hip", "train_step.hip"]
+SOURCES = ["abi.hip", "project.hip", "sort.hip", "composite.hip", "train_step.hip", "view.hip"]
 # -fno-slp-vectorize: the SLP pass pairs scalar fp32 ops into v_pk_* forms; on gfx950 a packed fp32 op issues
 # at the cost of two scalar ones and the register shuffling around it (v_mov) is pure loss -- measured 8 % per step
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-fno-slp-vectorize", "-Wall",

@@ -232,7 +232,11 @@ def _wait_slot_impl(slot) -> None:
 _SH_AUX = True
 
 
-PROJECT_GEOMETRY, PROJECT_RECORDS = 1, 2   # gsa_project_fwd_parts
+# gsa_project_fwd_parts (developer A/B: GSPLAT_AMD_RECORDS_NOSTAGE=1 -- the records part without LDS row staging;
+# GSPLAT_AMD_RECORDS_BLOCKS=k -- its launch capped at k workgroups that walk the gaussians in strides)
+PROJECT_GEOMETRY = 1
+PROJECT_RECORDS = 2 | (4 if os.environ.get("GSPLAT_AMD_RECORDS_NOSTAGE") == "1" else 0) | \
+    (int(os.environ.get("GSPLAT_AMD_RECORDS_BLOCKS", "0")) << 8)
 # The projection of a view in two launches (r05): the GEOMETRY part (what the binning reads: 44 B in, 28 B out per gaussian) on
 # the caller's stream and the RECORDS part (the splat records with the colours and the coefficient digests: what the sweeps
 # read; it streams the 192-B coefficient rows) on a side stream BESIDE the view's binning chain, which is latency-bound and
@@ -793,15 +797,23 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
             _call("gsa_depth_order", lib.gsa_depth_order, N, _ptr(depth_keys), _ptr(tile_rects), key_bits, _ptr(order),
                   _ptr(rects), _ptr(offsets), _ptr(ctl[1:3]), _ptr(dws), dws_bytes, st)
 
-            def scan(capacity):   # the scan also notes the owner of every 4096-slot record block (+ the last owner)
+            def scan(capacity, report=None):   # the scan also notes the owner of every 4096-slot record block (+ the last owner)
                 n_blocks = 0 if capacity is None else (capacity + BIN_BLOCK - 1) // BIN_BLOCK
                 owner = torch.empty(n_blocks + 1, dtype=torch.int32, device=dev)
-                _call("gsa_scan_tiles", lib.gsa_scan_tiles_sorted, N, _ptr(offsets), _ptr(owner), n_blocks, _ptr(total),
-                      _ptr(ws), ws_bytes, st)
+                if report is not None:   # (steady state: the scan's middle launch leaves the control words in the pinned slot itself)
+                    _call("gsa_scan_tiles", lib.gsa_scan_tiles_sorted_report, N, _ptr(offsets), _ptr(owner), n_blocks, _ptr(ctl),
+                          ctypes.c_void_p(report[0].data_ptr()), report[2], _ptr(ws), ws_bytes, st)
+                else:
+                    _call("gsa_scan_tiles", lib.gsa_scan_tiles_sorted, N, _ptr(offsets), _ptr(owner), n_blocks, _ptr(total),
+                          _ptr(ws), ws_bytes, st)
                 return owner
 
             counts_copy = offsets.clone() if cap is None else None   # the scan is in place; a second scan needs the counts
-            block_owner = scan(cap)
+            if cap is not None:
+                m_host, m_event, pool = _pinned_scalar(dev)
+                m_host[3] = 0
+                slot = (m_host, m_event, _next_token(), pool)
+            block_owner = scan(cap, slot)
     else:
         _, order = sort_pairs(N, depth_keys, None, 0, 32)  # ties keep index order; culled gaussians sort last
         _call("gsa_scan_tiles", lib.gsa_scan_tiles, N, _ptr(tiles_touched), _ptr(order), _ptr(offsets), _ptr(total),

@@ -245,6 +245,13 @@ int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint32_t *tile_
                         size_t workspace_bytes, gsa_stream_t stream);
 int gsa_scan_tiles_sorted(int n, uint32_t *counts_offsets, int32_t *block_owner, int n_blocks, uint32_t *total,
                           void *workspace, size_t workspace_bytes, gsa_stream_t stream);
+/* ABI 13 -- gsa_scan_tiles_sorted behind gsa_depth_order(key_range = ctl + 1) that also REPORTS like gsa_depth_order_msd: ctl[0]
+ * = M, and the single workgroup of its middle launch stores ctl[0..2] into ctl_host (four words of pinned, device-mapped host
+ * memory) and releases word 3 = token << 8 (status 0) at system scope -- the caller polls for its token instead of queueing a
+ * 16-byte copy and an event behind the scan (19 + 6 us on the stream at 5 M gaussians). */
+int gsa_scan_tiles_sorted_report(int n, uint32_t *counts_offsets, int32_t *block_owner, int n_blocks, uint32_t *ctl,
+                                 uint32_t *ctl_host, uint32_t token, void *workspace, size_t workspace_bytes,
+                                 gsa_stream_t stream);
 int gsa_tile_bin16(int n, const uint32_t *order, const uint32_t *offsets, const uint32_t *rects,
                    const int32_t *block_owner, int width, int height, int bin_tile, uint32_t m_capacity,
                    const uint32_t *m_dev, uint16_t *tile_tmp,
@@ -415,6 +422,63 @@ int gsa_project_bwd_batch(int n, const float *means, const float *quats, const f
 int gsa_sh_grad_expand_split(int n, const float *means, int sh_degree, int sh_coeffs, int n_views,
                              const float *viewmats, const float *intrin, const float *v_rgb, float *v_dc,
                              float *v_rest, gsa_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * ABI 13 -- ONE call per view forward and ONE per view backward.  The steady-state chain of a view behind its projection is
+ * eight to ten launches: gsa_depth_order_msd -> gsa_tile_bin16_scheduled -> gsa_composite_fwd, then
+ * gsa_composite_bwd_prepare -> gsa_composite_bwd_lists (-> gsa_project_bwd_acc / _factored).  A host in the reference's
+ * language (Python, src/backends/gsplat_backend.py:168-182 makes ONE call per view) pays per C-ABI call and per argument;
+ * gsa_view_fwd / gsa_view_bwd take the whole chain's arguments in one plain struct and queue the launches back to back.
+ * Every field means what the argument of the same name means in the stage it is passed to; all scratch stays
+ * caller-provided; the results are the stage-by-stage path's, bit for bit.  What the fused calls do NOT cover stays with
+ * the stages: the first call of a frame size / a repair (exact sizes, LSD ordering), grids without the one-pass placement
+ * (gsa_tile_bin16_direct == 0: GSA_ERR_UNSUPPORTED), cull_mode 1.
+ *   struct_bytes   sizeof(gsa_view_args) as the caller sees it (checked: a layout mismatch is an error, not a crash)
+ *   wait_event     (optional) a hipEvent_t the stream is made to wait for between the binning and the forward sweep: the
+ *                  RECORDS part of a split projection (gsa_project_fwd_parts) running on another stream
+ *   v_splat        the gradient records [n,16]: cleared by the forward sweep on the side, accumulated into by the backward
+ *   bwd_tile_order the backward sweep's own launch order [8 * ceil(n_tiles16 / 8)] (written by gsa_view_bwd)
+ *   project_mode   gsa_view_bwd: 0 = stop behind the sweep (the caller finishes all views with gsa_project_bwd_batch);
+ *                  1 = gsa_project_bwd_acc into v_means .. v_colors; 2 = gsa_project_bwd_factored (v_rgb instead of v_colors)
+ *   wait_bucket    (optional) a hipEvent_t waited for in front of the projection backward (the bucket is summed in view order)
+ */
+typedef struct gsa_view_args {
+    uint32_t struct_bytes;
+    int32_t n, width, height, channels, bin_tile, gid_boxes, n_blocks;
+    uint32_t m_capacity, key_min, scale, token;
+    /* forward inputs */
+    const float *splat;
+    const uint32_t *depth_keys, *tile_rects, *key_range, *qbox;
+    const float *background;
+    /* binning: outputs and scratch */
+    uint32_t *order, *rects, *offsets;
+    int32_t *block_owner;
+    uint32_t *ctl, *ctl_host;
+    void *depth_ws;
+    size_t depth_ws_bytes;
+    uint32_t *sorted_gid;
+    int32_t *tile_offsets, *tile_order;
+    void *bin_ws;
+    size_t bin_ws_bytes;
+    void *wait_event;
+    /* forward sweep outputs */
+    float *render, *alpha, *final_T;
+    int32_t *last_id;
+    uint32_t *quad_list;
+    int32_t *quad_count;
+    float *v_splat;
+    /* backward */
+    const float *v_render, *v_alpha;
+    int32_t *bwd_tile_order;
+    int32_t project_mode, accumulate, sh_degree, sh_coeffs;
+    void *wait_bucket;
+    const float *means, *quats, *scales, *opacities, *colors, *viewmat, *intrin, *sh_aux;
+    const int32_t *radii;
+    float *v_means, *v_quats, *v_scales, *v_opacities, *v_colors, *v_rgb;
+} gsa_view_args;
+size_t gsa_view_args_size(void);
+int gsa_view_fwd(const gsa_view_args *args, gsa_stream_t stream);
+int gsa_view_bwd(const gsa_view_args *args, gsa_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training-step stages around the rasterizer.

@@ -1705,6 +1705,60 @@ def test_bucketed_depth_order_equals_lsd_sort(gsa, n, dist):
         assert int(b2[n_blocks]) == int(b0[n_blocks])
 
 
+@pytest.mark.parametrize("n", [5_000_000, 10_000_000])
+def test_depth_order_at_the_reference_population(gsa, n):
+    """The depth ordering at the population the reference trains at ("~5.5M gaussians", /root/reference/src/training/trainer.py:92-96;
+    cap 1e7, training_config.py:22): beyond ~4 M gaussians the LSD passes scatter through the 22-KB instance
+    (``radix_scatter_compact_kernel``: more blocks than the 38-KB instance has slots on the chip) and the scan reports the
+    control words into the caller's pinned slot itself (``gsa_scan_tiles_sorted_report``).  Order == a stable sort of the
+    keys (ties keep index order), rectangles and counts gathered in that order, offsets == their exclusive sum, count and key
+    range reported on both paths, bit for bit; 24 key bits (what these depths differ in) == 32."""
+    from gsplat_amd import stages as S
+    from gsplat_amd._lib import check, lib
+    g = torch.Generator().manual_seed(n % 1013)
+    keys = (torch.rand(n, generator=g) * 2 + 3).to(torch.float32).view(torch.int32).long()   # depths in [3, 5]
+    culled = torch.rand(n, generator=g) < 0.08
+    keys[culled] = 0xFFFFFFFF
+    counts = torch.randint(0, 6, (n,), generator=g)
+    counts[culled] = 0
+    counts[777_777] = 9000
+    rect_words = torch.randint(1, 2 ** 30, (n,), generator=g)
+    pairs = torch.stack([rect_words, counts], dim=1).to(torch.int32).contiguous().cuda()
+    k32 = torch.where(keys >= 2 ** 31, keys - 2 ** 32, keys).to(torch.int32).cuda()
+    m_true, n_vis = int(counts.sum()), int((~culled).sum())
+    lo, hi = int(keys[~culled].min()), int(keys[~culled].max())
+    assert S._key_bits_needed(lo, hi) == 24
+    n_blocks = (m_true + S.BIN_BLOCK - 1) // S.BIN_BLOCK
+    st = S._stream()
+    ref = torch.sort(keys.cuda(), stable=True).indices[:n_vis]
+    ref_counts = counts.cuda()[ref]
+    ref_offsets = torch.cumsum(ref_counts, 0) - ref_counts
+    ws = torch.empty(lib.gsa_depth_order_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    ws2 = torch.empty(lib.gsa_sort_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    for bits in (24, 32):
+        order, rects, offs = (torch.full((n,), -1, dtype=torch.int32, device="cuda") for _ in range(3))
+        owner = torch.full((n_blocks + 1,), -7, dtype=torch.int32, device="cuda")
+        ctl = torch.full((4,), -1, dtype=torch.int32, device="cuda")
+        host = torch.zeros(4, dtype=torch.int32, pin_memory=True)
+        token = 0x5A5A5 + bits
+        check(lib.gsa_depth_order(n, k32.data_ptr(), pairs.data_ptr(), bits, order.data_ptr(), rects.data_ptr(), offs.data_ptr(),
+                                  ctl[1:3].data_ptr(), ws.data_ptr(), ws.numel(), st), "gsa_depth_order")
+        check(lib.gsa_scan_tiles_sorted_report(n, offs.data_ptr(), owner.data_ptr(), n_blocks, ctl.data_ptr(), host.data_ptr(), token,
+                                               ws2.data_ptr(), ws2.numel(), st), "gsa_scan_tiles_sorted_report")
+        S._wait_slot((host, None, token))
+        assert [int(x) & 0xFFFFFFFF for x in host] == [m_true, lo, hi, token << 8]
+        torch.cuda.synchronize()
+        assert [int(x) & 0xFFFFFFFF for x in ctl[:3]] == [m_true, lo, hi]
+        assert torch.equal(order[:n_vis].long(), ref)
+        assert torch.equal(rects[:n_vis], pairs[:, 0][ref]) and torch.equal(offs[:n_vis].long(), ref_offsets)
+        # the owner of every 4096-slot record block: the last gaussian (in depth order) whose list starts at or before the block
+        starts = torch.arange(n_blocks, device="cuda") * S.BIN_BLOCK
+        has = ref_counts > 0
+        idx = torch.nonzero(has).squeeze(1)
+        want_owner = idx[torch.searchsorted(ref_offsets[has].contiguous(), starts, right=True) - 1]
+        assert torch.equal(owner[:n_blocks].long(), want_owner) and int(owner[n_blocks]) == int(idx[-1])
+
+
 def test_depth_table_levels_the_buckets(gsa):
     """The table the bucketed ordering builds for a view (cells -> buckets, from the per-wave sample of keys): valid --
     monotone, every bucket at most 2^24 keys wide -- and LEVEL: on keys as unevenly distributed as the diagonal cameras of
