@@ -662,55 +662,73 @@ class ViewParallelTrainer:
             from .rasterization import projection_buffers
             return projection_buffers(shared["views"])
 
-        def front(j, exact):
+        def project(j):
+            """view j's projection: its slice of the step's shared launch, or a launch of its own (split: the records part on
+            the projection side stream) -> (pose, splat, radii, tiles, keys, rects, aux, key range, boxes, records event)"""
             view = mine[j]
             W, H = view["width"], view["height"]
             bt = S.bin_tile_for(W, H, cull)   # 32 x 32 bins where the fused binning applies
-            ready = None
             if "views" in shared:
                 pv = shared["views"][j]
-                pose, kr, qb = pv.viewmat, pv.key_range, pv.qbox
-                splat, radii, tiles, keys, rects, aux = pv.splat, pv.radii, pv.tiles_touched, pv.depth_keys, pv.tile_rects, pv.sh_aux
-                ready = pv.records_ready
-            else:
-                pose = view["pose"].to(torch.float32).contiguous()
-                kr = S.key_range_buffer(leaves[0].shape[0], dev)   # the view's depth-key range: the depth ordering plans its buckets from it
-                qb = S.qbox_buffer(leaves[0].shape[0], dev)        # the gaussians' quadrant boxes: the forward sweep's masks
-                forked = [] if S._SPLIT_PROJECTION else None   # (records part beside the binning chain: stages.project_fwd)
-                splat, radii, tiles, keys, rects, aux = S.project_fwd(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4],
-                                                                      degree, pose, Kc, W, H, cull, return_rects=True,
-                                                                      return_aux=True, bin_tile=bt, key_range=kr, qbox=qb,
-                                                                      records_ready=forked)
-                ready = forked[0] if forked else None
-            bins = S.bin_tiles(splat, radii, tiles, keys, W, H, cull, tile_rects=rects, exact=exact, bin_tile=bt,
-                               key_range=kr, qbox=qb, speculation=self._pipe.speculation)
-            order = S.tile_schedule(bins, W, H, bt)
-            if ready is not None:   # the splat records (written on the projection side stream) are read from here on
-                torch.cuda.current_stream().wait_event(ready)
-            return pose, splat, radii, bins, order, aux
+                return (pv.viewmat, pv.splat, pv.radii, pv.tiles_touched, pv.depth_keys, pv.tile_rects, pv.sh_aux, pv.key_range,
+                        pv.qbox, pv.records_ready, bt)
+            pose = view["pose"].to(torch.float32).contiguous()
+            kr = S.key_range_buffer(leaves[0].shape[0], dev)   # the view's depth-key range: the depth ordering plans its buckets from it
+            qb = S.qbox_buffer(leaves[0].shape[0], dev)        # the gaussians' quadrant boxes: the forward sweep's masks
+            forked = [] if S._SPLIT_PROJECTION else None   # (records part beside the binning chain: stages.project_fwd)
+            splat, radii, tiles, keys, rects, aux = S.project_fwd(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4],
+                                                                  degree, pose, Kc, W, H, cull, return_rects=True,
+                                                                  return_aux=True, bin_tile=bt, key_range=kr, qbox=qb,
+                                                                  records_ready=forked)
+            return pose, splat, radii, tiles, keys, rects, aux, kr, qb, (forked[0] if forked else None), bt
 
         def forward(j, deferred):
             """front end, compositor forward and the loss of view j on the current stream"""
             from .pipeline import ViewState
             view = mine[j]
             W, H = view["width"], view["height"]
-            pose, splat, radii, bins, order, aux = front(j, exact=False)
+            pose, splat, radii, tiles, keys, rects, aux, kr, qb, ready, bt = project(j)
+            spec = self._pipe.speculation
+            # the steady state: the whole chain behind the projection in ONE C-ABI call (stages.ViewChain: gsa_view_fwd)
+            chain = S.ViewChain.forward(splat, keys, rects, kr, qb, W, H, 3, cull, bt, bgc, True, speculation=spec,
+                                        records_ready=ready) if deferred else None
+            if chain is not None:
+                _, v = S.view_loss(chain.render, view["image"], c.lambda_dssim, grad_scale=scale / n_views, sums_out=view_sums[j])
+                return ViewState((view, pose, splat, radii, chain, aux, v), lambda: chain.bins.finalize()[1])
+            # first call of a frame size, repair, what the fused call does not cover: stage by stage
+            bins = S.bin_tiles(splat, radii, tiles, keys, W, H, cull, tile_rects=rects, exact=False, bin_tile=bt,
+                               key_range=kr, qbox=qb, speculation=spec)
             if not deferred and not bins.finalize()[1]:   # (a remembered capacity / key range did not hold: exact sizes)
-                pose, splat, radii, bins, order, aux = front(j, exact=True)
+                bins = S.bin_tiles(splat, radii, tiles, keys, W, H, cull, tile_rects=rects, exact=True, bin_tile=bt,
+                                   key_range=kr, qbox=qb, speculation=spec)
                 bins.finalize()
-            bt = bins.bin_tile
+            order = S.tile_schedule(bins, W, H, bt)
+            if ready is not None:   # the splat records (written on the projection side stream) are read from here on
+                torch.cuda.current_stream().wait_event(ready)
             render, _, final_T, last_id, lists = S.composite_fwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bgc, W,
                                                                  H, 3, order, want_lists=True, bin_tile=bt,
                                                                  gid_boxes=bins.boxed)
             if not deferred:
                 view_sums[j].zero_()               # (a step that is rendered again counts every view once)
             _, v = S.view_loss(render, view["image"], c.lambda_dssim, grad_scale=scale / n_views, sums_out=view_sums[j])
-            return ViewState((view, pose, splat, radii, bins, order, aux, final_T, last_id, lists, v),
+            return ViewState((view, pose, splat, radii, (bins, order, final_T, last_id, lists), aux, v),
                              (lambda: bins.finalize()[1]) if deferred else (lambda: True))
 
         def backward(j, state, before_bucket):
-            view, pose, splat, radii, bins, order, aux, final_T, last_id, lists, v = state.payload
+            view, pose, splat, radii, fwd, aux, v = state.payload
             W, H = view["width"], view["height"]
+            if isinstance(fwd, S.ViewChain):   # reverse sweep (+ this view's projection backward) in ONE call: gsa_view_bwd
+                if batch_bwd:
+                    fwd.backward(v)
+                    shared.setdefault("v_splat", {})[j] = fwd.view("v_splat")
+                else:
+                    fwd.backward(v, project={"means": leaves[0], "quats": leaves[1], "scales": leaves[2], "opacities": leaves[3],
+                                             "colors": leaves[4], "sh_degree": degree, "viewmat": pose, "Kmat": Kc, "radii": radii,
+                                             "sh_aux": aux, "out": grad_out, "accumulate": j > 0,
+                                             "v_rgb_out": vr_all[self.rank, j] if factored else None},
+                                 wait_bucket=before_bucket)
+                return
+            bins, order, final_T, last_id, lists = fwd
             v_splat = S.composite_bwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bgc, final_T, last_id, v, None,
                                       W, H, 3, order, quad_lists=lists, bin_tile=bins.bin_tile, gid_boxes=bins.boxed)
             if batch_bwd:   # (finished for all views at once, below)

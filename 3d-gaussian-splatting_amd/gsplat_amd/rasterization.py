@@ -71,9 +71,36 @@ class _RasterizeOneCamera(torch.autograd.Function):
             sh_aux = proj[5] if want_lists else None
             records_ready = forked[0] if forked else None
         # the host does not wait for the record count: bins are sized for a remembered capacity, the compositor is
-        # queued, and only then is the count (long since copied back) checked -- a miss repeats with exact sizes
-        bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, tile_rects=rects,
-                           bin_tile=bt, key_range=kr, qbox=qb, speculation=speculation)
+        # queued, and only then is the count (long since copied back) checked -- a miss repeats with exact sizes.
+        # Steady state: the whole chain behind the projection -- depth ordering, placement, launch order, sweep -- is ONE
+        # C-ABI call on one workspace allocation (stages.ViewChain: gsa_view_fwd); what that does not cover (first call of a
+        # frame size, repairs, cull_mode 1, grids without the one-pass placement) goes stage by stage below.
+        chain = S.ViewChain.forward(splat, depth_keys, rects, kr, qb, width, height, channels, cull_mode, bt, bg_c, want_lists,
+                                    speculation=speculation, records_ready=records_ready)
+        repair = False
+        if chain is not None:
+            if deferred is not None:
+                deferred.append(chain.bins)
+            elif not chain.bins.finalize()[1]:
+                chain, repair = None, True
+        if chain is not None:
+            if collector is not None:
+                collector.append(chain.bins)
+            ctx.chain = chain
+            ctx.save_for_backward(means_c, quats_c, scales_c, opac_c, colors_c, view_c, K_c, bg_c, splat, radii, sh_aux)
+            ctx.dims = (width, height, sh_degree, channels)
+            ctx.grad_out = grad_out
+            ctx.grad_accumulate = bool(grad_accumulate)
+            ctx.sh_grad_factored = sh_grad_factored
+            ctx.in_shapes = (means.shape, quats.shape, scales.shape, opacities.shape, colors.shape)
+            ctx.deferred_projection = projection if (projection is not None and projection.defer_backward) else None
+            ctx.mark_non_differentiable(splat, radii, tiles_touched)
+            ctx.set_materialize_grads(False)
+            # (the record lists, offsets and last ids stay inside the chain's workspace: views are built when meta is asked)
+            return chain.render, chain.alpha, splat, radii, tiles_touched, chain
+        ctx.chain = None
+        bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, tile_rects=rects, exact=repair,
+                           bin_tile=bt, key_range=None if repair else kr, qbox=qb, speculation=speculation)
         tile_order = S.tile_schedule(bins, width, height, bt)   # longest record lists first (speed only)
         if records_ready is not None:   # (the records part of a split projection: everything below reads the splat records)
             torch.cuda.current_stream().wait_event(records_ready)
@@ -120,6 +147,8 @@ class _RasterizeOneCamera(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, v_render, v_alpha, *unused):
+        if ctx.chain is not None:
+            return _RasterizeOneCamera._backward_chain(ctx, v_render, v_alpha)
         (means_c, quats_c, scales_c, opac_c, colors_c, view_c, K_c, bg_c, splat, radii, sorted_gid, tile_offsets,
          final_T, last_id, tile_order, quad_list, quad_count, sh_aux) = ctx.saved_tensors
         width, height, sh_degree, channels = ctx.dims
@@ -145,6 +174,36 @@ class _RasterizeOneCamera(torch.autograd.Function):
         need = ctx.needs_input_grad
         grads = tuple(g.view(shp) if (nd and g is not None) else None for g, shp, nd in zip(grads, ctx.in_shapes, need[:5]))
         return grads + (None,) * 15
+
+
+def _backward_chain(ctx, v_render, v_alpha):
+    """The backward pass of a view whose forward ran as one fused call: reverse sweep (+ projection backward) = gsa_view_bwd."""
+    means_c, quats_c, scales_c, opac_c, colors_c, view_c, K_c, bg_c, splat, radii, sh_aux = ctx.saved_tensors
+    width, height, sh_degree, channels = ctx.dims
+    chain = ctx.chain
+    if v_render is None:
+        v_render = torch.zeros(height, width, channels, dtype=torch.float32, device=means_c.device)
+    v_render = v_render.to(torch.float32).contiguous()
+    v_alpha_c = None if v_alpha is None else v_alpha.to(torch.float32).contiguous()
+    if ctx.deferred_projection is not None:
+        chain.backward(v_render, v_alpha_c)
+        ctx.deferred_projection.v_splat = chain.view("v_splat")
+        return (None,) * 20
+    out = S.project_bwd_outputs(means_c, quats_c, scales_c, opac_c, colors_c, ctx.grad_out, ctx.grad_accumulate,
+                                ctx.sh_grad_factored, sh_aux)
+    chain.backward(v_render, v_alpha_c, project={"means": means_c, "quats": quats_c, "scales": scales_c, "opacities": opac_c,
+                                                 "colors": colors_c, "sh_degree": sh_degree, "viewmat": view_c, "Kmat": K_c,
+                                                 "radii": radii, "sh_aux": sh_aux, "out": out, "accumulate": ctx.grad_accumulate,
+                                                 "v_rgb_out": ctx.sh_grad_factored})
+    if ctx.grad_accumulate:   # the sums live in the caller's buffers; autograd gets nothing to accumulate
+        return (None,) * 20
+    grads = out[:4] + (None if ctx.sh_grad_factored is not None else out[4],)
+    need = ctx.needs_input_grad
+    grads = tuple(g.view(shp) if (nd and g is not None) else None for g, shp, nd in zip(grads, ctx.in_shapes, need[:5]))
+    return grads + (None,) * 15
+
+
+_RasterizeOneCamera._backward_chain = staticmethod(_backward_chain)
 
 
 def project_cameras(means, quats, scales, opacities, colors, viewmats, Ks, width: int, height: int,
@@ -346,10 +405,22 @@ def rasterization(
             render = render[..., 3:]
         renders.append(render)
         alphas.append(alpha)
-        per_cam.append(out[2:])  # splat, radii, tiles_touched, sorted_tile, sorted_gid, tile_offsets, last_id
+        # splat, radii, tiles_touched, sorted_tile, sorted_gid, tile_offsets, last_id -- the last four as views of the fused
+        # chain's workspace, built when somebody asks (``cam``)
+        per_cam.append(out[2:] if len(out) == 9 else tuple(out[2:5]) + (out[5],))
+
+    def cam(c):
+        pc = per_cam[c]
+        if len(pc) == 4:   # (fused chain: materialise the views once)
+            ch = pc[3]
+            pc = per_cam[c] = pc[:3] + (torch.empty(0, dtype=torch.int16, device=pc[0].device), ch.view("sorted_gid"),
+                                        ch.view("tile_offsets"), ch.view("last_id"))
+        return pc
 
     def settled():
         """per_cam with the record buffers cut to the record counts (deferred check: waits for the control words now)."""
+        for c in range(len(per_cam)):
+            cam(c)
         if all_bins:
             for c, b in enumerate(all_bins):
                 m = b.finalize()[0]
@@ -384,7 +455,8 @@ def rasterization(
                 tiled["v"] = settled()
             else:
                 out16 = []
-                for pc in per_cam:
+                for c_ in range(len(per_cam)):
+                    pc = cam(c_)
                     splat, radii, tiles = pc[0], pc[1], pc[2]
                     keys = torch.where((radii > 0).all(-1), splat[:, 9].contiguous().view(torch.int32),
                                        torch.full_like(tiles, -1))

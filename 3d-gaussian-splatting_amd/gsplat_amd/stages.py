@@ -241,8 +241,12 @@ PROJECT_RECORDS = 2 | (4 if os.environ.get("GSPLAT_AMD_RECORDS_NOSTAGE") == "1" 
 # the caller's stream and the RECORDS part (the splat records with the colours and the coefficient digests: what the sweeps
 # read; it streams the 192-B coefficient rows) on a side stream BESIDE the view's binning chain, which is latency-bound and
 # leaves the HBM idle.  The caller's stream waits for the records in front of its forward sweep (``records_ready``).
-# GSPLAT_AMD_SPLIT_PROJECTION=0: one launch on the caller's stream, as before (A/B).
-_SPLIT_PROJECTION = os.environ.get("GSPLAT_AMD_SPLIT_PROJECTION", "1") != "0"
+# MEASURED (r05, profiles/r05_projection_split.md) and left OFF: the two do not co-run -- the bucket sort takes 137 of a CU's
+# 160 KB of LDS and the placement its wave slots, so the records launch mostly waits its turn: a single view 0.593 -> 0.600 ms
+# with the plain launch, 0.586 with it capped to 512 strided workgroups (one 13-KB block beside a bucket sort), the 4-view
+# step +1 %; the fused training step lost its two-stream overlap to the third stream.  GSPLAT_AMD_SPLIT_PROJECTION=1 switches
+# it on (the parts are the same bits: test_split_projection_parts_equal_the_whole_stage).
+_SPLIT_PROJECTION = os.environ.get("GSPLAT_AMD_SPLIT_PROJECTION", "0") == "1"
 _PROJ_STREAMS = {}
 
 
@@ -443,7 +447,8 @@ class TileBins:
 
     def __init__(self, sorted_tile, sorted_gid, tile_offsets, capacity, m_known, key, slot=None, n=0, key_bits=32,
                  keys_ok=True, boxed=False, speculation=None):
-        self._tile, self._gid, self.tile_offsets = sorted_tile, sorted_gid, tile_offsets
+        self._tile, self._gid_t, self._offs_t = sorted_tile, sorted_gid, tile_offsets
+        self._chain = None   # (ViewChain: the id buffer and the offsets are views of its workspace, built when somebody asks)
         self._spec = speculation if speculation is not None else DEFAULT_SPECULATION   # who remembers what this view teaches
         # boxed: the top byte of every entry of the id buffer is the record's quadrant box (gsa_tile_bin16 given qbox), the
         # gaussian id its low 24 bits -- what the compositor stages must be told (their ``gid_boxes``)
@@ -454,6 +459,18 @@ class TileBins:
         self.key_bits, self._keys_ok = key_bits, keys_ok
         # the compositor's launch order (tile_schedule's output), where the one-pass placement wrote it on the side
         self.tile_order = None
+
+    @property
+    def _gid(self):
+        if self._gid_t is None and self._chain is not None:
+            self._gid_t = self._chain.view("sorted_gid", torch.int32)
+        return self._gid_t
+
+    @property
+    def tile_offsets(self):
+        if self._offs_t is None and self._chain is not None:
+            self._offs_t = self._chain.view("tile_offsets", torch.int32)
+        return self._offs_t
 
     @property
     def bin_tile(self) -> int:   # side of the tiles these bins index (16, or 32: see bin_tiles)
@@ -697,6 +714,35 @@ def _note_count(spec: Speculation, key, n: int, m: int) -> None:
         ent[1] = 0
 
 
+def _depth_plan(spec: "Speculation", key, n: int, cap, have_key_range: bool, exact: bool = False, depth_msd: Optional[bool] = None):
+    """Which depth ordering a view takes, from what ``spec`` remembers of its scene shape: None -- LSD passes (first call of
+    a shape, repair, back-off, populations outside the bucketed range) -- or the plan of the bucketed one, (key_min, scale)
+    for host-planned equal buckets / (0, 0, "device") for the view's own depth table.  Counts down the shape's back-offs."""
+    _KEY_RANGE, _MSD_BACKOFF, _TABLE_MODE, _HOST_PLAN_BACKOFF = spec.key_range, spec.msd_backoff, spec.table_mode, spec.host_plan_backoff
+    rng = None if exact else _KEY_RANGE.get(key)
+    backoff = _MSD_BACKOFF.get(key, 0)
+    if backoff:
+        _MSD_BACKOFF[key] = backoff - 1
+    use_msd = depth_msd if depth_msd is not None else (_DEPTH_MSD_DEFAULT and _MSD_MIN_N <= n <= _MSD_MAX_N and backoff == 0)
+    plan = None
+    if cap is not None and use_msd:
+        left = _TABLE_MODE.get(key, 0)
+        want_table = _DEPTH_TABLE == "1" or (_DEPTH_TABLE == "auto" and left > 0)
+        if want_table and have_key_range:
+            if left > 0:
+                _TABLE_MODE[key] = left - 1
+            plan = (0, 0, "device")     # the view's own depth table, built on the device
+        elif rng is not None:
+            # (a caller without a key range -- the stage API, tile_lists()'s re-binning -- stays on the host's equal
+            # buckets, with a back-off of their own after a miss, and does not use up the shape's views on the device plan)
+            wait = _HOST_PLAN_BACKOFF.get(key, 0)
+            if wait and depth_msd is None:
+                _HOST_PLAN_BACKOFF[key] = wait - 1
+            else:
+                plan = _msd_plan(rng[0], rng[1])
+    return plan
+
+
 def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, cull_mode: int = 0,
               exact: bool = False, fused: Optional[bool] = None, tile_rects=None, depth_msd: Optional[bool] = None,
               bin_tile: int = TILE_SIZE, key_range: Optional[torch.Tensor] = None,
@@ -753,26 +799,7 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
         order = torch.empty(N, dtype=torch.int32, device=dev)
         rects = torch.empty(N, dtype=torch.int32, device=dev)
         rng = None if exact else _KEY_RANGE.get(key)
-        backoff = _MSD_BACKOFF.get(key, 0)
-        if backoff:
-            _MSD_BACKOFF[key] = backoff - 1
-        use_msd = depth_msd if depth_msd is not None else (_DEPTH_MSD_DEFAULT and _MSD_MIN_N <= N <= _MSD_MAX_N and backoff == 0)
-        plan = None
-        if cap is not None and use_msd:
-            left = _TABLE_MODE.get(key, 0)
-            want_table = _DEPTH_TABLE == "1" or (_DEPTH_TABLE == "auto" and left > 0)
-            if want_table and key_range is not None:
-                if left > 0:
-                    _TABLE_MODE[key] = left - 1
-                plan = (0, 0, "device")     # the view's own depth table, built on the device
-            elif rng is not None:
-                # (a caller without a key range -- the stage API, tile_lists()'s re-binning -- stays on the host's equal
-                # buckets, with a back-off of their own after a miss, and does not use up the shape's views on the device plan)
-                wait = _HOST_PLAN_BACKOFF.get(key, 0)
-                if wait and depth_msd is None:
-                    _HOST_PLAN_BACKOFF[key] = wait - 1
-                else:
-                    plan = _msd_plan(rng[0], rng[1])
+        plan = _depth_plan(spec, key, N, cap, key_range is not None, exact, depth_msd)
         PATH_STATS["lsd" if plan is None else ("bucketed_device_table" if len(plan) == 3 else "bucketed_host_plan")] += 1
         if plan is not None:
             key_bits = plan
@@ -1010,6 +1037,28 @@ def composite_bwd(splat, sorted_gid, tile_offsets, background, final_T, last_id,
     return v_splat
 
 
+def project_bwd_outputs(means, quats, scales, opacities, colors, out, accumulate: bool, v_rgb_out, sh_aux):
+    """The five gradient tensors of a projection backward (``out`` checked, or fresh ones) -- what ``project_bwd`` validates,
+    for the fused per-view call (``ViewChain.backward``)."""
+    N = means.shape[0]
+    if accumulate and out is None:
+        raise ValueError("project_bwd(accumulate=True) needs the `out` buffers it adds to")
+    if out is None:
+        out = (torch.empty_like(means), torch.empty_like(quats), torch.empty_like(scales), torch.empty_like(opacities),
+               None if v_rgb_out is not None else torch.empty_like(colors))
+    else:
+        for got, like in zip(out, (means, quats, scales, opacities, colors)):
+            if got.numel() != like.numel() or got.dtype != torch.float32 or not got.is_contiguous() or got.device != like.device:
+                raise ValueError("grad_out tensors must be contiguous fp32, sized like the inputs, on their device")
+        out = tuple(out)
+    if sh_aux is not None and (sh_aux.shape != (N, 12) or sh_aux.dtype != torch.float32 or not sh_aux.is_contiguous()
+                               or sh_aux.device != means.device):
+        raise ValueError("sh_aux must be the contiguous fp32 [N,12] tensor project_fwd returned")
+    if v_rgb_out is not None and (v_rgb_out.shape != (N, 3) or v_rgb_out.dtype != torch.float32 or not v_rgb_out.is_contiguous()):
+        raise ValueError("v_rgb_out must be a contiguous fp32 [N,3] tensor")
+    return out
+
+
 def project_bwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat, Kmat, width: int, height: int,
                 splat, radii, v_splat, out=None, accumulate: bool = False, v_rgb_out=None, sh_aux=None):
     """-> v_means, v_quats, v_scales, v_opacities, v_colors (every element written).  ``out``: five preallocated
@@ -1045,6 +1094,167 @@ def project_bwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat
           _ptr(v_splat), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac), _ptr(v_colors),
           1 if accumulate else 0, _ptr(sh_aux), _stream())
     return v_means, v_quats, v_scales, v_opac, v_colors
+
+
+# ---- one C-ABI call per view forward, one per view backward (gsa_view_fwd / gsa_view_bwd, ABI 13) ----------------------
+# GSPLAT_AMD_VIEW_CALLS=0: the stage-by-stage path everywhere (A/B; tests set the module attribute).
+_VIEW_CALLS = os.environ.get("GSPLAT_AMD_VIEW_CALLS", "1") != "0"
+_VIEW_LAYOUTS = {}
+_ALIGN = 256
+
+
+def _view_layout(n: int, cap: int, width: int, height: int, channels: int, bin_tile: int, lists: bool):
+    """Byte offsets of everything a view's chain needs besides its projection and the two tensors the caller sees (render,
+    alpha) inside ONE workspace allocation -> ({name: offset}, total bytes, n_blocks, depth-ordering bytes, placement bytes).
+    Cached per shape: a view costs one ``torch.empty`` instead of fifteen."""
+    key = (n, cap, width, height, channels, bin_tile, lists)
+    lay = _VIEW_LAYOUTS.get(key)
+    if lay is None:
+        t16 = tile_grid(width, height)
+        n16 = t16[0] * t16[1]
+        tb = tile_grid(width, height, bin_tile)
+        n_blocks = (cap + BIN_BLOCK - 1) // BIN_BLOCK
+        dws = int(lib.gsa_depth_order_msd_workspace_bytes(n))
+        ws2 = int(lib.gsa_tile_bin16_workspace_bytes(width, height, bin_tile, cap))
+        order_words = 8 * ((n16 + 7) // 8)
+        p = width * height
+        parts = [("order", 4 * n), ("rects", 4 * n), ("offsets", 4 * n), ("block_owner", 4 * (n_blocks + 1)), ("ctl", 16),
+                 ("depth_ws", dws), ("sorted_gid", 4 * cap), ("tile_offsets", 4 * (tb[0] * tb[1] + 1)), ("tile_order", 4 * order_words),
+                 ("bin_ws", ws2), ("final_T", 4 * p), ("last_id", 4 * p)]
+        if lists:
+            slices = 4 * (bin_tile // TILE_SIZE) ** 2
+            parts += [("quad_list", 4 * slices * max(cap, 1)), ("quad_count", 16 * n16), ("v_splat", 4 * SPLAT_STRIDE * n),
+                      ("bwd_tile_order", 4 * order_words)]
+        off, offsets, sizes = 0, {}, {}
+        for name, nbytes in parts:
+            offsets[name], sizes[name] = off, nbytes
+            off = (off + nbytes + _ALIGN - 1) // _ALIGN * _ALIGN
+        while len(_VIEW_LAYOUTS) >= 64:
+            _VIEW_LAYOUTS.pop(next(iter(_VIEW_LAYOUTS)))
+        lay = _VIEW_LAYOUTS[key] = (offsets, sizes, max(off, _ALIGN), n_blocks, dws, ws2)
+    return lay
+
+
+class ViewChain:
+    """One view's chain behind its projection as TWO C-ABI calls: ``forward`` (bucketed depth ordering, one-pass placement with
+    the compositor's launch order, forward sweep -- ``gsa_view_fwd``) and ``backward`` (tile re-ordering, reverse sweep and,
+    unless the step finishes all views at once, the projection backward -- ``gsa_view_bwd``).  Everything the chain needs
+    besides the projection's tensors and the two the caller sees lives in ONE workspace tensor; views of it are built only
+    when somebody asks (``view``).  Same kernels, same arguments, same bits as ``bin_tiles`` + ``tile_schedule`` +
+    ``composite_fwd`` / ``composite_bwd`` + ``project_bwd``; what it does not cover (first call of a frame size, repairs,
+    populations or grids outside the bucketed ordering / the one-pass placement, ``cull_mode`` 1) returns None from
+    ``forward`` and the caller takes the stages."""
+
+    __slots__ = ("args", "ws", "lay", "render", "alpha", "bins", "dims", "keep", "has_lists", "_views")
+
+    @staticmethod
+    def forward(splat, depth_keys, tile_rects, key_range, qbox, width: int, height: int, channels: int, cull_mode: int,
+                bin_tile: int, background, want_lists: bool, speculation=None, records_ready=None) -> Optional["ViewChain"]:
+        from ._lib import ViewArgs
+        if not _VIEW_CALLS or cull_mode != 0 or TIMER.enabled or not _BIN_FUSED_DEFAULT or not _BIN_DIRECT or not _SCHEDULE_IN_PLACEMENT:
+            return None   # (the stage timer wants one event pair per stage)
+        dev, n = splat.device, int(splat.shape[0])
+        if n == 0 or tile_rects is None or not lib.gsa_tile_bin16_direct(width, height, bin_tile):
+            return None
+        spec = speculation if speculation is not None else DEFAULT_SPECULATION
+        key = (dev.type, dev.index, width, height, cull_mode, bin_tile)
+        cap = _capacity_for(spec, key, n)
+        if cap is None:
+            return None
+        plan = _depth_plan(spec, key, n, cap, key_range is not None)
+        if plan is None:
+            return None
+        PATH_STATS["bucketed_device_table" if len(plan) == 3 else "bucketed_host_plan"] += 1
+        if torch.cuda.current_device() != dev.index:
+            raise RuntimeError(f"gsplat_amd: a view on cuda:{dev.index} while the current device is cuda:{torch.cuda.current_device()}")
+        boxed = qbox is not None and bool(lib.gsa_tile_bin16_boxes(width, height, bin_tile, n))
+        offsets, _, total, n_blocks, dws, ws2 = lay = _view_layout(n, cap, width, height, channels, bin_tile, bool(want_lists))
+        ws = torch.empty(total, dtype=torch.uint8, device=dev)
+        render = torch.empty(height, width, channels, dtype=torch.float32, device=dev)
+        alpha = torch.empty(height, width, 1, dtype=torch.float32, device=dev)
+        m_host, m_event, pool = _pinned_scalar(dev)
+        token = _next_token()
+        m_host[3] = 0
+        base = ws.data_ptr()
+        a = ViewArgs()
+        a.struct_bytes = ctypes.sizeof(ViewArgs)
+        a.n, a.width, a.height, a.channels, a.bin_tile, a.gid_boxes, a.n_blocks = n, width, height, channels, bin_tile, int(boxed), n_blocks
+        a.m_capacity, a.key_min, a.scale, a.token = cap, plan[0], plan[1], token
+        a.splat, a.depth_keys, a.tile_rects = splat.data_ptr(), depth_keys.data_ptr(), tile_rects.data_ptr()
+        a.key_range = key_range.data_ptr() if len(plan) == 3 else None
+        a.qbox = qbox.data_ptr() if boxed else None
+        a.background = None if background is None else background.data_ptr()
+        a.order, a.rects, a.offsets = base + offsets["order"], base + offsets["rects"], base + offsets["offsets"]
+        a.block_owner, a.ctl, a.ctl_host = base + offsets["block_owner"], base + offsets["ctl"], m_host.data_ptr()
+        a.depth_ws, a.depth_ws_bytes = base + offsets["depth_ws"], dws
+        a.sorted_gid, a.tile_offsets, a.tile_order = base + offsets["sorted_gid"], base + offsets["tile_offsets"], base + offsets["tile_order"]
+        a.bin_ws, a.bin_ws_bytes = base + offsets["bin_ws"], ws2
+        a.wait_event = None if records_ready is None else records_ready.cuda_event
+        a.render, a.alpha = render.data_ptr(), alpha.data_ptr()
+        a.final_T, a.last_id = base + offsets["final_T"], base + offsets["last_id"]
+        if want_lists:
+            a.quad_list, a.quad_count, a.v_splat = base + offsets["quad_list"], base + offsets["quad_count"], base + offsets["v_splat"]
+            a.bwd_tile_order = base + offsets["bwd_tile_order"]
+        check(lib.gsa_view_fwd(ctypes.byref(a), _stream()), "gsa_view_fwd")
+        ch = ViewChain()
+        ch.args, ch.ws, ch.lay, ch.render, ch.alpha, ch._views = a, ws, lay, render, alpha, {}
+        ch.dims, ch.has_lists = (n, cap, width, height, channels, bin_tile), bool(want_lists)
+        # (what the struct points at must outlive the launches: the projection's tensors, the background, the records event)
+        ch.keep = (splat, depth_keys, tile_rects, key_range, qbox, background, records_ready)
+        bins = TileBins(None, None, None, cap, None, key, (m_host, m_event, token, pool), n, plan, True, boxed, spec)
+        bins._chain = ch
+        ch.bins = bins
+        return ch
+
+    _DTYPES = {"order": torch.int32, "rects": torch.int32, "offsets": torch.int32, "sorted_gid": torch.int32,
+               "tile_offsets": torch.int32, "tile_order": torch.int32, "bwd_tile_order": torch.int32, "final_T": torch.float32,
+               "last_id": torch.int32, "quad_list": torch.int32, "quad_count": torch.int32, "v_splat": torch.float32,
+               "ctl": torch.int32}
+
+    def view(self, name: str, dtype=None) -> torch.Tensor:
+        """A tensor view of one of the workspace's buffers (flat, or shaped where the stage API shapes it)."""
+        v = self._views.get(name)
+        if v is None:
+            offsets, sizes = self.lay[0], self.lay[1]
+            n, cap, width, height, channels, bt = self.dims
+            flat = self.ws[offsets[name]:offsets[name] + sizes[name]].view(dtype or self._DTYPES[name])
+            shape = {"final_T": (height, width), "last_id": (height, width), "v_splat": (n, SPLAT_STRIDE),
+                     "quad_count": (-1, 4)}.get(name)
+            v = self._views[name] = flat.view(shape) if shape else flat
+        return v
+
+    def backward(self, v_render, v_alpha=None, project=None, wait_bucket=None):
+        """Queues the view's backward on the current stream.  ``project``: None -- stop behind the sweep (the gradient record
+        is ``view('v_splat')``; ``project_views_bwd`` finishes the step's views) -- or a dict {means, quats, scales, opacities,
+        colors, sh_degree, viewmat, Kmat, radii, sh_aux, out: (v_means .. v_colors), accumulate, v_rgb_out}: the projection
+        backward behind the sweep, as ``project_bwd``.  ``wait_bucket``: an event the stream waits for in front of it."""
+        if not self.has_lists:
+            raise RuntimeError("ViewChain.backward: the forward was run without lists (no backward was announced)")
+        a = self.args
+        a.v_render = v_render.data_ptr()
+        a.v_alpha = None if v_alpha is None else v_alpha.data_ptr()
+        held = [v_render, v_alpha]
+        if project is None:
+            a.project_mode = 0
+        else:
+            out, v_rgb = project["out"], project.get("v_rgb_out")
+            colors = project["colors"]
+            a.project_mode = 2 if v_rgb is not None else 1
+            a.accumulate = 1 if project.get("accumulate") else 0
+            a.sh_degree = project["sh_degree"]
+            a.sh_coeffs = colors.shape[1] if project["sh_degree"] >= 0 else 0
+            a.wait_bucket = None if wait_bucket is None else wait_bucket.cuda_event
+            a.means, a.quats, a.scales = project["means"].data_ptr(), project["quats"].data_ptr(), project["scales"].data_ptr()
+            a.opacities, a.colors = project["opacities"].data_ptr(), colors.data_ptr()
+            a.viewmat, a.intrin, a.radii = project["viewmat"].data_ptr(), project["Kmat"].data_ptr(), project["radii"].data_ptr()
+            aux = project.get("sh_aux") if project["sh_degree"] >= 1 else None
+            a.sh_aux = None if aux is None else aux.data_ptr()
+            a.v_means, a.v_quats, a.v_scales, a.v_opacities = (t.data_ptr() for t in out[:4])
+            a.v_colors = None if (v_rgb is not None or out[4] is None) else out[4].data_ptr()
+            a.v_rgb = None if v_rgb is None else v_rgb.data_ptr()
+            held += [project, wait_bucket]
+        check(lib.gsa_view_bwd(ctypes.byref(a), _stream()), "gsa_view_bwd")
+        del held
 
 
 # ---- training-step stages around the rasterizer (SURVEY.md section 8f, rank 1) ------------------------------------
