@@ -42,7 +42,7 @@ constexpr int kTile = GSA_TILE_SIZE;
 constexpr int kWave = 64;     // threads per workgroup = one wave = one quadrant
 constexpr int kBatch = 64;    // records staged per wave and step (one per lane)
 constexpr float kLog2e = 1.4426950408889634f;
-constexpr uint32_t kSign = 0x80000000u;
+
 
 #ifdef GSA_TRACE   // developer build: per-wave timeline and phase times (tools/trace_tiles.py)
 __device__ unsigned long long *g_trace = nullptr;
@@ -274,15 +274,17 @@ __device__ __forceinline__ const float4 *rec_at(const Staged<F4> &st, uint32_t b
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-// Per-pixel state of the forward walk.  A pixel is LIVE until the stop rule fires (T (1 - alpha) <= 1e-4 at a
-// record that passes the alpha test); then `dead` holds the sign bit (which switches the lane off inside
-// record_alpha), Tend its final transmittance, and T is parked at 1 so the optimistic group test below passes.
+// Per-pixel state of the forward walk.  A pixel is LIVE until the stop rule fires (T (1 - alpha) <= 1e-4 at a record that
+// passes the alpha test).  From then on (r05) its T is FROZEN at the transmittance in front of that record -- which is what
+// the image wants as the final T, and which is > 1e-4, so a finished pixel never trips the optimistic group test below --
+// its x is a NaN (alpha 0 at every later record: the walk needs no per-record "is this lane off" operand) and `alive` is 0.
+// (r04 parked T at 1 and kept the final T and a dead flag in two more registers, and every record of a careful group paid
+// three selects for them.)
 template <int CH>
 struct FwdPixel {
-    float T, Tend, acc[CH];
-    float x;          // the pixel centre's x relative to the quadrant's centre (-3.5 .. 3.5) -- NaN once the pixel is finished: sigma
-                      // is then NaN and fails the one compare of the alpha test, so the walk needs no per-record "is this lane off" operand
-    uint32_t dead;
+    float T, acc[CH];
+    float x;          // the pixel centre's x relative to the quadrant's centre (-3.5 .. 3.5) -- NaN once the pixel is finished
+    uint32_t alive;   // all ones while the pixel accumulates, 0 once it has stopped (or lies outside the image)
     int last;
 };
 
@@ -347,6 +349,9 @@ __device__ __forceinline__ void note_taken(unsigned long long &contrib, unsigned
 // Walks n list entries.  Returns false when all 64 pixels of the wave are finished.
 // LISTS: `contrib` receives one bit per list entry that was BLENDED at one pixel of the quadrant at least (alpha test
 // passed, pixel live and not stopping there) -- the records the backward sweep has to visit here.
+__device__ __forceinline__ int select_bits(uint32_t mask, int a, int b) {   // mask ? a : b, bit by bit (v_bfi_b32: one plain-rate instruction)
+    return (int)(((uint32_t)a & mask) | ((uint32_t)b & ~mask));
+}
 template <int CH, int F4, bool CLAMP, int LISTS, typename ST>
 __device__ __forceinline__ bool walk_fwd(const ST &st, int n, float yrel, FwdPixel<CH> &px,
                                          unsigned long long &contrib) {
@@ -354,10 +359,11 @@ __device__ __forceinline__ bool walk_fwd(const ST &st, int n, float yrel, FwdPix
     int i = 0;
     while (i < n) {
         // Optimistic loop: as long as no pixel stops inside a group (T only shrinks, so testing the group's last
-        // value is enough; finished pixels have alpha 0 and T parked at 1) no per-record select is needed at all.
+        // value is enough; finished pixels have alpha 0 and a frozen T above the threshold) no per-record select is needed.
+        float a[G], col[G][CH];
+        int idx[G];
         for (; i < n; i += G) {
-            float a[G], col[G][CH], t[G + 1];
-            int idx[G];
+            float t[G + 1];
             unsigned long long passed[G];
             eval_group<CH, F4, CLAMP, G>(st, i, px.x, yrel, a, col, idx, passed);
             t[0] = px.T;
@@ -377,32 +383,28 @@ __device__ __forceinline__ bool walk_fwd(const ST &st, int n, float yrel, FwdPix
                 for (int k = 0; k < CH; ++k) px.acc[k] = __builtin_fmaf(col[e][k], wgt, px.acc[k]);
             }
             px.T = t[G];
-            px.last = px.dead ? px.last : idx[G - 1];   // last record seen while live (the backward starts there)
+            px.last = select_bits(px.alive, idx[G - 1], px.last);   // last record seen while live (the backward starts there)
         }
         if (i >= n) break;
-        // some pixel stops in the group at i: the careful path, record by record
+        // some pixel stops in the group at i: the careful path, record by record, on the alphas the optimistic evaluation left
+        // (a pixel that stops inside the group has its later alphas switched off by `alive`; its x becomes a NaN behind the group)
         {
-            float a[G], col[G][CH];
-            int idx[G];
-            unsigned long long passed[G];
-            eval_group<CH, F4, CLAMP, G>(st, i, px.x, yrel, a, col, idx, passed);
 #pragma unroll
             for (int e = 0; e < G; ++e) {
-                const float ae = px.dead ? 0.f : a[e];      // a pixel that stopped earlier in this group
+                const float ae = __uint_as_float(__float_as_uint(a[e]) & px.alive);
                 const float nT = __builtin_fmaf(-ae, px.T, px.T);
-                const bool ok = nT > GSA_TRANSMITTANCE_EPS; // finished pixels: alpha 0, T = 1 -> true, no effect
+                const bool ok = nT > GSA_TRANSMITTANCE_EPS;   // finished pixels: alpha 0, T frozen above the threshold -> true, no effect
                 const float wgt = ok ? ae * px.T : 0.f;
                 if (LISTS == 2) note_taken(contrib, __ballot(wgt != 0.f), i + e);
 #pragma unroll
                 for (int k = 0; k < CH; ++k) px.acc[k] = __builtin_fmaf(col[e][k], wgt, px.acc[k]);
-                px.last = (ok && !px.dead) ? idx[e] : px.last;
-                px.Tend = ok ? px.Tend : px.T;              // the stop rule fired: this record is not blended
-                px.dead = ok ? px.dead : kSign;
-                px.x = ok ? px.x : __builtin_nanf("");
-                px.T = ok ? nT : 1.f;
+                px.T = ok ? nT : px.T;              // the stop rule fired: this record is not blended, T stays what it was
+                px.alive = ok ? px.alive : 0u;
+                px.last = select_bits(px.alive, idx[e], px.last);
             }
+            px.x = __uint_as_float(__float_as_uint(px.x) | ~px.alive);   // (all ones: a NaN)
             i += G;
-            if (__ballot(px.dead == 0u) == 0ull) return false;   // all 64 pixels finished
+            if (__ballot(px.alive != 0u) == 0ull) return false;   // all 64 pixels finished
         }
     }
     return true;
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 7 : GSA_FWD_WAVES)) void composit
     const uint32_t my_sel = (1u << (24 + my_col)) | (1u << (28 + my_row));   // (wave-uniform: an SGPR)
 
     FwdPixel<CH> px;
-    px.T = 1.f; px.Tend = 1.f; px.dead = inside ? 0u : kSign; px.last = -1;
+    px.T = 1.f; px.alive = inside ? ~0u : 0u; px.last = -1;
     px.x = inside ? xrel : __builtin_nanf("");
 #pragma unroll
     for (int k = 0; k < CH; ++k) px.acc[k] = 0.f;
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 7 : GSA_FWD_WAVES)) void composit
             // ---- STAGE: reach test against the bounding box of the pixels that are still accumulating (lane = 8 y + x) -- as
             // the quadrant saturates, and at the image border, fewer records can reach anything that still matters --
             // survivors to consecutive slots
-            const unsigned long long alive = __ballot(px.dead == 0u);
+            const unsigned long long alive = __ballot(px.alive != 0u);
             const uint32_t cols8 = (uint32_t)alive | (uint32_t)(alive >> 32);
             const uint32_t cols = (cols8 | (cols8 >> 16) | (cols8 >> 8) | (cols8 >> 24)) & 0xFFu;
             const float bx0 = qx0 + (float)__builtin_ctz(cols), bx1 = qx0 + (float)(31 - __builtin_clz(cols));
@@ -591,7 +593,7 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 7 : GSA_FWD_WAVES)) void composit
 
     if (inside) {
         const size_t pix = (size_t)py_ * width + px_;
-        const float Tf = px.dead ? px.Tend : px.T;
+        const float Tf = px.T;   // (a finished pixel's T is frozen at the transmittance in front of the record that stopped it)
 #pragma unroll
         for (int k = 0; k < CH; ++k) render[pix * CH + k] = px.acc[k] + (background ? Tf * background[k] : 0.f);
         alpha_out[pix] = 1.f - Tf;
@@ -888,7 +890,12 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 5 : GSA_BWD_WAVES)) void composit
     const uint32_t *__restrict__ sorted_gid, uint32_t gid_mask, const int32_t *__restrict__ tile_offsets,
     const float *__restrict__ background, const int32_t *__restrict__ tile_order, const float *__restrict__ final_T,
     const int32_t *__restrict__ last_id, const float *__restrict__ v_render, const float *__restrict__ v_alpha,
-    const uint32_t *__restrict__ quad_list, const int32_t *__restrict__ quad_count, float *__restrict__ v_splat) {
+    const uint32_t *__restrict__ quad_list, const int32_t *__restrict__ quad_count, float *__restrict__ v_splat,
+    float *__restrict__ v_rgb) {
+    // v_rgb (optional, [N,3], zeroed by the caller; gsa_composite_bwd_lists_rgb): the colour moments (fields 6..8) are added
+    // THERE instead of into the gradient record, already masked by the colour clamp (a channel the forward clamped at 0 --
+    // its staged colour is exactly 0 -- has no gradient): d loss / d rgb per gaussian in the 12-byte layout the view-parallel
+    // exchange all-gathers, straight out of the sweep -- no projection backward in front of the collective.
     constexpr int F4 = 3;
     constexpr int NF = 6 + CH;
     static_assert(NF <= 2 * kSub, "the epilogue's totals of a record fit the non-padding words of a matrix row");
@@ -1062,10 +1069,15 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 5 : GSA_BWD_WAVES)) void composit
             for (int t = 0; t < 2; ++t) {
                 const int r = 4 * t + (lane >> 4), f = lane & 15;
                 if (4 * t < nv) {
-                    const float total = tile[kTilePitch * r + min(f, NF - 1)];
+                    float total = tile[kTilePitch * r + min(f, NF - 1)];
                     if (f < NF && r < nv) {
                         const uint32_t g = tp.gid[s0 + r];
-                        atomicAdd(v_splat + (size_t)g * GSA_SPLAT_STRIDE + f, total);
+                        float *dst = v_splat + (size_t)g * GSA_SPLAT_STRIDE + f;
+                        if (v_rgb && f >= 6 && f < 9) {   // (uniform pointer test; the record image's floats 6..8 ARE r, g, b)
+                            if (reinterpret_cast<const float *>(tp.rec)[4 * F4 * (s0 + r) + f] == 0.f) total = 0.f;
+                            dst = v_rgb + (size_t)g * 3 + (f - 6);
+                        }
+                        atomicAdd(dst, total);
                     }
                 }
             }
@@ -1226,12 +1238,12 @@ extern "C" int gsa_composite_bwd(int width, int height, int channels, const floa
 }
 
 
-extern "C" int gsa_composite_bwd_lists(int width, int height, int channels, const float *splat,
+static int composite_bwd_lists_impl(int width, int height, int channels, const float *splat,
                                        const uint32_t *sorted_gid, int gid_boxes, const int32_t *tile_offsets,
                                        const float *background, const int32_t *tile_order, const float *final_T,
                                        const int32_t *last_id, const float *v_render, const float *v_alpha,
                                        const uint32_t *quad_list, const int32_t *quad_count, float *v_splat,
-                                       int bin_tile, gsa_stream_t stream) {
+                                       float *v_rgb, int bin_tile, gsa_stream_t stream) {
     GSA_RETURN_IF(width <= 0 || height <= 0 || (channels != 3 && channels != 4), GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(!tile_offsets || !final_T || !last_id || !v_render || !v_splat || !quad_list || !quad_count,
                   GSA_ERR_INVALID_ARGUMENT);
@@ -1245,11 +1257,32 @@ extern "C" int gsa_composite_bwd_lists(int width, int height, int channels, cons
     if (channels == 3)
         composite_bwd_2p_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid, gid_mask,
                                                          tile_offsets, background, tile_order, final_T, last_id,
-                                                         v_render, v_alpha, quad_list, quad_count, v_splat);
+                                                         v_render, v_alpha, quad_list, quad_count, v_splat, v_rgb);
     else
         composite_bwd_2p_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid, gid_mask,
                                                          tile_offsets, background, tile_order, final_T, last_id,
-                                                         v_render, v_alpha, quad_list, quad_count, v_splat);
+                                                         v_render, v_alpha, quad_list, quad_count, v_splat, v_rgb);
     GSA_LAUNCH_CHECK();
     return GSA_OK;
+}
+
+extern "C" int gsa_composite_bwd_lists(int width, int height, int channels, const float *splat,
+                                       const uint32_t *sorted_gid, int gid_boxes, const int32_t *tile_offsets,
+                                       const float *background, const int32_t *tile_order, const float *final_T,
+                                       const int32_t *last_id, const float *v_render, const float *v_alpha,
+                                       const uint32_t *quad_list, const int32_t *quad_count, float *v_splat,
+                                       int bin_tile, gsa_stream_t stream) {
+    return composite_bwd_lists_impl(width, height, channels, splat, sorted_gid, gid_boxes, tile_offsets, background, tile_order,
+                                    final_T, last_id, v_render, v_alpha, quad_list, quad_count, v_splat, nullptr, bin_tile, stream);
+}
+
+extern "C" int gsa_composite_bwd_lists_rgb(int width, int height, int channels, const float *splat,
+                                           const uint32_t *sorted_gid, int gid_boxes, const int32_t *tile_offsets,
+                                           const float *background, const int32_t *tile_order, const float *final_T,
+                                           const int32_t *last_id, const float *v_render, const float *v_alpha,
+                                           const uint32_t *quad_list, const int32_t *quad_count, float *v_splat,
+                                           float *v_rgb, int bin_tile, gsa_stream_t stream) {
+    GSA_RETURN_IF(!v_rgb, GSA_ERR_INVALID_ARGUMENT);
+    return composite_bwd_lists_impl(width, height, channels, splat, sorted_gid, gid_boxes, tile_offsets, background, tile_order,
+                                    final_T, last_id, v_render, v_alpha, quad_list, quad_count, v_splat, v_rgb, bin_tile, stream);
 }

@@ -79,6 +79,7 @@ SIGNATURES = {
     "gsa_composite_fwd": (c_int, [c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P, P, P, P, P, c_longlong, c_int, P]),
     "gsa_composite_bwd_prepare": (c_int, [c_longlong, P, c_int, P, P, P]),
     "gsa_composite_bwd_lists": (c_int, [c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, P]),
+    "gsa_composite_bwd_lists_rgb": (c_int, [c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, c_int, P]),
     "gsa_tile_schedule": (c_int, [c_int, P, P, c_int, c_int, P]),
     "gsa_composite_bwd": (c_int, [c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P, P, P, c_int, P]),
     "gsa_densify_gather": (c_int, [c_longlong, c_longlong, c_int, P, c_int, c_int, c_float, P, P, P, P, P, P, P, P, P, P]),

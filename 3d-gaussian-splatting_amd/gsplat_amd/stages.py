@@ -10,6 +10,7 @@ import math
 import os
 import threading
 import time
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -448,7 +449,9 @@ class TileBins:
     def __init__(self, sorted_tile, sorted_gid, tile_offsets, capacity, m_known, key, slot=None, n=0, key_bits=32,
                  keys_ok=True, boxed=False, speculation=None):
         self._tile, self._gid_t, self._offs_t = sorted_tile, sorted_gid, tile_offsets
-        self._chain = None   # (ViewChain: the id buffer and the offsets are views of its workspace, built when somebody asks)
+        self._chain = None   # (a WEAK reference to the ViewChain whose workspace holds the id buffer and the offsets: views are
+                             # built when somebody asks; the chain owns these bins, not the other way round -- no cycle, the
+                             # 0.4-GB workspace goes back to the allocator the moment the view's graph is dropped)
         self._spec = speculation if speculation is not None else DEFAULT_SPECULATION   # who remembers what this view teaches
         # boxed: the top byte of every entry of the id buffer is the record's quadrant box (gsa_tile_bin16 given qbox), the
         # gaussian id its low 24 bits -- what the compositor stages must be told (their ``gid_boxes``)
@@ -462,14 +465,16 @@ class TileBins:
 
     @property
     def _gid(self):
-        if self._gid_t is None and self._chain is not None:
-            self._gid_t = self._chain.view("sorted_gid", torch.int32)
+        ch = self._chain() if self._chain is not None else None
+        if self._gid_t is None and ch is not None:
+            self._gid_t = ch.view("sorted_gid", torch.int32)
         return self._gid_t
 
     @property
     def tile_offsets(self):
-        if self._offs_t is None and self._chain is not None:
-            self._offs_t = self._chain.view("tile_offsets", torch.int32)
+        ch = self._chain() if self._chain is not None else None
+        if self._offs_t is None and ch is not None:
+            self._offs_t = ch.view("tile_offsets", torch.int32)
         return self._offs_t
 
     @property
@@ -1100,6 +1105,7 @@ def project_bwd(means, quats, scales, opacities, colors, sh_degree: int, viewmat
 # GSPLAT_AMD_VIEW_CALLS=0: the stage-by-stage path everywhere (A/B; tests set the module attribute).
 _VIEW_CALLS = os.environ.get("GSPLAT_AMD_VIEW_CALLS", "1") != "0"
 _VIEW_LAYOUTS = {}
+_VIEW_WS_CAP = {}     # frame shape -> the largest record capacity a workspace of this shape was laid out for
 _ALIGN = 256
 
 
@@ -1145,7 +1151,7 @@ class ViewChain:
     populations or grids outside the bucketed ordering / the one-pass placement, ``cull_mode`` 1) returns None from
     ``forward`` and the caller takes the stages."""
 
-    __slots__ = ("args", "ws", "lay", "render", "alpha", "bins", "dims", "keep", "has_lists", "_views")
+    __slots__ = ("args", "ws", "lay", "render", "alpha", "bins", "dims", "keep", "has_lists", "_views", "__weakref__")
 
     @staticmethod
     def forward(splat, depth_keys, tile_rects, key_range, qbox, width: int, height: int, channels: int, cull_mode: int,
@@ -1168,7 +1174,18 @@ class ViewChain:
         if torch.cuda.current_device() != dev.index:
             raise RuntimeError(f"gsplat_amd: a view on cuda:{dev.index} while the current device is cuda:{torch.cuda.current_device()}")
         boxed = qbox is not None and bool(lib.gsa_tile_bin16_boxes(width, height, bin_tile, n))
-        offsets, _, total, n_blocks, dws, ws2 = lay = _view_layout(n, cap, width, height, channels, bin_tile, bool(want_lists))
+        # The workspace is laid out for the LARGEST capacity this frame shape has asked for (in steps of 256 K records), the
+        # kernels run with the view's own: the remembered capacity follows the cameras (a decaying maximum of records per
+        # gaussian), and a workspace whose size changed from view to view made the caching allocator split and re-malloc its
+        # 0.4-GB blocks -- 2 ms of host time per view where the whole view takes 0.6 on the device.
+        shape = (n, width, height, channels, bin_tile, bool(want_lists))
+        ws_cap = max(_VIEW_WS_CAP.get(shape, 0), (cap + (1 << 18) - 1) >> 18 << 18)
+        if _VIEW_WS_CAP.get(shape) != ws_cap:
+            while len(_VIEW_WS_CAP) >= 64:
+                _VIEW_WS_CAP.pop(next(iter(_VIEW_WS_CAP)))
+            _VIEW_WS_CAP[shape] = ws_cap
+        offsets, _, total, _, dws, ws2 = lay = _view_layout(n, ws_cap, width, height, channels, bin_tile, bool(want_lists))
+        n_blocks = (cap + BIN_BLOCK - 1) // BIN_BLOCK
         ws = torch.empty(total, dtype=torch.uint8, device=dev)
         render = torch.empty(height, width, channels, dtype=torch.float32, device=dev)
         alpha = torch.empty(height, width, 1, dtype=torch.float32, device=dev)
@@ -1202,7 +1219,7 @@ class ViewChain:
         # (what the struct points at must outlive the launches: the projection's tensors, the background, the records event)
         ch.keep = (splat, depth_keys, tile_rects, key_range, qbox, background, records_ready)
         bins = TileBins(None, None, None, cap, None, key, (m_host, m_event, token, pool), n, plan, True, boxed, spec)
-        bins._chain = ch
+        bins._chain = weakref.ref(ch)
         ch.bins = bins
         return ch
 

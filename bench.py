@@ -428,7 +428,7 @@ def main() -> None:
             rings[v] = torch.stack([scene.make_camera(i, v) for i in range(v)]).to(dev)
         return rings[v]
 
-    def make_step(form: str, views: int, n_streams: int, ring_size: int, cams_override=None):
+    def make_step(form: str, views: int, n_streams: int, ring_size: int, cams_override=None, rank_form: bool = False):
         """One step = `views` views on this rank (cameras j * world + rank of the step's window of the ring), forward +
         backward each, their gradients summed into the bucket, then the exchange.  form: "factored" | "allreduce".
         The views are queued by the product's own orchestrator (gsplat_amd.pipeline.ViewPipeline): alternating streams,
@@ -439,7 +439,8 @@ def main() -> None:
         # ... and, in one process, their projection BACKWARD in one launch behind the last sweep (geometry read once, every
         # gradient written once, the SH-coefficient gradient formed in registers: no per-view rgb gradients, no expansion
         # kernel).  With several ranks the per-view factored form stays: its all-gathers travel under the next view.
-        batch_bwd = batch_proj and dist is None and deg >= 1 and views <= 8 and not args.no_batch_backward   # (the kernel's camera limit)
+        # rank_form: the step a rank of a multi-GPU run executes (per-view factored backward, local SH rebuild), in ONE process
+        batch_bwd = batch_proj and dist is None and deg >= 1 and views <= 8 and not args.no_batch_backward and not rank_form   # (the kernel's camera limit)
         # one process, one view: nothing to sum, the backward writes the whole gradient itself
         factored = form == "factored" and (world > 1 or views > 1) and not batch_bwd
         ex = Exchange(dist, world, rank, n, views, factored, dev, expand=stages.sh_grad_expand)
@@ -686,6 +687,10 @@ def main() -> None:
     if args.dump_grad and rank == 0:
         torch.save(flat_grad.detach().cpu(), args.dump_grad)
     dist_ms = timed(head_step, args.steps, 0, per_step=True)["per_step_ms"]   # the same steps, one event per step
+    # the step form the ranks of a multi-GPU run execute (shared projection forward; per-view factored backward + local SH
+    # rebuild, no shared projection backward), timed in this one process: what the N > 1 values are like-for-like with
+    rank_step = timed(make_step(args.exchange, B, n_streams, head_ring, rank_form=True), args.steps, 2, converge=True) \
+        if (dist is None and B > 1) else None
     # the same step on the SAME cameras every step (r04's headline protocol), beside it
     fixed = timed(make_step(args.exchange, B, n_streams, world * B), args.steps, 2, converge=True) if head_ring != world * B else head
     c4 = None
@@ -919,6 +924,12 @@ def main() -> None:
                                   "intersections_M": round(wide["M"], 1), "binned_records": round(wide["binned"], 1),
                                   "capacity_misses_per_100": round(st["capacity_misses"] * per100, 2),
                                   "key_range_repairs_per_100": round(st["key_range_repairs"] * per100, 2)}
+        if rank_step is not None:
+            rs_ms = rank_step["s"] / args.steps * 1e3 / B
+            line["rank_step"] = {"what": "the step a rank of an N > 1 run executes (shared projection forward, per-view factored "
+                                         "projection backward, local SH rebuild; no collectives in this process)",
+                                 "ms_per_view": round(rs_ms, 4), "value": round(p / rs_ms / 1e3, 3),
+                                 "frac": round(ring_bytes / (rs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
         if fwd_only is not None:
             fo_ms = fwd_only["s"] / args.steps * 1e3
             line["forward_only"] = {"what": "HipBackend.render_with_depth under no_grad (the reference's validation / eval callers, "

@@ -359,6 +359,17 @@ int gsa_composite_bwd_lists(int width, int height, int channels, const float *sp
                             const float *v_render, const float *v_alpha, const uint32_t *quad_list,
                             const int32_t *quad_count, float *v_splat, int bin_tile, gsa_stream_t stream);
 
+/* ABI 13 -- gsa_composite_bwd_lists with the COLOUR moments going to v_rgb [N,3] (zeroed by the caller) instead of fields 6..8
+ * of the gradient record, already masked by the colour clamp (a channel the forward clamped at 0 -- its record colour is
+ * exactly 0 -- gets no gradient): d loss / d rgb per gaussian in the 12-byte layout the view-parallel exchange all-gathers,
+ * straight out of the sweep, so a rank's collective for view j is queued behind view j's SWEEP and the projection backward
+ * of all its views runs once per step (gsa_project_bwd_batch_geometry).  Fields 0..5 and 9 go to v_splat as before. */
+int gsa_composite_bwd_lists_rgb(int width, int height, int channels, const float *splat,
+                                const uint32_t *sorted_gid, int gid_boxes, const int32_t *tile_offsets, const float *background,
+                                const int32_t *tile_order, const float *final_T, const int32_t *last_id,
+                                const float *v_render, const float *v_alpha, const uint32_t *quad_list,
+                                const int32_t *quad_count, float *v_splat, float *v_rgb, int bin_tile, gsa_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Stage 5 (row a3.6): projection + SH backward.  Reads the sweep's moment records (stage 4), the raw
  * parameters and the saved radii; writes EVERY element of v_means[N,3], v_quats[N,4], v_scales[N,3],

@@ -305,6 +305,14 @@ def _bench_bucket(tmp_path, tag, gpus, views_per_gpu, streams, exchange="factore
            "--warmup", "1", "--views-per-gpu", str(views_per_gpu), "--view-streams", str(streams), "--exchange", exchange,
            "--no-cpu-baseline", "--views", "1", "--dump-grad", out, *extra]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    if res.returncode != 0:   # (the whole stderr of the ranks: the first rank to fail is rarely in the last lines)
+        try:
+            dump = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(HERE)), "gpurun_out")
+            os.makedirs(dump, exist_ok=True)
+            with open(os.path.join(dump, f"bench_{tag}.stderr"), "w") as fh:
+                fh.write(res.stderr)
+        except OSError:
+            pass
     assert res.returncode == 0, res.stderr[-3000:]
     line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
     return torch.load(out), line

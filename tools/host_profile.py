@@ -41,6 +41,10 @@ if os.environ.get("HOST_PROFILE_SECTIONS", "1") != "0":
     for nm in ("project_fwd", "bin_tiles", "tile_schedule", "composite_fwd", "composite_bwd", "project_bwd", "key_range_buffer",
                "_wait_slot", "_pinned_scalar", "f32c", "_call"):
         wrap(S, nm)
+    wrap(S.ViewChain, "forward", "ViewChain.forward")
+    wrap(S.ViewChain, "backward", "ViewChain.backward")
+    wrap(S, "_view_layout")
+    wrap(torch, "empty", "torch.empty")
     wrap(gsplat_amd, "rasterization", "rasterization()")
     wrap(torch.Tensor, "backward", "Tensor.backward")
 for j in range(20): view(j)
