@@ -717,16 +717,23 @@ struct BwdCamRows {
     const int32_t *radii[kMaxBatchCams];
     const float *v_splat[kMaxBatchCams];
     const float *sh_aux[kMaxBatchCams];
+    const float *v_rgb[kMaxBatchCams];   // GEOM_ONLY: camera c's masked d loss / d rgb [N,3] (the sweep's own output)
 };
 
-template <int DEG>
+// GEOM_ONLY (gsa_project_bwd_batch_geometry): the step of a view-parallel RANK.  The sweeps already left every camera's masked
+// colour gradient in the 12-byte exchange layout (gsa_composite_bwd_lists_rgb: the ranks' all-gathers travel behind the
+// sweeps, and every rank rebuilds the coefficient gradient of ALL views from the gathered slabs: gsa_sh_grad_expand), so this
+// launch only sums the geometry gradients of the rank's own cameras -- 44 B in, 44 B out per gaussian plus 124 B per camera
+// (gradient record 48, digest 48 + its flags, colour gradient 12, radii 8): the per-view launches it replaces read the
+// geometry per view and read-modify-write the sums.  No coefficient accumulators, no LDS rows: half the registers.
+template <int DEG, bool GEOM_ONLY = false>
 __global__ __launch_bounds__(kBlock, 1) void project_bwd_batch_kernel(
     int n, const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
     const float *__restrict__ opacities, const float *__restrict__ viewmats, const float *__restrict__ intrins, int n_cams,
     int intrin_stride, int width, int height, BwdCamRows rows_of, float *__restrict__ v_means, float *__restrict__ v_quats,
     float *__restrict__ v_scales, float *__restrict__ v_opacities, float *__restrict__ v_colors, int accumulate) {
     static_assert(DEG >= 1, "view-dependent colour only");
-    __shared__ float4 sh_lds[(kBlock / 64) * kWaveLds];   // rows out
+    __shared__ float4 sh_lds[GEOM_ONLY ? 1 : (kBlock / 64) * kWaveLds];   // rows out
     const int wave = threadIdx.x >> 6;
     const long i = (long)blockIdx.x * kBlock + threadIdx.x;
     const long wave_base = (long)blockIdx.x * kBlock + wave * 64;
@@ -750,6 +757,10 @@ __global__ __launch_bounds__(kBlock, 1) void project_bwd_batch_kernel(
         r.rx = rr.x; r.ry = rr.y;
         const float4 *vrow = reinterpret_cast<const float4 *>(rows_of.v_splat[ci] + ic * GSA_SPLAT_STRIDE);
         r.v0 = vrow[0]; r.v1 = vrow[1]; r.v2 = vrow[2];
+        if constexpr (GEOM_ONLY) {   // the colour moments are not in the record: the sweep put them, masked, into v_rgb
+            const float *c3 = rows_of.v_rgb[ci] + ic * 3;
+            r.v1.z = c3[0]; r.v1.w = c3[1]; r.v2.x = c3[2];
+        }
         const float4 *arow = reinterpret_cast<const float4 *>(rows_of.sh_aux[ci]) + ic * 3;
         r.a0 = arow[0]; r.a1 = arow[1]; r.a2 = arow[2];
         return r;
@@ -757,9 +768,9 @@ __global__ __launch_bounds__(kBlock, 1) void project_bwd_batch_kernel(
     CamRow cur = load_cam(0);
 
     float sm[3] = {0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f}, ss[3] = {0.f, 0.f, 0.f}, so = 0.f;
-    float vc[NB * 3];
+    float vc[GEOM_ONLY ? 1 : NB * 3];
 #pragma unroll
-    for (int k = 0; k < NB * 3; ++k) vc[k] = 0.f;
+    for (int k = 0; k < (GEOM_ONLY ? 1 : NB * 3); ++k) vc[k] = 0.f;
 
     for (int ci = 0; ci < n_cams; ++ci) {
         CamRow nxt = cur;
@@ -774,15 +785,17 @@ __global__ __launch_bounds__(kBlock, 1) void project_bwd_batch_kernel(
             {
                 const float dx = g_mean[0] - cam.campos[0], dy = g_mean[1] - cam.campos[1], dz = g_mean[2] - cam.campos[2];
                 const float inv = rsqrtf(dx * dx + dy * dy + dz * dz);
-                float B[NB];
-                gsa_sh_basis<DEG>(dx * inv, dy * inv, dz * inv, B);
                 const float vr[3] = {cur.a0.w != 0.f ? v_rgb[0] : 0.f, cur.a1.w != 0.f ? v_rgb[1] : 0.f,
                                      cur.a2.w != 0.f ? v_rgb[2] : 0.f};
+                if constexpr (!GEOM_ONLY) {
+                    float B[NB];
+                    gsa_sh_basis<DEG>(dx * inv, dy * inv, dz * inv, B);
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    vc[3 * j] = __builtin_fmaf(B[j], vr[0], vc[3 * j]);
-                    vc[3 * j + 1] = __builtin_fmaf(B[j], vr[1], vc[3 * j + 1]);
-                    vc[3 * j + 2] = __builtin_fmaf(B[j], vr[2], vc[3 * j + 2]);
+                    for (int j = 0; j < NB; ++j) {
+                        vc[3 * j] = __builtin_fmaf(B[j], vr[0], vc[3 * j]);
+                        vc[3 * j + 1] = __builtin_fmaf(B[j], vr[1], vc[3 * j + 1]);
+                        vc[3 * j + 2] = __builtin_fmaf(B[j], vr[2], vc[3 * j + 2]);
+                    }
                 }
                 vdir[0] = cur.a0.x * vr[0] + cur.a1.x * vr[1] + cur.a2.x * vr[2];
                 vdir[1] = cur.a0.y * vr[0] + cur.a1.y * vr[1] + cur.a2.y * vr[2];
@@ -816,6 +829,7 @@ __global__ __launch_bounds__(kBlock, 1) void project_bwd_batch_kernel(
     }
 
     // ---- the coefficient-gradient rows leave through the wave's LDS image, 32 whole rows a pass (as the single-camera kernel)
+    if constexpr (!GEOM_ONLY) {
     float4 *wrows = &sh_lds[wave * kWaveLds];
     float4 *dst = reinterpret_cast<float4 *>(v_colors) + wave_base * kRowQ;
     auto elem = [&](int e) { return e < NB * 3 ? vc[e] : 0.f; };
@@ -854,6 +868,7 @@ __global__ __launch_bounds__(kBlock, 1) void project_bwd_batch_kernel(
             }
         }
     }
+    }   // !GEOM_ONLY
 }
 
 template <int DEG>
@@ -1240,42 +1255,77 @@ extern "C" int gsa_sh_grad_expand_split(int n, const float *means, int sh_degree
     return sh_grad_expand_impl(n, means, sh_degree, sh_coeffs, n_views, viewmats, intrin, v_rgb, v_dc, 0, v_rest, stream);
 }
 
-extern "C" int gsa_project_bwd_batch(int n, const float *means, const float *quats, const float *scales,
-                                     const float *opacities, int sh_degree, int sh_coeffs, int n_cams, const float *viewmats,
-                                     const float *intrins, int intrin_stride, int width, int height,
-                                     const int32_t *const *radii, const float *const *v_splat, const float *const *sh_aux,
-                                     float *v_means, float *v_quats, float *v_scales, float *v_opacities, float *v_colors,
-                                     int accumulate, gsa_stream_t stream) {
+static int project_bwd_batch_impl(int n, const float *means, const float *quats, const float *scales,
+                                  const float *opacities, int sh_degree, int sh_coeffs, int n_cams, const float *viewmats,
+                                  const float *intrins, int intrin_stride, int width, int height,
+                                  const int32_t *const *radii, const float *const *v_splat, const float *const *sh_aux,
+                                  const float *const *v_rgb, float *v_means, float *v_quats, float *v_scales,
+                                  float *v_opacities, float *v_colors, int accumulate, gsa_stream_t stream) {
+    const bool geom = v_rgb != nullptr;
     GSA_RETURN_IF(n < 0 || width <= 0 || height <= 0 || n_cams < 1 || (intrin_stride != 0 && intrin_stride != 9),
                   GSA_ERR_INVALID_ARGUMENT);
-    GSA_RETURN_IF(sh_degree < 1 || sh_degree > 3 || sh_coeffs != 16 || n_cams > kMaxBatchCams, GSA_ERR_UNSUPPORTED);
+    GSA_RETURN_IF(sh_degree < 1 || sh_degree > 3 || (!geom && sh_coeffs != 16) || n_cams > kMaxBatchCams, GSA_ERR_UNSUPPORTED);
     if (n == 0) return GSA_OK;
     GSA_RETURN_IF(!means || !quats || !scales || !opacities || !viewmats || !intrins || !radii || !v_splat || !sh_aux ||
-                      !v_means || !v_quats || !v_scales || !v_opacities || !v_colors,
+                      !v_means || !v_quats || !v_scales || !v_opacities || (!geom && !v_colors),
                   GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF((reinterpret_cast<uintptr_t>(v_colors) & 15) != 0 || (reinterpret_cast<uintptr_t>(quats) & 15) != 0,
                   GSA_ERR_INVALID_ARGUMENT);
     BwdCamRows rows{};
     for (int c = 0; c < kMaxBatchCams; ++c) {   // (unused slots repeat the last camera: never read)
         const int k = c < n_cams ? c : n_cams - 1;
-        GSA_RETURN_IF(!radii[k] || !v_splat[k] || !sh_aux[k], GSA_ERR_INVALID_ARGUMENT);
+        GSA_RETURN_IF(!radii[k] || !v_splat[k] || !sh_aux[k] || (geom && !v_rgb[k]), GSA_ERR_INVALID_ARGUMENT);
         GSA_RETURN_IF(((reinterpret_cast<uintptr_t>(v_splat[k]) | reinterpret_cast<uintptr_t>(sh_aux[k])) & 15) != 0 ||
                           (reinterpret_cast<uintptr_t>(radii[k]) & 7) != 0,
                       GSA_ERR_INVALID_ARGUMENT);
         rows.radii[c] = radii[k]; rows.v_splat[c] = v_splat[k]; rows.sh_aux[c] = sh_aux[k];
+        rows.v_rgb[c] = geom ? v_rgb[k] : nullptr;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     dim3 grid(gsa_div_up(n, kBlock)), block(kBlock);
-#define GSA_BWDB(D)                                                                                                        \
-    project_bwd_batch_kernel<D><<<grid, block, 0, s>>>(n, means, quats, scales, opacities, viewmats, intrins, n_cams,      \
-                                                       intrin_stride, width, height, rows, v_means, v_quats, v_scales,    \
-                                                       v_opacities, v_colors, accumulate ? 1 : 0)
-    switch (sh_degree) {
-        case 1: GSA_BWDB(1); break;
-        case 2: GSA_BWDB(2); break;
-        default: GSA_BWDB(3); break;
+#define GSA_BWDB(D, G)                                                                                                     \
+    project_bwd_batch_kernel<D, G><<<grid, block, 0, s>>>(n, means, quats, scales, opacities, viewmats, intrins, n_cams,   \
+                                                          intrin_stride, width, height, rows, v_means, v_quats, v_scales, \
+                                                          v_opacities, v_colors, accumulate ? 1 : 0)
+    if (geom) {
+        switch (sh_degree) {
+            case 1: GSA_BWDB(1, true); break;
+            case 2: GSA_BWDB(2, true); break;
+            default: GSA_BWDB(3, true); break;
+        }
+    } else {
+        switch (sh_degree) {
+            case 1: GSA_BWDB(1, false); break;
+            case 2: GSA_BWDB(2, false); break;
+            default: GSA_BWDB(3, false); break;
+        }
     }
 #undef GSA_BWDB
     GSA_LAUNCH_CHECK();
     return GSA_OK;
+}
+
+extern "C" int gsa_project_bwd_batch(int n, const float *means, const float *quats, const float *scales,
+                                     const float *opacities, int sh_degree, int sh_coeffs, int n_cams, const float *viewmats,
+                                     const float *intrins, int intrin_stride, int width, int height,
+                                     const int32_t *const *radii, const float *const *v_splat, const float *const *sh_aux,
+                                     float *v_means, float *v_quats, float *v_scales, float *v_opacities, float *v_colors,
+                                     int accumulate, gsa_stream_t stream) {
+    GSA_RETURN_IF(!v_colors && n > 0, GSA_ERR_INVALID_ARGUMENT);
+    return project_bwd_batch_impl(n, means, quats, scales, opacities, sh_degree, sh_coeffs, n_cams, viewmats, intrins,
+                                  intrin_stride, width, height, radii, v_splat, sh_aux, nullptr, v_means, v_quats, v_scales,
+                                  v_opacities, v_colors, accumulate, stream);
+}
+
+extern "C" int gsa_project_bwd_batch_geometry(int n, const float *means, const float *quats, const float *scales,
+                                              const float *opacities, int sh_degree, int n_cams, const float *viewmats,
+                                              const float *intrins, int intrin_stride, int width, int height,
+                                              const int32_t *const *radii, const float *const *v_splat,
+                                              const float *const *sh_aux, const float *const *v_rgb, float *v_means,
+                                              float *v_quats, float *v_scales, float *v_opacities, int accumulate,
+                                              gsa_stream_t stream) {
+    GSA_RETURN_IF(!v_rgb, GSA_ERR_INVALID_ARGUMENT);
+    return project_bwd_batch_impl(n, means, quats, scales, opacities, sh_degree, 16, n_cams, viewmats, intrins, intrin_stride,
+                                  width, height, radii, v_splat, sh_aux, v_rgb, v_means, v_quats, v_scales, v_opacities, nullptr,
+                                  accumulate, stream);
 }

@@ -44,9 +44,13 @@ extern "C" int gsa_view_bwd(const gsa_view_args *a, gsa_stream_t stream) {
     // (the forward sweep cleared the gradient records on the side: n = 0 -- only the tiles are ordered by their blended records)
     int rc = gsa_composite_bwd_prepare(0, a->v_splat, tile_w * tile_h, a->quad_count, a->bwd_tile_order, stream);
     if (rc != GSA_OK) return rc;
-    rc = gsa_composite_bwd_lists(a->width, a->height, a->channels, a->splat, a->sorted_gid, a->gid_boxes, a->tile_offsets,
-                                 a->background, a->bwd_tile_order, a->final_T, a->last_id, a->v_render, a->v_alpha,
-                                 a->quad_list, a->quad_count, a->v_splat, a->bin_tile, stream);
+    rc = a->sweep_rgb
+             ? gsa_composite_bwd_lists_rgb(a->width, a->height, a->channels, a->splat, a->sorted_gid, a->gid_boxes, a->tile_offsets,
+                                           a->background, a->bwd_tile_order, a->final_T, a->last_id, a->v_render, a->v_alpha,
+                                           a->quad_list, a->quad_count, a->v_splat, a->sweep_rgb, a->bin_tile, stream)
+             : gsa_composite_bwd_lists(a->width, a->height, a->channels, a->splat, a->sorted_gid, a->gid_boxes, a->tile_offsets,
+                                       a->background, a->bwd_tile_order, a->final_T, a->last_id, a->v_render, a->v_alpha,
+                                       a->quad_list, a->quad_count, a->v_splat, a->bin_tile, stream);
     if (rc != GSA_OK || a->project_mode == 0) return rc;
     if (a->wait_bucket) {   // the gradient bucket is summed into in view order: the previous view's accumulation
         hipError_t e = hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(a->wait_bucket), 0);

@@ -39,6 +39,7 @@ class ViewArgs(ctypes.Structure):
         ("means", P), ("quats", P), ("scales", P), ("opacities", P), ("colors", P), ("viewmat", P), ("intrin", P), ("sh_aux", P),
         ("radii", P),
         ("v_means", P), ("v_quats", P), ("v_scales", P), ("v_opacities", P), ("v_colors", P), ("v_rgb", P),
+        ("sweep_rgb", P),
     ]
 
 
@@ -96,6 +97,8 @@ SIGNATURES = {
     "gsa_project_bwd_factored": (c_int, [c_int, P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, P, P, P, P, P, P, P, P, c_int, P, P]),
     "gsa_project_bwd_batch": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P,
                                       c_int, P]),
+    "gsa_project_bwd_batch_geometry": (c_int, [c_int, P, P, P, P, c_int, c_int, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P,
+                                               c_int, P]),
     "gsa_sh_grad_expand_split": (c_int, [c_int, P, c_int, c_int, c_int, P, P, P, P, P, P]),
     "gsa_activate_fwd": (c_int, [c_longlong, P, P, P, P, P, P, P, P, P, P]),
     "gsa_activate_partials": (c_size_t, [c_longlong]),

@@ -617,6 +617,10 @@ class ViewParallelTrainer:
         same_frame = len(mine) > 1 and len({(v["width"], v["height"]) for v in mine}) == 1
         batch_bwd = same_frame and self.world == 1 and degree >= 1 and len(mine) <= 8 and m.sh.shape[1] == 16
         factored = self.factored and not batch_bwd
+        # ... with several ranks (r05): every view's backward SWEEP leaves its masked colour gradient in the exchange's [N,3]
+        # slot, and the geometry gradients of the rank's views are summed by ONE launch behind the last sweep
+        # (stages.project_views_bwd(v_rgbs=...)) -- instead of one factored projection backward per view
+        rank_batch = factored and same_frame and degree >= 1 and len(mine) <= 8
         if factored:  # slot (r, j) = the j-th view of rank r; ranks with fewer views leave zeros (skipped by the expand)
             slots = -(-n_views // self.world)
             vr_all = torch.empty(self.world, slots, n, 3, device=dev)   # (every slot of a view is written whole by its backward)
@@ -718,8 +722,8 @@ class ViewParallelTrainer:
             view, pose, splat, radii, fwd, aux, v = state.payload
             W, H = view["width"], view["height"]
             if isinstance(fwd, S.ViewChain):   # reverse sweep (+ this view's projection backward) in ONE call: gsa_view_bwd
-                if batch_bwd:
-                    fwd.backward(v)
+                if batch_bwd or rank_batch:
+                    fwd.backward(v, sweep_rgb=vr_all[self.rank, j] if rank_batch else None)
                     shared.setdefault("v_splat", {})[j] = fwd.view("v_splat")
                 else:
                     fwd.backward(v, project={"means": leaves[0], "quats": leaves[1], "scales": leaves[2], "opacities": leaves[3],
@@ -730,8 +734,9 @@ class ViewParallelTrainer:
                 return
             bins, order, final_T, last_id, lists = fwd
             v_splat = S.composite_bwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bgc, final_T, last_id, v, None,
-                                      W, H, 3, order, quad_lists=lists, bin_tile=bins.bin_tile, gid_boxes=bins.boxed)
-            if batch_bwd:   # (finished for all views at once, below)
+                                      W, H, 3, order, quad_lists=lists, bin_tile=bins.bin_tile, gid_boxes=bins.boxed,
+                                      v_rgb_out=vr_all[self.rank, j] if rank_batch else None)
+            if batch_bwd or rank_batch:   # (finished for all views at once, below)
                 shared.setdefault("v_splat", {})[j] = v_splat
                 return
             if before_bucket is not None:   # (the bucket is summed into in view order)
@@ -743,12 +748,12 @@ class ViewParallelTrainer:
         def finish():
             ok = S.project_views_bwd(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], degree, shared["views"],
                                      [shared["v_splat"][j] for j in range(len(mine))], mine[0]["width"], mine[0]["height"],
-                                     grad_out)
+                                     grad_out, v_rgbs=[vr_all[self.rank, j] for j in range(len(mine))] if rank_batch else None)
             assert ok, "project_views_bwd refused a configuration batch_bwd admitted"
             shared.pop("v_splat")
 
         self._pipe.run(len(mine), forward, backward, inputs_ready=params_ready, defer=not exact,
-                       prepare=prepare if same_frame else None, finish=finish if batch_bwd else None)
+                       prepare=prepare if same_frame else None, finish=finish if (batch_bwd or rank_batch) else None)
         first = not mine
         if first:                                          # this rank rendered nothing
             m.flat_grad.zero_()

@@ -160,11 +160,12 @@ class _RasterizeOneCamera(torch.autograd.Function):
         if quad_list is not None:
             lists = S.QuadLists((quad_list, quad_count))
             lists.zeroed, ctx.zeroed_records = ctx.zeroed_records, None
+        rgb_here = ctx.sh_grad_factored if (ctx.deferred_projection is not None and lists is not None) else None
         v_splat = S.composite_bwd(splat, sorted_gid, tile_offsets, bg_c, final_T, last_id, v_render, v_alpha_c,
                                   width, height, channels, tile_order,
-                                  quad_lists=lists, bin_tile=ctx.bin_tile, gid_boxes=ctx.gid_boxes)
+                                  quad_lists=lists, bin_tile=ctx.bin_tile, gid_boxes=ctx.gid_boxes, v_rgb_out=rgb_here)
         if ctx.deferred_projection is not None:
-            ctx.deferred_projection.v_splat = v_splat
+            ctx.deferred_projection.v_splat, ctx.deferred_projection.v_rgb = v_splat, rgb_here
             return (None,) * 20
         grads = S.project_bwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
                               splat, radii, v_splat, out=ctx.grad_out, accumulate=ctx.grad_accumulate,
@@ -186,8 +187,10 @@ def _backward_chain(ctx, v_render, v_alpha):
     v_render = v_render.to(torch.float32).contiguous()
     v_alpha_c = None if v_alpha is None else v_alpha.to(torch.float32).contiguous()
     if ctx.deferred_projection is not None:
-        chain.backward(v_render, v_alpha_c)
-        ctx.deferred_projection.v_splat = chain.view("v_splat")
+        # (with sh_grad_factored: the sweep itself leaves the masked colour gradient in the exchange layout, and
+        # project_cameras_backward finishes the cameras' GEOMETRY in one launch -- the step of a view-parallel rank)
+        chain.backward(v_render, v_alpha_c, sweep_rgb=ctx.sh_grad_factored)
+        ctx.deferred_projection.v_splat, ctx.deferred_projection.v_rgb = chain.view("v_splat"), ctx.sh_grad_factored
         return (None,) * 20
     out = S.project_bwd_outputs(means_c, quats_c, scales_c, opac_c, colors_c, ctx.grad_out, ctx.grad_accumulate,
                                 ctx.sh_grad_factored, sh_aux)
@@ -259,7 +262,10 @@ def project_cameras_backward(projections, means, quats, scales, opacities, color
     ``grad_out`` = (means, quats, scales, opacities [N], colors [N,16,3] shaped tensors; ``accumulate``: added to them).
     What it saves against one projection backward per camera: the geometry is read once instead of once per camera, no
     gradient is read back and added to, and the SH-coefficient gradient -- sum over the cameras of basis(direction) x
-    d loss / d rgb -- is formed in registers instead of by an expansion kernel."""
+    d loss / d rgb -- is formed in registers instead of by an expansion kernel.
+    Cameras that were backpropagated with ``sh_grad_factored`` (the sweeps left d loss / d rgb in the caller's [N,3] tensors):
+    only the four GEOMETRY gradients are written; ``grad_out[4]`` is not touched (the caller rebuilds the coefficient gradient
+    of all views -- its own and the other ranks' -- with ``stages.sh_grad_expand``)."""
     if not projections or not all(p.defer_backward for p in projections):
         raise ValueError("project_cameras_backward: these projections were not made with a deferred backward (project_cameras("
                          "defer_backward=True) drops the flag where the shared launch does not apply -- its result's `.deferred` "
@@ -267,13 +273,17 @@ def project_cameras_backward(projections, means, quats, scales, opacities, color
     if any(p.v_splat is None for p in projections):
         raise RuntimeError("project_cameras_backward: a camera's output has not been backpropagated yet")
     width, height, _, deg = projections[0].dims
+    with_rgb = [p.v_rgb is not None for p in projections]
+    if any(with_rgb) and not all(with_rgb):
+        raise RuntimeError("project_cameras_backward: some cameras were backpropagated with sh_grad_factored and some without")
     done = S.project_views_bwd(S.f32c(means, "means"), S.f32c(quats, "quats"), S.f32c(scales, "scales"),
                                S.f32c(opacities, "opacities"), S.f32c(colors, "colors"), deg, projections,
-                               [p.v_splat for p in projections], width, height, grad_out, accumulate=accumulate)
+                               [p.v_splat for p in projections], width, height, grad_out, accumulate=accumulate,
+                               v_rgbs=[p.v_rgb for p in projections] if all(with_rgb) else None)
     if not done:
         raise RuntimeError("project_cameras_backward: the batched kernel does not cover this configuration")
     for p in projections:
-        p.v_splat = None
+        p.v_splat = p.v_rgb = None
 
 
 def rasterization(
@@ -318,6 +328,9 @@ def rasterization(
     gaussian instead of the [N,K,3] SH-coefficient gradient (``colors`` then gets no gradient; ``grad_out[4]`` is not
     written).  The coefficient gradient is the outer product of the view's SH basis with it
     (``stages.sh_grad_expand``): the form in which view-parallel ranks exchange it -- 3 floats instead of 48.
+    With a ``projection`` of ``project_cameras(defer_backward=True)`` the backward SWEEP itself leaves it there (masked by the
+    colour clamp), and ``project_cameras_backward`` then only sums the cameras' geometry gradients: a rank queues its
+    all-gather for a view right behind the view's sweep.
     ``defer_check`` (extension): the bins are sized for a remembered record capacity and the depth ordering assumes a
     remembered key range; by default the call waits (host side) for the view's control words once its sweep is queued and
     repeats the binning if either was too small, so what it returns is always right.  With ``defer_check=True`` it does
@@ -368,8 +381,11 @@ def rasterization(
         raise ValueError("grad_out needs a single camera (each camera's backward would overwrite it)")
     if grad_accumulate and grad_out is None:
         raise ValueError("grad_accumulate needs grad_out")
-    if sh_grad_factored is not None and (grad_out is None or sh_degree is None):
-        raise ValueError("sh_grad_factored needs grad_out and SH colours (sh_degree given)")
+    deferred_cams = projection is not None and all(getattr(p_, "defer_backward", False) for p_ in
+                                                   (projection if isinstance(projection, (list, tuple)) else [projection]))
+    if sh_grad_factored is not None and ((grad_out is None and not deferred_cams) or sh_degree is None or C != 1):
+        raise ValueError("sh_grad_factored needs SH colours (sh_degree given), a single camera, and grad_out or a projection "
+                         "with a deferred backward")
     width, height = int(width), int(height)
     cull = S.DEFAULT_CULL_MODE if cull_mode is None else int(cull_mode)
     want_depth = render_mode != "RGB"

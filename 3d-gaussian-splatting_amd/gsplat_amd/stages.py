@@ -324,7 +324,7 @@ class ViewProjection:
     a key range and quadrant boxes): what the binning, the sweeps and ``project_bwd`` of that view need."""
 
     __slots__ = ("splat", "radii", "tiles_touched", "depth_keys", "tile_rects", "sh_aux", "key_range", "qbox", "viewmat",
-                 "Kmat", "bin_tile", "dims", "defer_backward", "v_splat", "made_from", "camera_stamp", "records_ready")
+                 "Kmat", "bin_tile", "dims", "defer_backward", "v_splat", "made_from", "camera_stamp", "records_ready", "v_rgb")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -384,26 +384,33 @@ def project_views(means, quats, scales, opacities, colors, sh_degree: int, viewm
                            qbox=None if qbox is None else qbox[c], viewmat=vm[c], Kmat=km[c] if km.dim() == 3 else km,
                            bin_tile=bt, dims=(width, height, cull_mode, sh_degree), defer_backward=False, v_splat=None,
                            made_from=None, camera_stamp=input_stamp(vm[c], km[c] if km.dim() == 3 else km),
-                           records_ready=done)
+                           records_ready=done, v_rgb=None)
             for c in range(C)]
 
 
 def project_views_bwd(means, quats, scales, opacities, colors, sh_degree: int, views, v_splats, width: int, height: int,
-                      out, accumulate: bool = False) -> bool:
+                      out, accumulate: bool = False, v_rgbs=None) -> bool:
     """The backward projection of ALL of ``views`` (``ViewProjection``s of one ``project_views`` call, or any per-camera
     projections with digests) in ONE launch (``gsa_project_bwd_batch``): ``v_splats[c]`` is camera c's gradient record from
     ``composite_bwd``; ``out`` = (v_means, v_quats, v_scales, v_opacities, v_colors) receives the gradients summed over the
     cameras -- written once (``accumulate``: added).  -> False (nothing launched) where the batched kernel does not apply
     (no digests: SH degree < 1; more than 8 cameras; coefficient rows that are not [N,16,3]): the caller then runs
-    ``project_bwd`` per camera."""
+    ``project_bwd`` per camera.
+    ``v_rgbs`` (one [N,3] tensor per camera: what ``composite_bwd(v_rgb_out=...)`` left): the GEOMETRY-only launch of a
+    view-parallel rank (``gsa_project_bwd_batch_geometry``) -- ``out[4]`` is not written (may be None): the coefficient
+    gradient of all views is rebuilt from the gathered colour gradients (``sh_grad_expand``)."""
     C = len(views)
-    if C < 1 or C > 8 or sh_degree < 1 or colors.dim() != 3 or colors.shape[1] != 16 or any(v.sh_aux is None for v in views):
+    geom = v_rgbs is not None
+    if C < 1 or C > 8 or sh_degree < 1 or any(v.sh_aux is None for v in views) or \
+            (not geom and (colors.dim() != 3 or colors.shape[1] != 16)):
         return False
     N = means.shape[0]
     v_means, v_quats, v_scales, v_opac, v_colors = out
-    for got, like in zip(out, (means, quats, scales, opacities, colors)):
+    for got, like in zip(out[:4] if geom else out, (means, quats, scales, opacities, colors)):
         if got.numel() != like.numel() or got.dtype != torch.float32 or not got.is_contiguous() or got.device != like.device:
             raise ValueError("project_views_bwd: out tensors must be contiguous fp32, sized like the inputs, on their device")
+    if geom and (len(v_rgbs) != C or any(t.shape != (N, 3) or t.dtype != torch.float32 or not t.is_contiguous() for t in v_rgbs)):
+        raise ValueError("project_views_bwd: v_rgbs must be one contiguous fp32 [N,3] tensor per camera")
     vms = torch.stack([v.viewmat for v in views]).contiguous()
     shared_k = all(v.Kmat is views[0].Kmat or v.Kmat.data_ptr() == views[0].Kmat.data_ptr() for v in views)
     kms = views[0].Kmat.contiguous() if shared_k else torch.stack([v.Kmat for v in views]).contiguous()
@@ -421,6 +428,16 @@ def project_views_bwd(means, quats, scales, opacities, colors, sh_degree: int, v
     radii = arr(*[v.radii.data_ptr() for v in views])
     vsp = arr(*[t.data_ptr() for t in keep])
     aux = arr(*[v.sh_aux.data_ptr() for v in views])
+    if geom:
+        for t in v_rgbs:
+            t.record_stream(here)
+        rgb = arr(*[t.data_ptr() for t in v_rgbs])
+        _call("gsa_project_bwd", lib.gsa_project_bwd_batch_geometry, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
+              sh_degree, C, _ptr(vms), _ptr(kms), 0 if shared_k else 9, width, height, ctypes.cast(radii, ctypes.c_void_p),
+              ctypes.cast(vsp, ctypes.c_void_p), ctypes.cast(aux, ctypes.c_void_p), ctypes.cast(rgb, ctypes.c_void_p),
+              _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac), 1 if accumulate else 0, _stream())
+        del v_rgbs
+        return True
     _call("gsa_project_bwd", lib.gsa_project_bwd_batch, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), sh_degree,
           int(colors.shape[1]), C, _ptr(vms), _ptr(kms), 0 if shared_k else 9, width, height,
           ctypes.cast(radii, ctypes.c_void_p), ctypes.cast(vsp, ctypes.c_void_p), ctypes.cast(aux, ctypes.c_void_p),
@@ -1012,10 +1029,17 @@ def record_grads_to_moments(splat: torch.Tensor, g: torch.Tensor) -> torch.Tenso
 
 def composite_bwd(splat, sorted_gid, tile_offsets, background, final_T, last_id, v_render, v_alpha, width: int,
                   height: int, channels: int, tile_order=None, quad_lists=None, bin_tile: int = TILE_SIZE,
-                  gid_boxes: bool = False):
+                  gid_boxes: bool = False, v_rgb_out: Optional[torch.Tensor] = None):
     """-> v_splat [N,16]: per gaussian the raw moments of u = d loss / d sigma over d = mean2d - pixel
     (sum u dx, u dy, u dx^2, u dx dy, u dy^2, u) and sum fac * v_out per channel -- the gradient record
-    ``project_bwd`` consumes (``moments_to_record_grads`` gives the mean / conic / opacity gradients)."""
+    ``project_bwd`` consumes (``moments_to_record_grads`` gives the mean / conic / opacity gradients).
+    ``v_rgb_out`` (a contiguous fp32 [N,3] tensor; sweeps over the forward's lists only): receives the colour moments --
+    fields 6..8 -- already masked by the forward's colour clamp, i.e. d loss / d rgb per gaussian in the layout the
+    view-parallel exchange all-gathers (it is zeroed here; those fields of ``v_splat`` stay zero)."""
+    if v_rgb_out is not None:
+        if quad_lists is None or v_rgb_out.shape != (splat.shape[0], 3) or v_rgb_out.dtype != torch.float32 or not v_rgb_out.is_contiguous():
+            raise ValueError("composite_bwd(v_rgb_out=...): needs the forward's lists and a contiguous fp32 [N,3] tensor")
+        v_rgb_out.zero_()
     if quad_lists is not None:   # sweep the forward pass's lists of blended records (same result, fewer visits)
         quad_list, quad_count = quad_lists
         # one launch: order the tiles by the work the lists hold (exact, unlike the list lengths `tile_order` was built
@@ -1031,6 +1055,11 @@ def composite_bwd(splat, sorted_gid, tile_offsets, background, final_T, last_id,
             tile_order = torch.empty(8 * ((tile_w * tile_h + 7) // 8), dtype=torch.int32, device=splat.device)
             _call("gsa_composite_bwd_prepare", lib.gsa_composite_bwd_prepare, splat.shape[0] if fill else 0, _ptr(v_splat),
                   tile_w * tile_h, _ptr(quad_count), _ptr(tile_order), _stream())
+        if v_rgb_out is not None:
+            _call("gsa_composite_bwd", lib.gsa_composite_bwd_lists_rgb, width, height, channels, _ptr(splat), _ptr(sorted_gid),
+                  1 if gid_boxes else 0, _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(final_T), _ptr(last_id),
+                  _ptr(v_render), _ptr(v_alpha), _ptr(quad_list), _ptr(quad_count), _ptr(v_splat), _ptr(v_rgb_out), bin_tile, _stream())
+            return v_splat
         _call("gsa_composite_bwd", lib.gsa_composite_bwd_lists, width, height, channels, _ptr(splat), _ptr(sorted_gid),
               1 if gid_boxes else 0, _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(final_T), _ptr(last_id), _ptr(v_render),
               _ptr(v_alpha), _ptr(quad_list), _ptr(quad_count), _ptr(v_splat), bin_tile, _stream())
@@ -1240,17 +1269,23 @@ class ViewChain:
             v = self._views[name] = flat.view(shape) if shape else flat
         return v
 
-    def backward(self, v_render, v_alpha=None, project=None, wait_bucket=None):
+    def backward(self, v_render, v_alpha=None, project=None, wait_bucket=None, sweep_rgb=None):
         """Queues the view's backward on the current stream.  ``project``: None -- stop behind the sweep (the gradient record
         is ``view('v_splat')``; ``project_views_bwd`` finishes the step's views) -- or a dict {means, quats, scales, opacities,
         colors, sh_degree, viewmat, Kmat, radii, sh_aux, out: (v_means .. v_colors), accumulate, v_rgb_out}: the projection
-        backward behind the sweep, as ``project_bwd``.  ``wait_bucket``: an event the stream waits for in front of it."""
+        backward behind the sweep, as ``project_bwd``.  ``wait_bucket``: an event the stream waits for in front of it.
+        ``sweep_rgb``: as ``composite_bwd(v_rgb_out=...)`` (zeroed here)."""
         if not self.has_lists:
             raise RuntimeError("ViewChain.backward: the forward was run without lists (no backward was announced)")
         a = self.args
         a.v_render = v_render.data_ptr()
         a.v_alpha = None if v_alpha is None else v_alpha.data_ptr()
-        held = [v_render, v_alpha]
+        held = [v_render, v_alpha, sweep_rgb]
+        if sweep_rgb is not None:
+            if sweep_rgb.shape != (self.dims[0], 3) or sweep_rgb.dtype != torch.float32 or not sweep_rgb.is_contiguous():
+                raise ValueError("ViewChain.backward(sweep_rgb=...): a contiguous fp32 [N,3] tensor")
+            sweep_rgb.zero_()
+        a.sweep_rgb = None if sweep_rgb is None else sweep_rgb.data_ptr()
         if project is None:
             a.project_mode = 0
         else:

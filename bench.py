@@ -443,6 +443,11 @@ def main() -> None:
         batch_bwd = batch_proj and dist is None and deg >= 1 and views <= 8 and not args.no_batch_backward and not rank_form   # (the kernel's camera limit)
         # one process, one view: nothing to sum, the backward writes the whole gradient itself
         factored = form == "factored" and (world > 1 or views > 1) and not batch_bwd
+        # ... and for the RANKS of a view-parallel run (r05): every view's backward SWEEP leaves its masked colour gradient in
+        # the exchange's [N,3] slot (the all-gather of view j is queued behind view j's sweep, under view j + 1), and the
+        # geometry gradients of the rank's views are summed by ONE launch behind the last sweep (project_cameras_backward on
+        # projections that carry v_rgb) -- instead of one factored projection backward per view
+        rank_batch = factored and batch_proj and deg >= 1 and views <= 8 and not args.no_batch_backward
         ex = Exchange(dist, world, rank, n, views, factored, dev, expand=stages.sh_grad_expand)
         pipe = ViewPipeline(dev, n_streams)
         cams, windows = (ring(ring_size) if cams_override is None else cams_override), {}
@@ -462,7 +467,7 @@ def main() -> None:
                     step_cams[base] = cams[idx].contiguous()
                 shared["proj"] = gsplat_amd.project_cameras(leaves[0], leaves[1], leaves[2], opac.squeeze(-1), leaves[4],
                                                             step_cams[base], K[0], width, height, sh_degree=deg,
-                                                            cull_mode=args.cull_mode, defer_backward=batch_bwd)
+                                                            cull_mode=args.cull_mode, defer_backward=batch_bwd or rank_batch)
                 return gsplat_amd.projection_buffers(shared["proj"])
 
             def forward(j: int, deferred: bool) -> ViewState:
@@ -485,7 +490,7 @@ def main() -> None:
             def backward(j: int, state: ViewState, before_bucket) -> None:
                 # (with the shared projection backward a view's own backward pass stops behind its sweep and never touches
                 # the bucket: nothing to wait for)
-                if before_bucket is not None and not batch_bwd:
+                if before_bucket is not None and not (batch_bwd or rank_batch):
                     torch.cuda.current_stream().wait_event(before_bucket)
                 state.payload.backward(v_render)
 
@@ -500,7 +505,7 @@ def main() -> None:
                                                     grad_views)
 
             pipe.run(views, forward, backward, after_view=after_view, agree=agree if dist is not None else None, defer=defer,
-                     prepare=prepare if batch_proj else None, finish=finish if batch_bwd else None)
+                     prepare=prepare if batch_proj else None, finish=finish if (batch_bwd or rank_batch) else None)
             if factored or dist is not None:
                 if base not in windows:   # the cameras of the step's views, entry j * world + r = rank r's view j
                     windows[base] = cams[torch.tensor(step_window(i, views, world, ring_size), device=dev)].contiguous()
@@ -513,7 +518,7 @@ def main() -> None:
 
         step.exchange = ex
         step.pipe = pipe
-        step.batch_proj, step.batch_bwd = batch_proj, batch_bwd
+        step.batch_proj, step.batch_bwd, step.rank_batch = batch_proj, batch_bwd, rank_batch
         return step
 
     def fence():
@@ -835,7 +840,9 @@ def main() -> None:
                        "overlap": ("alternate" if n_streams > 1 else "none"),
                        # what the views of a step share: one projection launch (and, in one process, one projection-backward
                        # launch) for all of them -- gsplat_amd.project_cameras / project_cameras_backward
-                       "projection": ("per step: %s" % ("forward + backward" if head_step.batch_bwd else "forward"))
+                       "projection": ("per step: %s" % ("forward + backward" if head_step.batch_bwd else
+                                                         "forward + geometry backward (colour gradients out of the sweeps)"
+                                                         if head_step.rank_batch else "forward"))
                                      if head_step.batch_proj else "per view",
                        "speculation_check": ("per step, repairs: %d" % head_step.pipe.repairs) if B > 1 and not args.no_defer_check else "per view",
                        "ms_per_view": round(ms_per_view, 4), "ring_cameras": head_ring,
@@ -926,8 +933,9 @@ def main() -> None:
                                   "key_range_repairs_per_100": round(st["key_range_repairs"] * per100, 2)}
         if rank_step is not None:
             rs_ms = rank_step["s"] / args.steps * 1e3 / B
-            line["rank_step"] = {"what": "the step a rank of an N > 1 run executes (shared projection forward, per-view factored "
-                                         "projection backward, local SH rebuild; no collectives in this process)",
+            line["rank_step"] = {"what": "the step a rank of an N > 1 run executes (shared projection forward; every sweep leaves its "
+                                         "masked colour gradient in the exchange layout; ONE geometry-only projection backward per "
+                                         "step; local SH rebuild; no collectives in this process)",
                                  "ms_per_view": round(rs_ms, 4), "value": round(p / rs_ms / 1e3, 3),
                                  "frac": round(ring_bytes / (rs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
         if fwd_only is not None:

@@ -428,6 +428,19 @@ int gsa_project_bwd_batch(int n, const float *means, const float *quats, const f
                           float *v_means, float *v_quats, float *v_scales, float *v_opacities, float *v_colors,
                           int accumulate, gsa_stream_t stream);
 
+/* ABI 13 -- gsa_project_bwd_batch for the step of a view-parallel RANK: the sweeps of the rank's n_cams views left their
+ * masked colour gradients in v_rgb[c] ([N,3] each: gsa_composite_bwd_lists_rgb; all-gathered right behind the sweeps, the
+ * coefficient gradient of ALL views is rebuilt from the gathered slabs by gsa_sh_grad_expand), so this launch only sums the
+ * GEOMETRY gradients of the rank's cameras into v_means / v_quats / v_scales / v_opacities (written once; accumulate != 0:
+ * added) -- one launch per step instead of one gsa_project_bwd_factored per view: the geometry is read once and the sums are
+ * not read back.  v_rgb: a HOST array of n_cams DEVICE pointers, like radii / v_splat / sh_aux. */
+int gsa_project_bwd_batch_geometry(int n, const float *means, const float *quats, const float *scales,
+                                   const float *opacities, int sh_degree, int n_cams, const float *viewmats,
+                                   const float *intrins, int intrin_stride, int width, int height,
+                                   const int32_t *const *radii, const float *const *v_splat, const float *const *sh_aux,
+                                   const float *const *v_rgb, float *v_means, float *v_quats, float *v_scales,
+                                   float *v_opacities, int accumulate, gsa_stream_t stream);
+
 /* gsa_sh_grad_expand with the output split the way the reference model stores the coefficients: v_dc [N,1,3] and
  * v_rest [N, sh_coeffs - 1, 3] (both overwritten). */
 int gsa_sh_grad_expand_split(int n, const float *means, int sh_degree, int sh_coeffs, int n_views,
@@ -452,6 +465,9 @@ int gsa_sh_grad_expand_split(int n, const float *means, int sh_degree, int sh_co
  *   project_mode   gsa_view_bwd: 0 = stop behind the sweep (the caller finishes all views with gsa_project_bwd_batch);
  *                  1 = gsa_project_bwd_acc into v_means .. v_colors; 2 = gsa_project_bwd_factored (v_rgb instead of v_colors)
  *   wait_bucket    (optional) a hipEvent_t waited for in front of the projection backward (the bucket is summed in view order)
+ *   sweep_rgb      (optional, [n,3], zeroed by the caller) gsa_view_bwd's sweep is gsa_composite_bwd_lists_rgb: the masked colour
+ *                  gradient leaves the sweep in the exchange layout (with project_mode 0: the rank's step ends in ONE
+ *                  gsa_project_bwd_batch_geometry)
  */
 typedef struct gsa_view_args {
     uint32_t struct_bytes;
@@ -486,6 +502,7 @@ typedef struct gsa_view_args {
     const float *means, *quats, *scales, *opacities, *colors, *viewmat, *intrin, *sh_aux;
     const int32_t *radii;
     float *v_means, *v_quats, *v_scales, *v_opacities, *v_colors, *v_rgb;
+    float *sweep_rgb;
 } gsa_view_args;
 size_t gsa_view_args_size(void);
 int gsa_view_fwd(const gsa_view_args *args, gsa_stream_t stream);

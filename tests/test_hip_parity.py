@@ -580,6 +580,55 @@ def test_multi_camera_projection_backward_equals_the_accumulating_launches(gsa, 
     assert S.project_views_bwd(means, quats, scales, opac, colors, deg, plain, v_splats, W, H, got) is False
 
 
+@pytest.mark.parametrize("deg", [3, 1])
+def test_rank_step_colour_gradients_out_of_the_sweep_and_one_geometry_backward(gsa, deg):
+    """The step of a view-parallel rank (r05): ``rasterization(projection=deferred, sh_grad_factored=slot)`` makes every view's
+    backward SWEEP leave its masked d loss / d rgb in the exchange's [N,3] slot (``gsa_composite_bwd_lists_rgb``), and
+    ``project_cameras_backward`` then sums the cameras' GEOMETRY gradients in one launch (``gsa_project_bwd_batch_geometry``).
+    Against the chain it replaces -- one factored projection backward per view, accumulating: same colour slabs, same geometry
+    sums (float atomics reorder the sweeps' sums between two runs: 2e-5), and the coefficient gradient rebuilt from the slabs
+    equals the per-view autograd one."""
+    from gsplat_amd import scene, stages as S
+    W, H, N, C = 320, 192, 9000, 3
+    sc = _scene(N, seed=77 + deg)
+    vms = torch.stack([scene.make_camera(k, 7) for k in (1, 4, 6)]).cuda()
+    K = scene.make_intrinsics(W, H).cuda()
+    v = torch.from_numpy(np.random.default_rng(deg).uniform(-1, 1, (C, H, W, 3)).astype(np.float32)).cuda()
+    bg = torch.full((1, 3), 0.2, device="cuda")
+    # (colours pushed towards the clamp so that the mask matters)
+    base = [sc[k].cuda() for k in NAMES]
+    base[4] = base[4] - 0.9
+    for attempt in range(2):   # (first pass: the first calls of the frame size, stage by stage; second: the fused per-view calls)
+        # reference: the per-view chain with the factored projection backward, accumulating
+        lv = [t.clone().requires_grad_(True) for t in base]
+        args = (lv[0], lv[1], lv[2], lv[3][:, 0], lv[4])
+        ref_out = [torch.zeros_like(t.detach()) for t in args]
+        ref_rgb = torch.zeros(C, N, 3, device="cuda")
+        for c in range(C):
+            r, _, _ = gsa.rasterization(*args, vms[c:c + 1], K[None], W, H, sh_degree=deg, backgrounds=bg, grad_out=ref_out,
+                                        grad_accumulate=c > 0, sh_grad_factored=ref_rgb[c])
+            (r[0] * v[c]).sum().backward()
+        # the rank step
+        proj = gsa.project_cameras(*args, vms, K, W, H, sh_degree=deg, defer_backward=True)
+        assert proj.deferred
+        rgb = torch.full((C, N, 3), float("nan"), device="cuda")
+        for c in range(C):
+            r, _, _ = gsa.rasterization(*args, vms[c:c + 1], K[None], W, H, sh_degree=deg, backgrounds=bg, projection=proj[c],
+                                        sh_grad_factored=rgb[c])
+            (r[0] * v[c]).sum().backward()
+        out = [torch.full_like(t.detach(), float("nan")) for t in args]
+        gsa.project_cameras_backward(proj, *args, out)
+        assert torch.isnan(out[4]).all()                       # the coefficient gradient is the caller's to rebuild
+        scale_rgb = float(ref_rgb.abs().max())
+        assert scale_rgb > 0 and float((rgb - ref_rgb).abs().max()) <= 2e-5 * scale_rgb
+        assert float((rgb == 0).float().mean()) > 0.05         # (clamped channels and culled gaussians: exact zeros)
+        for name, a, b in zip(NAMES[:4], out[:4], ref_out[:4]):
+            assert _rel(a, b) <= 2e-5, (name, _rel(a, b))
+        S.sh_grad_expand(lv[0].detach(), deg, vms, K[None], rgb, out[4])
+        S.sh_grad_expand(lv[0].detach(), deg, vms, K[None], ref_rgb, ref_out[4])
+        assert _rel(out[4], ref_out[4]) <= 2e-5
+
+
 def test_deferred_projection_backward_of_a_step_equals_per_camera_autograd(gsa):
     """The product path of a multi-view step: ``project_cameras(defer_backward=True)`` -> one ``rasterization(projection=...)``
     per camera -> ``backward()`` per camera (stops behind its sweep) -> ``project_cameras_backward`` once.  The gradient bucket
