@@ -927,8 +927,8 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 5 : GSA_BWD_WAVES)) void composit
     int pos_next = load_pos(1);
     uint32_t gid_cur = load_gid(pos_cur);
 
-    // phase A state (lane = pixel): T = transmittance behind the current record; Wd = T_final (v_alpha - bg.v_out) - sum of
-    // (colour . v_out) * weight over the splats behind -- what d(out)/d(alpha_i) multiplies by 1/(1-alpha_i)
+    // phase A state (lane = pixel): T = transmittance behind the current record; Wn = (T_final (v_alpha - bg.v_out) - sum of
+    // (colour . v_out) * weight over the splats behind) / T -- d(out)/d(alpha_i) = Tn (c_i . v_out + Wn)
     const size_t pix = inside ? (size_t)py * width + px : 0;
     const int binf = inside ? last_id[pix] : -1;   // last list position the pixel saw while live
     const float Tf = inside ? final_T[pix] : 1.f;
@@ -939,7 +939,7 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 5 : GSA_BWD_WAVES)) void composit
         vout[k] = inside ? v_render[pix * CH + k] : 0.f;
         if (background) bgdot += background[k] * vout[k];
     }
-    float Wd = Tf * (((inside && v_alpha) ? v_alpha[pix] : 0.f) - bgdot);
+    float Wn = ((inside && v_alpha) ? v_alpha[pix] : 0.f) - bgdot;   // (Wd / T with Wd = T_final (v_alpha - bg . v_out) at the start)
     Row row = load_row(splat, gid_cur, pos_cur >= 0);
     uint32_t gid_next = load_gid(pos_next);
     int pos_next2 = load_pos(2);
@@ -994,10 +994,13 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 5 : GSA_BWD_WAVES)) void composit
                         fac = a * Tn;
                         float cv = q1.z * vout[0] + q1.w * vout[1] + q2.x * vout[2];
                         if (CH == 4) cv += q2.z * vout[CH - 1];
-                        const float v_a = Tn * cv + ra * Wd;
-                        Wd -= fac * cv;
+                        // d out / d alpha = Tn (cv + Wn) with Wn = (what lies behind, weighted) / T: the NORMALISED form of the
+                        // recurrence (r05) -- Wn' = Wn (1 - a) - a cv = Wn - a (cv + Wn) -- needs no 1 / (1 - a) of its own and one
+                        // instruction less per (pixel, record) than carrying Wd = Wn T (v_a = Tn cv + ra Wd; Wd -= fac cv)
+                        const float q = cv + Wn;
+                        Wn = __builtin_fmaf(-a, q, Wn);
                         T = Tn;
-                        u = CLAMP ? ((a == raw) ? -raw * v_a : 0.f) : -a * v_a;
+                        u = CLAMP ? ((a == raw) ? -fac * q : 0.f) : -fac * q;
                     }
                     tp.mat[lane * kMatPitch + r] = make_float2(u, fac);
                 }

@@ -302,6 +302,9 @@ def main() -> None:
     ap.add_argument("--cull-mode", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true", help="skip the (untimed-by-value) training-step leg")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the legs `value` and the multi-rank figures come from (tests): no fixed-camera / rank-step / "
+                         "forward-only / rotating / wide-depth / training-step legs")
     ap.add_argument("--exchange", default="factored", choices=("factored", "allreduce"),
                     help="how the gaussian gradients of the views are summed (see DESIGN.md section 6)")
     ap.add_argument("--views-per-gpu", type=int, default=DEFAULT_VIEWS_PER_GPU,
@@ -695,9 +698,10 @@ def main() -> None:
     # the step form the ranks of a multi-GPU run execute (shared projection forward; per-view factored backward + local SH
     # rebuild, no shared projection backward), timed in this one process: what the N > 1 values are like-for-like with
     rank_step = timed(make_step(args.exchange, B, n_streams, head_ring, rank_form=True), args.steps, 2, converge=True) \
-        if (dist is None and B > 1) else None
+        if (dist is None and B > 1 and not args.no_extras) else None
     # the same step on the SAME cameras every step (r04's headline protocol), beside it
-    fixed = timed(make_step(args.exchange, B, n_streams, world * B), args.steps, 2, converge=True) if head_ring != world * B else head
+    fixed = timed(make_step(args.exchange, B, n_streams, world * B), args.steps, 2, converge=True) \
+        if (head_ring != world * B and not args.no_extras) else head
     c4 = None
     if dist is not None and B > 1:   # BASELINE config C4 as written: ONE view per GPU per step (a world-view batch)
         c4_step = make_step(args.exchange, 1, 1, world)
@@ -734,7 +738,7 @@ def main() -> None:
     # ---- rotating views: one view per step cycling a ring of cameras -- how often the speculation behind the
     # asynchronous binning (record capacity, depth-key range, bucket capacity) has to be repaired
     rot = None
-    if world == 1 and args.views > 1:
+    if world == 1 and args.views > 1 and not args.no_extras:
         rot_step = make_step(args.exchange, 1, 1, args.views)
         for i in range(args.views):   # every camera once: the first call of a shape is exact by construction
             rot_step(i)
@@ -744,7 +748,7 @@ def main() -> None:
     # ---- wide depth: the same scene seen from INSIDE the cloud (ring of radius 0.35: visible depths from the near plane to
     # ~2.3, i.e. 8 octaves of depth-key span where the ring of radius 4 shows 0.7) -- which depth ordering ran, how often
     wide = None
-    if world == 1 and args.views > 1:
+    if world == 1 and args.views > 1 and not args.no_extras:
         wide_cams = torch.stack([scene.make_camera(i, args.views, radius=0.35) for i in range(args.views)]).to(dev)
         wide_step = make_step(args.exchange, 1, 1, args.views, cams_override=wide_cams)
         for i in range(2 * args.views):
@@ -759,7 +763,7 @@ def main() -> None:
     # ---- forward only: what the reference's no_grad callers get (validation renders trainer.py:417-424, eval.py:171-183):
     # backend.render_with_depth under no_grad, one view per call, a fixed camera, the call checking its own speculation
     fwd_only = None
-    if world == 1:
+    if world == 1 and not args.no_extras:
         backend = gsplat_amd.HipBackend(K[0])
         params = {"means3D": leaves[0], "rotations": leaves[1], "scales": leaves[2], "opacities": opac, "shs": leaves[4]}
         viewpoint = {"world_view_transform": ring(max(args.views, 1))[0], "image_width": width, "image_height": height}
@@ -771,11 +775,11 @@ def main() -> None:
         fwd_only = timed(fwd_step, args.steps, 3)
     # mean record counts over the cameras of the headline ring (its whole-step roofline is priced with THEIR intersections)
     ring_M, ring_binned = count_records(list(ring(head_ring))) if rank == 0 else (None, None)
-    fixed_M = (count_records(list(ring(world * B)))[0] if head_ring != world * B else ring_M) if rank == 0 else None
+    fixed_M = (count_records(list(ring(world * B)))[0] if (head_ring != world * B and not args.no_extras) else ring_M) if rank == 0 else None
     # ---- the optimisation step around the rasterizer (BASELINE config C3 "full Adam loop"): the fused harness step -- loss,
     # backward, SH rebuild, Adam -- on the same scene and views; NOT part of `value`
     train = None
-    if world == 1 and args.workload in ("C3", "T") and not args.no_train_step:
+    if world == 1 and args.workload in ("C3", "T") and not args.no_train_step and not args.no_extras:
         # (no reset of what the passes above remembered: every pipeline / backend speculates on its own memory of the frame size)
         train = train_step_leg(sc, n, width, height, deg, B, dev, max(5, min(args.steps, 20)))
     copy_peak = measured_copy_peak(dev) if rank == 0 else 0.0   # after the timed regions

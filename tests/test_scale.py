@@ -301,9 +301,10 @@ def _bench_bucket(tmp_path, tag, gpus, views_per_gpu, streams, exchange="factore
     env = dict(os.environ, GSPLAT_AMD_BENCH_BACKEND="gloo")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
+    torch.cuda.empty_cache()   # (the ranks share this process's card: what the tests before left cached here is theirs to use)
     cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", str(gpus), "--workload", "T", "--steps", "3",
            "--warmup", "1", "--views-per-gpu", str(views_per_gpu), "--view-streams", str(streams), "--exchange", exchange,
-           "--no-cpu-baseline", "--views", "1", "--dump-grad", out, *extra]
+           "--no-cpu-baseline", "--no-extras", "--views", "1", "--dump-grad", out, *extra]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     if res.returncode != 0:   # (the whole stderr of the ranks: the first rank to fail is rarely in the last lines)
         try:
@@ -384,7 +385,7 @@ def test_bench_exchange_executes_over_rccl_with_one_rank(tmp_path):
         if force:
             env["GSPLAT_AMD_BENCH_FORCE_DIST"] = "1"
         cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "1", "--workload", "T", "--steps", "3",
-               "--warmup", "1", "--views-per-gpu", "4", "--no-cpu-baseline", "--no-train-step", "--views", "1", "--dump-grad", out]
+               "--warmup", "1", "--views-per-gpu", "4", "--no-cpu-baseline", "--no-extras", "--views", "1", "--dump-grad", out]
         res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stderr[-3000:]
         return torch.load(out), json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
