@@ -97,7 +97,11 @@ class _RasterizeOneCamera(torch.autograd.Function):
             ctx.mark_non_differentiable(splat, radii, tiles_touched)
             ctx.set_materialize_grads(False)
             # (the record lists, offsets and last ids stay inside the chain's workspace: views are built when meta is asked)
-            return chain.render, chain.alpha, splat, radii, tiles_touched, chain
+            render, alpha = chain.render, chain.alpha
+            # (the chain must not keep the two OUTPUT tensors: their grad_fn is this node, which holds the chain -- a reference
+            # cycle that only the cyclic collector frees, 0.4 GB a view in a loop that has frozen it)
+            chain.render = chain.alpha = None
+            return render, alpha, splat, radii, tiles_touched, chain
         ctx.chain = None
         bins = S.bin_tiles(splat, radii, tiles_touched, depth_keys, width, height, cull_mode, tile_rects=rects, exact=repair,
                            bin_tile=bt, key_range=None if repair else kr, qbox=qb, speculation=speculation)

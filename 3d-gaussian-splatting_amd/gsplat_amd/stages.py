@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes
 import math
 import os
+import sys
 import threading
 import time
 import weakref
@@ -511,10 +512,22 @@ class TileBins:
             _wait_slot(self._slot)
             ctl_host = self._slot[0]
             self._m = int(ctl_host[0]) & 0xFFFFFFFF
-            _note_count(self._spec, self._key, self._n, self._m)
-            if self.key_bits is not None:   # (the unfused path sorts all 32 bits and leaves no range)
-                self._keys_ok = _note_keys(self._spec, self._key, int(ctl_host[1]) & 0xFFFFFFFF, int(ctl_host[2]) & 0xFFFFFFFF,
-                                           self.key_bits, int(ctl_host[3]) & 0xFF if isinstance(self.key_bits, tuple) else 0)
+            # A record count no frame of this size can have (more than one record per gaussian and bin): the control words did
+            # not arrive as written.  Seen once in ~5 full test runs with four processes on one card (r05) and not explained;
+            # such a view is reported as a failed speculation WITHOUT teaching the remembered capacity anything -- the caller
+            # repeats it with exact sizes, whose count comes back through a plain copy.
+            w, h, bt = self._key[2], self._key[3], self.bin_tile
+            plausible = self._m <= max(self._n, 1) * (tile_grid(w, h, bt)[0] * tile_grid(w, h, bt)[1]) + 1
+            if not plausible or os.environ.get("GSPLAT_AMD_DEBUG_SLOTS") == "1":
+                print(f"[gsplat_amd] finalize: implausible control words {[int(x) & 0xFFFFFFFF for x in ctl_host]} token={self._slot[2]} "
+                      f"key={self._key} n={self._n} capacity={self.capacity} ordering={self.key_bits}", file=sys.stderr, flush=True)
+            if plausible:
+                _note_count(self._spec, self._key, self._n, self._m)
+                if self.key_bits is not None:   # (the unfused path sorts all 32 bits and leaves no range)
+                    self._keys_ok = _note_keys(self._spec, self._key, int(ctl_host[1]) & 0xFFFFFFFF, int(ctl_host[2]) & 0xFFFFFFFF,
+                                               self.key_bits, int(ctl_host[3]) & 0xFF if isinstance(self.key_bits, tuple) else 0)
+            else:
+                self._keys_ok = False
             for stats in (REPAIR_STATS, self._spec.repairs):   # (process-wide, and of the object this view speculated on)
                 stats["views"] += 1
                 if self._m > self.capacity:

@@ -952,6 +952,56 @@ def test_degenerate_inputs(gsa):
         gsa.rasterization(*[t.cpu() for t in one], vm.cpu(), K.cpu(), W, H, sh_degree=3)
 
 
+def test_views_free_their_memory_without_the_cyclic_collector(gsa):
+    """A view's buffers (the fused chain's 0.4-GB workspace at bench size) must go back to the allocator by reference counting
+    alone: bench.py and any long-running trainer freeze or disable the cyclic collector, and a reference cycle through the
+    autograd node (r05: node -> chain -> output tensor -> grad_fn = node) leaked a workspace per view until the card was
+    full.  With the collector off, 40 forward + backward views -- through ``rasterization`` and through the deferred-step
+    form -- leave the allocated bytes where they were after the first few."""
+    import gc
+    from gsplat_amd import scene
+    W, H, N = 640, 352, 40_000
+    sc = _scene(N, seed=5)
+    leaves = [sc[k].cuda().clone().requires_grad_(True) for k in NAMES]
+    args = (leaves[0], leaves[1], leaves[2], leaves[3][:, 0], leaves[4])
+    vms = torch.stack([scene.make_camera(k, 5) for k in range(3)]).cuda()
+    K = scene.make_intrinsics(W, H).cuda()
+    v = torch.rand(H, W, 3, device="cuda")
+    out = [torch.empty_like(t.detach()) for t in args]
+
+    def single(i):
+        for t in leaves:
+            t.grad = None
+        r, _, meta = gsa.rasterization(*args, vms[i % 3:i % 3 + 1], K[None], W, H, sh_degree=3)
+        (r[0] * v).sum().backward()
+
+    def step(i):
+        proj = gsa.project_cameras(*args, vms, K, W, H, sh_degree=3, defer_backward=True)
+        for c in range(3):
+            r, _, meta = gsa.rasterization(*args, vms[c:c + 1], K[None], W, H, sh_degree=3, projection=proj[c], defer_check=True)
+            (r[0] * v).sum().backward()
+            assert meta["speculation_ok"] in (True, False)
+        gsa.project_cameras_backward(proj, *args, out)
+
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        for fn in (single, step):
+            for i in range(6):
+                fn(i)
+            torch.cuda.synchronize()
+            base = torch.cuda.memory_allocated()
+            for i in range(40):
+                fn(i)
+            torch.cuda.synchronize()
+            grown = torch.cuda.memory_allocated() - base
+            assert grown <= 8 << 20, f"{fn.__name__}: {grown / 2**20:.1f} MiB allocated and not freed over 40 iterations"
+    finally:
+        if was:
+            gc.enable()
+
+
 def test_projection_is_checked_against_the_camera_and_the_parameters(gsa):
     """``rasterization(projection=...)`` refuses a projection made for another camera, or from parameters that were written
     since: the forward would blend the projection's splats while the backward differentiates the arguments.
