@@ -1854,8 +1854,9 @@ __device__ __forceinline__ void bucket_local_pass(BucketLds &L, int src, int mm,
 }
 
 __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
-    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, const uint32_t *__restrict__ digit_total,
-    uint32_t key_min, uint32_t scale, const uint2 *__restrict__ tile_rects, uint32_t *__restrict__ order,
+    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, const uint32_t *__restrict__ rects_in,
+    const uint32_t *__restrict__ counts_in, const uint32_t *__restrict__ digit_total,
+    uint32_t key_min, uint32_t scale, uint32_t *__restrict__ order,
     uint32_t *__restrict__ rects, uint32_t *__restrict__ offsets, int32_t *__restrict__ block_owner, int n_owner_blocks,
     unsigned long long *granule, uint32_t *ticket, uint32_t *__restrict__ ctl, uint32_t *__restrict__ ctl_host,
     uint32_t token, const uint32_t *__restrict__ table) {
@@ -1906,12 +1907,11 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
 #pragma unroll
     for (int g4 = 0; g4 < kStrides; g4 += 4) {
         if (g4 * kLocalThreads >= mm) break;   // (uniform)
-        uint32_t kk[4], vv[4];
+        uint32_t kk[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int i = min((g4 + j) * kLocalThreads + t, mm - 1);
             kk[j] = keys_in[lo + i];
-            vv[j] = vals_in[lo + i];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1920,7 +1920,10 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
                 const uint32_t x = kk[j] - sub;        // (< width <= 2^24, unless a key lies outside the planned range: reported)
                 L.key[0][i] = (uint16_t)((wide ? x >> 8 : x) & 0xFFFFu);
                 if (wide) L.low[i] = (uint8_t)x;
-                L.val[0][i] = vv[j];
+                // (r05) the local sorts carry the item's PLACE in the bucket, not its gaussian id: id, rectangle and record
+                // count then come out of the bucket's own 32-KB windows of the first pass's output (which brought the
+                // rectangles along) instead of one random 8-byte gather per gaussian over the whole scene
+                L.val[0][i] = (uint32_t)i;
             }
         }
     }
@@ -1941,8 +1944,9 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
         uint2 pr[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            gg[j] = L.val[cur][min((g4 + j) * kLocalThreads + t, mm - 1)];
-            pr[j] = tile_rects[gg[j]];
+            const uint32_t p = L.val[cur][min((g4 + j) * kLocalThreads + t, mm - 1)];   // where the item sat in the bucket
+            gg[j] = vals_in[lo + p];
+            pr[j] = make_uint2(rects_in[lo + p], counts_in[lo + p]);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -2042,9 +2046,11 @@ __global__ __launch_bounds__(kLocalThreads) void depth_bucket_sort_kernel(
 
 extern "C" size_t gsa_depth_order_msd_workspace_bytes(int n) {
     if (n < 0) n = 0;
-    // first-pass output (keys, values), per-block key ranges, histograms, granules + ticket
+    // first-pass output (keys, values), per-block key ranges, histograms, granules + ticket, the depth table -- and, behind
+    // those, the rectangles and record counts the first pass brings into bucket order (r05)
     return (size_t)2 * n * sizeof(uint32_t) + (size_t)2 * ((size_t)sort_blocks(n) + 1) * sizeof(uint32_t) +
-           gsa_sort_workspace_bytes(n) + (size_t)(2 * kRadix + 16 + kTabWords) * sizeof(uint32_t) + 16;
+           gsa_sort_workspace_bytes(n) + (size_t)(2 * kRadix + 16 + kTabWords) * sizeof(uint32_t) + 16 +
+           (size_t)2 * n * sizeof(uint32_t) + 16;
 }
 
 extern "C" int gsa_depth_order_msd_max_width(void) { return 1 << kLocalBits; }
@@ -2097,6 +2103,9 @@ extern "C" int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint
     // key_range_dev: what gsa_project_fwd left per wave -> one workgroup builds this view's depth table behind the ticket
     // for the launches that follow (the row scan zeroes only granules, ticket and ctl[3])
     uint32_t *table = key_range_dev ? ticket + 16 : nullptr;
+    // (behind everything else: the packed rectangles and record counts in the first pass's output order)
+    uint32_t *rbuf = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(ticket + 16 + kTabWords) + 15) & ~(uintptr_t)15);
+    uint32_t *cbuf = rbuf + n;
     const RadixDigit dg{(int)scale, key_min, table ? 2 : 1, table, nullptr, 0u};
     if (key_range_dev) {
         depth_table_kernel<<<1, kTabThreads, 0, s>>>(reinterpret_cast<const uint4 *>(key_range_dev), gsa_div_up(n, 64), table);
@@ -2109,10 +2118,10 @@ extern "C" int gsa_depth_order_msd(int n, const uint32_t *depth_keys, const uint
                                                            reinterpret_cast<uint32_t *>(granule), 2 * kRadix + 4);
     GSA_LAUNCH_CHECK();
     radix_scatter_kernel<uint32_t><<<nblocks, kSortThreads, 0, s>>>(n, nullptr, depth_keys, nullptr, kbuf, vbuf, dg, nblocks,
-                                                                    hist, digit_total);
+                                                                    hist, digit_total,
+                                                                    reinterpret_cast<const uint2 *>(tile_rects), rbuf, cbuf);
     GSA_LAUNCH_CHECK();
-    depth_bucket_sort_kernel<<<kRadix, kLocalThreads, 0, s>>>(kbuf, vbuf, digit_total, key_min, scale,
-                                                              reinterpret_cast<const uint2 *>(tile_rects), order, rects,
+    depth_bucket_sort_kernel<<<kRadix, kLocalThreads, 0, s>>>(kbuf, vbuf, rbuf, cbuf, digit_total, key_min, scale, order, rects,
                                                               offsets, n_blocks > 0 ? block_owner : nullptr, n_blocks,
                                                               granule, ticket, ctl, ctl_host, token, table);
     GSA_LAUNCH_CHECK();
