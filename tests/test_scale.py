@@ -301,7 +301,12 @@ def _bench_bucket(tmp_path, tag, gpus, views_per_gpu, streams, exchange="factore
     env = dict(os.environ, GSPLAT_AMD_BENCH_BACKEND="gloo")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    torch.cuda.empty_cache()   # (the ranks share this process's card: what the tests before left cached here is theirs to use)
+    # (the ranks share this process's card: what the tests before left cached here -- and what only the cyclic collector
+    # frees -- is theirs to use; a rank that cannot allocate dies inside a collective's worker thread, which aborts the process)
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    free_b, total_b = torch.cuda.mem_get_info()
     cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", str(gpus), "--workload", "T", "--steps", "3",
            "--warmup", "1", "--views-per-gpu", str(views_per_gpu), "--view-streams", str(streams), "--exchange", exchange,
            "--no-cpu-baseline", "--no-extras", "--views", "1", "--dump-grad", out, *extra]
@@ -311,6 +316,7 @@ def _bench_bucket(tmp_path, tag, gpus, views_per_gpu, streams, exchange="factore
             dump = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(HERE)), "gpurun_out")
             os.makedirs(dump, exist_ok=True)
             with open(os.path.join(dump, f"bench_{tag}.stderr"), "w") as fh:
+                fh.write(f"[test] card memory before the launch: {free_b / 2**30:.1f} GiB free of {total_b / 2**30:.1f}\n")
                 fh.write(res.stderr)
         except OSError:
             pass
