@@ -617,10 +617,11 @@ class ViewParallelTrainer:
         same_frame = len(mine) > 1 and len({(v["width"], v["height"]) for v in mine}) == 1
         batch_bwd = same_frame and self.world == 1 and degree >= 1 and len(mine) <= 8 and m.sh.shape[1] == 16
         factored = self.factored and not batch_bwd
-        # ... with several ranks (r05): every view's backward SWEEP leaves its masked colour gradient in the exchange's [N,3]
-        # slot, and the geometry gradients of the rank's views are summed by ONE launch behind the last sweep
-        # (stages.project_views_bwd(v_rgbs=...)) -- instead of one factored projection backward per view
-        rank_batch = factored and same_frame and degree >= 1 and len(mine) <= 8
+        # ... with several ranks (r05, ``self.rank_batch``; OFF: measured slower, profiles/r05_rank_step.md): every view's
+        # backward SWEEP leaves its masked colour gradient in the exchange's [N,3] slot, and the geometry gradients of the
+        # rank's views are summed by ONE launch behind the last sweep (stages.project_views_bwd(v_rgbs=...)) -- instead of one
+        # factored projection backward per view
+        rank_batch = getattr(self, "rank_batch", False) and factored and same_frame and degree >= 1 and len(mine) <= 8
         if factored:  # slot (r, j) = the j-th view of rank r; ranks with fewer views leave zeros (skipped by the expand)
             slots = -(-n_views // self.world)
             vr_all = torch.empty(self.world, slots, n, 3, device=dev)   # (every slot of a view is written whole by its backward)

@@ -330,6 +330,10 @@ def main() -> None:
     ap.add_argument("--no-batch-backward", action="store_true",
                     help="one projection backward per view (+ the SH expansion) instead of one launch for all views of the step "
                          "(gsplat_amd.project_cameras_backward; single process only)")
+    ap.add_argument("--rank-batch", action="store_true",
+                    help="multi-rank / rank-form steps: colour gradients out of the backward sweeps + ONE geometry-only projection "
+                         "backward per step (gsa_composite_bwd_lists_rgb / gsa_project_bwd_batch_geometry) instead of one factored "
+                         "projection backward per view -- measured slower (profiles/r05_rank_step.md), kept for A/B")
     ap.add_argument("--dump-grad", default=None,
                     help="(tests) rank 0 saves the gradient bucket of the last step of the timed region to this .pt file")
     ap.add_argument("--profile-views", type=int, default=1,
@@ -450,7 +454,9 @@ def main() -> None:
         # the exchange's [N,3] slot (the all-gather of view j is queued behind view j's sweep, under view j + 1), and the
         # geometry gradients of the rank's views are summed by ONE launch behind the last sweep (project_cameras_backward on
         # projections that carry v_rgb) -- instead of one factored projection backward per view
-        rank_batch = factored and batch_proj and deg >= 1 and views <= 8 and not args.no_batch_backward
+        # MEASURED SLOWER and off (profiles/r05_rank_step.md; --rank-batch switches it on): the compact [N,3] atomics cost the
+        # sweep 0.13 ms per view where the factored projection backward they replace takes 0.037
+        rank_batch = args.rank_batch and factored and batch_proj and deg >= 1 and views <= 8 and not args.no_batch_backward
         ex = Exchange(dist, world, rank, n, views, factored, dev, expand=stages.sh_grad_expand)
         pipe = ViewPipeline(dev, n_streams)
         cams, windows = (ring(ring_size) if cams_override is None else cams_override), {}
@@ -937,9 +943,8 @@ def main() -> None:
                                   "key_range_repairs_per_100": round(st["key_range_repairs"] * per100, 2)}
         if rank_step is not None:
             rs_ms = rank_step["s"] / args.steps * 1e3 / B
-            line["rank_step"] = {"what": "the step a rank of an N > 1 run executes (shared projection forward; every sweep leaves its "
-                                         "masked colour gradient in the exchange layout; ONE geometry-only projection backward per "
-                                         "step; local SH rebuild; no collectives in this process)",
+            line["rank_step"] = {"what": "the step a rank of an N > 1 run executes (shared projection forward, per-view factored "
+                                         "projection backward, local SH rebuild; no collectives in this process)",
                                  "ms_per_view": round(rs_ms, 4), "value": round(p / rs_ms / 1e3, 3),
                                  "frac": round(ring_bytes / (rs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
         if fwd_only is not None:

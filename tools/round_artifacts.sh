@@ -22,5 +22,8 @@ python tools/prof_summary.py $O/stats_solo/p_kernel_stats.csv > $O/summary_table
 echo "summary done"
 bash tools/collect_pmc.sh gpurun_out/$tag/pmc > $O/pmc.log 2>&1
 echo "pmc done"
-python tools/make_traffic_json.py $O/pmc "$tag" $O/traffic.json > $O/traffic.log
+# the VALU roofline passes of the two sweeps (lanes / busy / lds / mix + the kernels' durations in the same protocol)
+bash tools/r05_valu_pmc.sh gpurun_out/$tag/valu > $O/valu.log 2>&1
+echo "valu pmc done"
+python tools/make_traffic_json.py $O/pmc "$tag" $O/traffic.json $O/valu > $O/traffic.log
 ls $O
