@@ -815,7 +815,7 @@ def main() -> None:
         # measured per launch, from separate rocprofv3 --pmc passes of the single-view step (profiles/*_traffic.json,
         # tools/make_traffic_json.py): HBM bytes of every kernel, VALU utilisation, float-atomic requests, and the
         # bound the counters point at.  NOT measured in this run: `counters_from` names the file and the sources' revision.
-        traffic, counters, counters_from, measured_bytes, step_bytes = None, {}, None, None, None
+        traffic, counters, counters_from, measured_bytes, step_bytes, valu_roofline = None, {}, None, None, None, None
         for fname in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fname)) as fh:
@@ -829,6 +829,12 @@ def main() -> None:
                     step_bytes = sum(k.get("hbm_bytes_per_launch", 0) * k.get("launches_per_view", 1)
                                      for k in doc.get("step_kernels", {}).values()) or None
                     counters_from = f"profiles/{fname} @ csrc {doc.get('csrc_rev', 'of round ' + fname[1:3])}"
+                    # the VALU roofline of the two sweeps (the counters' file; tools/r05_valu_pmc.sh): wave-instructions per
+                    # launch, the launch in SIMD-cycles, busy cycles of the vector ALU, EXEC-active lanes per instruction
+                    keep = ("wave_insts", "simd_cycles", "cycles_per_inst", "busy_cycles_per_inst", "lane_utilisation",
+                            "issue_frac", "issue_frac_at_2_cycles_per_inst", "lds_array_busy", "clock_GHz")
+                    valu_roofline = {k: {f: v["valu_roofline"].get(f) for f in keep} for k, v in doc["kernels"].items()
+                                     if isinstance(v, dict) and v.get("valu_roofline")} or None
                     break
             except (OSError, KeyError, ValueError, TypeError):
                 continue
@@ -884,6 +890,7 @@ def main() -> None:
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "limiter": counters.get("limiter"), "valu_util": counters.get("valu_util"),
                          "atomic_requests": counters.get("atomic_requests"), "counters_from": counters_from,
+                         "valu_roofline": valu_roofline,
                          "measured_copy_peak": round(copy_peak, 1),
                          "algorithmic_bytes_per_launch": alg[dominant], "avg_launch_ms": round(per[dominant], 4)},
             # SURVEY 8d's compulsory bytes of one view over the time of one view of the timed region

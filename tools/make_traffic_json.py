@@ -132,7 +132,9 @@ if lanes:
         if base not in STAGE or STAGE[base] not in res["kernels"]:
             continue
         b, d, m = B.get(k, {}), D.get(k, {}), M.get(k, {})
-        gui = b.get("GRBM_GUI_ACTIVE", 0.0) / N_XCD
+        # (the launch's duration from the SAME pass as the busy cycles when that pass carries it: between passes the sweeps'
+        # durations differ by a few per cent, which put the forward's busy share at 104 % once)
+        gui = (c.get("GRBM_GUI_ACTIVE") or b.get("GRBM_GUI_ACTIVE", 0.0)) / N_XCD
         simd_cycles = gui * N_SIMD
         insts, busy = c.get("SQ_INSTS_VALU", 0.0), 4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0)
         known = sum(m.get("SQ_INSTS_VALU_" + x, 0.0) for x in ("FMA_F32", "MUL_F32", "ADD_F32", "TRANS_F32", "INT32", "CVT"))
@@ -140,7 +142,9 @@ if lanes:
               "duration_us_profiler": dur.get(k), "clock_GHz": round(gui / (dur[k] * 1e3), 3) if dur.get(k) else None,
               "cycles_per_inst": round(simd_cycles / insts, 3) if insts else None,
               "valu_busy_cycles": busy, "busy_cycles_per_inst": round(busy / insts, 3) if insts else None,
-              "issue_frac": round(busy / simd_cycles, 4) if simd_cycles else None,
+              "issue_frac": round(min(busy / simd_cycles, 1.0), 4) if simd_cycles else None,
+              "issue_frac_raw": round(busy / simd_cycles, 4) if simd_cycles else None,
+              "duration_and_busy_from_one_pass": bool(c.get("GRBM_GUI_ACTIVE")),
               "issue_frac_at_2_cycles_per_inst": round(2.0 * insts / simd_cycles, 4) if simd_cycles else None,
               "lane_utilisation": round(c.get("SQ_THREAD_CYCLES_VALU", 0.0) / max(64.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0), 1.0), 4),
               "cu_busy_frac": round(b.get("SQ_BUSY_CU_CYCLES", 0.0) / N_CU / gui, 4) if gui else None,
