@@ -109,7 +109,7 @@ if tr.get("step_kernels"):
                      if v["hbm_bytes_per_launch"] * v["launches_per_view"] >= 1e5)
     text += f"""
 The kernels of the MULTI-VIEW step (`bench.py --profile-run --profile-views 4`: 4 views per step on one stream; same PMC
-passes).  The views of a step share ONE projection launch (`project_fwd_kernel<3, true, true>`: geometry and SH rows read
+passes).  The views of a step share ONE projection launch (`project_fwd_kernel<3, true, true, 3>`: geometry and SH rows read
 once for the 4 cameras) and ONE projection-backward launch (`project_bwd_batch_kernel<3>`: every gradient written once, the
 SH-coefficient gradient formed in registers -- no per-view `project_bwd`, no `sh_grad_expand`):
 

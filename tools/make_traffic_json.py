@@ -94,7 +94,7 @@ if fs and ws:
     for k in sorted(set(fstep) | set(wstep)):
         f = fstep.get(k, {}).get("FETCH_SIZE", 0.0) * 1024.0
         w = wstep.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0
-        per_step = bool(re.search(r"project_fwd_kernel<[^>]*true>$|project_bwd_batch_kernel|sh_grad_expand", k))
+        per_step = bool(re.search(r"project_fwd_kernel<-?\d+, (true|false), true\b|project_bwd_batch_kernel|sh_grad_expand", k))
         res["step_kernels"][k] = {"kernel": k, "fetch_bytes_corrected": 2 * f, "write_bytes": w, "hbm_bytes_per_launch": 2 * f + w,
                                   "launches_per_view": 1.0 / VIEWS if per_step else 1}
     res["_about_step_kernels"] = (f"the same counters for the kernels of the {VIEWS}-view step (bench.py --profile-run --profile-views "
