@@ -105,6 +105,9 @@ stage by stage (`GSPLAT_AMD_VIEW_CALLS=0`):
 {chr(10).join(host0)}
 ```
 
+Host WORK per step = host time in `training_step` minus the wait for the step's control words: ~0.83 ms with the per-view calls,
+~1.06 ms stage by stage (an earlier box: 0.81 / 1.11); the step is device-paced either way.
+
 `rocprofv3 --kernel-trace --stats -- python3 tools/bench_train_step.py` (FUSED_ONLY=1: 3 warm-up + 10 timed steps of 4 views;
 durations INCLUDE the time a kernel waits beside another stream's sweep, which is why the short kernels read long):
 
