@@ -63,6 +63,27 @@ def test_error_codes_and_strings():
         check(-1, "x")
 
 
+def test_view_calls_guard_their_argument_struct():
+    """ABI 13: gsa_view_fwd / gsa_view_bwd take ONE struct; a host built against another layout must be refused before
+    anything is queued (struct_bytes), and so must a struct without the buffers the chain needs."""
+    from gsplat_amd._lib import ViewArgs, lib
+
+    assert lib.gsa_view_args_size() == ctypes.sizeof(ViewArgs)
+    assert lib.gsa_view_fwd(None, None) == -1 and lib.gsa_view_bwd(None, None) == -1
+    a = ViewArgs()
+    a.struct_bytes = ctypes.sizeof(ViewArgs) - 8        # another layout
+    a.n, a.m_capacity = 100, 4096
+    assert lib.gsa_view_fwd(ctypes.byref(a), None) == -1 and lib.gsa_view_bwd(ctypes.byref(a), None) == -1
+    a.struct_bytes = ctypes.sizeof(ViewArgs)
+    a.n = 0                                             # nothing to order
+    assert lib.gsa_view_fwd(ctypes.byref(a), None) == -1
+    a.n, a.m_capacity = 100, 0                          # no record capacity: the caller has to run the stages
+    assert lib.gsa_view_fwd(ctypes.byref(a), None) == -1
+    a.m_capacity = 4096                                 # no launch-order buffer (tile_order): not the scheduled placement
+    assert lib.gsa_view_fwd(ctypes.byref(a), None) == -1
+    assert lib.gsa_view_bwd(ctypes.byref(a), None) == -1   # no lists / gradient buffers
+
+
 def test_product_does_not_import_oracle():
     """The product path must not route through the oracle (or any CPU fallback)."""
     pkg = os.path.join(ROOT, "3d-gaussian-splatting_amd")
