@@ -863,9 +863,44 @@ struct TwoPhase {
 
 // Lane l stages ITS record of the batch (list position idx; !valid: a record that blends nothing).  Returns the number of
 // valid records (a prefix of the lanes); any_cap: does one of them exceed the 0.999 alpha cap.
-template <int F4>
+// ---- replicas of the gradient records of HOT gaussians (r05) ------------------------------------------------------------------
+// Every (quadrant, record) visit of the sweep ends in one 64-B float-atomic request on the gaussian's gradient record.  A
+// camera INSIDE the scene sees splats that cover hundreds to thousands of tiles: a full-screen splat takes ~30 000 requests
+// on ONE line, which the memory side serialises (measured: bench.py's wide_depth pass, the sweep 0.535 ms with the atomics,
+// 0.158 ms with plain stores in their place).  So a gaussian whose tile rectangle is at least GSA_HOT_MIN_WIDTH tiles wide
+// (word 11 of its splat record) gets GSA_HOT_REPLICAS gradient rows of its own in the HOT REGION behind the caller's N
+// gradient records -- [N rows | GSA_HOT_REPLICAS x GSA_HOT_ENTRIES replica rows | GSA_HOT_ENTRIES tag words], all zero when
+// the sweep starts -- and a wave adds into replica (4 tile + quadrant) mod GSA_HOT_REPLICAS.  Entries are claimed on first
+// touch: hash of the gaussian index, compare-and-swap on the tag (0 -> index + 1), a few probes; the claiming lane leaves
+// entry + 1 in the reserved word 11 of the gaussian's OWN gradient record, where the projection backward -- which reads that
+// record anyway -- finds it and adds the replicas (project.hip: fold_hot_replicas).  A gaussian that finds no entry adds to
+// its own record as before; nothing changes for gaussians below the width (the bench scene C3 has none above it).
+__device__ __forceinline__ uint32_t hot_row(float *__restrict__ v_splat, long n_rows, uint32_t g, uint32_t replica) {
+    uint32_t *tags = reinterpret_cast<uint32_t *>(v_splat + (n_rows + (long)GSA_HOT_ENTRIES * GSA_HOT_REPLICAS) * GSA_SPLAT_STRIDE);
+    uint32_t h = g * 2654435761u;
+#pragma unroll 1
+    for (int probe = 0; probe < GSA_HOT_PROBES; ++probe) {
+        const uint32_t e = h >> (32 - GSA_HOT_LOG_ENTRIES);
+        h = h * 2246822519u + 3266489917u;
+        // (agent scope: the XCDs' L2s are not coherent for plain loads; a tag only ever goes 0 -> index + 1 inside a sweep)
+        uint32_t t = __hip_atomic_load(&tags[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == 0u) {
+            t = atomicCAS(&tags[e], 0u, g + 1u);
+            if (t == 0u) {   // this lane claimed the entry: tell the projection backward where the replicas are
+                t = g + 1u;
+                reinterpret_cast<uint32_t *>(v_splat)[(size_t)g * GSA_SPLAT_STRIDE + GSA_HOT_MARK_FIELD] = e + 1u;
+            }
+        }
+        if (t == g + 1u) return (uint32_t)n_rows + replica * GSA_HOT_ENTRIES + e;   // (replica-major: a gaussian's replicas lie 256 KB apart)
+    }
+    return g;
+}
+
+// (HOT: `row_of` receives the gradient ROW of the staged record -- the gaussian's own, or one of its replicas)
+template <int F4, bool HOT = false>
 __device__ __forceinline__ int stage_listed(TwoPhase<F4> &tp, int lane, const Row &row, bool valid, int idx, float qcx,
-                                            float qcy, bool &any_cap) {
+                                            float qcy, bool &any_cap, float *__restrict__ v_splat = nullptr, long n_rows = 0,
+                                            uint32_t replica = 0u) {
     const float4 r0 = row.r0, r1 = row.r1, r2 = row.r2;
     const float A = 0.5f * kLog2e * r0.z, B = kLog2e * r0.w, C = 0.5f * kLog2e * r1.x;
     const SigmaForm f = sigma_form(r0.x, r0.y, A, B, C, r1.y, qcx, qcy);
@@ -873,7 +908,12 @@ __device__ __forceinline__ int stage_listed(TwoPhase<F4> &tp, int lane, const Ro
     tp.rec[F4 * lane + 1] = make_float4(B, C, r1.z, r1.w);
     tp.rec[F4 * lane + 2] = make_float4(r2.x, __int_as_float(idx), r2.y, 0.f);
     tp.mat[lane * kMatPitch + kSub] = make_float2(r0.x, r0.y);
-    tp.gid[lane] = row.gid;
+    uint32_t grad_row = row.gid;
+    if constexpr (HOT) {   // word 11 of the splat record: tile x0 | y0 << 10 | columns << 20 (0: not packable -- never hot)
+        if (valid && ((__float_as_uint(r2.w) >> 20) & 0x3FFu) >= (uint32_t)GSA_HOT_MIN_WIDTH)
+            grad_row = hot_row(v_splat, n_rows, row.gid, replica);
+    }
+    tp.gid[lane] = grad_row;
     const unsigned long long b = __ballot(valid);          // valid lanes are a prefix: lane < n
     any_cap = __ballot(valid && r1.y > GSA_MAX_ALPHA) != 0ull;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -884,14 +924,15 @@ __device__ __forceinline__ int stage_listed(TwoPhase<F4> &tp, int lane, const Ro
 
 // (register budget: five waves per SIMD for the three-channel instance -- 96 registers; the four-channel instance would
 // spill there and keeps what it needs)
-template <int CH>
+template <int CH, bool HOT>
 __global__ __launch_bounds__(kWave, (CH == 3 ? 5 : GSA_BWD_WAVES)) void composite_bwd_2p_kernel(
     int width, int height, int tile_w, int n_tiles, int bin_shift, const float *__restrict__ splat,
     const uint32_t *__restrict__ sorted_gid, uint32_t gid_mask, const int32_t *__restrict__ tile_offsets,
     const float *__restrict__ background, const int32_t *__restrict__ tile_order, const float *__restrict__ final_T,
     const int32_t *__restrict__ last_id, const float *__restrict__ v_render, const float *__restrict__ v_alpha,
     const uint32_t *__restrict__ quad_list, const int32_t *__restrict__ quad_count, float *__restrict__ v_splat,
-    float *__restrict__ v_rgb) {
+    float *__restrict__ v_rgb, long hot_rows_at) {
+    // HOT: the hot region lies behind row `hot_rows_at` (= N) of v_splat (hot_row above); v_rgb is not given then.
     // v_rgb (optional, [N,3], zeroed by the caller; gsa_composite_bwd_lists_rgb): the colour moments (fields 6..8) are added
     // THERE instead of into the gradient record, already masked by the colour clamp (a channel the forward clamped at 0 --
     // its staged colour is exactly 0 -- has no gradient): d loss / d rgb per gaussian in the 12-byte layout the view-parallel
@@ -963,7 +1004,8 @@ __global__ __launch_bounds__(kWave, (CH == 3 ? 5 : GSA_BWD_WAVES)) void composit
         // sweep, which runs at its 96-register budget)
         int cxi = qx + 4, cyi = qy + 4;
         asm volatile("" : "+s"(cxi), "+s"(cyi));
-        const int n = stage_listed(tp, lane, row, pos_cur >= 0, pos_cur, (float)cxi, (float)cyi, any_cap);
+        const int n = stage_listed<F4, HOT>(tp, lane, row, pos_cur >= 0, pos_cur, (float)cxi, (float)cyi, any_cap, v_splat,
+                                            hot_rows_at, (uint32_t)(4 * tile_id + q) & (GSA_HOT_REPLICAS - 1));
         row = load_row(splat, gid_next, pos_next >= 0);
         pos_cur = pos_next;
         gid_next = load_gid(pos_next2);
@@ -1246,10 +1288,12 @@ static int composite_bwd_lists_impl(int width, int height, int channels, const f
                                        const float *background, const int32_t *tile_order, const float *final_T,
                                        const int32_t *last_id, const float *v_render, const float *v_alpha,
                                        const uint32_t *quad_list, const int32_t *quad_count, float *v_splat,
-                                       float *v_rgb, int bin_tile, gsa_stream_t stream) {
+                                       float *v_rgb, int bin_tile, gsa_stream_t stream, long long hot_n = -1) {
     GSA_RETURN_IF(width <= 0 || height <= 0 || (channels != 3 && channels != 4), GSA_ERR_INVALID_ARGUMENT);
     GSA_RETURN_IF(!tile_offsets || !final_T || !last_id || !v_render || !v_splat || !quad_list || !quad_count,
                   GSA_ERR_INVALID_ARGUMENT);
+    // (rows are addressed with 32 bits in the wave's LDS image)
+    GSA_RETURN_IF(hot_n >= 0 && (v_rgb || hot_n + gsa_hot_rows() >= (1ll << 31)), GSA_ERR_INVALID_ARGUMENT);
     const int bin_shift = bin_shift_of(bin_tile);
     GSA_RETURN_IF(bin_shift < 0, GSA_ERR_INVALID_ARGUMENT);
     const int tile_w = gsa_div_up(width, kTile), tile_h = gsa_div_up(height, kTile);
@@ -1257,14 +1301,17 @@ static int composite_bwd_lists_impl(int width, int height, int channels, const f
     const int grid = 32 * gsa_div_up(n_tiles, 8);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint32_t gid_mask = gid_boxes ? 0xFFFFFFu : 0xFFFFFFFFu;
-    if (channels == 3)
-        composite_bwd_2p_kernel<3><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid, gid_mask,
-                                                         tile_offsets, background, tile_order, final_T, last_id,
-                                                         v_render, v_alpha, quad_list, quad_count, v_splat, v_rgb);
-    else
-        composite_bwd_2p_kernel<4><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid, gid_mask,
-                                                         tile_offsets, background, tile_order, final_T, last_id,
-                                                         v_render, v_alpha, quad_list, quad_count, v_splat, v_rgb);
+#define GSA_BWD_2P(CH_, HOT_)                                                                                             \
+    composite_bwd_2p_kernel<CH_, HOT_><<<grid, kWave, 0, s>>>(width, height, tile_w, n_tiles, bin_shift, splat, sorted_gid,    \
+                                                              gid_mask, tile_offsets, background, tile_order, final_T, last_id, \
+                                                              v_render, v_alpha, quad_list, quad_count, v_splat, v_rgb,       \
+                                                              (long)hot_n)
+    if (channels == 3) {
+        if (hot_n >= 0) GSA_BWD_2P(3, true); else GSA_BWD_2P(3, false);
+    } else {
+        if (hot_n >= 0) GSA_BWD_2P(4, true); else GSA_BWD_2P(4, false);
+    }
+#undef GSA_BWD_2P
     GSA_LAUNCH_CHECK();
     return GSA_OK;
 }
@@ -1277,6 +1324,19 @@ extern "C" int gsa_composite_bwd_lists(int width, int height, int channels, cons
                                        int bin_tile, gsa_stream_t stream) {
     return composite_bwd_lists_impl(width, height, channels, splat, sorted_gid, gid_boxes, tile_offsets, background, tile_order,
                                     final_T, last_id, v_render, v_alpha, quad_list, quad_count, v_splat, nullptr, bin_tile, stream);
+}
+
+extern "C" long long gsa_hot_rows(void) { return GSA_HOT_ROWS; }
+
+extern "C" int gsa_composite_bwd_lists_hot(int width, int height, int channels, const float *splat,
+                                           const uint32_t *sorted_gid, int gid_boxes, const int32_t *tile_offsets,
+                                           const float *background, const int32_t *tile_order, const float *final_T,
+                                           const int32_t *last_id, const float *v_render, const float *v_alpha,
+                                           const uint32_t *quad_list, const int32_t *quad_count, long long n, float *v_splat,
+                                           int bin_tile, gsa_stream_t stream) {
+    GSA_RETURN_IF(n < 0, GSA_ERR_INVALID_ARGUMENT);
+    return composite_bwd_lists_impl(width, height, channels, splat, sorted_gid, gid_boxes, tile_offsets, background, tile_order,
+                                    final_T, last_id, v_render, v_alpha, quad_list, quad_count, v_splat, nullptr, bin_tile, stream, n);
 }
 
 extern "C" int gsa_composite_bwd_lists_rgb(int width, int height, int channels, const float *splat,

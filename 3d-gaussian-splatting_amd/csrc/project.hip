@@ -379,6 +379,27 @@ __global__ __launch_bounds__(kBlock, (BATCH ? GSA_PROJ_BATCH_WAVES : GSA_PROJ_FW
     }   // blocks of this workgroup
 }
 
+// HOT gaussians (composite.hip, hot_row): the reverse sweep spreads the atomics of a gaussian whose splat covers many tiles over
+// GSA_HOT_REPLICAS rows of the hot region behind the n gradient records, and leaves entry + 1 in the reserved word
+// GSA_HOT_MARK_FIELD of the gaussian's own record.  The record is read here anyway: a set mark adds the replicas (a few
+// thousand gaussians of a view from inside the scene, none of the bench scene C3).  Any other value of the word -- zero from
+// the sweeps' clearing; whatever a caller's own records hold, short of an integer in 1 .. GSA_HOT_ENTRIES -- leaves the record alone.
+__device__ __forceinline__ void fold_hot_replicas(const float *__restrict__ v_splat, long n, float4 &v0, float4 &v1, float4 &v2) {
+    static_assert(GSA_HOT_MARK_FIELD == 11, "the mark is the fourth word of the record's third quad");
+    const uint32_t mark = __float_as_uint(v2.w);
+    if (mark - 1u < (uint32_t)GSA_HOT_ENTRIES) {
+        const float4 *rep = reinterpret_cast<const float4 *>(v_splat + (n + (long)(mark - 1u)) * GSA_SPLAT_STRIDE);
+#pragma unroll 1
+        for (int k = 0; k < GSA_HOT_REPLICAS; ++k) {   // (replica k of entry e: row n + k GSA_HOT_ENTRIES + e)
+            const float4 *r = rep + (long)k * GSA_HOT_ENTRIES * (GSA_SPLAT_STRIDE / 4);
+            const float4 a = r[0], b = r[1], c = r[2];
+            v0.x += a.x; v0.y += a.y; v0.z += a.z; v0.w += a.w;
+            v1.x += b.x; v1.y += b.y; v1.z += b.z; v1.w += b.w;
+            v2.x += c.x; v2.y += c.y;
+        }
+    }
+}
+
 // The chain rule of the projection for ONE gaussian and ONE camera: the sweep's raw moments (v0, v1, v2: the gradient
 // record, composite.hip) and the view-direction part of the colour gradient (vdir) -> d loss / d (mean, quaternion,
 // scale, opacity).  One function for the single-camera and the multi-camera backward kernels: the same arithmetic.
@@ -557,7 +578,8 @@ __global__ __launch_bounds__(kBlock, GSA_PROJ_BWD_WAVES) void project_bwd_kernel
 
     if (visible) {
         GsaCamera cam = gsa_load_camera(viewmat, intrin);
-        const float4 v0 = g_v0, v1 = g_v1, v2 = g_v2;
+        float4 v0 = g_v0, v1 = g_v1, v2 = g_v2;
+        fold_hot_replicas(v_splat, (long)n, v0, v1, v2);
         float v_rgb[3] = {v1.z, v1.w, v2.x};
         // ---- colour FIRST: the coefficient row (48 registers) is dead before the projection chain needs its own
         float vdir[3] = {0.f, 0.f, 0.f};   // d loss / d mean through the view direction
@@ -777,7 +799,8 @@ __global__ __launch_bounds__(kBlock, 1) void project_bwd_batch_kernel(
         if (ci + 1 < n_cams) nxt = load_cam(ci + 1);   // (uniform)
         if (active && cur.rx > 0 && cur.ry > 0) {
             GsaCamera cam = gsa_load_camera(viewmats + 16 * ci, intrins + (long)intrin_stride * ci);
-            const float4 v0 = cur.v0, v1 = cur.v1, v2 = cur.v2;
+            float4 v0 = cur.v0, v1 = cur.v1, v2 = cur.v2;
+            fold_hot_replicas(rows_of.v_splat[ci], (long)n, v0, v1, v2);
             const float v_rgb[3] = {v1.z, v1.w, v2.x};
             // ---- colour first (as the single-camera kernel): d loss / d rgb after the clamp mask, the view-direction part of
             // the mean gradient from the digest, and this camera's share of the coefficient gradient

@@ -1,4 +1,4 @@
-// view.hip -- ONE C-ABI call per view forward and one per view backward (ABI 13).
+// view.hip -- ONE C-ABI call per view forward and one per view backward (ABI 13; `hot`: ABI 14).
 //
 // The steady-state chain of a view behind its projection -- bucketed depth ordering, one-pass placement with the compositor's
 // launch order, forward sweep; then tile re-ordering + reverse sweep (+ the projection backward) -- is eight to ten kernel
@@ -34,7 +34,8 @@ extern "C" int gsa_view_fwd(const gsa_view_args *a, gsa_stream_t stream) {
     }
     return gsa_composite_fwd(a->width, a->height, a->channels, a->splat, a->sorted_gid, a->gid_boxes, a->tile_offsets,
                              a->background, a->tile_order, a->render, a->alpha, a->final_T, a->last_id, a->quad_list,
-                             a->quad_count, a->v_splat, a->quad_list ? (long long)a->n : 0, a->bin_tile, stream);
+                             a->quad_count, a->v_splat, a->quad_list ? (long long)a->n + (a->hot ? gsa_hot_rows() : 0) : 0,
+                             a->bin_tile, stream);
 }
 
 extern "C" int gsa_view_bwd(const gsa_view_args *a, gsa_stream_t stream) {
@@ -44,7 +45,12 @@ extern "C" int gsa_view_bwd(const gsa_view_args *a, gsa_stream_t stream) {
     // (the forward sweep cleared the gradient records on the side: n = 0 -- only the tiles are ordered by their blended records)
     int rc = gsa_composite_bwd_prepare(0, a->v_splat, tile_w * tile_h, a->quad_count, a->bwd_tile_order, stream);
     if (rc != GSA_OK) return rc;
-    rc = a->sweep_rgb
+    GSA_RETURN_IF(a->hot && a->sweep_rgb, GSA_ERR_INVALID_ARGUMENT);
+    rc = a->hot
+             ? gsa_composite_bwd_lists_hot(a->width, a->height, a->channels, a->splat, a->sorted_gid, a->gid_boxes, a->tile_offsets,
+                                           a->background, a->bwd_tile_order, a->final_T, a->last_id, a->v_render, a->v_alpha,
+                                           a->quad_list, a->quad_count, (long long)a->n, a->v_splat, a->bin_tile, stream)
+         : a->sweep_rgb
              ? gsa_composite_bwd_lists_rgb(a->width, a->height, a->channels, a->splat, a->sorted_gid, a->gid_boxes, a->tile_offsets,
                                            a->background, a->bwd_tile_order, a->final_T, a->last_id, a->v_render, a->v_alpha,
                                            a->quad_list, a->quad_count, a->v_splat, a->sweep_rgb, a->bin_tile, stream)

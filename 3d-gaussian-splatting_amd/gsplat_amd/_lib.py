@@ -13,7 +13,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_u
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # GSPLAT_AMD_LIB: developer override to A/B another build of the SAME C ABI (still a HIP library; no fallback)
 LIB_PATH = os.environ.get("GSPLAT_AMD_LIB") or os.path.join(_PKG_ROOT, "lib", "libgsplat_amd.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 SPLAT_STRIDE = 16
 
 P = c_void_p  # every device pointer and the stream cross the boundary as void*
@@ -39,7 +39,7 @@ class ViewArgs(ctypes.Structure):
         ("means", P), ("quats", P), ("scales", P), ("opacities", P), ("colors", P), ("viewmat", P), ("intrin", P), ("sh_aux", P),
         ("radii", P),
         ("v_means", P), ("v_quats", P), ("v_scales", P), ("v_opacities", P), ("v_colors", P), ("v_rgb", P),
-        ("sweep_rgb", P),
+        ("sweep_rgb", P), ("hot", c_int),
     ]
 
 
@@ -80,6 +80,8 @@ SIGNATURES = {
     "gsa_composite_fwd": (c_int, [c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P, P, P, P, P, c_longlong, c_int, P]),
     "gsa_composite_bwd_prepare": (c_int, [c_longlong, P, c_int, P, P, P]),
     "gsa_composite_bwd_lists": (c_int, [c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, P]),
+    "gsa_composite_bwd_lists_hot": (c_int, [c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P, P, P, P, c_longlong, P, c_int, P]),
+    "gsa_hot_rows": (c_longlong, []),
     "gsa_composite_bwd_lists_rgb": (c_int, [c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, c_int, P]),
     "gsa_tile_schedule": (c_int, [c_int, P, P, c_int, c_int, P]),
     "gsa_composite_bwd": (c_int, [c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P, P, P, c_int, P]),

@@ -974,6 +974,13 @@ def tile_schedule(tile_offsets, width: int, height: int, bin_tile: int = TILE_SI
 _BWD_REORDER = True
 
 
+# Replicas for the gradient records of gaussians that cover many tiles (cameras inside the scene: thousands of same-line
+# atomics per splat; gsa_composite_bwd_lists_hot): the gradient-record buffer gets gsa_hot_rows() rows behind the N records.
+# GSPLAT_AMD_HOT_SPLATS=0: the plain sweep (same sums up to the order of the additions).
+_HOT_SPLATS = os.environ.get("GSPLAT_AMD_HOT_SPLATS", "1") != "0"
+HOT_ROWS = int(lib.gsa_hot_rows())
+
+
 class QuadLists(tuple):
     """(quad_list, quad_count) of ``composite_fwd(want_lists=True)``, plus ``zeroed``: the [N,16] gradient-record buffer
     the forward kernel cleared on the side -- ``composite_bwd`` accumulates into it ONCE (a second backward pass over
@@ -999,7 +1006,8 @@ def composite_fwd(splat, sorted_gid, tile_offsets, background, width: int, heigh
         slices = 4 * (bin_tile // TILE_SIZE) ** 2   # quadrant slices per record list (a 32 x 32 bin: four tiles' worth)
         quad_list = torch.empty(slices * max(int(sorted_gid.numel()), 1), dtype=torch.int32, device=dev)
         quad_count = torch.empty(tile_w * tile_h, 4, dtype=torch.int32, device=dev)
-        zeroed = torch.empty_like(splat)   # the backward sweep's gradient records: the forward kernel clears them
+        # the backward sweep's gradient records (+ the hot region behind them): the forward kernel clears them
+        zeroed = torch.empty(splat.shape[0] + (HOT_ROWS if _HOT_SPLATS else 0), SPLAT_STRIDE, dtype=torch.float32, device=dev)
     _call("gsa_composite_fwd", lib.gsa_composite_fwd, width, height, channels, _ptr(splat), _ptr(sorted_gid),
           1 if gid_boxes else 0, _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(render), _ptr(alpha), _ptr(final_T),
           _ptr(last_id), _ptr(quad_list), _ptr(quad_count), _ptr(zeroed), 0 if zeroed is None else zeroed.shape[0],
@@ -1057,17 +1065,26 @@ def composite_bwd(splat, sorted_gid, tile_offsets, background, final_T, last_id,
         quad_list, quad_count = quad_lists
         # one launch: order the tiles by the work the lists hold (exact, unlike the list lengths `tile_order` was built
         # from before the forward pass) -- and clear the gradient records, unless the forward kernel did (QuadLists)
+        n = splat.shape[0]
+        hot = _HOT_SPLATS and v_rgb_out is None
+        rows = n + (HOT_ROWS if hot else 0)   # (the hot region lies behind the N records, cleared with them)
         v_splat = getattr(quad_lists, "zeroed", None)
-        fill = v_splat is None or v_splat.shape != splat.shape
+        fill = v_splat is None or v_splat.shape[0] < rows
         if fill:
-            v_splat = torch.empty_like(splat)
+            v_splat = torch.empty(rows, SPLAT_STRIDE, dtype=torch.float32, device=splat.device)
         else:
             quad_lists.zeroed = None   # (accumulated into once)
         tile_w, tile_h = tile_grid(width, height)
         if fill or tile_order is None or _BWD_REORDER:
             tile_order = torch.empty(8 * ((tile_w * tile_h + 7) // 8), dtype=torch.int32, device=splat.device)
-            _call("gsa_composite_bwd_prepare", lib.gsa_composite_bwd_prepare, splat.shape[0] if fill else 0, _ptr(v_splat),
+            _call("gsa_composite_bwd_prepare", lib.gsa_composite_bwd_prepare, rows if fill else 0, _ptr(v_splat),
                   tile_w * tile_h, _ptr(quad_count), _ptr(tile_order), _stream())
+        if hot:
+            _call("gsa_composite_bwd", lib.gsa_composite_bwd_lists_hot, width, height, channels, _ptr(splat), _ptr(sorted_gid),
+                  1 if gid_boxes else 0, _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(final_T), _ptr(last_id),
+                  _ptr(v_render), _ptr(v_alpha), _ptr(quad_list), _ptr(quad_count), n, _ptr(v_splat), bin_tile, _stream())
+            return v_splat[:n]   # (a view: the replicas stay behind it, where the projection backward looks for them)
+        v_splat = v_splat[:n]
         if v_rgb_out is not None:
             _call("gsa_composite_bwd", lib.gsa_composite_bwd_lists_rgb, width, height, channels, _ptr(splat), _ptr(sorted_gid),
                   1 if gid_boxes else 0, _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(final_T), _ptr(last_id),
@@ -1155,7 +1172,7 @@ def _view_layout(n: int, cap: int, width: int, height: int, channels: int, bin_t
     """Byte offsets of everything a view's chain needs besides its projection and the two tensors the caller sees (render,
     alpha) inside ONE workspace allocation -> ({name: offset}, total bytes, n_blocks, depth-ordering bytes, placement bytes).
     Cached per shape: a view costs one ``torch.empty`` instead of fifteen."""
-    key = (n, cap, width, height, channels, bin_tile, lists)
+    key = (n, cap, width, height, channels, bin_tile, lists, _HOT_SPLATS)
     lay = _VIEW_LAYOUTS.get(key)
     if lay is None:
         t16 = tile_grid(width, height)
@@ -1171,7 +1188,7 @@ def _view_layout(n: int, cap: int, width: int, height: int, channels: int, bin_t
                  ("bin_ws", ws2), ("final_T", 4 * p), ("last_id", 4 * p)]
         if lists:
             slices = 4 * (bin_tile // TILE_SIZE) ** 2
-            parts += [("quad_list", 4 * slices * max(cap, 1)), ("quad_count", 16 * n16), ("v_splat", 4 * SPLAT_STRIDE * n),
+            parts += [("quad_list", 4 * slices * max(cap, 1)), ("quad_count", 16 * n16), ("v_splat", 4 * SPLAT_STRIDE * (n + (HOT_ROWS if _HOT_SPLATS else 0))),
                       ("bwd_tile_order", 4 * order_words)]
         off, offsets, sizes = 0, {}, {}
         for name, nbytes in parts:
@@ -1254,6 +1271,7 @@ class ViewChain:
         if want_lists:
             a.quad_list, a.quad_count, a.v_splat = base + offsets["quad_list"], base + offsets["quad_count"], base + offsets["v_splat"]
             a.bwd_tile_order = base + offsets["bwd_tile_order"]
+            a.hot = 1 if _HOT_SPLATS else 0   # (with sweep_rgb the backward clears the flag: that sweep has no hot form)
         check(lib.gsa_view_fwd(ctypes.byref(a), _stream()), "gsa_view_fwd")
         ch = ViewChain()
         ch.args, ch.ws, ch.lay, ch.render, ch.alpha, ch._views = a, ws, lay, render, alpha, {}
@@ -1276,7 +1294,8 @@ class ViewChain:
         if v is None:
             offsets, sizes = self.lay[0], self.lay[1]
             n, cap, width, height, channels, bt = self.dims
-            flat = self.ws[offsets[name]:offsets[name] + sizes[name]].view(dtype or self._DTYPES[name])
+            nbytes = 4 * SPLAT_STRIDE * n if name == "v_splat" else sizes[name]   # (without the hot region behind the records)
+            flat = self.ws[offsets[name]:offsets[name] + nbytes].view(dtype or self._DTYPES[name])
             shape = {"final_T": (height, width), "last_id": (height, width), "v_splat": (n, SPLAT_STRIDE),
                      "quad_count": (-1, 4)}.get(name)
             v = self._views[name] = flat.view(shape) if shape else flat
@@ -1299,6 +1318,8 @@ class ViewChain:
                 raise ValueError("ViewChain.backward(sweep_rgb=...): a contiguous fp32 [N,3] tensor")
             sweep_rgb.zero_()
         a.sweep_rgb = None if sweep_rgb is None else sweep_rgb.data_ptr()
+        if sweep_rgb is not None:
+            a.hot = 0   # (the hot region was cleared by the forward and simply stays unused)
         if project is None:
             a.project_mode = 0
         else:

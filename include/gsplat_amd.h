@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSA_ABI_VERSION 13
+#define GSA_ABI_VERSION 14
 #define GSA_SPLAT_STRIDE 16
 
 #define GSA_OK 0
@@ -370,6 +370,41 @@ int gsa_composite_bwd_lists_rgb(int width, int height, int channels, const float
                                 const float *v_render, const float *v_alpha, const uint32_t *quad_list,
                                 const int32_t *quad_count, float *v_splat, float *v_rgb, int bin_tile, gsa_stream_t stream);
 
+/* ABI 14 -- HOT gaussians.  Every (quadrant, record) visit of the reverse sweep is one 64-byte float-atomic request on the
+ * gaussian's gradient record; a camera inside the scene sees splats that cover thousands of tiles, and tens of thousands of
+ * requests on one line serialise (measured: the sweep 0.535 ms with them, 0.158 ms without).  gsa_composite_bwd_lists_hot
+ * is gsa_composite_bwd_lists for a v_splat buffer of n + gsa_hot_rows() rows, ALL zero on entry (gsa_composite_fwd's
+ * n_zero_rows / gsa_composite_bwd_prepare's n take the sum): behind the n gradient records lies the HOT REGION,
+ * GSA_HOT_REPLICAS x GSA_HOT_ENTRIES replica rows (replica k of entry e is row n + k GSA_HOT_ENTRIES + e: the replicas of
+ * one gaussian lie 256 KB apart, on different memory channels) and GSA_HOT_ENTRIES tag words.  A gaussian whose tile rectangle (word 11 of
+ * its splat record) is at least GSA_HOT_MIN_WIDTH tiles wide claims an entry on first touch (hash of its index, compare-and-
+ * swap on the tag, GSA_HOT_PROBES probes; none free: it adds to its own record as before) and every quadrant's wave adds
+ * into replica (4 tile + quadrant) mod GSA_HOT_REPLICAS; the claiming wave leaves entry + 1 (an integer) in word
+ * GSA_HOT_MARK_FIELD of the gaussian's own gradient record.  gsa_project_bwd / _acc / _factored / _batch* read that word with
+ * the record and add the replicas of a marked gaussian, taking the hot region to lie behind row n of the v_splat they are
+ * given -- so WORDS 10 .. 15 OF A GRADIENT RECORD ARE RESERVED: zero, or anything that is not the bit pattern of an integer in
+ * 1 .. GSA_HOT_ENTRIES, unless the record comes out of gsa_composite_bwd_lists_hot.  Sums are the same up to the order of the
+ * float additions (the atomics' order is not fixed either way). */
+#ifndef GSA_HOT_LOG_ENTRIES   /* (developer builds override these three: tools/wide_ab.sh) */
+#define GSA_HOT_LOG_ENTRIES 12
+#endif
+#define GSA_HOT_ENTRIES (1 << GSA_HOT_LOG_ENTRIES)
+#ifndef GSA_HOT_REPLICAS
+#define GSA_HOT_REPLICAS 16
+#endif
+#ifndef GSA_HOT_MIN_WIDTH
+#define GSA_HOT_MIN_WIDTH 24
+#endif
+#define GSA_HOT_PROBES 8
+#define GSA_HOT_MARK_FIELD 11
+#define GSA_HOT_ROWS ((long long)GSA_HOT_ENTRIES * GSA_HOT_REPLICAS + GSA_HOT_ENTRIES / GSA_SPLAT_STRIDE)
+long long gsa_hot_rows(void);   /* = GSA_HOT_ROWS, for hosts that do not compile against this header */
+int gsa_composite_bwd_lists_hot(int width, int height, int channels, const float *splat,
+                                const uint32_t *sorted_gid, int gid_boxes, const int32_t *tile_offsets, const float *background,
+                                const int32_t *tile_order, const float *final_T, const int32_t *last_id,
+                                const float *v_render, const float *v_alpha, const uint32_t *quad_list,
+                                const int32_t *quad_count, long long n, float *v_splat, int bin_tile, gsa_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Stage 5 (row a3.6): projection + SH backward.  Reads the sweep's moment records (stage 4), the raw
  * parameters and the saved radii; writes EVERY element of v_means[N,3], v_quats[N,4], v_scales[N,3],
@@ -503,6 +538,7 @@ typedef struct gsa_view_args {
     const int32_t *radii;
     float *v_means, *v_quats, *v_scales, *v_opacities, *v_colors, *v_rgb;
     float *sweep_rgb;
+    int hot;   /* ABI 14: 1 -- v_splat has n + gsa_hot_rows() rows; the forward clears them all, the sweep is gsa_composite_bwd_lists_hot */
 } gsa_view_args;
 size_t gsa_view_args_size(void);
 int gsa_view_fwd(const gsa_view_args *args, gsa_stream_t stream);

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(raw, n), f"{n} declared in gsplat_amd.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes binding and header disagree"
-    assert gsplat_amd.lib.gsa_abi_version() == gsplat_amd.ABI_VERSION == 13
+    assert gsplat_amd.lib.gsa_abi_version() == gsplat_amd.ABI_VERSION == 14
 
 
 def test_header_cites_reference_boundary():

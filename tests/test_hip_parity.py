@@ -1521,6 +1521,92 @@ def test_backward_sweep_over_blended_record_lists(gsa, W, H, N, cull_mode, chann
     assert float(((g0 - g1).abs().amax(0) / scale).max()) < 2e-5
 
 
+def test_hot_gaussians_spread_their_atomics_over_replicas(gsa):
+    """ABI 14: a camera inside the scene sees splats that cover most of the frame; every (quadrant, record) visit of the reverse
+    sweep is a 64-byte atomic on the gaussian's gradient record, and thousands of them on one line serialise.  A gaussian whose
+    tile rectangle is >= GSA_HOT_MIN_WIDTH tiles wide claims an entry of the hot region behind the N records and the waves add
+    into its replicas (gsa_composite_bwd_lists_hot); the claiming wave marks the gaussian's own record and the projection
+    backward -- single-camera and per-step kernels -- adds the replicas when it reads a marked record.  Checked: wide gaussians
+    exist and get marked; record + replicas equal the plain sweep's record; both projection backward kernels give the plain
+    path's gradients (to the order of the float additions); the whole operator holds the oracle's tolerance on this scene."""
+    from gsplat_amd import scene, stages as S
+    W, H, N, deg = 800, 592, 4000, 3     # 50 x 37 tiles
+    sc = _scene(N, seed=12, s_min=0.02, s_max=0.9)
+    K = scene.make_intrinsics(W, H)
+    vms = [scene.make_camera(1, 7, radius=0.6), scene.make_camera(4, 7, radius=0.6)]
+    d = {k: v.cuda().contiguous() for k, v in sc.items()}
+    args = (d["means3D"], d["rotations"], d["scales"], d["opacities"][:, 0].contiguous(), d["shs"])
+    views = S.project_views(*args, deg, torch.stack(vms).cuda(), K.cuda(), W, H, 0, return_aux=True)
+    bg = torch.tensor([0.3, 0.6, 0.1]).cuda()
+    rng = np.random.default_rng(3)
+    hot_rows, entries, replicas = S.HOT_ROWS, 4096, 16
+    assert hot_rows == entries * replicas + entries // 16
+    records = {True: [], False: []}
+    try:
+        for hot in (True, False):
+            S._HOT_SPLATS = hot
+            for c, v in enumerate(views):
+                st, sg, to = S.bin_tiles(v.splat, v.radii, v.tiles_touched, v.depth_keys, W, H, 0)
+                v_r = torch.from_numpy(np.random.default_rng(10 + c).uniform(-1, 1, (H, W, 3)).astype(np.float32)).cuda()
+                v_a = torch.from_numpy(np.random.default_rng(20 + c).uniform(-1, 1, (H, W)).astype(np.float32)).cuda()
+                r, a, T, last, lists = S.composite_fwd(v.splat, sg, to, bg, W, H, 3, want_lists=True)
+                assert lists.zeroed.shape[0] == N + (hot_rows if hot else 0)
+                g = S.composite_bwd(v.splat, sg, to, bg, T, last, v_r, v_a, W, H, 3, quad_lists=lists)
+                assert g.shape == (N, 16)
+                records[hot].append(g)
+    finally:
+        S._HOT_SPLATS = True
+    for c, v in enumerate(views):
+        g_hot, g_plain = records[True][c], records[False][c]
+        width = (v.splat[:, 11].contiguous().view(torch.int32) >> 20) & 0x3FF
+        wide = (width >= 24) & (v.radii > 0).all(-1)
+        marks = g_hot[:, 11].contiguous().view(torch.int32)
+        assert int(wide.sum()) >= 20, int(wide.sum())
+        assert int((marks != 0).sum()) >= 20 and not bool((marks != 0)[~wide].any())   # only wide gaussians claim entries
+        assert int(marks.max()) <= entries and float(g_plain[:, 10:].abs().max()) == 0.0
+        # record + replicas == the plain sweep's record
+        whole = g_hot._base if g_hot._base is not None else g_hot
+        assert whole.shape[0] == N + hot_rows
+        folded = g_hot.clone()
+        idx = torch.nonzero(marks != 0)[:, 0]
+        e = (marks[idx] - 1).long()
+        rep = whole[N:N + entries * replicas].view(replicas, entries, 16)[:, e].sum(0)   # (replica-major)
+        folded[idx] += rep
+        tags = whole[N + entries * replicas:].contiguous().view(torch.int32).view(-1)[:entries]
+        assert torch.equal(tags[e].long(), idx + 1)                                     # the entries are tagged with their owners
+        scale = g_plain[:, :10].abs().amax(0).clamp_min(1e-30)
+        assert float(((folded[:, :10] - g_plain[:, :10]).abs().amax(0) / scale).max()) < 2e-5
+        # a marked gaussian's own record is NOT the whole sum any more: the replicas carry most of it
+        assert float((g_hot[idx, 5] - g_plain[idx, 5]).abs().max()) > 0
+    # the projection backward folds the replicas: the single-camera kernel ...
+    outs = {}
+    for hot in (True, False):
+        got = None
+        for c, v in enumerate(views):
+            got = S.project_bwd(*args, deg, v.viewmat, v.Kmat, W, H, v.splat, v.radii, records[hot][c], out=got,
+                                accumulate=c > 0, sh_aux=v.sh_aux)
+        outs[hot] = got
+    # (both paths sum thousands of fp32 atomics per wide gaussian in an order of their own, and the projection backward
+    # amplifies that through cancelling terms: two runs of ONE path differ by a few 1e-5 here; the bar against the fp64
+    # oracle is at the end)
+    for name, a_, b_ in zip(("v_means", "v_quats", "v_scales", "v_opacities", "v_colors"), outs[True], outs[False]):
+        assert torch.isfinite(a_).all() and _rel(a_, b_) <= 2e-4, (name, _rel(a_, b_))
+    # ... and the per-step kernel
+    step = [torch.empty_like(t) for t in outs[False]]
+    assert S.project_views_bwd(*args, deg, views, records[True], W, H, step)
+    for name, a_, b_ in zip(("v_means", "v_quats", "v_scales", "v_opacities", "v_colors"), step, outs[True]):
+        assert _rel(a_, b_) <= 1e-5, (name, _rel(a_, b_))   # (the same records through the other kernel)
+    # the operator against the oracle with hot gaussians in the frame (the default path: hot region on) -- a smaller frame and
+    # population: the CPU oracle takes minutes on the scene above
+    W2, H2 = 448, 272     # 28 x 17 tiles
+    sc2 = _scene(1200, seed=13, s_min=0.02, s_max=0.9)
+    vm2, K2 = scene.make_camera(2, 7, radius=0.6), scene.make_intrinsics(W2, H2)
+    _, splat2, radii2, _, _ = _hip_front_end(sc2, vm2, K2, W2, H2, deg)
+    wide2 = (((splat2[:, 11].contiguous().view(torch.int32) >> 20) & 0x3FF) >= 24) & (radii2 > 0).all(-1)
+    assert int(wide2.sum()) >= 3, int(wide2.sum())
+    _compare(sc2, vm2, K2, W2, H2, deg, bg=torch.tensor([0.3, 0.6, 0.1]))
+
+
 @pytest.mark.parametrize("W,H,N,s_max,giants", [(640, 360, 30_000, 0.05, 0), (160, 96, 4000, 0.3, 0),
                                                  (1920, 1080, 50_000, 0.02, 5), (40, 24, 500, 0.5, 0),
                                                  (800, 592, 60_000, 0.03, 4)])
