@@ -868,7 +868,9 @@ def main() -> None:
                        "intersections_M_ring_mean": round(ring_M, 1), "binned_records_ring_mean": round(ring_binned, 1),
                        "intersections_M": m, "bin_tile": stages.bin_tile_for(width, height, stages.DEFAULT_CULL_MODE if args.cull_mode is None else args.cull_mode), "binned_records": info.get("binned"),
                        "grad_l1": round(grad_l1_head, 3), "grad_l1_single_view": round(grad_l1, 3),
-                       "cull_mode": stages.DEFAULT_CULL_MODE if args.cull_mode is None else args.cull_mode},
+                       "cull_mode": stages.DEFAULT_CULL_MODE if args.cull_mode is None else args.cull_mode,
+                       # replica gradient rows for gaussians that cover >= 24 tile columns (ABI 14; none in this scene from outside)
+                       "hot_splats": bool(stages._HOT_SPLATS)},
             # the same step on the SAME gpus x views cameras every step (r04's protocol: remembered capacities / key ranges
             # never move), and what the moving window cost the timed region in speculation
             "value_fixed_cameras": round(world * B * p * args.steps / fixed["s"] / 1e6, 3),
