@@ -736,7 +736,7 @@ class ViewParallelTrainer:
             bins, order, final_T, last_id, lists = fwd
             v_splat = S.composite_bwd(splat, bins.sorted_gid_buffer, bins.tile_offsets, bgc, final_T, last_id, v, None,
                                       W, H, 3, order, quad_lists=lists, bin_tile=bins.bin_tile, gid_boxes=bins.boxed,
-                                      v_rgb_out=vr_all[self.rank, j] if rank_batch else None)
+                                      v_rgb_out=vr_all[self.rank, j] if rank_batch else None, fold=False)
             if batch_bwd or rank_batch:   # (finished for all views at once, below)
                 shared.setdefault("v_splat", {})[j] = v_splat
                 return

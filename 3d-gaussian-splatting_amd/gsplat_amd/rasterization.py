@@ -167,7 +167,8 @@ class _RasterizeOneCamera(torch.autograd.Function):
         rgb_here = ctx.sh_grad_factored if (ctx.deferred_projection is not None and lists is not None) else None
         v_splat = S.composite_bwd(splat, sorted_gid, tile_offsets, bg_c, final_T, last_id, v_render, v_alpha_c,
                                   width, height, channels, tile_order,
-                                  quad_lists=lists, bin_tile=ctx.bin_tile, gid_boxes=ctx.gid_boxes, v_rgb_out=rgb_here)
+                                  quad_lists=lists, bin_tile=ctx.bin_tile, gid_boxes=ctx.gid_boxes, v_rgb_out=rgb_here,
+                                  fold=False)   # (the projection backward resolves the hot gaussians' replicas)
         if ctx.deferred_projection is not None:
             ctx.deferred_projection.v_splat, ctx.deferred_projection.v_rgb = v_splat, rgb_here
             return (None,) * 20

@@ -1048,15 +1048,36 @@ def record_grads_to_moments(splat: torch.Tensor, g: torch.Tensor) -> torch.Tenso
     return m
 
 
+def fold_hot_replicas(v_splat: torch.Tensor, n: int) -> torch.Tensor:
+    """What the projection backward does when it reads a marked record, for callers that look at the records themselves:
+    adds every claimed entry's replica rows (the hot region behind row ``n`` of ``v_splat``, ``gsa_composite_bwd_lists_hot``)
+    to its owner's record and clears the marks.  Plain torch ops, no host wait.  -> the [n,16] records (a view)."""
+    entries = int(lib.gsa_hot_rows()) * SPLAT_STRIDE // (SPLAT_STRIDE * _HOT_REPLICAS + 1)
+    records, rep = v_splat[:n], v_splat[n:n + entries * _HOT_REPLICAS].view(_HOT_REPLICAS, entries, SPLAT_STRIDE)
+    tags = v_splat[n + entries * _HOT_REPLICAS:].contiguous().view(torch.int32).view(-1)[:entries]
+    claimed = tags > 0
+    owner = torch.where(claimed, tags.long() - 1, torch.zeros_like(tags, dtype=torch.long))
+    records.index_add_(0, owner, rep.sum(0) * claimed[:, None])
+    records[:, 11] = 0.0
+    return records
+
+
+_HOT_REPLICAS = 16   # (GSA_HOT_REPLICAS of include/gsplat_amd.h: the layout of the hot region)
+
+
 def composite_bwd(splat, sorted_gid, tile_offsets, background, final_T, last_id, v_render, v_alpha, width: int,
                   height: int, channels: int, tile_order=None, quad_lists=None, bin_tile: int = TILE_SIZE,
-                  gid_boxes: bool = False, v_rgb_out: Optional[torch.Tensor] = None):
+                  gid_boxes: bool = False, v_rgb_out: Optional[torch.Tensor] = None, fold: bool = True):
     """-> v_splat [N,16]: per gaussian the raw moments of u = d loss / d sigma over d = mean2d - pixel
     (sum u dx, u dy, u dx^2, u dx dy, u dy^2, u) and sum fac * v_out per channel -- the gradient record
     ``project_bwd`` consumes (``moments_to_record_grads`` gives the mean / conic / opacity gradients).
     ``v_rgb_out`` (a contiguous fp32 [N,3] tensor; sweeps over the forward's lists only): receives the colour moments --
     fields 6..8 -- already masked by the forward's colour clamp, i.e. d loss / d rgb per gaussian in the layout the
-    view-parallel exchange all-gathers (it is zeroed here; those fields of ``v_splat`` stay zero)."""
+    view-parallel exchange all-gathers (it is zeroed here; those fields of ``v_splat`` stay zero).
+    ``fold`` (sweeps over the forward's lists with the hot region on): True -- the records are complete on return
+    (``fold_hot_replicas``); False -- what the sweep left: gaussians that cover many tiles have their sums in the replica rows
+    behind the returned view and a mark in word 11, which ``project_bwd`` / ``project_views_bwd`` resolve themselves (the
+    product's callers: no extra pass)."""
     if v_rgb_out is not None:
         if quad_lists is None or v_rgb_out.shape != (splat.shape[0], 3) or v_rgb_out.dtype != torch.float32 or not v_rgb_out.is_contiguous():
             raise ValueError("composite_bwd(v_rgb_out=...): needs the forward's lists and a contiguous fp32 [N,3] tensor")
@@ -1083,7 +1104,8 @@ def composite_bwd(splat, sorted_gid, tile_offsets, background, final_T, last_id,
             _call("gsa_composite_bwd", lib.gsa_composite_bwd_lists_hot, width, height, channels, _ptr(splat), _ptr(sorted_gid),
                   1 if gid_boxes else 0, _ptr(tile_offsets), _ptr(background), _ptr(tile_order), _ptr(final_T), _ptr(last_id),
                   _ptr(v_render), _ptr(v_alpha), _ptr(quad_list), _ptr(quad_count), n, _ptr(v_splat), bin_tile, _stream())
-            return v_splat[:n]   # (a view: the replicas stay behind it, where the projection backward looks for them)
+            # (a view: the replicas stay behind it, where the projection backward looks for them)
+            return fold_hot_replicas(v_splat, n) if fold else v_splat[:n]
         v_splat = v_splat[:n]
         if v_rgb_out is not None:
             _call("gsa_composite_bwd", lib.gsa_composite_bwd_lists_rgb, width, height, channels, _ptr(splat), _ptr(sorted_gid),

@@ -1551,7 +1551,7 @@ def test_hot_gaussians_spread_their_atomics_over_replicas(gsa):
                 v_a = torch.from_numpy(np.random.default_rng(20 + c).uniform(-1, 1, (H, W)).astype(np.float32)).cuda()
                 r, a, T, last, lists = S.composite_fwd(v.splat, sg, to, bg, W, H, 3, want_lists=True)
                 assert lists.zeroed.shape[0] == N + (hot_rows if hot else 0)
-                g = S.composite_bwd(v.splat, sg, to, bg, T, last, v_r, v_a, W, H, 3, quad_lists=lists)
+                g = S.composite_bwd(v.splat, sg, to, bg, T, last, v_r, v_a, W, H, 3, quad_lists=lists, fold=False)
                 assert g.shape == (N, 16)
                 records[hot].append(g)
     finally:
@@ -1578,6 +1578,9 @@ def test_hot_gaussians_spread_their_atomics_over_replicas(gsa):
         assert float(((folded[:, :10] - g_plain[:, :10]).abs().amax(0) / scale).max()) < 2e-5
         # a marked gaussian's own record is NOT the whole sum any more: the replicas carry most of it
         assert float((g_hot[idx, 5] - g_plain[idx, 5]).abs().max()) > 0
+        # the stage function's default hands complete records back (what a caller that reads them expects), marks cleared
+        done = S.fold_hot_replicas(whole.clone(), N)
+        assert float(((done[:, :10] - g_plain[:, :10]).abs().amax(0) / scale).max()) < 2e-5 and float(done[:, 10:].abs().max()) == 0
     # the projection backward folds the replicas: the single-camera kernel ...
     outs = {}
     for hot in (True, False):
