@@ -166,6 +166,7 @@ def key_range_buffer(n: int, dev) -> torch.Tensor:
     return torch.empty((n + 63) // 64, 4, dtype=torch.int32, device=dev)
 
 
+_DEBUG_BINS = os.environ.get("GSPLAT_AMD_DEBUG_BINS") == "1"
 _TOKEN = [0]
 
 
@@ -521,6 +522,17 @@ class TileBins:
             if not plausible or os.environ.get("GSPLAT_AMD_DEBUG_SLOTS") == "1":
                 print(f"[gsplat_amd] finalize: implausible control words {[int(x) & 0xFFFFFFFF for x in ctl_host]} token={self._slot[2]} "
                       f"key={self._key} n={self._n} capacity={self.capacity} ordering={self.key_bits}", file=sys.stderr, flush=True)
+                dbg = getattr(self, "_debug", None)
+                if dbg is not None:   # (GSPLAT_AMD_DEBUG_BINS=1: what the device holds once everything queued has run)
+                    torch.cuda.synchronize()
+                    ctl_d, rects_d, keys_d, offs_d = dbg
+                    keys64 = keys_d.to(torch.int64) & 0xFFFFFFFF
+                    cnt = rects_d.view(-1, 2)[:, 1].to(torch.int64) & 0xFFFFFFFF
+                    print(f"[gsplat_amd]   after a device sync: host words {[int(x) & 0xFFFFFFFF for x in ctl_host]}, device ctl "
+                          f"{[int(x) & 0xFFFFFFFF for x in ctl_d.tolist()]}; inputs: sum of counts {int(cnt.sum())} (max {int(cnt.max())}), "
+                          f"keys min {int(keys64.min())} zeros {int((keys64 == 0).sum())} culled {int((keys64 == 0xFFFFFFFF).sum())}; "
+                          f"offsets max {int((offs_d.to(torch.int64) & 0xFFFFFFFF).max())}; stream {torch.cuda.current_stream()}",
+                          file=sys.stderr, flush=True)
             if plausible:
                 _note_count(self._spec, self._key, self._n, self._m)
                 if self.key_bits is not None:   # (the unfused path sorts all 32 bits and leaves no range)
@@ -926,6 +938,8 @@ def bin_tiles(splat, radii, tiles_touched, depth_keys, width: int, height: int, 
                   _ptr(qbox) if boxed else None, _ptr(ws2), ws2_bytes, st)
         bins = TileBins(sorted_tile, sorted_gid, tile_offsets, cap, m_known, key, slot, N, key_bits, keys_ok, boxed, spec)
         bins.tile_order = tile_order
+        if _DEBUG_BINS:   # (diagnostics of an implausible read-back: what went in and what the device holds)
+            bins._debug = (ctl, tile_rects, depth_keys, offsets)
         return bins
     isect_tile = torch.empty(cap, dtype=torch.int32, device=dev)
     isect_gid = torch.empty(cap, dtype=torch.int32, device=dev)

@@ -298,7 +298,7 @@ def _bench_bucket(tmp_path, tag, gpus, views_per_gpu, streams, exchange="factore
     import json
     import subprocess
     out = os.path.join(str(tmp_path), f"{tag}.pt")
-    env = dict(os.environ, GSPLAT_AMD_BENCH_BACKEND="gloo")
+    env = dict(os.environ, GSPLAT_AMD_BENCH_BACKEND="gloo", GSPLAT_AMD_DEBUG_BINS="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     # (the ranks share this process's card: what the tests before left cached here -- and what only the cyclic collector
