@@ -524,7 +524,11 @@ class TileBins:
                       f"key={self._key} n={self._n} capacity={self.capacity} ordering={self.key_bits}", file=sys.stderr, flush=True)
                 dbg = getattr(self, "_debug", None)
                 if dbg is not None:   # (GSPLAT_AMD_DEBUG_BINS=1: what the device holds once everything queued has run)
-                    torch.cuda.synchronize()
+                    try:
+                        torch.cuda.synchronize()
+                    except Exception as exc:   # noqa: BLE001  (a device fault surfaces here: say which)
+                        print(f"[gsplat_amd]   device sync raised {type(exc).__name__}: {exc}", file=sys.stderr, flush=True)
+                        raise
                     ctl_d, rects_d, keys_d, offs_d = dbg
                     keys64 = keys_d.to(torch.int64) & 0xFFFFFFFF
                     cnt = rects_d.view(-1, 2)[:, 1].to(torch.int64) & 0xFFFFFFFF
