@@ -167,7 +167,7 @@ def key_range_buffer(n: int, dev) -> torch.Tensor:
 
 
 _DEBUG_BINS = os.environ.get("GSPLAT_AMD_DEBUG_BINS") == "1"
-_DEBUG_SUMS = {}   # (debug) data pointer of a projection's rectangle slab -> sum of its record counts right behind the launch
+_DEBUG_CALLS, _DEBUG_RANGES = [0], []   # (debug) project_views calls; (call, slab name, pointer, bytes, stream) of the last ones
 _TOKEN = [0]
 
 
@@ -382,16 +382,14 @@ def project_views(means, quats, scales, opacities, colors, sh_degree: int, viewm
               _ptr(colors), sh_degree, sh_coeffs, C, _ptr(vm), _ptr(km), stride, width, height, cull_mode,
               _ptr(splat), _ptr(radii), _ptr(tiles_touched), _ptr(depth_keys), _ptr(tile_rects), _ptr(sh_aux), bt,
               _ptr(key_range), _ptr(qbox), _stream())
-    if _DEBUG_BINS and N > 0:   # (diagnostics: what the projection left, checked right behind it and remembered per slab)
-        torch.cuda.current_stream().synchronize()
-        for c in range(C):
-            cnt = int((tile_rects[c][:, 1].to(torch.int64) & 0xFFFFFFFF).sum())
-            _DEBUG_SUMS[tile_rects[c].data_ptr()] = cnt
-            if cnt > 4096 * N:
-                print(f"[gsplat_amd] project_views: camera {c} of {C}: sum of record counts {cnt} right behind the launch; viewmat "
-                      f"{vm[c].flatten().tolist()} K {km.flatten().tolist()[:9]} means finite {bool(torch.isfinite(means).all())} "
-                      f"absmax {float(means.abs().max())} opac range {float(opacities.min())}..{float(opacities.max())} stream "
-                      f"{torch.cuda.current_stream()}", file=sys.stderr, flush=True)
+    if _DEBUG_BINS and N > 0:   # (diagnostics, no synchronisation: where this call's slabs lie, for the overlap search below)
+        _DEBUG_CALLS[0] += 1
+        for name, t in (("splat", splat), ("radii", radii), ("tiles_touched", tiles_touched), ("depth_keys", depth_keys),
+                        ("tile_rects", tile_rects), ("sh_aux", sh_aux), ("key_range", key_range), ("qbox", qbox)):
+            if t is not None:
+                _DEBUG_RANGES.append((_DEBUG_CALLS[0], name, t.data_ptr(), t.numel() * t.element_size(),
+                                      torch.cuda.current_stream().cuda_stream))
+        del _DEBUG_RANGES[:-64]
     return [ViewProjection(splat=splat[c], radii=radii[c], tiles_touched=tiles_touched[c], depth_keys=depth_keys[c],
                            tile_rects=tile_rects[c], sh_aux=None if sh_aux is None else sh_aux[c], key_range=key_range[c],
                            qbox=None if qbox is None else qbox[c], viewmat=vm[c], Kmat=km[c] if km.dim() == 3 else km,
@@ -546,9 +544,13 @@ class TileBins:
                     print(f"[gsplat_amd]   after a device sync: host words {[int(x) & 0xFFFFFFFF for x in ctl_host]}, device ctl "
                           f"{[int(x) & 0xFFFFFFFF for x in ctl_d.tolist()]}; inputs: sum of counts {int(cnt.sum())} (max {int(cnt.max())}), "
                           f"keys min {int(keys64.min())} zeros {int((keys64 == 0).sum())} culled {int((keys64 == 0xFFFFFFFF).sum())}; "
-                          f"offsets max {int((offs_d.to(torch.int64) & 0xFFFFFFFF).max())}; stream {torch.cuda.current_stream()}; "
-                          f"sum of counts right behind the projection launch: {_DEBUG_SUMS.get(rects_d.data_ptr())}",
+                          f"offsets max {int((offs_d.to(torch.int64) & 0xFFFFFFFF).max())}; stream {torch.cuda.current_stream()}",
                           file=sys.stderr, flush=True)
+                    lo, hi = rects_d.data_ptr(), rects_d.data_ptr() + rects_d.numel() * 4
+                    mine = [r for r in _DEBUG_RANGES if r[2] <= lo < r[2] + r[3]]
+                    over = [r for r in _DEBUG_RANGES if r[2] < hi and lo < r[2] + r[3] and r not in mine]
+                    print(f"[gsplat_amd]   the rectangles lie at {lo:#x}..{hi:#x}; slab(s) they belong to: {mine}; OTHER projection "
+                          f"slabs overlapping them: {over}; all calls so far: {_DEBUG_CALLS[0]}", file=sys.stderr, flush=True)
             if plausible:
                 _note_count(self._spec, self._key, self._n, self._m)
                 if self.key_bits is not None:   # (the unfused path sorts all 32 bits and leaves no range)
