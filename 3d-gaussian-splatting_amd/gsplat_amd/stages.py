@@ -551,6 +551,21 @@ class TileBins:
                     over = [r for r in _DEBUG_RANGES if r[2] < hi and lo < r[2] + r[3] and r not in mine]
                     print(f"[gsplat_amd]   the rectangles lie at {lo:#x}..{hi:#x}; slab(s) they belong to: {mine}; OTHER projection "
                           f"slabs overlapping them: {over}; all calls so far: {_DEBUG_CALLS[0]}", file=sys.stderr, flush=True)
+                    import gc
+                    seen, owners = set(), []
+                    for o in gc.get_objects():   # every live device tensor whose STORAGE overlaps the rectangles
+                        try:
+                            if torch.is_tensor(o) and o.is_cuda:
+                                st_ = o.untyped_storage()
+                                p0, nb = st_.data_ptr(), st_.nbytes()
+                                if p0 < hi and lo < p0 + nb and (p0, nb) not in seen:
+                                    seen.add((p0, nb))
+                                    owners.append((hex(p0), nb, tuple(o.shape), str(o.dtype), sys.getrefcount(o)))
+                        except Exception:   # noqa: BLE001
+                            pass
+                    print(f"[gsplat_amd]   live tensor storages overlapping them: {owners}; allocator: "
+                          f"{ {k: v for k, v in torch.cuda.memory_stats().items() if k in ('num_alloc_retries', 'num_ooms', 'num_device_free', 'num_device_alloc', 'num_sync_all_streams')} }",
+                          file=sys.stderr, flush=True)
             if plausible:
                 _note_count(self._spec, self._key, self._n, self._m)
                 if self.key_bits is not None:   # (the unfused path sorts all 32 bits and leaves no range)
