@@ -23,6 +23,7 @@ They hand it two callables; it owns streams, events, ordering, the deferred chec
 from __future__ import annotations
 
 import contextlib
+import os
 from typing import Callable, List, Optional, Sequence
 
 import torch
@@ -43,6 +44,8 @@ class ViewState:
 # evaluator) ended up with a pipeline whose two streams shared ONE queue -- its views then ran one after the other (the
 # training-step leg of bench.py 2.82 ms where the same step alone in a process takes 2.53).
 _STREAMS = {}
+# GSPLAT_AMD_DEBUG_LAG="<stream index>:<cycles>" (developer aid): a spin kernel in front of every view of that side stream
+_DEBUG_LAG = tuple(int(x) for x in os.environ["GSPLAT_AMD_DEBUG_LAG"].split(":")) if os.environ.get("GSPLAT_AMD_DEBUG_LAG") else None
 
 
 def _side_streams(device, n: int, priority: int) -> List[torch.cuda.Stream]:
@@ -135,6 +138,8 @@ class ViewPipeline:
                         if shared is not None and id(st) not in waited:
                             st.wait_event(shared)
                             waited.add(id(st))
+                    if _DEBUG_LAG and st is not None and (j % len(use)) == _DEBUG_LAG[0]:
+                        torch.cuda._sleep(_DEBUG_LAG[1])   # (debug: this stream falls behind the others, as on a shared card)
                     state = forward(j, defer)
                     # the bucket is summed into in view order; the first view also waits for the previous step's last use of it
                     before = prev if j > 0 else (self._step_done if st is not None else None)
