@@ -353,26 +353,6 @@ def test_bench_multi_view_step_overlapped_equals_serial_and_one_process(tmp_path
     assert line["config"]["speculation_check"] == "per view" and line["config"]["overlap"] == "alternate"
 
 
-def test_bench_rehearses_four_ranks_by_two_views_on_a_moving_ring(tmp_path):
-    """The widest multi-rank shape a one-GPU box admits (its process guard allows six processes on the card: four ranks and
-    this one): bench.py with 4 gloo ranks x 2 views per step on a ring of 16 cameras -- the window moves from step to step, a
-    rank's view j is camera base + 4 j + rank -- leaves the bucket of ONE process rendering the same 8 cameras as an 8-view
-    step (shared projection backward), and the line carries what the driver's scaling run reads (`value_c4`: one view per
-    rank and step, the exchange tails, the host-side agreement).  The 8 x 1 shape (BASELINE C4 as written) runs over real
-    collectives on the CPU: tests/test_bench_exchange.py::test_exchange_over_gloo_at_the_8_gpu_shapes.  No scaling number is
-    claimed from ranks that share a card."""
-    n = 20_000
-    four, line4 = _bench_bucket(tmp_path, "w4b2", 4, 2, 2, extra=("--ring", "16", "--no-train-step"))
-    one, line1 = _bench_bucket(tmp_path, "w1b8", 1, 8, 2, extra=("--ring", "16", "--no-train-step"))
-    assert line4["n_gpus"] == 4 and line4["exchange"]["world_size"] == 4 and line4["config"]["ring_cameras"] == 16
-    assert line4["config"]["views_per_gpu_per_step"] == 2 and line1["config"]["views_per_gpu_per_step"] == 8
-    assert line4["value_c4"] > 0 and line4["c4"]["exchange_tail_ms"] >= 0 and line4["agree_ms_per_step"] >= 0
-    assert line1["config"]["projection"] == "per step: forward + backward"
-    scale = float(one.abs().max())
-    assert scale > 0 and float((four[:11 * n] - one[:11 * n]).abs().max()) <= 2e-5 * scale
-    assert float((four[11 * n:] - one[11 * n:]).abs().max()) <= 2e-5 * float(one[11 * n:].abs().max())
-
-
 def test_bench_exchange_executes_over_rccl_with_one_rank(tmp_path):
     """The RCCL branch of bench.py's exchange on the device: ONE rank with a real ``nccl`` process group
     (GSPLAT_AMD_BENCH_FORCE_DIST=1) -- ``all_gather_into_tensor`` behind every view's backward, the asynchronous
