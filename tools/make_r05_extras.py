@@ -74,6 +74,11 @@ shutil.copy(f"{src}/stats_c5/p_kernel_stats.csv", f"{out}/r05_c5_kernel_stats.cs
 log = [ln for ln in open(f"{src}/train_step.log").read().splitlines() if ln.startswith("fused=")]
 host = open(f"{src}/train_host.txt").read().strip().splitlines()[-12:] if os.path.exists(f"{src}/train_host.txt") else []
 host0 = open(f"{src}/train_host_nochain.txt").read().strip().splitlines()[-12:] if os.path.exists(f"{src}/train_host_nochain.txt") else []
+def work(lines):
+    m = re.search(r"median ([0-9.]+) ms.*waiting for control words ([0-9.]+) ms", " ".join(lines))
+    return f"{float(m.group(1)) - float(m.group(2)):.2f}" if m else "?"
+
+
 host = [ln for ln in host if "amdgpu.ids" not in ln]
 host0 = [ln for ln in host0 if "amdgpu.ids" not in ln]
 text = f"""# r05 -- BASELINE config C3 as the loop runs it: full optimisation steps (4 views -> loss -> backward -> Adam), 1 M gaussians, 1080p, SH 3
@@ -105,8 +110,8 @@ stage by stage (`GSPLAT_AMD_VIEW_CALLS=0`):
 {chr(10).join(host0)}
 ```
 
-Host WORK per step = host time in `training_step` minus the wait for the step's control words: ~0.83 ms with the per-view calls,
-~1.06 ms stage by stage (an earlier box: 0.81 / 1.11); the step is device-paced either way.
+Host WORK per step = host time in `training_step` minus the wait for the step's control words: {work(host)} ms with the per-view
+calls, {work(host0)} ms stage by stage (earlier boxes of the round: 0.81 / 1.11 and 0.83 / 1.06); the step is device-paced either way.
 
 `rocprofv3 --kernel-trace --stats -- python3 tools/bench_train_step.py` (FUSED_ONLY=1: 3 warm-up + 10 timed steps of 4 views;
 durations INCLUDE the time a kernel waits beside another stream's sweep, which is why the short kernels read long):
