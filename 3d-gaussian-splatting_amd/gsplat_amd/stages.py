@@ -366,6 +366,9 @@ def project_views(means, quats, scales, opacities, colors, sh_degree: int, viewm
     vm, km = f32c(viewmats, "viewmats"), f32c(Kmats, "Ks")
     stride = 9 if km.dim() == 3 else 0
     done = None
+    if _DEBUG_BINS:   # (diagnostics: a slab that still holds this pattern when it is read was never written by the launch below)
+        tile_rects.fill_(0x5EADBEEF)
+        depth_keys.fill_(0x5EADBEEF)
     if (_SPLIT_PROJECTION if split is None else split) and N > 0:
         side = _fork_records(dev)
         _call("gsa_project_fwd_records", lib.gsa_project_fwd_parts, PROJECT_RECORDS, N, _ptr(means), _ptr(quats), _ptr(scales),
@@ -544,8 +547,10 @@ class TileBins:
                     print(f"[gsplat_amd]   after a device sync: host words {[int(x) & 0xFFFFFFFF for x in ctl_host]}, device ctl "
                           f"{[int(x) & 0xFFFFFFFF for x in ctl_d.tolist()]}; inputs: sum of counts {int(cnt.sum())} (max {int(cnt.max())}), "
                           f"keys min {int(keys64.min())} zeros {int((keys64 == 0).sum())} culled {int((keys64 == 0xFFFFFFFF).sum())}; "
-                          f"offsets max {int((offs_d.to(torch.int64) & 0xFFFFFFFF).max())}; stream {torch.cuda.current_stream()}",
-                          file=sys.stderr, flush=True)
+                          f"offsets max {int((offs_d.to(torch.int64) & 0xFFFFFFFF).max())}; stream {torch.cuda.current_stream()}; "
+                          f"words still holding the pre-launch pattern: rectangles {int((rects_d == 0x5EADBEEF).sum())} of "
+                          f"{rects_d.numel()}, keys {int((keys_d == 0x5EADBEEF).sum())} of {keys_d.numel()}; first rectangle words "
+                          f"{[hex(int(x) & 0xFFFFFFFF) for x in rects_d.view(-1)[:8].tolist()]}", file=sys.stderr, flush=True)
                     lo, hi = rects_d.data_ptr(), rects_d.data_ptr() + rects_d.numel() * 4
                     mine = [r for r in _DEBUG_RANGES if r[2] <= lo < r[2] + r[3]]
                     over = [r for r in _DEBUG_RANGES if r[2] < hi and lo < r[2] + r[3] and r not in mine]
