@@ -27,7 +27,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, colors, viewmat, Kmat, background,
                 width: int, height: int, sh_degree: int, channels: int, cull_mode: int, grad_out, grad_accumulate,
-                sh_grad_factored, deferred=None, projection=None, collector=None, speculation=None):
+                sh_grad_factored, deferred=None, projection=None, collector=None, speculation=None, grad_ready=None):
         means_c, quats_c, scales_c = S.f32c(means, "means"), S.f32c(quats, "quats"), S.f32c(scales, "scales")
         opac_c, colors_c = S.f32c(opacities, "opacities"), S.f32c(colors, "colors")
         view_c, K_c = S.f32c(viewmat, "viewmats"), S.f32c(Kmat, "Ks")
@@ -92,6 +92,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
             ctx.grad_out = grad_out
             ctx.grad_accumulate = bool(grad_accumulate)
             ctx.sh_grad_factored = sh_grad_factored
+            ctx.grad_ready = grad_ready
             ctx.in_shapes = (means.shape, quats.shape, scales.shape, opacities.shape, colors.shape)
             ctx.deferred_projection = projection if (projection is not None and projection.defer_backward) else None
             ctx.mark_non_differentiable(splat, radii, tiles_touched)
@@ -140,6 +141,7 @@ class _RasterizeOneCamera(torch.autograd.Function):
         ctx.grad_out = grad_out
         ctx.grad_accumulate = bool(grad_accumulate)
         ctx.sh_grad_factored = sh_grad_factored
+        ctx.grad_ready = grad_ready
         ctx.in_shapes = (means.shape, quats.shape, scales.shape, opacities.shape, colors.shape)
         # (project_cameras(defer_backward=True): this camera's backward pass stops behind the sweep and leaves its gradient
         # record with the projection; project_cameras_backward finishes all cameras of the step in one launch)
@@ -171,15 +173,18 @@ class _RasterizeOneCamera(torch.autograd.Function):
                                   fold=False)   # (the projection backward resolves the hot gaussians' replicas)
         if ctx.deferred_projection is not None:
             ctx.deferred_projection.v_splat, ctx.deferred_projection.v_rgb = v_splat, rgb_here
-            return (None,) * 20
+            return (None,) * 21
+        ready = ctx.grad_ready() if ctx.grad_ready is not None else None
+        if ready is not None:   # (the sweep above touched nothing of the caller's: only the sums below wait for their turn)
+            torch.cuda.current_stream().wait_event(ready)
         grads = S.project_bwd(means_c, quats_c, scales_c, opac_c, colors_c, sh_degree, view_c, K_c, width, height,
                               splat, radii, v_splat, out=ctx.grad_out, accumulate=ctx.grad_accumulate,
                               v_rgb_out=ctx.sh_grad_factored, sh_aux=sh_aux)
         if ctx.grad_accumulate:   # the sums live in the caller's buffers; autograd gets nothing to accumulate
-            return (None,) * 20
+            return (None,) * 21
         need = ctx.needs_input_grad
         grads = tuple(g.view(shp) if (nd and g is not None) else None for g, shp, nd in zip(grads, ctx.in_shapes, need[:5]))
-        return grads + (None,) * 15
+        return grads + (None,) * 16
 
 
 def _backward_chain(ctx, v_render, v_alpha):
@@ -196,19 +201,20 @@ def _backward_chain(ctx, v_render, v_alpha):
         # project_cameras_backward finishes the cameras' GEOMETRY in one launch -- the step of a view-parallel rank)
         chain.backward(v_render, v_alpha_c, sweep_rgb=ctx.sh_grad_factored)
         ctx.deferred_projection.v_splat, ctx.deferred_projection.v_rgb = chain.view("v_splat"), ctx.sh_grad_factored
-        return (None,) * 20
+        return (None,) * 21
     out = S.project_bwd_outputs(means_c, quats_c, scales_c, opac_c, colors_c, ctx.grad_out, ctx.grad_accumulate,
                                 ctx.sh_grad_factored, sh_aux)
     chain.backward(v_render, v_alpha_c, project={"means": means_c, "quats": quats_c, "scales": scales_c, "opacities": opac_c,
                                                  "colors": colors_c, "sh_degree": sh_degree, "viewmat": view_c, "Kmat": K_c,
                                                  "radii": radii, "sh_aux": sh_aux, "out": out, "accumulate": ctx.grad_accumulate,
-                                                 "v_rgb_out": ctx.sh_grad_factored})
+                                                 "v_rgb_out": ctx.sh_grad_factored},
+                   wait_bucket=ctx.grad_ready() if ctx.grad_ready is not None else None)
     if ctx.grad_accumulate:   # the sums live in the caller's buffers; autograd gets nothing to accumulate
-        return (None,) * 20
+        return (None,) * 21
     grads = out[:4] + (None if ctx.sh_grad_factored is not None else out[4],)
     need = ctx.needs_input_grad
     grads = tuple(g.view(shp) if (nd and g is not None) else None for g, shp, nd in zip(grads, ctx.in_shapes, need[:5]))
-    return grads + (None,) * 15
+    return grads + (None,) * 16
 
 
 _RasterizeOneCamera._backward_chain = staticmethod(_backward_chain)
@@ -317,6 +323,7 @@ def rasterization(
     defer_check: bool = False,
     projection=None,
     speculation=None,
+    grad_ready=None,
     **unsupported,
 ) -> Tuple[torch.Tensor, torch.Tensor, Dict]:
     """Returns ``(renders [C,H,W,D], alphas [C,H,W,1], meta)``; ``meta['means2d']`` [C,N,2] and
@@ -336,6 +343,9 @@ def rasterization(
     With a ``projection`` of ``project_cameras(defer_backward=True)`` the backward SWEEP itself leaves it there (masked by the
     colour clamp), and ``project_cameras_backward`` then only sums the cameras' geometry gradients: a rank queues its
     all-gather for a view right behind the view's sweep.
+    ``grad_ready`` (extension, with ``grad_out``): a callable asked DURING the backward pass for the event (or None) behind
+    which ``grad_out`` may be written / added to -- the projection backward waits for it on its stream, the reverse sweep in
+    front of it does not (views of a step that sum into one bucket in view order: their sweeps overlap, only the sums queue).
     ``defer_check`` (extension): the bins are sized for a remembered record capacity and the depth ordering assumes a
     remembered key range; by default the call waits (host side) for the view's control words once its sweep is queued and
     repeats the binning if either was too small, so what it returns is always right.  With ``defer_check=True`` it does
@@ -418,7 +428,8 @@ def rasterization(
             vm_c, K_c = projection[c].viewmat, projection[c].Kmat
         out = _RasterizeOneCamera.apply(means, quats, scales, opacities, colors, vm_c, K_c, bg,
                                         width, height, deg, channels, cull, grad_out, grad_accumulate, sh_grad_factored,
-                                        pending, None if projection is None else projection[c], all_bins, speculation)
+                                        pending, None if projection is None else projection[c], all_bins, speculation,
+                                        grad_ready)
         render, alpha = out[0], out[1]
         if render_mode in ("ED", "RGB+ED"):
             render = torch.cat([render[..., :3], render[..., 3:] / alpha.clamp(min=1e-10)], dim=-1)

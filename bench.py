@@ -471,7 +471,7 @@ def main() -> None:
             for t in leaves:
                 t.grad = None
             base = (i * views * world) % ring_size
-            marks = {}
+            marks, turns = {}, {}
 
             def prepare():
                 if base not in step_cams:   # this rank's cameras of the step, one [views, 4, 4] tensor per window of the ring
@@ -493,7 +493,8 @@ def main() -> None:
                                                       cull_mode=args.cull_mode, grad_out=grad_views,
                                                       grad_accumulate=j > 0, sh_grad_factored=ex.view_target(j),
                                                       defer_check=deferred, speculation=pipe.speculation,
-                                                      projection=shared["proj"][j] if batch_proj else None)
+                                                      projection=shared["proj"][j] if batch_proj else None,
+                                                      grad_ready=(lambda j=j: turns.get(j)))
                 if "M" not in info:   # (once: with 32 x 32 bins in the hot path the 16 x 16 record count is a reduction + read-back)
                     info["M"] = meta["n_isects"]
                     info["binned"] = meta["n_binned"]
@@ -502,8 +503,9 @@ def main() -> None:
             def backward(j: int, state: ViewState, before_bucket) -> None:
                 # (with the shared projection backward a view's own backward pass stops behind its sweep and never touches
                 # the bucket: nothing to wait for)
-                if before_bucket is not None and not (batch_bwd or rank_batch):
-                    torch.cuda.current_stream().wait_event(before_bucket)
+                # (a view that finishes its own projection backward: THAT waits for the bucket's turn -- rasterization(grad_ready=)
+                # -- not the sweep in front of it, which touches nothing of the bucket)
+                turns[j] = before_bucket if not (batch_bwd or rank_batch) else None
                 state.payload.backward(v_render)
 
             def after_view(j: int) -> None:
