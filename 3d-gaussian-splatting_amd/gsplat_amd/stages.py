@@ -473,6 +473,49 @@ def sort_pairs(n: int, keys: torch.Tensor, vals: Optional[torch.Tensor], begin_b
     return k_out, v_out
 
 
+def _debug_implausible(bins, ctl_host) -> None:
+    """GSPLAT_AMD_DEBUG_BINS=1 (developer aid; profiles/r05_four_rank_rehearsal.md): what the device holds behind an implausible
+    read-back once everything queued has run -- the control words, the view's inputs, where its rectangles lie and which other
+    projection slabs / live tensor storages overlap them."""
+    dbg = getattr(bins, "_debug", None)
+    if dbg is not None:   # (GSPLAT_AMD_DEBUG_BINS=1: what the device holds once everything queued has run)
+        try:
+            torch.cuda.synchronize()
+        except Exception as exc:   # noqa: BLE001  (a device fault surfaces here: say which)
+            print(f"[gsplat_amd]   device sync raised {type(exc).__name__}: {exc}", file=sys.stderr, flush=True)
+            raise
+        ctl_d, rects_d, keys_d, offs_d = dbg
+        keys64 = keys_d.to(torch.int64) & 0xFFFFFFFF
+        cnt = rects_d.view(-1, 2)[:, 1].to(torch.int64) & 0xFFFFFFFF
+        print(f"[gsplat_amd]   after a device sync: host words {[int(x) & 0xFFFFFFFF for x in ctl_host]}, device ctl "
+              f"{[int(x) & 0xFFFFFFFF for x in ctl_d.tolist()]}; inputs: sum of counts {int(cnt.sum())} (max {int(cnt.max())}), "
+              f"keys min {int(keys64.min())} zeros {int((keys64 == 0).sum())} culled {int((keys64 == 0xFFFFFFFF).sum())}; "
+              f"offsets max {int((offs_d.to(torch.int64) & 0xFFFFFFFF).max())}; stream {torch.cuda.current_stream()}; "
+              f"words still holding the pre-launch pattern: rectangles {int((rects_d == 0x5EADBEEF).sum())} of "
+              f"{rects_d.numel()}, keys {int((keys_d == 0x5EADBEEF).sum())} of {keys_d.numel()}; first rectangle words "
+              f"{[hex(int(x) & 0xFFFFFFFF) for x in rects_d.view(-1)[:8].tolist()]}", file=sys.stderr, flush=True)
+        lo, hi = rects_d.data_ptr(), rects_d.data_ptr() + rects_d.numel() * 4
+        mine = [r for r in _DEBUG_RANGES if r[2] <= lo < r[2] + r[3]]
+        over = [r for r in _DEBUG_RANGES if r[2] < hi and lo < r[2] + r[3] and r not in mine]
+        print(f"[gsplat_amd]   the rectangles lie at {lo:#x}..{hi:#x}; slab(s) they belong to: {mine}; OTHER projection "
+              f"slabs overlapping them: {over}; all calls so far: {_DEBUG_CALLS[0]}", file=sys.stderr, flush=True)
+        import gc
+        seen, owners = set(), []
+        for o in gc.get_objects():   # every live device tensor whose STORAGE overlaps the rectangles
+            try:
+                if torch.is_tensor(o) and o.is_cuda:
+                    st_ = o.untyped_storage()
+                    p0, nb = st_.data_ptr(), st_.nbytes()
+                    if p0 < hi and lo < p0 + nb and (p0, nb) not in seen:
+                        seen.add((p0, nb))
+                        owners.append((hex(p0), nb, tuple(o.shape), str(o.dtype), sys.getrefcount(o)))
+            except Exception:   # noqa: BLE001
+                pass
+        print(f"[gsplat_amd]   live tensor storages overlapping them: {owners}; allocator: "
+              f"{ {k: v for k, v in torch.cuda.memory_stats().items() if k in ('num_alloc_retries', 'num_ooms', 'num_device_free', 'num_device_alloc', 'num_sync_all_streams')} }",
+              file=sys.stderr, flush=True)
+
+
 class TileBins:
     """Result of ``bin_tiles``: record buffers sized for a CAPACITY, the live record count on the device, and
     ``finalize()`` which the caller runs after it has queued the work that consumes the bins."""
@@ -525,52 +568,16 @@ class TileBins:
             _wait_slot(self._slot)
             ctl_host = self._slot[0]
             self._m = int(ctl_host[0]) & 0xFFFFFFFF
-            # A record count no frame of this size can have (more than one record per gaussian and bin): the control words did
-            # not arrive as written.  Seen once in ~5 full test runs with four processes on one card (r05) and not explained;
-            # such a view is reported as a failed speculation WITHOUT teaching the remembered capacity anything -- the caller
-            # repeats it with exact sizes, whose count comes back through a plain copy.
+            # A record count no frame of this size can have (more than one record per gaussian and bin): the view's INPUTS were
+            # not what its projection wrote.  Seen in r05 with four processes time-slicing one card behind a long-lived parent
+            # (profiles/r05_four_rank_rehearsal.md; not explained); such a view is reported as a failed speculation WITHOUT
+            # teaching the remembered capacity anything -- loud instead of a silently wrong step.
             w, h, bt = self._key[2], self._key[3], self.bin_tile
             plausible = self._m <= max(self._n, 1) * (tile_grid(w, h, bt)[0] * tile_grid(w, h, bt)[1]) + 1
             if not plausible or os.environ.get("GSPLAT_AMD_DEBUG_SLOTS") == "1":
                 print(f"[gsplat_amd] finalize: implausible control words {[int(x) & 0xFFFFFFFF for x in ctl_host]} token={self._slot[2]} "
                       f"key={self._key} n={self._n} capacity={self.capacity} ordering={self.key_bits}", file=sys.stderr, flush=True)
-                dbg = getattr(self, "_debug", None)
-                if dbg is not None:   # (GSPLAT_AMD_DEBUG_BINS=1: what the device holds once everything queued has run)
-                    try:
-                        torch.cuda.synchronize()
-                    except Exception as exc:   # noqa: BLE001  (a device fault surfaces here: say which)
-                        print(f"[gsplat_amd]   device sync raised {type(exc).__name__}: {exc}", file=sys.stderr, flush=True)
-                        raise
-                    ctl_d, rects_d, keys_d, offs_d = dbg
-                    keys64 = keys_d.to(torch.int64) & 0xFFFFFFFF
-                    cnt = rects_d.view(-1, 2)[:, 1].to(torch.int64) & 0xFFFFFFFF
-                    print(f"[gsplat_amd]   after a device sync: host words {[int(x) & 0xFFFFFFFF for x in ctl_host]}, device ctl "
-                          f"{[int(x) & 0xFFFFFFFF for x in ctl_d.tolist()]}; inputs: sum of counts {int(cnt.sum())} (max {int(cnt.max())}), "
-                          f"keys min {int(keys64.min())} zeros {int((keys64 == 0).sum())} culled {int((keys64 == 0xFFFFFFFF).sum())}; "
-                          f"offsets max {int((offs_d.to(torch.int64) & 0xFFFFFFFF).max())}; stream {torch.cuda.current_stream()}; "
-                          f"words still holding the pre-launch pattern: rectangles {int((rects_d == 0x5EADBEEF).sum())} of "
-                          f"{rects_d.numel()}, keys {int((keys_d == 0x5EADBEEF).sum())} of {keys_d.numel()}; first rectangle words "
-                          f"{[hex(int(x) & 0xFFFFFFFF) for x in rects_d.view(-1)[:8].tolist()]}", file=sys.stderr, flush=True)
-                    lo, hi = rects_d.data_ptr(), rects_d.data_ptr() + rects_d.numel() * 4
-                    mine = [r for r in _DEBUG_RANGES if r[2] <= lo < r[2] + r[3]]
-                    over = [r for r in _DEBUG_RANGES if r[2] < hi and lo < r[2] + r[3] and r not in mine]
-                    print(f"[gsplat_amd]   the rectangles lie at {lo:#x}..{hi:#x}; slab(s) they belong to: {mine}; OTHER projection "
-                          f"slabs overlapping them: {over}; all calls so far: {_DEBUG_CALLS[0]}", file=sys.stderr, flush=True)
-                    import gc
-                    seen, owners = set(), []
-                    for o in gc.get_objects():   # every live device tensor whose STORAGE overlaps the rectangles
-                        try:
-                            if torch.is_tensor(o) and o.is_cuda:
-                                st_ = o.untyped_storage()
-                                p0, nb = st_.data_ptr(), st_.nbytes()
-                                if p0 < hi and lo < p0 + nb and (p0, nb) not in seen:
-                                    seen.add((p0, nb))
-                                    owners.append((hex(p0), nb, tuple(o.shape), str(o.dtype), sys.getrefcount(o)))
-                        except Exception:   # noqa: BLE001
-                            pass
-                    print(f"[gsplat_amd]   live tensor storages overlapping them: {owners}; allocator: "
-                          f"{ {k: v for k, v in torch.cuda.memory_stats().items() if k in ('num_alloc_retries', 'num_ooms', 'num_device_free', 'num_device_alloc', 'num_sync_all_streams')} }",
-                          file=sys.stderr, flush=True)
+                _debug_implausible(self, ctl_host)
             if plausible:
                 _note_count(self._spec, self._key, self._n, self._m)
                 if self.key_bits is not None:   # (the unfused path sorts all 32 bits and leaves no range)
